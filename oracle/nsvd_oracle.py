@@ -1,0 +1,398 @@
+"""CPU ORACLE for the NestedLoRA / PDE hot path.  *** TEST INFRASTRUCTURE, NOT PRODUCT ***
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this file.  The product path (``neural_svd_amd``) never does; it fails loudly when the HIP
+library is missing.
+
+It is a from-scratch restatement, in plain torch-CPU tensor algebra with a HAND-DERIVED backward
+(no autograd), of what the reference computes on the path below.  Every function cites the
+reference ``file:line`` it follows (paths relative to the upstream repo root).  dtype is a
+parameter: float64 is the truth the HIP kernels are compared against, float32 reproduces the
+reference's own arithmetic.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here against the golden vectors in
+``tests/golden/*.npz`` that were produced by importing the reference itself
+(``tests/golden/make_golden.py``).  Unpinned piece: EMA (``torch_ema`` is an un-vendored,
+un-versioned dependency of the reference that is not installed in the build image) - the formula
+below is torch_ema's documented update; DESIGN.md says so too.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+SOFTPLUS_THRESHOLD = 20.0  # torch.nn.Softplus default (reference examples/models/mlp.py:84-85)
+SQRT_P_CLAMP = 1e-5        # reference examples/operator/pde/diff_ops.py:15
+
+POT_HYDROGEN = 0
+POT_HARMONIC = 1
+
+
+# ----------------------------------------------------------------------------- masks
+def sequential_nesting_masks(L: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """reference methods/nestedlora.py:49-54: v = 1_L, M = triu(1_{LxL})."""
+    return torch.ones(L), torch.triu(torch.ones(L, L))
+
+
+def joint_nesting_masks(L: int, step: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """reference methods/nestedlora.py:183-192 (step weights) + :40-46 (reverse cumsum, min)."""
+    ends = list(range(step, L + 1, step))
+    if L not in ends:
+        ends.append(L)
+    w = np.zeros(L)
+    w[np.array(ends) - 1] = 1.0
+    w = w / w.sum()
+    v = np.cumsum(w[::-1])[::-1].copy()
+    v = torch.tensor(v).float()
+    M = torch.minimum(v.unsqueeze(1), v.unsqueeze(0)).float()
+    return v, M
+
+
+# ----------------------------------------------------------------------------- loss
+def evd_loss_forward(f, Tf, v, M):
+    """reference methods/nestedlora.py:70-94 with f1,f2 = torch.chunk(f, 2) (:263).
+
+    returns loss, lam1, lam2, loss_op, loss_metric
+    """
+    B = f.shape[0]
+    B1 = (B + 1) // 2  # torch.chunk: first chunk gets the ceil
+    f1, f2 = f[:B1], f[B1:]
+    lam1 = f1.T @ f1 / f1.shape[0]            # :10-11
+    lam2 = f2.T @ f2 / f2.shape[0]
+    loss_metric = (M * lam1 * lam2).sum()     # :64
+    loss_op = -2.0 * ((f * Tf) @ v).mean()    # :92
+    return loss_op + loss_metric, lam1, lam2, loss_op, loss_metric
+
+
+def evd_loss_backward(f, Tf, v, M, lam1, lam2, grad_output=1.0):
+    """reference methods/nestedlora.py:98-111; returns d loss / d f with the f1/f2 terms summed in.
+
+    NOTE (deliberate, reference behaviour): no gradient flows through Tf, and the metric term uses
+    f1 @ (M*lam2) (not the symmetrised autograd gradient).
+    """
+    B = f.shape[0]
+    B1 = (B + 1) // 2
+    f1, f2 = f[:B1], f[B1:]
+    g = -(4.0 / B) * Tf * v.unsqueeze(0)
+    g1 = (2.0 / f1.shape[0]) * (f1 @ (M * lam2))
+    g2 = (2.0 / f2.shape[0]) * (f2 @ (M * lam1))
+    g = g.clone()
+    g[:B1] += g1
+    g[B1:] += g2
+    return grad_output * g
+
+
+# ----------------------------------------------------------------------------- model
+@dataclass
+class Params:
+    """Trainable + frozen tensors of WaveFunctions(ParallelMLP(FourierFeatures)) in the reference's
+    state_dict layout: ws[i]: (L, h_i, h_{i-1}), bs[i]: (L, h_i, 1), fourier_B: (D, m),
+    scales: (L,) or None (ExponentialMask)."""
+    ws: List[torch.Tensor]
+    bs: List[torch.Tensor]
+    fourier_B: torch.Tensor
+    scales: Optional[torch.Tensor] = None
+
+    def to(self, dtype):
+        return Params([w.to(dtype) for w in self.ws], [b.to(dtype) for b in self.bs],
+                      self.fourier_B.to(dtype), None if self.scales is None else self.scales.to(dtype))
+
+    def clone(self):
+        return Params([w.clone() for w in self.ws], [b.clone() for b in self.bs],
+                      self.fourier_B.clone(), None if self.scales is None else self.scales.clone())
+
+    def trainable(self) -> List[torch.Tensor]:
+        """Order of ``method.parameters()`` in the reference with requires_grad=True:
+        model.base.ws.*, model.base.bs.*, then model.boundary_mask.scales."""
+        out = list(self.ws) + list(self.bs)
+        if self.scales is not None:
+            out.append(self.scales)
+        return out
+
+
+@dataclass
+class Problem:
+    """Scalar configuration of OperatorWrapper(NegativeHamiltonian(...)) + Gaussian importance."""
+    potential: int = POT_HYDROGEN     # reference examples/operator/pde/schrodinger/potentials.py:5-8 / :24-27
+    charge_or_k: float = 1.0
+    scale_kinetic: float = 1.0        # reference examples/operator/pde/problems.py:26
+    eps: float = 0.01                 # --laplacian_eps
+    op_scale: float = 1.0             # reference examples/__init__.py:9
+    op_shift: float = 0.0
+    sigma: float = 16.0               # --sampling_scale (Gaussian importance, main_pde.py:94-100)
+    hard_mul_const: float = 1.0       # reference examples/operator/pde/__init__.py:16
+    use_importance: bool = True
+
+
+def init_params(L, D, mapping_size, hidden, fourier_scale, exp_mask_init=None, seed=None) -> Params:
+    """Same draw ORDER as the reference so that torch.manual_seed(seed) reproduces its weights:
+    Fourier _B first (examples/operator/pde/__init__.py:21-28 -> examples/utils.py:116-119), then
+    per layer W ~ sqrt(2/fan_in) randn(L, h, h_prev), b = 0 (examples/models/mlp.py:185-189)."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    fB = 2 * torch.pi * fourier_scale * torch.randn((D, mapping_size)).float()
+    ws, bs = [], []
+    prev = 2 * mapping_size
+    for h in list(hidden) + [1]:
+        ws.append(math.sqrt(2.0 / prev) * torch.randn(L, h, prev))
+        bs.append(torch.zeros(L, h, 1))
+        prev = h
+    scales = None if exp_mask_init is None else exp_mask_init * torch.ones(L)
+    return Params(ws, bs, fB, scales)
+
+
+def softplus(z):
+    """torch.nn.Softplus(beta=1, threshold=20): z if z > 20 else log1p(exp(z))."""
+    return torch.where(z > SOFTPLUS_THRESHOLD, z, torch.log1p(torch.exp(torch.clamp(z, max=SOFTPLUS_THRESHOLD))))
+
+
+def softplus_grad(z):
+    """d softplus / dz = sigmoid(z) (1 above the threshold)."""
+    return torch.where(z > SOFTPLUS_THRESHOLD, torch.ones_like(z), torch.sigmoid(z))
+
+
+def fourier_features(x, fB):
+    """reference examples/utils.py:139-140: [sin(x B), cos(x B)]."""
+    proj = x @ fB
+    return torch.cat([torch.sin(proj), torch.cos(proj)], dim=1)
+
+
+def mlp_forward(phi, p: Params, keep=False):
+    """reference examples/models/mlp.py:204-221 (norm()==1, bias=True). phi: (R, F).
+    returns out (R, L) and, if keep, the list of pre-activations z_i (L, h_i, R)."""
+    zs = []
+    h = torch.einsum("lhd,bd->lhb", p.ws[0], phi) + p.bs[0]
+    zs.append(h)
+    h = softplus(h)
+    n = len(p.ws)
+    for i in range(1, n):
+        h = torch.einsum("lhp,lpb->lhb", p.ws[i], h) + p.bs[i]
+        if i < n - 1:
+            zs.append(h)
+            h = softplus(h)
+    out = h.permute(2, 0, 1).reshape(phi.shape[0], -1)  # (R, L); output_dim == 1
+    return (out, zs) if keep else out
+
+
+def boundary_mask(x, p: Params):
+    """ExponentialMask: exp(-|x| / s_l) (reference examples/operator/pde/boundary.py:46-53);
+    1 when absent (examples/operator/pde/__init__.py:46)."""
+    if p.scales is None:
+        return None
+    r = torch.linalg.norm(x, dim=-1).view(-1, 1)
+    return torch.exp(-r / p.scales.view(1, -1))
+
+
+def sqrt_importance(x, sigma):
+    """sqrt of the isotropic Gaussian pdf (reference main_pde.py:94-100 via MultivariateNormal)."""
+    D = x.shape[1]
+    logp = -0.5 * (x * x).sum(-1) / sigma ** 2 - D * math.log(sigma) - 0.5 * D * math.log(2 * math.pi)
+    return torch.exp(logp).sqrt().view(-1, 1)
+
+
+def potential(x, prob: Problem):
+    r = torch.linalg.norm(x, dim=1)
+    if prob.potential == POT_HYDROGEN:
+        return (-prob.charge_or_k / r).view(-1, 1)
+    return (prob.charge_or_k * r ** 2).view(-1, 1)
+
+
+def stencil_points(x, eps):
+    """Order used everywhere in this repo: [x, x+e*e_0, x-e*e_0, x+e*e_1, x-e*e_1, ...]
+    (reference examples/operator/pde/diff_ops.py:36-45). eps is added as a float32 value, exactly
+    like the reference's float32 ``epsi`` tensor."""
+    D = x.shape[1]
+    e32 = float(np.float32(eps))
+    pts = [x]
+    for i in range(D):
+        d = torch.zeros(1, D, dtype=x.dtype)
+        d[0, i] = e32
+        pts.append(x + d)
+        pts.append(x - d)
+    return pts
+
+
+@dataclass
+class OperatorCache:
+    x: torch.Tensor
+    phi0: torch.Tensor
+    zs: List[torch.Tensor]
+    base0: torch.Tensor
+    mask0: Optional[torch.Tensor]
+    sp0: torch.Tensor
+    spc0: torch.Tensor
+    f: torch.Tensor
+    Tf: torch.Tensor
+
+
+def operator_forward(x, p: Params, prob: Problem) -> OperatorCache:
+    """Tf, f = OperatorWrapper(NegativeHamiltonian)(method, x, importance)
+    reference: examples/__init__.py:7-9 -> schrodinger/__init__.py:16-22 -> diff_ops.py:9-52."""
+    D = x.shape[1]
+    pts = stencil_points(x, prob.eps)
+    gs = []
+    cache0 = None
+    for j, xe in enumerate(pts):
+        phi = fourier_features(xe, p.fourier_B)
+        if j == 0:
+            base, zs = mlp_forward(phi, p, keep=True)
+        else:
+            base = mlp_forward(phi, p)
+        m = boundary_mask(xe, p)
+        model = prob.hard_mul_const * base
+        if m is not None:
+            model = model * m
+        sp = sqrt_importance(xe, prob.sigma) if prob.use_importance else torch.ones(x.shape[0], 1, dtype=x.dtype)
+        gs.append(sp * model)
+        if j == 0:
+            cache0 = (phi, zs, base, m, sp)
+    lap = -2 * D * gs[0]
+    for i in range(D):
+        lap = lap + (gs[1 + 2 * i] + gs[2 + 2 * i])
+    lap = lap / (prob.eps ** 2)
+    phi0, zs, base0, mask0, sp0 = cache0
+    spc0 = torch.clamp(sp0, min=SQRT_P_CLAMP) if prob.use_importance else sp0
+    lap = lap / spc0
+    fs = gs[0] / spc0
+    kinetic = -prob.scale_kinetic * lap
+    pot = potential(x, prob) * fs
+    Tf = -(kinetic + pot)
+    Tf = prob.op_scale * Tf + prob.op_shift * fs
+    return OperatorCache(x, phi0, zs, base0, mask0, sp0, spc0, fs, Tf)
+
+
+def operator_backward(c: OperatorCache, p: Params, prob: Problem, df):
+    """Hand-derived gradient of sum(df * f) w.r.t. the trainable parameters; f = g(x)/clamp(sqrt p)
+    is the ONLY differentiable output (Tf carries no gradient: reference nestedlora.py:108-111).
+    Returns grads in ``Params.trainable()`` order."""
+    n = len(p.ws)
+    dmodel = df * (c.sp0 / c.spc0)
+    dscales = None
+    if c.mask0 is not None:
+        r = torch.linalg.norm(c.x, dim=-1).view(-1, 1)
+        # d/ds exp(-r/s) = exp(-r/s) * r / s^2
+        dscales = (dmodel * prob.hard_mul_const * c.base0 * c.mask0 * r / p.scales.view(1, -1) ** 2).sum(0)
+        dbase = dmodel * prob.hard_mul_const * c.mask0
+    else:
+        dbase = dmodel * prob.hard_mul_const
+    # dbase: (B, L) -> (L, 1, B)
+    dz = dbase.T.unsqueeze(1)
+    dws = [None] * n
+    dbs = [None] * n
+    hs = [softplus(z) for z in c.zs]  # (L, h, B)
+    for i in range(n - 1, -1, -1):
+        a_prev = hs[i - 1] if i > 0 else None
+        if i > 0:
+            dws[i] = torch.einsum("lhb,lpb->lhp", dz, a_prev)
+        else:
+            dws[i] = torch.einsum("lhb,bd->lhd", dz, c.phi0)
+        dbs[i] = dz.sum(-1, keepdim=True)
+        if i > 0:
+            dh = torch.einsum("lhp,lhb->lpb", p.ws[i], dz)
+            dz = dh * softplus_grad(c.zs[i - 1])
+    out = dws + dbs
+    if dscales is not None:
+        out.append(dscales)
+    return out
+
+
+def loss_and_grads(x, p: Params, prob: Problem, v, M):
+    """One NestedLoRA.compute_loss_operator + backward (reference nestedlora.py:254-267)."""
+    c = operator_forward(x, p, prob)
+    v = v.to(x.dtype)
+    M = M.to(x.dtype)
+    loss, lam1, lam2, loss_op, loss_metric = evd_loss_forward(c.f, c.Tf, v, M)
+    df = evd_loss_backward(c.f, c.Tf, v, M, lam1, lam2)
+    grads = operator_backward(c, p, prob, df)
+    return dict(loss=loss, f=c.f, Tf=c.Tf, lam1=lam1, lam2=lam2, df=df, grads=grads)
+
+
+# ----------------------------------------------------------------------------- optimiser
+def cosine_lr(base_lr, t, T, eta_min=0.0):
+    """closed form of torch.optim.lr_scheduler.CosineAnnealingLR after t scheduler steps
+    (reference examples/operator/__init__.py:35,71-72)."""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t / T)) / 2
+
+
+def rmsprop_step(params, grads, sq, lr, alpha=0.999, eps=1e-10):
+    """torch.optim.RMSprop(momentum=0, centered=False, weight_decay=0) as configured by the
+    reference (examples/utils.py:50-57): v = a v + (1-a) g^2 ; p -= lr g / (sqrt(v) + eps)."""
+    for p_, g, s in zip(params, grads, sq):
+        s.mul_(alpha).addcmul_(g, g, value=1 - alpha)
+        p_.addcdiv_(g, s.sqrt().add_(eps), value=-lr)
+
+
+def ema_update(shadow, params, decay, num_updates):
+    """torch_ema.ExponentialMovingAverage.update (documented behaviour; PARITY UNPINNED):
+    num_updates += 1; d = min(decay, (1+n)/(10+n)); s -= (1-d)(s-p). Returns new num_updates."""
+    num_updates += 1
+    d = min(decay, (1 + num_updates) / (10 + num_updates))
+    for s, p_ in zip(shadow, params):
+        s.sub_((1.0 - d) * (s - p_))
+    return num_updates
+
+
+# ----------------------------------------------------------------------------- spectrum
+def validation_grid(lim, val_eps, D=2):
+    """reference main_pde.py:121-125."""
+    ax = np.arange(-lim, lim, val_eps)
+    xxs = np.meshgrid(*(D * [ax]))
+    pts = np.array(list(zip(*[xx.flatten() for xx in xxs])))
+    return torch.tensor(pts).float()
+
+
+def spectrum_evd(grid, p: Params, prob: Problem, lim, chunk=4096):
+    """reference methods/spectrum.py:29-102 with importance_val = uniform on [-lim,lim]^D
+    (main_pde.py:129-130): cov = sum phi^T phi / n, quad = sum phi^T Tphi / n, RQ eigvals."""
+    L = p.ws[0].shape[0]
+    D = grid.shape[1]
+    cov = torch.zeros(L, L, dtype=grid.dtype)
+    quad = torch.zeros(L, L, dtype=grid.dtype)
+    n = 0
+    # the reference builds this density as a float32 tensor (main_pde.py:130 `.float()`)
+    sqrt_val = math.sqrt(float(np.float32(1.0 / (2 * lim) ** D)))
+    for i in range(0, grid.shape[0], chunk):
+        x = grid[i:i + chunk]
+        c = operator_forward(x, p, prob)
+        sp_train = sqrt_importance(x, prob.sigma) if prob.use_importance else 1.0
+        w = sp_train / sqrt_val                                  # spectrum.py:56-61
+        phi = torch.nan_to_num(w * c.f)
+        Tphi = torch.nan_to_num(w * c.Tf)
+        zero = torch.all(torch.isclose(x, torch.zeros_like(x[0])), dim=1)  # :73
+        Tphi[zero] = 0.0
+        cov += phi.T @ phi
+        quad += phi.T @ Tphi
+        n += x.shape[0]
+    cov /= n
+    quad /= n
+    eig = torch.diag(quad) / torch.diag(cov)
+    norms = torch.diag(cov)
+    return dict(cov=cov, quad=quad, eigvals=eig, norms=norms)
+
+
+# ----------------------------------------------------------------------------- ground truth
+def hydrogen2d_eigvals(neigs, charge=1.0):
+    """reference examples/operator/pde/schrodinger/ground_truths.py:120-132."""
+    q = []
+    n = 0
+    while len(q) < neigs:
+        q += [n] * (2 * n + 1)
+        n += 1
+    q = np.array(q[:neigs], dtype=np.float64)
+    return -charge ** 2 / (4 * (q + 0.5) ** 2)
+
+
+def oscillator2d_eigvals(neigs, k=1.0):
+    """reference ground_truths.py:78-90 INCLUDING its quirk: it emits every shell up to and
+    including one shell past the one that reaches ``neigs`` (never truncated)."""
+    nend, states = 0, 0
+    while True:
+        states += nend + 1  # binom(2+n-1, n) = n+1
+        nend += 1
+        if states >= neigs:
+            break
+    return math.sqrt(k) * np.concatenate([(n + 1) * [2 * n + 2] for n in range(nend + 1)]).astype(np.float64)

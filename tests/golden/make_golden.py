@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box and the
+test-suite never run it, they only read the committed ``*.npz`` files.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What it does: pre-seeds ``sys.modules`` with empty stand-ins for the optional
+third-party modules the reference imports at module scope but never uses on the
+NestedLoRA/PDE hot path (torch_ema, uncertainties, toml, configargparse,
+termplotlib, tensorboardX, classy_vision), imports the reference's own
+``get_problem`` / ``get_wavefunctions`` / ``get_dataloader`` / ``get_evd_method``
+/ ``get_optimizer`` / ``compute_spectrum_evd`` and records inputs + outputs.
+No reference source text is stored: fixtures are arrays only.
+
+Every case is produced twice: float64 (truth) and float32 (reference behaviour).
+"""
+import os
+import sys
+import types
+import argparse
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    mod("torch_ema", ExponentialMovingAverage=_Dummy)
+    mod("uncertainties", ufloat=lambda *a, **k: None, unumpy=types.ModuleType("unumpy"))
+    sys.modules["uncertainties.unumpy"] = sys.modules["uncertainties"].unumpy
+    mod("toml", loads=lambda s: {}, load=lambda f: {})
+    mod("configargparse", ArgumentParser=argparse.ArgumentParser)
+    mod("termplotlib", figure=_Dummy)
+    mod("tensorboardX", SummaryWriter=_Dummy)
+    cv = mod("classy_vision")
+    cvg = mod("classy_vision.generic")
+    cvd = mod("classy_vision.generic.distributed_util", is_distributed_training_run=lambda: False,
+              convert_to_distributed_tensor=lambda t: (t, None), convert_to_normal_tensor=lambda t, d: t)
+    cv.generic = cvg
+    cvg.distributed_util = cvd
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from methods.nestedlora import (  # noqa: E402
+    NestedLoRALossFunctionEVD,
+    get_joint_nesting_masks,
+    get_sequential_nesting_masks,
+    NestedLoRA,
+)
+from methods.general import get_evd_method  # noqa: E402
+from methods.spectrum import compute_spectrum_evd  # noqa: E402
+from examples.operator.pde.problems import get_problem  # noqa: E402
+from examples.operator.pde import get_wavefunctions  # noqa: E402
+from examples.operator.pde.main_pde import get_dataloader  # noqa: E402
+from examples.utils import get_optimizer  # noqa: E402
+from examples.operator.pde.schrodinger.ground_truths import Hydrogen2D, HarmonicOscillator  # noqa: E402
+from tools.generic import Namespace  # noqa: E402
+
+
+def np64(t):
+    return t.detach().cpu().double().numpy().copy()
+
+
+def make_args(**over):
+    a = argparse.Namespace(
+        seed=0,
+        # model
+        ndim=2, n_particles=1, neigs=4, mlp_hidden_dims="32,32", nonlinearity="softplus",
+        parallel=1, weight_normalization=0,
+        use_fourier_feature=True, fourier_mapping_size=16, fourier_scale=0.1,
+        fourier_deterministic=False, fourier_append_raw=False,
+        apply_boundary=0, boundary_mode="dir_box_sqrt", lim=5.0,
+        apply_exp_mask=0, exp_mask_init_scale=10.0, hard_mul_const=1.0,
+        # problem
+        problem="sch", potential_type="hydrogen", charge=1.0, laplacian_eps=0.01,
+        operator_scale=100.0, operator_shift=0.0,
+        # sampler
+        sampling_mode="gaussian", sampling_scale=16.0, batch_size=24, val_eps=0.5,
+        # optimiser
+        optimizer="rmsprop", lr=1e-4, rmsprop_decay=0.999, momentum=0.0, num_iters=100,
+        sort=0,
+    )
+    seq = over.pop("sequential", 1)
+    step = over.pop("step", 1)
+    for k, v in over.items():
+        setattr(a, k, v)
+    a.loss = Namespace(dict(name="neuralsvd", neuralsvd=dict(step=step, sequential=seq)))
+    return a
+
+
+# --------------------------------------------------------------------------- masks
+def golden_masks(out):
+    for L in (1, 4, 16, 33):
+        v, M = get_sequential_nesting_masks(L)
+        out[f"seq_L{L}_v"] = v.numpy()
+        out[f"seq_L{L}_M"] = M.numpy()
+    for (L, step) in ((4, 1), (16, 1), (10, 4), (16, 4), (7, 3), (5, 7)):
+        m = NestedLoRA(model=None, neigs=L, step=step, sequential=False)
+        out[f"joint_L{L}_s{step}_v"] = m.vector_mask.numpy()
+        out[f"joint_L{L}_s{step}_M"] = m.matrix_mask.numpy()
+
+
+# --------------------------------------------------------------------------- loss only
+def golden_loss(out):
+    g = torch.Generator().manual_seed(1234)
+    cases = dict(
+        a=dict(B=12, L=5, seq=True, step=1),
+        b=dict(B=13, L=5, seq=False, step=1),   # odd B: torch.chunk gives 7 + 6
+        c=dict(B=64, L=16, seq=False, step=1),
+        d=dict(B=10, L=7, seq=False, step=3),
+        e=dict(B=2, L=1, seq=True, step=1),
+        f=dict(B=256, L=64, seq=True, step=1),
+    )
+    for name, c in cases.items():
+        B, L = c["B"], c["L"]
+        f64 = torch.randn(B, L, generator=g, dtype=torch.float64)
+        Tf64 = torch.randn(B, L, generator=g, dtype=torch.float64) * 3.0
+        m = NestedLoRA(model=None, neigs=L, step=c["step"], sequential=c["seq"])
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            f = f64.to(dt).clone().requires_grad_(True)
+            Tf = Tf64.to(dt).clone().requires_grad_(True)
+            f1, f2 = torch.chunk(f, 2)
+            loss = NestedLoRALossFunctionEVD.apply(f, Tf, f1, f2, m.vector_mask.to(dt), m.matrix_mask.to(dt))
+            (loss * 1.0).backward()
+            p = f"loss_{name}_{tag}_"
+            out[p + "loss"] = np64(loss)
+            out[p + "grad_f"] = np64(f.grad)
+            assert Tf.grad is None
+            f1d, f2d = torch.chunk(f.detach(), 2)
+            out[p + "lam1"] = np64(f1d.T @ f1d / f1d.shape[0])
+            out[p + "lam2"] = np64(f2d.T @ f2d / f2d.shape[0])
+        p = f"loss_{name}_"
+        out[p + "f"] = f64.numpy()
+        out[p + "Tf"] = Tf64.numpy()
+        out[p + "v"] = m.vector_mask.numpy()
+        out[p + "M"] = m.matrix_mask.numpy()
+        out[p + "cfg"] = np.array([B, L, int(c["seq"]), c["step"]])
+
+
+# --------------------------------------------------------------------------- full model
+def build(args, dtype):
+    torch.manual_seed(args.seed)
+    operator, gt = get_problem(args, torch.device("cpu"))
+    model = get_wavefunctions(args)
+    make_batch, val_data, batch_ftn_val, imp_train, imp_val = get_dataloader(args, torch.device("cpu"))
+    method = get_evd_method(args, "neuralsvd", model)
+    method = method.to(dtype)
+    return operator, gt, method, make_batch, val_data, batch_ftn_val, imp_train, imp_val
+
+
+def importance_for(args, dtype):
+    # the reference builds its MultivariateNormal in float32; for the float64 truth
+    # we rebuild the same density in float64
+    from torch.distributions import MultivariateNormal
+    d = args.n_particles * args.ndim
+    mvn = MultivariateNormal(loc=torch.zeros(d, dtype=dtype),
+                             covariance_matrix=args.sampling_scale ** 2 * torch.eye(d, dtype=dtype))
+    return lambda x: mvn.log_prob(x.view(x.shape[0], -1)).exp().view(-1, 1)
+
+
+def golden_model(out, name, nsteps=2, grid=True, store_params=True, sample_stride=None, **over):
+    args64 = make_args(**over)
+    # draw x once (float32, like the reference's sampler), reuse for both dtypes
+    torch.manual_seed(args64.seed + 1000)
+    xs = [args64.sampling_scale * torch.randn((args64.batch_size, 1, args64.ndim)) for _ in range(nsteps)]
+    out[f"{name}_x"] = np.stack([x.reshape(x.shape[0], -1).numpy() for x in xs])
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        args = make_args(**over)
+        operator, gt, method, _, val_data, batch_ftn_val, _, imp_val = build(args, dtype)
+        imp_train = importance_for(args, dtype)
+        p = f"{name}_{tag}_"
+        names = [n for n, _ in method.named_parameters()]
+        if tag == "f64":
+            out[f"{name}_param_names"] = np.array(names)
+            out[f"{name}_gt"] = np.asarray(gt, dtype=np.float64)
+            out[f"{name}_v"] = method.vector_mask.numpy()
+            out[f"{name}_M"] = method.matrix_mask.numpy()
+            if store_params:
+                # parameters are created in float32 by the reference; both dtypes start from the same values
+                for n, t in method.named_parameters():
+                    out[f"{name}_param0_{n}"] = t.detach().float().numpy()
+        optimizer = get_optimizer(args, method)
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.num_iters)
+        for it in range(nsteps):
+            method.train()
+            optimizer.zero_grad()
+            x = xs[it].to(dtype)
+            x = x.reshape(x.shape[0], -1)
+            loss, aux = method.compute_loss_operator(operator, x, importance=imp_train)
+            loss.backward()
+            out[p + f"step{it}_loss"] = np64(loss)
+            out[p + f"step{it}_f"] = np64(aux["f"])
+            out[p + f"step{it}_Tf"] = np64(aux["Tf"])
+            for n, t in method.named_parameters():
+                if t.grad is None:
+                    continue
+                g = np64(t.grad)
+                if sample_stride is None:
+                    out[p + f"step{it}_grad_{n}"] = g
+                else:
+                    out[p + f"step{it}_gradnorm_{n}"] = np.array(np.linalg.norm(g))
+                    out[p + f"step{it}_gradsample_{n}"] = g.reshape(-1)[::sample_stride]
+            optimizer.step()
+            scheduler.step()
+            if sample_stride is None:
+                for n, t in method.named_parameters():
+                    out[p + f"step{it}_param_{n}"] = np64(t)
+        if grid and batch_ftn_val is not None:
+            method.eval()
+            with torch.no_grad():
+                vd = val_data.to(dtype)
+                bs = args.batch_size
+
+                def loader():
+                    for i in range(int(np.ceil(len(vd) / float(bs)))):
+                        yield vd[i * bs:min((i + 1) * bs, len(vd))], 0.
+
+                imp_val_d = lambda x: imp_val(x).to(dtype)  # noqa: E731
+                res = compute_spectrum_evd(method, dataloader=loader(), operator=operator,
+                                           importance_train=imp_train, importance_val=imp_val_d,
+                                           normalize=True, set_first_mode_const=False, device=torch.device("cpu"))
+            out[p + "spec_eigvals"] = np.asarray(res["eigvals"], dtype=np.float64)
+            out[p + "spec_norms"] = np.asarray(res["norms"], dtype=np.float64)
+            out[p + "spec_quad"] = np.asarray(res["quad"], dtype=np.float64)
+            out[p + "spec_cov_normalized"] = np.asarray(res["cov"], dtype=np.float64)
+            if tag == "f64":
+                out[f"{name}_val_data"] = val_data.numpy()
+    cfg = {k: v for k, v in vars(make_args(**over)).items() if k != "loss"}
+    cfg["sequential"] = int(over.get("sequential", 1))
+    cfg["step"] = int(over.get("step", 1))
+    out[f"{name}_cfg"] = np.array(repr(cfg))
+
+
+def golden_debug_model(out):
+    """RNG-free model: ParallelMLP(debug=True) + deterministic Fourier map (reference
+    examples/models/mlp.py:190-193, examples/utils.py:106-113)."""
+    from examples.models.mlp import ParallelMLP
+    from examples.utils import GaussianFourierFeatureTransform
+    fm = GaussianFourierFeatureTransform(input_dim=2, mapping_size=3, scale=0.25, deterministic=True)
+    mlp = ParallelMLP(input_dim=2, mlp_hidden_dims=[8, 8], output_dim=1, num_copies=3, nonlinearity="softplus",
+                      bias=True, feature_map=fm, debug=True)
+    x = torch.tensor([[0.1, -0.2], [1.5, 0.3], [-0.7, 0.9], [2.0, -1.0], [0.0, 0.0]])
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        y = mlp.to(dtype)(x.to(dtype))
+        out[f"debug_{tag}_y"] = np64(y)
+    out["debug_x"] = x.numpy()
+    out["debug_B"] = fm._B.detach().float().numpy()
+
+
+def golden_ground_truth(out):
+    out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
+    out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
+    for n in (1, 6, 16, 32, 55):
+        out[f"gt_oscillator_{n}"] = HarmonicOscillator(k=1.0, ndim=2).get_eigvals(n)
+
+
+def main():
+    torch.set_num_threads(8)
+    o = {}
+    golden_masks(o)
+    np.savez_compressed(os.path.join(HERE, "masks.npz"), **o)
+
+    o = {}
+    golden_loss(o)
+    np.savez_compressed(os.path.join(HERE, "evd_loss.npz"), **o)
+
+    o = {}
+    golden_ground_truth(o)
+    golden_debug_model(o)
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **o)
+
+    # small seeded models (fit the MFMA fast path: H=32 blocks) -----------------
+    o = {}
+    golden_model(o, "hyd_small", potential_type="hydrogen", neigs=4, mlp_hidden_dims="32,32",
+                 fourier_mapping_size=16, fourier_scale=0.1, sampling_scale=16.0, batch_size=24,
+                 operator_scale=100.0, operator_shift=0.0, lim=5.0, val_eps=0.5, sequential=1)
+    golden_model(o, "osc_small", potential_type="harmonic_oscillator", neigs=5, mlp_hidden_dims="32,32,32",
+                 fourier_mapping_size=16, fourier_scale=1.0, sampling_scale=4.0, batch_size=32,
+                 operator_scale=1.0, operator_shift=16.0, apply_exp_mask=1, exp_mask_init_scale=10.0,
+                 lim=5.0, val_eps=0.5, sequential=0)
+    # ragged shapes: generic path (H not multiple of 32, odd B, odd m, step>1 joint)
+    golden_model(o, "hyd_ragged", potential_type="hydrogen", neigs=3, mlp_hidden_dims="12,20",
+                 fourier_mapping_size=5, fourier_scale=0.1, sampling_scale=16.0, batch_size=11,
+                 operator_scale=100.0, operator_shift=0.0, lim=2.0, val_eps=0.5, sequential=0, step=2)
+    np.savez_compressed(os.path.join(HERE, "model_small.npz"), **o)
+
+    # medium: H=128x3 (the headline hidden sizes) at reduced L/B/m --------------
+    o = {}
+    golden_model(o, "hyd_med", nsteps=1, grid=False, store_params=False, sample_stride=997,
+                 potential_type="hydrogen", neigs=4, mlp_hidden_dims="128,128,128",
+                 fourier_mapping_size=64, fourier_scale=0.1, sampling_scale=16.0, batch_size=64,
+                 operator_scale=100.0, operator_shift=0.0, sequential=0, seed=3)
+    # cfg1-shaped (hydrogen L=16 B=128 seq, m=1024): outputs only, params from the seed recipe
+    golden_model(o, "cfg1", nsteps=1, grid=False, store_params=False, sample_stride=9973,
+                 potential_type="hydrogen", neigs=16, mlp_hidden_dims="128,128,128",
+                 fourier_mapping_size=1024, fourier_scale=0.1, sampling_scale=16.0, batch_size=128,
+                 operator_scale=100.0, operator_shift=0.0, sequential=1, seed=0)
+    np.savez_compressed(os.path.join(HERE, "model_headline.npz"), **o)
+    for fn in ("masks", "evd_loss", "misc", "model_small", "model_headline"):
+        p = os.path.join(HERE, fn + ".npz")
+        print(fn, os.path.getsize(p) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+"""Pin the CPU oracle (oracle/nsvd_oracle.py) against golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsvd_oracle as O
+from tests import _golden as G
+
+
+# ------------------------------------------------------------------ masks (exact)
+@pytest.mark.parametrize("L", [1, 4, 16, 33])
+def test_sequential_masks(L):
+    z = G.load("masks")
+    v, M = O.sequential_nesting_masks(L)
+    assert np.array_equal(v.numpy(), z[f"seq_L{L}_v"])
+    assert np.array_equal(M.numpy(), z[f"seq_L{L}_M"])
+
+
+@pytest.mark.parametrize("L,step", [(4, 1), (16, 1), (10, 4), (16, 4), (7, 3), (5, 7)])
+def test_joint_masks(L, step):
+    z = G.load("masks")
+    v, M = O.joint_nesting_masks(L, step)
+    assert v.dtype == torch.float32 and M.dtype == torch.float32
+    assert np.array_equal(v.numpy(), z[f"joint_L{L}_s{step}_v"])
+    assert np.array_equal(M.numpy(), z[f"joint_L{L}_s{step}_M"])
+
+
+# ------------------------------------------------------------------ loss fwd/bwd
+@pytest.mark.parametrize("case", list("abcdef"))
+@pytest.mark.parametrize("tag,dtype,tol", [("f64", torch.float64, 1e-13), ("f32", torch.float32, 2e-5)])
+def test_evd_loss(case, tag, dtype, tol):
+    z = G.load("evd_loss")
+    f = torch.tensor(z[f"loss_{case}_f"]).to(dtype)
+    Tf = torch.tensor(z[f"loss_{case}_Tf"]).to(dtype)
+    v = torch.tensor(z[f"loss_{case}_v"]).to(dtype)
+    M = torch.tensor(z[f"loss_{case}_M"]).to(dtype)
+    loss, lam1, lam2, _, _ = O.evd_loss_forward(f, Tf, v, M)
+    g = O.evd_loss_backward(f, Tf, v, M, lam1, lam2)
+    p = f"loss_{case}_{tag}_"
+    assert abs(float(loss) - float(z[p + "loss"])) <= tol * max(1.0, abs(float(z[p + "loss"])))
+    assert G.rel(lam1.numpy(), z[p + "lam1"]) <= tol
+    assert G.rel(lam2.numpy(), z[p + "lam2"]) <= tol
+    assert G.rel(g.numpy(), z[p + "grad_f"]) <= tol
+
+
+# ------------------------------------------------------------------ full model, float64 truth
+SMALL = ["hyd_small", "osc_small", "hyd_ragged"]
+
+
+@pytest.mark.parametrize("case", SMALL)
+def test_model_f64_two_steps(case):
+    """operator fwd, loss, every parameter gradient and two RMSprop+cosine steps in float64 must
+    reproduce the reference to round-off."""
+    z = G.load("model_small")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p = G.params_from_golden(z, case).to(torch.float64)
+    v, M = G.masks_of(z, case)
+    names = G.trainable_names(z, case)
+    sq = [torch.zeros_like(t) for t in p.trainable()]
+    for it in range(2):
+        x = torch.tensor(z[f"{case}_x"][it]).double()
+        r = O.loss_and_grads(x, p, prob, v, M)
+        pre = f"{case}_f64_step{it}_"
+        assert G.rel(r["f"], z[pre + "f"]) < 1e-12
+        assert G.rel(r["Tf"], z[pre + "Tf"]) < 1e-9       # FD cancellation amplifies round-off
+        assert abs(float(r["loss"]) - float(z[pre + "loss"])) < 1e-9 * abs(float(z[pre + "loss"]))
+        for n, g in zip(names, r["grads"]):
+            assert G.rel(g, z[pre + "grad_" + n]) < 1e-9, n
+        lr = O.cosine_lr(cfg["lr"], it, cfg["num_iters"])
+        O.rmsprop_step(p.trainable(), r["grads"], sq, lr, alpha=cfg["rmsprop_decay"], eps=1e-10)
+        for n, t in zip(names, p.trainable()):
+            assert G.rel(t, z[pre + "param_" + n]) < 1e-9, n  # grads carry FD round-off
+
+
+@pytest.mark.parametrize("case", SMALL)
+def test_model_f32_matches_reference_f32(case):
+    """float32 oracle vs float32 reference: same arithmetic up to summation order."""
+    z = G.load("model_small")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p = G.params_from_golden(z, case)
+    v, M = G.masks_of(z, case)
+    x = torch.tensor(z[f"{case}_x"][0])
+    r = O.loss_and_grads(x, p, prob, v, M)
+    pre = f"{case}_f32_step0_"
+    assert G.rel(r["f"], z[pre + "f"]) < 5e-6
+    # Tf: two correct float32 evaluations differ at the FD-noise level; compare against float64
+    # truth with the float32 reference's own error as the yardstick
+    t64 = z[f"{case}_f64_step0_Tf"]
+    ref_err = G.rel(z[pre + "Tf"], t64)
+    assert G.rel(r["Tf"], t64) < max(3 * ref_err, 1e-4)
+
+
+@pytest.mark.parametrize("case", SMALL)
+def test_spectrum_f64(case):
+    z = G.load("model_small")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    # the spectrum golden was taken after the two optimiser steps
+    p = G.params_from_golden(z, case, prefix="f64_step1_param_").to(torch.float64)
+    grid = O.validation_grid(cfg["lim"], cfg["val_eps"], cfg["ndim"])
+    assert np.array_equal(grid.numpy(), z[f"{case}_val_data"])
+    r = O.spectrum_evd(grid.double(), p, prob, cfg["lim"], chunk=cfg["batch_size"])
+    assert G.rel(r["eigvals"], z[f"{case}_f64_spec_eigvals"]) < 1e-9
+    assert G.rel(r["norms"], z[f"{case}_f64_spec_norms"]) < 1e-10
+    assert G.rel(r["quad"], z[f"{case}_f64_spec_quad"]) < 1e-9
+    nrm = r["norms"].sqrt()
+    assert G.rel(r["cov"] / (nrm[:, None] * nrm[None, :]), z[f"{case}_f64_spec_cov_normalized"]) < 1e-10
+
+
+# ------------------------------------------------------------------ headline shapes from the seed recipe
+@pytest.mark.parametrize("case", ["hyd_med", "cfg1"])
+def test_headline_from_seed(case):
+    """Weights regenerated from torch.manual_seed(seed) in the reference's draw order must give the
+    reference's outputs (this is how the 18.9 MB cfg1 weights travel: as a recipe)."""
+    z = G.load("model_headline")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p32 = G.params_from_seed(cfg)
+    v, M = G.masks_of(z, case)
+    x = torch.tensor(z[f"{case}_x"][0])
+    r = O.loss_and_grads(x.double(), p32.to(torch.float64), prob, v, M)
+    pre = f"{case}_f64_step0_"
+    assert G.rel(r["f"], z[pre + "f"]) < 1e-11
+    assert G.rel(r["Tf"], z[pre + "Tf"]) < 1e-8
+    assert abs(float(r["loss"]) - float(z[pre + "loss"])) < 1e-8 * abs(float(z[pre + "loss"]))
+    names = G.trainable_names(z, case)
+    stride = 997 if case == "hyd_med" else 9973
+    for n, g in zip(names, r["grads"]):
+        g = g.numpy()
+        assert abs(np.linalg.norm(g) - float(z[pre + "gradnorm_" + n])) < 1e-8 * float(z[pre + "gradnorm_" + n]), n
+        assert G.rel(g.reshape(-1)[::stride], z[pre + "gradsample_" + n]) < 1e-8, n
+
+
+# ------------------------------------------------------------------ misc
+def test_ground_truth_spectra():
+    z = G.load("misc")
+    assert np.allclose(O.hydrogen2d_eigvals(64), z["gt_hydrogen2d_64"], rtol=0, atol=0)
+    assert np.allclose(O.hydrogen2d_eigvals(9, charge=2.0), z["gt_hydrogen2d_z2_9"], rtol=0, atol=0)
+    for n in (1, 6, 16, 32, 55):
+        assert np.array_equal(O.oscillator2d_eigvals(n), z[f"gt_oscillator_{n}"]), n
+
+
+def test_debug_model():
+    """RNG-free model (all weights .1, integer Fourier harmonics)."""
+    z = G.load("misc")
+    fB = torch.tensor(z["debug_B"])
+    L, hid = 3, [8, 8]
+    ws, bs, prev = [], [], fB.shape[1] * 2
+    for h in hid + [1]:
+        ws.append(0.1 * torch.ones(L, h, prev))
+        bs.append(0.1 * torch.ones(L, h, 1))
+        prev = h
+    p = O.Params(ws, bs, fB)
+    x = torch.tensor(z["debug_x"])
+    y = O.mlp_forward(O.fourier_features(x.double(), fB.double()), p.to(torch.float64))
+    assert G.rel(y, z["debug_f64_y"]) < 1e-13
+    y32 = O.mlp_forward(O.fourier_features(x, fB), p)
+    assert G.rel(y32, z["debug_f32_y"]) < 1e-6
+
+
+def test_ema_formula():
+    s = [torch.zeros(3)]
+    p = [torch.ones(3)]
+    n = 0
+    n = O.ema_update(s, p, 0.995, n)
+    assert n == 1 and torch.allclose(s[0], torch.full((3,), 1 - 2 / 11))
