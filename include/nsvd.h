@@ -1,0 +1,175 @@
+/*
+ * nsvd.h - C ABI of libnsvd_hip.so: the MI355X (gfx950) NestedLoRA / NeuralSVD PDE training step.
+ *
+ * This is the drop-in boundary for ONE path of jongharyu/neural-svd (all citations are paths in
+ * that repository):
+ *
+ *     loss, aux = method.compute_loss_operator(operator, x, importance)   methods/nestedlora.py:254-267
+ *     loss.backward(); optimizer.step(); ema.update()                     examples/operator/__init__.py:55-74
+ *     compute_spectrum_evd(...)                                           methods/spectrum.py:29-102
+ *
+ * The reference has no FFI (it is pure Python on torch eager ops); the entry points below are the
+ * functions a maintainer would bind (ctypes stub in INTEGRATION.md) to replace the torch op
+ * sequences cited per function.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous float32 unless it says "host";
+ *   - the caller owns every buffer, including the workspace (size: nsvd_workspace_bytes);
+ *     nothing here allocates, frees or synchronises;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*), is safe to capture in
+ *     a HIP graph, and keeps no global mutable state (re-entrant across streams / devices);
+ *   - return value: 0 on success, negative on error (-(int)hipError_t for HIP failures,
+ *     NSVD_EINVAL / NSVD_EUNSUPPORTED for argument errors); no C++ exception crosses the ABI.
+ *
+ * Tensor layouts (B = batch rows, D = space dims, E = 1 + 2D stencil points, R = E*B stencil
+ * rows ordered [x, x+eps e_0, x-eps e_0, x+eps e_1, ...] x B, L = eigenfunctions/heads,
+ * m = Fourier mapping size, F = 2m features, h_i = width of layer i, h_last = 1):
+ *     x        (B, D)           row-major
+ *     fourier_B(D, m)           examples/utils.py:116-121  (`_B`, frozen)
+ *     W_i      (L, h_i, h_{i-1})examples/models/mlp.py:187  (`ws[i]`)
+ *     b_i      (L, h_i, 1)      examples/models/mlp.py:189  (`bs[i]`)
+ *     scales   (L,)             examples/operator/pde/boundary.py:43 (ExponentialMask), may be NULL
+ *     f, Tf    (B, L)           what operator(model, x, importance) returns
+ *     lam      (2, L, L)        lam_f1, lam_f2 of methods/nestedlora.py:89
+ */
+#ifndef NSVD_H
+#define NSVD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSVD_ABI_VERSION 1
+#define NSVD_MAX_LAYERS 8
+
+#define NSVD_EINVAL (-10001)
+#define NSVD_EUNSUPPORTED (-10002)
+
+/* potentials: examples/operator/pde/schrodinger/potentials.py:5-8 and :24-27 */
+#define NSVD_POT_HYDROGEN 0 /* V = -Z / |x|  */
+#define NSVD_POT_HARMONIC 1 /* V = k |x|^2   */
+
+/* nesting masks: methods/nestedlora.py:40-54 */
+#define NSVD_MASK_CUSTOM 0     /* v (L) and M (L,L) given by pointer                    */
+#define NSVD_MASK_SEQUENTIAL 1 /* v = 1, M = triu(1): generated in registers, v/M NULL  */
+#define NSVD_MASK_JOINT 2      /* step 1: v_l = (L-l)/L, M = min(v_i, v_j); v/M NULL    */
+
+/* which implementation nsvd_operator_* picks */
+#define NSVD_PATH_AUTO 0    /* fused MFMA kernels when the shape allows, else generic   */
+#define NSVD_PATH_GENERIC 1 /* layer-by-layer generic kernels (any shape)               */
+#define NSVD_PATH_FUSED 2   /* fused MFMA kernels or NSVD_EUNSUPPORTED                  */
+
+/* Shape of WaveFunctions(ParallelMLP(GaussianFourierFeatureTransform)):
+ * examples/operator/pde/__init__.py:19-55, examples/models/mlp.py:167-221, examples/utils.py:90-143 */
+typedef struct nsvd_model_desc {
+    int32_t L;                       /* --neigs                                        */
+    int32_t D;                       /* --ndim * n_particles                           */
+    int32_t m;                       /* --fourier_mapping_size                         */
+    int32_t nlayers;                 /* number of weight matrices = len(hidden) + 1    */
+    int32_t dims[NSVD_MAX_LAYERS];   /* h_0 .. h_{nlayers-1}; the last one must be 1   */
+    int32_t has_exp_mask;            /* --apply_exp_mask                               */
+} nsvd_model_desc;
+
+/* Device pointers of one parameter set (weights, their gradients, RMSprop state or EMA shadow
+ * all use this same struct). */
+typedef struct nsvd_params {
+    float* fourier_B;                /* (D, m); unused in gradient/state sets          */
+    float* W[NSVD_MAX_LAYERS];
+    float* b[NSVD_MAX_LAYERS];
+    float* scales;                   /* NULL when has_exp_mask == 0                    */
+} nsvd_params;
+
+/* OperatorWrapper(NegativeHamiltonian(potential), scale, shift) with Gaussian importance:
+ * examples/__init__.py:1-9, examples/operator/pde/schrodinger/__init__.py:4-22,
+ * examples/operator/pde/diff_ops.py:4-52, examples/operator/pde/main_pde.py:94-100 */
+typedef struct nsvd_problem {
+    int32_t potential;               /* NSVD_POT_*                                     */
+    float charge_or_k;               /* Z (hydrogen) or k (oscillator)                 */
+    float scale_kinetic;             /* problems.py:26 (1.0)                           */
+    float eps;                       /* --laplacian_eps (> 0: central differences)     */
+    float op_scale;                  /* --operator_scale                               */
+    float op_shift;                  /* --operator_shift                               */
+    float sigma;                     /* --sampling_scale of the Gaussian sampler       */
+    float hard_mul_const;            /* --hard_mul_const                               */
+    int32_t use_importance;          /* 1: importance = N(0, sigma^2 I) pdf; 0: None   */
+} nsvd_problem;
+
+int nsvd_abi_version(void);
+
+/* Name of the implementation nsvd_operator_forward would take ("fused_h128x3", "generic"). host */
+const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int path);
+
+/* Bytes of scratch nsvd_operator_forward / _backward need for batches of up to B rows. */
+size_t nsvd_workspace_bytes(const nsvd_model_desc* desc, int B);
+
+/* phiT[(j | m + j), r] = (sin | cos)(x_r . B_j) for the R = E*B stencil rows of x.
+ * Replaces GaussianFourierFeatureTransform.forward at the 1+2D points of
+ * VectorizedLaplacian.approx_laplacian (examples/utils.py:126-143, diff_ops.py:36-45).
+ * phiT: (2m, ldr) feature-major, sample-contiguous; ldr >= E*B. nstencil = 1 (centre only) or E. */
+int nsvd_fourier_features(const float* x, const float* fourier_B, float* phiT, int B, int D, int m,
+                          float eps, int nstencil, int ldr, void* stream);
+
+/* Tf, f = operator(method, x, importance):  the 1+2D ParallelMLP evaluations, importance
+ * re-weighting, central-difference Laplacian, potential, scale/shift
+ * (examples/__init__.py:7-9 -> schrodinger/__init__.py:16-22 -> diff_ops.py:9-52 ->
+ *  pde/__init__.py:15-16 -> models/mlp.py:204-221).
+ * save_for_backward != 0 keeps the centre-row pre-activations in `ws` for nsvd_operator_backward. */
+int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_params* params,
+                          const nsvd_problem* prob, const float* x, int B, float* f, float* Tf,
+                          void* ws, size_t ws_bytes, int save_for_backward, int path, void* stream);
+
+/* Parameter gradients of sum(df * f) (f is the only differentiable output: Tf receives no
+ * gradient, methods/nestedlora.py:108-111).  Replaces autograd through the centre evaluation.
+ * `ws` must be the workspace the matching nsvd_operator_forward(save_for_backward=1) filled.
+ * Gradients are OVERWRITTEN (the reference calls optimizer.zero_grad() every step). */
+int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_params* params,
+                           const nsvd_problem* prob, const float* x, int B, const float* df,
+                           const nsvd_params* grads, void* ws, size_t ws_bytes, int path, void* stream);
+
+/* out[b, l] = hard_mul_const * base_l(x_b) * mask_l(x_b): WaveFunctions.forward, i.e. what
+ * NestedLoRA.forward / method(x) returns (examples/operator/pde/__init__.py:15-16,
+ * methods/nestedlora.py:195-200). Forward only (eigenfunction evaluation); out: (B, L). */
+int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
+                       float hard_mul_const, float* out, void* ws, size_t ws_bytes, int path, void* stream);
+
+/* NestedLoRALossFunctionEVD.forward with f1, f2 = chunk(f, 2) (methods/nestedlora.py:70-94, :263).
+ * Stage 1: moments[0 : L*L] = lam_f1, [L*L : 2*L*L] = lam_f2, [2*L*L] = mean_b sum_l v_l f Tf.
+ * These 2L^2+1 floats are the data-parallel exchange payload (all-reduce mean over ranks).
+ * scratch: nsvd_evd_scratch_bytes(B, L) bytes. */
+size_t nsvd_evd_scratch_bytes(int B, int L);
+int nsvd_evd_moments(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v,
+                     float* moments, void* scratch, void* stream);
+
+/* Stage 2: loss[0] = -2 * moments[2L^2] + sum(M * lam_f1 * lam_f2); loss[1] = operator term,
+ * loss[2] = metric term; and, when df != NULL, NestedLoRALossFunctionEVD.backward
+ * (methods/nestedlora.py:98-111) with the f1/f2 contributions summed into d loss / d f:
+ *   df[b, :] = grad_scale * ( -(4/B) v * Tf[b] + (2/B_half) f[b] @ (M * lam_other) ).
+ * grad_scale folds grad_output and, for data parallel runs, nothing else (ranks average later). */
+int nsvd_evd_loss_grad(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v,
+                       const float* M, const float* moments, float grad_scale, float* loss, float* df,
+                       void* stream);
+
+/* torch.optim.RMSprop(alpha, eps, momentum=0, centered=False) step + torch_ema update, fused
+ * (examples/utils.py:50-57, examples/operator/__init__.py:69-73):
+ *   g = grad_scale * grad; sq = alpha sq + (1-alpha) g^2; p -= lr g / (sqrt(sq) + eps);
+ *   ema -= (1 - ema_decay) (ema - p)        (skipped when ema == NULL)
+ * over n contiguous floats. lr is the already-scheduled learning rate, ema_decay the already
+ * warmed-up decay min(decay, (1+t)/(10+t)). */
+int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, size_t n, float lr,
+                          float alpha, float eps, float ema_decay, float grad_scale, void* stream);
+
+/* compute_spectrum_evd accumulation for one chunk (methods/spectrum.py:56-75):
+ *   w = sqrt(p_train(x)) / sqrt(p_val), phi = nan_to_num(w f), Tphi = nan_to_num(w Tf),
+ *   Tphi rows with x ~ 0 zeroed, cov += phi^T phi, quad += phi^T Tphi   (cov, quad: (L, L)).
+ * p_val = uniform on [-lim, lim]^D (main_pde.py:129-130). */
+int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, int B, int L, int D,
+                             float sigma, int use_importance, float lim, float* cov, float* quad,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSVD_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of ``libnsvd_hip.so`` (C ABI declared in ``include/nsvd.h``).
+
+There is deliberately NO fallback: if the shared library is missing or does not export the
+expected ABI, importing the ops raises, and every op raises when handed a non-GPU tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+NSVD_MAX_LAYERS = 8
+ABI_VERSION = 1
+
+EINVAL = -10001
+EUNSUPPORTED = -10002
+
+POT_HYDROGEN, POT_HARMONIC = 0, 1
+MASK_CUSTOM, MASK_SEQUENTIAL, MASK_JOINT = 0, 1, 2
+PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libnsvd_hip.so")
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("L", C.c_int32), ("D", C.c_int32), ("m", C.c_int32), ("nlayers", C.c_int32),
+                ("dims", C.c_int32 * NSVD_MAX_LAYERS), ("has_exp_mask", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("fourier_B", C.c_void_p), ("W", C.c_void_p * NSVD_MAX_LAYERS),
+                ("b", C.c_void_p * NSVD_MAX_LAYERS), ("scales", C.c_void_p)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("potential", C.c_int32), ("charge_or_k", C.c_float), ("scale_kinetic", C.c_float),
+                ("eps", C.c_float), ("op_scale", C.c_float), ("op_shift", C.c_float), ("sigma", C.c_float),
+                ("hard_mul_const", C.c_float), ("use_importance", C.c_int32)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/nsvd.h
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "nsvd_abi_version": (_I, []),
+    "nsvd_path_name": (C.c_char_p, [C.POINTER(ModelDesc), _I, _I]),
+    "nsvd_workspace_bytes": (_Z, [C.POINTER(ModelDesc), _I]),
+    "nsvd_fourier_features": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
+    "nsvd_operator_forward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _P,
+                                   _P, _Z, _I, _I, _P]),
+    "nsvd_operator_backward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
+                                    C.POINTER(Params), _P, _Z, _I, _P]),
+    "nsvd_model_forward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), _P, _I, _F, _P, _P, _Z, _I, _P]),
+    "nsvd_evd_scratch_bytes": (_Z, [_I, _I]),
+    "nsvd_evd_moments": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "nsvd_evd_loss_grad": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P]),
+    "nsvd_rmsprop_ema_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _P]),
+    "nsvd_spectrum_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class NsvdError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library. Raises NsvdError when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NsvdError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C neural_svd_amd/csrc`). "
+            f"neural_svd_amd has no CPU / eager fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NsvdError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.nsvd_abi_version()
+    if v != ABI_VERSION:
+        raise NsvdError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}; rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == EINVAL:
+        raise NsvdError(f"{what}: invalid argument (NSVD_EINVAL)")
+    if rc == EUNSUPPORTED:
+        raise NsvdError(f"{what}: unsupported configuration (NSVD_EUNSUPPORTED)")
+    raise NsvdError(f"{what}: HIP error {-rc}")

@@ -1,0 +1,63 @@
+// Per-(sample, head) math of the importance-weighted finite-difference Hamiltonian, shared by the
+// generic epilogue kernel and the fused MFMA kernel's epilogue so both paths are the same arithmetic.
+#pragma once
+#include "nsvd_common.h"
+
+#define NSVD_FD_MAXD 4
+
+struct NsvdFdOut {
+    float f, Tf, jac, dsc;
+};
+
+// bv[e]: raw head output base_l(x_e) at the stencil points (e = 0 centre, 1+2i: +eps e_i, 2+2i: -eps e_i)
+// xc: centre coordinates. Follows the reference's operation order:
+//   g_e   = sqrt(p(x_e)) * (c * base_e * mask_l(x_e))          pde/__init__.py:16, diff_ops.py:13
+//   lap_g = (-2 D g_0 + sum_i (g_+i + g_-i)) / eps^2           diff_ops.py:38-48
+//   lap   = lap_g / clamp(sqrt p(x_0), 1e-5),  fs = g_0 / clamp(...)   diff_ops.py:15-18
+//   Tf    = scale * -( -c_k lap + V(x) fs ) + shift * fs       schrodinger/__init__.py:18-22, examples/__init__.py:9
+__device__ __forceinline__ NsvdFdOut nsvd_fd_point(const float* bv, const float* xc, int D, bool has_mask, float s_l,
+                                                   const nsvd_problem& prob, float log_norm) {
+    const int E = 1 + 2 * D;
+    float g[2 * NSVD_FD_MAXD + 1];
+    float sp0 = 1.f, mask0 = 1.f, r0 = 0.f;
+    for (int e = 0; e < E; ++e) {
+        float xe[NSVD_FD_MAXD];
+        float r2 = 0.f;
+        for (int d = 0; d < D; ++d) {
+            xe[d] = nsvd_stencil_coord(xc[d], d, e, prob.eps);
+            r2 = fmaf(xe[d], xe[d], r2);
+        }
+        const float sp = prob.use_importance ? nsvd_sqrt_gauss_pdf(xe, D, prob.sigma, log_norm) : 1.f;
+        float model = prob.hard_mul_const * bv[e];
+        float mk = 1.f;
+        if (has_mask) {
+            mk = expf(-sqrtf(r2) / s_l);
+            model *= mk;
+        }
+        g[e] = sp * model;
+        if (e == 0) {
+            sp0 = sp;
+            mask0 = mk;
+            r0 = sqrtf(r2);
+        }
+    }
+    float lap = -2.f * (float)D * g[0];
+    for (int i = 0; i < D; ++i) lap += (g[1 + 2 * i] + g[2 + 2 * i]);
+    const float eps2 = (float)((double)prob.eps * (double)prob.eps);
+    lap = lap / eps2;
+    const float spc = prob.use_importance ? fmaxf(sp0, NSVD_SQRT_P_CLAMP) : 1.f;
+    lap = lap / spc;
+    const float fs = g[0] / spc;
+    float V;
+    if (prob.potential == NSVD_POT_HYDROGEN) V = -(prob.charge_or_k / r0);
+    else V = prob.charge_or_k * (r0 * r0);
+    const float kinetic = -prob.scale_kinetic * lap;
+    const float H = kinetic + V * fs;
+    NsvdFdOut o;
+    o.f = fs;
+    o.Tf = prob.op_scale * (-H) + prob.op_shift * fs;
+    const float w = (sp0 / spc) * prob.hard_mul_const;
+    o.jac = w * mask0;
+    o.dsc = has_mask ? w * bv[0] * mask0 * r0 / (s_l * s_l) : 0.f;
+    return o;
+}

@@ -1,0 +1,108 @@
+// Generic strided, batched fp32 GEMM for shapes the fused MFMA kernels do not cover
+// (hidden widths that are not 128, ragged batches). LDS-tiled 64x64x16, 4x4 register tiles.
+// Used for: ParallelMLP layers (reference mlp.py:204-221), their data gradients and weight
+// gradients (what autograd derives for those einsums).
+#include "nsvd_kernels.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16, PAD = 4;
+
+__global__ void __launch_bounds__(256) gemm_generic_kernel(NsvdGemm g) {
+    __shared__ float As[TK][TM + PAD];
+    __shared__ float Bs[TK][TN + PAD];
+    const int bz = blockIdx.z;
+    const float* A = g.A + (size_t)bz * g.bA;
+    const float* Bm = g.B + (size_t)bz * g.bB;
+    float* C = g.C + (size_t)bz * g.bC;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int t = threadIdx.x;
+    const int tx = t & 15, ty = t >> 4;
+    float acc[4][4] = {};
+    const bool a_kfast = (g.sAk == 1);
+    const bool b_nfast = (g.sBn == 1);
+    for (int k0 = 0; k0 < g.K; k0 += TK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int mm, kk;
+            if (a_kfast) { kk = t & 15; mm = (t >> 4) + 16 * i; }
+            else         { mm = t & 63; kk = (t >> 6) + 4 * i; }
+            const int gm = m0 + mm, gk = k0 + kk;
+            float v = 0.f;
+            if (gm < g.M && gk < g.K) v = A[(size_t)gm * g.sAm + (size_t)gk * g.sAk];
+            As[kk][mm] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int nn, kk;
+            if (b_nfast) { nn = t & 63; kk = (t >> 6) + 4 * i; }
+            else         { kk = t & 15; nn = (t >> 4) + 16 * i; }
+            const int gn = n0 + nn, gk = k0 + kk;
+            float v = 0.f;
+            if (gn < g.N && gk < g.K) {
+                v = Bm[(size_t)gk * g.sBk + (size_t)gn * g.sBn];
+                if (g.softplus_b) v = nsvd_softplus(v);
+            }
+            Bs[kk][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) {
+            const float4 a = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+            const float4 b = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    const float* bias = g.bias ? g.bias + (size_t)bz * g.bBias : nullptr;
+    const float* Z = g.Z ? g.Z + (size_t)bz * g.bZ : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty * 4 + i;
+        if (gm >= g.M) continue;
+        const float bi = bias ? bias[gm] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx * 4 + j;
+            if (gn >= g.N) continue;
+            float v = acc[i][j] + bi;
+            if (g.sigmoid_mul) v *= nsvd_sigmoid(Z[(size_t)gm * g.sZm + gn]);
+            C[(size_t)gm * g.sCm + gn] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                     int n, long ld) {
+    // one wave per row
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= rows) return;
+    const float* p = in + (size_t)wave * ld;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += p[j];
+    s = nsvd_wave_sum(s);
+    if (lane == 0) out[wave] = s;
+}
+
+}  // namespace
+
+int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return NSVD_EINVAL;
+    dim3 grid(nsvd_cdiv(g.N, TN), nsvd_cdiv(g.M, TM), g.batch);
+    hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, s, g);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+int nsvd_rowsum(const float* in, float* out, int rows, int n, long ld, hipStream_t s) {
+    const int blocks = nsvd_cdiv(rows, 4);
+    hipLaunchKernelGGL(rowsum_kernel, dim3(blocks), dim3(256), 0, s, in, out, rows, n, ld);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}

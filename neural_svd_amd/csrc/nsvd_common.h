@@ -1,0 +1,70 @@
+// Shared host/device helpers for libnsvd_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nsvd.h"
+
+#define NSVD_SOFTPLUS_THRESHOLD 20.0f  // torch.nn.Softplus default (reference mlp.py:84-85)
+#define NSVD_SQRT_P_CLAMP 1e-5f        // reference diff_ops.py:15
+#define NSVD_LOG2E 1.4426950408889634f
+#define NSVD_LN2 0.6931471805599453f
+
+#define NSVD_CHECK_LAUNCH()                          \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return -(int)e__;     \
+    } while (0)
+
+static inline int nsvd_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t nsvd_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// softplus(z) = log(1 + e^z) with torch's threshold. Hardware exp2/log2 (v_exp_f32 / v_log_f32,
+// ~1 ulp) plus the u-1 correction that makes log1p accurate for small t: ~12 VALU instead of the
+// ~60 of ocml log1pf(expf()). max(z,0) + log1p(exp(-|z|)) never overflows.
+__device__ __forceinline__ float nsvd_softplus(float z) {
+    const float t = __builtin_amdgcn_exp2f(-fabsf(z) * NSVD_LOG2E);  // e^{-|z|} in (0, 1]
+    const float u = 1.0f + t;
+    const float d = u - 1.0f;
+    float l = __builtin_amdgcn_logf(u) * NSVD_LN2;                   // ln(u)
+    l = (d == 0.0f) ? t : l * (t * __builtin_amdgcn_rcpf(d));        // ln(1+t) to ~1 ulp
+    const float r = fmaxf(z, 0.0f) + l;
+    return z > NSVD_SOFTPLUS_THRESHOLD ? z : r;
+}
+
+// d softplus / dz = sigmoid(z)  (1 above the threshold, like torch's softplus_backward)
+__device__ __forceinline__ float nsvd_sigmoid(float z) {
+    const float t = __builtin_amdgcn_exp2f(-fabsf(z) * NSVD_LOG2E);  // e^{-|z|}
+    const float r = __builtin_amdgcn_rcpf(1.0f + t);                 // sigma(|z|)
+    const float s = z >= 0.0f ? r : t * r;
+    return z > NSVD_SOFTPLUS_THRESHOLD ? 1.0f : s;
+}
+
+__device__ __forceinline__ float nsvd_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sqrt of the isotropic Gaussian pdf N(0, sigma^2 I) the way MultivariateNormal.log_prob().exp().sqrt()
+// evaluates it (reference main_pde.py:94-100): M = sum (x_d / sigma)^2.
+__device__ __forceinline__ float nsvd_sqrt_gauss_pdf(const float* xr, int D, float sigma, float log_norm) {
+    float M = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float t = xr[d] / sigma;
+        M = fmaf(t, t, M);
+    }
+    return sqrtf(expf(-0.5f * M + log_norm));
+}
+
+// host: -0.5 D log(2 pi) - D log(sigma)
+static inline float nsvd_gauss_log_norm(int D, float sigma) {
+    return (float)(-0.5 * D * 1.8378770664093453 - D * log((double)sigma));
+}
+
+// stencil point e of row b: e = 0 centre, e = 1 + 2i: +eps on axis i, e = 2 + 2i: -eps
+__device__ __forceinline__ float nsvd_stencil_coord(float xc, int d, int e, float eps) {
+    if (e == 0) return xc;
+    const int axis = (e - 1) >> 1;
+    if (axis != d) return xc;
+    return ((e - 1) & 1) ? xc - eps : xc + eps;
+}

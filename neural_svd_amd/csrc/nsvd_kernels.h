@@ -1,0 +1,46 @@
+// Internal (C++) launch interface between the translation units of libnsvd_hip.so.
+#pragma once
+#include "nsvd_common.h"
+
+// ---- generic strided batched GEMM (gemm_generic.hip) -------------------------------------------
+//   C[g][i][j] = epi( sum_k A[g][i*sAm + k*sAk] * pro(B[g][k*sBk + j*sBn]) + bias[g][i] )
+// pro: optional softplus on B elements; epi: optional multiply by sigmoid(Z[g][i*sZm + j]).
+struct NsvdGemm {
+    const float* A = nullptr;
+    const float* B = nullptr;
+    float* C = nullptr;
+    int M = 0, N = 0, K = 0, batch = 1;
+    long sAm = 0, sAk = 0, sBk = 0, sBn = 0, sCm = 0;
+    long bA = 0, bB = 0, bC = 0;
+    const float* bias = nullptr;
+    long bBias = 0;
+    const float* Z = nullptr;
+    long sZm = 0, bZ = 0;
+    int softplus_b = 0;
+    int sigmoid_mul = 0;
+};
+int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s);
+
+// out[g][i] = sum_j in[g][i*ld + j], j < n   (bias gradients)
+int nsvd_rowsum(const float* in, float* out, int rows, int n, long ld, hipStream_t s);
+
+// ---- FD Hamiltonian epilogue + its backward head (fd_epilogue.hip) ------------------------------
+// base: (L, ldr) head outputs at the E*B stencil rows -> f, Tf (B, L); optionally jac, dsc (B, L):
+//   jac = d f / d base(centre), dsc = d f / d scales_l per row (ExponentialMask only).
+int nsvd_fd_epilogue(const float* base, int ldr, const float* x, const float* scales, const nsvd_problem& prob,
+                     int B, int D, int L, float* f, float* Tf, float* jac, float* dsc, hipStream_t s);
+// dzT[l][b] = df[b][l] * jac[b][l]; dscales[l] = sum_b df[b][l] * dsc[b][l] (when dscales != null)
+int nsvd_head_backward(const float* df, const float* jac, const float* dsc, int B, int L, float* dzT,
+                       float* dscales, hipStream_t s);
+
+// out[b][l] = c * base[l*ldr + b] * exp(-|x_b| / scales[l])   (WaveFunctions.forward at the centre rows)
+int nsvd_model_out(const float* base, int ldr, const float* x, const float* scales, float c, int B, int D, int L,
+                   float* out, hipStream_t s);
+
+// ---- fused MFMA path (pmlp_fused.hip) -----------------------------------------------------------
+bool nsvd_fused_supported(const nsvd_model_desc& d, int B);
+size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B);
+int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                       int B, float* f, float* Tf, void* ws, int save, hipStream_t s);
+int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                        int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s);

@@ -1,0 +1,211 @@
+// extern "C" entry points for the operator forward / backward: argument validation, workspace
+// carving, and the choice between the fused MFMA kernels (pmlp_fused.hip) and the generic
+// layer-by-layer path implemented here on top of gemm_generic.hip / fd_epilogue.hip.
+#include <string.h>
+#include "nsvd_kernels.h"
+
+namespace {
+
+struct GenericWs {
+    float* phiT;                      // (F, R)
+    float* z[NSVD_MAX_LAYERS];        // z[i]: (L, h_i, R) for i < nl-1 ; z[nl-1] = base (L, R)
+    float* jac;                       // (B, L)
+    float* dsc;                       // (B, L)
+    float* dz[2];                     // ping-pong (L, hmax, B)
+    size_t bytes;
+};
+
+int validate(const nsvd_model_desc* d) {
+    if (!d) return NSVD_EINVAL;
+    if (d->L <= 0 || d->D <= 0 || d->m <= 0) return NSVD_EINVAL;
+    if (d->nlayers < 1 || d->nlayers > NSVD_MAX_LAYERS) return NSVD_EINVAL;
+    for (int i = 0; i < d->nlayers; ++i)
+        if (d->dims[i] <= 0) return NSVD_EINVAL;
+    if (d->dims[d->nlayers - 1] != 1) return NSVD_EINVAL;
+    if (d->D > 4) return NSVD_EUNSUPPORTED;
+    return 0;
+}
+
+GenericWs carve(const nsvd_model_desc& d, int B, void* base) {
+    GenericWs w;
+    memset(&w, 0, sizeof(w));
+    const size_t E = 1 + 2 * (size_t)d.D, R = E * B, F = 2 * (size_t)d.m;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float* q = (float*)(p + off);
+        off += nsvd_align(nfloats * sizeof(float));
+        return q;
+    };
+    w.phiT = take(F * R);
+    int hmax = 1;
+    for (int i = 0; i < d.nlayers; ++i) {
+        w.z[i] = take((size_t)d.L * d.dims[i] * R);
+        if (d.dims[i] > hmax) hmax = d.dims[i];
+    }
+    w.jac = take((size_t)B * d.L);
+    w.dsc = take((size_t)B * d.L);
+    w.dz[0] = take((size_t)d.L * hmax * B);
+    w.dz[1] = take((size_t)d.L * hmax * B);
+    w.bytes = off;
+    return w;
+}
+
+bool want_fused(const nsvd_model_desc& d, int B, int path) {
+    if (path == NSVD_PATH_GENERIC) return false;
+    return nsvd_fused_supported(d, B);
+}
+
+int check_params(const nsvd_model_desc& d, const nsvd_params* p, bool need_fourier) {
+    if (!p) return NSVD_EINVAL;
+    if (need_fourier && !p->fourier_B) return NSVD_EINVAL;
+    for (int i = 0; i < d.nlayers; ++i)
+        if (!p->W[i] || !p->b[i]) return NSVD_EINVAL;
+    if (d.has_exp_mask && !p->scales) return NSVD_EINVAL;
+    return 0;
+}
+
+// Fourier map + every ParallelMLP layer for the first `nst` stencil blocks (nst = E: all rows, 1: centre only)
+int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float eps, int nst,
+                const GenericWs& w, hipStream_t s) {
+    const int E = 1 + 2 * d.D, R = E * B, F = 2 * d.m;
+    int rc = nsvd_fourier_features(x, p.fourier_B, w.phiT, B, d.D, d.m, eps, nst, R, s);
+    if (rc) return rc;
+    int kin = F;
+    for (int i = 0; i < d.nlayers; ++i) {
+        NsvdGemm g;
+        g.batch = d.L;
+        g.M = d.dims[i]; g.N = nst * B; g.K = kin;
+        g.A = p.W[i]; g.sAm = kin; g.sAk = 1; g.bA = (long)d.dims[i] * kin;
+        g.B = (i == 0) ? w.phiT : w.z[i - 1]; g.sBk = R; g.sBn = 1; g.bB = (i == 0) ? 0 : (long)kin * R;
+        g.C = w.z[i]; g.sCm = R; g.bC = (long)d.dims[i] * R;
+        g.bias = p.b[i]; g.bBias = d.dims[i];
+        g.softplus_b = (i > 0);
+        rc = nsvd_gemm_generic(g, s);
+        if (rc) return rc;
+        kin = d.dims[i];
+    }
+    return 0;
+}
+
+int generic_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x, int B,
+                    float* f, float* Tf, void* ws, hipStream_t s) {
+    const GenericWs w = carve(d, B, ws);
+    const int E = 1 + 2 * d.D, R = E * B;
+    int rc = generic_mlp(d, p, x, B, prob.eps, E, w, s);
+    if (rc) return rc;
+    return nsvd_fd_epilogue(w.z[d.nlayers - 1], R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
+                            w.jac, w.dsc, s);
+}
+
+int generic_backward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, const float* df,
+                     const nsvd_params& g, void* ws, hipStream_t s) {
+    (void)x;
+    const GenericWs w = carve(d, B, ws);
+    const int E = 1 + 2 * d.D, R = E * B, F = 2 * d.m;
+    int cur = 0;
+    int rc = nsvd_head_backward(df, w.jac, w.dsc, B, d.L, w.dz[cur], d.has_exp_mask ? g.scales : nullptr, s);
+    if (rc) return rc;
+    for (int i = d.nlayers - 1; i >= 0; --i) {
+        const int hi = d.dims[i];
+        const int kin = (i == 0) ? F : d.dims[i - 1];
+        // weight gradient: dW_i[l][n][k] = sum_b dz_i[l][n][b] * a_{i-1}[l][k][b]
+        NsvdGemm wg;
+        wg.batch = d.L;
+        wg.M = hi; wg.N = kin; wg.K = B;
+        wg.A = w.dz[cur]; wg.sAm = B; wg.sAk = 1; wg.bA = (long)hi * B;
+        wg.B = (i == 0) ? w.phiT : w.z[i - 1]; wg.sBk = 1; wg.sBn = R; wg.bB = (i == 0) ? 0 : (long)kin * R;
+        wg.C = g.W[i]; wg.sCm = kin; wg.bC = (long)hi * kin;
+        wg.softplus_b = (i > 0);
+        rc = nsvd_gemm_generic(wg, s);
+        if (rc) return rc;
+        rc = nsvd_rowsum(w.dz[cur], g.b[i], d.L * hi, B, B, s);
+        if (rc) return rc;
+        if (i > 0) {
+            // data gradient: dz_{i-1}[l][k][b] = (sum_n W_i[l][n][k] dz_i[l][n][b]) * sigmoid(z_{i-1}[l][k][b])
+            NsvdGemm dg;
+            dg.batch = d.L;
+            dg.M = kin; dg.N = B; dg.K = hi;
+            dg.A = p.W[i]; dg.sAm = 1; dg.sAk = kin; dg.bA = (long)hi * kin;
+            dg.B = w.dz[cur]; dg.sBk = B; dg.sBn = 1; dg.bB = (long)hi * B;
+            dg.C = w.dz[cur ^ 1]; dg.sCm = B; dg.bC = (long)kin * B;
+            dg.Z = w.z[i - 1]; dg.sZm = R; dg.bZ = (long)kin * R;
+            dg.sigmoid_mul = 1;
+            rc = nsvd_gemm_generic(dg, s);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int nsvd_abi_version(void) { return NSVD_ABI_VERSION; }
+
+extern "C" const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int path) {
+    if (validate(desc) != 0 || B <= 0) return "invalid";
+    return want_fused(*desc, B, path) ? "fused_mfma" : "generic";
+}
+
+extern "C" size_t nsvd_workspace_bytes(const nsvd_model_desc* desc, int B) {
+    if (validate(desc) != 0 || B <= 0) return 0;
+    const size_t gen = carve(*desc, B, nullptr).bytes;
+    const size_t fus = nsvd_fused_supported(*desc, B) ? nsvd_fused_workspace_bytes(*desc, B) : 0;
+    return gen > fus ? gen : fus;
+}
+
+extern "C" int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_params* params,
+                                     const nsvd_problem* prob, const float* x, int B, float* f, float* Tf, void* ws,
+                                     size_t ws_bytes, int save_for_backward, int path, void* stream) {
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!prob || !x || !f || !Tf || !ws || B <= 0) return NSVD_EINVAL;
+    if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;  // exact-Laplacian mode is not on this path
+    if (prob->potential != NSVD_POT_HYDROGEN && prob->potential != NSVD_POT_HARMONIC) return NSVD_EINVAL;
+    rc = check_params(*desc, params, true);
+    if (rc) return rc;
+    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    const bool fused = want_fused(*desc, B, path);
+    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if (fused) return nsvd_fused_forward(*desc, *params, *prob, x, B, f, Tf, ws, save_for_backward, (hipStream_t)stream);
+    return generic_forward(*desc, *params, *prob, x, B, f, Tf, ws, (hipStream_t)stream);
+}
+
+extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
+                                  float hard_mul_const, float* out, void* ws, size_t ws_bytes, int path,
+                                  void* stream) {
+    (void)path;  // forward-only evaluation always takes the generic kernels
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!x || !out || !ws || B <= 0) return NSVD_EINVAL;
+    rc = check_params(*desc, params, true);
+    if (rc) return rc;
+    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    const GenericWs w = carve(*desc, B, ws);
+    const int R = (1 + 2 * desc->D) * B;
+    rc = generic_mlp(*desc, *params, x, B, 0.f, 1, w, (hipStream_t)stream);
+    if (rc) return rc;
+    return nsvd_model_out(w.z[desc->nlayers - 1], R, x, desc->has_exp_mask ? params->scales : nullptr,
+                          hard_mul_const, B, desc->D, desc->L, out, (hipStream_t)stream);
+}
+
+extern "C" int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_params* params,
+                                      const nsvd_problem* prob, const float* x, int B, const float* df,
+                                      const nsvd_params* grads, void* ws, size_t ws_bytes, int path, void* stream) {
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!prob || !x || !df || !ws || B <= 0) return NSVD_EINVAL;
+    rc = check_params(*desc, params, true);
+    if (rc) return rc;
+    rc = check_params(*desc, grads, false);
+    if (rc) return rc;
+    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    const bool fused = want_fused(*desc, B, path);
+    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if (fused) return nsvd_fused_backward(*desc, *params, *prob, x, B, df, *grads, ws, (hipStream_t)stream);
+    return generic_backward(*desc, *params, x, B, df, *grads, ws, (hipStream_t)stream);
+}

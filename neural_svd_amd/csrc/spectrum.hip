@@ -1,0 +1,69 @@
+// Streaming accumulators of compute_spectrum_evd (reference methods/spectrum.py:56-75):
+//   cov += phi^T phi, quad += phi^T Tphi  with phi = nan_to_num(w f), Tphi = nan_to_num(w Tf),
+//   w = sqrt(p_train(x)) / sqrt(p_val), rows with x ~ 0 zeroed in Tphi (:73).
+// One workgroup per 256 rows: rows staged in LDS, L x L partial products in registers, then one
+// float atomic per (i, j) and workgroup.
+#include "nsvd_kernels.h"
+#include <float.h>
+
+namespace {
+
+constexpr int SR = 128;     // rows per workgroup
+constexpr int SMAXL = 64;
+
+__device__ __forceinline__ float nan_to_num(float v) {
+    if (isnan(v)) return 0.f;
+    if (isinf(v)) return v > 0 ? FLT_MAX : -FLT_MAX;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) spectrum_kernel(const float* __restrict__ f, const float* __restrict__ Tf,
+                                                       const float* __restrict__ x, int B, int L, int D, float sigma,
+                                                       float log_norm, int use_imp, float inv_sqrt_val,
+                                                       float* __restrict__ cov, float* __restrict__ quad) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // phi[SR][L], tphi[SR][L]
+    float* ph = sm;
+    float* tp = sm + SR * L;
+    const int r0 = blockIdx.x * SR;
+    const int nr = min(SR, B - r0);
+    for (int i = threadIdx.x; i < nr * L; i += 256) {
+        const int r = i / L;
+        const float* xr = x + (size_t)(r0 + r) * D;
+        const float sp = use_imp ? nsvd_sqrt_gauss_pdf(xr, D, sigma, log_norm) : 1.f;
+        const float w = sp * inv_sqrt_val;
+        bool zero = true;
+        for (int d = 0; d < D; ++d) zero = zero && (fabsf(xr[d]) <= 1e-8f);  // torch.isclose(x, 0)
+        ph[i] = nan_to_num(w * f[(size_t)r0 * L + i]);
+        const float t = nan_to_num(w * Tf[(size_t)r0 * L + i]);
+        tp[i] = zero ? 0.f : t;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < L * L; o += 256) {
+        const int i = o / L, j = o - i * L;
+        float c = 0.f, q = 0.f;
+        for (int r = 0; r < nr; ++r) {
+            const float pi = ph[r * L + i];
+            c = fmaf(pi, ph[r * L + j], c);
+            q = fmaf(pi, tp[r * L + j], q);
+        }
+        atomicAdd(&cov[o], c);
+        atomicAdd(&quad[o], q);
+    }
+}
+
+}  // namespace
+
+extern "C" int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, int B, int L, int D,
+                                        float sigma, int use_importance, float lim, float* cov, float* quad,
+                                        void* stream) {
+    if (!f || !Tf || !x || !cov || !quad || B <= 0 || L <= 0 || D <= 0) return NSVD_EINVAL;
+    if (L > SMAXL) return NSVD_EUNSUPPORTED;
+    // importance_val is built as a float32 tensor in the reference (main_pde.py:130)
+    const float pval = (float)(1.0 / pow(2.0 * (double)lim, (double)D));
+    const float inv_sqrt_val = 1.f / sqrtf(pval);
+    const size_t lds = (size_t)2 * SR * L * sizeof(float);
+    hipLaunchKernelGGL(spectrum_kernel, dim3(nsvd_cdiv(B, SR)), dim3(256), lds, (hipStream_t)stream, f, Tf, x, B, L, D,
+                       sigma, nsvd_gauss_log_norm(D, sigma), use_importance, inv_sqrt_val, cov, quad);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,239 @@
+"""Tensor-level wrappers over the C ABI (``include/nsvd.h``): validation, pointers, current stream.
+
+PyTorch is used here only as plumbing (device memory + the current HIP stream). Every function
+requires contiguous float32 tensors on a GPU and raises otherwise - there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (MASK_CUSTOM, MASK_JOINT, MASK_SEQUENTIAL, PATH_AUTO, PATH_FUSED, PATH_GENERIC,  # noqa: F401
+                   POT_HARMONIC, POT_HYDROGEN, ModelDesc, NsvdError, Params, Problem, check)
+
+
+def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NsvdError(f"{name} must live on the GPU (got {t.device}); neural_svd_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise NsvdError(f"{name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise NsvdError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass(frozen=True)
+class ModelShape:
+    """Shape of WaveFunctions(ParallelMLP(FourierFeatures)); ``hidden`` excludes the final width 1."""
+    L: int
+    D: int
+    m: int
+    hidden: Tuple[int, ...]
+    has_exp_mask: bool = False
+
+    @property
+    def dims(self) -> Tuple[int, ...]:
+        return tuple(self.hidden) + (1,)
+
+    def desc(self) -> ModelDesc:
+        d = ModelDesc()
+        d.L, d.D, d.m = self.L, self.D, self.m
+        dims = self.dims
+        if len(dims) > _lib.NSVD_MAX_LAYERS:
+            raise NsvdError(f"at most {_lib.NSVD_MAX_LAYERS} layers are supported")
+        d.nlayers = len(dims)
+        for i, h in enumerate(dims):
+            d.dims[i] = h
+        d.has_exp_mask = int(self.has_exp_mask)
+        return d
+
+    def param_shapes(self) -> List[Tuple[int, ...]]:
+        """Trainable tensors in the reference's parameter order: ws..., bs..., [scales]."""
+        shapes, prev = [], 2 * self.m
+        for h in self.dims:
+            shapes.append((self.L, h, prev))
+            prev = h
+        for h in self.dims:
+            shapes.append((self.L, h, 1))
+        if self.has_exp_mask:
+            shapes.append((self.L,))
+        return shapes
+
+
+def make_problem(potential: int, charge_or_k: float, eps: float, op_scale: float, op_shift: float, sigma: float,
+                 scale_kinetic: float = 1.0, hard_mul_const: float = 1.0, use_importance: bool = True) -> Problem:
+    p = Problem()
+    p.potential = int(potential)
+    p.charge_or_k = float(charge_or_k)
+    p.scale_kinetic = float(scale_kinetic)
+    p.eps = float(eps)
+    p.op_scale = float(op_scale)
+    p.op_shift = float(op_shift)
+    p.sigma = float(sigma)
+    p.hard_mul_const = float(hard_mul_const)
+    p.use_importance = int(bool(use_importance))
+    return p
+
+
+def pack_params(shape: ModelShape, ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],
+                fourier_B: Optional[torch.Tensor], scales: Optional[torch.Tensor]) -> Params:
+    """Fill an ``nsvd_params`` struct after checking every tensor against ``shape``."""
+    dims = shape.dims
+    if len(ws) != len(dims) or len(bs) != len(dims):
+        raise NsvdError("number of weight/bias tensors does not match the model shape")
+    p = Params()
+    if fourier_B is not None:
+        if tuple(fourier_B.shape) != (shape.D, shape.m):
+            raise NsvdError(f"fourier_B must be {(shape.D, shape.m)}, got {tuple(fourier_B.shape)}")
+        p.fourier_B = _ptr(fourier_B, "fourier_B")
+    prev = 2 * shape.m
+    for i, h in enumerate(dims):
+        if tuple(ws[i].shape) != (shape.L, h, prev):
+            raise NsvdError(f"W[{i}] must be {(shape.L, h, prev)}, got {tuple(ws[i].shape)}")
+        if ws[i].numel() != 0 and bs[i].numel() != shape.L * h:
+            raise NsvdError(f"b[{i}] must have {shape.L * h} elements")
+        p.W[i] = _ptr(ws[i], f"W[{i}]")
+        p.b[i] = _ptr(bs[i], f"b[{i}]")
+        prev = h
+    if shape.has_exp_mask:
+        if scales is None or scales.numel() != shape.L:
+            raise NsvdError("scales (L,) required when has_exp_mask")
+        p.scales = _ptr(scales, "scales")
+    return p
+
+
+def workspace_bytes(shape: ModelShape, B: int) -> int:
+    d = shape.desc()
+    n = _lib.load().nsvd_workspace_bytes(C.byref(d), int(B))
+    if n == 0:
+        raise NsvdError("nsvd_workspace_bytes: invalid model description")
+    return int(n)
+
+
+def path_name(shape: ModelShape, B: int, path: int = PATH_AUTO) -> str:
+    d = shape.desc()
+    return _lib.load().nsvd_path_name(C.byref(d), int(B), int(path)).decode()
+
+
+def new_workspace(shape: ModelShape, B: int, device) -> torch.Tensor:
+    return torch.empty(workspace_bytes(shape, B), dtype=torch.uint8, device=device)
+
+
+def fourier_features(x: torch.Tensor, fourier_B: torch.Tensor, eps: float, nstencil: int) -> torch.Tensor:
+    B, D = x.shape
+    m = fourier_B.shape[1]
+    R = nstencil * B
+    out = torch.empty((2 * m, R), dtype=torch.float32, device=x.device)
+    rc = _lib.load().nsvd_fourier_features(_ptr(x, "x"), _ptr(fourier_B, "fourier_B"), _ptr(out), B, D, m, float(eps),
+                                           int(nstencil), R, _stream())
+    check(rc, "nsvd_fourier_features")
+    return out
+
+
+def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, ws: torch.Tensor,
+                     save_for_backward: bool = True, path: int = PATH_AUTO,
+                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Tf, f = operator(model, x, importance). Returns (f, Tf), each (B, L)."""
+    B = x.shape[0]
+    if x.dim() != 2 or x.shape[1] != shape.D:
+        raise NsvdError(f"x must be (B, {shape.D})")
+    if out is None:
+        f = torch.empty((B, shape.L), dtype=torch.float32, device=x.device)
+        Tf = torch.empty_like(f)
+    else:
+        f, Tf = out
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_forward(C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"),
+                                           _ptr(Tf, "Tf"), ws.data_ptr(), ws.numel(), int(save_for_backward),
+                                           int(path), _stream())
+    check(rc, "nsvd_operator_forward")
+    return f, Tf
+
+
+def operator_backward(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, df: torch.Tensor,
+                      grads: Params, ws: torch.Tensor, path: int = PATH_AUTO) -> None:
+    B = x.shape[0]
+    if tuple(df.shape) != (B, shape.L):
+        raise NsvdError(f"df must be {(B, shape.L)}")
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_backward(C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B,
+                                            _ptr(df, "df"), C.byref(grads), ws.data_ptr(), ws.numel(), int(path),
+                                            _stream())
+    check(rc, "nsvd_operator_backward")
+
+
+def model_forward(shape: ModelShape, params: Params, x: torch.Tensor, hard_mul_const: float,
+                  ws: torch.Tensor) -> torch.Tensor:
+    B = x.shape[0]
+    out = torch.empty((B, shape.L), dtype=torch.float32, device=x.device)
+    d = shape.desc()
+    rc = _lib.load().nsvd_model_forward(C.byref(d), C.byref(params), _ptr(x, "x"), B, float(hard_mul_const),
+                                        _ptr(out), ws.data_ptr(), ws.numel(), PATH_AUTO, _stream())
+    check(rc, "nsvd_model_forward")
+    return out
+
+
+def evd_scratch(B: int, L: int, device) -> torch.Tensor:
+    n = int(_lib.load().nsvd_evd_scratch_bytes(int(B), int(L)))
+    return torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+
+
+def evd_moments(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                moments: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """moments = [lam_f1 (L*L) | lam_f2 (L*L) | mean_b sum_l v_l f Tf]  with f1, f2 = chunk(f, 2)."""
+    B, L = f.shape
+    if moments is None:
+        moments = torch.empty(2 * L * L + 1, dtype=torch.float32, device=f.device)
+    if scratch is None:
+        scratch = evd_scratch(B, L, f.device)
+    rc = _lib.load().nsvd_evd_moments(_ptr(f, "f"), _ptr(Tf, "Tf"), B, L, int(mask_kind), _ptr(v, "v"),
+                                      _ptr(moments, "moments"), scratch.data_ptr(), _stream())
+    check(rc, "nsvd_evd_moments")
+    return moments
+
+
+def evd_loss_grad(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                  M: Optional[torch.Tensor], moments: torch.Tensor, grad_scale: float = 1.0, want_grad: bool = True,
+                  loss: Optional[torch.Tensor] = None,
+                  df: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    B, L = f.shape
+    if loss is None:
+        loss = torch.empty(3, dtype=torch.float32, device=f.device)
+    if want_grad and df is None:
+        df = torch.empty_like(f)
+    rc = _lib.load().nsvd_evd_loss_grad(_ptr(f, "f"), _ptr(Tf, "Tf"), B, L, int(mask_kind), _ptr(v, "v"),
+                                        _ptr(M, "M"), _ptr(moments, "moments"), float(grad_scale),
+                                        _ptr(loss, "loss"), _ptr(df, "df") if want_grad else None, _stream())
+    check(rc, "nsvd_evd_loss_grad")
+    return loss, (df if want_grad else None)
+
+
+def rmsprop_ema_step(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, ema: Optional[torch.Tensor], lr: float,
+                     alpha: float, eps: float, ema_decay: float, grad_scale: float = 1.0) -> None:
+    n = p.numel()
+    if grad.numel() != n or sq.numel() != n or (ema is not None and ema.numel() != n):
+        raise NsvdError("rmsprop_ema_step: size mismatch")
+    rc = _lib.load().nsvd_rmsprop_ema_step(_ptr(p, "p"), _ptr(grad, "grad"), _ptr(sq, "sq"), _ptr(ema, "ema"), n,
+                                           float(lr), float(alpha), float(eps), float(ema_decay), float(grad_scale),
+                                           _stream())
+    check(rc, "nsvd_rmsprop_ema_step")
+
+
+def spectrum_accumulate(f: torch.Tensor, Tf: torch.Tensor, x: torch.Tensor, sigma: float, use_importance: bool,
+                        lim: float, cov: torch.Tensor, quad: torch.Tensor) -> None:
+    B, L = f.shape
+    D = x.shape[1]
+    rc = _lib.load().nsvd_spectrum_accumulate(_ptr(f, "f"), _ptr(Tf, "Tf"), _ptr(x, "x"), B, L, D, float(sigma),
+                                              int(bool(use_importance)), float(lim), _ptr(cov, "cov"),
+                                              _ptr(quad, "quad"), _stream())
+    check(rc, "nsvd_spectrum_accumulate")

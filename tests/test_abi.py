@@ -1,0 +1,71 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads, and exports exactly the
+entry points include/nsvd.h declares (no compute calls - there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "nsvd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nsvd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_what_binding_binds():
+    from neural_svd_amd import _lib
+    assert _declared() == sorted(_lib.SIGNATURES.keys())
+
+
+def test_library_exports_every_declared_symbol():
+    from neural_svd_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    typed = _lib.load()
+    assert typed.nsvd_abi_version() == _lib.ABI_VERSION
+
+
+def test_host_side_queries_work_without_gpu():
+    from neural_svd_amd import hip_ops as H
+    shape = H.ModelShape(L=16, D=2, m=1024, hidden=(128, 128, 128))
+    n = H.workspace_bytes(shape, 512)
+    assert n > 0 and n % 256 == 0
+    assert H.path_name(shape, 512, H.PATH_GENERIC) == "generic"
+    bad = H.ModelShape(L=16, D=2, m=1024, hidden=(128, 7))  # fine: any widths
+    assert H.workspace_bytes(bad, 8) > 0
+
+
+def test_struct_layout_matches_header():
+    """sizeof of the three PODs as the C compiler sees them == ctypes' view."""
+    import subprocess
+    import tempfile
+    from neural_svd_amd import _lib
+    prog = r'''
+    #include <stdio.h>
+    #include "nsvd.h"
+    int main(){ printf("%zu %zu %zu\n", sizeof(nsvd_model_desc), sizeof(nsvd_params), sizeof(nsvd_problem)); return 0; }
+    '''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    assert [int(v) for v in out] == [ctypes.sizeof(_lib.ModelDesc), ctypes.sizeof(_lib.Params),
+                                     ctypes.sizeof(_lib.Problem)]
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd._lib import NsvdError
+    with pytest.raises(NsvdError):
+        H.evd_moments(torch.zeros(4, 2), torch.zeros(4, 2), H.MASK_SEQUENTIAL, None,
+                      moments=torch.zeros(9), scratch=torch.zeros(1024, dtype=torch.uint8))

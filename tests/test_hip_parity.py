@@ -1,0 +1,366 @@
+"""GPU parity tests: every C-ABI entry point vs the CPU oracle / the reference's golden vectors.
+
+Tolerances (float32 path, see DESIGN.md "Numerics"):
+  * f, moments, loss-given-(f,Tf), gradients-given-df, optimiser: <= 2e-5 relative (L2) vs float64;
+  * Tf: two correct float32 evaluations of the eps=0.01 central difference differ at the percent
+    level (the reference's own float32 Tf is 1e-3..4e-2 away from its float64 Tf), so Tf and
+    everything downstream of it is compared against the float64 truth with the float32 reference's
+    own error as yardstick: err <= max(3 * ref_err, floor).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsvd_oracle as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+H = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    global H
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from neural_svd_amd import hip_ops
+    H = hip_ops
+    yield
+
+
+DEV = "cuda:0"
+PATHS = ["generic", "auto"]
+
+
+def _path(name):
+    return H.PATH_GENERIC if name == "generic" else H.PATH_AUTO
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu().numpy()
+    b = np.asarray(torch.as_tensor(b).double().cpu().numpy())
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def to_dev(p: O.Params):
+    ws = [w.float().to(DEV).contiguous() for w in p.ws]
+    bs = [b.float().to(DEV).contiguous() for b in p.bs]
+    fB = p.fourier_B.float().to(DEV).contiguous()
+    sc = None if p.scales is None else p.scales.float().to(DEV).contiguous()
+    return ws, bs, fB, sc
+
+
+def shape_of(p: O.Params):
+    L, h0, F = p.ws[0].shape
+    hidden = tuple(w.shape[1] for w in p.ws[:-1])
+    return H.ModelShape(L=L, D=p.fourier_B.shape[0], m=F // 2, hidden=hidden, has_exp_mask=p.scales is not None)
+
+
+def hip_problem(prob: O.Problem):
+    return H.make_problem(prob.potential, prob.charge_or_k, prob.eps, prob.op_scale, prob.op_shift, prob.sigma,
+                          prob.scale_kinetic, prob.hard_mul_const, prob.use_importance)
+
+
+def run_hip(p: O.Params, prob: O.Problem, x, v, M, path, df_override=None, mask_kind=None):
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    gw = [torch.full_like(w, float("nan")) for w in ws_t]
+    gb = [torch.full_like(b, float("nan")) for b in bs_t]
+    gs = None if sc is None else torch.full_like(sc, float("nan"))
+    grads = H.pack_params(shape, gw, gb, None, gs)
+    hp = hip_problem(prob)
+    xd = x.float().to(DEV).contiguous()
+    B = xd.shape[0]
+    ws = H.new_workspace(shape, B, DEV)
+    f, Tf = H.operator_forward(shape, params, hp, xd, ws, path=path)
+    vd, Md = v.float().to(DEV), M.float().to(DEV).contiguous()
+    kind = H.MASK_CUSTOM if mask_kind is None else mask_kind
+    mom = H.evd_moments(f, Tf, kind, vd if kind == H.MASK_CUSTOM else None)
+    loss, df = H.evd_loss_grad(f, Tf, kind, vd if kind == H.MASK_CUSTOM else None,
+                               Md if kind == H.MASK_CUSTOM else None, mom)
+    dfin = df if df_override is None else df_override.float().to(DEV).contiguous()
+    H.operator_backward(shape, params, hp, xd, dfin, grads, ws, path=path)
+    torch.cuda.synchronize()
+    g = gw + gb + ([gs] if gs is not None else [])
+    return dict(f=f, Tf=Tf, loss=loss, df=df, mom=mom, grads=g, path=H.path_name(shape, B, path))
+
+
+# ------------------------------------------------------------------------------ Fourier features
+@pytest.mark.parametrize("B,D,m", [(7, 2, 5), (64, 2, 64), (33, 3, 17), (5, 1, 4)])
+def test_fourier_features(B, D, m):
+    g = torch.Generator().manual_seed(B * 100 + m)
+    x = 16 * torch.randn(B, D, generator=g)
+    fB = 2 * np.pi * 0.1 * torch.randn(D, m, generator=g)
+    E = 1 + 2 * D
+    out = H.fourier_features(x.to(DEV), fB.to(DEV), 0.01, E).cpu()
+    pts = O.stencil_points(x.double(), 0.01)
+    ref = torch.cat([O.fourier_features(p, fB.double()) for p in pts], dim=0).T  # (F, R)
+    # |phi| <= 1; float32 projections of size ~50 rad carry ~4e-6 absolute argument error
+    assert float((out.double() - ref).abs().max()) < 2e-5
+    out1 = H.fourier_features(x.to(DEV), fB.to(DEV), 0.01, 1).cpu()
+    assert torch.equal(out1, out[:, :B])
+
+
+# ------------------------------------------------------------------------------ loss kernels vs reference goldens
+@pytest.mark.parametrize("case", list("abcdef"))
+def test_evd_loss_golden(case):
+    z = G.load("evd_loss")
+    B, L, seq, step = [int(v) for v in z[f"loss_{case}_cfg"]]
+    f = torch.tensor(z[f"loss_{case}_f"]).float().to(DEV)
+    Tf = torch.tensor(z[f"loss_{case}_Tf"]).float().to(DEV)
+    v = torch.tensor(z[f"loss_{case}_v"]).float().to(DEV)
+    M = torch.tensor(z[f"loss_{case}_M"]).float().to(DEV).contiguous()
+    kinds = [H.MASK_CUSTOM]
+    if seq:
+        kinds.append(H.MASK_SEQUENTIAL)
+    elif step == 1:
+        kinds.append(H.MASK_JOINT)
+    p = f"loss_{case}_f64_"
+    for kind in kinds:
+        cust = kind == H.MASK_CUSTOM
+        mom = H.evd_moments(f, Tf, kind, v if cust else None)
+        loss, df = H.evd_loss_grad(f, Tf, kind, v if cust else None, M if cust else None, mom)
+        torch.cuda.synchronize()
+        LL = L * L
+        assert rel(mom[:LL].view(L, L), z[p + "lam1"]) < 2e-6
+        if B > 1:
+            assert rel(mom[LL:2 * LL].view(L, L), z[p + "lam2"]) < 2e-6
+        assert abs(float(loss[0]) - float(z[p + "loss"])) < 2e-5 * max(1.0, abs(float(z[p + "loss"])))
+        assert abs(float(loss[1]) + float(loss[2]) - float(loss[0])) < 1e-4 * max(1.0, abs(float(loss[0])))
+        assert rel(df, z[p + "grad_f"]) < 2e-6
+    # grad_scale and loss-only call
+    loss2, none = H.evd_loss_grad(f, Tf, H.MASK_CUSTOM, v, M, mom, want_grad=False)
+    assert none is None and float(loss2[0]) == float(loss[0])
+    _, df3 = H.evd_loss_grad(f, Tf, H.MASK_CUSTOM, v, M, mom, grad_scale=0.25)
+    assert rel(df3 * 4, z[p + "grad_f"]) < 2e-6
+
+
+def test_evd_loss_large_L_and_B():
+    g = torch.Generator().manual_seed(5)
+    B, L = 8192, 64
+    f = torch.randn(B, L, generator=g)
+    Tf = torch.randn(B, L, generator=g)
+    v, M = O.joint_nesting_masks(L, 1)
+    loss, lam1, lam2, _, _ = O.evd_loss_forward(f.double(), Tf.double(), v.double(), M.double())
+    gref = O.evd_loss_backward(f.double(), Tf.double(), v.double(), M.double(), lam1, lam2)
+    fd, Td = f.to(DEV), Tf.to(DEV)
+    mom = H.evd_moments(fd, Td, H.MASK_JOINT, None)
+    l, df = H.evd_loss_grad(fd, Td, H.MASK_JOINT, None, None, mom)
+    assert abs(float(l[0]) - float(loss)) < 1e-5 * abs(float(loss))
+    assert rel(df, gref) < 5e-6
+
+
+# ------------------------------------------------------------------------------ operator fwd/bwd on the goldens
+SMALL = ["hyd_small", "osc_small", "hyd_ragged"]
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("case", SMALL)
+def test_operator_forward_backward_small(case, path):
+    z = G.load("model_small")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p = G.params_from_golden(z, case)
+    v, M = G.masks_of(z, case)
+    x = torch.tensor(z[f"{case}_x"][0])
+    ref = O.loss_and_grads(x.double(), p.to(torch.float64), prob, v, M)
+    r = run_hip(p, prob, x, v, M, _path(path), df_override=ref["df"])
+    pre64, pre32 = f"{case}_f64_step0_", f"{case}_f32_step0_"
+    assert rel(r["f"], z[pre64 + "f"]) < 2e-5
+    tf_ref_err = rel(z[pre32 + "Tf"], z[pre64 + "Tf"])
+    assert rel(r["Tf"], z[pre64 + "Tf"]) < max(3 * tf_ref_err, 1e-3), (rel(r["Tf"], z[pre64 + "Tf"]), tf_ref_err)
+    # gradients given the SAME df (isolates the backward kernels from the FD noise in Tf)
+    names = G.trainable_names(z, case)
+    for n, g, gr in zip(names, r["grads"], ref["grads"]):
+        assert torch.isfinite(g).all(), n
+        assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, (n, rel(g.view(-1), gr.reshape(-1)))
+    # end-to-end (df from the HIP loss kernels, Tf noise included) against the reference's float64
+    r2 = run_hip(p, prob, x, v, M, _path(path))
+    loss_ref_err = abs(float(z[pre32 + "loss"]) - float(z[pre64 + "loss"])) / abs(float(z[pre64 + "loss"]))
+    assert abs(float(r2["loss"][0]) - float(z[pre64 + "loss"])) <= max(3 * loss_ref_err, 1e-3) * abs(
+        float(z[pre64 + "loss"]))
+    for n, g in zip(names, r2["grads"]):
+        g64 = z[pre64 + "grad_" + n]
+        ref_err = rel(z[pre32 + "grad_" + n], g64)
+        assert rel(g.view(-1), g64.reshape(-1)) < max(3 * ref_err, 2e-3), (n, ref_err)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("case", ["hyd_med", "cfg1"])
+def test_operator_headline_shapes(case, path):
+    """H=128x3 shapes (the fused-kernel shapes) with weights regenerated from the seed recipe."""
+    z = G.load("model_headline")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p = G.params_from_seed(cfg)
+    v, M = G.masks_of(z, case)
+    x = torch.tensor(z[f"{case}_x"][0])
+    r = run_hip(p, prob, x, v, M, _path(path))
+    pre64, pre32 = f"{case}_f64_step0_", f"{case}_f32_step0_"
+    assert rel(r["f"], z[pre64 + "f"]) < 2e-5
+    tf_ref_err = rel(z[pre32 + "Tf"], z[pre64 + "Tf"])
+    assert rel(r["Tf"], z[pre64 + "Tf"]) < max(3 * tf_ref_err, 1e-3), (rel(r["Tf"], z[pre64 + "Tf"]), tf_ref_err)
+    loss_ref_err = abs(float(z[pre32 + "loss"]) - float(z[pre64 + "loss"])) / abs(float(z[pre64 + "loss"]))
+    assert abs(float(r["loss"][0]) - float(z[pre64 + "loss"])) <= max(3 * loss_ref_err, 1e-3) * abs(
+        float(z[pre64 + "loss"]))
+    names = G.trainable_names(z, case)
+    stride = 997 if case == "hyd_med" else 9973
+    for n, g in zip(names, r["grads"]):
+        gs64 = z[pre64 + "gradsample_" + n]
+        ref_err = rel(z[pre32 + "gradsample_" + n], gs64)
+        got = g.reshape(-1)[::stride]
+        assert rel(got, gs64) < max(3 * ref_err, 2e-3), (n, rel(got, gs64), ref_err)
+        gn = float(z[pre64 + "gradnorm_" + n])
+        assert abs(float(g.double().norm()) - gn) < max(3 * ref_err, 2e-3) * gn, n
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_backward_given_df_headline(path):
+    """Backward kernels in isolation at H=128x3: same df in, float64 oracle gradients out."""
+    z = G.load("model_headline")
+    cfg = G.cfg_of(z, "hyd_med")
+    prob = G.problem_of(cfg)
+    p = G.params_from_seed(cfg)
+    v, M = G.masks_of(z, "hyd_med")
+    x = torch.tensor(z["hyd_med_x"][0])
+    ref = O.loss_and_grads(x.double(), p.to(torch.float64), prob, v, M)
+    r = run_hip(p, prob, x, v, M, _path(path), df_override=ref["df"])
+    for i, (g, gr) in enumerate(zip(r["grads"], ref["grads"])):
+        assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, (i, rel(g.view(-1), gr.reshape(-1)))
+
+
+def test_edge_cases_clamp_and_origin():
+    """sqrt(p) clamp (far-out samples), x exactly at the origin (hydrogen potential singular -> the
+    same inf/nan pattern as the oracle), B = 2 (one row per half)."""
+    L, D, m, hidden = 3, 2, 4, (8,)
+    p = O.init_params(L, D, m, hidden, 0.1, seed=11)
+    prob = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, sigma=1.0)
+    x = torch.tensor([[8.0, 7.0], [0.0, 0.0], [0.3, -0.2], [30.0, 1.0]])  # sigma=1: rows 0 and 3 hit the clamp
+    c = O.operator_forward(x.double(), p.to(torch.float64), prob)
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    ws = H.new_workspace(shape, 4, DEV)
+    f, Tf = H.operator_forward(shape, params, hip_problem(prob), x.to(DEV), ws)
+    f, Tf = f.cpu(), Tf.cpu()
+    assert rel(f[[0, 2]], c.f[[0, 2]]) < 1e-4
+    assert torch.equal(torch.isfinite(Tf), torch.isfinite(c.Tf.float()))
+    assert float(c.spc0[0]) == 1e-5  # the clamp really is active in this test
+    x2 = x[2:4].contiguous()
+    v, M = O.sequential_nesting_masks(L)
+    r = run_hip(p, O.Problem(potential=O.POT_HARMONIC, eps=0.01, sigma=4.0, op_shift=16.0), x2, v, M, H.PATH_AUTO)
+    ref = O.loss_and_grads(x2.double(), p.to(torch.float64), O.Problem(potential=O.POT_HARMONIC, eps=0.01, sigma=4.0,
+                                                                        op_shift=16.0), v, M)
+    assert rel(r["f"], ref["f"]) < 2e-5
+
+
+def test_invalid_arguments_are_rejected():
+    from neural_svd_amd._lib import NsvdError
+    shape = H.ModelShape(L=2, D=2, m=4, hidden=(8,))
+    p = O.init_params(2, 2, 4, (8,), 0.1, seed=0)
+    ws_t, bs_t, fB, _ = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, None)
+    x = torch.zeros(4, 2, device=DEV)
+    small = torch.empty(256, dtype=torch.uint8, device=DEV)
+    with pytest.raises(NsvdError):
+        H.operator_forward(shape, params, H.make_problem(0, 1.0, 0.01, 1.0, 0.0, 1.0), x, small)  # workspace too small
+    ws = H.new_workspace(shape, 4, DEV)
+    with pytest.raises(NsvdError):
+        H.operator_forward(shape, params, H.make_problem(0, 1.0, 0.0, 1.0, 0.0, 1.0), x, ws)  # eps == 0
+    with pytest.raises(NsvdError):
+        H.operator_forward(shape, params, H.make_problem(7, 1.0, 0.01, 1.0, 0.0, 1.0), x, ws)  # unknown potential
+    with pytest.raises(NsvdError):
+        H.pack_params(shape, ws_t[::-1], bs_t, fB, None)  # wrong shapes
+
+
+# ------------------------------------------------------------------------------ model forward (eigenfunction eval)
+@pytest.mark.parametrize("case", ["hyd_small", "osc_small"])
+def test_model_forward(case):
+    z = G.load("model_small")
+    cfg = G.cfg_of(z, case)
+    p = G.params_from_golden(z, case)
+    x = torch.tensor(z[f"{case}_x"][0])
+    p64 = p.to(torch.float64)
+    base = O.mlp_forward(O.fourier_features(x.double(), p64.fourier_B), p64)
+    mk = O.boundary_mask(x.double(), p64)
+    ref = base if mk is None else base * mk
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    out = H.model_forward(shape, params, x.to(DEV), 1.0, H.new_workspace(shape, x.shape[0], DEV))
+    assert rel(out, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize("n", [1, 3, 1000, 4099, 1 << 20])
+def test_rmsprop_ema(n):
+    g = torch.Generator().manual_seed(n)
+    p = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g) * 10
+    sq = torch.rand(n, generator=g)
+    em = torch.randn(n, generator=g)
+    pr, sr, er = [p.double().clone()], [sq.double().clone()], [em.double().clone()]
+    pd, gd, sd, ed = p.to(DEV), gr.to(DEV), sq.to(DEV), em.to(DEV)
+    nup = 0
+    for it in range(3):
+        lr = O.cosine_lr(1e-3, it, 10)
+        O.rmsprop_step(pr, [gr.double()], sr, lr, alpha=0.999, eps=1e-10)
+        d = min(0.995, (1 + nup + 1) / (10 + nup + 1))
+        nup = O.ema_update(er, pr, 0.995, nup)
+        H.rmsprop_ema_step(pd, gd, sd, ed, lr, 0.999, 1e-10, d)
+    torch.cuda.synchronize()
+    assert rel(pd, pr[0]) < 1e-6 and rel(sd, sr[0]) < 1e-6 and rel(ed, er[0]) < 1e-6
+    # no-EMA variant and grad_scale
+    p2 = p.to(DEV)
+    s2 = sq.to(DEV)
+    H.rmsprop_ema_step(p2, gd * 4, s2, None, 1e-3, 0.999, 1e-10, 0.0, grad_scale=0.25)
+    p3, s3 = [p.double().clone()], [sq.double().clone()]
+    O.rmsprop_step(p3, [gr.double()], s3, 1e-3)
+    assert rel(p2, p3[0]) < 1e-6
+
+
+def test_rmsprop_golden_two_steps():
+    """the reference's own RMSprop + cosine schedule trajectory (float32 golden)."""
+    z = G.load("model_small")
+    case = "hyd_small"
+    cfg = G.cfg_of(z, case)
+    names = G.trainable_names(z, case)
+    for n in names:
+        p = torch.tensor(z[f"{case}_param0_{n}"]).float().to(DEV).contiguous()
+        sq = torch.zeros_like(p)
+        for it in range(2):
+            g = torch.tensor(z[f"{case}_f32_step{it}_grad_{n}"]).float().to(DEV).contiguous()
+            H.rmsprop_ema_step(p.view(-1), g.view(-1), sq.view(-1), None, O.cosine_lr(cfg["lr"], it, cfg["num_iters"]),
+                               cfg["rmsprop_decay"], 1e-10, 0.0)
+            assert rel(p, z[f"{case}_f32_step{it}_param_{n}"]) < 1e-6, (n, it)
+
+
+# ------------------------------------------------------------------------------ spectrum
+@pytest.mark.parametrize("case", SMALL)
+def test_spectrum_matches_reference(case):
+    z = G.load("model_small")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p = G.params_from_golden(z, case, prefix="f64_step1_param_")
+    grid = torch.tensor(z[f"{case}_val_data"])
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    L = shape.L
+    cov = torch.zeros(L, L, device=DEV)
+    quad = torch.zeros(L, L, device=DEV)
+    chunk = 150  # ragged chunks on purpose
+    for i in range(0, grid.shape[0], chunk):
+        xb = grid[i:i + chunk].to(DEV).contiguous()
+        ws = H.new_workspace(shape, xb.shape[0], DEV)
+        f, Tf = H.operator_forward(shape, params, hip_problem(prob), xb, ws, save_for_backward=False)
+        H.spectrum_accumulate(f, Tf, xb, prob.sigma, True, cfg["lim"], cov, quad)
+    n = grid.shape[0]
+    cov, quad = cov.cpu().double() / n, quad.cpu().double() / n
+    eig = torch.diag(quad) / torch.diag(cov)
+    assert rel(torch.diag(cov), z[f"{case}_f64_spec_norms"]) < 1e-4
+    e64, e32 = z[f"{case}_f64_spec_eigvals"], z[f"{case}_f32_spec_eigvals"]
+    ref_err = float(np.max(np.abs(e32 - e64) / np.abs(e64)))
+    got_err = float(np.max(np.abs(eig.numpy() - e64) / np.abs(e64)))
+    assert got_err < max(3 * ref_err, 1e-4), (got_err, ref_err)
