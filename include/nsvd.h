@@ -157,9 +157,10 @@ int nsvd_evd_loss_grad(const float* f, const float* Tf, int B, int L, int mask_k
  *   g = grad_scale * grad; sq = alpha sq + (1-alpha) g^2; p -= lr g / (sqrt(sq) + eps);
  *   ema -= (1 - ema_decay) (ema - p)        (skipped when ema == NULL)
  * over n contiguous floats. lr is the already-scheduled learning rate, ema_decay the already
- * warmed-up decay min(decay, (1+t)/(10+t)). */
-int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, size_t n, float lr,
-                          float alpha, float eps, float ema_decay, float grad_scale, void* stream);
+ * warmed-up decay min(decay, (1+t)/(10+t)). Host scalars are doubles (Python floats) and are rounded
+ * to float32 exactly where torch rounds them: alpha, (1 - alpha), lr, eps, (1 - ema_decay). */
+int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, size_t n, double lr,
+                          double alpha, double eps, double ema_decay, double grad_scale, void* stream);
 
 /* compute_spectrum_evd accumulation for one chunk (methods/spectrum.py:56-75):
  *   w = sqrt(p_train(x)) / sqrt(p_val), phi = nan_to_num(w f), Tphi = nan_to_num(w Tf),
@@ -168,6 +169,12 @@ int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, si
 int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, int B, int L, int D,
                              float sigma, int use_importance, float lim, float* cov, float* quad,
                              void* stream);
+
+/* Measurement aid (bench.py): record the two hipEvent_t handles immediately before / after the
+ * DOMINANT kernel of the next nsvd_operator_forward call made by this host thread (the fused MFMA
+ * forward kernel, or the layer-0 GEMM on the generic path), on that call's stream. One-shot;
+ * pass NULLs to clear. Per-thread state; the compute entry points themselves stay stateless. */
+int nsvd_profile_next_forward(void* ev_start, void* ev_stop);
 
 #ifdef __cplusplus
 }

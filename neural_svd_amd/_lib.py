@@ -40,7 +40,7 @@ class Problem(C.Structure):
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/nsvd.h
-_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_P, _I, _F, _Z, _Dbl = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
 SIGNATURES = {
     "nsvd_abi_version": (_I, []),
     "nsvd_path_name": (C.c_char_p, [C.POINTER(ModelDesc), _I, _I]),
@@ -54,7 +54,8 @@ SIGNATURES = {
     "nsvd_evd_scratch_bytes": (_Z, [_I, _I]),
     "nsvd_evd_moments": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "nsvd_evd_loss_grad": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P]),
-    "nsvd_rmsprop_ema_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _P]),
+    "nsvd_rmsprop_ema_step": (_I, [_P, _P, _P, _P, _Z, _Dbl, _Dbl, _Dbl, _Dbl, _Dbl, _P]),
+    "nsvd_profile_next_forward": (_I, [_P, _P]),
     "nsvd_spectrum_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
 }
 

@@ -2,6 +2,10 @@
 #pragma once
 #include "nsvd_common.h"
 
+// ---- measurement hook (operator_api.hip): bracket the dominant forward kernel with events ----------
+void nsvd_prof_begin(hipStream_t s);
+void nsvd_prof_end(hipStream_t s);
+
 // ---- generic strided batched GEMM (gemm_generic.hip) -------------------------------------------
 //   C[g][i][j] = epi( sum_k A[g][i*sAm + k*sAk] * pro(B[g][k*sBk + j*sBn]) + bias[g][i] )
 // pro: optional softplus on B elements; epi: optional multiply by sigmoid(Z[g][i*sZm + j]).

@@ -4,6 +4,24 @@
 #include <string.h>
 #include "nsvd_kernels.h"
 
+static thread_local hipEvent_t g_prof_start = nullptr;
+static thread_local hipEvent_t g_prof_stop = nullptr;
+
+void nsvd_prof_begin(hipStream_t s) {
+    if (g_prof_start) (void)hipEventRecord(g_prof_start, s);
+    g_prof_start = nullptr;
+}
+void nsvd_prof_end(hipStream_t s) {
+    if (g_prof_stop) (void)hipEventRecord(g_prof_stop, s);
+    g_prof_stop = nullptr;
+}
+
+extern "C" int nsvd_profile_next_forward(void* ev_start, void* ev_stop) {
+    g_prof_start = (hipEvent_t)ev_start;
+    g_prof_stop = (hipEvent_t)ev_stop;
+    return 0;
+}
+
 namespace {
 
 struct GenericWs {
@@ -81,7 +99,9 @@ int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, 
         g.C = w.z[i]; g.sCm = R; g.bC = (long)d.dims[i] * R;
         g.bias = p.b[i]; g.bBias = d.dims[i];
         g.softplus_b = (i > 0);
+        if (i == 0 && nst > 1) nsvd_prof_begin(s);
         rc = nsvd_gemm_generic(g, s);
+        if (i == 0 && nst > 1) nsvd_prof_end(s);
         if (rc) return rc;
         kin = d.dims[i];
     }

@@ -7,10 +7,14 @@
 
 namespace {
 
-__device__ __forceinline__ void upd(float& p, float g, float& sq, float* ema, float lr, float alpha, float eps,
-                                    float one_minus_decay, float gs) {
-    g *= gs;
-    sq = alpha * sq + (1.f - alpha) * g * g;   // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
+struct Hyper {
+    float lr, alpha, one_minus_alpha, eps, one_minus_decay, grad_scale;
+};
+
+__device__ __forceinline__ void upd(float& p, float g, float& sq, float* ema, const Hyper& h) {
+    const float lr = h.lr, eps = h.eps, one_minus_decay = h.one_minus_decay;
+    g *= h.grad_scale;
+    sq = h.alpha * sq + h.one_minus_alpha * (g * g);  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
     const float avg = sqrtf(sq) + eps;         // square_avg.sqrt().add_(eps)
     p = p - lr * (g / avg);                    // param.addcdiv_(g, avg, value=-lr)
     if (ema) *ema = *ema - one_minus_decay * (*ema - p);
@@ -19,18 +23,17 @@ __device__ __forceinline__ void upd(float& p, float g, float& sq, float* ema, fl
 template <bool HAS_EMA>
 __global__ void __launch_bounds__(256) rmsprop_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ sq, float* __restrict__ ema, size_t n4,
-                                                          size_t n, float lr, float alpha, float eps, float omd,
-                                                          float gs) {
+                                                          size_t n, Hyper h) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
         float4 sv = reinterpret_cast<float4*>(sq)[i];
         float4 ev = HAS_EMA ? reinterpret_cast<float4*>(ema)[i] : make_float4(0, 0, 0, 0);
-        upd(pv.x, gv.x, sv.x, HAS_EMA ? &ev.x : nullptr, lr, alpha, eps, omd, gs);
-        upd(pv.y, gv.y, sv.y, HAS_EMA ? &ev.y : nullptr, lr, alpha, eps, omd, gs);
-        upd(pv.z, gv.z, sv.z, HAS_EMA ? &ev.z : nullptr, lr, alpha, eps, omd, gs);
-        upd(pv.w, gv.w, sv.w, HAS_EMA ? &ev.w : nullptr, lr, alpha, eps, omd, gs);
+        upd(pv.x, gv.x, sv.x, HAS_EMA ? &ev.x : nullptr, h);
+        upd(pv.y, gv.y, sv.y, HAS_EMA ? &ev.y : nullptr, h);
+        upd(pv.z, gv.z, sv.z, HAS_EMA ? &ev.z : nullptr, h);
+        upd(pv.w, gv.w, sv.w, HAS_EMA ? &ev.w : nullptr, h);
         reinterpret_cast<float4*>(p)[i] = pv;
         reinterpret_cast<float4*>(sq)[i] = sv;
         if (HAS_EMA) reinterpret_cast<float4*>(ema)[i] = ev;
@@ -38,7 +41,7 @@ __global__ void __launch_bounds__(256) rmsprop_ema_kernel(float* __restrict__ p,
     // tail (n not a multiple of 4, or unaligned buffers: n4 == 0 and everything goes through here)
     for (size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
         float pv = p[t], sv = sq[t], ev = HAS_EMA ? ema[t] : 0.f;
-        upd(pv, g[t], sv, HAS_EMA ? &ev : nullptr, lr, alpha, eps, omd, gs);
+        upd(pv, g[t], sv, HAS_EMA ? &ev : nullptr, h);
         p[t] = pv;
         sq[t] = sv;
         if (HAS_EMA) ema[t] = ev;
@@ -47,21 +50,28 @@ __global__ void __launch_bounds__(256) rmsprop_ema_kernel(float* __restrict__ p,
 
 }  // namespace
 
-extern "C" int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, size_t n, float lr,
-                                     float alpha, float eps, float ema_decay, float grad_scale, void* stream) {
+extern "C" int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, size_t n, double lr,
+                                     double alpha, double eps, double ema_decay, double grad_scale,
+                                     void* stream) {
     if (!p || !grad || !sq) return NSVD_EINVAL;
     if (n == 0) return 0;
     const uintptr_t al = (uintptr_t)p | (uintptr_t)grad | (uintptr_t)sq | (uintptr_t)ema;
     const size_t n4 = (al & 15) ? 0 : n / 4;  // unaligned (never with torch allocations): scalar path
-    const float omd = 1.f - ema_decay;
+    Hyper h;
+    h.lr = (float)lr;
+    h.alpha = (float)alpha;
+    h.one_minus_alpha = (float)(1.0 - alpha);
+    h.eps = (float)eps;
+    h.one_minus_decay = (float)(1.0 - ema_decay);
+    h.grad_scale = (float)grad_scale;
     hipStream_t s = (hipStream_t)stream;
     const size_t work = n4 ? n4 : n;
     size_t blocks = (work + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (ema) hipLaunchKernelGGL(rmsprop_ema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p, grad, sq, ema,
-                                n4, n, lr, alpha, eps, omd, grad_scale);
+                                n4, n, h);
     else hipLaunchKernelGGL(rmsprop_ema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p, grad, sq,
-                            (float*)nullptr, n4, n, lr, alpha, eps, omd, grad_scale);
+                            (float*)nullptr, n4, n, h);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

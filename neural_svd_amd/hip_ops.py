@@ -237,3 +237,15 @@ def spectrum_accumulate(f: torch.Tensor, Tf: torch.Tensor, x: torch.Tensor, sigm
                                               int(bool(use_importance)), float(lim), _ptr(cov, "cov"),
                                               _ptr(quad, "quad"), _stream())
     check(rc, "nsvd_spectrum_accumulate")
+
+
+def profile_next_forward(ev_start: "torch.cuda.Event", ev_stop: "torch.cuda.Event") -> None:
+    """Bracket the dominant kernel of the next operator_forward with two timing events (bench.py)."""
+    for e in (ev_start, ev_stop):
+        if e.cuda_event == 0:  # torch creates the hipEvent lazily, at the first record
+            e.record()
+    check(_lib.load().nsvd_profile_next_forward(ev_start.cuda_event, ev_stop.cuda_event), "nsvd_profile_next_forward")
+
+
+def dominant_kernel_name(shape: ModelShape, B: int, path: int = PATH_AUTO) -> str:
+    return "pmlp_fused_fwd_kernel" if path_name(shape, B, path).startswith("fused") else "gemm_generic_kernel[layer0]"

@@ -1,0 +1,194 @@
+"""Drop-in surface of the reference's ``methods/`` package for the NestedLoRA (NeuralSVD) path,
+backed by the HIP C ABI.  Same names, argument meaning and return values as the reference:
+
+    get_evd_method(args, 'neuralsvd', model)                     methods/general.py:7-39
+    NestedLoRA(model, neigs, step, sort, sequential)             methods/nestedlora.py:167-267
+    NestedLoRALossFunctionEVD.apply(f, Tf, f1, f2, vmask, mmask) methods/nestedlora.py:67-111
+    get_sequential_nesting_masks / get_joint_nesting_masks       methods/nestedlora.py:40-54
+
+``compute_loss_operator(operator, x, importance)`` takes the fused HIP path when ``operator`` is
+this package's OperatorWrapper(NegativeHamiltonian) and ``self.model`` its WaveFunctions; anything
+else is refused loudly (there is no eager fallback).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip_ops as H
+from ._lib import NsvdError
+
+
+# ------------------------------------------------------------------------------------- masks
+def get_sequential_nesting_masks(L: int, set_first_mode_const: bool = False):
+    if set_first_mode_const:
+        L += 1
+    return torch.ones(L), torch.triu(torch.ones(L, L))
+
+
+def get_joint_nesting_masks(weights: np.ndarray, set_first_mode_const: bool = False):
+    """weights: per-index step weights (sum 1); v = reverse cumulative sum, M = min(v_i, v_j)."""
+    tail = np.cumsum(np.asarray(weights, dtype=np.float64)[::-1])[::-1]
+    v = list(tail)
+    if set_first_mode_const:
+        v = [v[0]] + v
+    v = torch.tensor(np.array(v)).float()
+    return v, torch.minimum(v.view(-1, 1), v.view(1, -1)).float()
+
+
+def joint_step_weights(neigs: int, step: int) -> np.ndarray:
+    """weight 1/#ends on every step-th index and on the last one (methods/nestedlora.py:185-190)."""
+    ends = list(range(step, neigs + 1, step))
+    if neigs not in ends:
+        ends.append(neigs)
+    w = np.zeros(neigs)
+    w[np.array(ends) - 1] = 1.0
+    return w / w.sum()
+
+
+def nesting_masks(neigs: int, sequential: bool, step: int = 1):
+    """-> (vector_mask, matrix_mask, mask_kind for the kernels)."""
+    if sequential:
+        v, M = get_sequential_nesting_masks(neigs)
+        return v, M, H.MASK_SEQUENTIAL
+    v, M = get_joint_nesting_masks(joint_step_weights(neigs, step))
+    # step-1 joint masks are regenerated in registers; they must agree bit for bit with the table
+    gen = (torch.arange(neigs, 0, -1, dtype=torch.float32) / float(neigs))
+    kind = H.MASK_JOINT if (step == 1 and torch.equal(gen, v)) else H.MASK_CUSTOM
+    return v, M, kind
+
+
+def _is_chunk_of(f: torch.Tensor, f1: torch.Tensor, f2: torch.Tensor) -> bool:
+    if f.dim() != 2 or f1.dim() != 2 or f2.dim() != 2 or not f.is_contiguous():
+        return False
+    B, L = f.shape
+    B1 = (B + 1) // 2
+    return (f1.shape == (B1, L) and f2.shape == (B - B1, L) and f1.data_ptr() == f.data_ptr()
+            and (f2.numel() == 0 or f2.data_ptr() == f.data_ptr() + B1 * L * f.element_size())
+            and f1.is_contiguous() and f2.is_contiguous())
+
+
+def _mask_kind(vector_mask: torch.Tensor, matrix_mask: torch.Tensor) -> int:
+    L = vector_mask.numel()
+    v, M = vector_mask.detach().float().cpu(), matrix_mask.detach().float().cpu()
+    if torch.equal(v, torch.ones(L)) and torch.equal(M, torch.triu(torch.ones(L, L))):
+        return H.MASK_SEQUENTIAL
+    gen = torch.arange(L, 0, -1, dtype=torch.float32) / float(L)
+    if torch.equal(v, gen) and torch.equal(M, torch.minimum(gen.view(-1, 1), gen.view(1, -1))):
+        return H.MASK_JOINT
+    return H.MASK_CUSTOM
+
+
+class NestedLoRALossFunctionEVD(torch.autograd.Function):
+    """loss = -2 mean_b sum_l v_l f_bl Tf_bl + sum(M * lam_f1 * lam_f2); gradients to f, f1, f2 only
+    (Tf gets none: the operator is assumed self-adjoint, reference :108-111)."""
+
+    @staticmethod
+    def forward(ctx, f, Tf, f1, f2, vector_mask, matrix_mask):
+        if not _is_chunk_of(f, f1, f2):
+            raise NsvdError("NestedLoRALossFunctionEVD (HIP): f1, f2 must be torch.chunk(f, 2) of a contiguous "
+                            "(B, L) f; independent f1/f2 (compute_loss_kernel split_batch) is not on this path")
+        kind = _mask_kind(vector_mask, matrix_mask)
+        dev = f.device
+        v = vector_mask.to(dev).float().contiguous() if kind == H.MASK_CUSTOM else None
+        M = matrix_mask.to(dev).float().contiguous() if kind == H.MASK_CUSTOM else None
+        fd, Tfd = f.detach(), Tf.detach().contiguous()
+        moments = H.evd_moments(fd, Tfd, kind, v)
+        loss, _ = H.evd_loss_grad(fd, Tfd, kind, v, M, moments, want_grad=False)
+        ctx.kind, ctx.v, ctx.M = kind, v, M
+        ctx.save_for_backward(fd, Tfd, moments)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        fd, Tfd, moments = ctx.saved_tensors
+        _, df = H.evd_loss_grad(fd, Tfd, ctx.kind, ctx.v, ctx.M, moments, 1.0, True)
+        df = df * grad_output
+        # the f1 / f2 contributions are already summed into df (they are views of f)
+        return df, None, None, None, None, None
+
+
+class _OperatorFn(torch.autograd.Function):
+    """(Tf, f) = operator(model, x, importance) through nsvd_operator_forward; the backward is
+    nsvd_operator_backward (gradient through f only)."""
+
+    @staticmethod
+    def forward(ctx, x, method, operator, prob, *params):
+        model = method.model
+        shape = model.shape
+        packed = model.packed_params()
+        ws = H.new_workspace(shape, x.shape[0], x.device)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        f, Tf = H.operator_forward(shape, packed, prob, x, ws, save_for_backward=need_grad, path=method.path)
+        ctx.model, ctx.prob, ctx.path = model, prob, method.path
+        ctx.ws = ws if need_grad else None
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(Tf)
+        return Tf, f
+
+    @staticmethod
+    def backward(ctx, dTf, df):
+        (x,) = ctx.saved_tensors
+        model = ctx.model
+        grads = model.grad_buffers()
+        H.operator_backward(model.shape, model.packed_params(), ctx.prob, x, df.contiguous(), grads.packed, ctx.ws,
+                            ctx.path)
+        return (None, None, None, None) + tuple(grads.tensors)
+
+
+class NestedLoRA(nn.Module):
+    def __init__(self, model, neigs, step=1, sort=False, sequential=False, path: int = H.PATH_AUTO):
+        self.name = "nestedlora"
+        super().__init__()
+        self.neigs, self.sort, self.sequential = neigs, sort, sequential
+        self.eigvals = None
+        self.sort_indices = None
+        self.vector_mask, self.matrix_mask, _ = nesting_masks(neigs, bool(sequential), step)
+        self.model = model
+        self.path = path
+
+    def forward(self, *args):
+        out = self.model(*args)
+        if self.sort_indices is not None and self.training:
+            return out[:, self.sort_indices, ...]
+        return out
+
+    def register_eigvals(self, eigvals):
+        self.eigvals = torch.Tensor(eigvals)
+        self.sort_indices = torch.sort(self.eigvals)[1].flip(0)
+
+    def reset_eigvals(self):
+        self.eigvals = None
+        self.sort_indices = None
+
+    def _compute_loss(self, *args, evd=True) -> torch.Tensor:
+        if not evd:
+            raise NotImplementedError("the SVD loss has no caller in the reference and is not on this path")
+        return NestedLoRALossFunctionEVD.apply(*args, self.vector_mask, self.matrix_mask)
+
+    def compute_loss_operator(self, operator, x, importance=None, evd: bool = True):
+        if not evd:
+            raise NotImplementedError
+        Tf, f = self.apply_operator(operator, x, importance)
+        f1, f2 = torch.chunk(f, 2)
+        loss = self._compute_loss(f, Tf, f1, f2, evd=True)
+        return loss, dict(f=f, Tf=Tf, eigvals=None)
+
+    def apply_operator(self, operator, x, importance=None):
+        """Tf, f = operator(self, x, importance) on the HIP path."""
+        from .operators import fused_problem_of
+        prob = fused_problem_of(operator, importance, self.model)
+        if self.sort_indices is not None and self.training:
+            raise NsvdError("register_eigvals() column permutation is not supported on the HIP path")
+        x = x.reshape(x.shape[0], -1).float().contiguous()
+        return _OperatorFn.apply(x, self, operator, prob, *self.model.trainable_tensors())
+
+
+def get_evd_method(args, method_name, model):
+    if method_name != "neuralsvd":
+        raise NotImplementedError(f"{method_name}: only 'neuralsvd' (NestedLoRA) is built on this path")
+    return NestedLoRA(model=model, neigs=args.neigs, step=args.loss.neuralsvd.step, sort=args.sort,
+                      sequential=args.loss.neuralsvd.sequential)

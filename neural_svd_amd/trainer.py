@@ -1,0 +1,192 @@
+"""The NestedLoRA PDE training step as ONE object: sample -> operator forward -> EVD loss -> backward
+-> RMSprop (+ cosine LR) -> EMA, every stage a HIP kernel launch on the current stream.
+
+Mirrors the body of the reference's ``train_operator`` loop (examples/operator/__init__.py:55-74)
+with the optimiser of examples/utils.py:50-57 and the sampler of main_pde.py:92-93; parameters,
+gradients and optimiser state live in flat float32 buffers (one RCCL all-reduce per step covers
+every gradient) with per-tensor views in the reference's state_dict layout.
+
+Data parallel (one process per GPU): each rank draws its own B rows; the (2 L^2 + 1)-float moment
+vector and the flat gradient are all-reduced (mean). See parallel.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hip_ops as H
+
+
+def cosine_lr(base_lr: float, t: int, T: int, eta_min: float = 0.0) -> float:
+    """torch.optim.lr_scheduler.CosineAnnealingLR after t scheduler steps (closed form)."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * t / T)) / 2.0
+
+
+def reference_init(shape: H.ModelShape, fourier_scale: float, exp_mask_init: Optional[float], seed: Optional[int]):
+    """Draw weights on the CPU generator in the reference's order (Fourier _B, then W_i; b_i = 0) so
+    that ``seed`` reproduces the reference's initial weights bit for bit
+    (examples/utils.py:116-119, examples/models/mlp.py:185-189, pde/boundary.py:43)."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    fB = 2 * torch.pi * fourier_scale * torch.randn((shape.D, shape.m)).float()
+    ws, bs, prev = [], [], 2 * shape.m
+    for h in shape.dims:
+        ws.append(math.sqrt(2.0 / prev) * torch.randn(shape.L, h, prev))
+        bs.append(torch.zeros(shape.L, h, 1))
+        prev = h
+    scales = exp_mask_init * torch.ones(shape.L) if shape.has_exp_mask else None
+    return fB, ws, bs, scales
+
+
+class FlatParams:
+    """All trainable tensors of one model in one contiguous float32 buffer (+ same-layout gradient,
+    RMSprop square-average and EMA shadow buffers). Names follow the reference's state_dict:
+    model.base.ws.{i}, model.base.bs.{i}, model.boundary_mask.scales, model.base.feature_map._B."""
+
+    def __init__(self, shape: H.ModelShape, device, with_state: bool = True):
+        self.shape = shape
+        self.device = torch.device(device)
+        shapes = shape.param_shapes()
+        # every tensor starts on a 256-B boundary so kernels may use 16-B accesses per tensor
+        self.offsets, off = [], 0
+        for s in shapes:
+            self.offsets.append(off)
+            n = 1
+            for d in s:
+                n *= d
+            off += (n + 63) // 64 * 64
+        self.numel = off
+        self.n_trainable = sum(math.prod(s) for s in shapes)
+        self.shapes = shapes
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.sq = torch.zeros_like(self.flat) if with_state else None
+        self.ema = torch.zeros_like(self.flat) if with_state else None
+        self.fourier_B = torch.zeros((shape.D, shape.m), dtype=torch.float32, device=self.device)
+        nl = len(shape.dims)
+        self.names = [f"model.base.ws.{i}" for i in range(nl)] + [f"model.base.bs.{i}" for i in range(nl)]
+        if shape.has_exp_mask:
+            self.names.append("model.boundary_mask.scales")
+
+    def views(self, buf: torch.Tensor) -> List[torch.Tensor]:
+        return [buf[o:o + math.prod(s)].view(s) for o, s in zip(self.offsets, self.shapes)]
+
+    def pack(self, buf: torch.Tensor, with_fourier: bool) -> H.Params:
+        v = self.views(buf)
+        nl = len(self.shape.dims)
+        return H.pack_params(self.shape, v[:nl], v[nl:2 * nl], self.fourier_B if with_fourier else None,
+                             v[2 * nl] if self.shape.has_exp_mask else None)
+
+    def load(self, fB, ws, bs, scales=None) -> None:
+        self.fourier_B.copy_(fB)
+        tensors = list(ws) + list(bs) + ([scales] if self.shape.has_exp_mask else [])
+        for dst, src in zip(self.views(self.flat), tensors):
+            dst.copy_(src.reshape(dst.shape))
+        if self.ema is not None:
+            self.ema.copy_(self.flat)  # torch_ema: shadow = clone of the parameters at construction
+
+    def state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
+        src = self.ema if ema else self.flat
+        d = {n: t.clone() for n, t in zip(self.names, self.views(src))}
+        d["model.base.feature_map._B"] = self.fourier_B.clone()
+        return d
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        for n, t in zip(self.names, self.views(self.flat)):
+            t.copy_(sd[n].reshape(t.shape))
+        self.fourier_B.copy_(sd["model.base.feature_map._B"])
+
+
+class FusedTrainer:
+    def __init__(self, shape: H.ModelShape, problem: H.Problem, batch_size: int, sequential: bool, step: int = 1,
+                 lr: float = 1e-4, rmsprop_decay: float = 0.999, rmsprop_eps: float = 1e-10, ema_decay: float = 0.995,
+                 num_iters: int = 500000, use_lr_scheduler: bool = True, sampling_scale: float = 16.0,
+                 fourier_scale: float = 0.1, exp_mask_init: Optional[float] = None, seed: Optional[int] = 0,
+                 device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None):
+        self.shape, self.problem, self.B = shape, problem, int(batch_size)
+        self.device = torch.device(device)
+        self.path = path
+        self.comm = comm  # parallel.Communicator or None
+        self.lr, self.alpha, self.eps = lr, rmsprop_decay, rmsprop_eps
+        self.ema_decay, self.num_iters, self.use_sched = ema_decay, num_iters, use_lr_scheduler
+        self.sigma = sampling_scale
+        self.P = FlatParams(shape, self.device)
+        self.P.load(*reference_init(shape, fourier_scale, exp_mask_init, seed))
+        self._params = self.P.pack(self.P.flat, True)
+        self._grads = self.P.pack(self.P.grad, False)
+        self._ema_params = self.P.pack(self.P.ema, True)
+        # nesting masks (methods/nestedlora.py:183-192)
+        from .nested_lowrank import nesting_masks
+        self.vector_mask, self.matrix_mask, self.mask_kind = nesting_masks(shape.L, sequential, step)
+        self.v_dev = self.vector_mask.to(self.device)
+        self.M_dev = self.matrix_mask.to(self.device).contiguous()
+        L = shape.L
+        self.ws = H.new_workspace(shape, self.B, self.device)
+        self.f = torch.empty((self.B, L), dtype=torch.float32, device=self.device)
+        self.Tf = torch.empty_like(self.f)
+        self.df = torch.empty_like(self.f)
+        self.moments = torch.empty(2 * L * L + 1, dtype=torch.float32, device=self.device)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.scratch = H.evd_scratch(self.B, L, self.device)
+        self.x = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device)
+        self.gen = torch.Generator(device=self.device)
+        rank = comm.rank if comm is not None else 0
+        self.gen.manual_seed((sample_seed if sample_seed is not None else (seed or 0)) * 1000003 + 7919 * rank + 1)
+        self.t = 0            # optimiser / scheduler steps taken
+        self.num_updates = 0  # torch_ema counter
+
+    # -- stages -------------------------------------------------------------------------------
+    def sample(self) -> torch.Tensor:
+        """x = sigma * randn(B, D) on the device (reference: host randn + H2D copy, main_pde.py:92-93)."""
+        torch.randn(self.x.shape, generator=self.gen, out=self.x, device=self.device)
+        self.x.mul_(self.sigma)
+        return self.x
+
+    def forward_backward(self, x: torch.Tensor) -> None:
+        H.operator_forward(self.shape, self._params, self.problem, x, self.ws, True, self.path, out=(self.f, self.Tf))
+        cust = self.mask_kind == H.MASK_CUSTOM
+        H.evd_moments(self.f, self.Tf, self.mask_kind, self.v_dev if cust else None, self.moments, self.scratch)
+        if self.comm is not None and self.comm.world > 1:
+            self.comm.all_reduce_mean(self.moments)
+        H.evd_loss_grad(self.f, self.Tf, self.mask_kind, self.v_dev if cust else None, self.M_dev if cust else None,
+                        self.moments, 1.0, True, self.loss, self.df)
+        H.operator_backward(self.shape, self._params, self.problem, x, self.df, self._grads, self.ws, self.path)
+
+    def optimizer_step(self) -> None:
+        gscale = 1.0
+        if self.comm is not None and self.comm.world > 1:
+            self.comm.all_reduce_sum(self.P.grad)
+            gscale = 1.0 / self.comm.world
+        lr = cosine_lr(self.lr, self.t, self.num_iters) if self.use_sched else self.lr
+        self.num_updates += 1
+        decay = min(self.ema_decay, (1 + self.num_updates) / (10 + self.num_updates))
+        H.rmsprop_ema_step(self.P.flat, self.P.grad, self.P.sq, self.P.ema, lr, self.alpha, self.eps, decay, gscale)
+        self.t += 1
+
+    def step(self, x: Optional[torch.Tensor] = None) -> None:
+        if x is None:
+            x = self.sample()
+        self.forward_backward(x)
+        self.optimizer_step()
+
+    # -- evaluation (methods/spectrum.py:29-102 under EMA weights, operator/__init__.py:108) ----
+    @torch.no_grad()
+    def spectrum(self, lim: float, val_eps: float, use_ema: bool = True, chunk: int = 16384):
+        import numpy as np
+        D, L = self.shape.D, self.shape.L
+        ax = np.arange(-lim, lim, val_eps)
+        xxs = np.meshgrid(*(D * [ax]))
+        grid = torch.tensor(np.array(list(zip(*[xx.flatten() for xx in xxs])))).float().to(self.device)
+        params = self._ema_params if use_ema else self._params
+        cov = torch.zeros((L, L), dtype=torch.float32, device=self.device)
+        quad = torch.zeros_like(cov)
+        for i in range(0, grid.shape[0], chunk):
+            xb = grid[i:i + chunk].contiguous()
+            ws = H.new_workspace(self.shape, xb.shape[0], self.device)
+            f, Tf = H.operator_forward(self.shape, params, self.problem, xb, ws, False, self.path)
+            H.spectrum_accumulate(f, Tf, xb, self.problem.sigma, bool(self.problem.use_importance), lim, cov, quad)
+        n = grid.shape[0]
+        cov, quad = cov.double().cpu() / n, quad.double().cpu() / n
+        return dict(cov=cov, quad=quad, eigvals=torch.diag(quad) / torch.diag(cov), norms=torch.diag(cov))

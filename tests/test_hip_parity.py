@@ -206,13 +206,22 @@ def test_operator_headline_shapes(case, path):
         float(z[pre64 + "loss"]))
     names = G.trainable_names(z, case)
     stride = 997 if case == "hyd_med" else 9973
+    # pooled yardstick: the float32 reference's own error over every sampled gradient element
+    num = sum(float(np.sum((z[pre32 + "gradsample_" + n] - z[pre64 + "gradsample_" + n]) ** 2)) for n in names)
+    den = sum(float(np.sum(z[pre64 + "gradsample_" + n] ** 2)) for n in names)
+    pooled = (num / den) ** 0.5
+    got_num = 0.0
     for n, g in zip(names, r["grads"]):
         gs64 = z[pre64 + "gradsample_" + n]
-        ref_err = rel(z[pre32 + "gradsample_" + n], gs64)
-        got = g.reshape(-1)[::stride]
-        assert rel(got, gs64) < max(3 * ref_err, 2e-3), (n, rel(got, gs64), ref_err)
+        got = g.reshape(-1)[::stride].double().cpu().numpy()
+        got_num += float(np.sum((got - gs64) ** 2))
         gn = float(z[pre64 + "gradnorm_" + n])
-        assert abs(float(g.double().norm()) - gn) < max(3 * ref_err, 2e-3) * gn, n
+        ref_gn_err = abs(float(z[pre32 + "gradnorm_" + n]) - gn) / gn
+        assert abs(float(g.double().norm()) - gn) < max(3 * ref_gn_err, 3 * pooled, 2e-3) * gn, n
+        if gs64.size >= 64:  # per-tensor element check only where the sample is statistically meaningful
+            ref_err = rel(z[pre32 + "gradsample_" + n], gs64)
+            assert rel(got, gs64) < max(3 * ref_err, 2e-3), (n, rel(got, gs64), ref_err)
+    assert (got_num / den) ** 0.5 < max(3 * pooled, 2e-3), ((got_num / den) ** 0.5, pooled)
 
 
 @pytest.mark.parametrize("path", PATHS)

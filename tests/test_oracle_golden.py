@@ -167,3 +167,32 @@ def test_ema_formula():
     n = 0
     n = O.ema_update(s, p, 0.995, n)
     assert n == 1 and torch.allclose(s[0], torch.full((3,), 1 - 2 / 11))
+
+
+# ------------------------------------------------------------------ the eager op-sequence port (CPU baseline)
+@pytest.mark.parametrize("case", SMALL)
+def test_torch_port_matches_reference_f32(case):
+    """oracle/torch_port.py (what bench.py times as cpu_baseline) reproduces the reference's own
+    float32 outputs: same op sequence => f, loss and the two-step RMSprop trajectory agree to
+    float32 round-off."""
+    from oracle import torch_port as TP
+    z = G.load("model_small")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p = G.params_from_golden(z, case)
+    v, M = G.masks_of(z, case)
+    st = TP.PortStep(p, prob, v, M, lr=cfg["lr"], alpha=cfg["rmsprop_decay"], num_iters=cfg["num_iters"])
+    names = G.trainable_names(z, case)
+    for it in range(2):
+        x = torch.tensor(z[f"{case}_x"][it])
+        pre = f"{case}_f32_step{it}_"
+        loss, f, Tf = st.loss(x)
+        assert G.rel(f.detach(), z[pre + "f"]) < 2e-6
+        ref_err = G.rel(z[pre + "Tf"], z[f"{case}_f64_step{it}_Tf"])
+        assert G.rel(Tf.detach(), z[f"{case}_f64_step{it}_Tf"]) < max(3 * ref_err, 1e-4)
+        st.step(x)
+        got = dict(st.model.named_parameters())
+        params = {n: got[n.replace("model.base.", "").replace("model.boundary_mask.", "")] for n in names}
+        for n in names:
+            # RMSprop's first steps are +-lr/sqrt(1-alpha) * sign(g): insensitive to gradient noise
+            assert G.rel(params[n].detach(), z[pre + "param_" + n]) < 1e-3, n
