@@ -39,6 +39,32 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
     return z > NSVD_SOFTPLUS_THRESHOLD ? 1.0f : s;
 }
 
+// sin and cos of one float32 argument, ~1 ulp, ~30 VALU: 3-constant Cody-Waite reduction by pi/2 with
+// FMAs (exact enough for |x| < 1e5) + degree-7/8 minimax polynomials on [-pi/4, pi/4]; ocml's sincosf
+// (Payne-Hanek, ~10x the cost at the 10..60 rad arguments the Fourier features see) beyond that.
+__device__ __forceinline__ void nsvd_sincos(float x, float* sp, float* cp) {
+    if (!(fabsf(x) < 65536.0f)) {  // also catches nan / inf
+        sincosf(x, sp, cp);
+        return;
+    }
+    const float n = rintf(x * 0.636619772367581343f);  // x * 2/pi
+    float r = fmaf(n, -1.57079601287841796875f, x);     // pi/2 = c1 + c2 + c3
+    r = fmaf(n, -3.1391647326017846353e-7f, r);
+    r = fmaf(n, -5.3903025299577647655e-15f, r);
+    const float s2 = r * r;
+    float ps = fmaf(s2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, s2, -1.6666654611e-1f);
+    const float sn = fmaf(ps * s2, r, r);
+    float pc = fmaf(s2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, s2, 4.166664568298827e-2f);
+    const float cs = fmaf(pc * s2, s2, fmaf(-0.5f, s2, 1.0f));
+    const int q = (int)n & 3;
+    const float so = (q & 1) ? cs : sn;
+    const float co = (q & 1) ? sn : cs;
+    *sp = (q & 2) ? -so : so;
+    *cp = ((q + 1) & 2) ? -co : co;
+}
+
 __device__ __forceinline__ float nsvd_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

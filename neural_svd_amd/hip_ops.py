@@ -109,6 +109,9 @@ def pack_params(shape: ModelShape, ws: Sequence[torch.Tensor], bs: Sequence[torc
         if scales is None or scales.numel() != shape.L:
             raise NsvdError("scales (L,) required when has_exp_mask")
         p.scales = _ptr(scales, "scales")
+    # the struct only holds raw addresses: pin the tensors to it so a temporary (e.g. `fB.to(dev)`)
+    # cannot be freed and recycled by the caching allocator while the struct is still in use
+    p._keepalive = (list(ws), list(bs), fourier_B, scales)
     return p
 
 
