@@ -121,7 +121,7 @@ class _OperatorFn(torch.autograd.Function):
         shape = model.shape
         packed = model.packed_params()
         ws = H.new_workspace(shape, x.shape[0], x.device)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad)  # grad mode is off inside Function.forward; ask the ctx
         f, Tf = H.operator_forward(shape, packed, prob, x, ws, save_for_backward=need_grad, path=method.path)
         ctx.model, ctx.prob, ctx.path = model, prob, method.path
         ctx.ws = ws if need_grad else None

@@ -1,0 +1,180 @@
+"""GPU tests of the host-side mirror of the reference API (get_problem / get_wavefunctions /
+get_evd_method / compute_loss_operator / train_operator / compute_spectrum_evd) and of the fused
+trainer, against the oracle and the reference's golden vectors."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsvd_oracle as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().numpy()
+    b = np.asarray(torch.as_tensor(b).double().cpu().numpy())
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def make_args(cfg):
+    from neural_svd_amd.nested_lowrank import get_evd_method  # noqa: F401
+    a = argparse.Namespace(**{k: v for k, v in cfg.items() if k not in ("sequential", "step")})
+    a.loss = argparse.Namespace(name="neuralsvd",
+                                neuralsvd=argparse.Namespace(step=cfg["step"], sequential=cfg["sequential"]))
+    a.adam_eps = 1e-7
+    a.use_lr_scheduler = True
+    a.ema_decay = 0.995
+    a.print_freq = 10 ** 9
+    a.eval_freq = 10 ** 9
+    a.log_dir = None
+    return a
+
+
+def build(case, z):
+    from neural_svd_amd.models import get_wavefunctions
+    from neural_svd_amd.nested_lowrank import get_evd_method
+    from neural_svd_amd.operators import get_dataloader, get_problem
+    cfg = G.cfg_of(z, case)
+    args = make_args(cfg)
+    torch.manual_seed(cfg["seed"])
+    operator, gt = get_problem(args, DEV)
+    model = get_wavefunctions(args)
+    loaders = get_dataloader(args, DEV)
+    method = get_evd_method(args, "neuralsvd", model).to(DEV)
+    return cfg, args, operator, gt, method, loaders
+
+
+@pytest.mark.parametrize("case", ["hyd_small", "osc_small"])
+def test_reference_style_pipeline(case):
+    z = G.load("model_small")
+    cfg, args, operator, gt, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = build(case, z)
+    # same names / values as the reference objects
+    names = [n for n, _ in method.named_parameters()]
+    assert names == [str(n) for n in z[f"{case}_param_names"]]
+    assert np.allclose(gt[:cfg["neigs"]], z[f"{case}_gt"][:cfg["neigs"]])
+    assert torch.equal(method.vector_mask, torch.tensor(z[f"{case}_v"]))
+    assert torch.equal(method.matrix_mask, torch.tensor(z[f"{case}_M"]))
+    # the seeded construction draws the reference's initial weights bit for bit
+    sd = method.state_dict()
+    for n in names:
+        assert torch.equal(sd[n].cpu(), torch.tensor(z[f"{case}_param0_{n}"])), n
+    x = torch.tensor(z[f"{case}_x"][0]).to(DEV)
+    method.train()
+    loss, aux = method.compute_loss_operator(operator, x, importance=imp_train)
+    assert loss.dim() == 0 and loss.requires_grad and aux["eigvals"] is None
+    loss.backward()
+    pre64, pre32 = f"{case}_f64_step0_", f"{case}_f32_step0_"
+    assert rel(aux["f"], z[pre64 + "f"]) < 2e-5
+    assert abs(float(loss) - float(z[pre64 + "loss"])) < 0.1 * abs(float(z[pre64 + "loss"]))
+    for n, p in method.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        g64 = z[pre64 + "grad_" + n]
+        ref_err = rel(z[pre32 + "grad_" + n], g64)
+        assert p.grad is not None and rel(p.grad, g64) < max(5 * ref_err, 5e-2), n
+    # forward(x): eigenfunction values
+    p64 = G.params_from_golden(z, case).to(torch.float64)
+    base = O.mlp_forward(O.fourier_features(x.double().cpu(), p64.fourier_B), p64)
+    mk = O.boundary_mask(x.double().cpu(), p64)
+    assert rel(method(x), base if mk is None else base * mk) < 1e-5
+    # evaluation with the reference's dataloader protocol
+    from neural_svd_amd.spectrum import compute_spectrum_evd
+    method.eval()
+    out = compute_spectrum_evd(method, dataloader=batch_ftn_val(), operator=operator, importance_train=imp_train,
+                               importance_val=imp_val, normalize=True, device=DEV)
+    assert out["eigvals"].shape == (cfg["neigs"],) and out["eigfuncs"].shape == (len(val_data), cfg["neigs"])
+    assert np.allclose(np.diag(out["cov"]), 1.0, atol=1e-5)
+
+
+def test_foreign_operator_is_refused():
+    from neural_svd_amd._lib import NsvdError
+    z = G.load("model_small")
+    _, _, operator, _, method, loaders = build("hyd_small", z)
+    x = torch.randn(8, 2, device=DEV)
+    with pytest.raises(NsvdError):
+        method.compute_loss_operator(lambda m, xx, importance=None: (xx, xx), x, importance=loaders[3])
+
+
+def test_train_operator_smoke():
+    """the reference-signature loop: a few iterations with eval + checkpoint dict, parameters move and stay finite."""
+    from neural_svd_amd.drop_in import train_operator
+    z = G.load("model_small")
+    cfg, args, operator, gt, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = build("osc_small", z)
+    args.num_iters, args.eval_freq, args.print_freq = 6, 3, 2
+    before = {n: p.detach().clone() for n, p in method.named_parameters()}
+    eigs, norms = train_operator(args, method, operator, make_batch, val_data, batch_ftn_val, None, None, DEV,
+                                 imp_train, imp_val, gt)
+    assert len(eigs) == 2 and eigs[0].shape == (cfg["neigs"],)
+    for n, p in method.named_parameters():
+        assert torch.isfinite(p).all()
+        if p.requires_grad:
+            assert not torch.equal(p, before[n]), n
+
+
+@pytest.mark.parametrize("hidden,m,B", [((32, 32), 16, 24), ((128, 128, 128), 64, 64)])
+def test_fused_trainer_step_matches_oracle(hidden, m, B):
+    """one full optimiser step of FusedTrainer (generic and fused-MFMA shapes) vs the float64 oracle
+    on the same batch: loss, gradient, RMSprop update, EMA."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    L, D = 4, 2
+    shape = H.ModelShape(L=L, D=D, m=m, hidden=hidden)
+    prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+    tr = FusedTrainer(shape, prob, B, sequential=False, lr=1e-4, num_iters=100, sampling_scale=16.0,
+                      fourier_scale=0.1, seed=5, device=DEV)
+    p = O.init_params(L, D, m, hidden, 0.1, seed=5)
+    for got, want in zip(tr.P.views(tr.P.flat), p.trainable()):
+        assert torch.equal(got.cpu(), want)
+    x = tr.sample().clone()
+    assert abs(float(x.std()) - 16.0) < 16.0 * 5.0 / np.sqrt(x.numel())
+    prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+    v, M = O.joint_nesting_masks(L, 1)
+    p64 = p.to(torch.float64)
+    ref = O.loss_and_grads(x.double().cpu(), p64, prob_o, v, M)
+    tr.step(x)
+    torch.cuda.synchronize()
+    assert abs(float(tr.loss[0]) - float(ref["loss"])) < 0.1 * abs(float(ref["loss"]))
+    gflat = torch.cat([g.reshape(-1) for g in ref["grads"]])
+    got = torch.cat([g.reshape(-1) for g in tr.P.views(tr.P.grad)])
+    assert rel(got, gflat) < 0.1
+    # RMSprop's first step is -lr/sqrt(1-alpha) * sign(g) (+-3.16e-3): compare the update where the
+    # gradient is not at the noise floor
+    sq = [torch.zeros_like(t) for t in p64.trainable()]
+    before = [t.clone() for t in p64.trainable()]
+    O.rmsprop_step(p64.trainable(), ref["grads"], sq, O.cosine_lr(1e-4, 0, 100), alpha=0.999, eps=1e-10)
+    upd_ref = torch.cat([(a - b).reshape(-1) for a, b in zip(p64.trainable(), before)])
+    upd_got = torch.cat([(a.double().cpu() - b).reshape(-1) for a, b in zip(tr.P.views(tr.P.flat), before)])
+    strong = gflat.abs() > 0.05 * gflat.abs().mean()
+    agree = (torch.sign(upd_ref[strong]) == torch.sign(upd_got[strong])).double().mean()
+    assert agree > 0.97, float(agree)
+    # every update (away from the eps = 1e-10 regime of vanishing gradients) has the RMSprop first-step size
+    assert float((upd_got[strong].abs() - 1e-4 / np.sqrt(1e-3)).abs().max()) < 1e-6
+    # EMA after one update: shadow = p0 - (1 - 2/11) (p0 - p1)
+    ema = torch.cat([t.reshape(-1) for t in tr.P.views(tr.P.ema)]).double().cpu()
+    p0 = torch.cat([t.reshape(-1) for t in before])
+    p1 = torch.cat([t.reshape(-1) for t in tr.P.views(tr.P.flat)]).double().cpu()
+    assert rel(ema, p0 - (1 - 2 / 11) * (p0 - p1)) < 1e-6
+    assert tr.t == 1 and tr.num_updates == 1
+
+
+def test_fused_trainer_learns_oscillator():
+    """convergence smoke: tiny oscillator model, a few thousand steps, Rayleigh quotients
+    approach the analytic spectrum [14, 12, 12, 10, 10, 10] (shift 16 - (2n + 2))."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    shape = H.ModelShape(L=6, D=2, m=64, hidden=(64, 64, 64), has_exp_mask=True)
+    prob = H.make_problem(H.POT_HARMONIC, 1.0, 0.01, 1.0, 16.0, 4.0)
+    steps = 4000
+    tr = FusedTrainer(shape, prob, 256, sequential=True, lr=1e-3, num_iters=steps, sampling_scale=4.0,
+                      fourier_scale=0.15, exp_mask_init=10.0, seed=0, device=DEV)
+    for _ in range(steps):
+        tr.step()
+    out = tr.spectrum(lim=5.0, val_eps=0.1)
+    gt = np.array([14.0, 12, 12, 10, 10, 10])
+    err = np.abs(out["eigvals"].numpy() - gt) / gt
+    assert np.isfinite(err).all() and err.mean() < 2e-2, (out["eigvals"], err)
