@@ -20,7 +20,8 @@ MASK_CUSTOM, MASK_SEQUENTIAL, MASK_JOINT = 0, 1, 2
 PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libnsvd_hip.so")
+# NSVD_LIB_PATH: diagnostic builds only (e.g. the stamped kernels of scripts/dev_stamps.py)
+LIB_PATH = os.environ.get("NSVD_LIB_PATH") or os.path.join(_PKG_DIR, "libnsvd_hip.so")
 
 
 class ModelDesc(C.Structure):

@@ -18,6 +18,7 @@
 // workgroups of one head share an XCD (its 1 MB W_0 stays in that XCD's L2).
 // Reference arithmetic being replaced: examples/models/mlp.py:204-221 x (1+2D) evaluations
 // (diff_ops.py:36-45) + diff_ops.py:9-23 + schrodinger/__init__.py:16-22 + examples/__init__.py:7-9.
+#include <stdlib.h>
 #include <string.h>
 #include "nsvd_kernels.h"
 #include "fd_math.h"
@@ -48,6 +49,7 @@ struct FwdArgs {
     float* dsc;
     float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null
     int xcd_remap;
+    unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
 
 // accumulator register r of lane-half hi holds row (r&3) + 8 (r>>2) + 4 hi of the 32-row tile
@@ -82,6 +84,20 @@ __device__ __forceinline__ void mma_frag(f32x16 (&acc)[E], const Frag<E>& f) {
 
 constexpr int H_LD = HID + 4;  // padded row of the activation image [column][k]
 
+// 16 bytes per lane global -> LDS without passing through VGPRs (global_load_lds_dwordx4). The LDS
+// destination is wave-uniform base + lane * 16; the global source is per lane.
+__device__ __forceinline__ void nsvd_glds16(const float* gsrc, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+#ifdef NSVD_FWD_STAMPS
+#define NSVD_STAMP(i)                                                                   \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define NSVD_STAMP(i)
+#endif
+
 template <int E>
 __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     constexpr int NC = E * BS;
@@ -91,7 +107,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     float* Hs = smem;                       // [NC][H_LD]       activations, k contiguous (aliases the stage buffers)
     constexpr int STAGE = 2 * HID * A_LD + 2 * NC * A_LD;
     constexpr int HSZ = NC * H_LD;
-    float* red = smem + (STAGE > HSZ ? STAGE : HSZ);  // [4][NC]
+    float* Wl = smem + (STAGE > HSZ ? STAGE : HSZ);   // [4 waves][32][128]  next layer's W rows of each wave (XOR-swizzled chunks)
+    float* red = Wl + HID * HID;                      // [4][NC]
     float* outs = red + 4 * NC;                       // [NC]
 
     const int tid = threadIdx.x;
@@ -106,6 +123,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int l = unit / nsb;
     const int b0 = (unit - l * nsb) * BS;
 
+    NSVD_STAMP(0)
     f32x16 acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e)
@@ -160,58 +178,130 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         if (E > 6) NSVD_STS(Bb_ + 192 * A_LD, rb6);                              \
     }
 
+    // Software pipeline, one barrier per chunk (80 MFMAs per wave between barriers):
+    //   * fragments are read one q-group (8 k) ahead of the MFMAs that use them;
+    //   * the LAST q-group of chunk c is multiplied AFTER the barrier, under the first fragment reads of
+    //     chunk c+1 and the global loads of chunk c+2, so neither latency is exposed;
+    //   * chunk c+1 is written to the other LDS buffer in the shadow of chunk c's third q-group.
     NSVD_LOAD_CHUNK(0);
     NSVD_STORE_CHUNK(0);
     __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        const int cur = c & 1;
-        const bool more = (c + 1 < nch);
-        if (more) NSVD_LOAD_CHUNK(c + 1);
-        const float* Ap = As + cur * HID * A_LD + (32 * w + li) * A_LD + 4 * hi;
-        const float* Bp = Bs + cur * NC * A_LD + li * A_LD + 4 * hi;
-        // two fragment sets: the reads of q-group q+1 are issued before the 4E MFMAs of q-group q
-        Frag<E> f0, f1;
+    NSVD_STAMP(1)
+    if (nch > 1) NSVD_LOAD_CHUNK(1);
+    Frag<E> f0, f1;
+    {
+        const float* Ap = As + (32 * w + li) * A_LD + 4 * hi;
+        const float* Bp = Bs + li * A_LD + 4 * hi;
         load_frag<E>(f0, Ap, Bp, A_LD);
-        load_frag<E>(f1, Ap + 8, Bp + 8, A_LD);
-        mma_frag<E>(acc, f0);
-        load_frag<E>(f0, Ap + 16, Bp + 16, A_LD);
-        mma_frag<E>(acc, f1);
-        load_frag<E>(f1, Ap + 24, Bp + 24, A_LD);
-        mma_frag<E>(acc, f0);
-        mma_frag<E>(acc, f1);
-        if (more) NSVD_STORE_CHUNK(cur ^ 1);
-        __syncthreads();
     }
+    // __builtin_amdgcn_sched_barrier(0) fences pin the phase order below; without them hipcc sinks the
+    // fragment reads next to their first use and parks the LDS stores right in front of the barrier,
+    // which exposes both latencies once per chunk.
+#define NSVD_FENCE() __builtin_amdgcn_sched_barrier(0)
+// n x { 1 MFMA, 1 instruction of class `mask` } in the current scheduling region (LLVM SchedGroupMask:
+// 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
+#define NSVD_INTERLEAVE(n, mask)                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+        __builtin_amdgcn_sched_group_barrier((mask), 1, 0);        \
+    }
+    // each region = 4E MFMAs + the memory instructions of the NEXT stage, interleaved one per MFMA gap
+    // (sched_group_barrier): a memory instruction issued in the shadow of an executing MFMA is free, a
+    // block of 9..15 of them in a row stalls the matrix pipe for ~250..500 cycles per chunk.
+    // The steady-state body is branch free (the last two chunks are peeled) so every region is one
+    // basic block the scheduler can interleave.
+#define NSVD_CHUNK_BODY(c, DO_STORE, DO_LOAD)                                                   \
+    {                                                                                           \
+        const int cur = (c) & 1;                                                                \
+        const float* Ap = As + cur * HID * A_LD + (32 * w + li) * A_LD + 4 * hi;                \
+        const float* Bp = Bs + cur * NC * A_LD + li * A_LD + 4 * hi;                            \
+        load_frag<E>(f1, Ap + 8, Bp + 8, A_LD);                                                 \
+        mma_frag<E>(acc, f0);                                                                   \
+        NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
+        NSVD_FENCE();                                                                           \
+        load_frag<E>(f0, Ap + 16, Bp + 16, A_LD);                                               \
+        mma_frag<E>(acc, f1);                                                                   \
+        NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
+        NSVD_FENCE();                                                                           \
+        load_frag<E>(f1, Ap + 24, Bp + 24, A_LD);                                               \
+        if (DO_STORE) NSVD_STORE_CHUNK(cur ^ 1);                                                \
+        mma_frag<E>(acc, f0);                                                                   \
+        NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
+        if (DO_STORE) NSVD_INTERLEAVE(4 + E, 0x200);                                            \
+        NSVD_FENCE();                                                                           \
+        __syncthreads();                                                                        \
+        if (DO_STORE) {                                                                         \
+            const float* An = As + (cur ^ 1) * HID * A_LD + (32 * w + li) * A_LD + 4 * hi;      \
+            const float* Bn = Bs + (cur ^ 1) * NC * A_LD + li * A_LD + 4 * hi;                  \
+            load_frag<E>(f0, An, Bn, A_LD);                                                     \
+        }                                                                                       \
+        if (DO_LOAD) NSVD_LOAD_CHUNK((c) + 2);                                                  \
+        mma_frag<E>(acc, f1);                                                                   \
+        if (DO_STORE) NSVD_INTERLEAVE(1 + E, 0x100);                                            \
+        if (DO_LOAD) NSVD_INTERLEAVE(4 + E, 0x020);                                             \
+        NSVD_FENCE();                                                                           \
+    }
+    {
+        int c = 0;
+        for (; c + 2 < nch; ++c) NSVD_CHUNK_BODY(c, true, true)
+        if (c + 1 < nch) {
+            NSVD_CHUNK_BODY(c, true, false)
+            ++c;
+        }
+        NSVD_CHUNK_BODY(c, false, false)
+    }
+#undef NSVD_CHUNK_BODY
 #undef NSVD_LOAD_CHUNK
 #undef NSVD_STORE_CHUNK
 #undef NSVD_LDG
 #undef NSVD_STS
 
+    NSVD_STAMP(2)
     // ------------------------------------------------------------------ hidden layers 1 .. nh-1
     const int nh = a.nlayers - 1;
     for (int i = 0; i < nh; ++i) {
-        // bias + (save centre pre-activations) + softplus, in registers
+        // next layer's weights for this wave (rows 32w..32w+31, all 128 columns) go global -> LDS by LDS-DMA
+        // (global_load_lds_dwordx4: no VGPRs, no ds_write), issued before the softplus so they land under
+        // it. One instruction moves 2 rows x 512 B; the tile is unpadded, so the 16-B chunks of row r are
+        // stored XOR-swizzled by (r & 15) - applied here on the SOURCE address, and again on the fragment
+        // reads below - which makes the ds_read_b128 fragment reads bank-conflict free.
+        // (Per-lane fragment loads straight from global touch 64 cache lines per instruction: 9k cycles.)
+        const bool has_next = (i + 1 < nh);
+        float* Wt = Wl + w * 32 * HID;
+        // order matters for the wait counters (vmcnt retires in issue order): bias loads and their use come
+        // BEFORE the DMA is issued, the pre-activation stores AFTER it, so that "vmcnt(#stores)" below
+        // means "the DMA has landed" without draining the stores.
         const float* bi = a.b[i] + (size_t)l * HID + 32 * w;
-        float* zs = a.zsave[i] ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int n = acc_row(r, hi);
-            const float bv = bi[n];
+            const float bv = bi[acc_row(r, hi)];
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const float z = acc[e][r] + bv;
-                if (e == 0 && zs) zs[(size_t)n * a.B] = z;
-                acc[e][r] = nsvd_softplus(z);
+            for (int e = 0; e < E; ++e) acc[e][r] += bv;
+        }
+        if (has_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias loads retired: nothing older than the DMA
+            const float* Wn = a.W[i + 1] + ((size_t)l * HID + 32 * w + hi) * HID;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = 2 * j + hi;
+                nsvd_glds16(Wn + (size_t)(2 * j) * HID + 4 * (li ^ (row & 15)), Wt + 2 * j * HID);
             }
         }
-        if (i == nh - 1) break;
-        // next layer's W fragments (row 32w+li, 16 B at column 8q + 4hi) straight from L2, issued before
-        // the activations move through LDS
-        const float* Wn = a.W[i + 1] + ((size_t)l * HID + 32 * w + li) * HID + 4 * hi;
-        float4 wf[16];
+        // (save centre pre-activations) + softplus, in registers
+        float* zs = a.zsave[i] ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
+        if (zs) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) wf[q] = *reinterpret_cast<const float4*>(Wn + 8 * q);
-        __syncthreads();  // every wave is done reading the previous LDS contents
+            for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
+        NSVD_STAMP(3 + 4 * i)
+        if (!has_next) break;
+        NSVD_STAMP(4 + 4 * i)
+        // raw barriers: __syncthreads() would drain the 16 stores above (vmcnt(0)) before every barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // previous LDS contents are dead
         // registers 4g..4g+3 of a lane are 4 consecutive hidden rows 8g + 4hi + (0..3): one 16-B store
         // into the [column][k] image
 #pragma unroll
@@ -222,22 +312,37 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 *reinterpret_cast<float4*>(hcol + 8 * g) =
                     make_float4(acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]);
         }
-        __syncthreads();
+        if (zs) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // DMA done, the 16 stores may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        NSVD_STAMP(5 + 4 * i)
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-        const float* Hp = Hs + li * H_LD + 4 * hi;
+        // K = 128 in 16 q-groups, fragments read one q-group ahead, one LDS read per MFMA gap
+        const float* Ap = Wt + li * HID;        // + 4 * ((2q + hi) ^ (li & 15)): swizzled 16-B chunk
+        const int sw = li & 15;
+        const float* Bp = Hs + li * H_LD + 4 * hi;
+        Frag<E> g0, g1;
+        load_frag<E>(g0, Ap + 4 * (hi ^ sw), Bp, H_LD);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            Frag<E> f;
-            f.a = wf[q];
-#pragma unroll
-            for (int e = 0; e < E; ++e) f.b[e] = *reinterpret_cast<const float4*>(Hp + e * BS * H_LD + 8 * q);
-            mma_frag<E>(acc, f);
+        for (int q = 0; q < 16; q += 2) {
+            load_frag<E>(g1, Ap + 4 * ((2 * (q + 1) + hi) ^ sw), Bp + 8 * (q + 1), H_LD);
+            mma_frag<E>(acc, g0);
+            NSVD_INTERLEAVE(1 + E, 0x100);
+            NSVD_FENCE();
+            if (q + 2 < 16) load_frag<E>(g0, Ap + 4 * ((2 * (q + 2) + hi) ^ sw), Bp + 8 * (q + 2), H_LD);
+            mma_frag<E>(acc, g1);
+            if (q + 2 < 16) NSVD_INTERLEAVE(1 + E, 0x100);
+            NSVD_FENCE();
         }
+        NSVD_STAMP(6 + 4 * i)
     }
 
+#undef NSVD_INTERLEAVE
+#undef NSVD_FENCE
+    NSVD_STAMP(12)
     // ------------------------------------------------------------------ last layer 128 -> 1
     {
         const float* wl = a.W[nh] + (size_t)l * HID + 32 * w;
@@ -260,6 +365,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     if (tid < NC) outs[tid] = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
     __syncthreads();
 
+    NSVD_STAMP(13)
     // ------------------------------------------------------------------ FD Hamiltonian epilogue
     if (tid < BS) {
         const int b = b0 + tid;
@@ -276,6 +382,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         if (a.jac) a.jac[idx] = o.jac;
         if (a.dsc) a.dsc[idx] = o.dsc;
     }
+    NSVD_STAMP(14)
 }
 
 template <int E>
@@ -283,7 +390,7 @@ size_t fwd_lds_bytes() {
     constexpr int NC = E * BS;
     constexpr int STAGE = 2 * HID * A_LD + 2 * NC * A_LD;
     constexpr int HSZ = NC * H_LD;
-    return ((STAGE > HSZ ? STAGE : HSZ) + 5 * NC) * sizeof(float);
+    return ((STAGE > HSZ ? STAGE : HSZ) + HID * HID + 5 * NC) * sizeof(float);
 }
 
 template <int E>
@@ -306,41 +413,25 @@ int launch_fwd(const FwdArgs& a, hipStream_t s) {
 
 // ================================================================================================
 // BACKWARD, part 1 (pmlp_fused_bwd_chain_kernel): one workgroup = head l x 32 centre samples.
-// Walks the layers from the output back to layer 0 with the same transposed tiles as the forward
+// Data gradients only, walking from the output back to layer 0 with the forward's transposed tiles
 // (rows = hidden units, columns = samples on the lanes; wave w owns rows 32w..32w+31):
-//   dz_i = dh_i * sigmoid(z_i)                                   (registers)
-//   dW_i[n][k] += sum_c dz_i[n][c] h_{i-1}[k][c]   (i >= 1)       64 MFMAs/wave, K = 32 samples, float atomics
-//   db_i[n]    += sum_c dz_i[n][c]                                wave shuffles + atomics
-//   dh_{i-1}[k][c] = sum_n W_i[n][k] dz_i[n][c]                   64 MFMAs/wave, K = 128, W_i from L2
-// and leaves dz_0 (L, 128, B) in the workspace for the layer-0 weight-gradient GEMM.
+//   dz_{nh-1} = W_last * dbase * sigmoid(z_{nh-1}),   dbase = df * d f / d base
+//   dz_{i-1}[k][c] = (sum_n W_i[n][k] dz_i[n][c]) * sigmoid(z_{i-1}[k][c])     64 MFMAs/wave, W_i from L2
+// Every dz_i (L, 128, B) goes to the workspace; all weight/bias gradients are reductions over the
+// batch and are done by pmlp_fused_wgrad_kernel without atomics.
 // This is autograd's backward of reference mlp.py:204-221 for the centre evaluation only (the 2D
-// shifted evaluations carry no gradient: nestedlora.py:108-111), plus pde/__init__.py:16 and
-// boundary.py:46-53 (d/d scales).
+// shifted evaluations carry no gradient: nestedlora.py:108-111) and of pde/__init__.py:16.
 struct ChainArgs {
     const float* df;
     const float* jac;
-    const float* dsc;
     const float* W[NSVD_MAX_LAYERS];
     const float* zsave[NSVD_MAX_LAYERS];
-    float* gW[NSVD_MAX_LAYERS];
-    float* gb[NSVD_MAX_LAYERS];
-    float* gscales;
-    float* dz0;
+    float* dz[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer
     int nlayers, B, L;
 };
 
-constexpr int C_LD = BS + 4;  // [row][sample] images, sample contiguous
-
-__device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes that share lane>>5
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
-    __shared__ __attribute__((aligned(16))) float DZ[BS * H_LD];     // [c][n]  n contiguous
-    __shared__ __attribute__((aligned(16))) float DZT[HID * C_LD];   // [n][c]  c contiguous
-    __shared__ __attribute__((aligned(16))) float HT[HID * C_LD];    // [k][c]  c contiguous
+    __shared__ __attribute__((aligned(16))) float DZ[BS * H_LD];  // [c][n]  n contiguous
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -349,140 +440,96 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
     const int b0 = (blockIdx.x - l * nsb) * BS;
     const int nh = a.nlayers - 1;
     const int b = b0 + li;
+    const size_t row0 = ((size_t)l * HID + 32 * w) * a.B + b;
 
-    const float dfv = a.df[(size_t)b * a.L + l];
-    const float dbase = dfv * a.jac[(size_t)b * a.L + l];
-    if (w == 0) {
-        const float s = half_sum(dbase);
-        if (lane == 0) atomicAdd(&a.gb[nh][l], s);
-        if (a.gscales) {
-            const float t = half_sum(dfv * a.dsc[(size_t)b * a.L + l]);
-            if (lane == 0) atomicAdd(&a.gscales[l], t);
-        }
-    }
-
-    // ---- output layer (128 -> 1): dW_last, and dz of the last hidden layer
-    float dz[16], hreg[16], sg[16];
+    const float dbase = a.df[(size_t)b * a.L + l] * a.jac[(size_t)b * a.L + l];
+    float dz[16];
     {
-        const float* zp = a.zsave[nh - 1] + ((size_t)l * HID + 32 * w) * a.B + b;
+        const float* zp = a.zsave[nh - 1] + row0;
         const float* wl = a.W[nh] + (size_t)l * HID + 32 * w;
-        float* gwl = a.gW[nh] + (size_t)l * HID + 32 * w;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = acc_row(r, hi);
-            const float z = zp[(size_t)n * a.B];
-            const float h = nsvd_softplus(z);
-            const float t = half_sum(dbase * h);
-            if (li == 0) atomicAdd(&gwl[n], t);
-            dz[r] = wl[n] * dbase * nsvd_sigmoid(z);
-            hreg[r] = h;
+            dz[r] = wl[n] * dbase * nsvd_sigmoid(zp[(size_t)n * a.B]);
         }
     }
-
     for (int i = nh - 1; i >= 0; --i) {
-        // bias gradient of layer i
-        float* gbi = a.gb[i] + (size_t)l * HID + 32 * w;
+        float* o = a.dz[i] + row0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float t = half_sum(dz[r]);
-            if (li == 0) atomicAdd(&gbi[acc_row(r, hi)], t);
-        }
+        for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
         if (i == 0) break;
-        // activations feeding layer i: h_{i-1} = softplus(z_{i-1}) (this wave's 32 rows), and sigmoid for later
+        // issue the loads the next tile needs before the LDS exchange: sigmoid inputs and W_i columns
+        float zin[16];
         {
-            const float* zp = a.zsave[i - 1] + ((size_t)l * HID + 32 * w) * a.B + b;
+            const float* zp = a.zsave[i - 1] + row0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float z = zp[(size_t)acc_row(r, hi) * a.B];
-                hreg[r] = nsvd_softplus(z);
-                sg[r] = nsvd_sigmoid(z);
-            }
+            for (int r = 0; r < 16; ++r) zin[r] = zp[(size_t)acc_row(r, hi) * a.B];
         }
         __syncthreads();  // previous round's LDS reads are done
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =
                 make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = 32 * w + acc_row(r, hi);
-            DZT[n * C_LD + li] = dz[r];
-            HT[n * C_LD + li] = hreg[r];
-        }
         __syncthreads();
-
-        // ---- weight gradient: rows n = 32w.., all 128 k, K = 32 samples
-        {
-            f32x16 acc[4];
+        f32x16 acc1[1];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+        for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+        const float* Wi = a.W[i] + (size_t)l * HID * HID + 32 * w + li;  // W_i[n][k = 32w + li]
+        const float* Bp = DZ + li * H_LD + 4 * hi;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
-            const float* Ap = DZT + (32 * w + li) * C_LD + 4 * hi;
-            const float* Bp = HT + li * C_LD + 4 * hi;
-#pragma unroll
-            for (int q = 0; q < BS / 8; ++q) {
-                Frag<4> f;
-                load_frag<4>(f, Ap + 8 * q, Bp + 8 * q, C_LD);
-                mma_frag<4>(acc, f);
-            }
-            float* gw = a.gW[i] + ((size_t)l * HID + 32 * w) * HID + li;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(&gw[(size_t)acc_row(r, hi) * HID + 32 * kb], acc[kb][r]);
+        for (int q = 0; q < 16; ++q) {
+            Frag<1> f;
+            const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;
+            f.a = make_float4(wp[0], wp[HID], wp[2 * HID], wp[3 * HID]);
+            f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * q);
+            mma_frag<1>(acc1, f);
         }
-        // ---- data gradient: rows k = 32w.., K = 128 hidden units of layer i
-        {
-            f32x16 acc1[1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-            const float* Wi = a.W[i] + (size_t)l * HID * HID + 32 * w + li;  // W_i[n][k = 32w + li]
-            const float* Bp = DZ + li * H_LD + 4 * hi;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                Frag<1> f;
-                const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;
-                f.a = make_float4(wp[0], wp[HID], wp[2 * HID], wp[3 * HID]);
-                f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * q);
-                mma_frag<1>(acc1, f);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * sg[r];
-        }
+        for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * nsvd_sigmoid(zin[r]);
     }
-    // dz_0 -> workspace (L, 128, B)
-    float* o = a.dz0 + ((size_t)l * HID + 32 * w) * a.B + b;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
 }
 
 // ================================================================================================
-// BACKWARD, part 2 (pmlp_fused_wgrad0_kernel): dW_0[l][n][k] = sum_b dz_0[l][n][b] phi^T[k][b] over the
-// B centre samples: per head a 128 x F x B GEMM with both operands b-contiguous. 128 x 128 output tile
-// per workgroup (F/128 * L workgroups), 4 waves as 2 x 2 of 64 x 64 (2 x 2 MFMA tiles each), K streamed
-// in 32-sample chunks through padded LDS tiles, register-staged and double buffered like the forward.
-struct Wgrad0Args {
-    const float* dz0;    // (L, 128, B)
-    const float* phiTc;  // (F, B)
-    float* gW0;          // (L, 128, F)
-    int B, L, F;
-    int xcd_remap;
+// BACKWARD, part 2 (pmlp_fused_wgrad_kernel): every parameter gradient, one launch, no atomics.
+// Three kinds of workgroup, told apart by blockIdx:
+//   A  (F/128 * L):      dW_0[l][n][k] = sum_b dz_0[l][n][b] phi^T[k][b]: 128 x 128 tile, K = B, both
+//                        operands b-contiguous, 4 waves as 2 x 2 of 64 x 64; the k = 0 tile of each head
+//                        also writes db_0[l] (row sums of dz_0).
+//   B  (4 (nh-1) L):     dW_i[l][n][k] = sum_b dz_i[l][n][b] softplus(z_{i-1}[l][k][b]), i >= 1: one
+//                        64 x 64 quadrant of the 128 x 128 result, 4 waves of one 32 x 32 tile; quadrants
+//                        in column 0 also write db_i.
+//   C  (L):              dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales.
+// K is streamed in 32-sample chunks through padded LDS tiles (rows of 36 floats, conflict-free
+// ds_read_b128 fragments), register-staged and double buffered, one barrier per chunk.
+struct WgradArgs {
+    const float* dz[NSVD_MAX_LAYERS];     // (L, 128, B)
+    const float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B)
+    const float* phiTc;                   // (F, B)
+    const float* df;
+    const float* jac;
+    const float* dsc;                     // null without the exponential mask
+    float* gW[NSVD_MAX_LAYERS];
+    float* gb[NSVD_MAX_LAYERS];
+    float* gscales;
+    int nlayers, B, L, F;
+    int nA, nB;
+    int bid0;  // first logical block of this launch (the A tiles and the B/C tiles are launched separately)
 };
 
-__global__ void __launch_bounds__(256, 1) pmlp_fused_wgrad0_kernel(Wgrad0Args a) {
-    __shared__ __attribute__((aligned(16))) float As[2 * HID * A_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * HID * A_LD];
+// stage one 32-row x 32-column (float4 per thread) slab global -> registers
+#define WG_LD(dst, src) dst = *reinterpret_cast<const float4*>(src)
+#define WG_ST(dst, v) *reinterpret_cast<float4*>(dst) = (v)
+
+__device__ __forceinline__ float4 softplus4(float4 v) {
+    return make_float4(nsvd_softplus(v.x), nsvd_softplus(v.y), nsvd_softplus(v.z), nsvd_softplus(v.w));
+}
+
+__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, float* Bs, int unit) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
     const int nkt = a.F / HID;
-    int unit = blockIdx.x;
-    if (a.xcd_remap) {
-        const int per = gridDim.x >> 3;
-        unit = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    }
     const int l = unit / nkt;
     const int kf0 = (unit - l * nkt) * HID;
 
@@ -495,86 +542,274 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_wgrad0_kernel(Wgrad0Args a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int s_row = tid >> 3, s_c4 = tid & 7;
-    const float* a_src = a.dz0 + ((size_t)l * HID + s_row) * a.B + 4 * s_c4;
+    const float* a_src = a.dz[0] + ((size_t)l * HID + s_row) * a.B + 4 * s_c4;
     const float* b_src = a.phiTc + (size_t)(kf0 + s_row) * a.B + 4 * s_c4;
     const size_t step = (size_t)32 * a.B;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define W0_LOAD(c)                                                                    \
-    {                                                                                 \
-        const float* pa_ = a_src + (c) * BK;                                          \
-        const float* pb_ = b_src + (c) * BK;                                          \
-        ra0 = *reinterpret_cast<const float4*>(pa_);                                  \
-        ra1 = *reinterpret_cast<const float4*>(pa_ + step);                           \
-        ra2 = *reinterpret_cast<const float4*>(pa_ + 2 * step);                       \
-        ra3 = *reinterpret_cast<const float4*>(pa_ + 3 * step);                       \
-        rb0 = *reinterpret_cast<const float4*>(pb_);                                  \
-        rb1 = *reinterpret_cast<const float4*>(pb_ + step);                           \
-        rb2 = *reinterpret_cast<const float4*>(pb_ + 2 * step);                       \
-        rb3 = *reinterpret_cast<const float4*>(pb_ + 3 * step);                       \
+    // two register sets (P, Q): chunk c+2 is fetched while chunk c is multiplied and chunk c+1 sits in
+    // the other LDS buffer, so a load has two chunk-times (~3.5 us) to land
+    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;  // bias gradient partials (only used when kf0 == 0)
+#define WA_LOAD(S, c)                                              \
+    {                                                              \
+        const float* pa_ = a_src + (c) * BK;                       \
+        const float* pb_ = b_src + (c) * BK;                       \
+        WG_LD(S##a0, pa_);                                         \
+        WG_LD(S##a1, pa_ + step);                                  \
+        WG_LD(S##a2, pa_ + 2 * step);                              \
+        WG_LD(S##a3, pa_ + 3 * step);                              \
+        WG_LD(S##b0, pb_);                                         \
+        WG_LD(S##b1, pb_ + step);                                  \
+        WG_LD(S##b2, pb_ + 2 * step);                              \
+        WG_LD(S##b3, pb_ + 3 * step);                              \
     }
-#define W0_STORE(buf)                                                                 \
-    {                                                                                 \
-        float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;               \
-        float* Bb_ = Bs + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;               \
-        *reinterpret_cast<float4*>(Ab_) = ra0;                                        \
-        *reinterpret_cast<float4*>(Ab_ + 32 * A_LD) = ra1;                            \
-        *reinterpret_cast<float4*>(Ab_ + 64 * A_LD) = ra2;                            \
-        *reinterpret_cast<float4*>(Ab_ + 96 * A_LD) = ra3;                            \
-        *reinterpret_cast<float4*>(Bb_) = rb0;                                        \
-        *reinterpret_cast<float4*>(Bb_ + 32 * A_LD) = rb1;                            \
-        *reinterpret_cast<float4*>(Bb_ + 64 * A_LD) = rb2;                            \
-        *reinterpret_cast<float4*>(Bb_ + 96 * A_LD) = rb3;                            \
+#define WA_STORE(S, buf)                                                           \
+    {                                                                              \
+        float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
+        float* Bb_ = Bs + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
+        WG_ST(Ab_, S##a0);                                                         \
+        WG_ST(Ab_ + 32 * A_LD, S##a1);                                             \
+        WG_ST(Ab_ + 64 * A_LD, S##a2);                                             \
+        WG_ST(Ab_ + 96 * A_LD, S##a3);                                             \
+        WG_ST(Bb_, S##b0);                                                         \
+        WG_ST(Bb_ + 32 * A_LD, S##b1);                                             \
+        WG_ST(Bb_ + 64 * A_LD, S##b2);                                             \
+        WG_ST(Bb_ + 96 * A_LD, S##b3);                                             \
+        rs0 += (S##a0.x + S##a0.y) + (S##a0.z + S##a0.w);                          \
+        rs1 += (S##a1.x + S##a1.y) + (S##a1.z + S##a1.w);                          \
+        rs2 += (S##a2.x + S##a2.y) + (S##a2.z + S##a2.w);                          \
+        rs3 += (S##a3.x + S##a3.y) + (S##a3.z + S##a3.w);                          \
     }
-    const int nch = a.B / BK;
-    W0_LOAD(0);
-    W0_STORE(0);
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        const int cur = c & 1;
-        const bool more = (c + 1 < nch);
-        if (more) W0_LOAD(c + 1);
-        const float* Ap = As + cur * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;
-        const float* Bp = Bs + cur * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            const float4 a0 = *reinterpret_cast<const float4*>(Ap + 8 * q);
-            const float4 a1 = *reinterpret_cast<const float4*>(Ap + 32 * A_LD + 8 * q);
-            const float4 b0v = *reinterpret_cast<const float4*>(Bp + 8 * q);
-            const float4 b1v = *reinterpret_cast<const float4*>(Bp + 32 * A_LD + 8 * q);
-#define W0_MMA(X)                                                                                       \
+#define WA_COMPUTE(cur)                                                                                      \
+    {                                                                                                        \
+        const float* Ap = As + (cur) * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;                          \
+        const float* Bp = Bs + (cur) * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;                          \
+        _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                                 \
+            const float4 a0 = *reinterpret_cast<const float4*>(Ap + 8 * q);                                  \
+            const float4 a1 = *reinterpret_cast<const float4*>(Ap + 32 * A_LD + 8 * q);                      \
+            const float4 b0v = *reinterpret_cast<const float4*>(Bp + 8 * q);                                 \
+            const float4 b1v = *reinterpret_cast<const float4*>(Bp + 32 * A_LD + 8 * q);                     \
+            WA_MMA(x) WA_MMA(y) WA_MMA(z) WA_MMA(w)                                                          \
+        }                                                                                                    \
+    }
+#define WA_MMA(X)                                                                                       \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.X, b0v.X, acc[0][0], 0, 0, 0);                 \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.X, b1v.X, acc[0][1], 0, 0, 0);                 \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.X, b0v.X, acc[1][0], 0, 0, 0);                 \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.X, b1v.X, acc[1][1], 0, 0, 0);
-            W0_MMA(x) W0_MMA(y) W0_MMA(z) W0_MMA(w)
-#undef W0_MMA
-        }
-        if (more) W0_STORE(cur ^ 1);
+    const int nch = a.B / BK;
+    pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = pb2 = pb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    WA_LOAD(p, 0);
+    if (nch > 1) WA_LOAD(q, 1);
+    WA_STORE(p, 0);
+    __syncthreads();
+    // chunk c lives in LDS buffer c & 1; registers P hold even chunks, Q odd chunks
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 2 < nch) WA_LOAD(p, c + 2);
+        WA_COMPUTE(0);
+        if (c + 1 < nch) WA_STORE(q, 1);
         __syncthreads();
+        if (c + 1 < nch) {
+            if (c + 3 < nch) WA_LOAD(q, c + 3);
+            WA_COMPUTE(1);
+            if (c + 2 < nch) WA_STORE(p, 0);
+            __syncthreads();
+        }
     }
-#undef W0_LOAD
-#undef W0_STORE
-    float* o = a.gW0 + ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
+#undef WA_MMA
+#undef WA_COMPUTE
+#undef WA_LOAD
+#undef WA_STORE
+    float* o = a.gW[0] + ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[(size_t)(32 * i + acc_row(r, hi)) * a.F + 32 * j] = acc[i][j][r];
-}
-
-// zero the gradient tensors that the chain kernel accumulates into with atomics
-struct ZeroArgs {
-    float* p[2 * NSVD_MAX_LAYERS + 1];
-    unsigned n[2 * NSVD_MAX_LAYERS + 1];
-    int count;
-};
-__global__ void __launch_bounds__(256) zero_many_kernel(ZeroArgs z) {
-    for (int t = 0; t < z.count; ++t) {
-        float* p = z.p[t];
-        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < z.n[t]; i += gridDim.x * blockDim.x) p[i] = 0.f;
+    if (kf0 == 0) {
+        // bias gradient: 8 threads (s_c4) hold partial sums of rows s_row + {0, 32, 64, 96}
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            rs0 += __shfl_xor(rs0, off, 64);
+            rs1 += __shfl_xor(rs1, off, 64);
+            rs2 += __shfl_xor(rs2, off, 64);
+            rs3 += __shfl_xor(rs3, off, 64);
+        }
+        if (s_c4 == 0) {
+            float* gb = a.gb[0] + (size_t)l * HID + s_row;
+            gb[0] = rs0;
+            gb[32] = rs1;
+            gb[64] = rs2;
+            gb[96] = rs3;
+        }
     }
 }
+
+__device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, float* Bs, int unit) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int nh = a.nlayers - 1;
+    // unit -> (layer i in 1..nh-1, head l, quadrant)
+    const int quad = unit & 3;
+    const int rest = unit >> 2;
+    const int l = rest % a.L;
+    const int i = 1 + rest / a.L;
+    (void)nh;
+    const int n0 = (quad >> 1) * 64, k0 = (quad & 1) * 64;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4; two slabs per operand (64 rows)
+    const float* a_src = a.dz[i] + ((size_t)l * HID + n0 + s_row) * a.B + 4 * s_c4;
+    const float* b_src = a.zsave[i - 1] + ((size_t)l * HID + k0 + s_row) * a.B + 4 * s_c4;
+    const size_t step = (size_t)32 * a.B;
+    float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+    float rs0 = 0.f, rs1 = 0.f;
+    constexpr int TS = 64 * A_LD;  // one 64-row tile
+#define WB_LOAD(S, c)                                 \
+    {                                                 \
+        WG_LD(S##a0, a_src + (c) * BK);               \
+        WG_LD(S##a1, a_src + (c) * BK + step);        \
+        WG_LD(S##b0, b_src + (c) * BK);               \
+        WG_LD(S##b1, b_src + (c) * BK + step);        \
+    }
+#define WB_STORE(S, buf)                                                \
+    {                                                                   \
+        float* Ab_ = As + (buf) * TS + s_row * A_LD + 4 * s_c4;         \
+        float* Bb_ = Bs + (buf) * TS + s_row * A_LD + 4 * s_c4;         \
+        WG_ST(Ab_, S##a0);                                              \
+        WG_ST(Ab_ + 32 * A_LD, S##a1);                                  \
+        WG_ST(Bb_, softplus4(S##b0));                                   \
+        WG_ST(Bb_ + 32 * A_LD, softplus4(S##b1));                       \
+        rs0 += (S##a0.x + S##a0.y) + (S##a0.z + S##a0.w);               \
+        rs1 += (S##a1.x + S##a1.y) + (S##a1.z + S##a1.w);               \
+    }
+#define WB_COMPUTE(cur)                                                                        \
+    {                                                                                          \
+        const float* Ap = As + (cur) * TS + (32 * wm + li) * A_LD + 4 * hi;                    \
+        const float* Bp = Bs + (cur) * TS + (32 * wn + li) * A_LD + 4 * hi;                    \
+        _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                   \
+            const float4 av = *reinterpret_cast<const float4*>(Ap + 8 * q);                    \
+            const float4 bv = *reinterpret_cast<const float4*>(Bp + 8 * q);                    \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);              \
+        }                                                                                      \
+    }
+    const int nch = a.B / BK;
+    pa0 = pa1 = pb0 = pb1 = qa0 = qa1 = qb0 = qb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    WB_LOAD(p, 0);
+    if (nch > 1) WB_LOAD(q, 1);
+    WB_STORE(p, 0);
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 2 < nch) WB_LOAD(p, c + 2);
+        WB_COMPUTE(0);
+        if (c + 1 < nch) WB_STORE(q, 1);
+        __syncthreads();
+        if (c + 1 < nch) {
+            if (c + 3 < nch) WB_LOAD(q, c + 3);
+            WB_COMPUTE(1);
+            if (c + 2 < nch) WB_STORE(p, 0);
+            __syncthreads();
+        }
+    }
+#undef WB_COMPUTE
+#undef WB_LOAD
+#undef WB_STORE
+    float* o = a.gW[i] + ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * HID] = acc[r];
+    if (k0 == 0) {
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            rs0 += __shfl_xor(rs0, off, 64);
+            rs1 += __shfl_xor(rs1, off, 64);
+        }
+        if (s_c4 == 0) {
+            float* gb = a.gb[i] + (size_t)l * HID + n0 + s_row;
+            gb[0] = rs0;
+            gb[32] = rs1;
+        }
+    }
+}
+
+__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int l) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int nh = a.nlayers - 1;
+    float* red = lds;            // [8]
+    float* dbl = lds + 16;       // [B] dbase of this head (B <= 2 * 128 * 36 - 16 floats, checked on the host)
+    float sb = 0.f, ss = 0.f;
+    for (int b = tid; b < a.B; b += 256) {
+        const float dfv = a.df[(size_t)b * a.L + l];
+        const float v = dfv * a.jac[(size_t)b * a.L + l];
+        dbl[b] = v;
+        sb += v;
+        if (a.dsc) ss += dfv * a.dsc[(size_t)b * a.L + l];
+    }
+    sb = nsvd_wave_sum(sb);
+    ss = nsvd_wave_sum(ss);
+    if (lane == 0) {
+        red[w] = sb;
+        red[4 + w] = ss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.gb[nh][l] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (a.gscales) a.gscales[l] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+    // dW_last[n] = sum_b dbase[b] softplus(z[n][b]): each wave owns 32 rows and walks them 8 at a time so
+    // that 8 independent 16-B loads are in flight per lane (a row-at-a-time loop is pure L2 latency)
+    for (int n0 = 32 * w; n0 < 32 * w + 32; n0 += 8) {
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        for (int b = 4 * lane; b < a.B; b += 256) {
+            float4 z[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                z[j] = *reinterpret_cast<const float4*>(a.zsave[nh - 1] + ((size_t)l * HID + n0 + j) * a.B + b);
+            const float4 d = *reinterpret_cast<const float4*>(dbl + b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] = fmaf(d.x, nsvd_softplus(z[j].x), s[j]);
+                s[j] = fmaf(d.y, nsvd_softplus(z[j].y), s[j]);
+                s[j] = fmaf(d.z, nsvd_softplus(z[j].z), s[j]);
+                s[j] = fmaf(d.w, nsvd_softplus(z[j].w), s[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = nsvd_wave_sum(s[j]);
+            if (lane == 0) a.gW[nh][(size_t)l * HID + n0 + j] = t;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2 * HID * A_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * HID * A_LD];
+    const int bid = blockIdx.x + a.bid0;
+    if (bid < a.nA) {
+        // heads share an XCD (dz_0[l] stays in that L2) when the tile count allows the remap
+        int unit = bid;
+        if ((a.nA & 7) == 0) unit = (bid & 7) * (a.nA >> 3) + (bid >> 3);
+        wgrad_tile_A(a, As, Bs, unit);
+    } else if (bid < a.nA + a.nB) {
+        wgrad_tile_B(a, As, Bs, bid - a.nA);
+    } else {
+        wgrad_tile_C(a, As, bid - a.nA - a.nB);
+    }
+}
+#undef WG_LD
+#undef WG_ST
 
 struct FusedWs {
     float* phi;                       // (R, F) sample-major Fourier features of every stencil row
@@ -582,7 +817,7 @@ struct FusedWs {
     float* zsave[NSVD_MAX_LAYERS];    // (L, 128, B) per hidden layer
     float* jac;                       // (B, L)
     float* dsc;                       // (B, L)
-    float* dz0;                       // (L, 128, B)
+    float* dz[NSVD_MAX_LAYERS];       // (L, 128, B) per hidden layer
     size_t bytes;
 };
 
@@ -602,7 +837,7 @@ FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     for (int i = 0; i < d.nlayers - 1; ++i) w.zsave[i] = take((size_t)d.L * HID * B);
     w.jac = take((size_t)B * d.L);
     w.dsc = take((size_t)B * d.L);
-    w.dz0 = take((size_t)d.L * HID * B);
+    for (int i = 0; i < d.nlayers - 1; ++i) w.dz[i] = take((size_t)d.L * HID * B);
     w.bytes = off;
     return w;
 }
@@ -610,11 +845,11 @@ FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
 }  // namespace
 
 bool nsvd_fused_supported(const nsvd_model_desc& d, int B) {
-    if (d.D < 1 || d.D > 3) return false;
+    if (d.D < 1 || d.D > 2) return false;  // E = 1 + 2D <= 5: the forward's LDS image (155 KB at E = 5)
     if (d.nlayers < 2) return false;
     for (int i = 0; i < d.nlayers - 1; ++i)
         if (d.dims[i] != HID) return false;
-    if (B % BS != 0) return false;
+    if (B % BS != 0 || B > 8192) return false;  // 8192: one head's dbase vector is staged in LDS (wgrad C)
     if ((2 * d.m) % HID != 0) return false;  // layer-0 weight gradient uses 128-wide feature tiles
     return true;
 }
@@ -651,10 +886,12 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
     const int grid = (B / BS) * d.L;
     a.xcd_remap = (grid % 8 == 0) ? 1 : 0;
+#ifdef NSVD_FWD_STAMPS
+    a.stamps = (unsigned long long*)w.dz[0];  // diagnostic build: stamps land in the (then unused) dz_0 scratch
+#endif
     switch (E) {
         case 3: return launch_fwd<3>(a, s);
         case 5: return launch_fwd<5>(a, s);
-        case 7: return launch_fwd<7>(a, s);
     }
     return NSVD_EUNSUPPORTED;
 }
@@ -665,50 +902,50 @@ int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const ns
     (void)x;
     const FusedWs w = carve_fused(d, B, ws);
     const int F = 2 * d.m, nh = d.nlayers - 1;
-    ZeroArgs z;
-    memset(&z, 0, sizeof(z));
-    int c = 0;
-    for (int i = 0; i < d.nlayers; ++i) {
-        if (i > 0) {
-            z.p[c] = g.W[i];
-            z.n[c++] = (unsigned)((size_t)d.L * d.dims[i] * d.dims[i - 1]);
-        }
-        z.p[c] = g.b[i];
-        z.n[c++] = (unsigned)((size_t)d.L * d.dims[i]);
-    }
-    if (d.has_exp_mask) {
-        z.p[c] = g.scales;
-        z.n[c++] = (unsigned)d.L;
-    }
-    z.count = c;
-    hipLaunchKernelGGL(zero_many_kernel, dim3(256), dim3(256), 0, s, z);
-    NSVD_CHECK_LAUNCH();
 
     ChainArgs a;
     memset(&a, 0, sizeof(a));
     a.df = df;
     a.jac = w.jac;
-    a.dsc = d.has_exp_mask ? w.dsc : nullptr;
     for (int i = 0; i < d.nlayers; ++i) {
         a.W[i] = p.W[i];
         a.zsave[i] = (i < nh) ? w.zsave[i] : nullptr;
-        a.gW[i] = g.W[i];
-        a.gb[i] = g.b[i];
+        a.dz[i] = (i < nh) ? w.dz[i] : nullptr;
     }
-    a.gscales = d.has_exp_mask ? g.scales : nullptr;
-    a.dz0 = w.dz0;
     a.nlayers = d.nlayers; a.B = B; a.L = d.L;
     hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel, dim3((B / BS) * d.L), dim3(256), 0, s, a);
     NSVD_CHECK_LAUNCH();
 
-    Wgrad0Args wa;
-    wa.dz0 = w.dz0;
+    WgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    for (int i = 0; i < d.nlayers; ++i) {
+        wa.dz[i] = (i < nh) ? w.dz[i] : nullptr;
+        wa.zsave[i] = (i < nh) ? w.zsave[i] : nullptr;
+        wa.gW[i] = g.W[i];
+        wa.gb[i] = g.b[i];
+    }
     wa.phiTc = w.phiTc;
-    wa.gW0 = g.W[0];
-    wa.B = B; wa.L = d.L; wa.F = F;
-    const int grid = (F / HID) * d.L;
-    wa.xcd_remap = (grid % 8 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(pmlp_fused_wgrad0_kernel, dim3(grid), dim3(256), 0, s, wa);
+    wa.df = df;
+    wa.jac = w.jac;
+    wa.dsc = d.has_exp_mask ? w.dsc : nullptr;
+    wa.gscales = d.has_exp_mask ? g.scales : nullptr;
+    wa.nlayers = d.nlayers; wa.B = B; wa.L = d.L; wa.F = F;
+    wa.nA = (F / HID) * d.L;
+    wa.nB = 4 * (nh - 1) * d.L;
+    // Two launches of the same kernel: the 128x128 dW_0 tiles with 16 KB of extra dynamic LDS so that
+    // exactly one lands on each CU (two co-resident tiles share the CU's matrix pipes and leave other CUs
+    // idle: 72 us vs 41 us measured), then the small dW_i / db / last-layer workgroups.
+    const char* ev = getenv("NSVD_WGRAD_MODE");
+    const int mode = ev ? atoi(ev) : 0;
+    if (mode == 0) {
+        wa.bid0 = 0;
+        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA + wa.nB + d.L), dim3(256), 0, s, wa);
+    } else {
+        wa.bid0 = 0;
+        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA), dim3(256), mode == 1 ? 16384 : 0, s, wa);
+        wa.bid0 = wa.nA;
+        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nB + d.L), dim3(256), 0, s, wa);
+    }
     NSVD_CHECK_LAUNCH();
     return 0;
 }

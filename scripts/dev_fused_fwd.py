@@ -29,9 +29,9 @@ run(2, 512, 64, (128, 128, 128))
 run(2, 64, 1024, (128, 128, 128))
 run(16, 512, 64, (128, 128, 128))
 run(8, 256, 256, (128, 128, 128))
-run(3, 32, 16, (128,))
-run(2, 96, 32, (128, 128), D=1)
-run(2, 64, 32, (128, 128), D=3, exp=True, pot=H.POT_HARMONIC)
+run(3, 32, 64, (128,))
+run(2, 96, 64, (128, 128), D=1)
+run(2, 64, 64, (128, 128), D=2, exp=True, pot=H.POT_HARMONIC)
 shape, p, prob, x, wsb = run(16, 512, 1024, (128, 128, 128))
 for path, name in ((H.PATH_GENERIC, "generic"), (H.PATH_FUSED, "fused")):
     for _ in range(3):
