@@ -152,6 +152,29 @@ int nsvd_evd_loss_grad(const float* f, const float* Tf, int B, int L, int mask_k
                        const float* M, const float* moments, float grad_scale, float* loss, float* df,
                        void* stream);
 
+/* Stages 1 + 2 in one call for the single-GPU case (no exchange between them): one launch when
+ * B*L <= 16384, the two-stage pipeline otherwise. Same outputs as the two calls above. */
+int nsvd_evd_loss_fused(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v,
+                        const float* M, float grad_scale, float* moments, float* loss, float* df,
+                        void* scratch, void* stream);
+
+/* Stage 1a alone: the per-chunk partial sums of the moments into `scratch` (nsvd_evd_scratch_bytes),
+ * without the reduction launch. Consumed by nsvd_operator_backward_evd(moments_reduced = 0). */
+int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v, void* scratch,
+                     void* stream);
+
+/* nsvd_evd_loss_grad + nsvd_operator_backward in ONE call: d loss / d f (methods/nestedlora.py:98-111) is
+ * evaluated per sample inside the backward kernels and never stored. `moments` (2L^2+1 floats) is
+ *   - an INPUT when moments_reduced != 0 (e.g. after the data-parallel all-reduce of nsvd_evd_moments), or
+ *   - an OUTPUT when moments_reduced == 0: the partial sums in `evd_scratch` (from nsvd_evd_partial on the
+ *     same f, Tf) are reduced on the fly and the reduced vector is stored here.
+ * loss[0..2] = {loss, operator term, metric term}. Gradients are overwritten as in nsvd_operator_backward. */
+int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsvd_params* params,
+                               const nsvd_problem* prob, const float* x, int B, const float* f, const float* Tf,
+                               int mask_kind, const float* v, const float* M, float* moments, int moments_reduced,
+                               const void* evd_scratch, float grad_scale, float* loss, const nsvd_params* grads,
+                               void* ws, size_t ws_bytes, int path, void* stream);
+
 /* torch.optim.RMSprop(alpha, eps, momentum=0, centered=False) step + torch_ema update, fused
  * (examples/utils.py:50-57, examples/operator/__init__.py:69-73):
  *   g = grad_scale * grad; sq = alpha sq + (1-alpha) g^2; p -= lr g / (sqrt(sq) + eps);

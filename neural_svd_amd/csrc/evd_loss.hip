@@ -9,34 +9,19 @@
 // reduction into the (2 L^2 + 1)-float exchange payload -> loss + gradient.  Rows are staged in LDS;
 // the mask is generated in registers for the sequential / joint(step 1) nestings.
 #include "nsvd_kernels.h"
+#include "evd_math.h"
 
 namespace {
 
-constexpr int CH = 64;       // rows per chunk
-constexpr int MAXL = 128;    // LDS budget: CH * MAXL floats
+constexpr int CH = NSVD_EVD_CH;  // rows per chunk
+constexpr int MAXL = 128;        // LDS budget: CH * MAXL floats
 
-__device__ __forceinline__ float mask_v(int kind, const float* v, int l, int L) {
-    if (kind == NSVD_MASK_SEQUENTIAL) return 1.f;
-    if (kind == NSVD_MASK_JOINT) return (float)(L - l) / (float)L;
-    return v[l];
-}
+__device__ __forceinline__ float mask_v(int kind, const float* v, int l, int L) { return nsvd_mask_v(kind, v, l, L); }
 __device__ __forceinline__ float mask_M(int kind, const float* M, int l, int m, int L) {
-    if (kind == NSVD_MASK_SEQUENTIAL) return l <= m ? 1.f : 0.f;
-    if (kind == NSVD_MASK_JOINT) return (float)(L - max(l, m)) / (float)L;  // min(v_l, v_m)
-    return M[l * L + m];
+    return nsvd_mask_M(kind, M, l, m, L);
 }
-
-struct Chunking {
-    int B1, B2, n1, n2;
-};
-__host__ __device__ inline Chunking chunking(int B) {
-    Chunking c;
-    c.B1 = (B + 1) / 2;  // torch.chunk: first half gets the ceil
-    c.B2 = B - c.B1;
-    c.n1 = (c.B1 + CH - 1) / CH;
-    c.n2 = (c.B2 + CH - 1) / CH;
-    return c;
-}
+typedef NsvdEvdChunking Chunking;
+__host__ __device__ inline Chunking chunking(int B) { return nsvd_evd_chunking(B); }
 __device__ __forceinline__ void chunk_rows(const Chunking& c, int chunk, int& r0, int& r1) {
     if (chunk < c.n1) { r0 = chunk * CH; r1 = min(r0 + CH, c.B1); }
     else { r0 = c.B1 + (chunk - c.n1) * CH; r1 = min(r0 + CH, c.B1 + c.B2); }
@@ -142,12 +127,176 @@ __global__ void __launch_bounds__(256) evd_loss_grad_kernel(const float* __restr
     }
 }
 
+// Single-workgroup variant for small problems (B*L <= FUSED_MAX floats per operand in LDS): moments,
+// loss and (optionally) the gradient in ONE launch - the three-launch pipeline above costs ~5 us per
+// launch for ~0.5 us of work at B = 512, L = 16. STAGE: 1 = moments only (data-parallel stage 1),
+// 3 = moments + loss + gradient (single GPU).
+constexpr int FUSED_MAX = 16384;
+constexpr int FUSED_THREADS = 1024;
+
+template <int STAGE>
+__global__ void __launch_bounds__(FUSED_THREADS) evd_fused_kernel(const float* __restrict__ f,
+                                                                  const float* __restrict__ Tf, int B, int L, int kind,
+                                                                  const float* __restrict__ v,
+                                                                  const float* __restrict__ M, float grad_scale,
+                                                                  float* __restrict__ moments,
+                                                                  float* __restrict__ loss, float* __restrict__ df) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* fs = sm;               // [B][L]
+    float* lam = sm + B * L;      // [2][L][L]
+    float* red = lam + 2 * L * L; // [32]
+    const int tid = threadIdx.x, nt = FUSED_THREADS;
+    const int B1 = (B + 1) / 2, B2 = B - B1, LL = L * L;
+    float op = 0.f;
+    const int n = B * L;
+    if ((n & 3) == 0) {
+        // 16-byte loads, 4 independent pairs in flight per thread: a scalar loop here is a chain of
+        // exposed HBM round trips (8 x ~2 us at B*L = 8192 on an otherwise idle chip)
+        const float4* f4 = reinterpret_cast<const float4*>(f);
+        const float4* T4 = reinterpret_cast<const float4*>(Tf);
+        const int n4 = n >> 2;
+#pragma unroll 4
+        for (int i = tid; i < n4; i += nt) {
+            const float4 a = f4[i], t = T4[i];
+            *reinterpret_cast<float4*>(fs + 4 * i) = a;
+            const int l0 = (4 * i) % L;
+            op = fmaf(mask_v(kind, v, l0, L) * a.x, t.x, op);
+            op = fmaf(mask_v(kind, v, (l0 + 1) % L, L) * a.y, t.y, op);
+            op = fmaf(mask_v(kind, v, (l0 + 2) % L, L) * a.z, t.z, op);
+            op = fmaf(mask_v(kind, v, (l0 + 3) % L, L) * a.w, t.w, op);
+        }
+    } else {
+        for (int i = tid; i < n; i += nt) {
+            const float fv = f[i];
+            fs[i] = fv;
+            op = fmaf(mask_v(kind, v, i % L, L) * fv, Tf[i], op);
+        }
+    }
+    op = nsvd_wave_sum(op);
+    if ((tid & 63) == 0) red[tid >> 6] = op;
+    __syncthreads();
+    // each (half, i, j) moment: split its B/2 rows over `parts` threads when there are spare threads
+    const int outs = 2 * LL;
+    int parts = 1;  // largest power of two <= min(16, threads per output)
+    while (parts * 2 <= 16 && parts * 2 * outs <= nt) parts *= 2;
+    for (int o = tid / parts; o < outs; o += nt / parts) {
+        const int h = o / LL, ij = o - h * LL, i = ij / L, j = ij - i * L;
+        const int r0 = h ? B1 : 0, nr = h ? B2 : B1;
+        const int part = tid % parts;
+        float s = 0.f;
+        for (int r = part; r < nr; r += parts) s = fmaf(fs[(r0 + r) * L + i], fs[(r0 + r) * L + j], s);
+        for (int off = 1; off < parts; off <<= 1) s += __shfl_xor(s, off, 64);  // parts is a power of two <= 16
+        if (part == 0) lam[o] = s / (float)nr;
+    }
+    __syncthreads();
+    float opm = 0.f;
+    if (tid == 0) {
+        for (int w = 0; w < FUSED_THREADS / 64; ++w) opm += red[w];
+        opm /= (float)B;
+    }
+    for (int o = tid; o < outs; o += nt) moments[o] = lam[o];
+    if (tid == 0) moments[2 * LL] = opm;
+    if (STAGE == 1) return;
+    // loss
+    float s = 0.f;
+    for (int o = tid; o < LL; o += nt) s = fmaf(mask_M(kind, M, o / L, o % L, L) * lam[o], lam[LL + o], s);
+    s = nsvd_wave_sum(s);
+    __syncthreads();
+    if ((tid & 63) == 0) red[16 + (tid >> 6)] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float metric = 0.f;
+        for (int w = 0; w < FUSED_THREADS / 64; ++w) metric += red[16 + w];
+        const float oper = -2.f * opm;
+        loss[0] = oper + metric;
+        loss[1] = oper;
+        loss[2] = metric;
+    }
+    if (!df) return;
+    // masked moments in place: lam[h] <- M * lam[h]
+    for (int o = tid; o < outs; o += nt) {
+        const int ij = o % LL;
+        lam[o] *= mask_M(kind, M, ij / L, ij % L, L);
+    }
+    __syncthreads();
+    const float cop = -4.f / (float)B;
+#pragma unroll 4
+    for (int i = tid; i < B * L; i += nt) {
+        const int r = i / L, m = i - r * L;
+        const bool first = r < B1;
+        const float* ML = lam + (first ? LL : 0);  // the OTHER half's moments
+        const float tfv = Tf[i];
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = fmaf(fs[r * L + l], ML[l * L + m], acc);
+        const float g = cop * mask_v(kind, v, m, L) * tfv + (2.f / (float)(first ? B1 : B2)) * acc;
+        df[i] = grad_scale * g;
+    }
+}
+
+bool fused_ok(int B, int L) { return (size_t)B * L <= FUSED_MAX && L <= 64 && B >= 2; }
+
+size_t fused_lds(int B, int L) { return ((size_t)B * L + 2 * (size_t)L * L + 32) * sizeof(float); }
+
+template <int STAGE>
+int launch_fused(const float* f, const float* Tf, int B, int L, int kind, const float* v, const float* M,
+                 float grad_scale, float* moments, float* loss, float* df, hipStream_t s) {
+    const size_t lds = fused_lds(B, L);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)evd_fused_kernel<STAGE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+    }
+    hipLaunchKernelGGL(evd_fused_kernel<STAGE>, dim3(1), dim3(FUSED_THREADS), lds, s, f, Tf, B, L, kind, v, M,
+                       grad_scale, moments, loss, df);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int nsvd_evd_loss_fused(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v,
+                                   const float* M, float grad_scale, float* moments, float* loss, float* df,
+                                   void* scratch, void* stream) {
+    if (!f || !Tf || !moments || !loss || B <= 0 || L <= 0) return NSVD_EINVAL;
+    if (mask_kind < 0 || mask_kind > NSVD_MASK_JOINT) return NSVD_EINVAL;
+    if (mask_kind == NSVD_MASK_CUSTOM && (!v || !M)) return NSVD_EINVAL;
+    if (fused_ok(B, L))
+        return launch_fused<3>(f, Tf, B, L, mask_kind, v, M, grad_scale, moments, loss, df, (hipStream_t)stream);
+    int rc = nsvd_evd_moments(f, Tf, B, L, mask_kind, v, moments, scratch, stream);
+    if (rc) return rc;
+    return nsvd_evd_loss_grad(f, Tf, B, L, mask_kind, v, M, moments, grad_scale, loss, df, stream);
+}
 
 extern "C" size_t nsvd_evd_scratch_bytes(int B, int L) {
     if (B <= 0 || L <= 0) return 0;
     const Chunking c = chunking(B);
     return nsvd_align((size_t)(c.n1 + c.n2) * ((size_t)L * L + 1) * sizeof(float));
+}
+
+int nsvd_evd_reduce_partials(const void* scratch, int B, int L, float* moments, hipStream_t s) {
+    const Chunking c = chunking(B);
+    const float* part = (const float*)scratch;
+    const float* part_op = part + (size_t)(c.n1 + c.n2) * L * L;
+    hipLaunchKernelGGL(evd_reduce_kernel, dim3(nsvd_cdiv(L * L + 1, 256)), dim3(256), 0, s, part, part_op, B, L,
+                       moments);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v,
+                                void* scratch, void* stream) {
+    if (!f || !Tf || !scratch || B <= 0 || L <= 0) return NSVD_EINVAL;
+    if (L > MAXL) return NSVD_EUNSUPPORTED;
+    if (mask_kind == NSVD_MASK_CUSTOM && !v) return NSVD_EINVAL;
+    if (mask_kind < 0 || mask_kind > NSVD_MASK_JOINT) return NSVD_EINVAL;
+    const Chunking c = chunking(B);
+    const int nch = c.n1 + c.n2;
+    float* part = (float*)scratch;
+    float* part_op = part + (size_t)nch * L * L;
+    hipLaunchKernelGGL(evd_partial_kernel, dim3(nch), dim3(256), (size_t)CH * L * sizeof(float), (hipStream_t)stream,
+                       f, Tf, B, L, mask_kind, v, part, part_op);
+    NSVD_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int nsvd_evd_moments(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v,
@@ -156,6 +305,9 @@ extern "C" int nsvd_evd_moments(const float* f, const float* Tf, int B, int L, i
     if (L > MAXL) return NSVD_EUNSUPPORTED;
     if (mask_kind == NSVD_MASK_CUSTOM && !v) return NSVD_EINVAL;
     if (mask_kind < 0 || mask_kind > NSVD_MASK_JOINT) return NSVD_EINVAL;
+    if (fused_ok(B, L))
+        return launch_fused<1>(f, Tf, B, L, mask_kind, v, nullptr, 1.f, moments, nullptr, nullptr,
+                               (hipStream_t)stream);
     const Chunking c = chunking(B);
     const int nch = c.n1 + c.n2;
     float* part = (float*)scratch;

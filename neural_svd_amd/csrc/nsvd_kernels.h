@@ -45,6 +45,9 @@ int nsvd_head_backward(const float* df, const float* jac, const float* dsc, int 
 int nsvd_model_out(const float* base, int ldr, const float* x, const float* scales, float c, int B, int D, int L,
                    float* out, hipStream_t s);
 
+// reduce the per-chunk partial moments of nsvd_evd_partial into the (2 L^2 + 1) vector (evd_loss.hip)
+int nsvd_evd_reduce_partials(const void* scratch, int B, int L, float* moments, hipStream_t s);
+
 // ---- fused MFMA path (pmlp_fused.hip) -----------------------------------------------------------
 bool nsvd_fused_supported(const nsvd_model_desc& d, int B);
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B);
@@ -52,3 +55,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
                        int B, float* f, float* Tf, void* ws, int save, hipStream_t s);
 int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                         int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s);
+struct NsvdEvdIn;  // evd_math.h
+// backward with d loss / d f derived from the EVD moments inside the chain kernel (no df round trip)
+int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
+                            const nsvd_params& g, void* ws, hipStream_t s);

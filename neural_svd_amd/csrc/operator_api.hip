@@ -3,6 +3,7 @@
 // layer-by-layer path implemented here on top of gemm_generic.hip / fd_epilogue.hip.
 #include <string.h>
 #include "nsvd_kernels.h"
+#include "evd_math.h"
 
 static thread_local hipEvent_t g_prof_start = nullptr;
 static thread_local hipEvent_t g_prof_stop = nullptr;
@@ -30,6 +31,7 @@ struct GenericWs {
     float* jac;                       // (B, L)
     float* dsc;                       // (B, L)
     float* dz[2];                     // ping-pong (L, hmax, B)
+    float* df;                        // (B, L) for nsvd_operator_backward_evd on the generic path
     size_t bytes;
 };
 
@@ -65,6 +67,7 @@ GenericWs carve(const nsvd_model_desc& d, int B, void* base) {
     w.dsc = take((size_t)B * d.L);
     w.dz[0] = take((size_t)d.L * hmax * B);
     w.dz[1] = take((size_t)d.L * hmax * B);
+    w.df = take((size_t)B * d.L);
     w.bytes = off;
     return w;
 }
@@ -228,4 +231,54 @@ extern "C" int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_pa
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
     if (fused) return nsvd_fused_backward(*desc, *params, *prob, x, B, df, *grads, ws, (hipStream_t)stream);
     return generic_backward(*desc, *params, x, B, df, *grads, ws, (hipStream_t)stream);
+}
+
+extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsvd_params* params,
+                                          const nsvd_problem* prob, const float* x, int B, const float* f,
+                                          const float* Tf, int mask_kind, const float* v, const float* M,
+                                          float* moments, int moments_reduced, const void* evd_scratch,
+                                          float grad_scale, float* loss, const nsvd_params* grads, void* ws,
+                                          size_t ws_bytes, int path, void* stream) {
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!prob || !x || !f || !Tf || !moments || !ws || B <= 0) return NSVD_EINVAL;
+    if (!moments_reduced && !evd_scratch) return NSVD_EINVAL;
+    if (mask_kind < 0 || mask_kind > NSVD_MASK_JOINT) return NSVD_EINVAL;
+    if (mask_kind == NSVD_MASK_CUSTOM && (!v || !M)) return NSVD_EINVAL;
+    rc = check_params(*desc, params, true);
+    if (rc) return rc;
+    rc = check_params(*desc, grads, false);
+    if (rc) return rc;
+    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = want_fused(*desc, B, path);
+    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    const int L = desc->L;
+    const NsvdEvdChunking c = nsvd_evd_chunking(B);
+    if (fused) {
+        NsvdEvdIn in;
+        memset(&in, 0, sizeof(in));
+        in.f = f; in.Tf = Tf; in.v = v; in.M = M;
+        in.kind = mask_kind;
+        in.grad_scale = grad_scale;
+        in.loss = loss;
+        if (moments_reduced) {
+            in.moments = moments;
+        } else {
+            in.part = (const float*)evd_scratch;
+            in.part_op = in.part + (size_t)(c.n1 + c.n2) * L * L;
+            in.moments_out = moments;
+        }
+        return nsvd_fused_backward_evd(*desc, *params, B, in, *grads, ws, s);
+    }
+    // generic path: finish the loss with the stand-alone kernels, then the layer-by-layer backward
+    const GenericWs w = carve(*desc, B, ws);
+    if (!moments_reduced) {
+        rc = nsvd_evd_reduce_partials(evd_scratch, B, L, moments, s);
+        if (rc) return rc;
+    }
+    rc = nsvd_evd_loss_grad(f, Tf, B, L, mask_kind, v, M, moments, grad_scale, loss, w.df, stream);
+    if (rc) return rc;
+    return generic_backward(*desc, *params, x, B, w.df, *grads, ws, s);
 }

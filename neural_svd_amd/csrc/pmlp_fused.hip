@@ -22,6 +22,7 @@
 #include <string.h>
 #include "nsvd_kernels.h"
 #include "fd_math.h"
+#include "evd_math.h"
 
 namespace {
 
@@ -422,12 +423,17 @@ int launch_fwd(const FwdArgs& a, hipStream_t s) {
 // This is autograd's backward of reference mlp.py:204-221 for the centre evaluation only (the 2D
 // shifted evaluations carry no gradient: nestedlora.py:108-111) and of pde/__init__.py:16.
 struct ChainArgs {
-    const float* df;
+    const float* df;             // (B, L) d loss / d f, or null: derive it from the moments below
     const float* jac;
+    const float* dsc;            // null without the exponential mask
     const float* W[NSVD_MAX_LAYERS];
     const float* zsave[NSVD_MAX_LAYERS];
     float* dz[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer
+    float* dbase;                // (L, B)  df * d f / d base    (for the last-layer gradient)
+    float* dfsc;                 // (L, B)  df * d f / d scales  (exponential mask only)
     int nlayers, B, L;
+    // EVD-loss mode (df == null): NestedLoRALossFunctionEVD.backward evaluated per sample right here
+    NsvdEvdIn evd;
 };
 
 __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
@@ -442,7 +448,36 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
     const int b = b0 + li;
     const size_t row0 = ((size_t)l * HID + 32 * w) * a.B + b;
 
-    const float dbase = a.df[(size_t)b * a.L + l] * a.jac[(size_t)b * a.L + l];
+    float dfv;
+    if (a.df) {
+        dfv = a.df[(size_t)b * a.L + l];
+    } else {
+        // d loss / d f[b][l] = gs * ( -(4/B) v_l Tf[b][l] + (2/B_half) sum_l' f[b][l'] M[l'][l] lam_other[l'][l] )
+        // (reference methods/nestedlora.py:98-111 with f1, f2 = chunk(f, 2)); the moments are either the
+        // reduced / all-reduced vector or this rank's per-chunk partial sums (reduced here, in a fixed order)
+        float* col = DZ;  // [2][L] masked moment columns of head l (LDS scratch, free until the first exchange)
+        const int B1 = (a.B + 1) / 2, B2 = a.B - B1, LL = a.L * a.L;
+        for (int t = tid; t < 2 * a.L; t += 256) {
+            const int h = t / a.L, lp = t - h * a.L;  // h = 0: lam_f1 column, 1: lam_f2 column
+            col[t] = nsvd_evd_mask_M(a.evd, lp, l, a.L) * nsvd_evd_lam(a.evd, h, lp * a.L + l, a.B, a.L);
+        }
+        if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, a.L, DZ + 256);
+        __syncthreads();
+        const bool first = b < B1;
+        const float* cp = col + (first ? a.L : 0);  // the OTHER half's moments
+        const float* fr = a.evd.f + (size_t)b * a.L;
+        float acc = 0.f;
+        for (int lp = 0; lp < a.L; ++lp) acc = fmaf(fr[lp], cp[lp], acc);
+        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, l, a.L) * a.evd.Tf[(size_t)b * a.L + l] +
+                                  (2.f / (float)(first ? B1 : B2)) * acc);
+        (void)LL;
+        __syncthreads();  // col[] is dead before DZ is reused
+    }
+    const float dbase = dfv * a.jac[(size_t)b * a.L + l];
+    if (w == 0 && hi == 0) {
+        a.dbase[(size_t)l * a.B + b] = dbase;
+        if (a.dfsc) a.dfsc[(size_t)l * a.B + b] = dfv * a.dsc[(size_t)b * a.L + l];
+    }
     float dz[16];
     {
         const float* zp = a.zsave[nh - 1] + row0;
@@ -505,9 +540,8 @@ struct WgradArgs {
     const float* dz[NSVD_MAX_LAYERS];     // (L, 128, B)
     const float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B)
     const float* phiTc;                   // (F, B)
-    const float* df;
-    const float* jac;
-    const float* dsc;                     // null without the exponential mask
+    const float* dbase;                   // (L, B) from the chain kernel
+    const float* dfsc;                    // (L, B), null without the exponential mask
     float* gW[NSVD_MAX_LAYERS];
     float* gb[NSVD_MAX_LAYERS];
     float* gscales;
@@ -545,80 +579,121 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
     const float* a_src = a.dz[0] + ((size_t)l * HID + s_row) * a.B + 4 * s_c4;
     const float* b_src = a.phiTc + (size_t)(kf0 + s_row) * a.B + 4 * s_c4;
     const size_t step = (size_t)32 * a.B;
-    // two register sets (P, Q): chunk c+2 is fetched while chunk c is multiplied and chunk c+1 sits in
-    // the other LDS buffer, so a load has two chunk-times (~3.5 us) to land
-    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
-    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    // Same software pipeline as the forward's layer 0: fragments one q-group ahead, chunk c+1 written to
+    // the other LDS buffer under chunk c's third q-group, chunk c+2 fetched from global under its fourth
+    // (after the barrier), every memory instruction in an MFMA gap, branch-free steady state.
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;  // bias gradient partials (only used when kf0 == 0)
-#define WA_LOAD(S, c)                                              \
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define WA_LOAD(c)                                                 \
     {                                                              \
         const float* pa_ = a_src + (c) * BK;                       \
         const float* pb_ = b_src + (c) * BK;                       \
-        WG_LD(S##a0, pa_);                                         \
-        WG_LD(S##a1, pa_ + step);                                  \
-        WG_LD(S##a2, pa_ + 2 * step);                              \
-        WG_LD(S##a3, pa_ + 3 * step);                              \
-        WG_LD(S##b0, pb_);                                         \
-        WG_LD(S##b1, pb_ + step);                                  \
-        WG_LD(S##b2, pb_ + 2 * step);                              \
-        WG_LD(S##b3, pb_ + 3 * step);                              \
+        WG_LD(ra0, pa_);                                           \
+        WG_LD(ra1, pa_ + step);                                    \
+        WG_LD(ra2, pa_ + 2 * step);                                \
+        WG_LD(ra3, pa_ + 3 * step);                                \
+        WG_LD(rb0, pb_);                                           \
+        WG_LD(rb1, pb_ + step);                                    \
+        WG_LD(rb2, pb_ + 2 * step);                                \
+        WG_LD(rb3, pb_ + 3 * step);                                \
     }
-#define WA_STORE(S, buf)                                                           \
+#define WA_STORE(buf)                                                              \
     {                                                                              \
         float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
         float* Bb_ = Bs + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
-        WG_ST(Ab_, S##a0);                                                         \
-        WG_ST(Ab_ + 32 * A_LD, S##a1);                                             \
-        WG_ST(Ab_ + 64 * A_LD, S##a2);                                             \
-        WG_ST(Ab_ + 96 * A_LD, S##a3);                                             \
-        WG_ST(Bb_, S##b0);                                                         \
-        WG_ST(Bb_ + 32 * A_LD, S##b1);                                             \
-        WG_ST(Bb_ + 64 * A_LD, S##b2);                                             \
-        WG_ST(Bb_ + 96 * A_LD, S##b3);                                             \
-        rs0 += (S##a0.x + S##a0.y) + (S##a0.z + S##a0.w);                          \
-        rs1 += (S##a1.x + S##a1.y) + (S##a1.z + S##a1.w);                          \
-        rs2 += (S##a2.x + S##a2.y) + (S##a2.z + S##a2.w);                          \
-        rs3 += (S##a3.x + S##a3.y) + (S##a3.z + S##a3.w);                          \
+        WG_ST(Ab_, ra0);                                                           \
+        WG_ST(Ab_ + 32 * A_LD, ra1);                                               \
+        WG_ST(Ab_ + 64 * A_LD, ra2);                                               \
+        WG_ST(Ab_ + 96 * A_LD, ra3);                                               \
+        WG_ST(Bb_, rb0);                                                           \
+        WG_ST(Bb_ + 32 * A_LD, rb1);                                               \
+        WG_ST(Bb_ + 64 * A_LD, rb2);                                               \
+        WG_ST(Bb_ + 96 * A_LD, rb3);                                               \
+        rs0 += (ra0.x + ra0.y) + (ra0.z + ra0.w);                                  \
+        rs1 += (ra1.x + ra1.y) + (ra1.z + ra1.w);                                  \
+        rs2 += (ra2.x + ra2.y) + (ra2.z + ra2.w);                                  \
+        rs3 += (ra3.x + ra3.y) + (ra3.z + ra3.w);                                  \
     }
-#define WA_COMPUTE(cur)                                                                                      \
-    {                                                                                                        \
-        const float* Ap = As + (cur) * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;                          \
-        const float* Bp = Bs + (cur) * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;                          \
-        _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                                 \
-            const float4 a0 = *reinterpret_cast<const float4*>(Ap + 8 * q);                                  \
-            const float4 a1 = *reinterpret_cast<const float4*>(Ap + 32 * A_LD + 8 * q);                      \
-            const float4 b0v = *reinterpret_cast<const float4*>(Bp + 8 * q);                                 \
-            const float4 b1v = *reinterpret_cast<const float4*>(Bp + 32 * A_LD + 8 * q);                     \
-            WA_MMA(x) WA_MMA(y) WA_MMA(z) WA_MMA(w)                                                          \
-        }                                                                                                    \
+    struct F4 {
+        float4 a0, a1, b0, b1;
+    };
+#define WA_READ(f, Ap, Bp, q)                                                      \
+    {                                                                              \
+        f.a0 = *reinterpret_cast<const float4*>((Ap) + 8 * (q));                   \
+        f.a1 = *reinterpret_cast<const float4*>((Ap) + 32 * A_LD + 8 * (q));       \
+        f.b0 = *reinterpret_cast<const float4*>((Bp) + 8 * (q));                   \
+        f.b1 = *reinterpret_cast<const float4*>((Bp) + 32 * A_LD + 8 * (q));       \
     }
-#define WA_MMA(X)                                                                                       \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.X, b0v.X, acc[0][0], 0, 0, 0);                 \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.X, b1v.X, acc[0][1], 0, 0, 0);                 \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.X, b0v.X, acc[1][0], 0, 0, 0);                 \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.X, b1v.X, acc[1][1], 0, 0, 0);
+#define WA_MMA1(f, X)                                                                                   \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0][0], 0, 0, 0);              \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[0][1], 0, 0, 0);              \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[1][0], 0, 0, 0);              \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[1][1], 0, 0, 0);
+#define WA_MMA(f) WA_MMA1(f, x) WA_MMA1(f, y) WA_MMA1(f, z) WA_MMA1(f, w)
+#define WA_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WA_IL(n, mask)                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+        __builtin_amdgcn_sched_group_barrier((mask), 1, 0);        \
+    }
+#define WA_BODY(c, DO_STORE, DO_LOAD)                                                           \
+    {                                                                                           \
+        const int cur = (c) & 1;                                                                \
+        const float* Ap = As + cur * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;               \
+        const float* Bp = Bs + cur * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;               \
+        WA_READ(f1, Ap, Bp, 1);                                                                 \
+        WA_MMA(f0);                                                                             \
+        WA_IL(4, 0x100);                                                                        \
+        WA_FENCE();                                                                             \
+        WA_READ(f0, Ap, Bp, 2);                                                                 \
+        WA_MMA(f1);                                                                             \
+        WA_IL(4, 0x100);                                                                        \
+        WA_FENCE();                                                                             \
+        WA_READ(f1, Ap, Bp, 3);                                                                 \
+        if (DO_STORE) WA_STORE(cur ^ 1);                                                        \
+        WA_MMA(f0);                                                                             \
+        WA_IL(4, 0x100);                                                                        \
+        if (DO_STORE) WA_IL(8, 0x200);                                                          \
+        WA_FENCE();                                                                             \
+        __syncthreads();                                                                        \
+        if (DO_STORE) {                                                                         \
+            const float* An = As + (cur ^ 1) * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;     \
+            const float* Bn = Bs + (cur ^ 1) * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;     \
+            WA_READ(f0, An, Bn, 0);                                                             \
+        }                                                                                       \
+        if (DO_LOAD) WA_LOAD((c) + 2);                                                          \
+        WA_MMA(f1);                                                                             \
+        if (DO_STORE) WA_IL(4, 0x100);                                                          \
+        if (DO_LOAD) WA_IL(8, 0x020);                                                           \
+        WA_FENCE();                                                                             \
+    }
     const int nch = a.B / BK;
-    pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = pb2 = pb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    WA_LOAD(p, 0);
-    if (nch > 1) WA_LOAD(q, 1);
-    WA_STORE(p, 0);
+    WA_LOAD(0);
+    WA_STORE(0);
     __syncthreads();
-    // chunk c lives in LDS buffer c & 1; registers P hold even chunks, Q odd chunks
-    for (int c = 0; c < nch; c += 2) {
-        if (c + 2 < nch) WA_LOAD(p, c + 2);
-        WA_COMPUTE(0);
-        if (c + 1 < nch) WA_STORE(q, 1);
-        __syncthreads();
-        if (c + 1 < nch) {
-            if (c + 3 < nch) WA_LOAD(q, c + 3);
-            WA_COMPUTE(1);
-            if (c + 2 < nch) WA_STORE(p, 0);
-            __syncthreads();
-        }
+    if (nch > 1) WA_LOAD(1);
+    F4 f0, f1;
+    {
+        const float* Ap = As + (64 * wm + li) * A_LD + 4 * hi;
+        const float* Bp = Bs + (64 * wn + li) * A_LD + 4 * hi;
+        WA_READ(f0, Ap, Bp, 0);
     }
+    {
+        int c = 0;
+        for (; c + 2 < nch; ++c) WA_BODY(c, true, true)
+        if (c + 1 < nch) {
+            WA_BODY(c, true, false)
+            ++c;
+        }
+        WA_BODY(c, false, false)
+    }
+#undef WA_BODY
+#undef WA_IL
+#undef WA_FENCE
 #undef WA_MMA
-#undef WA_COMPUTE
+#undef WA_MMA1
+#undef WA_READ
 #undef WA_LOAD
 #undef WA_STORE
     float* o = a.gW[0] + ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
@@ -748,11 +823,10 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
     float* dbl = lds + 16;       // [B] dbase of this head (B <= 2 * 128 * 36 - 16 floats, checked on the host)
     float sb = 0.f, ss = 0.f;
     for (int b = tid; b < a.B; b += 256) {
-        const float dfv = a.df[(size_t)b * a.L + l];
-        const float v = dfv * a.jac[(size_t)b * a.L + l];
+        const float v = a.dbase[(size_t)l * a.B + b];
         dbl[b] = v;
         sb += v;
-        if (a.dsc) ss += dfv * a.dsc[(size_t)b * a.L + l];
+        if (a.dfsc) ss += a.dfsc[(size_t)l * a.B + b];
     }
     sb = nsvd_wave_sum(sb);
     ss = nsvd_wave_sum(ss);
@@ -818,6 +892,8 @@ struct FusedWs {
     float* jac;                       // (B, L)
     float* dsc;                       // (B, L)
     float* dz[NSVD_MAX_LAYERS];       // (L, 128, B) per hidden layer
+    float* dbase;                     // (L, B)
+    float* dfsc;                      // (L, B)
     size_t bytes;
 };
 
@@ -838,6 +914,8 @@ FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     w.jac = take((size_t)B * d.L);
     w.dsc = take((size_t)B * d.L);
     for (int i = 0; i < d.nlayers - 1; ++i) w.dz[i] = take((size_t)d.L * HID * B);
+    w.dbase = take((size_t)B * d.L);
+    w.dfsc = take((size_t)B * d.L);
     w.bytes = off;
     return w;
 }
@@ -896,17 +974,19 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     return NSVD_EUNSUPPORTED;
 }
 
-int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
-                        int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s) {
-    (void)prob;
-    (void)x;
+static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, int B, const float* df,
+                               const NsvdEvdIn* evd, const nsvd_params& g, void* ws, hipStream_t s) {
     const FusedWs w = carve_fused(d, B, ws);
     const int F = 2 * d.m, nh = d.nlayers - 1;
 
     ChainArgs a;
     memset(&a, 0, sizeof(a));
     a.df = df;
+    if (evd) a.evd = *evd;
     a.jac = w.jac;
+    a.dsc = d.has_exp_mask ? w.dsc : nullptr;
+    a.dbase = w.dbase;
+    a.dfsc = d.has_exp_mask ? w.dfsc : nullptr;
     for (int i = 0; i < d.nlayers; ++i) {
         a.W[i] = p.W[i];
         a.zsave[i] = (i < nh) ? w.zsave[i] : nullptr;
@@ -925,27 +1005,28 @@ int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const ns
         wa.gb[i] = g.b[i];
     }
     wa.phiTc = w.phiTc;
-    wa.df = df;
-    wa.jac = w.jac;
-    wa.dsc = d.has_exp_mask ? w.dsc : nullptr;
+    wa.dbase = w.dbase;
+    wa.dfsc = d.has_exp_mask ? w.dfsc : nullptr;
     wa.gscales = d.has_exp_mask ? g.scales : nullptr;
     wa.nlayers = d.nlayers; wa.B = B; wa.L = d.L; wa.F = F;
     wa.nA = (F / HID) * d.L;
     wa.nB = 4 * (nh - 1) * d.L;
-    // Two launches of the same kernel: the 128x128 dW_0 tiles with 16 KB of extra dynamic LDS so that
-    // exactly one lands on each CU (two co-resident tiles share the CU's matrix pipes and leave other CUs
-    // idle: 72 us vs 41 us measured), then the small dW_i / db / last-layer workgroups.
-    const char* ev = getenv("NSVD_WGRAD_MODE");
-    const int mode = ev ? atoi(ev) : 0;
-    if (mode == 0) {
-        wa.bid0 = 0;
-        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA + wa.nB + d.L), dim3(256), 0, s, wa);
-    } else {
-        wa.bid0 = 0;
-        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA), dim3(256), mode == 1 ? 16384 : 0, s, wa);
-        wa.bid0 = wa.nA;
-        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nB + d.L), dim3(256), 0, s, wa);
-    }
+    // One launch: the 256 dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
+    // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
+    wa.bid0 = 0;
+    hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA + wa.nB + d.L), dim3(256), 0, s, wa);
     NSVD_CHECK_LAUNCH();
     return 0;
+}
+
+int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                        int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s) {
+    (void)prob;
+    (void)x;
+    return fused_backward_impl(d, p, B, df, nullptr, g, ws, s);
+}
+
+int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
+                            const nsvd_params& g, void* ws, hipStream_t s) {
+    return fused_backward_impl(d, p, B, nullptr, &evd, g, ws, s);
 }

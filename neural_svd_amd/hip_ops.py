@@ -221,6 +221,41 @@ def evd_loss_grad(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional
     return loss, (df if want_grad else None)
 
 
+def evd_loss_fused(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                   M: Optional[torch.Tensor], moments: torch.Tensor, loss: torch.Tensor, df: Optional[torch.Tensor],
+                   scratch: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """moments + loss + d loss / d f in one call (single GPU: nothing is exchanged in between)."""
+    B, L = f.shape
+    rc = _lib.load().nsvd_evd_loss_fused(_ptr(f, "f"), _ptr(Tf, "Tf"), B, L, int(mask_kind), _ptr(v, "v"),
+                                         _ptr(M, "M"), float(grad_scale), _ptr(moments, "moments"),
+                                         _ptr(loss, "loss"), _ptr(df, "df"), scratch.data_ptr(), _stream())
+    check(rc, "nsvd_evd_loss_fused")
+
+
+def evd_partial(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                scratch: torch.Tensor) -> None:
+    B, L = f.shape
+    rc = _lib.load().nsvd_evd_partial(_ptr(f, "f"), _ptr(Tf, "Tf"), B, L, int(mask_kind), _ptr(v, "v"),
+                                      scratch.data_ptr(), _stream())
+    check(rc, "nsvd_evd_partial")
+
+
+def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, f: torch.Tensor,
+                          Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor], M: Optional[torch.Tensor],
+                          moments: torch.Tensor, moments_reduced: bool, evd_scratch: Optional[torch.Tensor],
+                          loss: torch.Tensor, grads: Params, ws: torch.Tensor, grad_scale: float = 1.0,
+                          path: int = PATH_AUTO) -> None:
+    """loss gradient + operator backward in one call (d loss / d f is never materialised)."""
+    B = x.shape[0]
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_backward_evd(
+        C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
+        _ptr(v, "v"), _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
+        evd_scratch.data_ptr() if evd_scratch is not None else None, float(grad_scale), _ptr(loss, "loss"),
+        C.byref(grads), ws.data_ptr(), ws.numel(), int(path), _stream())
+    check(rc, "nsvd_operator_backward_evd")
+
+
 def rmsprop_ema_step(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, ema: Optional[torch.Tensor], lr: float,
                      alpha: float, eps: float, ema_decay: float, grad_scale: float = 1.0) -> None:
     n = p.numel()

@@ -140,19 +140,23 @@ class FusedTrainer:
     # -- stages -------------------------------------------------------------------------------
     def sample(self) -> torch.Tensor:
         """x = sigma * randn(B, D) on the device (reference: host randn + H2D copy, main_pde.py:92-93)."""
-        torch.randn(self.x.shape, generator=self.gen, out=self.x, device=self.device)
-        self.x.mul_(self.sigma)
+        self.x.normal_(0.0, self.sigma, generator=self.gen)  # one kernel (randn + scale)
         return self.x
 
     def forward_backward(self, x: torch.Tensor) -> None:
         H.operator_forward(self.shape, self._params, self.problem, x, self.ws, True, self.path, out=(self.f, self.Tf))
         cust = self.mask_kind == H.MASK_CUSTOM
-        H.evd_moments(self.f, self.Tf, self.mask_kind, self.v_dev if cust else None, self.moments, self.scratch)
+        v, M = (self.v_dev, self.M_dev) if cust else (None, None)
         if self.comm is not None and self.comm.world > 1:
+            H.evd_moments(self.f, self.Tf, self.mask_kind, v, self.moments, self.scratch)
             self.comm.all_reduce_mean(self.moments)
-        H.evd_loss_grad(self.f, self.Tf, self.mask_kind, self.v_dev if cust else None, self.M_dev if cust else None,
-                        self.moments, 1.0, True, self.loss, self.df)
-        H.operator_backward(self.shape, self._params, self.problem, x, self.df, self._grads, self.ws, self.path)
+            reduced = True
+        else:
+            H.evd_partial(self.f, self.Tf, self.mask_kind, v, self.scratch)
+            reduced = False
+        # loss + d loss / d f are evaluated inside the backward kernels from the moments
+        H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f, self.Tf, self.mask_kind, v, M,
+                                self.moments, reduced, self.scratch, self.loss, self._grads, self.ws, 1.0, self.path)
 
     def optimizer_step(self) -> None:
         gscale = 1.0

@@ -152,6 +152,13 @@ def test_evd_loss_golden(case):
         assert abs(float(loss[0]) - float(z[p + "loss"])) < 2e-5 * max(1.0, abs(float(z[p + "loss"])))
         assert abs(float(loss[1]) + float(loss[2]) - float(loss[0])) < 1e-4 * max(1.0, abs(float(loss[0])))
         assert rel(df, z[p + "grad_f"]) < 2e-6
+    # one-call variant (single launch at these sizes)
+    mom_f = torch.empty_like(mom)
+    loss_f = torch.empty(3, device=DEV)
+    df_f = torch.empty_like(f)
+    H.evd_loss_fused(f, Tf, H.MASK_CUSTOM, v, M, mom_f, loss_f, df_f, H.evd_scratch(B, L, DEV))
+    assert rel(df_f, z[p + "grad_f"]) < 2e-6 and rel(mom_f[:2 * L * L], mom[:2 * L * L]) < 1e-6
+    assert abs(float(loss_f[0]) - float(z[p + "loss"])) < 2e-5 * max(1.0, abs(float(z[p + "loss"])))
     # grad_scale and loss-only call
     loss2, none = H.evd_loss_grad(f, Tf, H.MASK_CUSTOM, v, M, mom, want_grad=False)
     assert none is None and float(loss2[0]) == float(loss[0])
@@ -172,6 +179,10 @@ def test_evd_loss_large_L_and_B():
     l, df = H.evd_loss_grad(fd, Td, H.MASK_JOINT, None, None, mom)
     assert abs(float(l[0]) - float(loss)) < 1e-5 * abs(float(loss))
     assert rel(df, gref) < 5e-6
+    # the one-call API falls back to the multi-launch pipeline at this size
+    mom2, l2, df2 = torch.empty_like(mom), torch.empty(3, device=DEV), torch.empty_like(fd)
+    H.evd_loss_fused(fd, Td, H.MASK_JOINT, None, None, mom2, l2, df2, H.evd_scratch(B, L, DEV))
+    assert torch.equal(df2, df) and torch.equal(l2, l)
 
 
 # ------------------------------------------------------------------------------ operator fwd/bwd on the goldens
@@ -262,6 +273,50 @@ def test_backward_given_df_headline(path):
     r = run_hip(p, prob, x, v, M, _path(path), df_override=ref["df"])
     for i, (g, gr) in enumerate(zip(r["grads"], ref["grads"])):
         assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, (i, rel(g.view(-1), gr.reshape(-1)))
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("case,fn", [("osc_small", "model_small"), ("hyd_ragged", "model_small"),
+                                     ("hyd_med", "model_headline")])
+def test_backward_evd_matches_two_step(case, fn, path):
+    """nsvd_operator_backward_evd (loss gradient evaluated inside the backward kernels, from partial or
+    reduced moments) == nsvd_evd_loss_grad followed by nsvd_operator_backward."""
+    z = G.load(fn)
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    p = G.params_from_golden(z, case) if fn == "model_small" else G.params_from_seed(cfg)
+    v, M = G.masks_of(z, case)
+    x = torch.tensor(z[f"{case}_x"][0])
+    two = run_hip(p, prob, x, v, M, _path(path))
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    hp = hip_problem(prob)
+    xd = x.float().to(DEV).contiguous()
+    B, L = xd.shape[0], shape.L
+    vd, Md = v.float().to(DEV), M.float().to(DEV).contiguous()
+    for reduced in (False, True):
+        gw = [torch.full_like(w, float("nan")) for w in ws_t]
+        gb = [torch.full_like(b, float("nan")) for b in bs_t]
+        gs = None if sc is None else torch.full_like(sc, float("nan"))
+        grads = H.pack_params(shape, gw, gb, None, gs)
+        ws = H.new_workspace(shape, B, DEV)
+        f, Tf = H.operator_forward(shape, params, hp, xd, ws, path=_path(path))
+        scratch = H.evd_scratch(B, L, DEV)
+        mom = torch.full((2 * L * L + 1,), float("nan"), device=DEV)
+        loss = torch.empty(3, device=DEV)
+        if reduced:
+            H.evd_moments(f, Tf, H.MASK_CUSTOM, vd, mom, scratch)
+        else:
+            H.evd_partial(f, Tf, H.MASK_CUSTOM, vd, scratch)
+        H.operator_backward_evd(shape, params, hp, xd, f, Tf, H.MASK_CUSTOM, vd, Md, mom, reduced, scratch, loss,
+                                grads, ws, 1.0, _path(path))
+        torch.cuda.synchronize()
+        assert rel(mom, two["mom"]) < 1e-6
+        assert abs(float(loss[0]) - float(two["loss"][0])) <= 1e-5 * abs(float(two["loss"][0]))
+        for i, (g, g2) in enumerate(zip(gw + gb + ([gs] if gs is not None else []), two["grads"])):
+            assert torch.isfinite(g).all()
+            assert rel(g, g2) < 2e-5, (i, reduced, rel(g, g2))
 
 
 def test_edge_cases_clamp_and_origin():
