@@ -112,6 +112,17 @@ size_t nsvd_workspace_bytes(const nsvd_model_desc* desc, int B);
 int nsvd_fourier_features(const float* x, const float* fourier_B, float* phiT, int B, int D, int m,
                           float eps, int nstencil, int ldr, void* stream);
 
+/* bit for nsvd_operator_forward's save_for_backward argument: the Fourier features of x are already in
+ * the workspace (put there by nsvd_operator_features, typically on another stream while the previous
+ * step's optimiser runs - they do not depend on the trainable weights) */
+#define NSVD_FEATURES_READY 0x100
+
+/* The weight-independent prologue of nsvd_operator_forward alone: Fourier features of the stencil rows of
+ * x into `ws`, in the layout the path selected by (desc, B, path) reads. */
+int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_params* params, const nsvd_problem* prob,
+                           const float* x, int B, void* ws, size_t ws_bytes, int save_for_backward, int path,
+                           void* stream);
+
 /* Tf, f = operator(method, x, importance):  the 1+2D ParallelMLP evaluations, importance
  * re-weighting, central-difference Laplacian, potential, scale/shift
  * (examples/__init__.py:7-9 -> schrodinger/__init__.py:16-22 -> diff_ops.py:9-52 ->

@@ -18,6 +18,7 @@ EUNSUPPORTED = -10002
 POT_HYDROGEN, POT_HARMONIC = 0, 1
 MASK_CUSTOM, MASK_SEQUENTIAL, MASK_JOINT = 0, 1, 2
 PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
+FEATURES_READY = 0x100
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # NSVD_LIB_PATH: diagnostic builds only (e.g. the stamped kernels of scripts/dev_stamps.py)
@@ -49,6 +50,8 @@ SIGNATURES = {
     "nsvd_fourier_features": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
     "nsvd_operator_forward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _P,
                                    _P, _Z, _I, _I, _P]),
+    "nsvd_operator_features": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _Z, _I,
+                                    _I, _P]),
     "nsvd_operator_backward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
                                     C.POINTER(Params), _P, _Z, _I, _P]),
     "nsvd_model_forward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), _P, _I, _F, _P, _P, _Z, _I, _P]),

@@ -51,6 +51,10 @@ int nsvd_evd_reduce_partials(const void* scratch, int B, int L, float* moments, 
 // ---- fused MFMA path (pmlp_fused.hip) -----------------------------------------------------------
 bool nsvd_fused_supported(const nsvd_model_desc& d, int B);
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B);
+// Fourier features of x into the fused path's workspace (phi, and phiT_c when save != 0)
+int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                        int B, void* ws, int save, hipStream_t s);
+// save: bit 0 = keep what the backward needs, bit 1 = features already prepared by nsvd_fused_features
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                        int B, float* f, float* Tf, void* ws, int save, hipStream_t s);
 int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,

@@ -88,9 +88,10 @@ int check_params(const nsvd_model_desc& d, const nsvd_params* p, bool need_fouri
 
 // Fourier map + every ParallelMLP layer for the first `nst` stencil blocks (nst = E: all rows, 1: centre only)
 int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float eps, int nst,
-                const GenericWs& w, hipStream_t s) {
+                const GenericWs& w, hipStream_t s, bool features_ready = false) {
     const int E = 1 + 2 * d.D, R = E * B, F = 2 * d.m;
-    int rc = nsvd_fourier_features(x, p.fourier_B, w.phiT, B, d.D, d.m, eps, nst, R, s);
+    int rc = 0;
+    if (!features_ready) rc = nsvd_fourier_features(x, p.fourier_B, w.phiT, B, d.D, d.m, eps, nst, R, s);
     if (rc) return rc;
     int kin = F;
     for (int i = 0; i < d.nlayers; ++i) {
@@ -112,10 +113,10 @@ int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, 
 }
 
 int generic_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x, int B,
-                    float* f, float* Tf, void* ws, hipStream_t s) {
+                    float* f, float* Tf, void* ws, hipStream_t s, bool features_ready = false) {
     const GenericWs w = carve(d, B, ws);
     const int E = 1 + 2 * d.D, R = E * B;
-    int rc = generic_mlp(d, p, x, B, prob.eps, E, w, s);
+    int rc = generic_mlp(d, p, x, B, prob.eps, E, w, s, features_ready);
     if (rc) return rc;
     return nsvd_fd_epilogue(w.z[d.nlayers - 1], R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
                             w.jac, w.dsc, s);
@@ -192,8 +193,27 @@ extern "C" int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_par
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     const bool fused = want_fused(*desc, B, path);
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
-    if (fused) return nsvd_fused_forward(*desc, *params, *prob, x, B, f, Tf, ws, save_for_backward, (hipStream_t)stream);
-    return generic_forward(*desc, *params, *prob, x, B, f, Tf, ws, (hipStream_t)stream);
+    const bool ready = (save_for_backward & NSVD_FEATURES_READY) != 0;
+    if (fused)
+        return nsvd_fused_forward(*desc, *params, *prob, x, B, f, Tf, ws, (save_for_backward & 1) | (ready ? 2 : 0),
+                                  (hipStream_t)stream);
+    return generic_forward(*desc, *params, *prob, x, B, f, Tf, ws, (hipStream_t)stream, ready);
+}
+
+extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_params* params,
+                                      const nsvd_problem* prob, const float* x, int B, void* ws, size_t ws_bytes,
+                                      int save_for_backward, int path, void* stream) {
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!prob || !x || !ws || !params || !params->fourier_B || B <= 0) return NSVD_EINVAL;
+    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    const bool fused = want_fused(*desc, B, path);
+    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if (fused) return nsvd_fused_features(*desc, *params, *prob, x, B, ws, save_for_backward & 1, (hipStream_t)stream);
+    const GenericWs w = carve(*desc, B, ws);
+    const int E = 1 + 2 * desc->D;
+    return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
 }
 
 extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,

@@ -934,16 +934,26 @@ bool nsvd_fused_supported(const nsvd_model_desc& d, int B) {
 
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B) { return carve_fused(d, B, nullptr).bytes; }
 
+int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                        int B, void* ws, int save, hipStream_t s) {
+    const FusedWs w = carve_fused(d, B, ws);
+    const int E = 1 + 2 * d.D;
+    int rc = nsvd_fourier_rows(x, p.fourier_B, w.phi, B, d.D, d.m, prob.eps, E, s);
+    if (rc) return rc;
+    if (save) rc = nsvd_fourier_features(x, p.fourier_B, w.phiTc, B, d.D, d.m, prob.eps, 1, B, s);
+    return rc;
+}
+
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                        int B, float* f, float* Tf, void* ws, int save, hipStream_t s) {
     const FusedWs w = carve_fused(d, B, ws);
     const int E = 1 + 2 * d.D, R = E * B, F = 2 * d.m;
-    int rc = nsvd_fourier_rows(x, p.fourier_B, w.phi, B, d.D, d.m, prob.eps, E, s);
-    if (rc) return rc;
-    if (save) {
-        rc = nsvd_fourier_features(x, p.fourier_B, w.phiTc, B, d.D, d.m, prob.eps, 1, B, s);
+    int rc = 0;
+    if (!(save & 2)) {  // bit 1 of `save`: the features are already in the workspace (nsvd_fused_features)
+        rc = nsvd_fused_features(d, p, prob, x, B, ws, save & 1, s);
         if (rc) return rc;
     }
+    save &= 1;
     FwdArgs a;
     memset(&a, 0, sizeof(a));
     a.phiT = w.phi;

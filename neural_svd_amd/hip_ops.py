@@ -145,7 +145,8 @@ def fourier_features(x: torch.Tensor, fourier_B: torch.Tensor, eps: float, nsten
 
 def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, ws: torch.Tensor,
                      save_for_backward: bool = True, path: int = PATH_AUTO,
-                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                     features_ready: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Tf, f = operator(model, x, importance). Returns (f, Tf), each (B, L)."""
     B = x.shape[0]
     if x.dim() != 2 or x.shape[1] != shape.D:
@@ -157,10 +158,20 @@ def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.
         f, Tf = out
     d = shape.desc()
     rc = _lib.load().nsvd_operator_forward(C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"),
-                                           _ptr(Tf, "Tf"), ws.data_ptr(), ws.numel(), int(save_for_backward),
+                                           _ptr(Tf, "Tf"), ws.data_ptr(), ws.numel(),
+                                           int(save_for_backward) | (_lib.FEATURES_READY if features_ready else 0),
                                            int(path), _stream())
     check(rc, "nsvd_operator_forward")
     return f, Tf
+
+
+def operator_features(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, ws: torch.Tensor,
+                      save_for_backward: bool = True, path: int = PATH_AUTO) -> None:
+    """Weight-independent prologue of operator_forward (Fourier features of x into ws)."""
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_features(C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), x.shape[0],
+                                            ws.data_ptr(), ws.numel(), int(save_for_backward), int(path), _stream())
+    check(rc, "nsvd_operator_features")
 
 
 def operator_backward(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, df: torch.Tensor,
