@@ -164,8 +164,17 @@ def main():
         if kname.startswith("gemm_generic"):  # generic path: the bracketed launch is the layer-0 GEMM only
             flops_fwd = 2.0 * (1 + 2 * cfg["D"]) * cfg["B"] * cfg["L"] * (2 * cfg["m"]) * cfg["hidden"][0]
         ach = flops_fwd / (kavg * 1e-3) / 1e12
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same workload only
+            tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
+            if tj.get("workload") == "cfg2" and cfg["B"] == CFG["B"] and kname.startswith("pmlp_fused_fwd"):
+                traffic = int(tj["kernels"]["pmlp_fused_fwd"]["hbm_bytes_corrected"])
+        except Exception:  # noqa: BLE001
+            traffic = None
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                    traffic_note="HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from "
+                                 "profiles/r01_pmc_traffic_cfg2.txt; algorithmic bytes 52.5 MB",
                     kernel=kname, kernel_avg_us=round(kavg * 1e3, 2),
                     kernel_flops=flops_fwd,
                     step_flops=flops_step, step_tflops=round(flops_step / (ms_per_step * 1e-3) / 1e12, 3),

@@ -49,7 +49,7 @@ struct FwdArgs {
     float* jac;
     float* dsc;
     float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null
-    int xcd_remap;
+    int xcd_remap;  // 0: plain mapping; else HX = number of head groups across the 8 XCDs (1, 2, 4 or 8)
     unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
 
@@ -116,13 +116,21 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int nsb = a.B / BS;
-    int unit = blockIdx.x;
+    int l, sb;
     if (a.xcd_remap) {
-        const int per = gridDim.x >> 3;
-        unit = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        // blocks b and b+8 share an XCD (round-robin dispatch: speed only, never correctness). XCD x gets the
+        // head group x % HX and the sample-block group x / HX, so its L2 sees L/HX W_0 slabs and nsb/SX phi
+        // slabs instead of everything (HX * SX = 8, chosen on the host to minimise bytes per XCD).
+        const int HX = a.xcd_remap, SX = 8 / HX;
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int hpg = a.L / HX, spg = nsb / SX;  // heads / sample blocks per group
+        l = (x % HX) * hpg + slot % hpg;
+        sb = (x / HX) * spg + slot / hpg;
+    } else {
+        l = blockIdx.x / nsb;
+        sb = blockIdx.x - l * nsb;
     }
-    const int l = unit / nsb;
-    const int b0 = (unit - l * nsb) * BS;
+    const int b0 = sb * BS;
 
     NSVD_STAMP(0)
     f32x16 acc[E];
@@ -972,8 +980,22 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     a.f = f; a.Tf = Tf;
     a.jac = save ? w.jac : nullptr;
     a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
-    const int grid = (B / BS) * d.L;
-    a.xcd_remap = (grid % 8 == 0) ? 1 : 0;
+    // XCD-aware block mapping: split heads into HX groups and sample blocks into 8/HX groups, minimising the
+    // bytes each XCD pulls through its L2: (L/HX) * |W_0 slab| + (nsb/SX) * |phi slab|
+    {
+        const int nsb = B / BS;
+        double best = 1e300;
+        a.xcd_remap = 0;
+        for (int HX = 1; HX <= 8; HX *= 2) {
+            const int SX = 8 / HX;
+            if (d.L % HX != 0 || nsb % SX != 0) continue;
+            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * E * F;
+            if (bytes < best) {
+                best = bytes;
+                a.xcd_remap = HX;
+            }
+        }
+    }
 #ifdef NSVD_FWD_STAMPS
     a.stamps = (unsigned long long*)w.dz[0];  // diagnostic build: stamps land in the (then unused) dz_0 scratch
 #endif
