@@ -28,7 +28,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak 
 PEAK_HBM_GBS = 8000.0
 
 CFG = dict(L=16, D=2, m=1024, hidden=(128, 128, 128), B=512, sequential=False, eps=0.01, op_scale=100.0, op_shift=0.0,
-           sigma=16.0, fourier_scale=0.1, lr=1e-4, alpha=0.999, ema_decay=0.995, num_iters=500000)
+           sigma=16.0, fourier_scale=0.1, lr=1e-4, alpha=0.999, ema_decay=0.995, num_iters=500000,
+           potential="hydrogen", exp_mask_init=None)
+# the other BASELINE.json configs are parity-test cases, not bench lines; --config lets a developer time them
+ALT = {
+    "cfg1": dict(CFG, B=128, sequential=True),
+    "cfg2": CFG,
+    "cfg3": dict(CFG, L=32, m=256, B=512, sequential=True, op_scale=1.0, op_shift=16.0, sigma=4.0, fourier_scale=1.0,
+                 num_iters=100000, potential="oscillator", exp_mask_init=10.0),
+}
 
 
 def macs_per_sample_head(m, hidden):
@@ -97,7 +105,8 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
-    ap.add_argument("--batch-size", type=int, default=CFG["B"])
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--config", default="cfg2", choices=sorted(ALT))
     args = ap.parse_args()
 
     from neural_svd_amd import hip_ops as H
@@ -115,14 +124,18 @@ def main():
     dev = torch.device("cuda", local_rank)
     comm = parallel.Communicator.from_env(dev) if world > 1 else None
 
-    cfg = dict(CFG)
-    cfg["B"] = args.batch_size
-    shape = H.ModelShape(L=cfg["L"], D=cfg["D"], m=cfg["m"], hidden=cfg["hidden"])
-    prob = H.make_problem(H.POT_HYDROGEN, 1.0, cfg["eps"], cfg["op_scale"], cfg["op_shift"], cfg["sigma"])
+    cfg = dict(ALT[args.config])
+    if args.batch_size:
+        cfg["B"] = args.batch_size
+    osc = cfg["potential"] == "oscillator"
+    shape = H.ModelShape(L=cfg["L"], D=cfg["D"], m=cfg["m"], hidden=cfg["hidden"], has_exp_mask=osc)
+    prob = H.make_problem(H.POT_HARMONIC if osc else H.POT_HYDROGEN, 1.0, cfg["eps"], cfg["op_scale"], cfg["op_shift"],
+                          cfg["sigma"])
     path = {"auto": H.PATH_AUTO, "generic": H.PATH_GENERIC, "fused": H.PATH_FUSED}[args.path]
     tr = FusedTrainer(shape, prob, cfg["B"], sequential=cfg["sequential"], lr=cfg["lr"], rmsprop_decay=cfg["alpha"],
                       ema_decay=cfg["ema_decay"], num_iters=cfg["num_iters"], sampling_scale=cfg["sigma"],
-                      fourier_scale=cfg["fourier_scale"], seed=0, device=dev, path=path, comm=comm)
+                      fourier_scale=cfg["fourier_scale"], exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev,
+                      path=path, comm=comm)
 
     for _ in range(args.warmup):
         tr.step()
@@ -191,7 +204,10 @@ def main():
         "final_loss": loss, "params_finite": finite,
         "roofline": roof,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if args.config != "cfg2":
+        out["metric"] = f"training steps/sec, developer config {args.config} (not the headline workload)"
+        out["config"]["workload"] = f"{args.config}: {cfg}"
+    if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
         cb = cpu_baseline(cfg)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)

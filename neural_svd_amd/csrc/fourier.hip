@@ -4,8 +4,27 @@
 
 namespace {
 
-// one thread per (stencil row r, frequency j): sin and cos of the same projection (nsvd_sincos:
-// ~1 ulp - projections reach tens of radians and the FD Laplacian amplifies feature error by 1/eps^2).
+__device__ __forceinline__ void sincos_d2f(double p, float* s, float* c) {
+    // p reduced in double (|p| < 1e9: two-constant Cody-Waite is exact to ~1e-17 * n), polynomials in float
+    const double n = rint(p * 0.63661977236758134308);
+    double r = fma(n, -1.57079632679489655800e+00, p);
+    r = fma(n, -6.12323399573676603587e-17, r);
+    const float rf = (float)r;
+    const float s2 = rf * rf;
+    float ps = fmaf(s2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, s2, -1.6666654611e-1f);
+    const float sn = fmaf(ps * s2, rf, rf);
+    float pc = fmaf(s2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, s2, 4.166664568298827e-2f);
+    const float cs = fmaf(pc * s2, s2, fmaf(-0.5f, s2, 1.0f));
+    const int q = (int)((long long)n & 3);
+    const float so = (q & 1) ? cs : sn;
+    const float co = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -so : so;
+    *c = ((q + 1) & 2) ? -co : co;
+}
+
+// generic path: one thread per (stencil row r, frequency j), feature-major output phiT[k][r]
 __global__ void __launch_bounds__(256) fourier_kernel(const float* __restrict__ x, const float* __restrict__ fB,
                                                       float* __restrict__ phiT, int B, int D, int m, float eps,
                                                       int nst, int ldr) {
@@ -15,36 +34,87 @@ __global__ void __launch_bounds__(256) fourier_kernel(const float* __restrict__ 
     if (r >= R) return;
     const int e = r / B;
     const int b = r - e * B;
-    float proj = 0.f;
+    // shifted coordinate and projection in double: their float32 rounding differs from stencil point to
+    // stencil point and would be amplified by 1/eps^2 in the finite-difference Laplacian
+    double proj = 0.0;
     for (int d = 0; d < D; ++d) {
-        const float xc = nsvd_stencil_coord(x[(size_t)b * D + d], d, e, eps);
-        proj = fmaf(xc, fB[(size_t)d * m + j], proj);
+        double xc = (double)x[(size_t)b * D + d];
+        if (e > 0 && ((e - 1) >> 1) == d) xc += ((e - 1) & 1) ? -(double)eps : (double)eps;
+        proj = fma(xc, (double)fB[(size_t)d * m + j], proj);
     }
     float s, c;
-    nsvd_sincos(proj, &s, &c);
+    sincos_d2f(proj, &s, &c);
     phiT[(size_t)j * ldr + r] = s;
     phiT[(size_t)(m + j) * ldr + r] = c;
 }
 
-// sample-major variant for the fused MFMA forward: phi[r][k], k contiguous (ld = 2m), one thread per
-// (frequency j, stencil row r), j fastest so both stores of a wave are 256-B contiguous.
-__global__ void __launch_bounds__(256) fourier_rows_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ fB, float* __restrict__ phi,
-                                                           int B, int D, int m, float eps, int nst) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (j >= m) return;
-    const int e = r / B;
-    const int b = r - e * B;
-    float proj = 0.f;
+// Fused-path feature kernel: phi[r][k] for every stencil row (sample-major, k contiguous, ld = 2m) and,
+// optionally, the feature-major copy of the centre rows phiT_c[k][b] for the weight-gradient GEMM.
+// One workgroup = 64 frequencies x 32 base samples. Per (b, j) ONE sincos of the centre projection
+// p = x_b . B_j evaluated in float64-accurate form (double projection + double Cody-Waite reduction), then
+// the 2D shifted points by angle addition with d_i = eps * B_ij (sin d, cos d computed once per (i, j)):
+//     sin(p +- d) = sin p cos d +- cos p sin d,   cos(p +- d) = cos p cos d -+ sin p sin d.
+// This is the same function the reference evaluates (sin/cos((x +- eps e_i) . B)) but without the float32
+// rounding of (x + eps) and of the projection, which are common-mode across the stencil here and would
+// otherwise be amplified by 1/eps^2 in the finite-difference Laplacian; and it needs 1 + D instead of
+// 1 + 2D sincos per (b, j).
+constexpr int FJ = 64, FB = 32;
+
+template <int D>
+__global__ void __launch_bounds__(256) fourier_stencil_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ fB,
+                                                              float* __restrict__ phi, float* __restrict__ phiTc,
+                                                              int B, int m, float eps) {
+    __shared__ float ts[FJ][FB + 1];  // transposed staging of the centre rows
+    __shared__ float tc[FJ][FB + 1];
+    const int tid = threadIdx.x;
+    const int jl = tid & (FJ - 1);           // frequency within the tile (fastest: coalesced row stores)
+    const int j = blockIdx.x * FJ + jl;
+    const int b0 = blockIdx.y * FB;
+    const int F = 2 * m;
+    const bool jok = j < m;
+    float bj[D], sd[D], cd[D];
+#pragma unroll
     for (int d = 0; d < D; ++d) {
-        const float xc = nsvd_stencil_coord(x[(size_t)b * D + d], d, e, eps);
-        proj = fmaf(xc, fB[(size_t)d * m + j], proj);
+        bj[d] = jok ? fB[(size_t)d * m + j] : 0.f;
+        sincos_d2f((double)eps * (double)bj[d], &sd[d], &cd[d]);
     }
-    float s, c;
-    nsvd_sincos(proj, &s, &c);
-    phi[(size_t)r * (2 * m) + j] = s;
-    phi[(size_t)r * (2 * m) + m + j] = c;
+    for (int bl = tid / FJ; bl < FB; bl += 256 / FJ) {
+        const int b = b0 + bl;
+        if (b >= B) break;
+        double p = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) p = fma((double)x[(size_t)b * D + d], (double)bj[d], p);
+        float s0, c0;
+        sincos_d2f(p, &s0, &c0);
+        if (jok) {
+            float* row = phi + (size_t)b * F;
+            row[j] = s0;
+            row[m + j] = c0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                float* rp = phi + (size_t)((1 + 2 * d) * B + b) * F;  // x + eps e_d
+                float* rm = phi + (size_t)((2 + 2 * d) * B + b) * F;  // x - eps e_d
+                rp[j] = fmaf(s0, cd[d], c0 * sd[d]);
+                rp[m + j] = fmaf(c0, cd[d], -(s0 * sd[d]));
+                rm[j] = fmaf(s0, cd[d], -(c0 * sd[d]));
+                rm[m + j] = fmaf(c0, cd[d], s0 * sd[d]);
+            }
+        }
+        ts[jl][bl] = s0;
+        tc[jl][bl] = c0;
+    }
+    if (!phiTc) return;
+    __syncthreads();
+    // phiT_c[k][b0 + bl]: 32 consecutive samples per frequency = one 128-B store
+    const int bl = tid & (FB - 1);
+    for (int jj = tid / FB; jj < FJ; jj += 256 / FB) {
+        const int jg = blockIdx.x * FJ + jj;
+        if (jg < m && b0 + bl < B) {
+            phiTc[(size_t)jg * B + b0 + bl] = ts[jj][bl];
+            phiTc[(size_t)(m + jg) * B + b0 + bl] = tc[jj][bl];
+        }
+    }
 }
 
 }  // namespace
@@ -62,11 +132,15 @@ extern "C" int nsvd_fourier_features(const float* x, const float* fourier_B, flo
     return 0;
 }
 
-int nsvd_fourier_rows(const float* x, const float* fourier_B, float* phi, int B, int D, int m, float eps,
-                      int nstencil, hipStream_t s) {
-    const int R = nstencil * B;
-    dim3 grid(nsvd_cdiv(m, 256), R);
-    hipLaunchKernelGGL(fourier_rows_kernel, grid, dim3(256), 0, s, x, fourier_B, phi, B, D, m, eps, nstencil);
+int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, int B, int D, int m,
+                         float eps, hipStream_t s) {
+    dim3 grid(nsvd_cdiv(m, FJ), nsvd_cdiv(B, FB));
+    switch (D) {
+        case 1: hipLaunchKernelGGL(fourier_stencil_kernel<1>, grid, dim3(256), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
+        case 2: hipLaunchKernelGGL(fourier_stencil_kernel<2>, grid, dim3(256), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
+        case 3: hipLaunchKernelGGL(fourier_stencil_kernel<3>, grid, dim3(256), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
+        default: return NSVD_EUNSUPPORTED;
+    }
     NSVD_CHECK_LAUNCH();
     return 0;
 }

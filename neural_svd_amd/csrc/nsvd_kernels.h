@@ -6,9 +6,10 @@
 void nsvd_prof_begin(hipStream_t s);
 void nsvd_prof_end(hipStream_t s);
 
-// phi[r][k] (sample-major, k contiguous, ld = 2m) for the R = nstencil*B stencil rows (fourier.hip)
-int nsvd_fourier_rows(const float* x, const float* fourier_B, float* phi, int B, int D, int m, float eps,
-                      int nstencil, hipStream_t s);
+// Fused-path features (fourier.hip): phi (E*B, 2m) sample-major for all stencil rows by angle addition from
+// one double-accurate sincos per (sample, frequency); phiTc (2m, B) feature-major centre copy, or null.
+int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, int B, int D, int m,
+                         float eps, hipStream_t s);
 
 // ---- generic strided batched GEMM (gemm_generic.hip) -------------------------------------------
 //   C[g][i][j] = epi( sum_k A[g][i*sAm + k*sAk] * pro(B[g][k*sBk + j*sBn]) + bias[g][i] )

@@ -945,11 +945,7 @@ size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B) { return carv
 int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                         int B, void* ws, int save, hipStream_t s) {
     const FusedWs w = carve_fused(d, B, ws);
-    const int E = 1 + 2 * d.D;
-    int rc = nsvd_fourier_rows(x, p.fourier_B, w.phi, B, d.D, d.m, prob.eps, E, s);
-    if (rc) return rc;
-    if (save) rc = nsvd_fourier_features(x, p.fourier_B, w.phiTc, B, d.D, d.m, prob.eps, 1, B, s);
-    return rc;
+    return nsvd_fourier_stencil(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, B, d.D, d.m, prob.eps, s);
 }
 
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
