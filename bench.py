@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--config", default="cfg2", choices=sorted(ALT))
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "dp", "hp"],
+                    help="N > 1: dp = samples sharded (moments + gradient all-reduce); hp = heads sharded (one "
+                         "all-gather of f, Tf, no gradient traffic); auto = hp when L %% N == 0")
     args = ap.parse_args()
 
     from neural_svd_amd import hip_ops as H
@@ -120,9 +123,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
+    # NSVD_FORCE_DEVICE / NSVD_DIST_BACKEND: developer aid to exercise the N > 1 code path on a 1-GPU box
+    # (all ranks on one device, gloo instead of RCCL); never set by the driver
+    if os.environ.get("NSVD_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["NSVD_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    comm = parallel.Communicator.from_env(dev) if world > 1 else None
+    comm = parallel.Communicator.from_env(dev, backend=os.environ.get("NSVD_DIST_BACKEND")) if world > 1 else None
 
     cfg = dict(ALT[args.config])
     if args.batch_size:
@@ -132,7 +139,10 @@ def main():
     prob = H.make_problem(H.POT_HARMONIC if osc else H.POT_HYDROGEN, 1.0, cfg["eps"], cfg["op_scale"], cfg["op_shift"],
                           cfg["sigma"])
     path = {"auto": H.PATH_AUTO, "generic": H.PATH_GENERIC, "fused": H.PATH_FUSED}[args.path]
-    tr = FusedTrainer(shape, prob, cfg["B"], sequential=cfg["sequential"], lr=cfg["lr"], rmsprop_decay=cfg["alpha"],
+    par = args.parallelism
+    if par == "auto":
+        par = "hp" if (world > 1 and cfg["L"] % world == 0) else "dp"
+    tr = FusedTrainer(shape, prob, cfg["B"], parallelism=par, sequential=cfg["sequential"], lr=cfg["lr"], rmsprop_decay=cfg["alpha"],
                       ema_decay=cfg["ema_decay"], num_iters=cfg["num_iters"], sampling_scale=cfg["sigma"],
                       fourier_scale=cfg["fourier_scale"], exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev,
                       path=path, comm=comm)
@@ -199,8 +209,13 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: 2D hydrogen, L=16, batch_size=512 per GPU, joint nesting, "
                                "MLP 2048(Fourier m=1024)->128->128->128->1 x16 heads, eps=0.01, RMSprop+cosine+EMA",
-                   "global_batch": cfg["B"] * world, "parallelism": f"dp{world}",
-                   "path": H.path_name(shape, cfg["B"], path), "params": tr.P.n_trainable},
+                   "global_batch": cfg["B"] * world,
+                   "parallelism": (f"{par}{world}" if world > 1 else "dp1"),
+                   "sharding": ("heads: each GPU owns L/N heads and evaluates them on the whole global batch; one "
+                                "all-gather of f,Tf per step, no gradient traffic" if (par == "hp" and world > 1) else
+                                "samples: each GPU draws its own 512 rows; all-reduce of 2L^2+1 moments and of the "
+                                "flat gradient per step"),
+                   "path": H.path_name(tr.shape, tr.B, path), "params": tr.P.n_trainable * (world if tr.hp else 1)},
         "final_loss": loss, "params_finite": finite,
         "roofline": roof,
     }

@@ -179,12 +179,15 @@ int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, int mask_kin
  *   - an INPUT when moments_reduced != 0 (e.g. after the data-parallel all-reduce of nsvd_evd_moments), or
  *   - an OUTPUT when moments_reduced == 0: the partial sums in `evd_scratch` (from nsvd_evd_partial on the
  *     same f, Tf) are reduced on the fly and the reduced vector is stored here.
- * loss[0..2] = {loss, operator term, metric term}. Gradients are overwritten as in nsvd_operator_backward. */
+ * loss[0..2] = {loss, operator term, metric term}. Gradients are overwritten as in nsvd_operator_backward.
+ * Head-parallel sharding: f, Tf, v, M and the moments may cover L_total >= desc->L heads, of which this
+ * model owns [l_offset, l_offset + desc->L) (f, Tf are then (B, L_total), gathered from all ranks); pass
+ * L_total = 0 / l_offset = 0 otherwise. */
 int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsvd_params* params,
                                const nsvd_problem* prob, const float* x, int B, const float* f, const float* Tf,
                                int mask_kind, const float* v, const float* M, float* moments, int moments_reduced,
-                               const void* evd_scratch, float grad_scale, float* loss, const nsvd_params* grads,
-                               void* ws, size_t ws_bytes, int path, void* stream);
+                               const void* evd_scratch, int L_total, int l_offset, float grad_scale, float* loss,
+                               const nsvd_params* grads, void* ws, size_t ws_bytes, int path, void* stream);
 
 /* torch.optim.RMSprop(alpha, eps, momentum=0, centered=False) step + torch_ema update, fused
  * (examples/utils.py:50-57, examples/operator/__init__.py:69-73):

@@ -42,6 +42,8 @@ struct NsvdEvdIn {
     float* loss;            // block 0 stores {loss, operator term, metric term} (may be null)
     float grad_scale;
     int kind;
+    int Lg;     // number of heads of f / Tf / the moments (>= the caller's local head count)
+    int l_off;  // first global head of the caller (head-parallel sharding); 0 otherwise
 };
 
 __device__ __forceinline__ float nsvd_evd_mask_v(const NsvdEvdIn& in, int l, int L) {

@@ -257,8 +257,9 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
                                           const nsvd_problem* prob, const float* x, int B, const float* f,
                                           const float* Tf, int mask_kind, const float* v, const float* M,
                                           float* moments, int moments_reduced, const void* evd_scratch,
-                                          float grad_scale, float* loss, const nsvd_params* grads, void* ws,
-                                          size_t ws_bytes, int path, void* stream) {
+                                          int L_total, int l_offset, float grad_scale, float* loss,
+                                          const nsvd_params* grads, void* ws, size_t ws_bytes, int path,
+                                          void* stream) {
     int rc = validate(desc);
     if (rc) return rc;
     if (!prob || !x || !f || !Tf || !moments || !ws || B <= 0) return NSVD_EINVAL;
@@ -274,7 +275,9 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
     hipStream_t s = (hipStream_t)stream;
     const bool fused = want_fused(*desc, B, path);
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
-    const int L = desc->L;
+    if (L_total <= 0) L_total = desc->L;
+    if (l_offset < 0 || l_offset + desc->L > L_total || L_total > 128) return NSVD_EINVAL;
+    const int L = L_total;  // f, Tf, moments and masks are indexed by GLOBAL head
     const NsvdEvdChunking c = nsvd_evd_chunking(B);
     if (fused) {
         NsvdEvdIn in;
@@ -283,6 +286,8 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
         in.kind = mask_kind;
         in.grad_scale = grad_scale;
         in.loss = loss;
+        in.Lg = L_total;
+        in.l_off = l_offset;
         if (moments_reduced) {
             in.moments = moments;
         } else {
@@ -293,6 +298,7 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
         return nsvd_fused_backward_evd(*desc, *params, B, in, *grads, ws, s);
     }
     // generic path: finish the loss with the stand-alone kernels, then the layer-by-layer backward
+    if (L_total != desc->L) return NSVD_EUNSUPPORTED;  // head-parallel sharding needs the fused kernels
     const GenericWs w = carve(*desc, B, ws);
     if (!moments_reduced) {
         rc = nsvd_evd_reduce_partials(evd_scratch, B, L, moments, s);

@@ -463,22 +463,22 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         // d loss / d f[b][l] = gs * ( -(4/B) v_l Tf[b][l] + (2/B_half) sum_l' f[b][l'] M[l'][l] lam_other[l'][l] )
         // (reference methods/nestedlora.py:98-111 with f1, f2 = chunk(f, 2)); the moments are either the
         // reduced / all-reduced vector or this rank's per-chunk partial sums (reduced here, in a fixed order)
-        float* col = DZ;  // [2][L] masked moment columns of head l (LDS scratch, free until the first exchange)
-        const int B1 = (a.B + 1) / 2, B2 = a.B - B1, LL = a.L * a.L;
-        for (int t = tid; t < 2 * a.L; t += 256) {
-            const int h = t / a.L, lp = t - h * a.L;  // h = 0: lam_f1 column, 1: lam_f2 column
-            col[t] = nsvd_evd_mask_M(a.evd, lp, l, a.L) * nsvd_evd_lam(a.evd, h, lp * a.L + l, a.B, a.L);
+        float* col = DZ;  // [2][Lg] masked moment columns of (global) head lg (LDS scratch, free until the first exchange)
+        const int Lg = a.evd.Lg, lg = a.evd.l_off + l;
+        const int B1 = (a.B + 1) / 2, B2 = a.B - B1;
+        for (int t = tid; t < 2 * Lg; t += 256) {
+            const int h = t / Lg, lp = t - h * Lg;  // h = 0: lam_f1 column, 1: lam_f2 column
+            col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * nsvd_evd_lam(a.evd, h, lp * Lg + lg, a.B, Lg);
         }
-        if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, a.L, DZ + 256);
+        if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, Lg, DZ + 2 * Lg);
         __syncthreads();
         const bool first = b < B1;
-        const float* cp = col + (first ? a.L : 0);  // the OTHER half's moments
-        const float* fr = a.evd.f + (size_t)b * a.L;
+        const float* cp = col + (first ? Lg : 0);  // the OTHER half's moments
+        const float* fr = a.evd.f + (size_t)b * Lg;
         float acc = 0.f;
-        for (int lp = 0; lp < a.L; ++lp) acc = fmaf(fr[lp], cp[lp], acc);
-        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, l, a.L) * a.evd.Tf[(size_t)b * a.L + l] +
+        for (int lp = 0; lp < Lg; ++lp) acc = fmaf(fr[lp], cp[lp], acc);
+        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * a.evd.Tf[(size_t)b * Lg + lg] +
                                   (2.f / (float)(first ? B1 : B2)) * acc);
-        (void)LL;
         __syncthreads();  // col[] is dead before DZ is reused
     }
     const float dbase = dfv * a.jac[(size_t)b * a.L + l];

@@ -255,14 +255,19 @@ def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: t
                           Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor], M: Optional[torch.Tensor],
                           moments: torch.Tensor, moments_reduced: bool, evd_scratch: Optional[torch.Tensor],
                           loss: torch.Tensor, grads: Params, ws: torch.Tensor, grad_scale: float = 1.0,
-                          path: int = PATH_AUTO) -> None:
-    """loss gradient + operator backward in one call (d loss / d f is never materialised)."""
+                          path: int = PATH_AUTO, l_offset: int = 0) -> None:
+    """loss gradient + operator backward in one call (d loss / d f is never materialised).
+    f, Tf: (B, L_total) with L_total >= shape.L; this model owns heads [l_offset, l_offset + shape.L)."""
     B = x.shape[0]
+    L_total = f.shape[1]
+    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or moments.numel() != 2 * L_total * L_total + 1:
+        raise NsvdError("operator_backward_evd: f/Tf must be (B, L_total), moments 2*L_total^2+1")
     d = shape.desc()
     rc = _lib.load().nsvd_operator_backward_evd(
         C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
         _ptr(v, "v"), _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
-        evd_scratch.data_ptr() if evd_scratch is not None else None, float(grad_scale), _ptr(loss, "loss"),
+        evd_scratch.data_ptr() if evd_scratch is not None else None, int(L_total), int(l_offset),
+        float(grad_scale), _ptr(loss, "loss"),
         C.byref(grads), ws.data_ptr(), ws.numel(), int(path), _stream())
     check(rc, "nsvd_operator_backward_evd")
 

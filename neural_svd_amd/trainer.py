@@ -105,36 +105,65 @@ class FusedTrainer:
                  num_iters: int = 500000, use_lr_scheduler: bool = True, sampling_scale: float = 16.0,
                  fourier_scale: float = 0.1, exp_mask_init: Optional[float] = None, seed: Optional[int] = 0,
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
-                 pipeline: bool = False):
-        self.shape, self.problem, self.B = shape, problem, int(batch_size)
+                 pipeline: bool = False, parallelism: str = "dp"):
+        """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
+        own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
+        them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py)."""
         self.device = torch.device(device)
         self.path = path
         self.comm = comm  # parallel.Communicator or None
+        world = comm.world if comm is not None else 1
+        rank = comm.rank if comm is not None else 0
+        self.hp = parallelism == "hp" and world > 1
+        if parallelism not in ("dp", "hp"):
+            raise ValueError("parallelism must be 'dp' or 'hp'")
+        self.full_shape = shape
+        self.Lg, self.l_off = shape.L, 0
+        if self.hp:
+            if shape.L % world != 0:
+                raise ValueError(f"head-parallel needs L ({shape.L}) divisible by the world size ({world})")
+            Ll = shape.L // world
+            self.l_off = rank * Ll
+            shape = H.ModelShape(L=Ll, D=shape.D, m=shape.m, hidden=shape.hidden, has_exp_mask=shape.has_exp_mask)
+            batch_size = int(batch_size) * world
+        self.shape, self.problem, self.B = shape, problem, int(batch_size)
         self.lr, self.alpha, self.eps = lr, rmsprop_decay, rmsprop_eps
         self.ema_decay, self.num_iters, self.use_sched = ema_decay, num_iters, use_lr_scheduler
         self.sigma = sampling_scale
         self.P = FlatParams(shape, self.device)
-        self.P.load(*reference_init(shape, fourier_scale, exp_mask_init, seed))
+        fB0, ws0, bs0, sc0 = reference_init(self.full_shape, fourier_scale, exp_mask_init, seed)
+        if self.hp:  # this rank's heads of the (identically seeded) full model
+            sl = slice(self.l_off, self.l_off + shape.L)
+            ws0, bs0 = [w[sl] for w in ws0], [b[sl] for b in bs0]
+            sc0 = sc0[sl] if sc0 is not None else None
+        self.P.load(fB0, ws0, bs0, sc0)
         self._params = self.P.pack(self.P.flat, True)
         self._grads = self.P.pack(self.P.grad, False)
         self._ema_params = self.P.pack(self.P.ema, True)
         # nesting masks (methods/nestedlora.py:183-192)
         from .nested_lowrank import nesting_masks
-        self.vector_mask, self.matrix_mask, self.mask_kind = nesting_masks(shape.L, sequential, step)
+        self.vector_mask, self.matrix_mask, self.mask_kind = nesting_masks(self.Lg, sequential, step)
         self.v_dev = self.vector_mask.to(self.device)
         self.M_dev = self.matrix_mask.to(self.device).contiguous()
-        L = shape.L
+        L, Lg = shape.L, self.Lg
         self.ws = H.new_workspace(shape, self.B, self.device)
-        self.f = torch.empty((self.B, L), dtype=torch.float32, device=self.device)
-        self.Tf = torch.empty_like(self.f)
-        self.df = torch.empty_like(self.f)
-        self.moments = torch.empty(2 * L * L + 1, dtype=torch.float32, device=self.device)
+        # local (B, L_local) outputs of the forward, packed [f | Tf] so that one all-gather moves both
+        self.fTf_loc = torch.empty((2, self.B, L), dtype=torch.float32, device=self.device)
+        self.f, self.Tf = self.fTf_loc[0], self.fTf_loc[1]
+        if self.hp:
+            self.gath = torch.empty((world, 2, self.B, L), dtype=torch.float32, device=self.device)
+            self.fTf_g = torch.empty((2, self.B, Lg), dtype=torch.float32, device=self.device)
+            self.f_g, self.Tf_g = self.fTf_g[0], self.fTf_g[1]
+        else:
+            self.f_g, self.Tf_g = self.f, self.Tf
+        self.moments = torch.empty(2 * Lg * Lg + 1, dtype=torch.float32, device=self.device)
         self.loss = torch.zeros(3, dtype=torch.float32, device=self.device)
-        self.scratch = H.evd_scratch(self.B, L, self.device)
+        self.scratch = H.evd_scratch(self.B, Lg, self.device)
         self.x = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device)
         self.gen = torch.Generator(device=self.device)
-        rank = comm.rank if comm is not None else 0
-        self.gen.manual_seed((sample_seed if sample_seed is not None else (seed or 0)) * 1000003 + 7919 * rank + 1)
+        # dp: every rank its own stream of samples; hp: all ranks draw the SAME global batch
+        srank = 0 if self.hp else rank
+        self.gen.manual_seed((sample_seed if sample_seed is not None else (seed or 0)) * 1000003 + 7919 * srank + 1)
         self.t = 0            # optimiser / scheduler steps taken
         self.num_updates = 0  # torch_ema counter
         # optional batch pipelining: the sample + Fourier features of step k+1 do not depend on the weights, so
@@ -158,20 +187,27 @@ class FusedTrainer:
                            features_ready=features_ready)
         cust = self.mask_kind == H.MASK_CUSTOM
         v, M = (self.v_dev, self.M_dev) if cust else (None, None)
-        if self.comm is not None and self.comm.world > 1:
+        world = self.comm.world if self.comm is not None else 1
+        reduced = False
+        if self.hp:
+            # the one exchange of the head-parallel step: everybody's (B, L/world) blocks of f and Tf
+            self.comm.all_gather(self.gath, self.fTf_loc)
+            self.fTf_g.view(2, self.B, world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
+            H.evd_partial(self.f_g, self.Tf_g, self.mask_kind, v, self.scratch)
+        elif world > 1:
             H.evd_moments(self.f, self.Tf, self.mask_kind, v, self.moments, self.scratch)
             self.comm.all_reduce_mean(self.moments)
             reduced = True
         else:
             H.evd_partial(self.f, self.Tf, self.mask_kind, v, self.scratch)
-            reduced = False
         # loss + d loss / d f are evaluated inside the backward kernels from the moments
-        H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f, self.Tf, self.mask_kind, v, M,
-                                self.moments, reduced, self.scratch, self.loss, self._grads, self.ws, 1.0, self.path)
+        H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g, self.mask_kind, v, M,
+                                self.moments, reduced, self.scratch, self.loss, self._grads, self.ws, 1.0, self.path,
+                                l_offset=self.l_off)
 
     def optimizer_step(self) -> None:
         gscale = 1.0
-        if self.comm is not None and self.comm.world > 1:
+        if self.comm is not None and self.comm.world > 1 and not self.hp:
             self.comm.all_reduce_sum(self.P.grad)
             gscale = 1.0 / self.comm.world
         lr = cosine_lr(self.lr, self.t, self.num_iters) if self.use_sched else self.lr

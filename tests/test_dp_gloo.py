@@ -40,6 +40,17 @@ class OracleBackend:
     def apply(self, g, scale):
         self.applied = g * scale
 
+    def backward_from_moments(self, c, f, Tf, mom):
+        """head-parallel: f, Tf cover all L heads, this backend owns heads [l_off, l_off + L_loc)."""
+        loss, df = self.loss_grad(f, Tf, mom)
+        Ll = c.f.shape[1]
+        return loss, self.backward(c, df[:, self.l_off:self.l_off + Ll].contiguous())
+
+
+def slice_heads(p, lo, hi):
+    return O.Params([w[lo:hi] for w in p.ws], [b[lo:hi] for b in p.bs], p.fourier_B,
+                    None if p.scales is None else p.scales[lo:hi])
+
 
 def _setup():
     L, D, m, hidden, Bg = 3, 2, 6, (10, 8), 16
@@ -67,6 +78,20 @@ def _worker(rank, world, port, tmp):
     assert abs(comm.max_float(float(rank)) - (world - 1)) < 1e-12
     comm.barrier()
     torch.save(dict(loss=out["loss"], grad=be.applied, mom=out["moments"]), os.path.join(tmp, f"r{rank}.pt"))
+    comm.close()
+
+
+def _worker_hp(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from neural_svd_amd import parallel
+    comm = parallel.Communicator.from_env(device=None, backend="gloo")
+    p, prob, v, M, x = _setup()
+    L = p.ws[0].shape[0]
+    Ll = L // world
+    be = OracleBackend(slice_heads(p, rank * Ll, (rank + 1) * Ll), prob, v, M)
+    be.l_off = rank * Ll
+    out = parallel.hp_step(be, comm, x, None)
+    torch.save(dict(loss=out["loss"], grad=be.applied, f=out["f"]), os.path.join(tmp, f"h{rank}.pt"))
     comm.close()
 
 
@@ -103,3 +128,19 @@ def test_dp_step_single_process_is_plain_step():
     ref = O.loss_and_grads(x, p, prob, v, M)
     assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
     assert out["grad_scale"] == 1.0
+
+
+@pytest.mark.timeout(300)
+def test_hp_three_ranks_equals_single_process(tmp_path):
+    """head-parallel: 3 heads over 3 ranks, each on the whole batch; gathered f, local gradients == the
+    corresponding head slices of the single-process gradient."""
+    world = 3
+    mp.spawn(_worker_hp, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    p, prob, v, M, x = _setup()
+    ref = O.loss_and_grads(x, p, prob, v, M)
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), f"h{r}.pt"))
+        assert abs(float(o["loss"]) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
+        assert torch.allclose(o["f"], ref["f"], rtol=1e-13, atol=1e-15)
+        want = torch.cat([(g[r:r + 1]).reshape(-1) for g in ref["grads"]])
+        assert float((o["grad"] - want).norm() / want.norm()) < 1e-12

@@ -319,6 +319,55 @@ def test_backward_evd_matches_two_step(case, fn, path):
             assert rel(g, g2) < 2e-5, (i, reduced, rel(g, g2))
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_head_parallel_matches_single_rank(world):
+    """Head-parallel sharding simulated on one GPU: each "rank" owns L/world heads of the same model, runs
+    the forward on the whole batch, the (B, L/world) blocks are concatenated by hand (what the all-gather
+    does), and nsvd_operator_backward_evd(L_total, l_offset) must give the head slices of the single-rank
+    gradients and the same loss."""
+    z = G.load("model_headline")
+    cfg = G.cfg_of(z, "hyd_med")  # L = 4, H = 128 x 3: fused kernels
+    prob = G.problem_of(cfg)
+    p = G.params_from_seed(cfg)
+    v, M = G.masks_of(z, "hyd_med")
+    x = torch.tensor(z["hyd_med_x"][0])
+    full = run_hip(p, prob, x, v, M, H.PATH_AUTO)
+    L = p.ws[0].shape[0]
+    Ll = L // world
+    hp = hip_problem(prob)
+    xd = x.float().to(DEV).contiguous()
+    B = xd.shape[0]
+    vd, Md = v.float().to(DEV), M.float().to(DEV).contiguous()
+    ranks = []
+    for r in range(world):
+        pr = O.Params([w[r * Ll:(r + 1) * Ll] for w in p.ws], [b[r * Ll:(r + 1) * Ll] for b in p.bs], p.fourier_B)
+        shape = shape_of(pr)
+        ws_t, bs_t, fB, sc = to_dev(pr)
+        params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+        ws = H.new_workspace(shape, B, DEV)
+        f, Tf = H.operator_forward(shape, params, hp, xd, ws)
+        ranks.append(dict(shape=shape, params=params, ws=ws, f=f, Tf=Tf, ws_t=ws_t, bs_t=bs_t))
+    f_g = torch.cat([r["f"] for r in ranks], dim=1).contiguous()
+    Tf_g = torch.cat([r["Tf"] for r in ranks], dim=1).contiguous()
+    assert rel(f_g, full["f"]) < 1e-6
+    for r, R in enumerate(ranks):
+        gw = [torch.full_like(w, float("nan")) for w in R["ws_t"]]
+        gb = [torch.full_like(b, float("nan")) for b in R["bs_t"]]
+        grads = H.pack_params(R["shape"], gw, gb, None, None)
+        scratch = H.evd_scratch(B, L, DEV)
+        H.evd_partial(f_g, Tf_g, H.MASK_CUSTOM, vd, scratch)
+        mom = torch.empty(2 * L * L + 1, device=DEV)
+        loss = torch.empty(3, device=DEV)
+        H.operator_backward_evd(R["shape"], R["params"], hp, xd, f_g, Tf_g, H.MASK_CUSTOM, vd, Md, mom, False,
+                                scratch, loss, grads, R["ws"], 1.0, H.PATH_AUTO, l_offset=r * Ll)
+        torch.cuda.synchronize()
+        assert abs(float(loss[0]) - float(full["loss"][0])) < 1e-5 * abs(float(full["loss"][0]))
+        nl = len(gw)
+        for i in range(nl):
+            assert rel(gw[i], full["grads"][i][r * Ll:(r + 1) * Ll]) < 2e-5, (r, i)
+            assert rel(gb[i], full["grads"][nl + i][r * Ll:(r + 1) * Ll]) < 2e-5, (r, i)
+
+
 def test_edge_cases_clamp_and_origin():
     """sqrt(p) clamp (far-out samples), x exactly at the origin (hydrogen potential singular -> the
     same inf/nan pattern as the oracle), B = 2 (one row per half)."""
