@@ -142,9 +142,15 @@ int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_params* param
 
 /* out[b, l] = hard_mul_const * base_l(x_b) * mask_l(x_b): WaveFunctions.forward, i.e. what
  * NestedLoRA.forward / method(x) returns (examples/operator/pde/__init__.py:15-16,
- * methods/nestedlora.py:195-200). Forward only (eigenfunction evaluation); out: (B, L). */
+ * methods/nestedlora.py:195-200); out: (B, L). save_for_backward != 0 keeps what nsvd_model_backward needs
+ * in `ws` (used by compute_loss_kernel-style callers that differentiate through model(x) itself). */
 int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
-                       float hard_mul_const, float* out, void* ws, size_t ws_bytes, int path, void* stream);
+                       float hard_mul_const, float* out, void* ws, size_t ws_bytes, int save_for_backward,
+                       void* stream);
+
+/* Parameter gradients of sum(dout * model(x)) for the matching nsvd_model_forward(save_for_backward=1). */
+int nsvd_model_backward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
+                        const float* dout, const nsvd_params* grads, void* ws, size_t ws_bytes, void* stream);
 
 /* NestedLoRALossFunctionEVD.forward with f1, f2 = chunk(f, 2) (methods/nestedlora.py:70-94, :263).
  * Stage 1: moments[0 : L*L] = lam_f1, [L*L : 2*L*L] = lam_f2, [2*L*L] = mean_b sum_l v_l f Tf.

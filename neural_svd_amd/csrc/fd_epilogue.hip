@@ -57,25 +57,30 @@ __global__ void __launch_bounds__(256) dscales_kernel(const float* __restrict__ 
 __global__ void __launch_bounds__(256) model_out_kernel(const float* __restrict__ base, int ldr,
                                                         const float* __restrict__ x,
                                                         const float* __restrict__ scales, float c, int B, int D, int L,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, float* __restrict__ jac,
+                                                        float* __restrict__ dsc) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * L) return;
     const int b = idx / L, l = idx - b * L;
-    float v = c * base[(size_t)l * ldr + b];
+    const float bv = base[(size_t)l * ldr + b];
+    float mk = 1.f, r = 0.f;
     if (scales) {
         float r2 = 0.f;
         for (int d = 0; d < D; ++d) r2 = fmaf(x[(size_t)b * D + d], x[(size_t)b * D + d], r2);
-        v *= expf(-sqrtf(r2) / scales[l]);
+        r = sqrtf(r2);
+        mk = expf(-r / scales[l]);
     }
-    out[idx] = v;
+    out[idx] = c * bv * mk;
+    if (jac) jac[idx] = c * mk;                                              // d out / d base
+    if (dsc) dsc[idx] = scales ? c * bv * mk * r / (scales[l] * scales[l]) : 0.f;  // d out / d scales_l
 }
 
 }  // namespace
 
 int nsvd_model_out(const float* base, int ldr, const float* x, const float* scales, float c, int B, int D, int L,
-                   float* out, hipStream_t s) {
+                   float* out, float* jac, float* dsc, hipStream_t s) {
     hipLaunchKernelGGL(model_out_kernel, dim3(nsvd_cdiv(B * L, 256)), dim3(256), 0, s, base, ldr, x, scales, c, B, D,
-                       L, out);
+                       L, out, jac, dsc);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

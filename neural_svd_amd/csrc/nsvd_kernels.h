@@ -43,8 +43,9 @@ int nsvd_head_backward(const float* df, const float* jac, const float* dsc, int 
                        float* dscales, hipStream_t s);
 
 // out[b][l] = c * base[l*ldr + b] * exp(-|x_b| / scales[l])   (WaveFunctions.forward at the centre rows)
+// optional jac = d out / d base, dsc = d out / d scales (both (B, L)) for nsvd_model_backward
 int nsvd_model_out(const float* base, int ldr, const float* x, const float* scales, float c, int B, int D, int L,
-                   float* out, hipStream_t s);
+                   float* out, float* jac, float* dsc, hipStream_t s);
 
 // reduce the per-chunk partial moments of nsvd_evd_partial into the (2 L^2 + 1) vector (evd_loss.hip)
 int nsvd_evd_reduce_partials(const void* scratch, int B, int L, float* moments, hipStream_t s);

@@ -217,9 +217,9 @@ extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_pa
 }
 
 extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
-                                  float hard_mul_const, float* out, void* ws, size_t ws_bytes, int path,
+                                  float hard_mul_const, float* out, void* ws, size_t ws_bytes, int save_for_backward,
                                   void* stream) {
-    (void)path;  // forward-only evaluation always takes the generic kernels
+    // plain model evaluation always takes the generic kernels
     int rc = validate(desc);
     if (rc) return rc;
     if (!x || !out || !ws || B <= 0) return NSVD_EINVAL;
@@ -232,7 +232,23 @@ extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params
     rc = generic_mlp(*desc, *params, x, B, 0.f, 1, w, (hipStream_t)stream);
     if (rc) return rc;
     return nsvd_model_out(w.z[desc->nlayers - 1], R, x, desc->has_exp_mask ? params->scales : nullptr,
-                          hard_mul_const, B, desc->D, desc->L, out, (hipStream_t)stream);
+                          hard_mul_const, B, desc->D, desc->L, out, save_for_backward ? w.jac : nullptr,
+                          (save_for_backward && desc->has_exp_mask) ? w.dsc : nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nsvd_model_backward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
+                                   const float* dout, const nsvd_params* grads, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!x || !dout || !ws || B <= 0) return NSVD_EINVAL;
+    rc = check_params(*desc, params, true);
+    if (rc) return rc;
+    rc = check_params(*desc, grads, false);
+    if (rc) return rc;
+    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    return generic_backward(*desc, *params, x, B, dout, *grads, ws, (hipStream_t)stream);
 }
 
 extern "C" int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_params* params,

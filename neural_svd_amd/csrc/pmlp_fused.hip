@@ -540,8 +540,9 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 //                        also writes db_0[l] (row sums of dz_0).
 //   B  (4 (nh-1) L):     dW_i[l][n][k] = sum_b dz_i[l][n][b] softplus(z_{i-1}[l][k][b]), i >= 1: one
 //                        64 x 64 quadrant of the 128 x 128 result, 4 waves of one 32 x 32 tile; quadrants
-//                        in column 0 also write db_i.
-//   C  (L):              dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales.
+//                        in column 0 also write db_i. (128 x 64 half tiles were measured slower: fewer,
+//                        longer workgroups next to the dW_0 tiles.)
+//   C  (4 L):              dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales.
 // K is streamed in 32-sample chunks through padded LDS tiles (rows of 36 floats, conflict-free
 // ds_read_b128 fragments), register-staged and double buffered, one barrier per chunk.
 struct WgradArgs {
@@ -823,7 +824,8 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
     }
 }
 
-__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int l) {
+__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int unit) {
+    const int l = unit >> 2, part = unit & 3;  // 4 workgroups per head: 32 of the 128 rows each
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int nh = a.nlayers - 1;
@@ -843,13 +845,14 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
         red[4 + w] = ss;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && part == 0) {
         a.gb[nh][l] = (red[0] + red[1]) + (red[2] + red[3]);
         if (a.gscales) a.gscales[l] = (red[4] + red[5]) + (red[6] + red[7]);
     }
     // dW_last[n] = sum_b dbase[b] softplus(z[n][b]): each wave owns 32 rows and walks them 8 at a time so
     // that 8 independent 16-B loads are in flight per lane (a row-at-a-time loop is pure L2 latency)
-    for (int n0 = 32 * w; n0 < 32 * w + 32; n0 += 8) {
+    {
+        const int n0 = 32 * part + 8 * w;  // this wave's 8 rows
         float s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = 0.f;
@@ -1042,7 +1045,7 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
     // One launch: the 256 dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
     // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
     wa.bid0 = 0;
-    hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA + wa.nB + d.L), dim3(256), 0, s, wa);
+    hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA + wa.nB + 4 * d.L), dim3(256), 0, s, wa);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

@@ -187,14 +187,22 @@ def operator_backward(shape: ModelShape, params: Params, prob: Problem, x: torch
 
 
 def model_forward(shape: ModelShape, params: Params, x: torch.Tensor, hard_mul_const: float,
-                  ws: torch.Tensor) -> torch.Tensor:
+                  ws: torch.Tensor, save_for_backward: bool = False) -> torch.Tensor:
     B = x.shape[0]
     out = torch.empty((B, shape.L), dtype=torch.float32, device=x.device)
     d = shape.desc()
     rc = _lib.load().nsvd_model_forward(C.byref(d), C.byref(params), _ptr(x, "x"), B, float(hard_mul_const),
-                                        _ptr(out), ws.data_ptr(), ws.numel(), PATH_AUTO, _stream())
+                                        _ptr(out), ws.data_ptr(), ws.numel(), int(save_for_backward), _stream())
     check(rc, "nsvd_model_forward")
     return out
+
+
+def model_backward(shape: ModelShape, params: Params, x: torch.Tensor, dout: torch.Tensor, grads: Params,
+                   ws: torch.Tensor) -> None:
+    d = shape.desc()
+    rc = _lib.load().nsvd_model_backward(C.byref(d), C.byref(params), _ptr(x, "x"), x.shape[0], _ptr(dout, "dout"),
+                                         C.byref(grads), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "nsvd_model_backward")
 
 
 def evd_scratch(B: int, L: int, device) -> torch.Tensor:

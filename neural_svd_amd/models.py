@@ -152,12 +152,31 @@ class WaveFunctions(nn.Module):
     def grad_buffers(self) -> _GradBuffers:
         return _GradBuffers(self.shape, [t.data for t in self.trainable_tensors()])
 
-    @torch.no_grad()
     def forward(self, x):
+        """model(x) -> (B, L). Differentiable w.r.t. the parameters (nsvd_model_forward / _backward)."""
         x = x.reshape(x.shape[0], -1).float().contiguous()
-        shape = self.shape
-        return H.model_forward(shape, self.packed_params(), x, float(self.hard_mul_const),
-                               H.new_workspace(shape, x.shape[0], x.device))
+        return _ModelFn.apply(x, self, *self.trainable_tensors())
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        shape = model.shape
+        need_grad = any(ctx.needs_input_grad)
+        ws = H.new_workspace(shape, x.shape[0], x.device)
+        out = H.model_forward(shape, model.packed_params(), x, float(model.hard_mul_const), ws,
+                              save_for_backward=need_grad)
+        ctx.model, ctx.ws = model, (ws if need_grad else None)
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        model = ctx.model
+        grads = model.grad_buffers()
+        H.model_backward(model.shape, model.packed_params(), x, dout.contiguous(), grads.packed, ctx.ws)
+        return (None, None) + tuple(grads.tensors)
 
 
 def parse_str(dims_str: str):

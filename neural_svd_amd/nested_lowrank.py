@@ -177,6 +177,22 @@ class NestedLoRA(nn.Module):
         loss = self._compute_loss(f, Tf, f1, f2, evd=True)
         return loss, dict(f=f, Tf=Tf, eigvals=None)
 
+    def compute_loss_kernel(self, get_approx_kernel_op, x, importance, split_batch: bool, evd: bool = True):
+        """reference methods/nestedlora.py:230-252 (no caller in the reference; kept for the interface).
+        ``get_approx_kernel_op(x)(self, x, importance)`` returns (Kf, f) built from ``self(x)`` (which is
+        differentiable here); the loss itself runs on the HIP EVD kernels. split_batch=True needs
+        independent f1 / f2 moments, which the HIP loss kernels do not take."""
+        if not evd:
+            raise NotImplementedError
+        if split_batch:
+            raise NotImplementedError("compute_loss_kernel(split_batch=True): independent f1/f2 batches are not "
+                                      "on the HIP path")
+        Kf, f = get_approx_kernel_op(x)(self, x, importance=importance)
+        f = f.contiguous()
+        f1, f2 = torch.chunk(f, 2)
+        loss = self._compute_loss(f, Kf.contiguous(), f1, f2, evd=True)
+        return loss, dict(f=f, Tf=Kf, eigvals=None)
+
     def apply_operator(self, operator, x, importance=None):
         """Tf, f = operator(self, x, importance) on the HIP path."""
         from .operators import fused_problem_of

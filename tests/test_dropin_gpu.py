@@ -178,3 +178,53 @@ def test_fused_trainer_learns_oscillator():
     gt = np.array([14.0, 12, 12, 10, 10, 10])
     err = np.abs(out["eigvals"].numpy() - gt) / gt
     assert np.isfinite(err).all() and err.mean() < 2e-2, (out["eigvals"], err)
+
+
+def test_model_autograd_and_compute_loss_kernel():
+    """method(x) is differentiable (nsvd_model_forward/_backward), and compute_loss_kernel
+    (methods/nestedlora.py:230-252, split_batch=False) runs a user kernel operator built on it."""
+    z = G.load("model_small")
+    case = "osc_small"
+    cfg, args, operator, gt, method, loaders = build(case, z)
+    p64 = G.params_from_golden(z, case).to(torch.float64)
+    x = torch.tensor(z[f"{case}_x"][0]).to(DEV)
+    xc = x.double().cpu()
+    B = x.shape[0]
+
+    # --- plain autograd through method(x)
+    wgt = torch.randn(B, cfg["neigs"], generator=torch.Generator().manual_seed(3))
+    out = method(x)
+    assert out.requires_grad
+    (out * wgt.to(DEV)).sum().backward()
+    prob_plain = O.Problem(potential=O.POT_HARMONIC, eps=0.01, use_importance=False)
+    c = O.operator_forward(xc, p64, prob_plain)          # without importance, f == model(x)
+    assert rel(out, c.f) < 1e-5
+    gref = O.operator_backward(c, p64, prob_plain, wgt.double())
+    names = G.trainable_names(z, case)
+    got = dict(method.named_parameters())
+    for n, g in zip(names, gref):
+        assert rel(got[n].grad, g) < 3e-5, n
+    method.zero_grad()
+
+    # --- a Gaussian kernel operator: (K f)(x_i) = mean_j k(x_i, x_j) f(x_j)
+    def get_approx_kernel_op(xk):
+        K = torch.exp(-0.02 * torch.cdist(xk, xk) ** 2)
+
+        def op(model, xx, importance=None):
+            f = model(xx)
+            return K @ f / xx.shape[0], f
+        return op
+
+    loss, aux = method.compute_loss_kernel(get_approx_kernel_op, x, None, split_batch=False)
+    loss.backward()
+    K64 = torch.exp(-0.02 * torch.cdist(xc, xc) ** 2)
+    Kf64 = K64 @ c.f / B
+    v, M = method.vector_mask.double(), method.matrix_mask.double()
+    l64, lam1, lam2, _, _ = O.evd_loss_forward(c.f, Kf64, v, M)
+    df = O.evd_loss_backward(c.f, Kf64, v, M, lam1, lam2)
+    gref = O.operator_backward(c, p64, prob_plain, df)
+    assert abs(float(loss) - float(l64)) < 1e-4 * abs(float(l64))
+    for n, g in zip(names, gref):
+        assert rel(got[n].grad, g) < 1e-4, n
+    with pytest.raises(NotImplementedError):
+        method.compute_loss_kernel(get_approx_kernel_op, x, None, split_batch=True)
