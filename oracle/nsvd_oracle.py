@@ -86,6 +86,57 @@ def evd_loss_backward(f, Tf, v, M, lam1, lam2, grad_output=1.0):
     return grad_output * g
 
 
+# ----------------------------------------------------------------------------- CDK loss
+def off_diagonal(x):
+    """reference methods/utils.py:16-22."""
+    n = x.shape[0]
+    return x.flatten()[:-1].view(n - 1, n + 1)[:, 1:].flatten()
+
+
+def joint_nesting_masks_from_weights(weights, set_first_mode_const=False):
+    """reference methods/nestedlora.py:40-46 incl. the duplicated first entry for the constant mode."""
+    v = list(np.cumsum(list(weights)[::-1])[::-1])
+    if set_first_mode_const:
+        v = [v[0]] + v
+    v = torch.tensor(np.array(v)).float()
+    return v, torch.minimum(v.unsqueeze(1), v.unsqueeze(0)).float()
+
+
+def cdk_masks(L, sequential, step=1, set_first_mode_const=True):
+    """NestedLoRAForCDK.__init__ (reference methods/nestedlora.py:345-359)."""
+    if sequential:
+        Lp = L + 1 if set_first_mode_const else L
+        return torch.ones(Lp), torch.triu(torch.ones(Lp, Lp))
+    ends = list(range(step, L + 1, step))
+    if L not in ends:
+        ends.append(L)
+    w = np.zeros(L)
+    w[np.array(ends) - 1] = 1.0
+    return joint_nesting_masks_from_weights(w / w.sum(), set_first_mode_const)
+
+
+def cdk_loss(f, g, v, M, set_first_mode_const=True, batch_weights=None):
+    """NestedLoRALossFunctionForCDK forward + backward (reference methods/nestedlora.py:273-332).
+    Returns loss, loss_operator, loss_metric, rs_joint, rs_indep, grad_f, grad_g. NOTE (reference
+    behaviour): the returned gradients are w.r.t. the batch-weighted, padded features; the weights are
+    not chain-ruled back, and the constant column's gradient is dropped."""
+    if set_first_mode_const:
+        one = torch.ones(f.shape[0], 1, dtype=f.dtype)
+        f, g = torch.cat([one, f], 1), torch.cat([one, g], 1)
+    if batch_weights is not None:
+        f, g = f * batch_weights, g * batch_weights
+    B = f.shape[0]
+    lam_f, lam_g = f.T @ f / B, g.T @ g / B
+    loss_metric = (M * lam_f * lam_g).sum()
+    loss_op = -2.0 * ((f * g) @ v).mean()
+    gram = f @ g.T
+    gf = -(2.0 / B) * g * v.unsqueeze(0) + (2.0 / B) * (f @ (M * lam_g))
+    gg = -(2.0 / B) * f * v.unsqueeze(0) + (2.0 / B) * (g @ (M * lam_f))
+    if set_first_mode_const:
+        gf, gg = gf[:, 1:], gg[:, 1:]
+    return loss_op + loss_metric, loss_op, loss_metric, gram.diag(), off_diagonal(gram), gf, gg
+
+
 # ----------------------------------------------------------------------------- model
 @dataclass
 class Params:

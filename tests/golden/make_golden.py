@@ -266,6 +266,42 @@ def golden_debug_model(out):
     out["debug_B"] = fm._B.detach().float().numpy()
 
 
+def golden_cdk(out):
+    """NestedLoRALossFunctionForCDK (methods/nestedlora.py:270-332) + NestedLoRAForCDK masks (:335-378)."""
+    from methods.nestedlora import NestedLoRALossFunctionForCDK, NestedLoRAForCDK
+    g = torch.Generator().manual_seed(4321)
+    cases = dict(
+        a=dict(B=9, L=5, seq=False, step=1, first=True, bw=False),
+        b=dict(B=16, L=8, seq=True, step=1, first=True, bw=True),
+        c=dict(B=12, L=6, seq=False, step=4, first=False, bw=False),
+        d=dict(B=70, L=33, seq=False, step=1, first=True, bw=False),
+        e=dict(B=64, L=512, seq=False, step=1, first=True, bw=False),
+    )
+    for name, c in cases.items():
+        B, L = c["B"], c["L"]
+        f64 = torch.randn(B, L, generator=g, dtype=torch.float64) * 0.5
+        g64 = torch.randn(B, L, generator=g, dtype=torch.float64) * 0.5
+        bw64 = (torch.rand(B, 1, generator=g, dtype=torch.float64) + 0.5) if c["bw"] else None
+        m = NestedLoRAForCDK(model=None, neigs=L, step=c["step"], sequential=c["seq"], set_first_mode_const=c["first"])
+        p = f"cdk_{name}_"
+        out[p + "f"], out[p + "g"] = f64.numpy(), g64.numpy()
+        if bw64 is not None:
+            out[p + "bw"] = bw64.numpy()
+        out[p + "v"], out[p + "M"] = m.vector_mask.numpy(), m.matrix_mask.numpy()
+        out[p + "cfg"] = np.array([B, L, int(c["seq"]), c["step"], int(c["first"]), int(c["bw"])])
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            f = f64.to(dt).clone().requires_grad_(True)
+            gg = g64.to(dt).clone().requires_grad_(True)
+            bw = None if bw64 is None else bw64.to(dt)
+            loss, lop, lmet, rj, ri = NestedLoRALossFunctionForCDK.apply(
+                f, gg, m.vector_mask.to(dt), m.matrix_mask.to(dt), c["first"], bw)
+            loss.backward()
+            q = p + tag + "_"
+            out[q + "loss"] = np.array([float(loss), float(lop), float(lmet)])
+            out[q + "rs_joint"], out[q + "rs_indep"] = np64(rj), np64(ri)
+            out[q + "grad_f"], out[q + "grad_g"] = np64(f.grad), np64(gg.grad)
+
+
 def golden_ground_truth(out):
     out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
     out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
@@ -287,6 +323,10 @@ def main():
     golden_ground_truth(o)
     golden_debug_model(o)
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **o)
+
+    o = {}
+    golden_cdk(o)
+    np.savez_compressed(os.path.join(HERE, "cdk_loss.npz"), **o)
 
     # small seeded models (fit the MFMA fast path: H=32 blocks) -----------------
     o = {}
@@ -315,7 +355,7 @@ def main():
                  fourier_mapping_size=1024, fourier_scale=0.1, sampling_scale=16.0, batch_size=128,
                  operator_scale=100.0, operator_shift=0.0, sequential=1, seed=0)
     np.savez_compressed(os.path.join(HERE, "model_headline.npz"), **o)
-    for fn in ("masks", "evd_loss", "misc", "model_small", "model_headline"):
+    for fn in ("masks", "evd_loss", "cdk_loss", "misc", "model_small", "model_headline"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

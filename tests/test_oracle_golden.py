@@ -196,3 +196,23 @@ def test_torch_port_matches_reference_f32(case):
         for n in names:
             # RMSprop's first steps are +-lr/sqrt(1-alpha) * sign(g): insensitive to gradient noise
             assert G.rel(params[n].detach(), z[pre + "param_" + n]) < 1e-3, n
+
+
+# ------------------------------------------------------------------ CDK loss (next row: methods/cdk.py path)
+@pytest.mark.parametrize("case", list("abcde"))
+@pytest.mark.parametrize("tag,dtype,tol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 3e-5)])
+def test_cdk_loss(case, tag, dtype, tol):
+    z = G.load("cdk_loss")
+    B, L, seq, step, first, has_bw = [int(t) for t in z[f"cdk_{case}_cfg"]]
+    v, M = O.cdk_masks(L, bool(seq), step, bool(first))
+    assert np.array_equal(v.numpy(), z[f"cdk_{case}_v"]) and np.array_equal(M.numpy(), z[f"cdk_{case}_M"])
+    f = torch.tensor(z[f"cdk_{case}_f"]).to(dtype)
+    g = torch.tensor(z[f"cdk_{case}_g"]).to(dtype)
+    bw = torch.tensor(z[f"cdk_{case}_bw"]).to(dtype) if has_bw else None
+    loss, lop, lmet, rj, ri, gf, gg = O.cdk_loss(f, g, v.to(dtype), M.to(dtype), bool(first), bw)
+    p = f"cdk_{case}_{tag}_"
+    want = z[p + "loss"]
+    for got, w in zip((loss, lop, lmet), want):
+        assert abs(float(got) - float(w)) <= tol * max(1.0, abs(float(w)))
+    assert G.rel(rj, z[p + "rs_joint"]) <= tol and G.rel(ri, z[p + "rs_indep"]) <= tol
+    assert G.rel(gf, z[p + "grad_f"]) <= tol and G.rel(gg, z[p + "grad_g"]) <= tol
