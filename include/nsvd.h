@@ -213,6 +213,31 @@ int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, in
                              float sigma, int use_importance, float lim, float* cov, float* quad,
                              void* stream);
 
+/* ---- next row: the CDK (two-tower) NestedLoRA loss ------------------------------------------------------
+ * NestedLoRALossFunctionForCDK (methods/nestedlora.py:273-332) as called by NestedLoRAForCDK.compute_loss
+ * (methods/nestedlora.py:366-378; examples/cdk/sketchy/main_sketchy.py:188).
+ * f, g: (B, L) row-major float32 tower outputs. With Lp = L + (set_first_mode_const != 0):
+ *   f~ = batch_weights[:, None] * [1, f]  (constant first mode when set_first_mode_const; weights optional, (B,))
+ *   lam_f = f~^T f~ / B, lam_g = g~^T g~ / B
+ *   loss[0] = loss[1] + loss[2]; loss[1] = -2 mean_b sum_l v_l f~ g~; loss[2] = sum(M * lam_f * lam_g)
+ *   rs_joint (B) = diag(f~ g~^T), rs_indep (B (B-1)) = off_diagonal(f~ g~^T) (methods/utils.py:16-22); either
+ *   may be NULL (both NULL skips the (B, B) gram contraction).
+ * v: (Lp), M: (Lp, Lp) nesting masks (methods/nestedlora.py:345-359), float32 on the device.
+ * ws: nsvd_cdk_workspace_bytes(B, L, set_first_mode_const) bytes; keeps f~, g~ and M * lam for the backward.
+ * Arithmetic is float32 on the fp32-input MFMA, independent of any autocast state of the caller. */
+size_t nsvd_cdk_workspace_bytes(int B, int L, int set_first_mode_const);
+int nsvd_cdk_loss_forward(const float* f, const float* g, const float* batch_weights, const float* v,
+                          const float* M, int B, int L, int set_first_mode_const, float* loss, float* rs_joint,
+                          float* rs_indep, void* ws, size_t ws_bytes, void* stream);
+
+/* NestedLoRALossFunctionForCDK.backward (methods/nestedlora.py:309-332) after nsvd_cdk_loss_forward on the
+ * same ws:  grad_f = grad_out * ( -(2/B) g~ v + (2/B) f~ (M * lam_g) )[:, first:], grad_g with f <-> g.
+ * As in the reference the result is the gradient w.r.t. the WEIGHTED features (batch_weights are not
+ * chain-ruled) and the constant column is dropped. grad_out: device scalar (the autograd grad_output, e.g.
+ * the AMP loss scale) or NULL for 1. grad_f / grad_g: (B, L), either may be NULL. */
+int nsvd_cdk_loss_backward(const float* v, int B, int L, int set_first_mode_const, const float* grad_out,
+                           float* grad_f, float* grad_g, void* ws, size_t ws_bytes, void* stream);
+
 /* Measurement aid (bench.py): record the two hipEvent_t handles immediately before / after the
  * DOMINANT kernel of the next nsvd_operator_forward call made by this host thread (the fused MFMA
  * forward kernel, or the layer-0 GEMM on the generic path), on that call's stream. One-shot;

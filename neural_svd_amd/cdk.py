@@ -1,0 +1,102 @@
+"""Drop-in surface of the reference's CDK (two-tower / cross-domain) NestedLoRA loss, backed by the HIP C ABI
+(``nsvd_cdk_loss_forward`` / ``nsvd_cdk_loss_backward``). Same names, arguments and return values:
+
+    NestedLoRALossFunctionForCDK.apply(f, g, vmask, mmask, set_first_mode_const, batch_weights)
+                                                                  methods/nestedlora.py:270-332
+    NestedLoRAForCDK(model, neigs, step, sequential, set_first_mode_const).compute_loss(f, g, batch_weights)
+                                                                  methods/nestedlora.py:335-378
+    get_cdk_method(args, model)                                   methods/cdk.py:4-16
+
+Differences, all deliberate: the arithmetic is float32 on the MFMA whatever the autocast state (the reference's
+un-decorated Function runs its matmuls in half precision under ``torch.cuda.amp.autocast``; half inputs are
+upcast here and the gradients returned in the input dtype); ``batch_weights`` must be one weight per row; the
+inputs are never modified in place (the reference's ``f *= batch_weights`` writes into the caller's tensor when
+``set_first_mode_const`` is off).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops as H
+from ._lib import NsvdError
+from .nested_lowrank import get_joint_nesting_masks, get_sequential_nesting_masks, joint_step_weights
+
+
+class NestedLoRALossFunctionForCDK(torch.autograd.Function):
+    """-> (loss, loss_operator, loss_metric, rs_joint, rs_indep); gradients flow to f and g only."""
+
+    @staticmethod
+    def forward(ctx, f, g, vector_mask, matrix_mask, set_first_mode_const=False, batch_weights=None):
+        if f.dim() != 2 or f.shape != g.shape:
+            raise NsvdError("NestedLoRALossFunctionForCDK: f and g must both be (B, L)")
+        if not f.is_cuda:
+            raise NsvdError("NestedLoRALossFunctionForCDK: tensors must live on the GPU (no CPU path)")
+        B, L = f.shape
+        first = bool(set_first_mode_const)
+        dev = f.device
+        f32, g32 = f.detach().float().contiguous(), g.detach().float().contiguous()
+        v = vector_mask.detach().to(device=dev, dtype=torch.float32).contiguous()
+        M = matrix_mask.detach().to(device=dev, dtype=torch.float32).contiguous()
+        bw = None
+        if batch_weights is not None:
+            if batch_weights.numel() != B:
+                raise NotImplementedError("HIP path: batch_weights must be one weight per row, (B,) or (B, 1)")
+            bw = batch_weights.detach().to(device=dev, dtype=torch.float32).reshape(B).contiguous()
+        ws = H.cdk_workspace(B, L, first, dev)
+        loss = torch.empty(3, device=dev, dtype=torch.float32)
+        rs_joint = torch.empty(B, device=dev, dtype=torch.float32)
+        rs_indep = torch.empty(B * (B - 1), device=dev, dtype=torch.float32)
+        H.cdk_loss_forward(f32, g32, bw, v, M, first, loss, rs_joint, rs_indep, ws)
+        ctx.ws, ctx.v, ctx.meta = ws, v, (B, L, first, f.dtype, g.dtype)
+        ctx.mark_non_differentiable(rs_joint, rs_indep)
+        return loss[0], loss[1], loss[2], rs_joint, rs_indep
+
+    @staticmethod
+    def backward(ctx, grad_output, *unused):
+        B, L, first, fdt, gdt = ctx.meta
+        need_f, need_g = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dev = ctx.v.device
+        gf = torch.empty(B, L, device=dev, dtype=torch.float32) if need_f else None
+        gg = torch.empty(B, L, device=dev, dtype=torch.float32) if need_g else None
+        if need_f or need_g:
+            go = grad_output.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+            H.cdk_loss_backward(ctx.v, B, L, first, go, gf, gg, ctx.ws)
+        return (None if gf is None else gf.to(fdt), None if gg is None else gg.to(gdt), None, None, None, None)
+
+
+class NestedLoRAForCDK(nn.Module):
+    def __init__(self, model, neigs, step=1, sequential=False, set_first_mode_const=True):
+        self.name = "nestedlora"
+        super().__init__()
+        self.neigs = neigs
+        self.sequential = sequential
+        if sequential:
+            self.vector_mask, self.matrix_mask = get_sequential_nesting_masks(neigs, set_first_mode_const)
+        else:
+            self.vector_mask, self.matrix_mask = get_joint_nesting_masks(joint_step_weights(neigs, step),
+                                                                         set_first_mode_const)
+        self.set_first_mode_const = set_first_mode_const
+        self.model = model
+        self._dev_masks = None
+
+    def forward(self, *args):
+        return self.model(*args)
+
+    def _masks_on(self, device):
+        if self._dev_masks is None or self._dev_masks[0].device != device:
+            self._dev_masks = (self.vector_mask.to(device), self.matrix_mask.to(device))
+        return self._dev_masks
+
+    def compute_loss(self, f, g, batch_weights=None):
+        v, M = self._masks_on(f.device)
+        return NestedLoRALossFunctionForCDK.apply(f, g, v, M, self.set_first_mode_const, batch_weights)
+
+
+def get_cdk_method(args, model):
+    """Same nested ``args.loss.neuralsvd.*`` attribute layout as the reference's config object."""
+    if args.loss.name == "neuralsvd":
+        return NestedLoRAForCDK(model, neigs=args.neigs, step=args.loss.neuralsvd.step,
+                                sequential=args.loss.neuralsvd.sequential,
+                                set_first_mode_const=args.loss.neuralsvd.set_first_mode_const)
+    raise NotImplementedError

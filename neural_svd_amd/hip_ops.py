@@ -280,6 +280,41 @@ def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: t
     check(rc, "nsvd_operator_backward_evd")
 
 
+def cdk_workspace(B: int, L: int, set_first_mode_const: bool, device) -> torch.Tensor:
+    n = _lib.load().nsvd_cdk_workspace_bytes(int(B), int(L), int(bool(set_first_mode_const)))
+    return torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+
+
+def cdk_loss_forward(f: torch.Tensor, g: torch.Tensor, batch_weights: Optional[torch.Tensor], v: torch.Tensor,
+                     M: torch.Tensor, set_first_mode_const: bool, loss: torch.Tensor,
+                     rs_joint: Optional[torch.Tensor], rs_indep: Optional[torch.Tensor], ws: torch.Tensor) -> None:
+    """NestedLoRALossFunctionForCDK.forward: loss (3), rs_joint (B), rs_indep (B(B-1)); state for the backward in ws."""
+    B, L = f.shape
+    Lp = L + int(bool(set_first_mode_const))
+    if tuple(g.shape) != (B, L) or v.numel() != Lp or tuple(M.shape) != (Lp, Lp) or loss.numel() < 3:
+        raise NsvdError(f"cdk_loss_forward: f, g (B, L); v ({Lp}); M ({Lp}, {Lp}); loss (3)")
+    if batch_weights is not None and batch_weights.numel() != B:
+        raise NsvdError("cdk_loss_forward: batch_weights must hold one weight per row")
+    if (rs_joint is not None and rs_joint.numel() != B) or (rs_indep is not None and rs_indep.numel() != B * (B - 1)):
+        raise NsvdError("cdk_loss_forward: rs_joint (B), rs_indep (B (B-1))")
+    rc = _lib.load().nsvd_cdk_loss_forward(_ptr(f, "f"), _ptr(g, "g"), _ptr(batch_weights, "batch_weights"),
+                                           _ptr(v, "v"), _ptr(M, "M"), B, L, int(bool(set_first_mode_const)),
+                                           _ptr(loss, "loss"), _ptr(rs_joint, "rs_joint"),
+                                           _ptr(rs_indep, "rs_indep"), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "nsvd_cdk_loss_forward")
+
+
+def cdk_loss_backward(v: torch.Tensor, B: int, L: int, set_first_mode_const: bool, grad_out: Optional[torch.Tensor],
+                      grad_f: Optional[torch.Tensor], grad_g: Optional[torch.Tensor], ws: torch.Tensor) -> None:
+    for t, n in ((grad_f, "grad_f"), (grad_g, "grad_g")):
+        if t is not None and tuple(t.shape) != (B, L):
+            raise NsvdError(f"cdk_loss_backward: {n} must be (B, L)")
+    rc = _lib.load().nsvd_cdk_loss_backward(_ptr(v, "v"), int(B), int(L), int(bool(set_first_mode_const)),
+                                            _ptr(grad_out, "grad_out"), _ptr(grad_f, "grad_f"),
+                                            _ptr(grad_g, "grad_g"), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "nsvd_cdk_loss_backward")
+
+
 def rmsprop_ema_step(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, ema: Optional[torch.Tensor], lr: float,
                      alpha: float, eps: float, ema_decay: float, grad_scale: float = 1.0) -> None:
     n = p.numel()
