@@ -195,6 +195,27 @@ int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsvd_params* p
                                const void* evd_scratch, int L_total, int l_offset, float grad_scale, float* loss,
                                const nsvd_params* grads, void* ws, size_t ws_bytes, int path, void* stream);
 
+/* nsvd_operator_backward_evd with the optimiser step of nsvd_rmsprop_ema_step taken inside the
+ * weight-gradient kernel: each gradient element updates its parameter (params->W/b/scales, IN PLACE), RMSprop
+ * square average (opt->sq) and EMA shadow (opt->ema, when has_ema) as it leaves the accumulator, so gradients
+ * never make the HBM round trip and the optimiser launch disappears (optimizer.step() + ema.update() of
+ * examples/operator/__init__.py:69-73 folded into loss.backward() of :68). Bit-identical to the two separate
+ * calls. grads may be NULL on the fused path (gradients are then not stored at all); on the generic path grads
+ * is required and the step is taken by per-tensor optimiser launches. lr / ema_decay are the already scheduled
+ * values, as for nsvd_rmsprop_ema_step. Not for data-parallel runs (gradients must be all-reduced first). */
+typedef struct nsvd_rmsprop {
+    nsvd_params sq;                  /* RMSprop square averages, parameter layouts      */
+    nsvd_params ema;                 /* EMA shadow parameters (ignored unless has_ema)  */
+    double lr, alpha, eps, ema_decay;
+    int32_t has_ema;
+} nsvd_rmsprop;
+int nsvd_operator_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params,
+                                    const nsvd_problem* prob, const float* x, int B, const float* f,
+                                    const float* Tf, int mask_kind, const float* v, const float* M,
+                                    float* moments, int moments_reduced, const void* evd_scratch, int L_total,
+                                    int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
+                                    const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream);
+
 /* torch.optim.RMSprop(alpha, eps, momentum=0, centered=False) step + torch_ema update, fused
  * (examples/utils.py:50-57, examples/operator/__init__.py:69-73):
  *   g = grad_scale * grad; sq = alpha sq + (1-alpha) g^2; p -= lr g / (sqrt(sq) + eps);

@@ -41,6 +41,11 @@ class Problem(C.Structure):
                 ("hard_mul_const", C.c_float), ("use_importance", C.c_int32)]
 
 
+class Rmsprop(C.Structure):
+    _fields_ = [("sq", Params), ("ema", Params), ("lr", C.c_double), ("alpha", C.c_double), ("eps", C.c_double),
+                ("ema_decay", C.c_double), ("has_ema", C.c_int32)]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/nsvd.h
 _P, _I, _F, _Z, _Dbl = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
 SIGNATURES = {
@@ -62,6 +67,9 @@ SIGNATURES = {
     "nsvd_evd_partial": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "nsvd_operator_backward_evd": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _P,
                                         _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params), _P, _Z, _I, _P]),
+    "nsvd_operator_backward_evd_step": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
+                                             _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params),
+                                             C.POINTER(Rmsprop), _P, _Z, _I, _P]),
     "nsvd_evd_loss_fused": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "nsvd_rmsprop_ema_step": (_I, [_P, _P, _P, _P, _Z, _Dbl, _Dbl, _Dbl, _Dbl, _Dbl, _P]),
     "nsvd_profile_next_forward": (_I, [_P, _P]),

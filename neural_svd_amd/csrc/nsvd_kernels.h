@@ -63,5 +63,12 @@ int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const ns
                         int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s);
 struct NsvdEvdIn;  // evd_math.h
 // backward with d loss / d f derived from the EVD moments inside the chain kernel (no df round trip)
+// g: where to store the gradients (null: not stored); opt: RMSprop + EMA applied in the weight-gradient kernel's
+// epilogue, parameters updated in place (null: no step). At least one of the two.
+struct NsvdOptStep;  // opt_math.h
+struct NsvdHyper;
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
-                            const nsvd_params& g, void* ws, hipStream_t s);
+                            const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s);
+// stand-alone optimiser launch over n contiguous floats (optimizer.hip)
+int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,
+                        hipStream_t s);

@@ -4,6 +4,7 @@
 #include <string.h>
 #include "nsvd_kernels.h"
 #include "evd_math.h"
+#include "opt_math.h"
 
 static thread_local hipEvent_t g_prof_start = nullptr;
 static thread_local hipEvent_t g_prof_stop = nullptr;
@@ -269,13 +270,12 @@ extern "C" int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_pa
     return generic_backward(*desc, *params, x, B, df, *grads, ws, (hipStream_t)stream);
 }
 
-extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsvd_params* params,
-                                          const nsvd_problem* prob, const float* x, int B, const float* f,
-                                          const float* Tf, int mask_kind, const float* v, const float* M,
-                                          float* moments, int moments_reduced, const void* evd_scratch,
-                                          int L_total, int l_offset, float grad_scale, float* loss,
-                                          const nsvd_params* grads, void* ws, size_t ws_bytes, int path,
-                                          void* stream) {
+namespace {
+int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, const nsvd_problem* prob,
+                      const float* x, int B, const float* f, const float* Tf, int mask_kind, const float* v,
+                      const float* M, float* moments, int moments_reduced, const void* evd_scratch, int L_total,
+                      int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
+                      const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream) {
     int rc = validate(desc);
     if (rc) return rc;
     if (!prob || !x || !f || !Tf || !moments || !ws || B <= 0) return NSVD_EINVAL;
@@ -284,8 +284,23 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
     if (mask_kind == NSVD_MASK_CUSTOM && (!v || !M)) return NSVD_EINVAL;
     rc = check_params(*desc, params, true);
     if (rc) return rc;
-    rc = check_params(*desc, grads, false);
-    if (rc) return rc;
+    if (grads || !opt) {
+        rc = check_params(*desc, grads, false);
+        if (rc) return rc;
+    }
+    NsvdOptStep st;
+    memset(&st, 0, sizeof(st));
+    if (opt) {
+        rc = check_params(*desc, &opt->sq, false);
+        if (rc) return rc;
+        if (opt->has_ema) {
+            rc = check_params(*desc, &opt->ema, false);
+            if (rc) return rc;
+            st.ema = &opt->ema;
+        }
+        st.sq = opt->sq;
+        st.h = nsvd_make_hyper(opt->lr, opt->alpha, opt->eps, opt->has_ema ? opt->ema_decay : 0.0, 1.0);
+    }
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -311,7 +326,7 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
             in.part_op = in.part + (size_t)(c.n1 + c.n2) * L * L;
             in.moments_out = moments;
         }
-        return nsvd_fused_backward_evd(*desc, *params, B, in, *grads, ws, s);
+        return nsvd_fused_backward_evd(*desc, *params, B, in, grads, opt ? &st : nullptr, ws, s);
     }
     // generic path: finish the loss with the stand-alone kernels, then the layer-by-layer backward
     if (L_total != desc->L) return NSVD_EUNSUPPORTED;  // head-parallel sharding needs the fused kernels
@@ -322,5 +337,49 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
     }
     rc = nsvd_evd_loss_grad(f, Tf, B, L, mask_kind, v, M, moments, grad_scale, loss, w.df, stream);
     if (rc) return rc;
-    return generic_backward(*desc, *params, x, B, w.df, *grads, ws, s);
+    if (!grads) return NSVD_EINVAL;  // the generic path needs somewhere to put the gradients
+    rc = generic_backward(*desc, *params, x, B, w.df, *grads, ws, s);
+    if (rc || !opt) return rc;
+    // generic path + fused-step request: one stand-alone optimiser launch per tensor
+    const int F = 2 * desc->m;
+    for (int i = 0; i < desc->nlayers; ++i) {
+        const size_t hin = i == 0 ? (size_t)F : (size_t)desc->dims[i - 1], hout = (size_t)desc->dims[i];
+        rc = nsvd_rmsprop_launch(params->W[i], grads->W[i], st.sq.W[i], st.ema ? st.ema->W[i] : nullptr,
+                                 (size_t)desc->L * hout * hin, st.h, s);
+        if (rc) return rc;
+        rc = nsvd_rmsprop_launch(params->b[i], grads->b[i], st.sq.b[i], st.ema ? st.ema->b[i] : nullptr,
+                                 (size_t)desc->L * hout, st.h, s);
+        if (rc) return rc;
+    }
+    if (desc->has_exp_mask)
+        rc = nsvd_rmsprop_launch(params->scales, grads->scales, st.sq.scales, st.ema ? st.ema->scales : nullptr,
+                                 (size_t)desc->L, st.h, s);
+    return rc;
+}
+}  // namespace
+
+extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsvd_params* params,
+                                          const nsvd_problem* prob, const float* x, int B, const float* f,
+                                          const float* Tf, int mask_kind, const float* v, const float* M,
+                                          float* moments, int moments_reduced, const void* evd_scratch,
+                                          int L_total, int l_offset, float grad_scale, float* loss,
+                                          const nsvd_params* grads, void* ws, size_t ws_bytes, int path,
+                                          void* stream) {
+    if (!grads) return NSVD_EINVAL;
+    return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
+                             evd_scratch, L_total, l_offset, grad_scale, loss, grads, nullptr, ws, ws_bytes, path,
+                             stream);
+}
+
+extern "C" int nsvd_operator_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params,
+                                               const nsvd_problem* prob, const float* x, int B, const float* f,
+                                               const float* Tf, int mask_kind, const float* v, const float* M,
+                                               float* moments, int moments_reduced, const void* evd_scratch,
+                                               int L_total, int l_offset, float grad_scale, float* loss,
+                                               const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
+                                               size_t ws_bytes, int path, void* stream) {
+    if (!opt) return NSVD_EINVAL;
+    return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
+                             evd_scratch, L_total, l_offset, grad_scale, loss, grads, opt, ws, ws_bytes, path,
+                             stream);
 }

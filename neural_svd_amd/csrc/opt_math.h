@@ -1,0 +1,45 @@
+// RMSprop + EMA update of one parameter, shared by the stand-alone optimiser kernel (optimizer.hip) and the
+// weight-gradient kernel's fused epilogue (pmlp_fused.hip).
+//   reference: torch.optim.RMSprop as configured at examples/utils.py:50-57 (alpha, eps = 1e-10, momentum 0,
+//              not centred), stepped at examples/operator/__init__.py:69-70; torch_ema update at :73.
+#pragma once
+#include "nsvd_common.h"
+
+struct NsvdHyper {
+    float lr, alpha, one_minus_alpha, eps, one_minus_decay, grad_scale;
+};
+
+// parameter / RMSprop square average / EMA shadow (null: none) of one tensor, element-aligned with its gradient
+struct NsvdOptPtrs {
+    float* p;
+    float* sq;
+    float* ema;
+};
+
+// optimiser step fused into the backward: state tensors in the parameters' layouts
+struct NsvdOptStep {
+    NsvdHyper h;
+    nsvd_params sq;
+    const nsvd_params* ema;  // null: no EMA
+};
+
+// host scalars are doubles (Python floats), rounded to float32 exactly where torch rounds them
+static inline NsvdHyper nsvd_make_hyper(double lr, double alpha, double eps, double ema_decay, double grad_scale) {
+    NsvdHyper h;
+    h.lr = (float)lr;
+    h.alpha = (float)alpha;
+    h.one_minus_alpha = (float)(1.0 - alpha);
+    h.eps = (float)eps;
+    h.one_minus_decay = (float)(1.0 - ema_decay);
+    h.grad_scale = (float)grad_scale;
+    return h;
+}
+
+__device__ __forceinline__ void nsvd_rmsprop_upd(float& p, float g, float& sq, float* ema, const NsvdHyper& h) {
+    const float lr = h.lr, eps = h.eps, one_minus_decay = h.one_minus_decay;
+    g *= h.grad_scale;
+    sq = h.alpha * sq + h.one_minus_alpha * (g * g);  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
+    const float avg = sqrtf(sq) + eps;                // square_avg.sqrt().add_(eps)
+    p = p - lr * (g / avg);                           // param.addcdiv_(g, avg, value=-lr)
+    if (ema) *ema = *ema - one_minus_decay * (*ema - p);
+}

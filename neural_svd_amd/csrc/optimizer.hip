@@ -4,20 +4,13 @@
 //              torch_ema update at examples/operator/__init__.py:73.
 // HBM-bound: reads p, g, sq, ema and writes p, sq, ema = 28 B per parameter.
 #include "nsvd_kernels.h"
+#include "opt_math.h"
 
 namespace {
 
-struct Hyper {
-    float lr, alpha, one_minus_alpha, eps, one_minus_decay, grad_scale;
-};
-
+typedef NsvdHyper Hyper;
 __device__ __forceinline__ void upd(float& p, float g, float& sq, float* ema, const Hyper& h) {
-    const float lr = h.lr, eps = h.eps, one_minus_decay = h.one_minus_decay;
-    g *= h.grad_scale;
-    sq = h.alpha * sq + h.one_minus_alpha * (g * g);  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
-    const float avg = sqrtf(sq) + eps;         // square_avg.sqrt().add_(eps)
-    p = p - lr * (g / avg);                    // param.addcdiv_(g, avg, value=-lr)
-    if (ema) *ema = *ema - one_minus_decay * (*ema - p);
+    nsvd_rmsprop_upd(p, g, sq, ema, h);
 }
 
 template <bool HAS_EMA>
@@ -50,21 +43,11 @@ __global__ void __launch_bounds__(256) rmsprop_ema_kernel(float* __restrict__ p,
 
 }  // namespace
 
-extern "C" int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, size_t n, double lr,
-                                     double alpha, double eps, double ema_decay, double grad_scale,
-                                     void* stream) {
-    if (!p || !grad || !sq) return NSVD_EINVAL;
+int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,
+                        hipStream_t s) {
     if (n == 0) return 0;
     const uintptr_t al = (uintptr_t)p | (uintptr_t)grad | (uintptr_t)sq | (uintptr_t)ema;
     const size_t n4 = (al & 15) ? 0 : n / 4;  // unaligned (never with torch allocations): scalar path
-    Hyper h;
-    h.lr = (float)lr;
-    h.alpha = (float)alpha;
-    h.one_minus_alpha = (float)(1.0 - alpha);
-    h.eps = (float)eps;
-    h.one_minus_decay = (float)(1.0 - ema_decay);
-    h.grad_scale = (float)grad_scale;
-    hipStream_t s = (hipStream_t)stream;
     const size_t work = n4 ? n4 : n;
     size_t blocks = (work + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -74,4 +57,12 @@ extern "C" int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, flo
                             (float*)nullptr, n4, n, h);
     NSVD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, size_t n, double lr,
+                                     double alpha, double eps, double ema_decay, double grad_scale,
+                                     void* stream) {
+    if (!p || !grad || !sq) return NSVD_EINVAL;
+    return nsvd_rmsprop_launch(p, grad, sq, ema, n, nsvd_make_hyper(lr, alpha, eps, ema_decay, grad_scale),
+                               (hipStream_t)stream);
 }

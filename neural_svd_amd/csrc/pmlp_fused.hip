@@ -23,6 +23,7 @@
 #include "nsvd_kernels.h"
 #include "fd_math.h"
 #include "evd_math.h"
+#include "opt_math.h"
 
 namespace {
 
@@ -551,13 +552,57 @@ struct WgradArgs {
     const float* phiTc;                   // (F, B)
     const float* dbase;                   // (L, B) from the chain kernel
     const float* dfsc;                    // (L, B), null without the exponential mask
-    float* gW[NSVD_MAX_LAYERS];
+    float* gW[NSVD_MAX_LAYERS];           // gradients; may be null when the optimiser step is fused (opt != 0)
     float* gb[NSVD_MAX_LAYERS];
     float* gscales;
     int nlayers, B, L, F;
     int nA, nB;
     int bid0;  // first logical block of this launch (the A tiles and the B/C tiles are launched separately)
+    // fused RMSprop + EMA epilogue (opt != 0): every gradient element is applied to its parameter in place
+    // the moment it leaves the accumulator, so it never makes the HBM round trip (-8 B/parameter, -1 launch).
+    // Safe in place: this kernel reads no parameter, the chain kernel that does has already run.
+    int opt;
+    NsvdHyper h;
+    NsvdOptPtrs oW[NSVD_MAX_LAYERS], ob[NSVD_MAX_LAYERS], oscales;
 };
+
+// one gradient element: store it and / or take the optimiser step on its parameter
+__device__ __forceinline__ void wg_emit1(const WgradArgs& a, float* g, const NsvdOptPtrs& o, size_t off, float val) {
+    if (g) g[off] = val;
+    if (a.opt) {
+        float pv = o.p[off], sv = o.sq[off], ev = o.ema ? o.ema[off] : 0.f;
+        nsvd_rmsprop_upd(pv, val, sv, o.ema ? &ev : nullptr, a.h);
+        o.p[off] = pv;
+        o.sq[off] = sv;
+        if (o.ema) o.ema[off] = ev;
+    }
+}
+
+// the 16 accumulator registers of one 32 x 32 MFMA tile: rows acc_row(r, hi) * ld, this lane's column at `base`
+__device__ __forceinline__ void wg_emit16(const WgradArgs& a, float* g, const NsvdOptPtrs& o, size_t base, size_t ld,
+                                          int hi, const f32x16& acc) {
+    if (g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[base + (size_t)acc_row(r, hi) * ld] = acc[r];
+    }
+    if (!a.opt) return;
+    float pv[16], sv[16], ev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // 48 independent loads in flight
+        const size_t off = base + (size_t)acc_row(r, hi) * ld;
+        pv[r] = o.p[off];
+        sv[r] = o.sq[off];
+        ev[r] = o.ema ? o.ema[off] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t off = base + (size_t)acc_row(r, hi) * ld;
+        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], o.ema ? &ev[r] : nullptr, a.h);
+        o.p[off] = pv[r];
+        o.sq[off] = sv[r];
+        if (o.ema) o.ema[off] = ev[r];
+    }
+}
 
 // stage one 32-row x 32-column (float4 per thread) slab global -> registers
 #define WG_LD(dst, src) dst = *reinterpret_cast<const float4*>(src)
@@ -705,13 +750,12 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
 #undef WA_READ
 #undef WA_LOAD
 #undef WA_STORE
-    float* o = a.gW[0] + ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
+    const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[(size_t)(32 * i + acc_row(r, hi)) * a.F + 32 * j] = acc[i][j][r];
+            wg_emit16(a, a.gW[0], a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
     if (kf0 == 0) {
         // bias gradient: 8 threads (s_c4) hold partial sums of rows s_row + {0, 32, 64, 96}
 #pragma unroll
@@ -722,11 +766,11 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
             rs3 += __shfl_xor(rs3, off, 64);
         }
         if (s_c4 == 0) {
-            float* gb = a.gb[0] + (size_t)l * HID + s_row;
-            gb[0] = rs0;
-            gb[32] = rs1;
-            gb[64] = rs2;
-            gb[96] = rs3;
+            const size_t gb = (size_t)l * HID + s_row;
+            wg_emit1(a, a.gb[0], a.ob[0], gb, rs0);
+            wg_emit1(a, a.gb[0], a.ob[0], gb + 32, rs1);
+            wg_emit1(a, a.gb[0], a.ob[0], gb + 64, rs2);
+            wg_emit1(a, a.gb[0], a.ob[0], gb + 96, rs3);
         }
     }
 }
@@ -807,9 +851,7 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
 #undef WB_COMPUTE
 #undef WB_LOAD
 #undef WB_STORE
-    float* o = a.gW[i] + ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * HID] = acc[r];
+    wg_emit16(a, a.gW[i], a.oW[i], ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li, HID, hi, acc);
     if (k0 == 0) {
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -817,9 +859,9 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
             rs1 += __shfl_xor(rs1, off, 64);
         }
         if (s_c4 == 0) {
-            float* gb = a.gb[i] + (size_t)l * HID + n0 + s_row;
-            gb[0] = rs0;
-            gb[32] = rs1;
+            const size_t gb = (size_t)l * HID + n0 + s_row;
+            wg_emit1(a, a.gb[i], a.ob[i], gb, rs0);
+            wg_emit1(a, a.gb[i], a.ob[i], gb + 32, rs1);
         }
     }
 }
@@ -846,8 +888,8 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
     }
     __syncthreads();
     if (tid == 0 && part == 0) {
-        a.gb[nh][l] = (red[0] + red[1]) + (red[2] + red[3]);
-        if (a.gscales) a.gscales[l] = (red[4] + red[5]) + (red[6] + red[7]);
+        wg_emit1(a, a.gb[nh], a.ob[nh], l, (red[0] + red[1]) + (red[2] + red[3]));
+        if (a.dfsc) wg_emit1(a, a.gscales, a.oscales, l, (red[4] + red[5]) + (red[6] + red[7]));
     }
     // dW_last[n] = sum_b dbase[b] softplus(z[n][b]): each wave owns 32 rows and walks them 8 at a time so
     // that 8 independent 16-B loads are in flight per lane (a row-at-a-time loop is pure L2 latency)
@@ -873,7 +915,7 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float t = nsvd_wave_sum(s[j]);
-            if (lane == 0) a.gW[nh][(size_t)l * HID + n0 + j] = t;
+            if (lane == 0) wg_emit1(a, a.gW[nh], a.oW[nh], (size_t)l * HID + n0 + j, t);
         }
     }
 }
@@ -1006,7 +1048,11 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
 }
 
 static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, int B, const float* df,
-                               const NsvdEvdIn* evd, const nsvd_params& g, void* ws, hipStream_t s) {
+                               const NsvdEvdIn* evd, const nsvd_params* gp, const NsvdOptStep* opt, void* ws,
+                               hipStream_t s) {
+    nsvd_params g;
+    memset(&g, 0, sizeof(g));
+    if (gp) g = *gp;
     const FusedWs w = carve_fused(d, B, ws);
     const int F = 2 * d.m, nh = d.nlayers - 1;
 
@@ -1040,6 +1086,15 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
     wa.dfsc = d.has_exp_mask ? w.dfsc : nullptr;
     wa.gscales = d.has_exp_mask ? g.scales : nullptr;
     wa.nlayers = d.nlayers; wa.B = B; wa.L = d.L; wa.F = F;
+    if (opt) {
+        wa.opt = 1;
+        wa.h = opt->h;
+        for (int i = 0; i < d.nlayers; ++i) {
+            wa.oW[i] = NsvdOptPtrs{p.W[i], opt->sq.W[i], opt->ema ? opt->ema->W[i] : nullptr};
+            wa.ob[i] = NsvdOptPtrs{p.b[i], opt->sq.b[i], opt->ema ? opt->ema->b[i] : nullptr};
+        }
+        if (d.has_exp_mask) wa.oscales = NsvdOptPtrs{p.scales, opt->sq.scales, opt->ema ? opt->ema->scales : nullptr};
+    }
     wa.nA = (F / HID) * d.L;
     wa.nB = 4 * (nh - 1) * d.L;
     // One launch: the 256 dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
@@ -1054,10 +1109,11 @@ int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const ns
                         int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s) {
     (void)prob;
     (void)x;
-    return fused_backward_impl(d, p, B, df, nullptr, g, ws, s);
+    return fused_backward_impl(d, p, B, df, nullptr, &g, nullptr, ws, s);
 }
 
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
-                            const nsvd_params& g, void* ws, hipStream_t s) {
-    return fused_backward_impl(d, p, B, nullptr, &evd, g, ws, s);
+                            const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s) {
+    if (!g && !opt) return NSVD_EINVAL;
+    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s);
 }

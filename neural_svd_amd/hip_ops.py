@@ -280,6 +280,40 @@ def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: t
     check(rc, "nsvd_operator_backward_evd")
 
 
+def rmsprop_state(sq: Params, ema: Optional[Params], lr: float, alpha: float, eps: float,
+                  ema_decay: float = 0.0) -> _lib.Rmsprop:
+    """nsvd_rmsprop for operator_backward_evd_step; sq / ema are pack_params() sets in the parameters' layouts."""
+    o = _lib.Rmsprop()
+    o.sq = sq
+    if ema is not None:
+        o.ema = ema
+    o.lr, o.alpha, o.eps, o.ema_decay = float(lr), float(alpha), float(eps), float(ema_decay)
+    o.has_ema = int(ema is not None)
+    o._keepalive = (sq, ema)
+    return o
+
+
+def operator_backward_evd_step(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, f: torch.Tensor,
+                               Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                               M: Optional[torch.Tensor], moments: torch.Tensor, moments_reduced: bool,
+                               evd_scratch: Optional[torch.Tensor], loss: torch.Tensor, grads: Optional[Params],
+                               opt: "_lib.Rmsprop", ws: torch.Tensor, grad_scale: float = 1.0,
+                               path: int = PATH_AUTO, l_offset: int = 0) -> None:
+    """operator_backward_evd + RMSprop/EMA step inside the weight-gradient kernel; params are updated in place."""
+    B = x.shape[0]
+    L_total = f.shape[1]
+    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or moments.numel() != 2 * L_total * L_total + 1:
+        raise NsvdError("operator_backward_evd_step: f/Tf must be (B, L_total), moments 2*L_total^2+1")
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_backward_evd_step(
+        C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
+        _ptr(v, "v"), _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
+        evd_scratch.data_ptr() if evd_scratch is not None else None, int(L_total), int(l_offset),
+        float(grad_scale), _ptr(loss, "loss"), C.byref(grads) if grads is not None else None, C.byref(opt),
+        ws.data_ptr(), ws.numel(), int(path), _stream())
+    check(rc, "nsvd_operator_backward_evd_step")
+
+
 def cdk_workspace(B: int, L: int, set_first_mode_const: bool, device) -> torch.Tensor:
     n = _lib.load().nsvd_cdk_workspace_bytes(int(B), int(L), int(bool(set_first_mode_const)))
     return torch.empty(max(n, 256), dtype=torch.uint8, device=device)

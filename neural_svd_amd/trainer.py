@@ -105,10 +105,14 @@ class FusedTrainer:
                  num_iters: int = 500000, use_lr_scheduler: bool = True, sampling_scale: float = 16.0,
                  fourier_scale: float = 0.1, exp_mask_init: Optional[float] = None, seed: Optional[int] = 0,
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
-                 pipeline: bool = False, parallelism: str = "dp"):
+                 pipeline: bool = False, parallelism: str = "dp", fused_step: bool = True,
+                 keep_grads: bool = False):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
-        them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py)."""
+        them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
+        fused_step: take the RMSprop + EMA step inside the weight-gradient kernel (nsvd_operator_backward_evd_step)
+        whenever no gradient exchange sits between backward and optimiser (single GPU, hp); keep_grads then
+        also stores the gradients (P.grad), which the fused step otherwise never writes."""
         self.device = torch.device(device)
         self.path = path
         self.comm = comm  # parallel.Communicator or None
@@ -140,6 +144,10 @@ class FusedTrainer:
         self._params = self.P.pack(self.P.flat, True)
         self._grads = self.P.pack(self.P.grad, False)
         self._ema_params = self.P.pack(self.P.ema, True)
+        self._sq_params = self.P.pack(self.P.sq, False)
+        self.fused_step = bool(fused_step) and (world == 1 or self.hp)
+        # the generic (non-MFMA) path takes the step with per-tensor optimiser launches and needs the gradients
+        self.keep_grads = bool(keep_grads) or H.path_name(shape, self.B, path) != "fused_mfma"
         # nesting masks (methods/nestedlora.py:183-192)
         from .nested_lowrank import nesting_masks
         self.vector_mask, self.matrix_mask, self.mask_kind = nesting_masks(self.Lg, sequential, step)
@@ -182,7 +190,8 @@ class FusedTrainer:
         self.x.normal_(0.0, self.sigma, generator=self.gen)  # one kernel (randn + scale)
         return self.x
 
-    def forward_backward(self, x: torch.Tensor, features_ready: bool = False) -> None:
+    def forward_backward(self, x: torch.Tensor, features_ready: bool = False, take_step: bool = True) -> None:
+        """forward + loss + backward (+ the optimiser step when fused_step; take_step=False: gradients only)."""
         H.operator_forward(self.shape, self._params, self.problem, x, self.ws, True, self.path, out=(self.f, self.Tf),
                            features_ready=features_ready)
         cust = self.mask_kind == H.MASK_CUSTOM
@@ -201,20 +210,35 @@ class FusedTrainer:
         else:
             H.evd_partial(self.f, self.Tf, self.mask_kind, v, self.scratch)
         # loss + d loss / d f are evaluated inside the backward kernels from the moments
+        if self.fused_step and take_step:
+            lr, decay = self._advance_schedule()
+            opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay)
+            H.operator_backward_evd_step(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
+                                         self.mask_kind, v, M, self.moments, reduced, self.scratch, self.loss,
+                                         self._grads if self.keep_grads else None, opt, self.ws, 1.0, self.path,
+                                         l_offset=self.l_off)
+            return
         H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g, self.mask_kind, v, M,
                                 self.moments, reduced, self.scratch, self.loss, self._grads, self.ws, 1.0, self.path,
                                 l_offset=self.l_off)
 
+    def _advance_schedule(self):
+        """(lr, ema decay) of the step being taken; advances the scheduler / torch_ema counters."""
+        lr = cosine_lr(self.lr, self.t, self.num_iters) if self.use_sched else self.lr
+        self.num_updates += 1
+        decay = min(self.ema_decay, (1 + self.num_updates) / (10 + self.num_updates))
+        self.t += 1
+        return lr, decay
+
     def optimizer_step(self) -> None:
+        if self.fused_step:
+            return  # already taken inside forward_backward
         gscale = 1.0
         if self.comm is not None and self.comm.world > 1 and not self.hp:
             self.comm.all_reduce_sum(self.P.grad)
             gscale = 1.0 / self.comm.world
-        lr = cosine_lr(self.lr, self.t, self.num_iters) if self.use_sched else self.lr
-        self.num_updates += 1
-        decay = min(self.ema_decay, (1 + self.num_updates) / (10 + self.num_updates))
+        lr, decay = self._advance_schedule()
         H.rmsprop_ema_step(self.P.flat, self.P.grad, self.P.sq, self.P.ema, lr, self.alpha, self.eps, decay, gscale)
-        self.t += 1
 
     def _prefetch(self) -> None:
         """Side stream: draw the next batch and write its Fourier features into the workspace."""

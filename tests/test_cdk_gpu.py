@@ -97,13 +97,13 @@ def test_cdk_module_autograd_and_half_inputs():
     loss, lop, lmet, rj, ri = method.compute_loss(f, g)
     (loss * 128.0).backward()
     want = O.cdk_loss(f0.double(), g0.double(), method.vector_mask.double(), method.matrix_mask.double(), True, None)
-    assert abs(float(loss) - float(want[0])) <= TOL * max(1.0, abs(float(want[0])))
-    assert abs(float(lop) - float(want[1])) <= TOL and abs(float(lmet) - float(want[2])) <= TOL
+    assert abs(float(loss.detach()) - float(want[0])) <= TOL * max(1.0, abs(float(want[0])))
+    assert abs(float(lop.detach()) - float(want[1])) <= TOL and abs(float(lmet.detach()) - float(want[2])) <= TOL
     assert rel(f.grad, 128.0 * want[5]) <= TOL and rel(g.grad, 128.0 * want[6]) <= TOL
     assert rj.shape == (B,) and ri.shape == (B * (B - 1),) and not rj.requires_grad
     # bit-reproducible (fixed-order reductions, no float atomics)
     loss2, *_ = method.compute_loss(f.detach(), g.detach())
-    assert float(loss2) == float(loss)
+    assert float(loss2) == float(loss.detach())
     # half inputs
     fh = f0.to(DEV).half().requires_grad_(True)
     gh = g0.to(DEV).half().requires_grad_(True)
@@ -111,7 +111,7 @@ def test_cdk_module_autograd_and_half_inputs():
     lh.backward()
     wh = O.cdk_loss(fh.detach().double().cpu(), gh.detach().double().cpu(), method.vector_mask.double(),
                     method.matrix_mask.double(), True, None)
-    assert fh.grad.dtype == torch.float16 and abs(float(lh) - float(wh[0])) <= TOL * max(1.0, abs(float(wh[0])))
+    assert fh.grad.dtype == torch.float16 and abs(float(lh.detach()) - float(wh[0])) <= TOL * max(1.0, abs(float(wh[0])))
     assert rel(fh.grad.float(), wh[5]) <= 2e-3  # fp16 rounding of the returned gradient
     # only one tower needs a gradient
     f1 = f0.to(DEV).requires_grad_(True)
