@@ -180,13 +180,21 @@ class NestedLoRA(nn.Module):
     def compute_loss_kernel(self, get_approx_kernel_op, x, importance, split_batch: bool, evd: bool = True):
         """reference methods/nestedlora.py:230-252 (no caller in the reference; kept for the interface).
         ``get_approx_kernel_op(x)(self, x, importance)`` returns (Kf, f) built from ``self(x)`` (which is
-        differentiable here); the loss itself runs on the HIP EVD kernels. split_batch=True needs
-        independent f1 / f2 moments, which the HIP loss kernels do not take."""
+        differentiable here); the loss itself runs on the HIP EVD kernels.
+        split_batch=True (operator term on the first half only, f2 = model(x2) an independent batch) is the same
+        kernel call on f = [f1; f2], Tf = [(B/B1) Kf1; 0]: the operator term and its gradient then carry the
+        reference's 1/B1, the metric term is unchanged."""
         if not evd:
             raise NotImplementedError
         if split_batch:
-            raise NotImplementedError("compute_loss_kernel(split_batch=True): independent f1/f2 batches are not "
-                                      "on the HIP path")
+            x1, x2 = torch.chunk(x, 2)
+            Kf1, f1 = get_approx_kernel_op(x2)(self, x1, importance=importance)
+            f2 = self.model(x2)
+            B1, B2 = f1.shape[0], f2.shape[0]
+            f = torch.cat([f1, f2]).contiguous()
+            Tf = torch.cat([Kf1.detach() * (float(B1 + B2) / B1), torch.zeros_like(f2)]).contiguous()
+            loss = self._compute_loss(f, Tf, *torch.chunk(f, 2), evd=True)
+            return loss, dict(f=f1, Tf=Kf1, eigvals=None)
         Kf, f = get_approx_kernel_op(x)(self, x, importance=importance)
         f = f.contiguous()
         f1, f2 = torch.chunk(f, 2)

@@ -213,7 +213,7 @@ def test_fused_trainer_learns_oscillator():
 
 def test_model_autograd_and_compute_loss_kernel():
     """method(x) is differentiable (nsvd_model_forward/_backward), and compute_loss_kernel
-    (methods/nestedlora.py:230-252, split_batch=False) runs a user kernel operator built on it."""
+    (methods/nestedlora.py:230-252, both split_batch modes) runs a user kernel operator built on it."""
     z = G.load("model_small")
     case = "osc_small"
     cfg, args, operator, gt, method, loaders = build(case, z)
@@ -254,8 +254,32 @@ def test_model_autograd_and_compute_loss_kernel():
     l64, lam1, lam2, _, _ = O.evd_loss_forward(c.f, Kf64, v, M)
     df = O.evd_loss_backward(c.f, Kf64, v, M, lam1, lam2)
     gref = O.operator_backward(c, p64, prob_plain, df)
-    assert abs(float(loss) - float(l64)) < 1e-4 * abs(float(l64))
+    assert abs(float(loss.detach()) - float(l64)) < 1e-4 * abs(float(l64))
     for n, g in zip(names, gref):
         assert rel(got[n].grad, g) < 1e-4, n
-    with pytest.raises(NotImplementedError):
-        method.compute_loss_kernel(get_approx_kernel_op, x, None, split_batch=True)
+
+    # --- split_batch=True: operator term on x1 with the kernel anchored at x2, f2 = model(x2) independent
+    method.zero_grad()
+
+    def get_cross_kernel_op(xk):
+        def op(model, xx, importance=None):
+            K = torch.exp(-0.02 * torch.cdist(xx, xk) ** 2)
+            return K @ model(xk) / xk.shape[0], model(xx)
+        return op
+
+    loss, aux = method.compute_loss_kernel(get_cross_kernel_op, x, None, split_batch=True)
+    loss.backward()
+    B1 = (B + 1) // 2
+    c1 = O.operator_forward(xc[:B1], p64, prob_plain)
+    c2 = O.operator_forward(xc[B1:], p64, prob_plain)
+    Kf1 = torch.exp(-0.02 * torch.cdist(xc[:B1], xc[B1:]) ** 2) @ c2.f / (B - B1)
+    lam1, lam2 = c1.f.T @ c1.f / B1, c2.f.T @ c2.f / (B - B1)
+    l64 = -2.0 * ((c1.f * Kf1) @ v).mean() + (M * lam1 * lam2).sum()
+    df1 = -(4.0 / B1) * Kf1 * v + (2.0 / B1) * c1.f @ (M * lam2)
+    df2 = (2.0 / (B - B1)) * c2.f @ (M * lam1)
+    gref = [a + b for a, b in zip(O.operator_backward(c1, p64, prob_plain, df1),
+                                  O.operator_backward(c2, p64, prob_plain, df2))]
+    assert abs(float(loss.detach()) - float(l64)) < 1e-4 * abs(float(l64))
+    assert aux["f"].shape[0] == B1 and rel(aux["Tf"], Kf1) < 1e-4
+    for n, g in zip(names, gref):
+        assert rel(got[n].grad, g) < 1e-4, n
