@@ -544,6 +544,13 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 //                        in column 0 also write db_i. (128 x 64 half tiles were measured slower: fewer,
 //                        longer workgroups next to the dW_0 tiles.)
 //   C  (4 L):              dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales.
+// Timeline at cfg2 (NSVD_WG_STAMPS build, scripts/dev_wgrad_stamps.py): A tiles run their K loop in 72-77 K
+// cycles (65.5 K of MFMA issue) and end at 35 us; the B tiles, co-resident with them from t = 0 and latency-
+// bound (single accumulator chain, softplus while staging), end at 49 us; the C tiles at 36 us. With the
+// fused optimiser step the A epilogue moves 112 MB through HBM at once (20 us at 5.6 TB/s, all tiles finish
+// together) and the B tail hides under it: 60 us, vs 50 + 20.5 us for separate backward and optimiser
+// launches. Raising the B / C wave priority (s_setprio 3) shortens them but stretches the A loops by the same
+// amount: no gain.
 // K is streamed in 32-sample chunks through padded LDS tiles (rows of 36 floats, conflict-free
 // ds_read_b128 fragments), register-staged and double buffered, one barrier per chunk.
 struct WgradArgs {
@@ -565,6 +572,14 @@ struct WgradArgs {
     NsvdHyper h;
     NsvdOptPtrs oW[NSVD_MAX_LAYERS], ob[NSVD_MAX_LAYERS], oscales;
 };
+
+#ifdef NSVD_WG_STAMPS
+// diagnostic build: per-block (kind, realtime start/end, cycles in prologue / loop / epilogue)
+__device__ unsigned long long g_wg_stamps[1024 * 8];
+#define WG_STAMP(slot, v) if (threadIdx.x == 0) g_wg_stamps[(size_t)blockIdx.x * 8 + (slot)] = (v)
+#else
+#define WG_STAMP(slot, v)
+#endif
 
 // one gradient element: store it and / or take the optimiser step on its parameter
 __device__ __forceinline__ void wg_emit1(const WgradArgs& a, float* g, const NsvdOptPtrs& o, size_t off, float val) {
@@ -723,10 +738,14 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
         WA_FENCE();                                                                             \
     }
     const int nch = a.B / BK;
+    WG_STAMP(0, 1ull);
+    WG_STAMP(1, wall_clock64());
+    WG_STAMP(2, __builtin_readcyclecounter());
     WA_LOAD(0);
     WA_STORE(0);
     __syncthreads();
     if (nch > 1) WA_LOAD(1);
+    WG_STAMP(3, __builtin_readcyclecounter());
     F4 f0, f1;
     {
         const float* Ap = As + (64 * wm + li) * A_LD + 4 * hi;
@@ -750,6 +769,7 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
 #undef WA_READ
 #undef WA_LOAD
 #undef WA_STORE
+    WG_STAMP(4, __builtin_readcyclecounter());
     const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -773,6 +793,8 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
             wg_emit1(a, a.gb[0], a.ob[0], gb + 96, rs3);
         }
     }
+    WG_STAMP(5, __builtin_readcyclecounter());
+    WG_STAMP(6, wall_clock64());
 }
 
 __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, float* Bs, int unit) {
@@ -930,9 +952,15 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
         if ((a.nA & 7) == 0) unit = (bid & 7) * (a.nA >> 3) + (bid >> 3);
         wgrad_tile_A(a, As, Bs, unit);
     } else if (bid < a.nA + a.nB) {
+        WG_STAMP(0, 2ull);
+        WG_STAMP(1, wall_clock64());
         wgrad_tile_B(a, As, Bs, bid - a.nA);
+        WG_STAMP(6, wall_clock64());
     } else {
+        WG_STAMP(0, 3ull);
+        WG_STAMP(1, wall_clock64());
         wgrad_tile_C(a, As, bid - a.nA - a.nB);
+        WG_STAMP(6, wall_clock64());
     }
 }
 #undef WG_LD
@@ -1104,6 +1132,12 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
     NSVD_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef NSVD_WG_STAMPS
+extern "C" int nsvd_debug_wgrad_stamps(unsigned long long* host, size_t n) {
+    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                         int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s) {
