@@ -100,8 +100,8 @@ def cpu_baseline(cfg, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
@@ -187,17 +187,18 @@ def main():
         if kname.startswith("gemm_generic"):  # generic path: the bracketed launch is the layer-0 GEMM only
             flops_fwd = 2.0 * (1 + 2 * cfg["D"]) * cfg["B"] * cfg["L"] * (2 * cfg["m"]) * cfg["hidden"][0]
         ach = flops_fwd / (kavg * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_src = None, "profiles/"
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same workload only
             tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
             if tj.get("workload") == "cfg2" and cfg["B"] == CFG["B"] and kname.startswith("pmlp_fused_fwd"):
                 traffic = int(tj["kernels"]["pmlp_fused_fwd"]["hbm_bytes_corrected"])
+                traffic_src = tj.get("source", "profiles/")
         except Exception:  # noqa: BLE001
             traffic = None
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                    traffic_note="HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from "
-                                 "profiles/r01_pmc_traffic_cfg2.txt; algorithmic bytes 52.5 MB",
+                    traffic_note=f"HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from "
+                                 f"{traffic_src}; algorithmic bytes 52.5 MB",
                     kernel=kname, kernel_avg_us=round(kavg * 1e3, 2),
                     kernel_flops=flops_fwd,
                     step_flops=flops_step, step_tflops=round(flops_step / (ms_per_step * 1e-3) / 1e12, 3),
@@ -214,7 +215,9 @@ def main():
                    "sharding": ("heads: each GPU owns L/N heads and evaluates them on the whole global batch; one "
                                 "all-gather of f,Tf per step, no gradient traffic" if (par == "hp" and world > 1) else
                                 "samples: each GPU draws its own 512 rows; all-reduce of 2L^2+1 moments and of the "
-                                "flat gradient per step"),
+                                "flat gradient per step" if world > 1 else "single GPU: no exchange"),
+                   "optimiser": ("RMSprop+EMA step fused into the weight-gradient kernel" if tr.fused_step else
+                                 "separate RMSprop+EMA kernel after the gradient all-reduce"),
                    "path": H.path_name(tr.shape, tr.B, path), "params": tr.P.n_trainable * (world if tr.hp else 1)},
         "final_loss": loss, "params_finite": finite,
         "roofline": roof,

@@ -60,8 +60,11 @@ __global__ void __launch_bounds__(256) fourier_kernel(const float* __restrict__ 
 // 1 + 2D sincos per (b, j).
 constexpr int FJ = 64, FB = 32;
 
+// 1024 threads per block (16 waves, 4 per SIMD): each thread walks only 2 of the tile's 32 samples, so the
+// ~1 us dependent chain of a double-accurate sincos is overlapped 4-fold instead of repeated 8 times.
+constexpr int FT = 1024;
 template <int D>
-__global__ void __launch_bounds__(256) fourier_stencil_kernel(const float* __restrict__ x,
+__global__ void __launch_bounds__(FT) fourier_stencil_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ fB,
                                                               float* __restrict__ phi, float* __restrict__ phiTc,
                                                               int B, int m, float eps) {
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(256) fourier_stencil_kernel(const float* __res
         bj[d] = jok ? fB[(size_t)d * m + j] : 0.f;
         sincos_d2f((double)eps * (double)bj[d], &sd[d], &cd[d]);
     }
-    for (int bl = tid / FJ; bl < FB; bl += 256 / FJ) {
+    for (int bl = tid / FJ; bl < FB; bl += FT / FJ) {
         const int b = b0 + bl;
         if (b >= B) break;
         double p = 0.0;
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(256) fourier_stencil_kernel(const float* __res
     __syncthreads();
     // phiT_c[k][b0 + bl]: 32 consecutive samples per frequency = one 128-B store
     const int bl = tid & (FB - 1);
-    for (int jj = tid / FB; jj < FJ; jj += 256 / FB) {
+    for (int jj = tid / FB; jj < FJ; jj += FT / FB) {
         const int jg = blockIdx.x * FJ + jj;
         if (jg < m && b0 + bl < B) {
             phiTc[(size_t)jg * B + b0 + bl] = ts[jj][bl];
@@ -136,9 +139,9 @@ int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, flo
                          float eps, hipStream_t s) {
     dim3 grid(nsvd_cdiv(m, FJ), nsvd_cdiv(B, FB));
     switch (D) {
-        case 1: hipLaunchKernelGGL(fourier_stencil_kernel<1>, grid, dim3(256), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
-        case 2: hipLaunchKernelGGL(fourier_stencil_kernel<2>, grid, dim3(256), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
-        case 3: hipLaunchKernelGGL(fourier_stencil_kernel<3>, grid, dim3(256), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
+        case 1: hipLaunchKernelGGL(fourier_stencil_kernel<1>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
+        case 2: hipLaunchKernelGGL(fourier_stencil_kernel<2>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
+        case 3: hipLaunchKernelGGL(fourier_stencil_kernel<3>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
         default: return NSVD_EUNSUPPORTED;
     }
     NSVD_CHECK_LAUNCH();
