@@ -571,7 +571,25 @@ struct WgradArgs {
     int opt;
     NsvdHyper h;
     NsvdOptPtrs oW[NSVD_MAX_LAYERS], ob[NSVD_MAX_LAYERS], oscales;
+    // split-K over the batch (S > 1; head-parallel ranks own few heads on many rows, so the tile count alone
+    // would not fill the chip): tile (unit, slice) contracts rows [slice * Bs, (slice + 1) * Bs) and stores a
+    // partial gradient into slice `slice` of `part`; wgrad_reduce_kernel adds the slices in order and stores the
+    // gradient / takes the optimiser step.
+    int S, Bs;
+    float* part;
+    size_t part_stride;                                        // floats per slice
+    size_t poW[NSVD_MAX_LAYERS], pob[NSVD_MAX_LAYERS], poscales;  // tensor offsets inside a slice
 };
+
+// where a gradient element goes: the caller's gradient tensor (+ fused optimiser) or this slice's partial buffer
+struct WgDst {
+    float* g;
+    int opt;
+};
+__device__ __forceinline__ WgDst wg_dst(const WgradArgs& a, float* g, size_t part_off, int slice) {
+    if (a.S > 1) return WgDst{a.part + (size_t)slice * a.part_stride + part_off, 0};
+    return WgDst{g, a.opt};
+}
 
 #ifdef NSVD_WG_STAMPS
 // diagnostic build: per-block (kind, realtime start/end, cycles in prologue / loop / epilogue)
@@ -582,9 +600,11 @@ __device__ unsigned long long g_wg_stamps[1024 * 8];
 #endif
 
 // one gradient element: store it and / or take the optimiser step on its parameter
-__device__ __forceinline__ void wg_emit1(const WgradArgs& a, float* g, const NsvdOptPtrs& o, size_t off, float val) {
+__device__ __forceinline__ void wg_emit1(const WgradArgs& a, const WgDst& d, const NsvdOptPtrs& o, size_t off,
+                                         float val) {
+    float* g = d.g;
     if (g) g[off] = val;
-    if (a.opt) {
+    if (d.opt) {
         float pv = o.p[off], sv = o.sq[off], ev = o.ema ? o.ema[off] : 0.f;
         nsvd_rmsprop_upd(pv, val, sv, o.ema ? &ev : nullptr, a.h);
         o.p[off] = pv;
@@ -594,13 +614,14 @@ __device__ __forceinline__ void wg_emit1(const WgradArgs& a, float* g, const Nsv
 }
 
 // the 16 accumulator registers of one 32 x 32 MFMA tile: rows acc_row(r, hi) * ld, this lane's column at `base`
-__device__ __forceinline__ void wg_emit16(const WgradArgs& a, float* g, const NsvdOptPtrs& o, size_t base, size_t ld,
-                                          int hi, const f32x16& acc) {
+__device__ __forceinline__ void wg_emit16(const WgradArgs& a, const WgDst& d, const NsvdOptPtrs& o, size_t base,
+                                          size_t ld, int hi, const f32x16& acc) {
+    float* g = d.g;
     if (g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[base + (size_t)acc_row(r, hi) * ld] = acc[r];
     }
-    if (!a.opt) return;
+    if (!d.opt) return;
     float pv[16], sv[16], ev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // 48 independent loads in flight
@@ -627,7 +648,7 @@ __device__ __forceinline__ float4 softplus4(float4 v) {
     return make_float4(nsvd_softplus(v.x), nsvd_softplus(v.y), nsvd_softplus(v.z), nsvd_softplus(v.w));
 }
 
-__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, float* Bs, int unit) {
+__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, float* Bs, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -645,8 +666,8 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int s_row = tid >> 3, s_c4 = tid & 7;
-    const float* a_src = a.dz[0] + ((size_t)l * HID + s_row) * a.B + 4 * s_c4;
-    const float* b_src = a.phiTc + (size_t)(kf0 + s_row) * a.B + 4 * s_c4;
+    const float* a_src = a.dz[0] + ((size_t)l * HID + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
+    const float* b_src = a.phiTc + (size_t)(kf0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
     const size_t step = (size_t)32 * a.B;
     // Same software pipeline as the forward's layer 0: fragments one q-group ahead, chunk c+1 written to
     // the other LDS buffer under chunk c's third q-group, chunk c+2 fetched from global under its fourth
@@ -737,7 +758,7 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
         if (DO_LOAD) WA_IL(8, 0x020);                                                           \
         WA_FENCE();                                                                             \
     }
-    const int nch = a.B / BK;
+    const int nch = a.Bs / BK;
     WG_STAMP(0, 1ull);
     WG_STAMP(1, wall_clock64());
     WG_STAMP(2, __builtin_readcyclecounter());
@@ -771,11 +792,12 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
 #undef WA_STORE
     WG_STAMP(4, __builtin_readcyclecounter());
     const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
+    const WgDst dW = wg_dst(a, a.gW[0], a.poW[0], slice), db = wg_dst(a, a.gb[0], a.pob[0], slice);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            wg_emit16(a, a.gW[0], a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
+            wg_emit16(a, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
     if (kf0 == 0) {
         // bias gradient: 8 threads (s_c4) hold partial sums of rows s_row + {0, 32, 64, 96}
 #pragma unroll
@@ -787,17 +809,17 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
         }
         if (s_c4 == 0) {
             const size_t gb = (size_t)l * HID + s_row;
-            wg_emit1(a, a.gb[0], a.ob[0], gb, rs0);
-            wg_emit1(a, a.gb[0], a.ob[0], gb + 32, rs1);
-            wg_emit1(a, a.gb[0], a.ob[0], gb + 64, rs2);
-            wg_emit1(a, a.gb[0], a.ob[0], gb + 96, rs3);
+            wg_emit1(a, db, a.ob[0], gb, rs0);
+            wg_emit1(a, db, a.ob[0], gb + 32, rs1);
+            wg_emit1(a, db, a.ob[0], gb + 64, rs2);
+            wg_emit1(a, db, a.ob[0], gb + 96, rs3);
         }
     }
     WG_STAMP(5, __builtin_readcyclecounter());
     WG_STAMP(6, wall_clock64());
 }
 
-__device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, float* Bs, int unit) {
+__device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, float* Bs, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -815,8 +837,8 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4; two slabs per operand (64 rows)
-    const float* a_src = a.dz[i] + ((size_t)l * HID + n0 + s_row) * a.B + 4 * s_c4;
-    const float* b_src = a.zsave[i - 1] + ((size_t)l * HID + k0 + s_row) * a.B + 4 * s_c4;
+    const float* a_src = a.dz[i] + ((size_t)l * HID + n0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
+    const float* b_src = a.zsave[i - 1] + ((size_t)l * HID + k0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
     const size_t step = (size_t)32 * a.B;
     float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
     float rs0 = 0.f, rs1 = 0.f;
@@ -852,7 +874,7 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);              \
         }                                                                                      \
     }
-    const int nch = a.B / BK;
+    const int nch = a.Bs / BK;
     pa0 = pa1 = pb0 = pb1 = qa0 = qa1 = qb0 = qb1 = make_float4(0.f, 0.f, 0.f, 0.f);
     WB_LOAD(p, 0);
     if (nch > 1) WB_LOAD(q, 1);
@@ -873,7 +895,8 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
 #undef WB_COMPUTE
 #undef WB_LOAD
 #undef WB_STORE
-    wg_emit16(a, a.gW[i], a.oW[i], ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li, HID, hi, acc);
+    wg_emit16(a, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
+              ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li, HID, hi, acc);
     if (k0 == 0) {
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -882,25 +905,27 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
         }
         if (s_c4 == 0) {
             const size_t gb = (size_t)l * HID + n0 + s_row;
-            wg_emit1(a, a.gb[i], a.ob[i], gb, rs0);
-            wg_emit1(a, a.gb[i], a.ob[i], gb + 32, rs1);
+            const WgDst db = wg_dst(a, a.gb[i], a.pob[i], slice);
+            wg_emit1(a, db, a.ob[i], gb, rs0);
+            wg_emit1(a, db, a.ob[i], gb + 32, rs1);
         }
     }
 }
 
-__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int unit) {
+__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int unit, int slice) {
     const int l = unit >> 2, part = unit & 3;  // 4 workgroups per head: 32 of the 128 rows each
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int nh = a.nlayers - 1;
     float* red = lds;            // [8]
-    float* dbl = lds + 16;       // [B] dbase of this head (B <= 2 * 128 * 36 - 16 floats, checked on the host)
+    float* dbl = lds + 16;       // [Bs] dbase of this head (Bs <= 2 * 128 * 36 - 16 floats, checked on the host)
+    const size_t row0 = (size_t)l * a.B + (size_t)slice * a.Bs;  // this slice's rows of the head's (B) vectors
     float sb = 0.f, ss = 0.f;
-    for (int b = tid; b < a.B; b += 256) {
-        const float v = a.dbase[(size_t)l * a.B + b];
+    for (int b = tid; b < a.Bs; b += 256) {
+        const float v = a.dbase[row0 + b];
         dbl[b] = v;
         sb += v;
-        if (a.dfsc) ss += a.dfsc[(size_t)l * a.B + b];
+        if (a.dfsc) ss += a.dfsc[row0 + b];
     }
     sb = nsvd_wave_sum(sb);
     ss = nsvd_wave_sum(ss);
@@ -910,8 +935,10 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
     }
     __syncthreads();
     if (tid == 0 && part == 0) {
-        wg_emit1(a, a.gb[nh], a.ob[nh], l, (red[0] + red[1]) + (red[2] + red[3]));
-        if (a.dfsc) wg_emit1(a, a.gscales, a.oscales, l, (red[4] + red[5]) + (red[6] + red[7]));
+        wg_emit1(a, wg_dst(a, a.gb[nh], a.pob[nh], slice), a.ob[nh], l, (red[0] + red[1]) + (red[2] + red[3]));
+        if (a.dfsc)
+            wg_emit1(a, wg_dst(a, a.gscales, a.poscales, slice), a.oscales, l,
+                     (red[4] + red[5]) + (red[6] + red[7]));
     }
     // dW_last[n] = sum_b dbase[b] softplus(z[n][b]): each wave owns 32 rows and walks them 8 at a time so
     // that 8 independent 16-B loads are in flight per lane (a row-at-a-time loop is pure L2 latency)
@@ -920,11 +947,12 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
         float s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = 0.f;
-        for (int b = 4 * lane; b < a.B; b += 256) {
+        const float* zrow = a.zsave[nh - 1] + (size_t)slice * a.Bs;
+        for (int b = 4 * lane; b < a.Bs; b += 256) {
             float4 z[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                z[j] = *reinterpret_cast<const float4*>(a.zsave[nh - 1] + ((size_t)l * HID + n0 + j) * a.B + b);
+                z[j] = *reinterpret_cast<const float4*>(zrow + ((size_t)l * HID + n0 + j) * a.B + b);
             const float4 d = *reinterpret_cast<const float4*>(dbl + b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -937,7 +965,8 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float t = nsvd_wave_sum(s[j]);
-            if (lane == 0) wg_emit1(a, a.gW[nh], a.oW[nh], (size_t)l * HID + n0 + j, t);
+            if (lane == 0)
+                wg_emit1(a, wg_dst(a, a.gW[nh], a.poW[nh], slice), a.oW[nh], (size_t)l * HID + n0 + j, t);
         }
     }
 }
@@ -945,22 +974,72 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
 __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2 * HID * A_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * HID * A_LD];
-    const int bid = blockIdx.x + a.bid0;
-    if (bid < a.nA) {
+    // grid = S x (nA | nB | 4 L) blocks, kind-major so that the long dW_0 tiles are dispatched first
+    int bid = blockIdx.x + a.bid0;
+    if (bid < a.nA * a.S) {
+        const int slice = bid / a.nA;
+        bid -= slice * a.nA;
         // heads share an XCD (dz_0[l] stays in that L2) when the tile count allows the remap
         int unit = bid;
         if ((a.nA & 7) == 0) unit = (bid & 7) * (a.nA >> 3) + (bid >> 3);
-        wgrad_tile_A(a, As, Bs, unit);
-    } else if (bid < a.nA + a.nB) {
+        wgrad_tile_A(a, As, Bs, unit, slice);
+        return;
+    }
+    bid -= a.nA * a.S;
+    if (bid < a.nB * a.S) {
         WG_STAMP(0, 2ull);
         WG_STAMP(1, wall_clock64());
-        wgrad_tile_B(a, As, Bs, bid - a.nA);
+        wgrad_tile_B(a, As, Bs, bid % a.nB, bid / a.nB);
         WG_STAMP(6, wall_clock64());
-    } else {
-        WG_STAMP(0, 3ull);
-        WG_STAMP(1, wall_clock64());
-        wgrad_tile_C(a, As, bid - a.nA - a.nB);
-        WG_STAMP(6, wall_clock64());
+        return;
+    }
+    bid -= a.nB * a.S;
+    WG_STAMP(0, 3ull);
+    WG_STAMP(1, wall_clock64());
+    wgrad_tile_C(a, As, bid % (4 * a.L), bid / (4 * a.L));
+    WG_STAMP(6, wall_clock64());
+}
+
+// Split-K second pass: gradient = sum of the S partial slices (in slice order), then stored and / or applied
+// (RMSprop + EMA) exactly as the S = 1 epilogue does. One launch over all tensors of the model.
+struct ReduceArgs {
+    const float* part;
+    size_t part_stride;
+    int S, ntensors, opt;
+    NsvdHyper h;
+    size_t off[2 * NSVD_MAX_LAYERS + 1], n[2 * NSVD_MAX_LAYERS + 1];  // slice offset / element count (multiples of 4)
+    float* g[2 * NSVD_MAX_LAYERS + 1];
+    NsvdOptPtrs o[2 * NSVD_MAX_LAYERS + 1];
+    size_t total4;  // float4 groups over all tensors
+};
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < a.total4; q += (size_t)gridDim.x * 256) {
+        // tensors are laid out back to back (padded to 4 floats) inside a slice: find the one holding group q
+        int t = 0;
+        size_t e = q * 4;
+        while (t + 1 < a.ntensors && e >= a.off[t + 1]) ++t;
+        e -= a.off[t];
+        if (e >= a.n[t]) continue;  // alignment padding between tensors
+        const float* src = a.part + a.off[t] + e;
+        float4 gsum = *reinterpret_cast<const float4*>(src);
+        for (int sl = 1; sl < a.S; ++sl) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * a.part_stride);
+            gsum.x += v.x; gsum.y += v.y; gsum.z += v.z; gsum.w += v.w;
+        }
+        const int cnt = a.n[t] - e < 4 ? (int)(a.n[t] - e) : 4;
+        const float gv[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+        for (int c = 0; c < cnt; ++c) {
+            if (a.g[t]) a.g[t][e + c] = gv[c];
+            if (a.opt) {
+                const NsvdOptPtrs& o = a.o[t];
+                float pv = o.p[e + c], sv = o.sq[e + c], ev = o.ema ? o.ema[e + c] : 0.f;
+                nsvd_rmsprop_upd(pv, gv[c], sv, o.ema ? &ev : nullptr, a.h);
+                o.p[e + c] = pv;
+                o.sq[e + c] = sv;
+                if (o.ema) o.ema[e + c] = ev;
+            }
+        }
     }
 }
 #undef WG_LD
@@ -975,8 +1054,42 @@ struct FusedWs {
     float* dz[NSVD_MAX_LAYERS];       // (L, 128, B) per hidden layer
     float* dbase;                     // (L, B)
     float* dfsc;                      // (L, B)
+    float* gpart;                     // (S, slice) split-K partial gradients, S = wgrad_slices() > 1 only
     size_t bytes;
 };
+
+// Batch slices of the weight-gradient contraction: doubled while the dW_0 tile count leaves CUs idle and a slice
+// keeps at least 256 rows (8 chunks) to amortise a tile's prologue and epilogue.
+int wgrad_slices(const nsvd_model_desc& d, int B) {
+    const int nA = (2 * d.m / HID) * d.L;
+    int S = 1;
+    while (S < 16 && nA * S < 256 && (B / (2 * S)) % BK == 0 && B / (2 * S) >= 256) S *= 2;
+    return S;
+}
+
+// per-slice layout of the partial gradients: [W_0 | .. | W_n | b_0 | .. | b_n | scales], each padded to 4 floats
+struct PartLayout {
+    size_t oW[NSVD_MAX_LAYERS], ob[NSVD_MAX_LAYERS], oscales, nW[NSVD_MAX_LAYERS], nb[NSVD_MAX_LAYERS], nscales;
+    size_t stride;
+};
+PartLayout part_layout(const nsvd_model_desc& d) {
+    PartLayout p;
+    memset(&p, 0, sizeof(p));
+    size_t off = 0;
+    auto put = [&](size_t n) { const size_t o = off; off += (n + 3) / 4 * 4; return o; };
+    for (int i = 0; i < d.nlayers; ++i) {
+        p.nW[i] = (size_t)d.L * d.dims[i] * (i == 0 ? 2 * (size_t)d.m : (size_t)d.dims[i - 1]);
+        p.oW[i] = put(p.nW[i]);
+    }
+    for (int i = 0; i < d.nlayers; ++i) {
+        p.nb[i] = (size_t)d.L * d.dims[i];
+        p.ob[i] = put(p.nb[i]);
+    }
+    p.nscales = d.has_exp_mask ? (size_t)d.L : 0;
+    p.oscales = put(p.nscales);
+    p.stride = (off + 63) / 64 * 64;
+    return p;
+}
 
 FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     FusedWs w;
@@ -997,6 +1110,8 @@ FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     for (int i = 0; i < d.nlayers - 1; ++i) w.dz[i] = take((size_t)d.L * HID * B);
     w.dbase = take((size_t)B * d.L);
     w.dfsc = take((size_t)B * d.L);
+    const int S = wgrad_slices(d, B);
+    w.gpart = S > 1 ? take((size_t)S * part_layout(d).stride) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -1008,7 +1123,8 @@ bool nsvd_fused_supported(const nsvd_model_desc& d, int B) {
     if (d.nlayers < 2) return false;
     for (int i = 0; i < d.nlayers - 1; ++i)
         if (d.dims[i] != HID) return false;
-    if (B % BS != 0 || B > 8192) return false;  // 8192: one head's dbase vector is staged in LDS (wgrad C)
+    if (B % BS != 0 || B > 65536) return false;
+    if (B / wgrad_slices(d, B) > 8192) return false;  // one head's slice of dbase is staged in LDS (wgrad C)
     if ((2 * d.m) % HID != 0) return false;  // layer-0 weight gradient uses 128-wide feature tiles
     return true;
 }
@@ -1125,10 +1241,47 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
     }
     wa.nA = (F / HID) * d.L;
     wa.nB = 4 * (nh - 1) * d.L;
-    // One launch: the 256 dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
+    wa.S = wgrad_slices(d, B);
+    wa.Bs = B / wa.S;
+    const PartLayout pl = part_layout(d);
+    if (wa.S > 1) {
+        wa.part = w.gpart;
+        wa.part_stride = pl.stride;
+        for (int i = 0; i < d.nlayers; ++i) {
+            wa.poW[i] = pl.oW[i];
+            wa.pob[i] = pl.ob[i];
+        }
+        wa.poscales = pl.oscales;
+    }
+    // One launch: the dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
     // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
     wa.bid0 = 0;
-    hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.nA + wa.nB + 4 * d.L), dim3(256), 0, s, wa);
+    hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.S * (wa.nA + wa.nB + 4 * d.L)), dim3(256), 0, s, wa);
+    NSVD_CHECK_LAUNCH();
+    if (wa.S == 1) return 0;
+    ReduceArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.part = w.gpart;
+    ra.part_stride = pl.stride;
+    ra.S = wa.S;
+    ra.opt = wa.opt;
+    ra.h = wa.h;
+    int t = 0;
+    for (int i = 0; i < d.nlayers; ++i, ++t) {
+        ra.off[t] = pl.oW[i]; ra.n[t] = pl.nW[i]; ra.g[t] = g.W[i]; ra.o[t] = wa.oW[i];
+    }
+    for (int i = 0; i < d.nlayers; ++i, ++t) {
+        ra.off[t] = pl.ob[i]; ra.n[t] = pl.nb[i]; ra.g[t] = g.b[i]; ra.o[t] = wa.ob[i];
+    }
+    if (d.has_exp_mask) {
+        ra.off[t] = pl.oscales; ra.n[t] = pl.nscales; ra.g[t] = g.scales; ra.o[t] = wa.oscales;
+        ++t;
+    }
+    ra.ntensors = t;
+    ra.total4 = (pl.oscales + (pl.nscales + 3) / 4 * 4) / 4;
+    size_t blocks = (ra.total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ra);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

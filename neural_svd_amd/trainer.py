@@ -172,6 +172,13 @@ class FusedTrainer:
         # dp: every rank its own stream of samples; hp: all ranks draw the SAME global batch
         srank = 0 if self.hp else rank
         self.gen.manual_seed((sample_seed if sample_seed is not None else (seed or 0)) * 1000003 + 7919 * srank + 1)
+        if self.hp:
+            # every rank must draw the SAME global batch: check once that equally seeded generators agree
+            probe = torch.empty(64, dtype=torch.float32, device=self.device).normal_(generator=self.gen)
+            allp = torch.empty((world, 64), dtype=torch.float32, device=self.device)
+            self.comm.all_gather(allp, probe)
+            if not bool((allp == allp[0:1]).all()):
+                raise RuntimeError("head-parallel sharding: ranks draw different samples from equal seeds")
         self.t = 0            # optimiser / scheduler steps taken
         self.num_updates = 0  # torch_ema counter
         # optional batch pipelining: the sample + Fourier features of step k+1 do not depend on the weights, so

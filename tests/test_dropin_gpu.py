@@ -163,11 +163,11 @@ def test_fused_trainer_step_matches_oracle(hidden, m, B):
 
 
 @pytest.mark.parametrize("hidden,m,B,mask", [((32, 32), 16, 24, False), ((128, 128, 128), 128, 64, True),
-                                              ((128, 128), 64, 96, False)])
+                                              ((128, 128), 64, 96, False), ((128, 128), 128, 1024, True)])
 def test_optimiser_step_fused_into_backward_is_bit_identical(hidden, m, B, mask):
     """nsvd_operator_backward_evd_step (RMSprop + EMA inside the weight-gradient kernel, gradients never stored)
     vs nsvd_operator_backward_evd + nsvd_rmsprop_ema_step: same parameters, square averages and EMA shadows bit
-    for bit after several steps, on the generic and on the fused-MFMA path."""
+    for bit after several steps, on the generic path, the fused-MFMA path and its split-K form (last case)."""
     from neural_svd_amd import hip_ops as H
     from neural_svd_amd.trainer import FusedTrainer
     shape = H.ModelShape(L=4, D=2, m=m, hidden=hidden, has_exp_mask=mask)
