@@ -67,7 +67,7 @@ template <int D>
 __global__ void __launch_bounds__(FT) fourier_stencil_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ fB,
                                                               float* __restrict__ phi, float* __restrict__ phiTc,
-                                                              int B, int m, float eps) {
+                                                              float* __restrict__ sctab, int B, int m, float eps) {
     __shared__ float ts[FJ][FB + 1];  // transposed staging of the centre rows
     __shared__ float tc[FJ][FB + 1];
     const int tid = threadIdx.x;
@@ -81,6 +81,10 @@ __global__ void __launch_bounds__(FT) fourier_stencil_kernel(const float* __rest
     for (int d = 0; d < D; ++d) {
         bj[d] = jok ? fB[(size_t)d * m + j] : 0.f;
         sincos_d2f((double)eps * (double)bj[d], &sd[d], &cd[d]);
+        if (jok && blockIdx.y == 0 && tid < FJ) {  // per-frequency stencil constants, written once
+            sctab[(size_t)(2 * d) * m + j] = cd[d];
+            sctab[(size_t)(2 * d + 1) * m + j] = sd[d];
+        }
     }
     for (int bl = tid / FJ; bl < FB; bl += FT / FJ) {
         const int b = b0 + bl;
@@ -94,15 +98,6 @@ __global__ void __launch_bounds__(FT) fourier_stencil_kernel(const float* __rest
             float* row = phi + (size_t)b * F;
             row[j] = s0;
             row[m + j] = c0;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                float* rp = phi + (size_t)((1 + 2 * d) * B + b) * F;  // x + eps e_d
-                float* rm = phi + (size_t)((2 + 2 * d) * B + b) * F;  // x - eps e_d
-                rp[j] = fmaf(s0, cd[d], c0 * sd[d]);
-                rp[m + j] = fmaf(c0, cd[d], -(s0 * sd[d]));
-                rm[j] = fmaf(s0, cd[d], -(c0 * sd[d]));
-                rm[m + j] = fmaf(c0, cd[d], s0 * sd[d]);
-            }
         }
         ts[jl][bl] = s0;
         tc[jl][bl] = c0;
@@ -135,13 +130,13 @@ extern "C" int nsvd_fourier_features(const float* x, const float* fourier_B, flo
     return 0;
 }
 
-int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, int B, int D, int m,
-                         float eps, hipStream_t s) {
+int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, float* sctab, int B, int D,
+                         int m, float eps, hipStream_t s) {
     dim3 grid(nsvd_cdiv(m, FJ), nsvd_cdiv(B, FB));
     switch (D) {
-        case 1: hipLaunchKernelGGL(fourier_stencil_kernel<1>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
-        case 2: hipLaunchKernelGGL(fourier_stencil_kernel<2>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
-        case 3: hipLaunchKernelGGL(fourier_stencil_kernel<3>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, B, m, eps); break;
+        case 1: hipLaunchKernelGGL(fourier_stencil_kernel<1>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps); break;
+        case 2: hipLaunchKernelGGL(fourier_stencil_kernel<2>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps); break;
+        case 3: hipLaunchKernelGGL(fourier_stencil_kernel<3>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps); break;
         default: return NSVD_EUNSUPPORTED;
     }
     NSVD_CHECK_LAUNCH();

@@ -6,10 +6,11 @@
 void nsvd_prof_begin(hipStream_t s);
 void nsvd_prof_end(hipStream_t s);
 
-// Fused-path features (fourier.hip): phi (E*B, 2m) sample-major for all stencil rows by angle addition from
-// one double-accurate sincos per (sample, frequency); phiTc (2m, B) feature-major centre copy, or null.
-int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, int B, int D, int m,
-                         float eps, hipStream_t s);
+// Fused-path features (fourier.hip): phi (B, 2m) sample-major features of the CENTRE rows from one double-accurate
+// sincos per (sample, frequency); phiTc (2m, B) feature-major copy, or null; sctab (D, 2, m) = cos / sin of
+// eps * fourier_B, from which the forward kernel builds the shifted stencil rows by angle addition.
+int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, float* sctab, int B, int D,
+                         int m, float eps, hipStream_t s);
 
 // ---- generic strided batched GEMM (gemm_generic.hip) -------------------------------------------
 //   C[g][i][j] = epi( sum_k A[g][i*sAm + k*sAk] * pro(B[g][k*sBk + j*sBn]) + bias[g][i] )

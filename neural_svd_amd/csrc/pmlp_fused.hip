@@ -35,7 +35,10 @@ constexpr int BK = 32;        // layer-0 K chunk
 constexpr int A_LD = BK + 4;  // padded row of the W_0 tile (floats)
 
 struct FwdArgs {
-    const float* phiT;
+    const float* phiT;   // (B, F) Fourier features of the CENTRE rows, sample-major: [sin(x.B) | cos(x.B)]
+    const float* sctab;  // (D, 2, m): cos(eps B_dj), sin(eps B_dj) - the stencil rows are built from the centre
+                         // features by angle addition while the layer-0 tiles are staged
+    int m;
     int ldr;
     const float* W[NSVD_MAX_LAYERS];
     const float* b[NSVD_MAX_LAYERS];
@@ -146,32 +149,52 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // Named registers, no arrays: hipcc leaves a conditionally written float4 array in scratch.
     const float* W0 = a.W[0] + (size_t)l * HID * a.F;
     const int nch = a.F / BK;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = rb4 = rb5 = rb6 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // K runs over PAIRS of chunks: 32 sin features k in [32 p, 32 p + 32) and their 32 cos partners m + k. The
+    // pair is loaded once (centre row only: 2 float4 per thread + the per-frequency constants) and the E stencil
+    // rows of both chunks are generated in registers by angle addition,
+    //   sin(t +- d) = sin t cos d +- cos t sin d,  cos(t +- d) = cos t cos d -+ sin t sin d,   d = eps B_dj,
+    // with the same float32 expressions the feature kernel used to evaluate: phi(x +- eps e_d) is never stored.
+    // (5x less feature traffic per tile; the feature kernel writes B x F instead of E x B x F.)
+    constexpr int DD = (E - 1) / 2;
+    float4 ra0, ra1, ra2, ra3, rs, rc, cd0, sd0, cd1, sd1, cd2, sd2;
+    ra0 = ra1 = ra2 = ra3 = rs = rc = cd0 = sd0 = cd1 = sd1 = cd2 = sd2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4 per slab
     const float* a_src = W0 + (size_t)s_row * a.F + 4 * s_c4;
-    const float* b_src = a.phiT + (size_t)(b0 + s_row) * a.F + 4 * s_c4;  // phi is (R, F) row-major here
+    const float* b_src = a.phiT + (size_t)(b0 + s_row) * a.F + 4 * s_c4;  // centre features, (B, F) row-major
+    const float* t_src = a.sctab + 4 * s_c4;
     const size_t a_step = (size_t)32 * a.F;
-    const size_t b_step = (size_t)a.B * a.F;  // next stencil point, same base samples
+    const int mm = a.m;
 #define NSVD_LDG(p) (*reinterpret_cast<const float4*>(p))
-#define NSVD_LOAD_CHUNK(c)                                                       \
+// chunk c = pair (c >> 1), half (c & 1): HALF = 0 the sin features, 1 their cos partners
+#define NSVD_LOAD_CHUNK(c, HALF)                                                 \
     {                                                                            \
-        const float* pa_ = a_src + (c) * BK;                                     \
-        const float* pb_ = b_src + (c) * BK;                                     \
+        const int kp_ = ((c) >> 1) * BK;                                         \
+        const float* pa_ = a_src + ((HALF) ? mm : 0) + kp_;                      \
         ra0 = NSVD_LDG(pa_);                                                     \
         ra1 = NSVD_LDG(pa_ + a_step);                                            \
         ra2 = NSVD_LDG(pa_ + 2 * a_step);                                        \
         ra3 = NSVD_LDG(pa_ + 3 * a_step);                                        \
-        rb0 = NSVD_LDG(pb_);                                                     \
-        if (E > 1) rb1 = NSVD_LDG(pb_ + b_step);                                 \
-        if (E > 2) rb2 = NSVD_LDG(pb_ + 2 * b_step);                             \
-        if (E > 3) rb3 = NSVD_LDG(pb_ + 3 * b_step);                             \
-        if (E > 4) rb4 = NSVD_LDG(pb_ + 4 * b_step);                             \
-        if (E > 5) rb5 = NSVD_LDG(pb_ + 5 * b_step);                             \
-        if (E > 6) rb6 = NSVD_LDG(pb_ + 6 * b_step);                             \
+        if (!(HALF)) {                                                           \
+            rs = NSVD_LDG(b_src + kp_);                                          \
+            rc = NSVD_LDG(b_src + mm + kp_);                                     \
+            if (DD > 0) cd0 = NSVD_LDG(t_src + kp_);                             \
+            if (DD > 0) sd0 = NSVD_LDG(t_src + mm + kp_);                        \
+            if (DD > 1) cd1 = NSVD_LDG(t_src + 2 * mm + kp_);                    \
+            if (DD > 1) sd1 = NSVD_LDG(t_src + 3 * mm + kp_);                    \
+            if (DD > 2) cd2 = NSVD_LDG(t_src + 4 * mm + kp_);                    \
+            if (DD > 2) sd2 = NSVD_LDG(t_src + 5 * mm + kp_);                    \
+        }                                                                        \
     }
 #define NSVD_STS(p, v) (*reinterpret_cast<float4*>(p) = (v))
-#define NSVD_STORE_CHUNK(buf)                                                    \
+// u cd + v sd and u cd - v sd, componentwise, as fmaf(u, cd, +-(v * sd)) (the feature kernel's expressions)
+#define NSVD_PM(plus, minus, u, v, cd, sd)                                                         \
+    {                                                                                              \
+        plus = make_float4(fmaf(u.x, cd.x, v.x * sd.x), fmaf(u.y, cd.y, v.y * sd.y),              \
+                           fmaf(u.z, cd.z, v.z * sd.z), fmaf(u.w, cd.w, v.w * sd.w));              \
+        minus = make_float4(fmaf(u.x, cd.x, -(v.x * sd.x)), fmaf(u.y, cd.y, -(v.y * sd.y)),        \
+                            fmaf(u.z, cd.z, -(v.z * sd.z)), fmaf(u.w, cd.w, -(v.w * sd.w)));       \
+    }
+#define NSVD_STORE_CHUNK(buf, HALF)                                              \
     {                                                                            \
         float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;          \
         float* Bb_ = Bs + (buf) * NC * A_LD + s_row * A_LD + 4 * s_c4;           \
@@ -179,13 +202,18 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         NSVD_STS(Ab_ + 32 * A_LD, ra1);                                          \
         NSVD_STS(Ab_ + 64 * A_LD, ra2);                                          \
         NSVD_STS(Ab_ + 96 * A_LD, ra3);                                          \
-        NSVD_STS(Bb_, rb0);                                                      \
-        if (E > 1) NSVD_STS(Bb_ + 32 * A_LD, rb1);                               \
-        if (E > 2) NSVD_STS(Bb_ + 64 * A_LD, rb2);                               \
-        if (E > 3) NSVD_STS(Bb_ + 96 * A_LD, rb3);                               \
-        if (E > 4) NSVD_STS(Bb_ + 128 * A_LD, rb4);                              \
-        if (E > 5) NSVD_STS(Bb_ + 160 * A_LD, rb5);                              \
-        if (E > 6) NSVD_STS(Bb_ + 192 * A_LD, rb6);                              \
+        float4 gp_, gm_;                                                         \
+        if (!(HALF)) {  /* sin rows: x + eps e_d -> s cd + c sd, x - eps e_d -> s cd - c sd */ \
+            NSVD_STS(Bb_, rs);                                                   \
+            if (DD > 0) { NSVD_PM(gp_, gm_, rs, rc, cd0, sd0) NSVD_STS(Bb_ + 32 * A_LD, gp_); NSVD_STS(Bb_ + 64 * A_LD, gm_); }   \
+            if (DD > 1) { NSVD_PM(gp_, gm_, rs, rc, cd1, sd1) NSVD_STS(Bb_ + 96 * A_LD, gp_); NSVD_STS(Bb_ + 128 * A_LD, gm_); }  \
+            if (DD > 2) { NSVD_PM(gp_, gm_, rs, rc, cd2, sd2) NSVD_STS(Bb_ + 160 * A_LD, gp_); NSVD_STS(Bb_ + 192 * A_LD, gm_); } \
+        } else {        /* cos rows: x + eps e_d -> c cd - s sd, x - eps e_d -> c cd + s sd */ \
+            NSVD_STS(Bb_, rc);                                                   \
+            if (DD > 0) { NSVD_PM(gp_, gm_, rc, rs, cd0, sd0) NSVD_STS(Bb_ + 32 * A_LD, gm_); NSVD_STS(Bb_ + 64 * A_LD, gp_); }   \
+            if (DD > 1) { NSVD_PM(gp_, gm_, rc, rs, cd1, sd1) NSVD_STS(Bb_ + 96 * A_LD, gm_); NSVD_STS(Bb_ + 128 * A_LD, gp_); }  \
+            if (DD > 2) { NSVD_PM(gp_, gm_, rc, rs, cd2, sd2) NSVD_STS(Bb_ + 160 * A_LD, gm_); NSVD_STS(Bb_ + 192 * A_LD, gp_); } \
+        }                                                                        \
     }
 
     // Software pipeline, one barrier per chunk (80 MFMAs per wave between barriers):
@@ -193,11 +221,11 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     //   * the LAST q-group of chunk c is multiplied AFTER the barrier, under the first fragment reads of
     //     chunk c+1 and the global loads of chunk c+2, so neither latency is exposed;
     //   * chunk c+1 is written to the other LDS buffer in the shadow of chunk c's third q-group.
-    NSVD_LOAD_CHUNK(0);
-    NSVD_STORE_CHUNK(0);
+    NSVD_LOAD_CHUNK(0, 0);
+    NSVD_STORE_CHUNK(0, 0);
     __syncthreads();
     NSVD_STAMP(1)
-    if (nch > 1) NSVD_LOAD_CHUNK(1);
+    NSVD_LOAD_CHUNK(1, 1);  // nch = F / 32 is even and >= 4 (F is a multiple of 128)
     Frag<E> f0, f1;
     {
         const float* Ap = As + (32 * w + li) * A_LD + 4 * hi;
@@ -220,7 +248,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // block of 9..15 of them in a row stalls the matrix pipe for ~250..500 cycles per chunk.
     // The steady-state body is branch free (the last two chunks are peeled) so every region is one
     // basic block the scheduler can interleave.
-#define NSVD_CHUNK_BODY(c, DO_STORE, DO_LOAD)                                                   \
+// PAR = parity of c: chunk c+1 (stored here) is the other half of a pair, chunk c+2 (loaded here) the same half
+#define NSVD_CHUNK_BODY(c, DO_STORE, DO_LOAD, PAR)                                              \
     {                                                                                           \
         const int cur = (c) & 1;                                                                \
         const float* Ap = As + cur * HID * A_LD + (32 * w + li) * A_LD + 4 * hi;                \
@@ -234,7 +263,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
         NSVD_FENCE();                                                                           \
         load_frag<E>(f1, Ap + 24, Bp + 24, A_LD);                                               \
-        if (DO_STORE) NSVD_STORE_CHUNK(cur ^ 1);                                                \
+        if (DO_STORE) NSVD_STORE_CHUNK(cur ^ 1, 1 - (PAR));                                     \
         mma_frag<E>(acc, f0);                                                                   \
         NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
         if (DO_STORE) NSVD_INTERLEAVE(4 + E, 0x200);                                            \
@@ -245,24 +274,25 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             const float* Bn = Bs + (cur ^ 1) * NC * A_LD + li * A_LD + 4 * hi;                  \
             load_frag<E>(f0, An, Bn, A_LD);                                                     \
         }                                                                                       \
-        if (DO_LOAD) NSVD_LOAD_CHUNK((c) + 2);                                                  \
+        if (DO_LOAD) NSVD_LOAD_CHUNK((c) + 2, (PAR));                                           \
         mma_frag<E>(acc, f1);                                                                   \
         if (DO_STORE) NSVD_INTERLEAVE(1 + E, 0x100);                                            \
-        if (DO_LOAD) NSVD_INTERLEAVE(4 + E, 0x020);                                             \
+        if (DO_LOAD) NSVD_INTERLEAVE((PAR) ? 4 : 5 + E, 0x020);                                 \
         NSVD_FENCE();                                                                           \
     }
     {
         int c = 0;
-        for (; c + 2 < nch; ++c) NSVD_CHUNK_BODY(c, true, true)
-        if (c + 1 < nch) {
-            NSVD_CHUNK_BODY(c, true, false)
-            ++c;
+        for (; c + 2 < nch; c += 2) {
+            NSVD_CHUNK_BODY(c, true, true, 0)
+            NSVD_CHUNK_BODY(c + 1, true, true, 1)
         }
-        NSVD_CHUNK_BODY(c, false, false)
+        NSVD_CHUNK_BODY(c, true, false, 0)      // c == nch - 2
+        NSVD_CHUNK_BODY(c + 1, false, false, 1)
     }
 #undef NSVD_CHUNK_BODY
 #undef NSVD_LOAD_CHUNK
 #undef NSVD_STORE_CHUNK
+#undef NSVD_PM
 #undef NSVD_LDG
 #undef NSVD_STS
 
@@ -1046,7 +1076,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
 #undef WG_ST
 
 struct FusedWs {
-    float* phi;                       // (R, F) sample-major Fourier features of every stencil row
+    float* phi;                       // (B, F) sample-major Fourier features of the centre rows
+    float* sctab;                     // (D, 2, m) cos / sin of eps * fourier_B (stencil rows by angle addition)
     float* phiTc;                     // (F, B) feature-major copy of the centre rows (weight gradient)
     float* zsave[NSVD_MAX_LAYERS];    // (L, 128, B) per hidden layer
     float* jac;                       // (B, L)
@@ -1094,7 +1125,7 @@ PartLayout part_layout(const nsvd_model_desc& d) {
 FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     FusedWs w;
     memset(&w, 0, sizeof(w));
-    const size_t E = 1 + 2 * (size_t)d.D, R = E * B, F = 2 * (size_t)d.m;
+    const size_t F = 2 * (size_t)d.m;
     char* p = (char*)base;
     size_t off = 0;
     auto take = [&](size_t nfloats) {
@@ -1102,7 +1133,8 @@ FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
         off += nsvd_align(nfloats * sizeof(float));
         return q;
     };
-    w.phi = take(F * R);
+    w.phi = take(F * B);
+    w.sctab = take((size_t)2 * d.D * d.m);
     w.phiTc = take(F * B);
     for (int i = 0; i < d.nlayers - 1; ++i) w.zsave[i] = take((size_t)d.L * HID * B);
     w.jac = take((size_t)B * d.L);
@@ -1134,7 +1166,7 @@ size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B) { return carv
 int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                         int B, void* ws, int save, hipStream_t s) {
     const FusedWs w = carve_fused(d, B, ws);
-    return nsvd_fourier_stencil(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, B, d.D, d.m, prob.eps, s);
+    return nsvd_fourier_stencil(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, w.sctab, B, d.D, d.m, prob.eps, s);
 }
 
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
@@ -1150,6 +1182,8 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     FwdArgs a;
     memset(&a, 0, sizeof(a));
     a.phiT = w.phi;
+    a.sctab = w.sctab;
+    a.m = d.m;
     a.ldr = R;
     a.nlayers = d.nlayers;
     for (int i = 0; i < d.nlayers; ++i) {
