@@ -137,11 +137,18 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int b0 = sb * BS;
 
     NSVD_STAMP(0)
+    // accumulators start from the bias (z = b + W a): its 16 loads fly under the first chunk's staging instead
+    // of sitting, exposed, between the K loop and the softplus
     f32x16 acc[E];
+    {
+        const float* bi0 = a.b[0] + (size_t)l * HID + 32 * w;
 #pragma unroll
-    for (int e = 0; e < E; ++e)
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bi0[acc_row(r, hi)];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+            for (int e = 0; e < E; ++e) acc[e][r] = bv;
+        }
+    }
 
     // ------------------------------------------------------------------ layer 0: K = F in chunks of BK
     // Both operands are k-contiguous rows (W_0[l][n][:] and phi[r][:]): each thread moves one float4 of a
@@ -308,18 +315,17 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         // (Per-lane fragment loads straight from global touch 64 cache lines per instruction: 9k cycles.)
         const bool has_next = (i + 1 < nh);
         float* Wt = Wl + w * 32 * HID;
-        // order matters for the wait counters (vmcnt retires in issue order): bias loads and their use come
-        // BEFORE the DMA is issued, the pre-activation stores AFTER it, so that "vmcnt(#stores)" below
-        // means "the DMA has landed" without draining the stores.
-        const float* bi = a.b[i] + (size_t)l * HID + 32 * w;
+        // order matters for the wait counters (vmcnt retires in issue order): the loads of the next layer's bias
+        // (or of the last layer's weights) are issued BEFORE the DMA, the pre-activation stores AFTER it, so that
+        // "vmcnt(#stores)" below means "the DMA has landed" without draining the stores. All of them land under
+        // the softplus.
+        float nb[16];  // next layer's bias rows of this lane, or (last hidden layer) the 128 -> 1 weights
+        {
+            const float* src = (has_next ? a.b[i + 1] : a.W[nh]) + (size_t)l * HID + 32 * w;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bv = bi[acc_row(r, hi)];
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e][r] += bv;
+            for (int r = 0; r < 16; ++r) nb[r] = src[acc_row(r, hi)];
         }
         if (has_next) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bias loads retired: nothing older than the DMA
             const float* Wn = a.W[i + 1] + ((size_t)l * HID + 32 * w + hi) * HID;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -338,7 +344,22 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
         NSVD_STAMP(3 + 4 * i)
-        if (!has_next) break;
+        if (!has_next) {
+            // ---------------------------------------------------------- last layer 128 -> 1 (weights in nb)
+            float part[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) part[e] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int e = 0; e < E; ++e) part[e] = fmaf(nb[r], acc[e][r], part[e]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                part[e] += __shfl_xor(part[e], 32, 64);
+                if (hi == 0) red[w * NC + e * BS + li] = part[e];
+            }
+            break;
+        }
         NSVD_STAMP(4 + 4 * i)
         // raw barriers: __syncthreads() would drain the 16 stores above (vmcnt(0)) before every barrier
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // previous LDS contents are dead
@@ -359,7 +380,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[e][r] = nb[r];
         // K = 128 in 16 q-groups, fragments read one q-group ahead, one LDS read per MFMA gap
         const float* Ap = Wt + li * HID;        // + 4 * ((2q + hi) ^ (li & 15)): swizzled 16-B chunk
         const int sw = li & 15;
@@ -383,24 +404,6 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #undef NSVD_INTERLEAVE
 #undef NSVD_FENCE
     NSVD_STAMP(12)
-    // ------------------------------------------------------------------ last layer 128 -> 1
-    {
-        const float* wl = a.W[nh] + (size_t)l * HID + 32 * w;
-        float part[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) part[e] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float wv = wl[acc_row(r, hi)];
-#pragma unroll
-            for (int e = 0; e < E; ++e) part[e] = fmaf(wv, acc[e][r], part[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            part[e] += __shfl_xor(part[e], 32, 64);
-            if (hi == 0) red[w * NC + e * BS + li] = part[e];
-        }
-    }
     __syncthreads();
     if (tid < NC) outs[tid] = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
     __syncthreads();
