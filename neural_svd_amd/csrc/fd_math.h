@@ -15,32 +15,34 @@ struct NsvdFdOut {
 //   lap_g = (-2 D g_0 + sum_i (g_+i + g_-i)) / eps^2           diff_ops.py:38-48
 //   lap   = lap_g / clamp(sqrt p(x_0), 1e-5),  fs = g_0 / clamp(...)   diff_ops.py:15-18
 //   Tf    = scale * -( -c_k lap + V(x) fs ) + shift * fs       schrodinger/__init__.py:18-22, examples/__init__.py:9
-__device__ __forceinline__ NsvdFdOut nsvd_fd_point(const float* bv, const float* xc, int D, bool has_mask, float s_l,
-                                                   const nsvd_problem& prob, float log_norm) {
-    const int E = 1 + 2 * D;
-    float g[2 * NSVD_FD_MAXD + 1];
-    float sp0 = 1.f, mask0 = 1.f, r0 = 0.f;
-    for (int e = 0; e < E; ++e) {
-        float xe[NSVD_FD_MAXD];
-        float r2 = 0.f;
-        for (int d = 0; d < D; ++d) {
-            xe[d] = nsvd_stencil_coord(xc[d], d, e, prob.eps);
-            r2 = fmaf(xe[d], xe[d], r2);
-        }
-        const float sp = prob.use_importance ? nsvd_sqrt_gauss_pdf(xe, D, prob.sigma, log_norm) : 1.f;
-        float model = prob.hard_mul_const * bv[e];
-        float mk = 1.f;
-        if (has_mask) {
-            mk = expf(-sqrtf(r2) / s_l);
-            model *= mk;
-        }
-        g[e] = sp * model;
-        if (e == 0) {
-            sp0 = sp;
-            mask0 = mk;
-            r0 = sqrtf(r2);
-        }
+// one stencil point: g_e and (needed of the centre only) sqrt p, mask, |x|
+struct NsvdFdG {
+    float g, sp, mk, r;
+};
+__device__ __forceinline__ NsvdFdG nsvd_fd_g(int e, float bve, const float* xc, int D, bool has_mask, float s_l,
+                                             const nsvd_problem& prob, float log_norm) {
+    float xe[NSVD_FD_MAXD];
+    float r2 = 0.f;
+    for (int d = 0; d < D; ++d) {
+        xe[d] = nsvd_stencil_coord(xc[d], d, e, prob.eps);
+        r2 = fmaf(xe[d], xe[d], r2);
     }
+    NsvdFdG o;
+    o.sp = prob.use_importance ? nsvd_sqrt_gauss_pdf(xe, D, prob.sigma, log_norm) : 1.f;
+    float model = prob.hard_mul_const * bve;
+    o.mk = 1.f;
+    o.r = sqrtf(r2);
+    if (has_mask) {
+        o.mk = expf(-o.r / s_l);
+        model *= o.mk;
+    }
+    o.g = o.sp * model;
+    return o;
+}
+
+// stencil combination; g[e] from nsvd_fd_g, (sp0, mask0, r0) of the centre point, bv0 = bv[0]
+__device__ __forceinline__ NsvdFdOut nsvd_fd_combine(const float* g, float sp0, float mask0, float r0, float bv0, int D,
+                                                     bool has_mask, float s_l, const nsvd_problem& prob) {
     float lap = -2.f * (float)D * g[0];
     for (int i = 0; i < D; ++i) lap += (g[1 + 2 * i] + g[2 + 2 * i]);
     const float eps2 = (float)((double)prob.eps * (double)prob.eps);
@@ -58,6 +60,23 @@ __device__ __forceinline__ NsvdFdOut nsvd_fd_point(const float* bv, const float*
     o.Tf = prob.op_scale * (-H) + prob.op_shift * fs;
     const float w = (sp0 / spc) * prob.hard_mul_const;
     o.jac = w * mask0;
-    o.dsc = has_mask ? w * bv[0] * mask0 * r0 / (s_l * s_l) : 0.f;
+    o.dsc = has_mask ? w * bv0 * mask0 * r0 / (s_l * s_l) : 0.f;
     return o;
+}
+
+__device__ __forceinline__ NsvdFdOut nsvd_fd_point(const float* bv, const float* xc, int D, bool has_mask, float s_l,
+                                                   const nsvd_problem& prob, float log_norm) {
+    const int E = 1 + 2 * D;
+    float g[2 * NSVD_FD_MAXD + 1];
+    float sp0 = 1.f, mask0 = 1.f, r0 = 0.f;
+    for (int e = 0; e < E; ++e) {
+        const NsvdFdG o = nsvd_fd_g(e, bv[e], xc, D, has_mask, s_l, prob, log_norm);
+        g[e] = o.g;
+        if (e == 0) {
+            sp0 = o.sp;
+            mask0 = o.mk;
+            r0 = o.r;
+        }
+    }
+    return nsvd_fd_combine(g, sp0, mask0, r0, bv[0], D, has_mask, s_l, prob);
 }

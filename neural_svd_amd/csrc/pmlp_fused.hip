@@ -405,20 +405,42 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #undef NSVD_FENCE
     NSVD_STAMP(12)
     __syncthreads();
-    if (tid < NC) outs[tid] = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
-    __syncthreads();
-
-    NSVD_STAMP(13)
     // ------------------------------------------------------------------ FD Hamiltonian epilogue
+    // one thread per (stencil point, sample): output of the 128 -> 1 layer, then g_e = sqrt p(x_e) c base_e mask(x_e)
+    // (the exp / sqrt heavy part, E x 32 threads wide instead of a 5-point loop on 32 threads)
+    float* gs = outs;         // [NC]   g_e
+    float* cen = red;         // [4][BS] centre: sqrt p, mask, |x|, base   (red is dead once read below)
+    NsvdFdG og;
+    float bve = 0.f;
+    og.g = og.sp = og.mk = og.r = 0.f;
+    const int e_t = tid / BS, sidx = tid - e_t * BS;
+    if (tid < NC) {
+        bve = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
+        float xc[NSVD_FD_MAXD];
+        for (int d = 0; d < a.D; ++d) xc[d] = a.x[(size_t)(b0 + sidx) * a.D + d];
+        const float s_l = a.scales ? a.scales[l] : 0.f;
+        og = nsvd_fd_g(e_t, bve, xc, a.D, a.scales != nullptr, s_l, a.prob, a.log_norm);
+    }
+    __syncthreads();          // every thread has consumed its red[] inputs before the centre values overwrite them
+    if (tid < NC) {
+        gs[tid] = og.g;
+        if (e_t == 0) {
+            cen[sidx] = og.sp;
+            cen[BS + sidx] = og.mk;
+            cen[2 * BS + sidx] = og.r;
+            cen[3 * BS + sidx] = bve;
+        }
+    }
+    __syncthreads();
+    NSVD_STAMP(13)
     if (tid < BS) {
         const int b = b0 + tid;
-        float xc[NSVD_FD_MAXD];
-        for (int d = 0; d < a.D; ++d) xc[d] = a.x[(size_t)b * a.D + d];
-        float bv[E];
+        float g[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) bv[e] = outs[e * BS + tid];
+        for (int e = 0; e < E; ++e) g[e] = gs[e * BS + tid];
         const float s_l = a.scales ? a.scales[l] : 0.f;
-        const NsvdFdOut o = nsvd_fd_point(bv, xc, a.D, a.scales != nullptr, s_l, a.prob, a.log_norm);
+        const NsvdFdOut o = nsvd_fd_combine(g, cen[tid], cen[BS + tid], cen[2 * BS + tid], cen[3 * BS + tid], a.D,
+                                            a.scales != nullptr, s_l, a.prob);
         const size_t idx = (size_t)b * a.L + l;
         a.f[idx] = o.f;
         a.Tf[idx] = o.Tf;

@@ -16,7 +16,7 @@ x = (16 * torch.randn(B, D)).to(dev)
 wsb = H.new_workspace(shape, B, dev)
 al = lambda n: (n * 4 + 255) // 256 * 256
 E = 1 + 2 * D; R = E * B; F = 2 * m
-off = al(F * R) + al(F * B) + len(hidden) * al(L * 128 * B) + 2 * al(B * L)
+off = al(F * B) + al(2 * D * m) + al(F * B) + len(hidden) * al(L * 128 * B) + 2 * al(B * L)  # FusedWs: dz[0]
 for _ in range(3):
     H.operator_forward(shape, p, prob, x, wsb, True, H.PATH_FUSED)
 torch.cuda.synchronize()
