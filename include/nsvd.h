@@ -148,6 +148,17 @@ int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, c
                        float hard_mul_const, float* out, void* ws, size_t ws_bytes, int save_for_backward,
                        void* stream);
 
+/* Draws the batch AND prepares its features in one launch: x[b][d] = sigma * N(0,1) with sigma = prob->sigma,
+ * from a counter-based generator (Philox4x32-10 + Box-Muller) keyed by (seed, offset, b): the device-side form of
+ * `x = sampling_scale * torch.randn(batch_size, ndim)` + host->device copy (examples/operator/pde/main_pde.py:92-93,
+ * examples/operator/__init__.py:58). x (B, D) is an OUTPUT; follow with nsvd_operator_forward(... |
+ * NSVD_FEATURES_READY). The stream of values is a pure function of (seed, offset): pass a fresh offset per batch;
+ * ranks that pass the same (seed, offset) draw the same batch. Not torch's generator: same distribution, different
+ * numbers. */
+int nsvd_operator_sample_features(const nsvd_model_desc* desc, const nsvd_params* params, const nsvd_problem* prob,
+                                  unsigned long long seed, unsigned long long offset, float* x, int B, void* ws,
+                                  size_t ws_bytes, int save_for_backward, int path, void* stream);
+
 /* Parameter gradients of sum(dout * model(x)) for the matching nsvd_model_forward(save_for_backward=1). */
 int nsvd_model_backward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
                         const float* dout, const nsvd_params* grads, void* ws, size_t ws_bytes, void* stream);

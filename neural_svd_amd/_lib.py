@@ -57,6 +57,8 @@ SIGNATURES = {
                                    _P, _Z, _I, _I, _P]),
     "nsvd_operator_features": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _Z, _I,
                                     _I, _P]),
+    "nsvd_operator_sample_features": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), C.c_uint64,
+                                           C.c_uint64, _P, _I, _P, _Z, _I, _I, _P]),
     "nsvd_operator_backward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
                                     C.POINTER(Params), _P, _Z, _I, _P]),
     "nsvd_model_forward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), _P, _I, _F, _P, _P, _Z, _I, _P]),

@@ -1,5 +1,6 @@
 // Fourier feature map at the 1+2D stencil points, written feature-major (phiT[k][r]).
 // Replaces reference examples/utils.py:139-140 evaluated at diff_ops.py:36-45's points.
+#include <string.h>
 #include "nsvd_kernels.h"
 
 namespace {
@@ -67,7 +68,8 @@ template <int D>
 __global__ void __launch_bounds__(FT) fourier_stencil_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ fB,
                                                               float* __restrict__ phi, float* __restrict__ phiTc,
-                                                              float* __restrict__ sctab, int B, int m, float eps) {
+                                                              float* __restrict__ sctab, int B, int m, float eps,
+                                                              NsvdSampler smp, float* __restrict__ xout) {
     __shared__ float ts[FJ][FB + 1];  // transposed staging of the centre rows
     __shared__ float tc[FJ][FB + 1];
     const int tid = threadIdx.x;
@@ -89,9 +91,22 @@ __global__ void __launch_bounds__(FT) fourier_stencil_kernel(const float* __rest
     for (int bl = tid / FJ; bl < FB; bl += FT / FJ) {
         const int b = b0 + bl;
         if (b >= B) break;
+        float xr[4];
+        if (smp.on) {
+            // the batch is DRAWN here (every frequency block regenerates the same counter-based values; the first
+            // one stores them for the epilogue and the backward)
+            nsvd_sample_row(smp, b, D, xr);
+            if (blockIdx.x == 0 && jl == 0) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) xout[(size_t)b * D + d] = xr[d];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xr[d] = x[(size_t)b * D + d];
+        }
         double p = 0.0;
 #pragma unroll
-        for (int d = 0; d < D; ++d) p = fma((double)x[(size_t)b * D + d], (double)bj[d], p);
+        for (int d = 0; d < D; ++d) p = fma((double)xr[d], (double)bj[d], p);
         float s0, c0;
         sincos_d2f(p, &s0, &c0);
         if (jok) {
@@ -130,13 +145,33 @@ extern "C" int nsvd_fourier_features(const float* x, const float* fourier_B, flo
     return 0;
 }
 
+namespace {
+__global__ void __launch_bounds__(256) sample_kernel(NsvdSampler smp, float* __restrict__ x, int B, int D) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float xr[4];
+    nsvd_sample_row(smp, b, D, xr);
+    for (int d = 0; d < D; ++d) x[(size_t)b * D + d] = xr[d];
+}
+}  // namespace
+
+int nsvd_sample_launch(const NsvdSampler& smp, float* x, int B, int D, hipStream_t s) {
+    if (D < 1 || D > 4) return NSVD_EUNSUPPORTED;
+    hipLaunchKernelGGL(sample_kernel, dim3(nsvd_cdiv(B, 256)), dim3(256), 0, s, smp, x, B, D);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
 int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, float* sctab, int B, int D,
-                         int m, float eps, hipStream_t s) {
+                         int m, float eps, const NsvdSampler* sampler, float* xout, hipStream_t s) {
+    NsvdSampler smp;
+    memset(&smp, 0, sizeof(smp));
+    if (sampler) smp = *sampler;
     dim3 grid(nsvd_cdiv(m, FJ), nsvd_cdiv(B, FB));
     switch (D) {
-        case 1: hipLaunchKernelGGL(fourier_stencil_kernel<1>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps); break;
-        case 2: hipLaunchKernelGGL(fourier_stencil_kernel<2>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps); break;
-        case 3: hipLaunchKernelGGL(fourier_stencil_kernel<3>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps); break;
+        case 1: hipLaunchKernelGGL(fourier_stencil_kernel<1>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps, smp, xout); break;
+        case 2: hipLaunchKernelGGL(fourier_stencil_kernel<2>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps, smp, xout); break;
+        case 3: hipLaunchKernelGGL(fourier_stencil_kernel<3>, grid, dim3(FT), 0, s, x, fourier_B, phi, phiTc, sctab, B, m, eps, smp, xout); break;
         default: return NSVD_EUNSUPPORTED;
     }
     NSVD_CHECK_LAUNCH();

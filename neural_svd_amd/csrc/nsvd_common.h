@@ -94,3 +94,50 @@ __device__ __forceinline__ float nsvd_stencil_coord(float xc, int d, int e, floa
     if (axis != d) return xc;
     return ((e - 1) & 1) ? xc - eps : xc + eps;
 }
+
+// ---- counter-based normal sampler (Philox4x32-10 + Box-Muller): x[b][d] ~ N(0, sigma^2) --------------------
+// Replaces the reference's host-side x = sigma * randn(B, D) + copy (examples/operator/pde/main_pde.py:92-93).
+// Stateless: the value of (seed, offset, b, d) is a pure function, so every block of the feature kernel can
+// regenerate the coordinates of its samples instead of reading them, and ranks that must agree (head-parallel
+// sharding) agree by construction.
+struct NsvdSampler {
+    unsigned long long seed;    // key
+    unsigned long long offset;  // call counter (one per batch)
+    float sigma;
+    int on;                     // 0: coordinates are read from x
+};
+
+__host__ __device__ __forceinline__ void nsvd_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                                            unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// up to 4 coordinates of sample b (D <= 4): two Box-Muller pairs from one Philox block
+__device__ __forceinline__ void nsvd_sample_row(const NsvdSampler& s, int b, int D, float* xr) {
+    unsigned r[4];
+    nsvd_philox4x32_10((unsigned)b, (unsigned)s.offset, (unsigned)(s.offset >> 32), 0x6e737664u, (unsigned)s.seed,
+                       (unsigned)(s.seed >> 32), r);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        if (2 * pr >= D) break;
+        const float u1 = ((float)(r[2 * pr] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1): 24 bits, never 0
+        const float u2 = ((float)(r[2 * pr + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float rad = s.sigma * sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        xr[2 * pr] = rad * cs;
+        if (2 * pr + 1 < D) xr[2 * pr + 1] = rad * sn;
+    }
+}

@@ -9,8 +9,11 @@ void nsvd_prof_end(hipStream_t s);
 // Fused-path features (fourier.hip): phi (B, 2m) sample-major features of the CENTRE rows from one double-accurate
 // sincos per (sample, frequency); phiTc (2m, B) feature-major copy, or null; sctab (D, 2, m) = cos / sin of
 // eps * fourier_B, from which the forward kernel builds the shifted stencil rows by angle addition.
+// sampler != null: the coordinates are drawn inside the kernel (N(0, sigma^2), counter-based) and stored to xout.
 int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, float* sctab, int B, int D,
-                         int m, float eps, hipStream_t s);
+                         int m, float eps, const NsvdSampler* sampler, float* xout, hipStream_t s);
+// stand-alone draw of the same values (generic path)
+int nsvd_sample_launch(const NsvdSampler& smp, float* x, int B, int D, hipStream_t s);
 
 // ---- generic strided batched GEMM (gemm_generic.hip) -------------------------------------------
 //   C[g][i][j] = epi( sum_k A[g][i*sAm + k*sAk] * pro(B[g][k*sBk + j*sBn]) + bias[g][i] )
@@ -56,7 +59,8 @@ bool nsvd_fused_supported(const nsvd_model_desc& d, int B);
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B);
 // Fourier features of x into the fused path's workspace (phi, and phiT_c when save != 0)
 int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
-                        int B, void* ws, int save, hipStream_t s);
+                        int B, void* ws, int save, hipStream_t s, const NsvdSampler* sampler = nullptr,
+                        float* xout = nullptr);
 // save: bit 0 = keep what the backward needs, bit 1 = features already prepared by nsvd_fused_features
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                        int B, float* f, float* Tf, void* ws, int save, hipStream_t s);

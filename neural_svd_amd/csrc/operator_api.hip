@@ -217,6 +217,31 @@ extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_pa
     return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
 }
 
+extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const nsvd_params* params,
+                                             const nsvd_problem* prob, unsigned long long seed,
+                                             unsigned long long offset, float* x, int B, void* ws, size_t ws_bytes,
+                                             int save_for_backward, int path, void* stream) {
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!prob || !x || !ws || !params || !params->fourier_B || B <= 0) return NSVD_EINVAL;
+    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    const bool fused = want_fused(*desc, B, path);
+    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    NsvdSampler smp;
+    smp.seed = seed;
+    smp.offset = offset;
+    smp.sigma = prob->sigma;
+    smp.on = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (fused) return nsvd_fused_features(*desc, *params, *prob, x, B, ws, save_for_backward & 1, s, &smp, x);
+    rc = nsvd_sample_launch(smp, x, B, desc->D, s);
+    if (rc) return rc;
+    const GenericWs w = carve(*desc, B, ws);
+    const int E = 1 + 2 * desc->D;
+    return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
+}
+
 extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
                                   float hard_mul_const, float* out, void* ws, size_t ws_bytes, int save_for_backward,
                                   void* stream) {

@@ -1189,9 +1189,10 @@ bool nsvd_fused_supported(const nsvd_model_desc& d, int B) {
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B) { return carve_fused(d, B, nullptr).bytes; }
 
 int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
-                        int B, void* ws, int save, hipStream_t s) {
+                        int B, void* ws, int save, hipStream_t s, const NsvdSampler* sampler, float* xout) {
     const FusedWs w = carve_fused(d, B, ws);
-    return nsvd_fourier_stencil(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, w.sctab, B, d.D, d.m, prob.eps, s);
+    return nsvd_fourier_stencil(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, w.sctab, B, d.D, d.m, prob.eps,
+                                sampler, xout, s);
 }
 
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,

@@ -174,6 +174,19 @@ def operator_features(shape: ModelShape, params: Params, prob: Problem, x: torch
     check(rc, "nsvd_operator_features")
 
 
+def operator_sample_features(shape: ModelShape, params: Params, prob: Problem, seed: int, offset: int,
+                             x: torch.Tensor, ws: torch.Tensor, save_for_backward: bool = True,
+                             path: int = PATH_AUTO) -> None:
+    """x <- sigma * N(0, 1) (counter-based, keyed by seed / offset) and its features into ws, one launch."""
+    B = x.shape[0]
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_sample_features(C.byref(d), C.byref(params), C.byref(prob),
+                                                   int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+                                                   _ptr(x, "x"), B, ws.data_ptr(), ws.numel(),
+                                                   int(bool(save_for_backward)), int(path), _stream())
+    check(rc, "nsvd_operator_sample_features")
+
+
 def operator_backward(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, df: torch.Tensor,
                       grads: Params, ws: torch.Tensor, path: int = PATH_AUTO) -> None:
     B = x.shape[0]

@@ -106,13 +106,15 @@ class FusedTrainer:
                  fourier_scale: float = 0.1, exp_mask_init: Optional[float] = None, seed: Optional[int] = 0,
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
                  pipeline: bool = False, parallelism: str = "dp", fused_step: bool = True,
-                 keep_grads: bool = False):
+                 keep_grads: bool = False, device_sampler: bool = True):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
         them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
         fused_step: take the RMSprop + EMA step inside the weight-gradient kernel (nsvd_operator_backward_evd_step)
         whenever no gradient exchange sits between backward and optimiser (single GPU, hp); keep_grads then
-        also stores the gradients (P.grad), which the fused step otherwise never writes."""
+        also stores the gradients (P.grad), which the fused step otherwise never writes.
+        device_sampler: draw the batch inside the feature kernel (nsvd_operator_sample_features, counter-based
+        Philox) instead of torch's generator + a separate feature launch."""
         self.device = torch.device(device)
         self.path = path
         self.comm = comm  # parallel.Communicator or None
@@ -171,7 +173,10 @@ class FusedTrainer:
         self.gen = torch.Generator(device=self.device)
         # dp: every rank its own stream of samples; hp: all ranks draw the SAME global batch
         srank = 0 if self.hp else rank
-        self.gen.manual_seed((sample_seed if sample_seed is not None else (seed or 0)) * 1000003 + 7919 * srank + 1)
+        self.sample_key = (sample_seed if sample_seed is not None else (seed or 0)) * 1000003 + 7919 * srank + 1
+        self.gen.manual_seed(self.sample_key)
+        self.device_sampler = bool(device_sampler)
+        self.batches_drawn = 0
         if self.hp:
             # every rank must draw the SAME global batch: check once that equally seeded generators agree
             probe = torch.empty(64, dtype=torch.float32, device=self.device).normal_(generator=self.gen)
@@ -264,9 +269,16 @@ class FusedTrainer:
             if self._pending:  # drop a prefetched batch: its features would be overwritten
                 torch.cuda.current_stream(self.device).wait_event(self._ev_ready)
                 self._pending = False
-            if x is None:
-                x = self.sample()
-            self.forward_backward(x)
+            if x is None and self.device_sampler:
+                # one launch draws the batch and writes its features; the forward then skips the feature stage
+                H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
+                                           self.batches_drawn, self.x, self.ws, True, self.path)
+                self.batches_drawn += 1
+                self.forward_backward(self.x, features_ready=True)
+            else:
+                if x is None:
+                    x = self.sample()
+                self.forward_backward(x)
             self.optimizer_step()
             return
         main = torch.cuda.current_stream(self.device)

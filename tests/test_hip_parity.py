@@ -319,6 +319,46 @@ def test_backward_evd_matches_two_step(case, fn, path):
             assert rel(g, g2) < 2e-5, (i, reduced, rel(g, g2))
 
 
+@pytest.mark.parametrize("B,hidden", [(65536, (128,)), (4099, (16,))])
+def test_device_sampler(B, hidden):
+    """nsvd_operator_sample_features: x ~ N(0, sigma^2) from the counter-based generator (fused into the feature
+    kernel on the MFMA path, stand-alone on the generic path): moments of the draw, reproducibility in
+    (seed, offset), and the features it leaves in the workspace equal those of nsvd_operator_features(x)."""
+    D, m, sigma = 2, 64, 16.0
+    shape = H.ModelShape(L=1, D=D, m=m, hidden=hidden)
+    p = O.init_params(1, D, m, hidden, 0.1, seed=1)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, sigma)
+    ws = H.new_workspace(shape, B, DEV)
+    x = torch.empty(B, D, device=DEV)
+    H.operator_sample_features(shape, params, prob, 1234, 7, x, ws)
+    f1, Tf1 = H.operator_forward(shape, params, prob, x, ws, features_ready=True)
+    xs = x.double().cpu()
+    n = xs.numel()
+    assert abs(float(xs.mean())) < 5 * sigma / np.sqrt(n)
+    assert abs(float(xs.std()) / sigma - 1) < 5 / np.sqrt(2 * n)
+    z = (xs / sigma).flatten()
+    assert abs(float((z ** 3).mean())) < 5 * np.sqrt(15.0 / n)          # skewness
+    assert abs(float((z ** 4).mean()) - 3.0) < 5 * np.sqrt(96.0 / n)    # kurtosis
+    assert abs(float((xs[:, 0] * xs[:, 1]).mean())) / sigma ** 2 < 5 / np.sqrt(B)   # the two coordinates
+    assert abs(float((xs[1:, 0] * xs[:-1, 0]).mean())) / sigma ** 2 < 5 / np.sqrt(B)  # neighbouring samples
+    # Kolmogorov-Smirnov against the normal CDF
+    from scipy import stats
+    assert stats.kstest(z.numpy()[::max(1, n // 20000)], "norm").pvalue > 1e-3
+    # pure function of (seed, offset); different offsets / seeds are different draws
+    x2 = torch.empty_like(x)
+    H.operator_sample_features(shape, params, prob, 1234, 7, x2, ws)
+    assert torch.equal(x, x2)
+    H.operator_sample_features(shape, params, prob, 1234, 8, x2, ws)
+    assert not torch.equal(x, x2) and abs(float((x2.double().cpu() * xs).mean())) / sigma ** 2 < 5 / np.sqrt(n)
+    H.operator_sample_features(shape, params, prob, 1235, 7, x2, ws)
+    assert not torch.equal(x, x2)
+    # the features written next to the draw are the features of that x
+    f2, Tf2 = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV))
+    assert torch.equal(f1, f2) and torch.equal(Tf1, Tf2)
+
+
 @pytest.mark.parametrize("L,B,mask", [(2, 1024, True), (1, 2048, False)])
 def test_backward_split_k_matches_oracle(L, B, mask):
     """Few heads on many rows (what a head-parallel rank sees): the weight-gradient kernel splits the batch
