@@ -25,16 +25,16 @@
 //            cdk_loss_reduce (one block: loss[3] from the partials)
 //            cdk_backward_gemm (both gradients in one grid)
 #include "nsvd_kernels.h"
+#include "tile_nt.h"
 
 namespace {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef nsvd_f32x16 floatx16;
 
-constexpr int T = 64;            // tile edge (rows of A x rows of B per block of 4 waves)
+constexpr int T = NSVD_TNT_T;    // tile edge (rows of A x rows of B per block of 4 waves)
 constexpr int TS = 32;           // tile edge of the staging / finish kernels
-constexpr int KC = 64;           // contraction chunk
-constexpr int LDT = KC + 4;      // padded LDS row: conflict-free ds_read_b128 over 32 rows
-constexpr int TILE_FLOATS = 2 * 2 * T * LDT;  // double-buffered A and B chunks: 68 KB
+constexpr int KC = NSVD_TNT_KC;  // contraction chunk
+constexpr int TILE_FLOATS = NSVD_TNT_FLOATS;  // double-buffered A and B chunks: 68 KB
 constexpr int NB0 = 8;           // batch slices of the constant-mode row (border blocks)
 constexpr int SPLIT_CHUNKS = 8;  // batch contraction: about this many chunks per block (split-K)
 
@@ -131,99 +131,12 @@ __global__ void __launch_bounds__(256) cdk_stage_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------ tile GEMM
-// acc(32x32 of this wave) += A[64 rows][k0 : k1] . B[64 rows][k0 : k1]^T for the 64 x 64 tile of a 256-thread
-// block; both operands K-contiguous. Global loads run TWO chunks ahead through two named register sets (the
-// operands were written by other XCDs: MALL / HBM latency); LDS is double-buffered with one barrier per chunk.
-// The loop body is branch-free (loads past the end re-read the last chunk; their LDS copy is never consumed)
-// so that the compiler's waitcnt counting keeps the younger set in flight.
-// Measured with s_memtime at B = 1024, L = 512 (9 chunks, one block per CU): 28.8 K cycles per tile, of which
-// 20.8 K are the 288 MFMAs themselves; the rest is the per-chunk write / barrier / first-read latency that a
-// single wave per SIMD cannot hide (larger tiles would hide it but leave CUs idle at this problem size).
-#define CDK_LOAD(S, ko)                                              \
-    sa##S##0 = *(const float4*)(ap + (ko));                          \
-    sa##S##1 = *(const float4*)(ap + 16 * lda + (ko));               \
-    sa##S##2 = *(const float4*)(ap + 32 * lda + (ko));               \
-    sa##S##3 = *(const float4*)(ap + 48 * lda + (ko));               \
-    sb##S##0 = *(const float4*)(bp + (ko));                          \
-    sb##S##1 = *(const float4*)(bp + 16 * ldb + (ko));               \
-    sb##S##2 = *(const float4*)(bp + 32 * ldb + (ko));               \
-    sb##S##3 = *(const float4*)(bp + 48 * ldb + (ko));
-#define CDK_PUT(S, buf)                                                       \
-    {                                                                         \
-        float* la_ = lds + (buf) * (2 * T * LDT) + lr0 * LDT + lc;            \
-        float* lb_ = la_ + T * LDT;                                           \
-        *(float4*)(la_) = sa##S##0;                                           \
-        *(float4*)(la_ + 16 * LDT) = sa##S##1;                                \
-        *(float4*)(la_ + 32 * LDT) = sa##S##2;                                \
-        *(float4*)(la_ + 48 * LDT) = sa##S##3;                                \
-        *(float4*)(lb_) = sb##S##0;                                           \
-        *(float4*)(lb_ + 16 * LDT) = sb##S##1;                                \
-        *(float4*)(lb_ + 32 * LDT) = sb##S##2;                                \
-        *(float4*)(lb_ + 48 * LDT) = sb##S##3;                                \
-    }
-// 32 MFMAs on LDS buffer `buf`; the reads of group s+1 are issued ahead of the 4 MFMAs of group s
-#define CDK_COMPUTE(buf)                                                                      \
-    {                                                                                         \
-        const float* la = lds + (buf) * (2 * T * LDT) + ra * LDT + kq;                        \
-        const float* lb = lds + (buf) * (2 * T * LDT) + T * LDT + rb * LDT + kq;              \
-        float4 av = *(const float4*)la, bv = *(const float4*)lb;                              \
-        _Pragma("unroll") for (int s = 0; s < KC / 8; ++s) {                                  \
-            float4 an = av, bn = bv;                                                          \
-            if (s + 1 < KC / 8) {                                                             \
-                an = *(const float4*)(la + (s + 1) * 8);                                      \
-                bn = *(const float4*)(lb + (s + 1) * 8);                                      \
-            }                                                                                 \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);             \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc1, 0, 0, 0);           \
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc2, 0, 0, 0);           \
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc3, 0, 0, 0);           \
-            av = an;                                                                          \
-            bv = bn;                                                                          \
-        }                                                                                     \
-    }
-// one pipeline step: prefetch chunk c+2 into set S, compute chunk c, stage chunk c+1 (set S^1) into LDS
-#define CDK_STEP(S, SN, c)                                                                    \
-    CDK_LOAD(S, min((c) + 2, nc - 1) * KC)                                                    \
-    CDK_COMPUTE(S)                                                                            \
-    __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);                                        \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                        \
-    _Pragma("unroll") for (int s = 0; s + 1 < KC / 8; ++s) {                                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                    \
-    }                                                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                        \
-    CDK_PUT(SN, SN)                                                                           \
-    __syncthreads();
-
+// tile_nt.h: acc(32x32 of this wave) += A[64 rows][k0 : k1] . B[64 rows][k0 : k1]^T
 __device__ __forceinline__ void tile_nt(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
                                         long ldb, int k0, int k1, float* __restrict__ lds, floatx16& acc) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int ra = (wv & 1) * 32 + (lane & 31), rb = (wv >> 1) * 32 + (lane & 31), kq = (lane >> 5) * 4;
-    // global -> register staging: rows lr0 + 16 i, 16 floats per row-quarter
-    const int lr0 = t >> 4, lc = (t & 15) * 4;
-    const float* ap = A + (long)lr0 * lda + lc + k0;
-    const float* bp = Bm + (long)lr0 * ldb + lc + k0;
-    const int nc = (k1 - k0) / KC;
-    // named registers + macros: hipcc demotes a conditionally rewritten float4 array to scratch
-    float4 sa00, sa01, sa02, sa03, sb00, sb01, sb02, sb03;  // set 0: even chunks -> LDS buffer 0
-    float4 sa10, sa11, sa12, sa13, sb10, sb11, sb12, sb13;  // set 1: odd chunks  -> LDS buffer 1
-    // four independent accumulation chains (k mod 4), summed at the end
-    floatx16 acc1 = {0}, acc2 = {0}, acc3 = {0};
-    CDK_LOAD(0, 0)
-    CDK_LOAD(1, min(1, nc - 1) * KC)
-    CDK_PUT(0, 0)
-    __syncthreads();
-    for (int c = 0; c < nc; c += 2) {
-        CDK_STEP(0, 1, c)
-        if (c + 1 >= nc) break;
-        CDK_STEP(1, 0, c + 1)
-    }
-    acc = (acc + acc1) + (acc2 + acc3);
+    float unused[4] = {0.f, 0.f, 0.f, 0.f};
+    nsvd_tile_nt<false>(A, lda, Bm, ldb, k0, k1, lds, acc, unused);
 }
-#undef CDK_LOAD
-#undef CDK_PUT
-#undef CDK_COMPUTE
-#undef CDK_STEP
 
 // accumulator element r of this lane sits at (row, col) of the wave's 32 x 32 block
 __device__ __forceinline__ int acc_row(int lane, int r) { return (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3); }

@@ -39,6 +39,18 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
     return z > NSVD_SOFTPLUS_THRESHOLD ? 1.0f : s;
 }
 
+// The same derivative from the ACTIVATION a = softplus(z) >= 0 (what the fused forward saves for the backward, so
+// that no kernel of the backward recomputes a softplus): sigmoid(z) = 1 - e^{-a}. Below a = 1/16 the series of
+// -expm1(-a) to a^4 (no cancellation; truncation a^4/120 < 1.3e-7 relative), above it 1 - exp directly (the result
+// is >= 0.06, so the 6e-8 absolute rounding of 1 - x is <= 1e-6 relative).
+__device__ __forceinline__ float nsvd_sigmoid_from_softplus(float a) {
+    const float direct = 1.0f - __builtin_amdgcn_exp2f(-a * NSVD_LOG2E);
+    float p = fmaf(a, -0.25f, 1.0f);
+    p = fmaf(p * a, -1.0f / 3.0f, 1.0f);
+    p = fmaf(p * a, -0.5f, 1.0f);
+    return a < 0.0625f ? p * a : direct;
+}
+
 // sin and cos of one float32 argument, ~1 ulp, ~30 VALU: 3-constant Cody-Waite reduction by pi/2 with
 // FMAs (exact enough for |x| < 1e5) + degree-7/8 minimax polynomials on [-pi/4, pi/4]; ocml's sincosf
 // (Payne-Hanek, ~10x the cost at the 10..60 rad arguments the Fourier features see) beyond that.

@@ -24,6 +24,7 @@
 #include "fd_math.h"
 #include "evd_math.h"
 #include "opt_math.h"
+#include "tile_nt.h"
 
 namespace {
 
@@ -52,7 +53,7 @@ struct FwdArgs {
     float* Tf;
     float* jac;
     float* dsc;
-    float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null
+    float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null: ACTIVATIONS softplus(z) of the centre rows
     int xcd_remap;  // 0: plain mapping; else HX = number of head groups across the 8 XCDs (1, 2, 4 or 8)
     unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
@@ -333,8 +334,11 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 nsvd_glds16(Wn + (size_t)(2 * j) * HID + 4 * (li ^ (row & 15)), Wt + 2 * j * HID);
             }
         }
-        // (save centre pre-activations) + softplus, in registers
+        // softplus in registers; the centre rows' ACTIVATIONS are saved for the backward (its kernels then need
+        // no softplus: sigmoid(z) = 1 - exp(-softplus(z)), and the weight gradients contract activations)
         float* zs = a.zsave[i] ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = nsvd_softplus(acc[0][r]);
         if (zs) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
@@ -342,7 +346,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
+            for (int e = 1; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
         NSVD_STAMP(3 + 4 * i)
         if (!has_next) {
             // ---------------------------------------------------------- last layer 128 -> 1 (weights in nb)
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = acc_row(r, hi);
-            dz[r] = wl[n] * dbase * nsvd_sigmoid(zp[(size_t)n * a.B]);
+            dz[r] = wl[n] * dbase * nsvd_sigmoid_from_softplus(zp[(size_t)n * a.B]);
         }
     }
     for (int i = nh - 1; i >= 0; --i) {
@@ -584,7 +588,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
             mma_frag<1>(acc1, f);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * nsvd_sigmoid(zin[r]);
+        for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * nsvd_sigmoid_from_softplus(zin[r]);
     }
 }
 
@@ -874,6 +878,44 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
     WG_STAMP(6, wall_clock64());
 }
 
+// dW_i quadrant through the shared C = A B^T tile routine (tile_nt.h): both operands are plain (L, 128, B) rows now
+// that the forward saves activations - no softplus while staging, loads two chunks ahead, four accumulator chains.
+// Needs the slice length to be a multiple of 64 (the 32-chunk form below takes the rest).
+__device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, float* lds, int unit, int slice) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int quad = unit & 3;
+    const int rest = unit >> 2;
+    const int l = rest % a.L;
+    const int i = 1 + rest / a.L;
+    const int n0 = (quad >> 1) * 64, k0 = (quad & 1) * 64;
+    const float* A = a.dz[i] + ((size_t)l * HID + n0) * a.B;
+    const float* Bm = a.zsave[i - 1] + ((size_t)l * HID + k0) * a.B;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int b0 = slice * a.Bs;
+    if (k0 == 0) nsvd_tile_nt<true>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
+    else nsvd_tile_nt<false>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
+    wg_emit16(a, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
+              ((size_t)l * HID + n0 + 32 * (wv & 1)) * HID + k0 + 32 * (wv >> 1) + li, HID, hi, acc);
+    if (k0 == 0) {
+        // bias gradient: the 16 threads t & 15 of a staging row hold partial sums of rows (t >> 4) + 16 j
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) rs[j] += __shfl_xor(rs[j], off, 64);
+        if ((tid & 15) == 0) {
+            const WgDst db = wg_dst(a, a.gb[i], a.pob[i], slice);
+            const size_t gb = (size_t)l * HID + n0 + (tid >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wg_emit1(a, db, a.ob[i], gb + 16 * j, rs[j]);
+        }
+    }
+}
+
 __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, float* Bs, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -911,8 +953,8 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
         float* Bb_ = Bs + (buf) * TS + s_row * A_LD + 4 * s_c4;         \
         WG_ST(Ab_, S##a0);                                              \
         WG_ST(Ab_ + 32 * A_LD, S##a1);                                  \
-        WG_ST(Bb_, softplus4(S##b0));                                   \
-        WG_ST(Bb_ + 32 * A_LD, softplus4(S##b1));                       \
+        WG_ST(Bb_, S##b0);                                              \
+        WG_ST(Bb_ + 32 * A_LD, S##b1);                                  \
         rs0 += (S##a0.x + S##a0.y) + (S##a0.z + S##a0.w);               \
         rs1 += (S##a1.x + S##a1.y) + (S##a1.z + S##a1.w);               \
     }
@@ -1011,10 +1053,10 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
             const float4 d = *reinterpret_cast<const float4*>(dbl + b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                s[j] = fmaf(d.x, nsvd_softplus(z[j].x), s[j]);
-                s[j] = fmaf(d.y, nsvd_softplus(z[j].y), s[j]);
-                s[j] = fmaf(d.z, nsvd_softplus(z[j].z), s[j]);
-                s[j] = fmaf(d.w, nsvd_softplus(z[j].w), s[j]);
+                s[j] = fmaf(d.x, z[j].x, s[j]);
+                s[j] = fmaf(d.y, z[j].y, s[j]);
+                s[j] = fmaf(d.z, z[j].z, s[j]);
+                s[j] = fmaf(d.w, z[j].w, s[j]);
             }
         }
 #pragma unroll
@@ -1027,8 +1069,10 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
 }
 
 __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[2 * HID * A_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * HID * A_LD];
+    __shared__ __attribute__((aligned(16))) float smem_wg[4 * HID * A_LD];  // 72 KB: two blocks per CU
+    static_assert(4 * HID * A_LD >= NSVD_TNT_FLOATS, "tile_nt buffers must fit the weight-gradient LDS");
+    float* As = smem_wg;
+    float* Bs = smem_wg + 2 * HID * A_LD;
     // grid = S x (nA | nB | 4 L) blocks, kind-major so that the long dW_0 tiles are dispatched first
     int bid = blockIdx.x + a.bid0;
     if (bid < a.nA * a.S) {
@@ -1044,7 +1088,8 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     if (bid < a.nB * a.S) {
         WG_STAMP(0, 2ull);
         WG_STAMP(1, wall_clock64());
-        wgrad_tile_B(a, As, Bs, bid % a.nB, bid / a.nB);
+        if (a.Bs % NSVD_TNT_KC == 0) wgrad_tile_B64(a, smem_wg, bid % a.nB, bid / a.nB);
+        else wgrad_tile_B(a, As, Bs, bid % a.nB, bid / a.nB);
         WG_STAMP(6, wall_clock64());
         return;
     }
