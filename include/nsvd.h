@@ -159,6 +159,10 @@ int nsvd_operator_sample_features(const nsvd_model_desc* desc, const nsvd_params
                                   unsigned long long seed, unsigned long long offset, float* x, int B, void* ws,
                                   size_t ws_bytes, int save_for_backward, int path, void* stream);
 
+/* Workspace of nsvd_model_forward / nsvd_model_backward alone (no stencil rows): smaller than
+ * nsvd_workspace_bytes, and defined for input dimensions up to 64 (the operator entry points stop at D = 4). */
+size_t nsvd_model_workspace_bytes(const nsvd_model_desc* desc, int B);
+
 /* Parameter gradients of sum(dout * model(x)) for the matching nsvd_model_forward(save_for_backward=1). */
 int nsvd_model_backward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
                         const float* dout, const nsvd_params* grads, void* ws, size_t ws_bytes, void* stream);
@@ -244,6 +248,20 @@ int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, si
 int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, int B, int L, int D,
                              float sigma, int use_importance, float lim, float* cov, float* quad,
                              void* stream);
+
+/* ---- next row: dense kernel operator on a minibatch (kernel-operator configuration) ---------------------------
+ * Kf[i][l] = scale * sum_k K[rows[i]][cols[k]] f[k][l]: the (Kf, f) producer that
+ * NestedLoRA.compute_loss_kernel's `get_approx_kernel_op(x)(model, x, importance)` contract consumes
+ * (methods/nestedlora.py:230-252; split_batch: rows = x1, cols = x2, f = model(x2), scale = 1 / B2). The reference
+ * ships no kernel operator; the definition is this build's (K = A A^T / r + 1e-3 I on N points,
+ * minibatch of indices drawn with replacement), restated in float64 by oracle/nsvd_oracle.py:kernel_apply.
+ * K: (N, ldk) row-major float32, ldk >= N rounded up to 64 (rows are read in whole 64-float chunks; the padding
+ * may hold anything finite), 16-byte aligned; rows (B1), cols (B2): int64 point indices; f: (B2, L); out: (B1, L).
+ * Indices outside [0, N) contribute / produce zeros. */
+size_t nsvd_kernel_apply_workspace_bytes(int N, int B1, int L);
+int nsvd_kernel_apply(const float* K, size_t ldk, int N, const long long* rows, int B1, const long long* cols,
+                      int B2, const float* f, int L, float scale, float* out, void* ws, size_t ws_bytes,
+                      void* stream);
 
 /* ---- next row: the CDK (two-tower) NestedLoRA loss ------------------------------------------------------
  * NestedLoRALossFunctionForCDK (methods/nestedlora.py:273-332) as called by NestedLoRAForCDK.compute_loss

@@ -75,6 +75,9 @@ SIGNATURES = {
     "nsvd_evd_loss_fused": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "nsvd_rmsprop_ema_step": (_I, [_P, _P, _P, _P, _Z, _Dbl, _Dbl, _Dbl, _Dbl, _Dbl, _P]),
     "nsvd_profile_next_forward": (_I, [_P, _P]),
+    "nsvd_model_workspace_bytes": (_Z, [C.POINTER(ModelDesc), _I]),
+    "nsvd_kernel_apply_workspace_bytes": (_Z, [_I, _I, _I]),
+    "nsvd_kernel_apply": (_I, [_P, _Z, _I, _P, _I, _P, _I, _P, _I, _F, _P, _P, _Z, _P]),
     "nsvd_cdk_workspace_bytes": (_Z, [_I, _I, _I]),
     "nsvd_cdk_loss_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "nsvd_cdk_loss_backward": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),

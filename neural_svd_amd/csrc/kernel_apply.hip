@@ -1,0 +1,136 @@
+// Dense kernel operator applied to a minibatch (the "Gram path" of the kernel-operator configuration):
+//     Kf[i][l] = scale * sum_k K[rows_i][cols_k] f[k][l],        i < B1, k < B2, l < L
+// K: (N, ldk) row-major symmetric PSD matrix on N points; rows / cols: minibatch indices (with replacement).
+// The reference defines only the consumer (`get_approx_kernel_op(x)(model, x, importance) -> (Kf, f)`,
+// methods/nestedlora.py:230-252) and ships no kernel operator, so this is the build's own definition
+// (cfg4) - restated in float64 by oracle/nsvd_oracle.py:kernel_apply.
+// Form used: scatter the batch into the index space, S^T[l][j] = sum_{k: cols_k = j} f[k][l], then
+//     Kf = K[rows, :] S    -  a (B1 x N) . (N x L) contraction with GATHERED rows of K, both operands K-contiguous,
+// on the fp32-input MFMA through the shared tile routine (tile_nt.h), split over N so that the grid fills the chip,
+// partial tiles reduced in slice order (bit-reproducible when cols has no duplicates; duplicates are summed with
+// float atomics in the scatter).
+#include <string.h>
+#include "nsvd_kernels.h"
+#include "tile_nt.h"
+
+namespace {
+
+constexpr int T = NSVD_TNT_T, KC = NSVD_TNT_KC;
+
+struct KaWs {
+    float* ST;      // (Lp, Np) scattered batch, zero padded
+    float* part;    // (S, B1p, Lp) split-K partial tiles
+    int Np, Lp, B1p, S;
+    size_t bytes;
+};
+
+KaWs carve(void* base, int N, int B1, int L) {
+    KaWs w;
+    w.Np = nsvd_cdiv(N, KC) * KC;
+    w.Lp = nsvd_cdiv(L, T) * T;
+    w.B1p = nsvd_cdiv(B1, T) * T;
+    const int tiles = (w.B1p / T) * (w.Lp / T), chunks = w.Np / KC;
+    int S = 1;
+    while (tiles * S < 512 && chunks / (2 * S) >= 8) S *= 2;  // enough blocks for two per CU, >= 8 chunks per slice
+    w.S = S;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* r = (float*)(p + off); off += nsvd_align(n * sizeof(float)); return r; };
+    w.ST = take((size_t)w.Lp * w.Np);
+    w.part = take((size_t)S * w.B1p * w.Lp);
+    w.bytes = off;
+    return w;
+}
+
+__global__ void __launch_bounds__(256) ka_zero_kernel(float4* __restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256) ka_scatter_kernel(const float* __restrict__ f, const long long* __restrict__ cols,
+                                                         int B2, int L, int N, float* __restrict__ ST, int Np) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B2 * L) return;
+    const int k = i / L, l = i - k * L;
+    const long long j = cols[k];
+    if (j < 0 || j >= N) return;  // out-of-range indices contribute nothing
+    atomicAdd(ST + (size_t)l * Np + j, f[i]);
+}
+
+// tile (tb, tl) x slice: rows of K gathered by `rows`, contraction range [c0, c1) chunks of the point index
+__global__ void __launch_bounds__(256, 2) ka_gemm_kernel(const float* __restrict__ K, long ldk, int N,
+                                                         const long long* __restrict__ rows, int B1, KaWs w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tb = blockIdx.x, tl = blockIdx.y, slice = blockIdx.z;
+    const int chunks = w.Np / KC;
+    const int c0 = (int)((long)chunks * slice / w.S), c1 = (int)((long)chunks * (slice + 1) / w.S);
+    const int t = threadIdx.x, lr0 = t >> 4, lc = (t & 15) * 4;
+    const float* ap[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = tb * T + lr0 + 16 * i;
+        long long g = r < B1 ? rows[r] : 0;  // padding rows of the tile read row 0; their results are never used
+        if (g < 0 || g >= N) g = 0;
+        ap[i] = K + g * ldk + lc + (long)c0 * KC;
+    }
+    nsvd_f32x16 acc = {0};
+    float unused[4] = {0.f, 0.f, 0.f, 0.f};
+    nsvd_tile_nt_rows<false>(ap[0], ap[1], ap[2], ap[3], w.ST + ((size_t)tl * T + lr0) * w.Np + lc + (size_t)c0 * KC,
+                             w.Np, c1 - c0, lds, acc, unused);
+    const int lane = t & 63, wv = t >> 6;
+    float* out = w.part + (size_t)slice * w.B1p * w.Lp;
+    const int col = tl * T + (wv >> 1) * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tb * T + (wv & 1) * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+        out[(size_t)row * w.Lp + col] = acc[r];
+    }
+}
+
+__global__ void __launch_bounds__(256) ka_reduce_kernel(KaWs w, const long long* __restrict__ rows, int N, int B1, int L,
+                                                        float scale, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B1 * L) return;
+    const int b = i / L, l = i - b * L;
+    float s = 0.f;
+    for (int sl = 0; sl < w.S; ++sl) s += w.part[((size_t)sl * w.B1p + b) * w.Lp + l];
+    const long long g = rows[b];
+    out[i] = (g < 0 || g >= N) ? 0.f : scale * s;
+}
+
+size_t ka_lds_bytes() {
+    static const size_t bytes = [] {
+        const size_t b = NSVD_TNT_FLOATS * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)ka_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+        return b;
+    }();
+    return bytes;
+}
+
+}  // namespace
+
+extern "C" size_t nsvd_kernel_apply_workspace_bytes(int N, int B1, int L) {
+    if (N <= 0 || B1 <= 0 || L <= 0) return 0;
+    return carve(nullptr, N, B1, L).bytes;
+}
+
+extern "C" int nsvd_kernel_apply(const float* K, size_t ldk, int N, const long long* rows, int B1,
+                                 const long long* cols, int B2, const float* f, int L, float scale, float* out,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!K || !rows || !cols || !f || !out || !ws || N <= 0 || B1 <= 0 || B2 <= 0 || L <= 0) return NSVD_EINVAL;
+    const KaWs w = carve(ws, N, B1, L);
+    // the tile routine reads whole 64-float chunks of a row: the leading dimension must cover the padded width
+    if (ldk < (size_t)w.Np || (ldk & 3) != 0 || ((uintptr_t)K & 15) != 0) return NSVD_EINVAL;
+    if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = (size_t)w.Lp * w.Np / 4;
+    ka_zero_kernel<<<(unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256), 256, 0, s>>>((float4*)w.ST, n4);
+    NSVD_CHECK_LAUNCH();
+    ka_scatter_kernel<<<nsvd_cdiv(B2 * L, 256), 256, 0, s>>>(f, cols, B2, L, N, w.ST, w.Np);
+    NSVD_CHECK_LAUNCH();
+    ka_gemm_kernel<<<dim3(w.B1p / T, w.Lp / T, w.S), 256, ka_lds_bytes(), s>>>(K, (long)ldk, N, rows, B1, w);
+    NSVD_CHECK_LAUNCH();
+    ka_reduce_kernel<<<nsvd_cdiv(B1 * L, 256), 256, 0, s>>>(w, rows, N, B1, L, scale, out);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}

@@ -33,24 +33,29 @@ struct GenericWs {
     float* dsc;                       // (B, L)
     float* dz[2];                     // ping-pong (L, hmax, B)
     float* df;                        // (B, L) for nsvd_operator_backward_evd on the generic path
+    int R;                            // rows per (head, unit): erows * B, erows = stencil blocks laid out
     size_t bytes;
 };
 
-int validate(const nsvd_model_desc* d) {
+// plain model evaluation (nsvd_model_forward / _backward) has no stencil: any input dimension up to 64
+constexpr int MODEL_MAX_D = 64;
+int validate(const nsvd_model_desc* d, int max_d = 4) {
     if (!d) return NSVD_EINVAL;
     if (d->L <= 0 || d->D <= 0 || d->m <= 0) return NSVD_EINVAL;
     if (d->nlayers < 1 || d->nlayers > NSVD_MAX_LAYERS) return NSVD_EINVAL;
     for (int i = 0; i < d->nlayers; ++i)
         if (d->dims[i] <= 0) return NSVD_EINVAL;
     if (d->dims[d->nlayers - 1] != 1) return NSVD_EINVAL;
-    if (d->D > 4) return NSVD_EUNSUPPORTED;
+    if (d->D > max_d) return NSVD_EUNSUPPORTED;
     return 0;
 }
 
-GenericWs carve(const nsvd_model_desc& d, int B, void* base) {
+// erows: stencil blocks the layout holds (1 + 2D for the operator, 1 for plain model evaluation)
+GenericWs carve(const nsvd_model_desc& d, int B, void* base, int erows = 0) {
     GenericWs w;
     memset(&w, 0, sizeof(w));
-    const size_t E = 1 + 2 * (size_t)d.D, R = E * B, F = 2 * (size_t)d.m;
+    const size_t E = erows > 0 ? (size_t)erows : 1 + 2 * (size_t)d.D, R = E * B, F = 2 * (size_t)d.m;
+    w.R = (int)R;
     char* p = (char*)base;
     size_t off = 0;
     auto take = [&](size_t nfloats) {
@@ -90,7 +95,7 @@ int check_params(const nsvd_model_desc& d, const nsvd_params* p, bool need_fouri
 // Fourier map + every ParallelMLP layer for the first `nst` stencil blocks (nst = E: all rows, 1: centre only)
 int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float eps, int nst,
                 const GenericWs& w, hipStream_t s, bool features_ready = false) {
-    const int E = 1 + 2 * d.D, R = E * B, F = 2 * d.m;
+    const int R = w.R, F = 2 * d.m;
     int rc = 0;
     if (!features_ready) rc = nsvd_fourier_features(x, p.fourier_B, w.phiT, B, d.D, d.m, eps, nst, R, s);
     if (rc) return rc;
@@ -124,10 +129,10 @@ int generic_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_p
 }
 
 int generic_backward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, const float* df,
-                     const nsvd_params& g, void* ws, hipStream_t s) {
+                     const nsvd_params& g, void* ws, hipStream_t s, int erows = 0) {
     (void)x;
-    const GenericWs w = carve(d, B, ws);
-    const int E = 1 + 2 * d.D, R = E * B, F = 2 * d.m;
+    const GenericWs w = carve(d, B, ws, erows);
+    const int R = w.R, F = 2 * d.m;
     int cur = 0;
     int rc = nsvd_head_backward(df, w.jac, w.dsc, B, d.L, w.dz[cur], d.has_exp_mask ? g.scales : nullptr, s);
     if (rc) return rc;
@@ -171,6 +176,11 @@ extern "C" int nsvd_abi_version(void) { return NSVD_ABI_VERSION; }
 extern "C" const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int path) {
     if (validate(desc) != 0 || B <= 0) return "invalid";
     return want_fused(*desc, B, path) ? "fused_mfma" : "generic";
+}
+
+extern "C" size_t nsvd_model_workspace_bytes(const nsvd_model_desc* desc, int B) {
+    if (validate(desc, MODEL_MAX_D) != 0 || B <= 0) return 0;
+    return carve(*desc, B, nullptr, 1).bytes;
 }
 
 extern "C" size_t nsvd_workspace_bytes(const nsvd_model_desc* desc, int B) {
@@ -245,16 +255,16 @@ extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const 
 extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
                                   float hard_mul_const, float* out, void* ws, size_t ws_bytes, int save_for_backward,
                                   void* stream) {
-    // plain model evaluation always takes the generic kernels
-    int rc = validate(desc);
+    // plain model evaluation always takes the generic kernels, on a workspace laid out for the centre rows only
+    int rc = validate(desc, MODEL_MAX_D);
     if (rc) return rc;
     if (!x || !out || !ws || B <= 0) return NSVD_EINVAL;
     rc = check_params(*desc, params, true);
     if (rc) return rc;
-    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (ws_bytes < nsvd_model_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
-    const GenericWs w = carve(*desc, B, ws);
-    const int R = (1 + 2 * desc->D) * B;
+    const GenericWs w = carve(*desc, B, ws, 1);
+    const int R = w.R;
     rc = generic_mlp(*desc, *params, x, B, 0.f, 1, w, (hipStream_t)stream);
     if (rc) return rc;
     return nsvd_model_out(w.z[desc->nlayers - 1], R, x, desc->has_exp_mask ? params->scales : nullptr,
@@ -265,16 +275,16 @@ extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params
 extern "C" int nsvd_model_backward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
                                    const float* dout, const nsvd_params* grads, void* ws, size_t ws_bytes,
                                    void* stream) {
-    int rc = validate(desc);
+    int rc = validate(desc, MODEL_MAX_D);
     if (rc) return rc;
     if (!x || !dout || !ws || B <= 0) return NSVD_EINVAL;
     rc = check_params(*desc, params, true);
     if (rc) return rc;
     rc = check_params(*desc, grads, false);
     if (rc) return rc;
-    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (ws_bytes < nsvd_model_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
-    return generic_backward(*desc, *params, x, B, dout, *grads, ws, (hipStream_t)stream);
+    return generic_backward(*desc, *params, x, B, dout, *grads, ws, (hipStream_t)stream, 1);
 }
 
 extern "C" int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_params* params,

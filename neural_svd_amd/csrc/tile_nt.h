@@ -25,10 +25,10 @@ __device__ __forceinline__ float nsvd_tnt_sum4(float4 v) { return (v.x + v.y) + 
 // ROWSUM: also return, in rsum[i], this thread's share of the row sums of A over [k0, k1) (tile rows
 // (t >> 4) + 16 i, columns 4 (t & 15) .. +3 of every chunk): reduce over the 16 threads that share a row.
 #define NSVD_TNT_LOAD(S, ko)                                         \
-    sa##S##0 = *(const float4*)(ap + (ko));                          \
-    sa##S##1 = *(const float4*)(ap + 16 * lda + (ko));               \
-    sa##S##2 = *(const float4*)(ap + 32 * lda + (ko));               \
-    sa##S##3 = *(const float4*)(ap + 48 * lda + (ko));               \
+    sa##S##0 = *(const float4*)(ap0 + (ko));                         \
+    sa##S##1 = *(const float4*)(ap1 + (ko));                         \
+    sa##S##2 = *(const float4*)(ap2 + (ko));                         \
+    sa##S##3 = *(const float4*)(ap3 + (ko));                         \
     sb##S##0 = *(const float4*)(bp + (ko));                          \
     sb##S##1 = *(const float4*)(bp + 16 * ldb + (ko));               \
     sb##S##2 = *(const float4*)(bp + 32 * ldb + (ko));               \
@@ -88,17 +88,16 @@ __device__ __forceinline__ float nsvd_tnt_sum4(float4 v) { return (v.x + v.y) + 
     if (ROWSUM && (c) + 1 < nc) NSVD_TNT_SUM(SN)                                              \
     __syncthreads();
 
+// core: the four A rows this thread stages (tile rows (t >> 4) + 16 i) are given as pointers, already offset to
+// its 4 columns of the first chunk - the rows of A may therefore be GATHERED (kernel_apply.hip); bp likewise.
 template <bool ROWSUM>
-__device__ __forceinline__ void nsvd_tile_nt(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
-                                             long ldb, int k0, int k1, float* __restrict__ lds, nsvd_f32x16& acc,
-                                             float (&rsum)[4]) {
+__device__ __forceinline__ void nsvd_tile_nt_rows(const float* __restrict__ ap0, const float* __restrict__ ap1,
+                                                  const float* __restrict__ ap2, const float* __restrict__ ap3,
+                                                  const float* __restrict__ bp, long ldb, int nc,
+                                                  float* __restrict__ lds, nsvd_f32x16& acc, float (&rsum)[4]) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int ra = (wv & 1) * 32 + (lane & 31), rb = (wv >> 1) * 32 + (lane & 31), kq = (lane >> 5) * 4;
-    // global -> register staging: rows lr0 + 16 i, 16 floats per row-quarter
     const int lr0 = t >> 4, lc = (t & 15) * 4;
-    const float* ap = A + (long)lr0 * lda + lc + k0;
-    const float* bp = Bm + (long)lr0 * ldb + lc + k0;
-    const int nc = (k1 - k0) / NSVD_TNT_KC;
     // named registers + macros: hipcc demotes a conditionally rewritten float4 array to scratch
     float4 sa00, sa01, sa02, sa03, sb00, sb01, sb02, sb03;  // set 0: even chunks -> LDS buffer 0
     float4 sa10, sa11, sa12, sa13, sb10, sb11, sb12, sb13;  // set 1: odd chunks  -> LDS buffer 1
@@ -114,6 +113,17 @@ __device__ __forceinline__ void nsvd_tile_nt(const float* __restrict__ A, long l
         NSVD_TNT_STEP(1, 0, c + 1)
     }
     acc = (acc + acc1) + (acc2 + acc3);
+}
+
+template <bool ROWSUM>
+__device__ __forceinline__ void nsvd_tile_nt(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
+                                             long ldb, int k0, int k1, float* __restrict__ lds, nsvd_f32x16& acc,
+                                             float (&rsum)[4]) {
+    const int t = threadIdx.x;
+    const int lr0 = t >> 4, lc = (t & 15) * 4;  // staging: rows lr0 + 16 i, 16 floats per row-quarter
+    const float* ap = A + (long)lr0 * lda + lc + k0;
+    nsvd_tile_nt_rows<ROWSUM>(ap, ap + 16 * lda, ap + 32 * lda, ap + 48 * lda, Bm + (long)lr0 * ldb + lc + k0, ldb,
+                              (k1 - k0) / NSVD_TNT_KC, lds, acc, rsum);
 }
 #undef NSVD_TNT_LOAD
 #undef NSVD_TNT_PUT

@@ -327,6 +327,38 @@ def operator_backward_evd_step(shape: ModelShape, params: Params, prob: Problem,
     check(rc, "nsvd_operator_backward_evd_step")
 
 
+def model_workspace(shape: ModelShape, B: int, device) -> torch.Tensor:
+    """workspace of model_forward / model_backward alone (no stencil rows; input dimension up to 64)."""
+    d = shape.desc()
+    n = _lib.load().nsvd_model_workspace_bytes(C.byref(d), int(B))
+    if n == 0:
+        raise NsvdError("nsvd_model_workspace_bytes: invalid model description")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def kernel_apply(K: torch.Tensor, N: int, rows: torch.Tensor, cols: torch.Tensor, f: torch.Tensor, scale: float,
+                 ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Kf = scale * K[rows][:, cols] @ f on the MFMA. K: (N_rows >= N, ldk) float32 with ldk >= N rounded up to 64;
+    rows (B1), cols (B2): int64; f: (B2, L). Returns (B1, L)."""
+    if K.dim() != 2 or not K.is_cuda or K.dtype != torch.float32 or K.stride(1) != 1:
+        raise NsvdError("kernel_apply: K must be a 2-D float32 GPU tensor with unit column stride")
+    for t, n in ((rows, "rows"), (cols, "cols")):
+        if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous() or t.dim() != 1:
+            raise NsvdError(f"kernel_apply: {n} must be a contiguous 1-D int64 GPU tensor")
+    B1, B2 = rows.numel(), cols.numel()
+    if f.dim() != 2 or f.shape[0] != B2:
+        raise NsvdError("kernel_apply: f must be (len(cols), L)")
+    L = f.shape[1]
+    lib = _lib.load()
+    if ws is None:
+        ws = torch.empty(lib.nsvd_kernel_apply_workspace_bytes(int(N), B1, L), dtype=torch.uint8, device=f.device)
+    out = torch.empty((B1, L), dtype=torch.float32, device=f.device)
+    rc = lib.nsvd_kernel_apply(K.data_ptr(), K.stride(0), int(N), rows.data_ptr(), B1, cols.data_ptr(), B2,
+                               _ptr(f, "f"), L, float(scale), _ptr(out, "out"), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "nsvd_kernel_apply")
+    return out
+
+
 def cdk_workspace(B: int, L: int, set_first_mode_const: bool, device) -> torch.Tensor:
     n = _lib.load().nsvd_cdk_workspace_bytes(int(B), int(L), int(bool(set_first_mode_const)))
     return torch.empty(max(n, 256), dtype=torch.uint8, device=device)

@@ -82,7 +82,7 @@ class ParallelMLP(nn.Module):
         shape = self.model_shape(False)
         x = x.reshape(x.shape[0], -1).float().contiguous()
         p = H.pack_params(shape, [w.data for w in self.ws], [b.data for b in self.bs], self.feature_map._B.data, None)
-        return H.model_forward(shape, p, x, 1.0, H.new_workspace(shape, x.shape[0], x.device))
+        return H.model_forward(shape, p, x, 1.0, H.model_workspace(shape, x.shape[0], x.device))
 
 
 class ExponentialMask(nn.Module):
@@ -163,7 +163,7 @@ class _ModelFn(torch.autograd.Function):
     def forward(ctx, x, model, *params):
         shape = model.shape
         need_grad = any(ctx.needs_input_grad)
-        ws = H.new_workspace(shape, x.shape[0], x.device)
+        ws = H.model_workspace(shape, x.shape[0], x.device)
         out = H.model_forward(shape, model.packed_params(), x, float(model.hard_mul_const), ws,
                               save_for_backward=need_grad)
         ctx.model, ctx.ws = model, (ws if need_grad else None)

@@ -86,6 +86,16 @@ def evd_loss_backward(f, Tf, v, M, lam1, lam2, grad_output=1.0):
     return grad_output * g
 
 
+# ----------------------------------------------------------------------------- dense kernel operator
+def kernel_apply(K, rows, cols, f, scale=None):
+    """Kf = scale * K[rows][:, cols] @ f (default scale 1 / len(cols)). PARITY UNPINNED: the reference has no kernel
+    operator (only the consumer contract methods/nestedlora.py:230-252); this restates the build's own definition
+     in the dtype of its inputs."""
+    if scale is None:
+        scale = 1.0 / len(cols)
+    return scale * (K[rows][:, cols] @ f)
+
+
 # ----------------------------------------------------------------------------- CDK loss
 def off_diagonal(x):
     """reference methods/utils.py:16-22."""

@@ -1,0 +1,125 @@
+"""GPU tests of the dense kernel-operator row (nsvd_kernel_apply, neural_svd_amd/kernel_ops.py). The reference ships
+no kernel operator (parity unpinned, see oracle/nsvd_oracle.py:kernel_apply): the checks are against the float64
+restatement of the build's own definition, Kf = K[rows][:, cols] @ f / len(cols). Tolerance 3e-5 relative (L2):
+float32 MFMA contraction over up to 10 000 terms."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsvd_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu().numpy()
+    b = np.asarray(torch.as_tensor(b).double().cpu().numpy())
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.parametrize("N,B1,B2,L", [(300, 64, 64, 8), (1000, 193, 70, 33), (130, 5, 400, 1), (2048, 512, 512, 64)])
+def test_kernel_apply_matches_float64(N, B1, B2, L):
+    from neural_svd_amd import hip_ops as H
+    g = torch.Generator().manual_seed(N + B1)
+    A = torch.randn(N, 32, generator=g, dtype=torch.float64)
+    K = (A @ A.T / 32 + 1e-3 * torch.eye(N, dtype=torch.float64)).float().double()
+    rows = torch.randint(N, (B1,), generator=g)
+    cols = torch.randint(N, (B2,), generator=g)  # with replacement: duplicates are summed
+    f = torch.randn(B2, L, generator=g, dtype=torch.float64).float().double()
+    want = O.kernel_apply(K, rows, cols, f)
+    ld = (N + 63) // 64 * 64
+    Kd = torch.full((N, ld), 7.0, device=DEV)  # finite garbage in the padding must not matter
+    Kd[:, :N] = K.float().to(DEV)
+    got = H.kernel_apply(Kd, N, rows.to(DEV), cols.to(DEV), f.float().to(DEV), 1.0 / B2)
+    assert rel(got, want) < 3e-5
+    # out-of-range indices: zero rows / no contribution
+    rows2 = rows.clone()
+    rows2[0] = -1
+    cols2 = cols.clone()
+    cols2[0] = N + 5
+    got2 = H.kernel_apply(Kd, N, rows2.to(DEV), cols2.to(DEV), f.float().to(DEV), 1.0 / B2)
+    f2 = f.clone()
+    f2[0] = 0
+    want2 = O.kernel_apply(K, rows, cols, f2)
+    want2[0] = 0
+    assert rel(got2, want2) < 3e-5
+
+
+def test_kernel_apply_full_size_sampled_rows():
+    """cfg4 size (N = 10 000, B = 8192, L = 64): 96 randomly chosen output rows against float64 on the CPU."""
+    from neural_svd_amd.kernel_ops import synthetic_psd_kernel
+    from neural_svd_amd import hip_ops as H
+    op = synthetic_psd_kernel(10000, 256, 16, 0, DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    idx = op.sample_indices(8192, g)
+    f = torch.randn(8192, 64, device=DEV, generator=g)
+    got = H.kernel_apply(op.K, op.N, idx, idx, f, 1.0 / 8192)
+    torch.cuda.synchronize()
+    pick = torch.randperm(8192, generator=torch.Generator().manual_seed(1))[:96]
+    K64 = op.K[:, :op.N].double().cpu()
+    ic = idx.cpu()
+    want = O.kernel_apply(K64, ic[pick], ic, f.double().cpu())
+    assert rel(got[pick.to(DEV)], want) < 3e-5
+    # K symmetric PSD => the batch quadratic form is non-negative
+    assert float((f * got).sum()) > 0
+
+
+def test_compute_loss_kernel_with_dense_operator():
+    """NestedLoRA.compute_loss_kernel (both split_batch modes) on a DenseKernelOperator with a 16-dimensional input
+    model (plain model evaluation takes any input dimension): loss and parameter gradients vs the float64 oracle."""
+    from types import SimpleNamespace as NS
+    from neural_svd_amd.kernel_ops import synthetic_psd_kernel
+    from neural_svd_amd.models import get_wavefunctions
+    from neural_svd_amd.nested_lowrank import get_evd_method
+    N, D, L, B = 500, 16, 6, 96
+    op = synthetic_psd_kernel(N, 32, D, 5, DEV)
+    args = NS(ndim=D, n_particles=1, use_fourier_feature=True, fourier_mapping_size=12, fourier_scale=0.05,
+              fourier_deterministic=False, fourier_append_raw=False, mlp_hidden_dims="24,16", neigs=L, parallel=1,
+              nonlinearity="softplus", apply_exp_mask=0, exp_mask_init_scale=1.0, hard_mul_const=1.0, apply_boundary=0,
+              sort=0, loss=NS(neuralsvd=NS(step=1, sequential=False)))
+    torch.manual_seed(4)
+    net = get_wavefunctions(args).to(DEV)
+    method = get_evd_method(args, "neuralsvd", op.index_model(net)).to(DEV)
+    sd = {k: v.detach().double().cpu() for k, v in method.state_dict().items()}
+    nl = 3
+    pre = "model.net.base."
+    p64 = O.Params([sd[f"{pre}ws.{i}"] for i in range(nl)], [sd[f"{pre}bs.{i}"] for i in range(nl)],
+                   sd[f"{pre}feature_map._B"], None)
+    prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, use_importance=False)
+    idx = op.sample_indices(B, torch.Generator(device=DEV).manual_seed(9))
+    z = op.points.double().cpu()
+    K64 = op.K[:, :N].double().cpu()
+    ic = idx.cpu()
+    v, M = method.vector_mask.double(), method.matrix_mask.double()
+    names = [f"{pre}ws.{i}" for i in range(nl)] + [f"{pre}bs.{i}" for i in range(nl)]
+    got = dict(method.named_parameters())
+
+    # split_batch = False
+    loss, aux = method.compute_loss_kernel(op.get_approx_kernel_op, idx, None, split_batch=False)
+    loss.backward()
+    c = O.operator_forward(z[ic], p64, prob)
+    Kf = O.kernel_apply(K64, ic, ic, c.f)
+    l64, lam1, lam2, _, _ = O.evd_loss_forward(c.f, Kf, v, M)
+    gref = O.operator_backward(c, p64, prob, O.evd_loss_backward(c.f, Kf, v, M, lam1, lam2))
+    assert abs(float(loss.detach()) - float(l64)) < 1e-4 * abs(float(l64))
+    assert rel(aux["Tf"], Kf) < 1e-4
+    for n, gr in zip(names, gref):
+        assert rel(got[n].grad, gr) < 1e-4, n
+
+    # split_batch = True
+    method.zero_grad()
+    loss, aux = method.compute_loss_kernel(op.get_approx_kernel_op, idx, None, split_batch=True)
+    loss.backward()
+    B1 = (B + 1) // 2
+    c1 = O.operator_forward(z[ic[:B1]], p64, prob)
+    c2 = O.operator_forward(z[ic[B1:]], p64, prob)
+    Kf1 = O.kernel_apply(K64, ic[:B1], ic[B1:], c2.f)
+    lam1, lam2 = c1.f.T @ c1.f / B1, c2.f.T @ c2.f / (B - B1)
+    l64 = -2.0 * ((c1.f * Kf1) @ v).mean() + (M * lam1 * lam2).sum()
+    df1 = -(4.0 / B1) * Kf1 * v + (2.0 / B1) * c1.f @ (M * lam2)
+    df2 = (2.0 / (B - B1)) * c2.f @ (M * lam1)
+    gref = [a + b for a, b in zip(O.operator_backward(c1, p64, prob, df1), O.operator_backward(c2, p64, prob, df2))]
+    assert abs(float(loss.detach()) - float(l64)) < 1e-4 * abs(float(l64))
+    for n, gr in zip(names, gref):
+        assert rel(got[n].grad, gr) < 1e-4, n

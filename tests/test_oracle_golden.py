@@ -216,3 +216,17 @@ def test_cdk_loss(case, tag, dtype, tol):
         assert abs(float(got) - float(w)) <= tol * max(1.0, abs(float(w)))
     assert G.rel(rj, z[p + "rs_joint"]) <= tol and G.rel(ri, z[p + "rs_indep"]) <= tol
     assert G.rel(gf, z[p + "grad_f"]) <= tol and G.rel(gg, z[p + "grad_g"]) <= tol
+
+
+def test_kernel_apply_definition():
+    """oracle kernel_apply (parity unpinned: the reference has no kernel operator) against the literal double sum of
+    its definition Kf[i, l] = (1 / B2) sum_k K[rows_i, cols_k] f[k, l], duplicates included."""
+    g = torch.Generator().manual_seed(0)
+    K = torch.randn(7, 7, generator=g, dtype=torch.float64)
+    rows, cols = torch.tensor([3, 3, 0, 6]), torch.tensor([1, 5, 5, 2, 0])
+    f = torch.randn(5, 3, generator=g, dtype=torch.float64)
+    want = torch.zeros(4, 3, dtype=torch.float64)
+    for i in range(4):
+        for k in range(5):
+            want[i] += K[rows[i], cols[k]] * f[k] / 5
+    assert torch.allclose(O.kernel_apply(K, rows, cols, f), want, rtol=1e-13, atol=1e-15)
