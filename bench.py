@@ -187,6 +187,9 @@ def main():
         if kname.startswith("gemm_generic"):  # generic path: the bracketed launch is the layer-0 GEMM only
             flops_fwd = 2.0 * (1 + 2 * cfg["D"]) * cfg["B"] * cfg["L"] * (2 * cfg["m"]) * cfg["hidden"][0]
         ach = flops_fwd / (kavg * 1e-3) / 1e12
+        nh = len(cfg["hidden"])
+        alg_mb = 4.0 * (tr.P.n_trainable + cfg["B"] * 2 * cfg["m"] + nh * tr.shape.L * cfg["hidden"][0] * tr.B
+                        + 3 * tr.B * tr.shape.L) / 1e6
         traffic, traffic_src = None, "profiles/"
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same workload only
             tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
@@ -198,7 +201,8 @@ def main():
         roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                     traffic_note=f"HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from "
-                                 f"{traffic_src}; algorithmic bytes 52.5 MB",
+                                 f"{traffic_src}; algorithmic bytes {alg_mb:.1f} MB (parameters + centre features "
+                                 f"read once, saved activations + f, Tf, jac written once)",
                     kernel=kname, kernel_avg_us=round(kavg * 1e3, 2),
                     kernel_flops=flops_fwd,
                     step_flops=flops_step, step_tflops=round(flops_step / (ms_per_step * 1e-3) / 1e12, 3),
