@@ -1279,7 +1279,8 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         for (int HX = 1; HX <= 8; HX *= 2) {
             const int SX = 8 / HX;
             if (d.L % HX != 0 || nsb % SX != 0) continue;
-            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * E * F;
+            // (the feature slab is the centre rows only: the stencil rows are generated in the kernel)
+            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * F;
             if (bytes < best) {
                 best = bytes;
                 a.xcd_remap = HX;
