@@ -146,6 +146,46 @@ extern "C" int nsvd_fourier_features(const float* x, const float* fourier_B, flo
 }
 
 namespace {
+// centre features for any input dimension (runtime D): same tile shape and double-accurate projection as above
+__global__ void __launch_bounds__(FT) fourier_plain_kernel(const float* __restrict__ x, const float* __restrict__ fB,
+                                                           float* __restrict__ phi, float* __restrict__ phiTc, int B,
+                                                           int D, int m) {
+    __shared__ float ts[FJ][FB + 1];
+    __shared__ float tc[FJ][FB + 1];
+    const int tid = threadIdx.x;
+    const int jl = tid & (FJ - 1);
+    const int j = blockIdx.x * FJ + jl;
+    const int b0 = blockIdx.y * FB;
+    const int F = 2 * m;
+    const bool jok = j < m;
+    for (int bl = tid / FJ; bl < FB; bl += FT / FJ) {
+        const int b = b0 + bl;
+        if (b >= B) break;
+        double p = 0.0;
+        if (jok)
+            for (int d = 0; d < D; ++d) p = fma((double)x[(size_t)b * D + d], (double)fB[(size_t)d * m + j], p);
+        float s0, c0;
+        sincos_d2f(p, &s0, &c0);
+        if (jok) {
+            float* row = phi + (size_t)b * F;
+            row[j] = s0;
+            row[m + j] = c0;
+        }
+        ts[jl][bl] = s0;
+        tc[jl][bl] = c0;
+    }
+    if (!phiTc) return;
+    __syncthreads();
+    const int bl = tid & (FB - 1);
+    for (int jj = tid / FB; jj < FJ; jj += FT / FB) {
+        const int jg = blockIdx.x * FJ + jj;
+        if (jg < m && b0 + bl < B) {
+            phiTc[(size_t)jg * B + b0 + bl] = ts[jj][bl];
+            phiTc[(size_t)(m + jg) * B + b0 + bl] = tc[jj][bl];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) sample_kernel(NsvdSampler smp, float* __restrict__ x, int B, int D) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
@@ -154,6 +194,14 @@ __global__ void __launch_bounds__(256) sample_kernel(NsvdSampler smp, float* __r
     for (int d = 0; d < D; ++d) x[(size_t)b * D + d] = xr[d];
 }
 }  // namespace
+
+int nsvd_fourier_plain(const float* x, const float* fourier_B, float* phi, float* phiTc, int B, int D, int m,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(fourier_plain_kernel, dim3(nsvd_cdiv(m, FJ), nsvd_cdiv(B, FB)), dim3(FT), 0, s, x, fourier_B, phi,
+                       phiTc, B, D, m);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
 
 int nsvd_sample_launch(const NsvdSampler& smp, float* x, int B, int D, hipStream_t s) {
     if (D < 1 || D > 4) return NSVD_EUNSUPPORTED;

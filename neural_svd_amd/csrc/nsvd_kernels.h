@@ -12,6 +12,9 @@ void nsvd_prof_end(hipStream_t s);
 // sampler != null: the coordinates are drawn inside the kernel (N(0, sigma^2), counter-based) and stored to xout.
 int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, float* sctab, int B, int D,
                          int m, float eps, const NsvdSampler* sampler, float* xout, hipStream_t s);
+// centre features only, any input dimension D (plain model evaluation): phi (B, 2m), phiTc (2m, B) or null
+int nsvd_fourier_plain(const float* x, const float* fourier_B, float* phi, float* phiTc, int B, int D, int m,
+                       hipStream_t s);
 // stand-alone draw of the same values (generic path)
 int nsvd_sample_launch(const NsvdSampler& smp, float* x, int B, int D, hipStream_t s);
 
@@ -55,6 +58,11 @@ int nsvd_model_out(const float* base, int ldr, const float* x, const float* scal
 int nsvd_evd_reduce_partials(const void* scratch, int B, int L, float* moments, hipStream_t s);
 
 // ---- fused MFMA path (pmlp_fused.hip) -----------------------------------------------------------
+// plain model evaluation out = c * model(x) on the fused kernels (E = 1 instance; input dimension up to 64);
+// save != 0 keeps what nsvd_fused_backward needs (dout plays the role of df)
+bool nsvd_fused_model_supported(const nsvd_model_desc& d, int B);
+int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float c,
+                             float* out, void* ws, int save, hipStream_t s);
 bool nsvd_fused_supported(const nsvd_model_desc& d, int B);
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B);
 // Fourier features of x into the fused path's workspace (phi, and phiT_c when save != 0)

@@ -180,7 +180,9 @@ extern "C" const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int pa
 
 extern "C" size_t nsvd_model_workspace_bytes(const nsvd_model_desc* desc, int B) {
     if (validate(desc, MODEL_MAX_D) != 0 || B <= 0) return 0;
-    return carve(*desc, B, nullptr, 1).bytes;
+    const size_t gen = carve(*desc, B, nullptr, 1).bytes;
+    const size_t fus = nsvd_fused_model_supported(*desc, B) ? nsvd_fused_workspace_bytes(*desc, B) : 0;
+    return gen > fus ? gen : fus;
 }
 
 extern "C" size_t nsvd_workspace_bytes(const nsvd_model_desc* desc, int B) {
@@ -263,6 +265,9 @@ extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params
     if (rc) return rc;
     if (ws_bytes < nsvd_model_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    if (nsvd_fused_model_supported(*desc, B))  // 128-wide hidden layers: the E = 1 instance of the MFMA forward
+        return nsvd_fused_model_forward(*desc, *params, x, B, hard_mul_const, out, ws, save_for_backward,
+                                        (hipStream_t)stream);
     const GenericWs w = carve(*desc, B, ws, 1);
     const int R = w.R;
     rc = generic_mlp(*desc, *params, x, B, 0.f, 1, w, (hipStream_t)stream);
@@ -284,6 +289,11 @@ extern "C" int nsvd_model_backward(const nsvd_model_desc* desc, const nsvd_param
     if (rc) return rc;
     if (ws_bytes < nsvd_model_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    if (nsvd_fused_model_supported(*desc, B)) {
+        nsvd_problem unused;
+        memset(&unused, 0, sizeof(unused));
+        return nsvd_fused_backward(*desc, *params, unused, x, B, dout, *grads, ws, (hipStream_t)stream);
+    }
     return generic_backward(*desc, *params, x, B, dout, *grads, ws, (hipStream_t)stream, 1);
 }
 

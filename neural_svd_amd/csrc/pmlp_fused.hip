@@ -54,6 +54,8 @@ struct FwdArgs {
     float* jac;
     float* dsc;
     float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null: ACTIVATIONS softplus(z) of the centre rows
+    int plain;      // E = 1 instance only: out = hard_mul_const * base * mask (WaveFunctions.forward), no Hamiltonian;
+                    // f receives the output, jac / dsc its derivatives w.r.t. base / scales
     int xcd_remap;  // 0: plain mapping; else HX = number of head groups across the 8 XCDs (1, 2, 4 or 8)
     unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
@@ -414,6 +416,31 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // (the exp / sqrt heavy part, E x 32 threads wide instead of a 5-point loop on 32 threads)
     float* gs = outs;         // [NC]   g_e
     float* cen = red;         // [4][BS] centre: sqrt p, mask, |x|, base   (red is dead once read below)
+    if (E == 1 && a.plain) {
+        // model(x) = c * base * exp(-|x| / scales_l)   (reference pde/__init__.py:15-16), any input dimension
+        if (tid < BS) {
+            const int b = b0 + tid;
+            const float bv = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
+            const float c = a.prob.hard_mul_const;
+            float mk = 1.f, r = 0.f, s_l = 1.f;
+            if (a.scales) {
+                float r2 = 0.f;
+                for (int d = 0; d < a.D; ++d) {
+                    const float xv = a.x[(size_t)b * a.D + d];
+                    r2 = fmaf(xv, xv, r2);
+                }
+                r = sqrtf(r2);
+                s_l = a.scales[l];
+                mk = expf(-r / s_l);
+            }
+            const size_t idx = (size_t)b * a.L + l;
+            a.f[idx] = c * bv * mk;
+            if (a.jac) a.jac[idx] = c * mk;
+            if (a.dsc) a.dsc[idx] = a.scales ? c * bv * mk * r / (s_l * s_l) : 0.f;
+        }
+        NSVD_STAMP(14)
+        return;
+    }
     NsvdFdG og;
     float bve = 0.f;
     og.g = og.sp = og.mk = og.r = 0.f;
@@ -1295,6 +1322,58 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         case 5: return launch_fwd<5>(a, s);
     }
     return NSVD_EUNSUPPORTED;
+}
+
+// ---- plain model evaluation on the fused kernels (E = 1): out = c * model(x), any input dimension --------------
+bool nsvd_fused_model_supported(const nsvd_model_desc& d, int B) {
+    if (d.D < 1 || d.D > 64) return false;
+    if (d.nlayers < 2) return false;
+    for (int i = 0; i < d.nlayers - 1; ++i)
+        if (d.dims[i] != HID) return false;
+    if (B % BS != 0 || B > 65536) return false;
+    if (B / wgrad_slices(d, B) > 8192) return false;
+    if ((2 * d.m) % HID != 0) return false;
+    return true;
+}
+
+int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float c,
+                             float* out, void* ws, int save, hipStream_t s) {
+    const FusedWs w = carve_fused(d, B, ws);
+    const int F = 2 * d.m;
+    int rc = nsvd_fourier_plain(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, B, d.D, d.m, s);
+    if (rc) return rc;
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.phiT = w.phi;
+    a.m = d.m;
+    a.nlayers = d.nlayers;
+    for (int i = 0; i < d.nlayers; ++i) {
+        a.W[i] = p.W[i];
+        a.b[i] = p.b[i];
+        a.zsave[i] = (save && i < d.nlayers - 1) ? w.zsave[i] : nullptr;
+    }
+    a.x = x;
+    a.scales = d.has_exp_mask ? p.scales : nullptr;
+    a.prob.hard_mul_const = c;
+    a.plain = 1;
+    a.B = B; a.D = d.D; a.L = d.L; a.F = F;
+    a.f = out;
+    a.jac = save ? w.jac : nullptr;
+    a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
+    {
+        const int nsb = B / BS;
+        double best = 1e300;
+        for (int HX = 1; HX <= 8; HX *= 2) {
+            const int SX = 8 / HX;
+            if (d.L % HX != 0 || nsb % SX != 0) continue;
+            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * F;
+            if (bytes < best) {
+                best = bytes;
+                a.xcd_remap = HX;
+            }
+        }
+    }
+    return launch_fwd<1>(a, s);
 }
 
 static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, int B, const float* df,

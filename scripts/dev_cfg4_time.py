@@ -33,4 +33,4 @@ def step():
     opt.zero_grad(set_to_none=True)
     loss, _ = method.compute_loss_kernel(op.get_approx_kernel_op, op.sample_indices(B, g), None, split_batch=False)
     loss.backward(); opt.step()
-print(f"full step (model forward/backward on the generic kernels, torch RMSprop): {t(step, 10):.0f} us")
+print(f"full step (model forward/backward on the E = 1 MFMA kernels, torch RMSprop): {t(step, 10):.0f} us")

@@ -491,6 +491,46 @@ def test_model_forward(case):
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True)])
+def test_model_forward_backward_mfma(D, L, B, mask):
+    """Plain model evaluation with 128-wide hidden layers takes the E = 1 instance of the fused MFMA forward (any
+    input dimension up to 64) and the fused backward: c * model(x) and the parameter gradients of sum(dout * out)
+    against the float64 oracle."""
+    m, hidden, c = 64, (128, 128), 0.7
+    p = O.init_params(L, D, m, hidden, 0.05, exp_mask_init=6.0 if mask else None, seed=D)
+    p64 = p.to(torch.float64)
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, D, generator=g, dtype=torch.float64).float().double()
+    dout = torch.randn(B, L, generator=g, dtype=torch.float64).float().double()
+    phi = O.fourier_features(x, p64.fourier_B)
+    base = O.mlp_forward(phi, p64)
+    mk = O.boundary_mask(x, p64)
+    ref = c * (base if mk is None else base * mk)
+    # float64 gradients through autograd on the oracle's own forward
+    leaves = [t.clone().requires_grad_(True) for t in p64.trainable()]
+    nl = len(p64.ws)
+    q = O.Params(leaves[:nl], leaves[nl:2 * nl], p64.fourier_B, leaves[2 * nl] if mask else None)
+    outq = O.mlp_forward(phi, q)
+    mq = O.boundary_mask(x, q)
+    (c * (outq if mq is None else outq * mq) * dout).sum().backward()
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    gw = [torch.full_like(w, float("nan")) for w in ws_t]
+    gb = [torch.full_like(b, float("nan")) for b in bs_t]
+    gs = None if sc is None else torch.full_like(sc, float("nan"))
+    grads = H.pack_params(shape, gw, gb, None, gs)
+    ws = H.model_workspace(shape, B, DEV)
+    xd = x.float().to(DEV).contiguous()
+    out = H.model_forward(shape, params, xd, c, ws, save_for_backward=True)
+    H.model_backward(shape, params, xd, dout.float().to(DEV).contiguous(), grads, ws)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 1e-5
+    for i, (got, leaf) in enumerate(zip(gw + gb + ([gs] if gs is not None else []), leaves)):
+        assert torch.isfinite(got).all()
+        assert rel(got, leaf.grad) < 3e-5, (i, rel(got, leaf.grad))
+
+
 # ------------------------------------------------------------------------------ optimiser
 @pytest.mark.parametrize("n", [1, 3, 1000, 4099, 1 << 20])
 def test_rmsprop_ema(n):
