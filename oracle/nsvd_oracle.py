@@ -290,10 +290,82 @@ class OperatorCache:
     Tf: torch.Tensor
 
 
+def exact_jets(x, p: Params, prob: Problem):
+    """Value, gradient and Laplacian of g(x) = sqrt p(x) * c * model(x) * mask(x) in closed form: what the reference's
+    exact mode (laplacian_eps <= 0: VectorizedLaplacian.exact_laplacian, diff_ops.py:54-61, via double autograd
+    :64-111) differentiates. Forward-mode propagation of (value, D first derivatives, Laplacian):
+      features   phi = [sin t, cos t], t = x B:   d_d phi = [B_d cos t, -B_d sin t],  Lap phi = -|B_j|^2 phi
+      linear     all streams through W; the bias joins the value stream only
+      softplus   a = sp(z):  d a = s z',  Lap a = s Lap z + s (1 - s) sum_d (d_d z)^2,   s = sigmoid(z)
+      product    Lap(u v) = u Lap v + 2 grad u . grad v + v Lap u   with u = sqrt p * mask (radial, closed form).
+    returns g (B, L), lap_g (B, L) and the pieces the backward needs (phi, zs, base, mask, sp)."""
+    D = x.shape[1]
+    fB = p.fourier_B
+    t = x @ fB
+    sn, cs = torch.sin(t), torch.cos(t)
+    phi = torch.cat([sn, cs], 1)
+    dphi = [torch.cat([cs * fB[d], -sn * fB[d]], 1) for d in range(D)]
+    lphi = -torch.cat([(fB * fB).sum(0), (fB * fB).sum(0)]) * phi
+    n = len(p.ws)
+    zs = []
+    z = torch.einsum("lhd,bd->lhb", p.ws[0], phi) + p.bs[0]
+    dz = [torch.einsum("lhd,bd->lhb", p.ws[0], dphi[d]) for d in range(D)]
+    lz = torch.einsum("lhd,bd->lhb", p.ws[0], lphi)
+    for i in range(1, n):
+        zs.append(z)
+        s1 = softplus_grad(z)
+        s2 = torch.where(z > SOFTPLUS_THRESHOLD, torch.zeros_like(z), s1 * (1 - s1))
+        a = softplus(z)
+        la = s1 * lz + s2 * sum(d_ * d_ for d_ in dz)
+        da = [s1 * d_ for d_ in dz]
+        z = torch.einsum("lhp,lpb->lhb", p.ws[i], a) + p.bs[i]
+        dz = [torch.einsum("lhp,lpb->lhb", p.ws[i], d_) for d_ in da]
+        lz = torch.einsum("lhp,lpb->lhb", p.ws[i], la)
+    B = x.shape[0]
+    to_bl = lambda h: h.permute(2, 0, 1).reshape(B, -1)  # noqa: E731
+    base, dbase, lbase = to_bl(z), [to_bl(d_) for d_ in dz], to_bl(lz)
+    # u = c * sqrt p * mask and its derivatives
+    r = torch.linalg.norm(x, dim=-1).view(-1, 1)
+    if prob.use_importance:
+        sp = sqrt_importance(x, prob.sigma)
+        dsp = [-(x[:, d:d + 1] / (2 * prob.sigma ** 2)) * sp for d in range(D)]
+        lsp = (-D / (2 * prob.sigma ** 2) + (r * r) / (4 * prob.sigma ** 4)) * sp
+    else:
+        sp = torch.ones(B, 1, dtype=x.dtype)
+        dsp = [torch.zeros(B, 1, dtype=x.dtype) for _ in range(D)]
+        lsp = torch.zeros(B, 1, dtype=x.dtype)
+    mask = boundary_mask(x, p)
+    if mask is None:
+        mk = torch.ones(B, 1, dtype=x.dtype)
+        dmk = [torch.zeros(B, 1, dtype=x.dtype) for _ in range(D)]
+        lmk = torch.zeros(B, 1, dtype=x.dtype)
+    else:
+        sc = p.scales.view(1, -1)
+        mk = mask
+        dmk = [-(x[:, d:d + 1] / r) / sc * mk for d in range(D)]
+        lmk = (1.0 / sc ** 2 - (D - 1) / (r * sc)) * mk
+    c = prob.hard_mul_const
+    u = c * sp * mk
+    du = [c * (dsp[d] * mk + sp * dmk[d]) for d in range(D)]
+    lu = c * (lsp * mk + 2 * sum(dsp[d] * dmk[d] for d in range(D)) + sp * lmk)
+    g = u * base
+    lap_g = u * lbase + 2 * sum(du[d] * dbase[d] for d in range(D)) + base * lu
+    return g, lap_g, (phi, zs, base, mask, sp)
+
+
 def operator_forward(x, p: Params, prob: Problem) -> OperatorCache:
     """Tf, f = OperatorWrapper(NegativeHamiltonian)(method, x, importance)
-    reference: examples/__init__.py:7-9 -> schrodinger/__init__.py:16-22 -> diff_ops.py:9-52."""
+    reference: examples/__init__.py:7-9 -> schrodinger/__init__.py:16-22 -> diff_ops.py:9-52.
+    prob.eps <= 0 selects the exact Laplacian like the reference does (diff_ops.py:7)."""
     D = x.shape[1]
+    if prob.eps <= 0:
+        g, lap, (phi0, zs, base0, mask0, sp0) = exact_jets(x, p, prob)
+        spc0 = torch.clamp(sp0, min=SQRT_P_CLAMP) if prob.use_importance else sp0
+        lap = lap / spc0
+        fs = g / spc0
+        Tf = -(-prob.scale_kinetic * lap + potential(x, prob) * fs)
+        Tf = prob.op_scale * Tf + prob.op_shift * fs
+        return OperatorCache(x, phi0, zs, base0, mask0, sp0, spc0, fs, Tf)
     pts = stencil_points(x, prob.eps)
     gs = []
     cache0 = None

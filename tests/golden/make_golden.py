@@ -355,7 +355,22 @@ def main():
                  fourier_mapping_size=1024, fourier_scale=0.1, sampling_scale=16.0, batch_size=128,
                  operator_scale=100.0, operator_shift=0.0, sequential=1, seed=0)
     np.savez_compressed(os.path.join(HERE, "model_headline.npz"), **o)
-    for fn in ("masks", "evd_loss", "cdk_loss", "misc", "model_small", "model_headline"):
+    # exact-Laplacian mode (laplacian_eps = 0: VectorizedLaplacian.exact_laplacian, diff_ops.py:54-61,64-111) ----
+    o = {}
+    golden_model(o, "hyd_exact", nsteps=1, grid=False, store_params=True, sample_stride=13, laplacian_eps=0.0,
+                 potential_type="hydrogen", neigs=3, mlp_hidden_dims="128,128", fourier_mapping_size=64,
+                 fourier_scale=0.1, sampling_scale=16.0, batch_size=32, operator_scale=100.0, operator_shift=0.0,
+                 sequential=0, seed=7)
+    golden_model(o, "osc_exact", nsteps=1, grid=False, store_params=True, sample_stride=13, laplacian_eps=0.0,
+                 potential_type="harmonic_oscillator", neigs=2, mlp_hidden_dims="128,128,128",
+                 fourier_mapping_size=64, fourier_scale=1.0, sampling_scale=4.0, batch_size=32, operator_scale=1.0,
+                 operator_shift=16.0, apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=1, seed=8)
+    golden_model(o, "osc_exact_small", nsteps=1, grid=False, store_params=True, laplacian_eps=0.0,
+                 potential_type="harmonic_oscillator", neigs=3, mlp_hidden_dims="12,9", fourier_mapping_size=5,
+                 fourier_scale=1.0, sampling_scale=4.0, batch_size=7, operator_scale=1.0, operator_shift=16.0,
+                 apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=0, seed=9)
+    np.savez_compressed(os.path.join(HERE, "model_exact.npz"), **o)
+    for fn in ("masks", "evd_loss", "cdk_loss", "misc", "model_small", "model_headline", "model_exact"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

@@ -230,3 +230,47 @@ def test_kernel_apply_definition():
         for k in range(5):
             want[i] += K[rows[i], cols[k]] * f[k] / 5
     assert torch.allclose(O.kernel_apply(K, rows, cols, f), want, rtol=1e-13, atol=1e-15)
+
+
+# ------------------------------------------------------------------ exact-Laplacian mode (laplacian_eps = 0)
+@pytest.mark.parametrize("case", ["hyd_exact", "osc_exact", "osc_exact_small"])
+def test_exact_laplacian_mode(case):
+    """oracle closed-form jets (exact_jets) vs the reference's double-autograd exact mode (diff_ops.py:54-111):
+    f, Tf, loss and gradients of one step in float64."""
+    z = G.load("model_exact")
+    cfg = G.cfg_of(z, case)
+    assert cfg["laplacian_eps"] == 0.0
+    prob = G.problem_of(cfg)
+    p = G.params_from_golden(z, case).to(torch.float64)
+    v, M = G.masks_of(z, case)
+    x = torch.tensor(z[f"{case}_x"][0]).double()
+    out = O.loss_and_grads(x, p, prob, v.double(), M.double())
+    pre = f"{case}_f64_step0_"
+    assert G.rel(out["f"], z[pre + "f"]) < 1e-11
+    assert G.rel(out["Tf"], z[pre + "Tf"]) < 1e-9
+    assert abs(float(out["loss"]) - float(z[pre + "loss"])) < 1e-9 * abs(float(z[pre + "loss"]))
+    for n, g in zip(G.trainable_names(z, case), out["grads"]):
+        if pre + f"grad_{n}" in z.files:
+            assert G.rel(g, z[pre + f"grad_{n}"]) < 1e-8, n
+        else:
+            gs = g.reshape(-1).numpy()
+            assert abs(np.linalg.norm(gs) - float(z[pre + f"gradnorm_{n}"])) < 1e-8 * float(z[pre + f"gradnorm_{n}"])
+            assert G.rel(gs[::13], z[pre + f"gradsample_{n}"]) < 1e-8, n
+
+
+def test_exact_jets_against_autograd():
+    """the same closed form against torch.autograd on the oracle's own model (independent of the reference)."""
+    p = O.init_params(2, 3, 5, (7, 6), 0.7, exp_mask_init=3.0, seed=1).to(torch.float64)
+    prob = O.Problem(potential=O.POT_HARMONIC, eps=0.0, op_scale=1.0, op_shift=2.0, sigma=1.5, hard_mul_const=0.8)
+    x = torch.randn(4, 3, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    g, lap, _ = O.exact_jets(x, p, prob)
+
+    def gfun(xx):
+        base = O.mlp_forward(O.fourier_features(xx, p.fourier_B), p)
+        return O.sqrt_importance(xx, prob.sigma) * prob.hard_mul_const * base * O.boundary_mask(xx, p)
+
+    for b in range(4):
+        for l in range(2):
+            H = torch.autograd.functional.hessian(lambda xx: gfun(xx.view(1, -1))[0, l], x[b])
+            assert abs(float(torch.trace(H)) - float(lap[b, l])) < 1e-9 * max(1.0, abs(float(lap[b, l])))
+    assert torch.allclose(gfun(x), g, rtol=1e-12, atol=1e-14)
