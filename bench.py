@@ -48,7 +48,7 @@ def macs_per_sample_head(m, hidden):
 def algorithmic_flops(cfg, B):
     """2 B L (E M + M + (M - M1)) per step; forward kernel: 2 B L E M."""
     M, M1 = macs_per_sample_head(cfg["m"], cfg["hidden"])
-    E = 1 + 2 * cfg["D"]
+    E = 1 + 2 * cfg["D"] if cfg["eps"] > 0 else 2 + cfg["D"]  # stencil points, or the streams of the exact-Laplacian jet
     return 2.0 * B * cfg["L"] * (E * M + M + (M - M1)), 2.0 * B * cfg["L"] * E * M
 
 
@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--laplacian-eps", type=float, default=None,
+                    help="developer option: override the config's finite-difference eps (<= 0: exact Laplacian)")
     ap.add_argument("--config", default="cfg2", choices=sorted(ALT))
     ap.add_argument("--parallelism", default="auto", choices=["auto", "dp", "hp"],
                     help="N > 1: dp = samples sharded (moments + gradient all-reduce); hp = heads sharded (one "
@@ -134,6 +136,8 @@ def main():
     cfg = dict(ALT[args.config])
     if args.batch_size:
         cfg["B"] = args.batch_size
+    if args.laplacian_eps is not None:
+        cfg["eps"] = args.laplacian_eps
     osc = cfg["potential"] == "oscillator"
     shape = H.ModelShape(L=cfg["L"], D=cfg["D"], m=cfg["m"], hidden=cfg["hidden"], has_exp_mask=osc)
     prob = H.make_problem(H.POT_HARMONIC if osc else H.POT_HYDROGEN, 1.0, cfg["eps"], cfg["op_scale"], cfg["op_shift"],
@@ -226,7 +230,7 @@ def main():
         "final_loss": loss, "params_finite": finite,
         "roofline": roof,
     }
-    if args.config != "cfg2":
+    if args.config != "cfg2" or args.laplacian_eps is not None or args.batch_size:
         out["metric"] = f"training steps/sec, developer config {args.config} (not the headline workload)"
         out["config"]["workload"] = f"{args.config}: {cfg}"
     if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":

@@ -89,7 +89,8 @@ typedef struct nsvd_problem {
     int32_t potential;               /* NSVD_POT_*                                     */
     float charge_or_k;               /* Z (hydrogen) or k (oscillator)                 */
     float scale_kinetic;             /* problems.py:26 (1.0)                           */
-    float eps;                       /* --laplacian_eps (> 0: central differences)     */
+    float eps;                       /* --laplacian_eps: > 0 central differences; <= 0 the exact Laplacian
+                                      * (diff_ops.py:7,54-61) by forward-mode jets, MFMA path only */
     float op_scale;                  /* --operator_scale                               */
     float op_shift;                  /* --operator_shift                               */
     float sigma;                     /* --sampling_scale of the Gaussian sampler       */

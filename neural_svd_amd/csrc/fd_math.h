@@ -80,3 +80,52 @@ __device__ __forceinline__ NsvdFdOut nsvd_fd_point(const float* bv, const float*
     }
     return nsvd_fd_combine(g, sp0, mask0, r0, bv[0], D, has_mask, s_l, prob);
 }
+
+// Exact-Laplacian mode (laplacian_eps <= 0: VectorizedLaplacian.exact_laplacian, diff_ops.py:54-61): the model's
+// value, gradient and Laplacian at x come from the forward-mode jet; here the product rule with the radial factor
+// u = c * sqrt p(x) * mask_l(x), whose derivatives are closed forms:
+//   sqrt p = C exp(-|x|^2 / (4 sigma^2)):  grad = -x / (2 sigma^2) sqrt p,  Lap = (-D / (2 sigma^2) + |x|^2 / (4 sigma^4)) sqrt p
+//   mask   = exp(-r / s):                  grad = -(x / r) / s mask,        Lap = (1 / s^2 - (D - 1) / (r s)) mask
+//   Lap(u v) = u Lap v + 2 grad u . grad v + v Lap u;  then lap / clamp(sqrt p), f = g / clamp(sqrt p), Tf as above.
+__device__ __forceinline__ NsvdFdOut nsvd_fd_exact(float base, const float* dbase, float lbase, const float* xc, int D,
+                                                   bool has_mask, float s_l, const nsvd_problem& prob, float log_norm) {
+    float r2 = 0.f;
+    for (int d = 0; d < D; ++d) r2 = fmaf(xc[d], xc[d], r2);
+    const float r0 = sqrtf(r2);
+    const float c = prob.hard_mul_const;
+    float sp = 1.f, lsp_f = 0.f, dsp_f = 0.f;  // sqrt p, Lap sqrt p / sqrt p, and grad sqrt p = dsp_f * x * sqrt p
+    if (prob.use_importance) {
+        sp = nsvd_sqrt_gauss_pdf(xc, D, prob.sigma, log_norm);
+        const float is2 = 1.f / (2.f * prob.sigma * prob.sigma);
+        dsp_f = -is2;
+        lsp_f = -(float)D * is2 + r2 * is2 * is2;
+    }
+    float mk = 1.f, lmk_f = 0.f, dmk_f = 0.f;  // mask, Lap mask / mask, grad mask = dmk_f * x * mask
+    if (has_mask) {
+        mk = expf(-r0 / s_l);
+        dmk_f = -1.f / (r0 * s_l);
+        lmk_f = 1.f / (s_l * s_l) - (float)(D - 1) / (r0 * s_l);
+    }
+    const float u = c * sp * mk;
+    // grad u = u (dsp_f + dmk_f) x;  Lap u = u (lsp_f + 2 dsp_f dmk_f |x|^2 + lmk_f)
+    const float gu = dsp_f + dmk_f;
+    float dot = 0.f;
+    for (int d = 0; d < D; ++d) dot = fmaf(xc[d], dbase[d], dot);
+    const float lu = lsp_f + 2.f * dsp_f * dmk_f * r2 + lmk_f;
+    const float g = u * base;
+    float lap = u * (lbase + 2.f * gu * dot + base * lu);
+    const float spc = prob.use_importance ? fmaxf(sp, NSVD_SQRT_P_CLAMP) : 1.f;
+    lap = lap / spc;
+    const float fs = g / spc;
+    float V;
+    if (prob.potential == NSVD_POT_HYDROGEN) V = -(prob.charge_or_k / r0);
+    else V = prob.charge_or_k * (r0 * r0);
+    const float H = -prob.scale_kinetic * lap + V * fs;
+    NsvdFdOut o;
+    o.f = fs;
+    o.Tf = prob.op_scale * (-H) + prob.op_shift * fs;
+    const float w = (sp / spc) * c;
+    o.jac = w * mk;
+    o.dsc = has_mask ? w * base * mk * r0 / (s_l * s_l) : 0.f;
+    return o;
+}

@@ -83,9 +83,23 @@ __global__ void __launch_bounds__(FT) fourier_stencil_kernel(const float* __rest
     for (int d = 0; d < D; ++d) {
         bj[d] = jok ? fB[(size_t)d * m + j] : 0.f;
         sincos_d2f((double)eps * (double)bj[d], &sd[d], &cd[d]);
-        if (jok && blockIdx.y == 0 && tid < FJ) {  // per-frequency stencil constants, written once
-            sctab[(size_t)(2 * d) * m + j] = cd[d];
-            sctab[(size_t)(2 * d + 1) * m + j] = sd[d];
+    }
+    if (jok && blockIdx.y == 0 && tid < FJ) {  // per-frequency constants of the forward kernel, written once
+        if (eps > 0.f) {  // stencil rows by angle addition: cos / sin of eps B_dj
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                sctab[(size_t)(2 * d) * m + j] = cd[d];
+                sctab[(size_t)(2 * d + 1) * m + j] = sd[d];
+            }
+        } else {          // exact-Laplacian jets: B_dj in the even slots, |B_j|^2 in slot 1
+            float q = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                q = fmaf(bj[d], bj[d], q);
+                sctab[(size_t)(2 * d) * m + j] = bj[d];
+                if (d > 0) sctab[(size_t)(2 * d + 1) * m + j] = 0.f;
+            }
+            sctab[(size_t)m + j] = q;
         }
     }
     for (int bl = tid / FJ; bl < FB; bl += FT / FJ) {

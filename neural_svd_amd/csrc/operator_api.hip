@@ -198,7 +198,6 @@ extern "C" int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_par
     int rc = validate(desc);
     if (rc) return rc;
     if (!prob || !x || !f || !Tf || !ws || B <= 0) return NSVD_EINVAL;
-    if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;  // exact-Laplacian mode is not on this path
     if (prob->potential != NSVD_POT_HYDROGEN && prob->potential != NSVD_POT_HARMONIC) return NSVD_EINVAL;
     rc = check_params(*desc, params, true);
     if (rc) return rc;
@@ -206,6 +205,8 @@ extern "C" int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_par
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     const bool fused = want_fused(*desc, B, path);
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    // eps <= 0 selects the exact Laplacian (reference diff_ops.py:7): forward-mode jets, MFMA path only
+    if (!(prob->eps > 0.f) && !fused) return NSVD_EUNSUPPORTED;
     const bool ready = (save_for_backward & NSVD_FEATURES_READY) != 0;
     if (fused)
         return nsvd_fused_forward(*desc, *params, *prob, x, B, f, Tf, ws, (save_for_backward & 1) | (ready ? 2 : 0),
@@ -224,6 +225,7 @@ extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_pa
     const bool fused = want_fused(*desc, B, path);
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
     if (fused) return nsvd_fused_features(*desc, *params, *prob, x, B, ws, save_for_backward & 1, (hipStream_t)stream);
+    if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;
     const GenericWs w = carve(*desc, B, ws);
     const int E = 1 + 2 * desc->D;
     return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
@@ -247,6 +249,7 @@ extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const 
     smp.on = 1;
     hipStream_t s = (hipStream_t)stream;
     if (fused) return nsvd_fused_features(*desc, *params, *prob, x, B, ws, save_for_backward & 1, s, &smp, x);
+    if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;
     rc = nsvd_sample_launch(smp, x, B, desc->D, s);
     if (rc) return rc;
     const GenericWs w = carve(*desc, B, ws);

@@ -106,7 +106,15 @@ __device__ __forceinline__ void nsvd_glds16(const float* gsrc, float* lds_base) 
 #define NSVD_STAMP(i)
 #endif
 
-template <int E>
+// JET = 0: the E columns of a sample are the 1 + 2D finite-difference stencil points (or the single centre point).
+// JET = 1: exact-Laplacian mode (laplacian_eps <= 0, reference diff_ops.py:54-61): the E = D + 2 columns carry a
+//   forward-mode jet - value, the D first derivatives and the Laplacian - of the same sample:
+//     features  d_d [sin t, cos t] = [B_dj cos t, -B_dj sin t],  Lap = -|B_j|^2 [sin t, cos t]    (while staging)
+//     linear    every stream through the same MFMAs; biases join the value stream only
+//     softplus  a = sp(z), d a = s d z, Lap a = s Lap z + s (1 - s) sum_d (d_d z)^2, s = sigmoid(z)  (per lane: the
+//               E accumulators of a lane are the E streams of one sample)
+//   One stream fewer than the stencil at D = 2 (4 instead of 5) and no finite-difference noise.
+template <int E, int JET>
 __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     constexpr int NC = E * BS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         for (int r = 0; r < 16; ++r) {
             const float bv = bi0[acc_row(r, hi)];
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e][r] = bv;
+            for (int e = 0; e < E; ++e) acc[e][r] = (JET && e > 0) ? 0.f : bv;
         }
     }
 
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     //   sin(t +- d) = sin t cos d +- cos t sin d,  cos(t +- d) = cos t cos d -+ sin t sin d,   d = eps B_dj,
     // with the same float32 expressions the feature kernel used to evaluate: phi(x +- eps e_d) is never stored.
     // (5x less feature traffic per tile; the feature kernel writes B x F instead of E x B x F.)
-    constexpr int DD = (E - 1) / 2;
+    constexpr int DD = JET ? E - 2 : (E - 1) / 2;  // input dimensions
     float4 ra0, ra1, ra2, ra3, rs, rc, cd0, sd0, cd1, sd1, cd2, sd2;
     ra0 = ra1 = ra2 = ra3 = rs = rc = cd0 = sd0 = cd1 = sd1 = cd2 = sd2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4 per slab
@@ -204,6 +212,9 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         minus = make_float4(fmaf(u.x, cd.x, -(v.x * sd.x)), fmaf(u.y, cd.y, -(v.y * sd.y)),        \
                             fmaf(u.z, cd.z, -(v.z * sd.z)), fmaf(u.w, cd.w, -(v.w * sd.w)));       \
     }
+// jet rows of a chunk: value u, derivative streams w * b_d (w = the partner feature, sign folded in), Laplacian -q u
+#define NSVD_MUL4(o, u, k) o = make_float4(u.x * k.x, u.y * k.y, u.z * k.z, u.w * k.w)
+#define NSVD_NMUL4(o, u, k) o = make_float4(-(u.x * k.x), -(u.y * k.y), -(u.z * k.z), -(u.w * k.w))
 #define NSVD_STORE_CHUNK(buf, HALF)                                              \
     {                                                                            \
         float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;          \
@@ -213,7 +224,23 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         NSVD_STS(Ab_ + 64 * A_LD, ra2);                                          \
         NSVD_STS(Ab_ + 96 * A_LD, ra3);                                          \
         float4 gp_, gm_;                                                         \
-        if (!(HALF)) {  /* sin rows: x + eps e_d -> s cd + c sd, x - eps e_d -> s cd - c sd */ \
+        if (JET) {      /* table: cd_d = B_dj, sd0 = |B_j|^2 */                  \
+            if (!(HALF)) {  /* sin: d_d = B_d cos, Lap = -|B|^2 sin */           \
+                NSVD_STS(Bb_, rs);                                               \
+                if (DD > 0) { NSVD_MUL4(gp_, rc, cd0); NSVD_STS(Bb_ + 32 * A_LD, gp_); }   \
+                if (DD > 1) { NSVD_MUL4(gp_, rc, cd1); NSVD_STS(Bb_ + 64 * A_LD, gp_); }   \
+                if (DD > 2) { NSVD_MUL4(gp_, rc, cd2); NSVD_STS(Bb_ + 96 * A_LD, gp_); }   \
+                NSVD_NMUL4(gm_, rs, sd0);                                        \
+                NSVD_STS(Bb_ + (DD + 1) * 32 * A_LD, gm_);                       \
+            } else {        /* cos: d_d = -B_d sin, Lap = -|B|^2 cos */          \
+                NSVD_STS(Bb_, rc);                                               \
+                if (DD > 0) { NSVD_NMUL4(gp_, rs, cd0); NSVD_STS(Bb_ + 32 * A_LD, gp_); }  \
+                if (DD > 1) { NSVD_NMUL4(gp_, rs, cd1); NSVD_STS(Bb_ + 64 * A_LD, gp_); }  \
+                if (DD > 2) { NSVD_NMUL4(gp_, rs, cd2); NSVD_STS(Bb_ + 96 * A_LD, gp_); }  \
+                NSVD_NMUL4(gm_, rc, sd0);                                        \
+                NSVD_STS(Bb_ + (DD + 1) * 32 * A_LD, gm_);                       \
+            }                                                                    \
+        } else if (!(HALF)) {  /* sin rows: x + eps e_d -> s cd + c sd, x - eps e_d -> s cd - c sd */ \
             NSVD_STS(Bb_, rs);                                                   \
             if (DD > 0) { NSVD_PM(gp_, gm_, rs, rc, cd0, sd0) NSVD_STS(Bb_ + 32 * A_LD, gp_); NSVD_STS(Bb_ + 64 * A_LD, gm_); }   \
             if (DD > 1) { NSVD_PM(gp_, gm_, rs, rc, cd1, sd1) NSVD_STS(Bb_ + 96 * A_LD, gp_); NSVD_STS(Bb_ + 128 * A_LD, gm_); }  \
@@ -287,7 +314,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         if (DO_LOAD) NSVD_LOAD_CHUNK((c) + 2, (PAR));                                           \
         mma_frag<E>(acc, f1);                                                                   \
         if (DO_STORE) NSVD_INTERLEAVE(1 + E, 0x100);                                            \
-        if (DO_LOAD) NSVD_INTERLEAVE((PAR) ? 4 : 5 + E, 0x020);                                 \
+        if (DO_LOAD) NSVD_INTERLEAVE((PAR) ? 4 : 6 + 2 * DD, 0x020);                            \
         NSVD_FENCE();                                                                           \
     }
     {
@@ -303,6 +330,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #undef NSVD_LOAD_CHUNK
 #undef NSVD_STORE_CHUNK
 #undef NSVD_PM
+#undef NSVD_MUL4
+#undef NSVD_NMUL4
 #undef NSVD_LDG
 #undef NSVD_STS
 
@@ -339,16 +368,38 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         // softplus in registers; the centre rows' ACTIVATIONS are saved for the backward (its kernels then need
         // no softplus: sigmoid(z) = 1 - exp(-softplus(z)), and the weight gradients contract activations)
         float* zs = a.zsave[i] ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
+        if (JET) {
+            // forward-mode jet through the softplus, all streams of a (row, sample) in this lane's registers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = nsvd_softplus(acc[0][r]);
-        if (zs) {
+            for (int r = 0; r < 16; ++r) {
+                const float z0 = acc[0][r];
+                const float s1 = nsvd_sigmoid(z0);
+                const float s2 = z0 > NSVD_SOFTPLUS_THRESHOLD ? 0.f : s1 * (1.f - s1);
+                float q = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
+                for (int e = 1; e < E - 1; ++e) {
+                    q = fmaf(acc[e][r], acc[e][r], q);
+                    acc[e][r] *= s1;
+                }
+                acc[E - 1][r] = fmaf(s1, acc[E - 1][r], s2 * q);
+                acc[0][r] = nsvd_softplus(z0);
+            }
+            if (zs) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = nsvd_softplus(acc[0][r]);
+            if (zs) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int e = 1; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int e = 1; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
         NSVD_STAMP(3 + 4 * i)
         if (!has_next) {
             // ---------------------------------------------------------- last layer 128 -> 1 (weights in nb)
@@ -386,7 +437,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[e][r] = nb[r];
+            for (int r = 0; r < 16; ++r) acc[e][r] = (JET && e > 0) ? 0.f : nb[r];
         // K = 128 in 16 q-groups, fragments read one q-group ahead, one LDS read per MFMA gap
         const float* Ap = Wt + li * HID;        // + 4 * ((2q + hi) ^ (li & 15)): swizzled 16-B chunk
         const int sw = li & 15;
@@ -441,6 +492,30 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         NSVD_STAMP(14)
         return;
     }
+    if (JET) {
+        // streams of the 128 -> 1 layer (its bias joins the value stream), then the closed-form product rule
+        if (tid < NC)
+            gs[tid] = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + (tid < BS ? a.b[nh][l] : 0.f);
+        __syncthreads();
+        if (tid < BS) {
+            const int b = b0 + tid;
+            float xc[NSVD_FD_MAXD], db[NSVD_FD_MAXD];
+            for (int d = 0; d < a.D; ++d) {
+                xc[d] = a.x[(size_t)b * a.D + d];
+                db[d] = gs[(1 + d) * BS + tid];
+            }
+            const float s_l = a.scales ? a.scales[l] : 0.f;
+            const NsvdFdOut o = nsvd_fd_exact(gs[tid], db, gs[(E - 1) * BS + tid], xc, a.D, a.scales != nullptr, s_l,
+                                              a.prob, a.log_norm);
+            const size_t idx = (size_t)b * a.L + l;
+            a.f[idx] = o.f;
+            a.Tf[idx] = o.Tf;
+            if (a.jac) a.jac[idx] = o.jac;
+            if (a.dsc) a.dsc[idx] = o.dsc;
+        }
+        NSVD_STAMP(14)
+        return;
+    }
     NsvdFdG og;
     float bve = 0.f;
     og.g = og.sp = og.mk = og.r = 0.f;
@@ -489,19 +564,19 @@ size_t fwd_lds_bytes() {
     return ((STAGE > HSZ ? STAGE : HSZ) + HID * HID + 5 * NC) * sizeof(float);
 }
 
-template <int E>
+template <int E, int JET = 0>
 int launch_fwd(const FwdArgs& a, hipStream_t s) {
     const size_t lds = fwd_lds_bytes<E>();
     static bool attr_done = false;  // idempotent, racing threads set the same value
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)pmlp_fused_fwd_kernel<E>,
+        hipError_t e = hipFuncSetAttribute((const void*)pmlp_fused_fwd_kernel<E, JET>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
     const int grid = (a.B / BS) * a.L;
     nsvd_prof_begin(s);
-    hipLaunchKernelGGL(pmlp_fused_fwd_kernel<E>, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((pmlp_fused_fwd_kernel<E, JET>), dim3(grid), dim3(256), lds, s, a);
     nsvd_prof_end(s);
     NSVD_CHECK_LAUNCH();
     return 0;
@@ -1317,6 +1392,13 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
 #ifdef NSVD_FWD_STAMPS
     a.stamps = (unsigned long long*)w.dz[0];  // diagnostic build: stamps land in the (then unused) dz_0 scratch
 #endif
+    if (prob.eps <= 0.f) {  // exact Laplacian: D + 2 jet streams
+        switch (d.D) {
+            case 1: return launch_fwd<3, 1>(a, s);
+            case 2: return launch_fwd<4, 1>(a, s);
+        }
+        return NSVD_EUNSUPPORTED;
+    }
     switch (E) {
         case 3: return launch_fwd<3>(a, s);
         case 5: return launch_fwd<5>(a, s);

@@ -50,8 +50,7 @@ class NegativeHamiltonian:
         self.scale_kinetic = scale_kinetic
         self.laplacian_eps = laplacian_eps
         self.n_particles = n_particles
-        if not laplacian_eps > 0:
-            raise NotImplementedError("exact (autograd) Laplacian, eps <= 0: not on the HIP path")
+        # laplacian_eps <= 0: exact Laplacian (reference diff_ops.py:7,54-61) - forward-mode jets on the MFMA path
 
     def __call__(self, f, xs, importance=None, threshold=1e5):
         return OperatorWrapper(self)(f, xs, importance)

@@ -491,6 +491,36 @@ def test_model_forward(case):
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("case", ["hyd_exact", "osc_exact"])
+def test_exact_laplacian_mode(case):
+    """laplacian_eps = 0: forward-mode jets in the fused kernel against the reference's double-autograd exact mode
+    (goldens model_exact.npz). No finite differences, so Tf is held to the tolerance of f: 2e-5 relative (the
+    float32 reference itself is 1e-6 .. 1e-5 from its float64 values here); loss and gradients follow."""
+    z = G.load("model_exact")
+    cfg = G.cfg_of(z, case)
+    prob = G.problem_of(cfg)
+    assert prob.eps == 0.0
+    p = G.params_from_golden(z, case)
+    v, M = G.masks_of(z, case)
+    x = torch.tensor(z[f"{case}_x"][0])
+    r = run_hip(p, prob, x, v, M, H.PATH_AUTO)
+    assert r["path"] == "fused_mfma"
+    pre = f"{case}_f64_step0_"
+    assert rel(r["f"], z[pre + "f"]) < 2e-5
+    ref32 = rel(z[f"{case}_f32_step0_Tf"], z[pre + "Tf"])
+    assert rel(r["Tf"], z[pre + "Tf"]) < max(2e-5, 3 * ref32), (rel(r["Tf"], z[pre + "Tf"]), ref32)
+    assert abs(float(r["loss"][0]) - float(z[pre + "loss"])) < 1e-4 * abs(float(z[pre + "loss"]))
+    for n, g in zip(G.trainable_names(z, case), r["grads"]):
+        gs = g.reshape(-1).double().cpu().numpy()
+        assert abs(np.linalg.norm(gs) - float(z[pre + f"gradnorm_{n}"])) < 1e-4 * float(z[pre + f"gradnorm_{n}"]), n
+        assert G.rel(gs[::13], z[pre + f"gradsample_{n}"]) < 1e-4, n
+    # shapes the MFMA path does not take have no exact mode
+    zs = "osc_exact_small"
+    ps = G.params_from_golden(z, zs)
+    with pytest.raises(Exception):
+        run_hip(ps, G.problem_of(G.cfg_of(z, zs)), torch.tensor(z[f"{zs}_x"][0]), *G.masks_of(z, zs), H.PATH_AUTO)
+
+
 @pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True)])
 def test_model_forward_backward_mfma(D, L, B, mask):
     """Plain model evaluation with 128-wide hidden layers takes the E = 1 instance of the fused MFMA forward (any
