@@ -151,6 +151,27 @@ def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.
     B = x.shape[0]
     if x.dim() != 2 or x.shape[1] != shape.D:
         raise NsvdError(f"x must be (B, {shape.D})")
+    if not prob.eps > 0 and (B % 32 != 0 or B > 8192) and not save_for_backward and not features_ready and B > 0:
+        # exact-Laplacian mode exists on the MFMA path only (batches of a multiple of 32 rows, at most 8192 of them
+        # without a backward layout): evaluation batches of any size go through in pieces of <= 8192 rows, the
+        # last one padded with copies of its last row, and the padding is dropped again
+        fs, Tfs = [], []
+        for i in range(0, B, 8192):
+            xc = x[i:i + 8192]
+            n = xc.shape[0]
+            npad = (n + 31) // 32 * 32
+            if npad != n:
+                xc = torch.cat([xc, xc[-1:].expand(npad - n, -1)])
+            fp, Tfp = operator_forward(shape, params, prob, xc.contiguous(), new_workspace(shape, npad, x.device),
+                                       False, path)
+            fs.append(fp[:n])
+            Tfs.append(Tfp[:n])
+        fa, Tfa = torch.cat(fs), torch.cat(Tfs)
+        if out is not None:
+            out[0].copy_(fa)
+            out[1].copy_(Tfa)
+            return out
+        return fa, Tfa
     if out is None:
         f = torch.empty((B, shape.L), dtype=torch.float32, device=x.device)
         Tf = torch.empty_like(f)

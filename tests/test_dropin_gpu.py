@@ -211,6 +211,27 @@ def test_fused_trainer_learns_oscillator():
     assert np.isfinite(err).all() and err.mean() < 2e-2, (out["eigvals"], err)
 
 
+@pytest.mark.parametrize("eps", [0.01, 0.0])
+def test_fused_trainer_learns_oscillator_mfma_path(eps):
+    """the same convergence smoke on the MFMA path (128-wide hidden layers), with the finite-difference stencil
+    (eps = 0.01) and with the exact-Laplacian jets (eps = 0): optimiser step inside the weight-gradient kernel,
+    batches drawn inside the feature kernel."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    shape = H.ModelShape(L=6, D=2, m=64, hidden=(128, 128), has_exp_mask=True)
+    prob = H.make_problem(H.POT_HARMONIC, 1.0, eps, 1.0, 16.0, 4.0)
+    steps = 4000
+    tr = FusedTrainer(shape, prob, 256, sequential=True, lr=1e-3, num_iters=steps, sampling_scale=4.0,
+                      fourier_scale=0.15, exp_mask_init=10.0, seed=0, device=DEV)
+    assert H.path_name(shape, 256) == "fused_mfma" and tr.fused_step and tr.device_sampler
+    for _ in range(steps):
+        tr.step()
+    out = tr.spectrum(lim=5.0, val_eps=0.1)
+    gt = np.array([14.0, 12, 12, 10, 10, 10])
+    err = np.abs(out["eigvals"].numpy() - gt) / gt
+    assert np.isfinite(err).all() and err.mean() < 2e-2, (out["eigvals"], err)
+
+
 def test_model_autograd_and_compute_loss_kernel():
     """method(x) is differentiable (nsvd_model_forward/_backward), and compute_loss_kernel
     (methods/nestedlora.py:230-252, both split_batch modes) runs a user kernel operator built on it."""
