@@ -201,6 +201,9 @@ int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, int mask_kin
  *   - an INPUT when moments_reduced != 0 (e.g. after the data-parallel all-reduce of nsvd_evd_moments), or
  *   - an OUTPUT when moments_reduced == 0: the partial sums in `evd_scratch` (from nsvd_evd_partial on the
  *     same f, Tf) are reduced on the fly and the reduced vector is stored here.
+ *   - ignored (may be NULL) when moments_reduced == 0 and evd_scratch == NULL ("direct" form, MFMA path only):
+ *     every workgroup of the backward takes the 2 L moments of its own head from f itself, no moment kernel
+ *     runs at all, and neither `moments` nor `loss` is written (use nsvd_evd_loss_fused when the value is wanted).
  * loss[0..2] = {loss, operator term, metric term}. Gradients are overwritten as in nsvd_operator_backward.
  * Head-parallel sharding: f, Tf, v, M and the moments may cover L_total >= desc->L heads, of which this
  * model owns [l_offset, l_offset + desc->L) (f, Tf are then (B, L_total), gathered from all ranks); pass

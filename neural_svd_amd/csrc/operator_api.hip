@@ -326,8 +326,11 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
                       const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream) {
     int rc = validate(desc);
     if (rc) return rc;
-    if (!prob || !x || !f || !Tf || !moments || !ws || B <= 0) return NSVD_EINVAL;
-    if (!moments_reduced && !evd_scratch) return NSVD_EINVAL;
+    if (!prob || !x || !f || !Tf || !ws || B <= 0) return NSVD_EINVAL;
+    // direct mode (fused path): neither reduced moments nor partial sums - the backward kernel takes the moments it
+    // needs from f itself; `moments` and `loss` are then not written
+    const bool direct = !moments_reduced && !evd_scratch;
+    if (!direct && !moments) return NSVD_EINVAL;
     if (mask_kind < 0 || mask_kind > NSVD_MASK_JOINT) return NSVD_EINVAL;
     if (mask_kind == NSVD_MASK_CUSTOM && (!v || !M)) return NSVD_EINVAL;
     rc = check_params(*desc, params, true);
@@ -367,7 +370,9 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
         in.loss = loss;
         in.Lg = L_total;
         in.l_off = l_offset;
-        if (moments_reduced) {
+        if (direct) {
+            in.loss = nullptr;
+        } else if (moments_reduced) {
             in.moments = moments;
         } else {
             in.part = (const float*)evd_scratch;
@@ -377,6 +382,7 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
         return nsvd_fused_backward_evd(*desc, *params, B, in, grads, opt ? &st : nullptr, ws, s);
     }
     // generic path: finish the loss with the stand-alone kernels, then the layer-by-layer backward
+    if (direct) return NSVD_EINVAL;  // needs the partial moments (evd_scratch) or the reduced ones
     if (L_total != desc->L) return NSVD_EUNSUPPORTED;  // head-parallel sharding needs the fused kernels
     const GenericWs w = carve(*desc, B, ws);
     if (!moments_reduced) {

@@ -628,11 +628,36 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         float* col = DZ;  // [2][Lg] masked moment columns of (global) head lg (LDS scratch, free until the first exchange)
         const int Lg = a.evd.Lg, lg = a.evd.l_off + l;
         const int B1 = (a.B + 1) / 2, B2 = a.B - B1;
-        for (int t = tid; t < 2 * Lg; t += 256) {
-            const int h = t / Lg, lp = t - h * Lg;  // h = 0: lam_f1 column, 1: lam_f2 column
-            col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * nsvd_evd_lam(a.evd, h, lp * Lg + lg, a.B, Lg);
+        if (a.evd.moments || a.evd.part) {
+            for (int t = tid; t < 2 * Lg; t += 256) {
+                const int h = t / Lg, lp = t - h * Lg;  // h = 0: lam_f1 column, 1: lam_f2 column
+                col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * nsvd_evd_lam(a.evd, h, lp * Lg + lg, a.B, Lg);
+            }
+            if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, Lg, DZ + 2 * Lg);
+        } else {
+            // direct mode: no moment kernel ran - the 2 Lg moments of THIS head's column straight from f
+            // (8 threads per moment, fixed summation order; the loss scalars are not produced)
+            const int sub = tid & 7;
+            for (int t = tid >> 3; t < 2 * Lg; t += 32) {
+                const int h = t / Lg, lp = t - h * Lg;
+                const int r0 = h ? B1 : 0, nr = h ? B2 : B1;
+                const float* fp = a.evd.f + (size_t)r0 * Lg;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int bb = sub;
+                for (; bb + 24 < nr; bb += 32) {
+                    s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
+                    s1 = fmaf(fp[(size_t)(bb + 8) * Lg + lp], fp[(size_t)(bb + 8) * Lg + lg], s1);
+                    s2 = fmaf(fp[(size_t)(bb + 16) * Lg + lp], fp[(size_t)(bb + 16) * Lg + lg], s2);
+                    s3 = fmaf(fp[(size_t)(bb + 24) * Lg + lp], fp[(size_t)(bb + 24) * Lg + lg], s3);
+                }
+                for (; bb < nr; bb += 8) s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
+                float sum = (s0 + s1) + (s2 + s3);
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                if (sub == 0) col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * (sum / (float)nr);
+            }
         }
-        if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, Lg, DZ + 2 * Lg);
         __syncthreads();
         const bool first = b < B1;
         const float* cp = col + (first ? Lg : 0);  // the OTHER half's moments

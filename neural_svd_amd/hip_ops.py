@@ -302,7 +302,8 @@ def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: t
     f, Tf: (B, L_total) with L_total >= shape.L; this model owns heads [l_offset, l_offset + shape.L)."""
     B = x.shape[0]
     L_total = f.shape[1]
-    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or moments.numel() != 2 * L_total * L_total + 1:
+    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or \
+            (moments is not None and moments.numel() != 2 * L_total * L_total + 1):
         raise NsvdError("operator_backward_evd: f/Tf must be (B, L_total), moments 2*L_total^2+1")
     d = shape.desc()
     rc = _lib.load().nsvd_operator_backward_evd(
@@ -336,7 +337,8 @@ def operator_backward_evd_step(shape: ModelShape, params: Params, prob: Problem,
     """operator_backward_evd + RMSprop/EMA step inside the weight-gradient kernel; params are updated in place."""
     B = x.shape[0]
     L_total = f.shape[1]
-    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or moments.numel() != 2 * L_total * L_total + 1:
+    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or \
+            (moments is not None and moments.numel() != 2 * L_total * L_total + 1):
         raise NsvdError("operator_backward_evd_step: f/Tf must be (B, L_total), moments 2*L_total^2+1")
     d = shape.desc()
     rc = _lib.load().nsvd_operator_backward_evd_step(

@@ -166,8 +166,14 @@ class FusedTrainer:
             self.f_g, self.Tf_g = self.fTf_g[0], self.fTf_g[1]
         else:
             self.f_g, self.Tf_g = self.f, self.Tf
-        self.moments = torch.empty(2 * Lg * Lg + 1, dtype=torch.float32, device=self.device)
-        self.loss = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self._moments = torch.empty(2 * Lg * Lg + 1, dtype=torch.float32, device=self.device)
+        self._loss = torch.zeros(3, dtype=torch.float32, device=self.device)
+        # "direct" moments: with no exchange between forward and backward and a batch of <= 1024 rows, the backward
+        # kernel takes the 2 L moments each head needs from f itself and no moment kernel runs; the loss scalars
+        # (logging only) and the moment vector are then evaluated on demand (properties below)
+        self.direct_moments = (world == 1 or self.hp) and self.B <= 1024 and \
+            H.path_name(shape, self.B, path) == "fused_mfma"
+        self._loss_stale = False
         self.scratch = H.evd_scratch(self.B, Lg, self.device)
         self.x = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device)
         self.gen = torch.Generator(device=self.device)
@@ -214,25 +220,47 @@ class FusedTrainer:
             # the one exchange of the head-parallel step: everybody's (B, L/world) blocks of f and Tf
             self.comm.all_gather(self.gath, self.fTf_loc)
             self.fTf_g.view(2, self.B, world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
-            H.evd_partial(self.f_g, self.Tf_g, self.mask_kind, v, self.scratch)
-        elif world > 1:
-            H.evd_moments(self.f, self.Tf, self.mask_kind, v, self.moments, self.scratch)
-            self.comm.all_reduce_mean(self.moments)
+        moments, scratch, loss = self._moments, self.scratch, self._loss
+        if self.direct_moments:
+            moments = scratch = loss = None
+            self._loss_stale = True
+        elif world > 1 and not self.hp:
+            H.evd_moments(self.f, self.Tf, self.mask_kind, v, self._moments, self.scratch)
+            self.comm.all_reduce_mean(self._moments)
             reduced = True
         else:
-            H.evd_partial(self.f, self.Tf, self.mask_kind, v, self.scratch)
+            H.evd_partial(self.f_g, self.Tf_g, self.mask_kind, v, self.scratch)
         # loss + d loss / d f are evaluated inside the backward kernels from the moments
         if self.fused_step and take_step:
             lr, decay = self._advance_schedule()
             opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay)
             H.operator_backward_evd_step(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
-                                         self.mask_kind, v, M, self.moments, reduced, self.scratch, self.loss,
+                                         self.mask_kind, v, M, moments, reduced, scratch, loss,
                                          self._grads if self.keep_grads else None, opt, self.ws, 1.0, self.path,
                                          l_offset=self.l_off)
             return
         H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g, self.mask_kind, v, M,
-                                self.moments, reduced, self.scratch, self.loss, self._grads, self.ws, 1.0, self.path,
+                                moments, reduced, scratch, loss, self._grads, self.ws, 1.0, self.path,
                                 l_offset=self.l_off)
+
+    def _refresh_loss(self) -> None:
+        if self._loss_stale:  # direct-moment steps do not produce them: evaluate for the last batch now
+            cust = self.mask_kind == H.MASK_CUSTOM
+            H.evd_loss_fused(self.f_g, self.Tf_g, self.mask_kind, self.v_dev if cust else None,
+                             self.M_dev if cust else None, self._moments, self._loss, None, self.scratch)
+            self._loss_stale = False
+
+    @property
+    def loss(self) -> torch.Tensor:
+        """{loss, operator term, metric term} of the last step's batch."""
+        self._refresh_loss()
+        return self._loss
+
+    @property
+    def moments(self) -> torch.Tensor:
+        """(2 L^2 + 1) moment vector of the last step's batch."""
+        self._refresh_loss()
+        return self._moments
 
     def _advance_schedule(self):
         """(lr, ema decay) of the step being taken; advances the scheduler / torch_ema counters."""

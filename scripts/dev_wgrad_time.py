@@ -12,7 +12,7 @@ x = tr.sample()
 H.operator_forward(tr.shape, tr._params, tr.problem, x, tr.ws, True, tr.path, out=(tr.f, tr.Tf))
 H.evd_partial(tr.f, tr.Tf, tr.mask_kind, None, tr.scratch)
 def bwd():
-    H.operator_backward_evd(tr.shape, tr._params, tr.problem, x, tr.f, tr.Tf, tr.mask_kind, None, None, tr.moments, False, tr.scratch, tr.loss, tr._grads, tr.ws, 1.0, tr.path)
+    H.operator_backward_evd(tr.shape, tr._params, tr.problem, x, tr.f, tr.Tf, tr.mask_kind, None, None, tr._moments, False, tr.scratch, tr._loss, tr._grads, tr.ws, 1.0, tr.path)
 for _ in range(3): bwd()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -295,7 +295,9 @@ def test_backward_evd_matches_two_step(case, fn, path):
     xd = x.float().to(DEV).contiguous()
     B, L = xd.shape[0], shape.L
     vd, Md = v.float().to(DEV), M.float().to(DEV).contiguous()
-    for reduced in (False, True):
+    fused = H.path_name(shape, B, _path(path)) == "fused_mfma"
+    for mode in ("partial", "reduced", "direct"):
+        reduced = mode == "reduced"
         gw = [torch.full_like(w, float("nan")) for w in ws_t]
         gb = [torch.full_like(b, float("nan")) for b in bs_t]
         gs = None if sc is None else torch.full_like(sc, float("nan"))
@@ -305,18 +307,29 @@ def test_backward_evd_matches_two_step(case, fn, path):
         scratch = H.evd_scratch(B, L, DEV)
         mom = torch.full((2 * L * L + 1,), float("nan"), device=DEV)
         loss = torch.empty(3, device=DEV)
-        if reduced:
-            H.evd_moments(f, Tf, H.MASK_CUSTOM, vd, mom, scratch)
+        if mode == "direct":
+            # no moment kernel at all: the backward takes each head's moments from f (MFMA path only)
+            if not fused:
+                with pytest.raises(H.NsvdError):
+                    H.operator_backward_evd(shape, params, hp, xd, f, Tf, H.MASK_CUSTOM, vd, Md, None, False, None, None,
+                                            grads, ws, 1.0, _path(path))
+                continue
+            H.operator_backward_evd(shape, params, hp, xd, f, Tf, H.MASK_CUSTOM, vd, Md, None, False, None, None, grads,
+                                    ws, 1.0, _path(path))
         else:
-            H.evd_partial(f, Tf, H.MASK_CUSTOM, vd, scratch)
-        H.operator_backward_evd(shape, params, hp, xd, f, Tf, H.MASK_CUSTOM, vd, Md, mom, reduced, scratch, loss,
-                                grads, ws, 1.0, _path(path))
+            if reduced:
+                H.evd_moments(f, Tf, H.MASK_CUSTOM, vd, mom, scratch)
+            else:
+                H.evd_partial(f, Tf, H.MASK_CUSTOM, vd, scratch)
+            H.operator_backward_evd(shape, params, hp, xd, f, Tf, H.MASK_CUSTOM, vd, Md, mom, reduced, scratch, loss,
+                                    grads, ws, 1.0, _path(path))
         torch.cuda.synchronize()
-        assert rel(mom, two["mom"]) < 1e-6
-        assert abs(float(loss[0]) - float(two["loss"][0])) <= 1e-5 * abs(float(two["loss"][0]))
+        if mode != "direct":
+            assert rel(mom, two["mom"]) < 1e-6
+            assert abs(float(loss[0]) - float(two["loss"][0])) <= 1e-5 * abs(float(two["loss"][0]))
         for i, (g, g2) in enumerate(zip(gw + gb + ([gs] if gs is not None else []), two["grads"])):
             assert torch.isfinite(g).all()
-            assert rel(g, g2) < 2e-5, (i, reduced, rel(g, g2))
+            assert rel(g, g2) < 2e-5, (i, mode, rel(g, g2))
 
 
 @pytest.mark.parametrize("B,hidden", [(65536, (128,)), (4099, (16,))])
