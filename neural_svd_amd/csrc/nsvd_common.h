@@ -18,15 +18,17 @@
 static inline int nsvd_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t nsvd_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// softplus(z) = log(1 + e^z) with torch's threshold. Hardware exp2/log2 (v_exp_f32 / v_log_f32,
-// ~1 ulp) plus the u-1 correction that makes log1p accurate for small t: ~12 VALU instead of the
-// ~60 of ocml log1pf(expf()). max(z,0) + log1p(exp(-|z|)) never overflows.
+// softplus(z) = log(1 + e^z) with torch's threshold. Hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp) plus the
+// first-order log1p correction: with u = fl(1 + t), d = u - 1 (exact), ln(1 + t) = ln(u) + (t - d) / u + ..., and
+// since |t - d| <= 2^-24 a crude 1/u ~ 1 - t/2 is enough (it is exact, = t, in the limit u = 1). 2 transcendental
+// and ~10 VALU instructions instead of the ~60 of ocml log1pf(expf()); max(z,0) + log1p(exp(-|z|)) never
+// overflows. Max relative error 1.8e-6 at z = -29 (the float32 rounding of |z| log2 e), checked against float64.
 __device__ __forceinline__ float nsvd_softplus(float z) {
     const float t = __builtin_amdgcn_exp2f(-fabsf(z) * NSVD_LOG2E);  // e^{-|z|} in (0, 1]
     const float u = 1.0f + t;
     const float d = u - 1.0f;
-    float l = __builtin_amdgcn_logf(u) * NSVD_LN2;                   // ln(u)
-    l = (d == 0.0f) ? t : l * (t * __builtin_amdgcn_rcpf(d));        // ln(1+t) to ~1 ulp
+    const float corr = (t - d) * fmaf(-0.5f, t, 1.0f);
+    const float l = fmaf(__builtin_amdgcn_logf(u), NSVD_LN2, corr);  // ln(1 + t)
     const float r = fmaxf(z, 0.0f) + l;
     return z > NSVD_SOFTPLUS_THRESHOLD ? z : r;
 }
