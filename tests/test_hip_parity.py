@@ -534,6 +534,29 @@ def test_exact_laplacian_mode(case):
         run_hip(ps, G.problem_of(G.cfg_of(z, zs)), torch.tensor(z[f"{zs}_x"][0]), *G.masks_of(z, zs), H.PATH_AUTO)
 
 
+@pytest.mark.parametrize("eps", [0.01, 0.0])
+def test_fused_path_one_dimensional(eps):
+    """D = 1 on the MFMA path (E = 3 stencil instance, and the 3-stream jet instance for eps = 0) against the
+    float64 oracle: f to 2e-5; Tf to 1e-4 in exact mode, to the finite-difference noise level otherwise; gradients
+    given the oracle's d loss / d f to 3e-5."""
+    L, D, m, hidden, B = 3, 1, 64, (128, 128), 64
+    p = O.init_params(L, D, m, hidden, 0.3, exp_mask_init=5.0, seed=21)
+    prob = O.Problem(potential=O.POT_HARMONIC, eps=eps, op_scale=1.0, op_shift=4.0, sigma=2.0)
+    v, M = O.joint_nesting_masks(L, 1)
+    x = (2.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(4), dtype=torch.float64)).float().double()
+    ref = O.loss_and_grads(x, p.to(torch.float64), prob, v, M)
+    r = run_hip(p, prob, x, v, M, H.PATH_AUTO, df_override=ref["df"])
+    assert r["path"] == "fused_mfma"
+    assert rel(r["f"], ref["f"]) < 2e-5
+    if eps > 0:
+        k = tf_noise_kappa(r["Tf"], ref["Tf"].numpy(), ref["f"].numpy(), dict(operator_scale=1.0, laplacian_eps=eps))
+        assert k < 3 * KAPPA_REF_MEDIAN, k
+    else:
+        assert rel(r["Tf"], ref["Tf"]) < 1e-4
+    for i, (g, gr) in enumerate(zip(r["grads"], ref["grads"])):
+        assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, i
+
+
 @pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True)])
 def test_model_forward_backward_mfma(D, L, B, mask):
     """Plain model evaluation with 128-wide hidden layers takes the E = 1 instance of the fused MFMA forward (any
