@@ -63,7 +63,7 @@ int nsvd_evd_reduce_partials(const void* scratch, int B, int L, float* moments, 
 bool nsvd_fused_model_supported(const nsvd_model_desc& d, int B);
 int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float c,
                              float* out, void* ws, int save, hipStream_t s);
-bool nsvd_fused_supported(const nsvd_model_desc& d, int B);
+bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact = false);
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B);
 // Fourier features of x into the fused path's workspace (phi, and phiT_c when save != 0)
 int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,

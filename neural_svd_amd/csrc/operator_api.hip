@@ -78,9 +78,10 @@ GenericWs carve(const nsvd_model_desc& d, int B, void* base, int erows = 0) {
     return w;
 }
 
-bool want_fused(const nsvd_model_desc& d, int B, int path) {
+// exact: the exact-Laplacian mode (prob->eps <= 0), whose D + 2 jet streams fit the MFMA path up to D = 3
+bool want_fused(const nsvd_model_desc& d, int B, int path, bool exact = false) {
     if (path == NSVD_PATH_GENERIC) return false;
-    return nsvd_fused_supported(d, B);
+    return nsvd_fused_supported(d, B, exact);
 }
 
 int check_params(const nsvd_model_desc& d, const nsvd_params* p, bool need_fourier) {
@@ -188,7 +189,7 @@ extern "C" size_t nsvd_model_workspace_bytes(const nsvd_model_desc* desc, int B)
 extern "C" size_t nsvd_workspace_bytes(const nsvd_model_desc* desc, int B) {
     if (validate(desc) != 0 || B <= 0) return 0;
     const size_t gen = carve(*desc, B, nullptr).bytes;
-    const size_t fus = nsvd_fused_supported(*desc, B) ? nsvd_fused_workspace_bytes(*desc, B) : 0;
+    const size_t fus = nsvd_fused_supported(*desc, B, true) ? nsvd_fused_workspace_bytes(*desc, B) : 0;
     return gen > fus ? gen : fus;
 }
 
@@ -203,7 +204,7 @@ extern "C" int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_par
     if (rc) return rc;
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
-    const bool fused = want_fused(*desc, B, path);
+    const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
     // eps <= 0 selects the exact Laplacian (reference diff_ops.py:7): forward-mode jets, MFMA path only
     if (!(prob->eps > 0.f) && !fused) return NSVD_EUNSUPPORTED;
@@ -222,7 +223,7 @@ extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_pa
     if (!prob || !x || !ws || !params || !params->fourier_B || B <= 0) return NSVD_EINVAL;
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
-    const bool fused = want_fused(*desc, B, path);
+    const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
     if (fused) return nsvd_fused_features(*desc, *params, *prob, x, B, ws, save_for_backward & 1, (hipStream_t)stream);
     if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;
@@ -240,7 +241,7 @@ extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const 
     if (!prob || !x || !ws || !params || !params->fourier_B || B <= 0) return NSVD_EINVAL;
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
-    const bool fused = want_fused(*desc, B, path);
+    const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
     NsvdSampler smp;
     smp.seed = seed;
@@ -312,7 +313,7 @@ extern "C" int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_pa
     if (rc) return rc;
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
-    const bool fused = want_fused(*desc, B, path);
+    const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
     if (fused) return nsvd_fused_backward(*desc, *params, *prob, x, B, df, *grads, ws, (hipStream_t)stream);
     return generic_backward(*desc, *params, x, B, df, *grads, ws, (hipStream_t)stream);
@@ -355,7 +356,7 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = want_fused(*desc, B, path);
+    const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
     if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
     if (L_total <= 0) L_total = desc->L;
     if (l_offset < 0 || l_offset + desc->L > L_total || L_total > 128) return NSVD_EINVAL;

@@ -1347,8 +1347,10 @@ FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
 
 }  // namespace
 
-bool nsvd_fused_supported(const nsvd_model_desc& d, int B) {
-    if (d.D < 1 || d.D > 2) return false;  // E = 1 + 2D <= 5: the forward's LDS image (155 KB at E = 5)
+bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact) {
+    // E <= 5 columns per sample: the forward's LDS image (155 KB at E = 5). Stencil: E = 1 + 2D, so D <= 2; the
+    // exact-Laplacian jets have E = D + 2, so D <= 3.
+    if (d.D < 1 || d.D > (exact ? 3 : 2)) return false;
     if (d.nlayers < 2) return false;
     for (int i = 0; i < d.nlayers - 1; ++i)
         if (d.dims[i] != HID) return false;
@@ -1421,6 +1423,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         switch (d.D) {
             case 1: return launch_fwd<3, 1>(a, s);
             case 2: return launch_fwd<4, 1>(a, s);
+            case 3: return launch_fwd<5, 1>(a, s);
         }
         return NSVD_EUNSUPPORTED;
     }

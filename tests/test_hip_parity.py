@@ -557,6 +557,26 @@ def test_fused_path_one_dimensional(eps):
         assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, i
 
 
+def test_exact_mode_three_dimensional():
+    """D = 3 fits the MFMA path in exact mode only (5 jet streams; the stencil would need 7 columns per sample):
+    f, Tf and the gradients against the float64 oracle, hydrogen potential with the exponential mask."""
+    L, D, m, hidden, B = 2, 3, 64, (128, 128, 128), 64
+    p = O.init_params(L, D, m, hidden, 0.2, exp_mask_init=4.0, seed=33)
+    prob = O.Problem(potential=O.POT_HYDROGEN, eps=0.0, op_scale=10.0, op_shift=1.0, sigma=3.0, hard_mul_const=0.9)
+    v, M = O.sequential_nesting_masks(L)
+    x = (3.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(8), dtype=torch.float64)).float().double()
+    ref = O.loss_and_grads(x, p.to(torch.float64), prob, v, M)
+    r = run_hip(p, prob, x, v, M, H.PATH_AUTO, df_override=ref["df"])
+    assert rel(r["f"], ref["f"]) < 2e-5
+    assert rel(r["Tf"], ref["Tf"]) < 1e-4
+    for i, (g, gr) in enumerate(zip(r["grads"], ref["grads"])):
+        assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, i
+    # ... and the stencil mode of the same model still runs, on the generic kernels
+    prob_fd = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=10.0, op_shift=1.0, sigma=3.0, hard_mul_const=0.9)
+    r2 = run_hip(p, prob_fd, x, v, M, H.PATH_AUTO)
+    assert rel(r2["f"], ref["f"]) < 2e-5
+
+
 @pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True)])
 def test_model_forward_backward_mfma(D, L, B, mask):
     """Plain model evaluation with 128-wide hidden layers takes the E = 1 instance of the fused MFMA forward (any
