@@ -50,10 +50,12 @@ class Communicator:
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
-        """out: (world, *inp.shape) contiguous; out[r] = rank r's inp."""
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out: (world, *inp.shape) contiguous; out[r] = rank r's inp. async_op: returns the work handle (wait()
+        orders the current stream after the collective) so that independent kernels can be enqueued meanwhile."""
         # concatenated-along-dim-0 view: the one output shape both RCCL and gloo accept
-        dist.all_gather_into_tensor(out.view(-1, *inp.shape[1:]), inp.contiguous(), group=self.group)
+        return dist.all_gather_into_tensor(out.view(-1, *inp.shape[1:]), inp.contiguous(), group=self.group,
+                                           async_op=async_op)
 
     def barrier(self) -> None:
         dist.barrier(group=self.group)

@@ -106,7 +106,7 @@ class FusedTrainer:
                  fourier_scale: float = 0.1, exp_mask_init: Optional[float] = None, seed: Optional[int] = 0,
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
                  pipeline: bool = False, parallelism: str = "dp", fused_step: bool = True,
-                 keep_grads: bool = False, device_sampler: bool = True):
+                 keep_grads: bool = False, device_sampler: bool = True, overlap_gather: bool = True):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
         them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
@@ -114,7 +114,9 @@ class FusedTrainer:
         whenever no gradient exchange sits between backward and optimiser (single GPU, hp); keep_grads then
         also stores the gradients (P.grad), which the fused step otherwise never writes.
         device_sampler: draw the batch inside the feature kernel (nsvd_operator_sample_features, counter-based
-        Philox) instead of torch's generator + a separate feature launch."""
+        Philox) instead of torch's generator + a separate feature launch.
+        overlap_gather (hp): the next batch and its features (they depend on no weight) are produced into a second
+        workspace while the all-gather of f, Tf is in flight, instead of leaving the GPU idle for its latency."""
         self.device = torch.device(device)
         self.path = path
         self.comm = comm  # parallel.Communicator or None
@@ -157,6 +159,12 @@ class FusedTrainer:
         self.M_dev = self.matrix_mask.to(self.device).contiguous()
         L, Lg = shape.L, self.Lg
         self.ws = H.new_workspace(shape, self.B, self.device)
+        # head-parallel overlap: two (workspace, x) sets used alternately; set k holds the features of batch k
+        self.overlap_gather = bool(overlap_gather) and self.hp and bool(device_sampler)
+        self._ws_other = H.new_workspace(shape, self.B, self.device) if self.overlap_gather else None
+        self._x_other = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device) \
+            if self.overlap_gather else None
+        self._next_ready = False  # the other set already holds the next batch and its features
         # local (B, L_local) outputs of the forward, packed [f | Tf] so that one all-gather moves both
         self.fTf_loc = torch.empty((2, self.B, L), dtype=torch.float32, device=self.device)
         self.f, self.Tf = self.fTf_loc[0], self.fTf_loc[1]
@@ -218,7 +226,16 @@ class FusedTrainer:
         reduced = False
         if self.hp:
             # the one exchange of the head-parallel step: everybody's (B, L/world) blocks of f and Tf
-            self.comm.all_gather(self.gath, self.fTf_loc)
+            if self.overlap_gather and features_ready and take_step:
+                work = self.comm.all_gather(self.gath, self.fTf_loc, async_op=True)
+                # meanwhile: draw batch t+1 and write its features into the other set
+                H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
+                                           self.batches_drawn, self._x_other, self._ws_other, True, self.path)
+                self.batches_drawn += 1
+                self._next_ready = True
+                work.wait()
+            else:
+                self.comm.all_gather(self.gath, self.fTf_loc)
             self.fTf_g.view(2, self.B, world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
         moments, scratch, loss = self._moments, self.scratch, self._loss
         if self.direct_moments:
@@ -299,11 +316,17 @@ class FusedTrainer:
                 self._pending = False
             if x is None and self.device_sampler:
                 # one launch draws the batch and writes its features; the forward then skips the feature stage
-                H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
-                                           self.batches_drawn, self.x, self.ws, True, self.path)
-                self.batches_drawn += 1
+                if self._next_ready:  # produced under the previous step's all-gather: switch sets
+                    self.ws, self._ws_other = self._ws_other, self.ws
+                    self.x, self._x_other = self._x_other, self.x
+                    self._next_ready = False
+                else:
+                    H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
+                                               self.batches_drawn, self.x, self.ws, True, self.path)
+                    self.batches_drawn += 1
                 self.forward_backward(self.x, features_ready=True)
             else:
+                self._next_ready = False  # an externally supplied batch: drop any batch prepared ahead
                 if x is None:
                     x = self.sample()
                 self.forward_backward(x)
