@@ -226,7 +226,7 @@ def main():
                                 "flat gradient per step" if world > 1 else "single GPU: no exchange"),
                    "optimiser": ("RMSprop+EMA step fused into the weight-gradient kernel" if tr.fused_step else
                                  "separate RMSprop+EMA kernel after the gradient all-reduce"),
-                   "path": H.path_name(tr.shape, tr.B, path), "params": tr.P.n_trainable * (world if tr.hp else 1)},
+                   "path": H.path_name(tr.shape, tr.B, path, prob), "params": tr.P.n_trainable * (world if tr.hp else 1)},
         "final_loss": loss, "params_finite": finite,
         "roofline": roof,
     }

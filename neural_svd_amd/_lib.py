@@ -51,6 +51,7 @@ _P, _I, _F, _Z, _Dbl = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
 SIGNATURES = {
     "nsvd_abi_version": (_I, []),
     "nsvd_path_name": (C.c_char_p, [C.POINTER(ModelDesc), _I, _I]),
+    "nsvd_path_name_for": (C.c_char_p, [C.POINTER(ModelDesc), C.POINTER(Problem), _I, _I]),
     "nsvd_workspace_bytes": (_Z, [C.POINTER(ModelDesc), _I]),
     "nsvd_fourier_features": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
     "nsvd_operator_forward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _P,

@@ -179,6 +179,13 @@ extern "C" const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int pa
     return want_fused(*desc, B, path) ? "fused_mfma" : "generic";
 }
 
+extern "C" const char* nsvd_path_name_for(const nsvd_model_desc* desc, const nsvd_problem* prob, int B, int path) {
+    if (validate(desc) != 0 || B <= 0 || !prob) return "invalid";
+    const bool exact = !(prob->eps > 0.f);
+    if (want_fused(*desc, B, path, exact)) return "fused_mfma";
+    return exact ? "unsupported" : "generic";
+}
+
 extern "C" size_t nsvd_model_workspace_bytes(const nsvd_model_desc* desc, int B) {
     if (validate(desc, MODEL_MAX_D) != 0 || B <= 0) return 0;
     const size_t gen = carve(*desc, B, nullptr, 1).bytes;

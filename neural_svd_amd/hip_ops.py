@@ -123,8 +123,11 @@ def workspace_bytes(shape: ModelShape, B: int) -> int:
     return int(n)
 
 
-def path_name(shape: ModelShape, B: int, path: int = PATH_AUTO) -> str:
+def path_name(shape: ModelShape, B: int, path: int = PATH_AUTO, prob: Optional[Problem] = None) -> str:
+    """"fused_mfma" / "generic" (/ "unsupported": exact-Laplacian mode on a shape the MFMA path does not take)."""
     d = shape.desc()
+    if prob is not None:
+        return _lib.load().nsvd_path_name_for(C.byref(d), C.byref(prob), int(B), int(path)).decode()
     return _lib.load().nsvd_path_name(C.byref(d), int(B), int(path)).decode()
 
 

@@ -151,7 +151,7 @@ class FusedTrainer:
         self._sq_params = self.P.pack(self.P.sq, False)
         self.fused_step = bool(fused_step) and (world == 1 or self.hp)
         # the generic (non-MFMA) path takes the step with per-tensor optimiser launches and needs the gradients
-        self.keep_grads = bool(keep_grads) or H.path_name(shape, self.B, path) != "fused_mfma"
+        self.keep_grads = bool(keep_grads) or H.path_name(shape, self.B, path, problem) != "fused_mfma"
         # nesting masks (methods/nestedlora.py:183-192)
         from .nested_lowrank import nesting_masks
         self.vector_mask, self.matrix_mask, self.mask_kind = nesting_masks(self.Lg, sequential, step)
@@ -180,7 +180,7 @@ class FusedTrainer:
         # kernel takes the 2 L moments each head needs from f itself and no moment kernel runs; the loss scalars
         # (logging only) and the moment vector are then evaluated on demand (properties below)
         self.direct_moments = (world == 1 or self.hp) and self.B <= 1024 and \
-            H.path_name(shape, self.B, path) == "fused_mfma"
+            H.path_name(shape, self.B, path, problem) == "fused_mfma"
         self._loss_stale = False
         self.scratch = H.evd_scratch(self.B, Lg, self.device)
         self.x = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device)
