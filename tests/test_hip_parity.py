@@ -689,3 +689,48 @@ def test_spectrum_matches_reference(case):
     ref_err = float(np.max(np.abs(e32 - e64) / np.abs(e64)))
     got_err = float(np.max(np.abs(eig.numpy() - e64) / np.abs(e64)))
     assert got_err < max(3 * ref_err, 1e-4), (got_err, ref_err)
+
+
+# ------------------------------------------------------------------------------ full-size properties (cfg2)
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_headline_size_properties(cfg):
+    """BASELINE.json configs[1] (hydrogen, L = 16, B = 512, m = 1024, H = 128 x 3) and configs[2] per GPU
+    (oscillator, L = 32, B = 512, m = 256, exponential mask) at full size, where a float64 oracle run is out of reach
+    for a unit test: size-independent properties of the operator.
+      * run-to-run bit reproducibility (no atomics anywhere on the path);
+      * row equivariance: permuting the batch permutes f and Tf bit for bit (a sample never sees its neighbours);
+      * homogeneity in the last layer: scaling W_last, b_last by c scales f and Tf by c;
+      * a sampled float64 check: 8 rows x all heads against the oracle."""
+    if cfg == "cfg2":
+        L, D, m, hidden, B = 16, 2, 1024, (128, 128, 128), 512
+        p = O.init_params(L, D, m, hidden, 0.1, seed=0)
+        prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+        kcfg = dict(operator_scale=100.0, laplacian_eps=0.01)
+    else:
+        L, D, m, hidden, B = 32, 2, 256, (128, 128, 128), 512
+        p = O.init_params(L, D, m, hidden, 1.0, exp_mask_init=10.0, seed=0)
+        prob_o = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=4.0)
+        kcfg = dict(operator_scale=1.0, laplacian_eps=0.01)
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    prob = hip_problem(prob_o)
+    x = (prob_o.sigma * torch.randn(B, D, generator=torch.Generator().manual_seed(5))).to(DEV)
+    ws = H.new_workspace(shape, B, DEV)
+    f, Tf = H.operator_forward(shape, params, prob, x, ws)
+    f2, Tf2 = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV))
+    assert H.path_name(shape, B, H.PATH_AUTO, prob) == "fused_mfma"
+    assert torch.equal(f, f2) and torch.equal(Tf, Tf2)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(6)).to(DEV)
+    fp, Tfp = H.operator_forward(shape, params, prob, x[perm].contiguous(), ws)
+    assert torch.equal(fp, f[perm]) and torch.equal(Tfp, Tf[perm])
+    c = 2.0  # a power of two: the scaled run is the same arithmetic with shifted exponents
+    ws_c = list(ws_t[:-1]) + [ws_t[-1] * c]
+    bs_c = list(bs_t[:-1]) + [bs_t[-1] * c]
+    fc, Tfc = H.operator_forward(shape, H.pack_params(shape, ws_c, bs_c, fB, sc), prob, x, ws)
+    assert torch.equal(fc, c * f) and torch.equal(Tfc, c * Tf)
+    rows = torch.tensor([0, 1, 63, 64, 255, 256, 300, 511])
+    ref = O.operator_forward(x[rows.to(DEV)].double().cpu(), p.to(torch.float64), prob_o)
+    assert rel(f[rows.to(DEV)], ref.f) < 2e-5
+    k = tf_noise_kappa(Tf[rows.to(DEV)], ref.Tf.numpy(), ref.f.numpy(), kcfg)
+    assert k < 3 * KAPPA_REF_MEDIAN, k
