@@ -734,3 +734,25 @@ def test_headline_size_properties(cfg):
     assert rel(f[rows.to(DEV)], ref.f) < 2e-5
     k = tf_noise_kappa(Tf[rows.to(DEV)], ref.Tf.numpy(), ref.f.numpy(), kcfg)
     assert k < 3 * KAPPA_REF_MEDIAN, k
+
+
+def test_backward_headline_size_sampled_heads():
+    """configs[1] at full size: the backward kernels with a given d loss / d f; the float64 oracle is evaluated for
+    two of the 16 heads only (a head's gradients depend on its own parameters and its own column of df)."""
+    L, D, m, hidden, B = 16, 2, 1024, (128, 128, 128), 512
+    p = O.init_params(L, D, m, hidden, 0.1, seed=0)
+    prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+    gen = torch.Generator().manual_seed(9)
+    x = (16.0 * torch.randn(B, D, generator=gen)).double()
+    df = torch.randn(B, L, generator=gen, dtype=torch.float64) / B
+    v, M = O.joint_nesting_masks(L, 1)
+    r = run_hip(p, prob_o, x, v, M, H.PATH_AUTO, df_override=df)
+    assert r["path"] == "fused_mfma"
+    nl = len(p.ws)
+    for l in (0, 15):
+        ph = O.Params([w[l:l + 1] for w in p.ws], [b[l:l + 1] for b in p.bs], p.fourier_B, None).to(torch.float64)
+        c = O.operator_forward(x, ph, prob_o)
+        gref = O.operator_backward(c, ph, prob_o, df[:, l:l + 1])
+        for i in range(nl):
+            assert rel(r["grads"][i][l], gref[i][0]) < 3e-5, (l, i, rel(r["grads"][i][l], gref[i][0]))
+            assert rel(r["grads"][nl + i][l], gref[nl + i][0]) < 3e-5, (l, i)
