@@ -102,7 +102,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused", "bf16x3"],
+                    help="bf16x3: developer option, first layer on the bf16 MFMA with three-way split operands "
+                         "(NSVD_PATH_FUSED_BF16X3; not the headline path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--batch-size", type=int, default=None)
@@ -142,7 +144,8 @@ def main():
     shape = H.ModelShape(L=cfg["L"], D=cfg["D"], m=cfg["m"], hidden=cfg["hidden"], has_exp_mask=osc)
     prob = H.make_problem(H.POT_HARMONIC if osc else H.POT_HYDROGEN, 1.0, cfg["eps"], cfg["op_scale"], cfg["op_shift"],
                           cfg["sigma"])
-    path = {"auto": H.PATH_AUTO, "generic": H.PATH_GENERIC, "fused": H.PATH_FUSED}[args.path]
+    path = {"auto": H.PATH_AUTO, "generic": H.PATH_GENERIC, "fused": H.PATH_FUSED,
+            "bf16x3": H.PATH_FUSED_BF16X3}[args.path]
     par = args.parallelism
     if par == "auto":
         par = "hp" if (world > 1 and cfg["L"] % world == 0) else "dp"
@@ -233,6 +236,10 @@ def main():
     if args.config != "cfg2" or args.laplacian_eps is not None or args.batch_size:
         out["metric"] = f"training steps/sec, developer config {args.config} (not the headline workload)"
         out["config"]["workload"] = f"{args.config}: {cfg}"
+    if args.path == "bf16x3":
+        out["metric"] += " [developer path: layer 0 as bf16x3 split products, fp32 accumulation]"
+        out["config"]["layer0"] = ("bf16 MFMA, operands split into 3 bf16 planes, 6 partial products, fp32 "
+                                   "accumulate; roofline.frac stays relative to the fp32 MFMA peak")
     if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
         cb = cpu_baseline(cfg)
         out["cpu_baseline"] = cb

@@ -61,6 +61,10 @@ extern "C" {
 #define NSVD_PATH_AUTO 0    /* fused MFMA kernels when the shape allows, else generic   */
 #define NSVD_PATH_GENERIC 1 /* layer-by-layer generic kernels (any shape)               */
 #define NSVD_PATH_FUSED 2   /* fused MFMA kernels or NSVD_EUNSUPPORTED                  */
+#define NSVD_PATH_FUSED_BF16X3 3 /* EXPERIMENTAL, never picked by AUTO: the fused kernels with the first layer on the
+                                  * bf16 MFMA, every float32 operand split into three bf16 planes and six partial
+                                  * products accumulated in float32 (error below the fp32 MFMA's own rounding);
+                                  * forward only - the backward entry points treat it as NSVD_PATH_FUSED */
 
 /* Shape of WaveFunctions(ParallelMLP(GaussianFourierFeatureTransform)):
  * examples/operator/pde/__init__.py:19-55, examples/models/mlp.py:167-221, examples/utils.py:90-143 */

@@ -17,7 +17,7 @@ EUNSUPPORTED = -10002
 
 POT_HYDROGEN, POT_HARMONIC = 0, 1
 MASK_CUSTOM, MASK_SEQUENTIAL, MASK_JOINT = 0, 1, 2
-PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
+PATH_AUTO, PATH_GENERIC, PATH_FUSED, PATH_FUSED_BF16X3 = 0, 1, 2, 3
 FEATURES_READY = 0x100
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))

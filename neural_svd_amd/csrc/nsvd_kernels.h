@@ -71,7 +71,7 @@ int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const ns
                         float* xout = nullptr);
 // save: bit 0 = keep what the backward needs, bit 1 = features already prepared by nsvd_fused_features
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
-                       int B, float* f, float* Tf, void* ws, int save, hipStream_t s);
+                       int B, float* f, float* Tf, void* ws, int save, hipStream_t s, int bf3 = 0);
 int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                         int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s);
 struct NsvdEvdIn;  // evd_math.h

@@ -80,7 +80,7 @@ GenericWs carve(const nsvd_model_desc& d, int B, void* base, int erows = 0) {
 
 // exact: the exact-Laplacian mode (prob->eps <= 0), whose D + 2 jet streams fit the MFMA path up to D = 3
 bool want_fused(const nsvd_model_desc& d, int B, int path, bool exact = false) {
-    if (path == NSVD_PATH_GENERIC) return false;
+    if (path == NSVD_PATH_GENERIC) return false;  // NSVD_PATH_FUSED and NSVD_PATH_FUSED_BF16X3 both need the MFMA path
     return nsvd_fused_supported(d, B, exact);
 }
 
@@ -212,13 +212,13 @@ extern "C" int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_par
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
-    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if ((path == NSVD_PATH_FUSED || path == NSVD_PATH_FUSED_BF16X3) && !fused) return NSVD_EUNSUPPORTED;
     // eps <= 0 selects the exact Laplacian (reference diff_ops.py:7): forward-mode jets, MFMA path only
     if (!(prob->eps > 0.f) && !fused) return NSVD_EUNSUPPORTED;
     const bool ready = (save_for_backward & NSVD_FEATURES_READY) != 0;
     if (fused)
         return nsvd_fused_forward(*desc, *params, *prob, x, B, f, Tf, ws, (save_for_backward & 1) | (ready ? 2 : 0),
-                                  (hipStream_t)stream);
+                                  (hipStream_t)stream, path == NSVD_PATH_FUSED_BF16X3);
     return generic_forward(*desc, *params, *prob, x, B, f, Tf, ws, (hipStream_t)stream, ready);
 }
 
@@ -231,7 +231,7 @@ extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_pa
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
-    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if ((path == NSVD_PATH_FUSED || path == NSVD_PATH_FUSED_BF16X3) && !fused) return NSVD_EUNSUPPORTED;
     if (fused) return nsvd_fused_features(*desc, *params, *prob, x, B, ws, save_for_backward & 1, (hipStream_t)stream);
     if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;
     const GenericWs w = carve(*desc, B, ws);
@@ -249,7 +249,7 @@ extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const 
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
-    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if ((path == NSVD_PATH_FUSED || path == NSVD_PATH_FUSED_BF16X3) && !fused) return NSVD_EUNSUPPORTED;
     NsvdSampler smp;
     smp.seed = seed;
     smp.offset = offset;
@@ -321,7 +321,7 @@ extern "C" int nsvd_operator_backward(const nsvd_model_desc* desc, const nsvd_pa
     if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
-    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if ((path == NSVD_PATH_FUSED || path == NSVD_PATH_FUSED_BF16X3) && !fused) return NSVD_EUNSUPPORTED;
     if (fused) return nsvd_fused_backward(*desc, *params, *prob, x, B, df, *grads, ws, (hipStream_t)stream);
     return generic_backward(*desc, *params, x, B, df, *grads, ws, (hipStream_t)stream);
 }
@@ -364,7 +364,7 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
-    if (path == NSVD_PATH_FUSED && !fused) return NSVD_EUNSUPPORTED;
+    if ((path == NSVD_PATH_FUSED || path == NSVD_PATH_FUSED_BF16X3) && !fused) return NSVD_EUNSUPPORTED;
     if (L_total <= 0) L_total = desc->L;
     if (l_offset < 0 || l_offset + desc->L > L_total || L_total > 128) return NSVD_EINVAL;
     const int L = L_total;  // f, Tf, moments and masks are indexed by GLOBAL head

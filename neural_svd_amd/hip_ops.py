@@ -12,7 +12,8 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (MASK_CUSTOM, MASK_JOINT, MASK_SEQUENTIAL, PATH_AUTO, PATH_FUSED, PATH_GENERIC,  # noqa: F401
+from ._lib import (MASK_CUSTOM, MASK_JOINT, MASK_SEQUENTIAL, PATH_AUTO, PATH_FUSED, PATH_FUSED_BF16X3,  # noqa: F401
+                   PATH_GENERIC,
                    POT_HARMONIC, POT_HYDROGEN, ModelDesc, NsvdError, Params, Problem, check)
 
 

@@ -1,0 +1,37 @@
+"""dev: bf16x3 layer 0 (NSVD_PATH_FUSED_BF16X3) against the native fp32 MFMA path and the float64 oracle at cfg2."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from neural_svd_amd import hip_ops as H
+from oracle import nsvd_oracle as O
+dev = "cuda:0"
+L, D, m, hidden, B = 16, 2, 1024, (128, 128, 128), 512
+p = O.init_params(L, D, m, hidden, 0.1, seed=0)
+shape = H.ModelShape(L=L, D=D, m=m, hidden=hidden)
+params = H.pack_params(shape, [w.to(dev).contiguous() for w in p.ws], [b.to(dev).contiguous() for b in p.bs],
+                       p.fourier_B.to(dev).contiguous(), None)
+prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+x = (16.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(5))).to(dev)
+ws = H.new_workspace(shape, B, dev)
+out = {}
+for name, path in (("fp32", H.PATH_FUSED), ("bf16x3", H.PATH_FUSED_BF16X3)):
+    f, Tf = H.operator_forward(shape, params, prob, x, ws, True, path)
+    torch.cuda.synchronize()
+    out[name] = (f.clone(), Tf.clone())
+    for _ in range(20): H.operator_forward(shape, params, prob, x, ws, True, path)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 300
+    for _ in range(n): H.operator_forward(shape, params, prob, x, ws, True, path)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n * 1e6
+    print(f"{name}: forward (features + kernel) {dt:.1f} us")
+rows = torch.arange(0, B, 8)
+ref = O.operator_forward(x[rows.to(dev)].double().cpu(), p.to(torch.float64), prob_o)
+def rel(a, b): return float((a.double().cpu() - b).norm() / b.norm())
+u = 2.0 ** -23
+for name, (f, Tf) in out.items():
+    fr, Tfr = f[rows.to(dev)], Tf[rows.to(dev)]
+    s = 100.0 * u * ref.f.abs().numpy() / 0.01 ** 2
+    kappa = float(np.median(np.abs(Tfr.double().cpu().numpy() - ref.Tf.numpy()) / np.maximum(s, 1e-300)))
+    print(f"{name}: f rel err vs float64 {rel(fr, ref.f):.2e}; Tf rel err {rel(Tfr, ref.Tf):.2e}; FD-noise kappa (median) {kappa:.2f}")
+print("bf16x3 vs fp32: f", rel(out["bf16x3"][0], out["fp32"][0].double().cpu()), "Tf", rel(out["bf16x3"][1], out["fp32"][1].double().cpu()))

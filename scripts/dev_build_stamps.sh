@@ -1,0 +1,9 @@
+#!/bin/bash
+# dev: diagnostic build with per-phase s_memtime stamps in the fused forward -> neural_svd_amd/libnsvd_hip_stamps.so
+#   NSVD_LIB_PATH=neural_svd_amd/libnsvd_hip_stamps.so [NSVD_DEV_PATH=3] python scripts/dev_stamps.py
+set -e
+cd "$(dirname "$0")/../neural_svd_amd/csrc"
+make -s
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-fast-math -ffp-contract=on -I../../include -DNSVD_FWD_STAMPS -c pmlp_fused.hip -o build/pmlp_st.o
+objs=$(ls build/*.o | grep -v -e pmlp_fused.o -e pmlp_wgst.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libnsvd_hip_stamps.so $objs

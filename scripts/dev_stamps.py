@@ -18,7 +18,7 @@ al = lambda n: (n * 4 + 255) // 256 * 256
 E = 1 + 2 * D; R = E * B; F = 2 * m
 off = al(F * B) + al(2 * D * m) + al(F * B) + len(hidden) * al(L * 128 * B) + 2 * al(B * L)  # FusedWs: dz[0]
 for _ in range(3):
-    H.operator_forward(shape, p, prob, x, wsb, True, H.PATH_FUSED)
+    H.operator_forward(shape, p, prob, x, wsb, True, int(os.environ.get("NSVD_DEV_PATH", H.PATH_FUSED)))
 torch.cuda.synchronize()
 nwg = (B // 32) * L
 st = wsb[off:off + nwg * 16 * 8].view(torch.int64).view(nwg, 16).cpu().numpy().astype(np.float64)

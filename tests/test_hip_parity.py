@@ -30,10 +30,12 @@ def _gpu():
 
 DEV = "cuda:0"
 PATHS = ["generic", "auto"]
+# the MFMA path with its first layer in native float32 MFMAs, and with the three-way bf16 split (opt-in path)
+FPATHS = ["auto", "bf16x3"]
 
 
 def _path(name):
-    return H.PATH_GENERIC if name == "generic" else H.PATH_AUTO
+    return {"generic": H.PATH_GENERIC, "auto": H.PATH_AUTO, "bf16x3": H.PATH_FUSED_BF16X3}[name]
 
 
 def rel(a, b):
@@ -221,7 +223,7 @@ def test_operator_forward_backward_small(case, path):
         assert rel(g.view(-1), g64.reshape(-1)) < max(5 * ref_err, 5e-2), (n, ref_err)
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", PATHS + ["bf16x3"])
 @pytest.mark.parametrize("case", ["hyd_med", "cfg1"])
 def test_operator_headline_shapes(case, path):
     """H=128x3 shapes (the fused-kernel shapes) with weights regenerated from the seed recipe."""
@@ -504,8 +506,9 @@ def test_model_forward(case):
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("fpath", FPATHS)
 @pytest.mark.parametrize("case", ["hyd_exact", "osc_exact"])
-def test_exact_laplacian_mode(case):
+def test_exact_laplacian_mode(case, fpath):
     """laplacian_eps = 0: forward-mode jets in the fused kernel against the reference's double-autograd exact mode
     (goldens model_exact.npz). No finite differences, so Tf is held to the tolerance of f: 2e-5 relative (the
     float32 reference itself is 1e-6 .. 1e-5 from its float64 values here); loss and gradients follow."""
@@ -516,7 +519,7 @@ def test_exact_laplacian_mode(case):
     p = G.params_from_golden(z, case)
     v, M = G.masks_of(z, case)
     x = torch.tensor(z[f"{case}_x"][0])
-    r = run_hip(p, prob, x, v, M, H.PATH_AUTO)
+    r = run_hip(p, prob, x, v, M, _path(fpath))
     assert r["path"] == "fused_mfma"
     pre = f"{case}_f64_step0_"
     assert rel(r["f"], z[pre + "f"]) < 2e-5
@@ -534,8 +537,9 @@ def test_exact_laplacian_mode(case):
         run_hip(ps, G.problem_of(G.cfg_of(z, zs)), torch.tensor(z[f"{zs}_x"][0]), *G.masks_of(z, zs), H.PATH_AUTO)
 
 
+@pytest.mark.parametrize("fpath", FPATHS)
 @pytest.mark.parametrize("eps", [0.01, 0.0])
-def test_fused_path_one_dimensional(eps):
+def test_fused_path_one_dimensional(eps, fpath):
     """D = 1 on the MFMA path (E = 3 stencil instance, and the 3-stream jet instance for eps = 0) against the
     float64 oracle: f to 2e-5; Tf to 1e-4 in exact mode, to the finite-difference noise level otherwise; gradients
     given the oracle's d loss / d f to 3e-5."""
@@ -545,7 +549,7 @@ def test_fused_path_one_dimensional(eps):
     v, M = O.joint_nesting_masks(L, 1)
     x = (2.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(4), dtype=torch.float64)).float().double()
     ref = O.loss_and_grads(x, p.to(torch.float64), prob, v, M)
-    r = run_hip(p, prob, x, v, M, H.PATH_AUTO, df_override=ref["df"])
+    r = run_hip(p, prob, x, v, M, _path(fpath), df_override=ref["df"])
     assert r["path"] == "fused_mfma"
     assert rel(r["f"], ref["f"]) < 2e-5
     if eps > 0:
@@ -557,7 +561,8 @@ def test_fused_path_one_dimensional(eps):
         assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, i
 
 
-def test_exact_mode_three_dimensional():
+@pytest.mark.parametrize("fpath", FPATHS)
+def test_exact_mode_three_dimensional(fpath):
     """D = 3 fits the MFMA path in exact mode only (5 jet streams; the stencil would need 7 columns per sample):
     f, Tf and the gradients against the float64 oracle, hydrogen potential with the exponential mask."""
     L, D, m, hidden, B = 2, 3, 64, (128, 128, 128), 64
@@ -566,7 +571,7 @@ def test_exact_mode_three_dimensional():
     v, M = O.sequential_nesting_masks(L)
     x = (3.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(8), dtype=torch.float64)).float().double()
     ref = O.loss_and_grads(x, p.to(torch.float64), prob, v, M)
-    r = run_hip(p, prob, x, v, M, H.PATH_AUTO, df_override=ref["df"])
+    r = run_hip(p, prob, x, v, M, _path(fpath), df_override=ref["df"])
     assert rel(r["f"], ref["f"]) < 2e-5
     assert rel(r["Tf"], ref["Tf"]) < 1e-4
     for i, (g, gr) in enumerate(zip(r["grads"], ref["grads"])):
@@ -692,8 +697,9 @@ def test_spectrum_matches_reference(case):
 
 
 # ------------------------------------------------------------------------------ full-size properties (cfg2)
+@pytest.mark.parametrize("fpath", FPATHS)
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
-def test_headline_size_properties(cfg):
+def test_headline_size_properties(cfg, fpath):
     """BASELINE.json configs[1] (hydrogen, L = 16, B = 512, m = 1024, H = 128 x 3) and configs[2] per GPU
     (oscillator, L = 32, B = 512, m = 256, exponential mask) at full size, where a float64 oracle run is out of reach
     for a unit test: size-independent properties of the operator.
@@ -717,17 +723,18 @@ def test_headline_size_properties(cfg):
     prob = hip_problem(prob_o)
     x = (prob_o.sigma * torch.randn(B, D, generator=torch.Generator().manual_seed(5))).to(DEV)
     ws = H.new_workspace(shape, B, DEV)
-    f, Tf = H.operator_forward(shape, params, prob, x, ws)
-    f2, Tf2 = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV))
+    path = _path(fpath)
+    f, Tf = H.operator_forward(shape, params, prob, x, ws, path=path)
+    f2, Tf2 = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV), path=path)
     assert H.path_name(shape, B, H.PATH_AUTO, prob) == "fused_mfma"
     assert torch.equal(f, f2) and torch.equal(Tf, Tf2)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(6)).to(DEV)
-    fp, Tfp = H.operator_forward(shape, params, prob, x[perm].contiguous(), ws)
+    fp, Tfp = H.operator_forward(shape, params, prob, x[perm].contiguous(), ws, path=path)
     assert torch.equal(fp, f[perm]) and torch.equal(Tfp, Tf[perm])
     c = 2.0  # a power of two: the scaled run is the same arithmetic with shifted exponents
     ws_c = list(ws_t[:-1]) + [ws_t[-1] * c]
     bs_c = list(bs_t[:-1]) + [bs_t[-1] * c]
-    fc, Tfc = H.operator_forward(shape, H.pack_params(shape, ws_c, bs_c, fB, sc), prob, x, ws)
+    fc, Tfc = H.operator_forward(shape, H.pack_params(shape, ws_c, bs_c, fB, sc), prob, x, ws, path=path)
     assert torch.equal(fc, c * f) and torch.equal(Tfc, c * Tf)
     rows = torch.tensor([0, 1, 63, 64, 255, 256, 300, 511])
     ref = O.operator_forward(x[rows.to(DEV)].double().cpu(), p.to(torch.float64), prob_o)
