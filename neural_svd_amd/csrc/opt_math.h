@@ -35,11 +35,13 @@ static inline NsvdHyper nsvd_make_hyper(double lr, double alpha, double eps, dou
     return h;
 }
 
-__device__ __forceinline__ void nsvd_rmsprop_upd(float& p, float g, float& sq, float* ema, const NsvdHyper& h) {
+// ema by reference + flag (not an optional pointer: a conditionally taken address of a local keeps it in scratch)
+__device__ __forceinline__ void nsvd_rmsprop_upd(float& p, float g, float& sq, float& ema, bool has_ema,
+                                                 const NsvdHyper& h) {
     const float lr = h.lr, eps = h.eps, one_minus_decay = h.one_minus_decay;
     g *= h.grad_scale;
     sq = h.alpha * sq + h.one_minus_alpha * (g * g);  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
     const float avg = sqrtf(sq) + eps;                // square_avg.sqrt().add_(eps)
     p = p - lr * (g / avg);                           // param.addcdiv_(g, avg, value=-lr)
-    if (ema) *ema = *ema - one_minus_decay * (*ema - p);
+    if (has_ema) ema = ema - one_minus_decay * (ema - p);
 }

@@ -10,7 +10,8 @@ namespace {
 
 typedef NsvdHyper Hyper;
 __device__ __forceinline__ void upd(float& p, float g, float& sq, float* ema, const Hyper& h) {
-    nsvd_rmsprop_upd(p, g, sq, ema, h);
+    float none = 0.f;
+    nsvd_rmsprop_upd(p, g, sq, ema ? *ema : none, ema != nullptr, h);
 }
 
 template <bool HAS_EMA>

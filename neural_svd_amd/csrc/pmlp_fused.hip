@@ -1055,38 +1055,55 @@ __device__ __forceinline__ void wg_emit1(const WgradArgs& a, const WgDst& d, con
     if (g) g[off] = val;
     if (d.opt) {
         float pv = o.p[off], sv = o.sq[off], ev = o.ema ? o.ema[off] : 0.f;
-        nsvd_rmsprop_upd(pv, val, sv, o.ema ? &ev : nullptr, a.h);
+        nsvd_rmsprop_upd(pv, val, sv, ev, o.ema != nullptr, a.h);
         o.p[off] = pv;
         o.sq[off] = sv;
         if (o.ema) o.ema[off] = ev;
     }
 }
 
-// the 16 accumulator registers of one 32 x 32 MFMA tile: rows acc_row(r, hi) * ld, this lane's column at `base`
+// the 16 accumulator registers of one 32 x 32 MFMA tile: rows acc_row(r, hi) * ld, this lane's column at `base`.
+// Element offsets are 32-bit (every tensor is far below 2^32 bytes: checked on the host) so that the three state
+// arrays share one offset register per element and the loads take the scalar-base form; with 64-bit offsets the 48
+// loads in flight spill, and every spill waits for its load.
+__device__ __forceinline__ float wg_ld(const float* p, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + byte_off);
+}
+__device__ __forceinline__ void wg_st(float* p, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(p) + byte_off) = v;
+}
+
+template <bool EMA>
+__device__ __forceinline__ void wg_opt16(const WgradArgs& a, const NsvdOptPtrs& o, unsigned base, unsigned ld, int hi,
+                                         const f32x16& acc) {
+    float pv[16], sv[16], ev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // 48 independent loads in flight
+        const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
+        pv[r] = wg_ld(o.p, off);
+        sv[r] = wg_ld(o.sq, off);
+        ev[r] = EMA ? wg_ld(o.ema, off) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
+        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], ev[r], EMA, a.h);
+        wg_st(o.p, off, pv[r]);
+        wg_st(o.sq, off, sv[r]);
+        if (EMA) wg_st(o.ema, off, ev[r]);
+    }
+}
+
 __device__ __forceinline__ void wg_emit16(const WgradArgs& a, const WgDst& d, const NsvdOptPtrs& o, size_t base,
                                           size_t ld, int hi, const f32x16& acc) {
     float* g = d.g;
     if (g) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[base + (size_t)acc_row(r, hi) * ld] = acc[r];
+        for (int r = 0; r < 16; ++r) wg_st(g, 4u * ((unsigned)base + (unsigned)acc_row(r, hi) * (unsigned)ld), acc[r]);
     }
     if (!d.opt) return;
-    float pv[16], sv[16], ev[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {  // 48 independent loads in flight
-        const size_t off = base + (size_t)acc_row(r, hi) * ld;
-        pv[r] = o.p[off];
-        sv[r] = o.sq[off];
-        ev[r] = o.ema ? o.ema[off] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const size_t off = base + (size_t)acc_row(r, hi) * ld;
-        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], o.ema ? &ev[r] : nullptr, a.h);
-        o.p[off] = pv[r];
-        o.sq[off] = sv[r];
-        if (o.ema) o.ema[off] = ev[r];
-    }
+    if (o.ema) wg_opt16<true>(a, o, (unsigned)base, (unsigned)ld, hi, acc);
+    else wg_opt16<false>(a, o, (unsigned)base, (unsigned)ld, hi, acc);
 }
 
 // stage one 32-row x 32-column (float4 per thread) slab global -> registers
@@ -1524,7 +1541,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
             if (a.opt) {
                 const NsvdOptPtrs& o = a.o[t];
                 float pv = o.p[e + c], sv = o.sq[e + c], ev = o.ema ? o.ema[e + c] : 0.f;
-                nsvd_rmsprop_upd(pv, gv[c], sv, o.ema ? &ev : nullptr, a.h);
+                nsvd_rmsprop_upd(pv, gv[c], sv, ev, o.ema != nullptr, a.h);
                 o.p[e + c] = pv;
                 o.sq[e + c] = sv;
                 if (o.ema) o.ema[e + c] = ev;
@@ -1622,6 +1639,8 @@ bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact) {
     if (B % BS != 0 || B > 65536) return false;
     if (B / wgrad_slices(d, B) > 8192) return false;  // one head's slice of dbase is staged in LDS (wgrad C)
     if ((2 * d.m) % HID != 0) return false;  // layer-0 weight gradient uses 128-wide feature tiles
+    // the weight-gradient epilogue addresses every tensor with 32-bit byte offsets (W_0 is the largest)
+    if ((size_t)d.L * HID * (size_t)(2 * d.m) * sizeof(float) >= ((size_t)1 << 32)) return false;
     return true;
 }
 
