@@ -1,4 +1,4 @@
-// NestedLoRA EVD loss pieces shared by evd_loss.hip (stand-alone loss kernels) and pmlp_fused.hip (the
+// NestedLoRA EVD loss pieces shared by evd_loss.hip (stand-alone loss kernels) and pmlp_bwd.hip (the
 // backward chain kernel evaluates d loss / d f per sample itself when handed the moments).
 //   reference: methods/nestedlora.py:40-54 (masks), :57-64 (metric), :70-111 (loss forward / backward)
 #pragma once

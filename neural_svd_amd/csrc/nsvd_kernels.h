@@ -57,7 +57,7 @@ int nsvd_model_out(const float* base, int ldr, const float* x, const float* scal
 // reduce the per-chunk partial moments of nsvd_evd_partial into the (2 L^2 + 1) vector (evd_loss.hip)
 int nsvd_evd_reduce_partials(const void* scratch, int B, int L, float* moments, hipStream_t s);
 
-// ---- fused MFMA path (pmlp_fused.hip) -----------------------------------------------------------
+// ---- fused MFMA path (pmlp_fwd.hip, pmlp_bwd.hip) -----------------------------------------------------------
 // plain model evaluation out = c * model(x) on the fused kernels (E = 1 instance; input dimension up to 64);
 // save != 0 keeps what nsvd_fused_backward needs (dout plays the role of df)
 bool nsvd_fused_model_supported(const nsvd_model_desc& d, int B);

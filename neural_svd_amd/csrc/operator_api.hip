@@ -1,5 +1,5 @@
 // extern "C" entry points for the operator forward / backward: argument validation, workspace
-// carving, and the choice between the fused MFMA kernels (pmlp_fused.hip) and the generic
+// carving, and the choice between the fused MFMA kernels (pmlp_fwd.hip, pmlp_bwd.hip) and the generic
 // layer-by-layer path implemented here on top of gemm_generic.hip / fd_epilogue.hip.
 #include <string.h>
 #include "nsvd_kernels.h"

@@ -1,5 +1,5 @@
 // RMSprop + EMA update of one parameter, shared by the stand-alone optimiser kernel (optimizer.hip) and the
-// weight-gradient kernel's fused epilogue (pmlp_fused.hip).
+// weight-gradient kernel's fused epilogue (pmlp_bwd.hip).
 //   reference: torch.optim.RMSprop as configured at examples/utils.py:50-57 (alpha, eps = 1e-10, momentum 0,
 //              not centred), stepped at examples/operator/__init__.py:69-70; torch_ema update at :73.
 #pragma once

@@ -1,0 +1,835 @@
+// Fused MFMA path, backward half: the data-gradient chain kernel, the weight-gradient kernel with the optimiser in
+// its epilogue, and the split-K reduction (forward half and the overall design: pmlp_fwd.hip).
+#include "pmlp_common.h"
+#include "evd_math.h"
+#include "opt_math.h"
+#include "tile_nt.h"
+
+using namespace nsvd_pmlp;
+
+namespace {
+
+
+// ================================================================================================
+// BACKWARD, part 1 (pmlp_fused_bwd_chain_kernel): one workgroup = head l x 32 centre samples.
+// Data gradients only, walking from the output back to layer 0 with the forward's transposed tiles
+// (rows = hidden units, columns = samples on the lanes; wave w owns rows 32w..32w+31):
+//   dz_{nh-1} = W_last * dbase * sigmoid(z_{nh-1}),   dbase = df * d f / d base
+//   dz_{i-1}[k][c] = (sum_n W_i[n][k] dz_i[n][c]) * sigmoid(z_{i-1}[k][c])     64 MFMAs/wave, W_i from L2
+// Every dz_i (L, 128, B) goes to the workspace; all weight/bias gradients are reductions over the
+// batch and are done by pmlp_fused_wgrad_kernel without atomics.
+// This is autograd's backward of reference mlp.py:204-221 for the centre evaluation only (the 2D
+// shifted evaluations carry no gradient: nestedlora.py:108-111) and of pde/__init__.py:16.
+struct ChainArgs {
+    const float* df;             // (B, L) d loss / d f, or null: derive it from the moments below
+    const float* jac;
+    const float* dsc;            // null without the exponential mask
+    const float* W[NSVD_MAX_LAYERS];
+    const float* zsave[NSVD_MAX_LAYERS];
+    float* dz[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer
+    float* dbase;                // (L, B)  df * d f / d base    (for the last-layer gradient)
+    float* dfsc;                 // (L, B)  df * d f / d scales  (exponential mask only)
+    int nlayers, B, L;
+    // EVD-loss mode (df == null): NestedLoRALossFunctionEVD.backward evaluated per sample right here
+    NsvdEvdIn evd;
+};
+
+__global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float DZ[BS * H_LD];  // [c][n]  n contiguous
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int nsb = a.B / BS;
+    const int l = blockIdx.x / nsb;
+    const int b0 = (blockIdx.x - l * nsb) * BS;
+    const int nh = a.nlayers - 1;
+    const int b = b0 + li;
+    const size_t row0 = ((size_t)l * HID + 32 * w) * a.B + b;
+
+    float dfv;
+    if (a.df) {
+        dfv = a.df[(size_t)b * a.L + l];
+    } else {
+        // d loss / d f[b][l] = gs * ( -(4/B) v_l Tf[b][l] + (2/B_half) sum_l' f[b][l'] M[l'][l] lam_other[l'][l] )
+        // (reference methods/nestedlora.py:98-111 with f1, f2 = chunk(f, 2)); the moments are either the
+        // reduced / all-reduced vector or this rank's per-chunk partial sums (reduced here, in a fixed order)
+        float* col = DZ;  // [2][Lg] masked moment columns of (global) head lg (LDS scratch, free until the first exchange)
+        const int Lg = a.evd.Lg, lg = a.evd.l_off + l;
+        const int B1 = (a.B + 1) / 2, B2 = a.B - B1;
+        if (a.evd.moments || a.evd.part) {
+            for (int t = tid; t < 2 * Lg; t += 256) {
+                const int h = t / Lg, lp = t - h * Lg;  // h = 0: lam_f1 column, 1: lam_f2 column
+                col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * nsvd_evd_lam(a.evd, h, lp * Lg + lg, a.B, Lg);
+            }
+            if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, Lg, DZ + 2 * Lg);
+        } else {
+            // direct mode: no moment kernel ran - the 2 Lg moments of THIS head's column straight from f
+            // (8 threads per moment, fixed summation order; the loss scalars are not produced)
+            const int sub = tid & 7;
+            for (int t = tid >> 3; t < 2 * Lg; t += 32) {
+                const int h = t / Lg, lp = t - h * Lg;
+                const int r0 = h ? B1 : 0, nr = h ? B2 : B1;
+                const float* fp = a.evd.f + (size_t)r0 * Lg;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int bb = sub;
+                for (; bb + 24 < nr; bb += 32) {
+                    s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
+                    s1 = fmaf(fp[(size_t)(bb + 8) * Lg + lp], fp[(size_t)(bb + 8) * Lg + lg], s1);
+                    s2 = fmaf(fp[(size_t)(bb + 16) * Lg + lp], fp[(size_t)(bb + 16) * Lg + lg], s2);
+                    s3 = fmaf(fp[(size_t)(bb + 24) * Lg + lp], fp[(size_t)(bb + 24) * Lg + lg], s3);
+                }
+                for (; bb < nr; bb += 8) s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
+                float sum = (s0 + s1) + (s2 + s3);
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                if (sub == 0) col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * (sum / (float)nr);
+            }
+        }
+        __syncthreads();
+        const bool first = b < B1;
+        const float* cp = col + (first ? Lg : 0);  // the OTHER half's moments
+        const float* fr = a.evd.f + (size_t)b * Lg;
+        float acc = 0.f;
+        for (int lp = 0; lp < Lg; ++lp) acc = fmaf(fr[lp], cp[lp], acc);
+        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * a.evd.Tf[(size_t)b * Lg + lg] +
+                                  (2.f / (float)(first ? B1 : B2)) * acc);
+        __syncthreads();  // col[] is dead before DZ is reused
+    }
+    const float dbase = dfv * a.jac[(size_t)b * a.L + l];
+    if (w == 0 && hi == 0) {
+        a.dbase[(size_t)l * a.B + b] = dbase;
+        if (a.dfsc) a.dfsc[(size_t)l * a.B + b] = dfv * a.dsc[(size_t)b * a.L + l];
+    }
+    float dz[16];
+    {
+        const float* zp = a.zsave[nh - 1] + row0;
+        const float* wl = a.W[nh] + (size_t)l * HID + 32 * w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = acc_row(r, hi);
+            dz[r] = wl[n] * dbase * nsvd_sigmoid_from_softplus(zp[(size_t)n * a.B]);
+        }
+    }
+    for (int i = nh - 1; i >= 0; --i) {
+        float* o = a.dz[i] + row0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
+        if (i == 0) break;
+        // issue the loads the next tile needs before the LDS exchange: sigmoid inputs and W_i columns
+        float zin[16];
+        {
+            const float* zp = a.zsave[i - 1] + row0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zin[r] = zp[(size_t)acc_row(r, hi) * a.B];
+        }
+        __syncthreads();  // previous round's LDS reads are done
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =
+                make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);
+        __syncthreads();
+        f32x16 acc1[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+        const float* Wi = a.W[i] + (size_t)l * HID * HID + 32 * w + li;  // W_i[n][k = 32w + li]
+        const float* Bp = DZ + li * H_LD + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            Frag<1> f;
+            const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;
+            f.a = make_float4(wp[0], wp[HID], wp[2 * HID], wp[3 * HID]);
+            f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * q);
+            mma_frag<1>(acc1, f);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * nsvd_sigmoid_from_softplus(zin[r]);
+    }
+}
+
+// ================================================================================================
+// BACKWARD, part 2 (pmlp_fused_wgrad_kernel): every parameter gradient, one launch, no atomics.
+// Three kinds of workgroup, told apart by blockIdx:
+//   A  (F/128 * L):      dW_0[l][n][k] = sum_b dz_0[l][n][b] phi^T[k][b]: 128 x 128 tile, K = B, both
+//                        operands b-contiguous, 4 waves as 2 x 2 of 64 x 64; the k = 0 tile of each head
+//                        also writes db_0[l] (row sums of dz_0).
+//   B  (4 (nh-1) L):     dW_i[l][n][k] = sum_b dz_i[l][n][b] softplus(z_{i-1}[l][k][b]), i >= 1: one
+//                        64 x 64 quadrant of the 128 x 128 result, 4 waves of one 32 x 32 tile; quadrants
+//                        in column 0 also write db_i. (128 x 64 half tiles were measured slower: fewer,
+//                        longer workgroups next to the dW_0 tiles.)
+//   C  (4 L):              dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales.
+// Timeline at cfg2 (NSVD_WG_STAMPS build, scripts/dev_wgrad_stamps.py): A tiles run their K loop in 72-77 K
+// cycles (65.5 K of MFMA issue) and end at 35 us; the B tiles, co-resident with them from t = 0 and latency-
+// bound (single accumulator chain, softplus while staging), end at 49 us; the C tiles at 36 us. With the
+// fused optimiser step the A epilogue moves 112 MB through HBM at once (20 us at 5.6 TB/s, all tiles finish
+// together) and the B tail hides under it: 60 us, vs 50 + 20.5 us for separate backward and optimiser
+// launches. Raising the B / C wave priority (s_setprio 3) shortens them but stretches the A loops by the same
+// amount: no gain.
+// K is streamed in 32-sample chunks through padded LDS tiles (rows of 36 floats, conflict-free
+// ds_read_b128 fragments), register-staged and double buffered, one barrier per chunk.
+struct WgradArgs {
+    const float* dz[NSVD_MAX_LAYERS];     // (L, 128, B)
+    const float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B)
+    const float* phiTc;                   // (F, B)
+    const float* dbase;                   // (L, B) from the chain kernel
+    const float* dfsc;                    // (L, B), null without the exponential mask
+    float* gW[NSVD_MAX_LAYERS];           // gradients; may be null when the optimiser step is fused (opt != 0)
+    float* gb[NSVD_MAX_LAYERS];
+    float* gscales;
+    int nlayers, B, L, F;
+    int nA, nB;
+    int bid0;  // first logical block of this launch (the A tiles and the B/C tiles are launched separately)
+    // fused RMSprop + EMA epilogue (opt != 0): every gradient element is applied to its parameter in place
+    // the moment it leaves the accumulator, so it never makes the HBM round trip (-8 B/parameter, -1 launch).
+    // Safe in place: this kernel reads no parameter, the chain kernel that does has already run.
+    int opt;
+    NsvdHyper h;
+    NsvdOptPtrs oW[NSVD_MAX_LAYERS], ob[NSVD_MAX_LAYERS], oscales;
+    // split-K over the batch (S > 1; head-parallel ranks own few heads on many rows, so the tile count alone
+    // would not fill the chip): tile (unit, slice) contracts rows [slice * Bs, (slice + 1) * Bs) and stores a
+    // partial gradient into slice `slice` of `part`; wgrad_reduce_kernel adds the slices in order and stores the
+    // gradient / takes the optimiser step.
+    int S, Bs;
+    float* part;
+    size_t part_stride;                                        // floats per slice
+    size_t poW[NSVD_MAX_LAYERS], pob[NSVD_MAX_LAYERS], poscales;  // tensor offsets inside a slice
+};
+
+// where a gradient element goes: the caller's gradient tensor (+ fused optimiser) or this slice's partial buffer
+struct WgDst {
+    float* g;
+    int opt;
+};
+__device__ __forceinline__ WgDst wg_dst(const WgradArgs& a, float* g, size_t part_off, int slice) {
+    if (a.S > 1) return WgDst{a.part + (size_t)slice * a.part_stride + part_off, 0};
+    return WgDst{g, a.opt};
+}
+
+#ifdef NSVD_WG_STAMPS
+// diagnostic build: per-block (kind, realtime start/end, cycles in prologue / loop / epilogue)
+__device__ unsigned long long g_wg_stamps[1024 * 8];
+#define WG_STAMP(slot, v) if (threadIdx.x == 0) g_wg_stamps[(size_t)blockIdx.x * 8 + (slot)] = (v)
+#else
+#define WG_STAMP(slot, v)
+#endif
+
+// one gradient element: store it and / or take the optimiser step on its parameter
+__device__ __forceinline__ void wg_emit1(const WgradArgs& a, const WgDst& d, const NsvdOptPtrs& o, size_t off,
+                                         float val) {
+    float* g = d.g;
+    if (g) g[off] = val;
+    if (d.opt) {
+        float pv = o.p[off], sv = o.sq[off], ev = o.ema ? o.ema[off] : 0.f;
+        nsvd_rmsprop_upd(pv, val, sv, ev, o.ema != nullptr, a.h);
+        o.p[off] = pv;
+        o.sq[off] = sv;
+        if (o.ema) o.ema[off] = ev;
+    }
+}
+
+// the 16 accumulator registers of one 32 x 32 MFMA tile: rows acc_row(r, hi) * ld, this lane's column at `base`.
+// Element offsets are 32-bit (every tensor is far below 2^32 bytes: checked on the host) so that the three state
+// arrays share one offset register per element and the loads take the scalar-base form; with 64-bit offsets the 48
+// loads in flight spill, and every spill waits for its load.
+__device__ __forceinline__ float wg_ld(const float* p, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + byte_off);
+}
+__device__ __forceinline__ void wg_st(float* p, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(p) + byte_off) = v;
+}
+
+template <bool EMA>
+__device__ __forceinline__ void wg_opt16(const WgradArgs& a, const NsvdOptPtrs& o, unsigned base, unsigned ld, int hi,
+                                         const f32x16& acc) {
+    float pv[16], sv[16], ev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // 48 independent loads in flight
+        const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
+        pv[r] = wg_ld(o.p, off);
+        sv[r] = wg_ld(o.sq, off);
+        ev[r] = EMA ? wg_ld(o.ema, off) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
+        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], ev[r], EMA, a.h);
+        wg_st(o.p, off, pv[r]);
+        wg_st(o.sq, off, sv[r]);
+        if (EMA) wg_st(o.ema, off, ev[r]);
+    }
+}
+
+__device__ __forceinline__ void wg_emit16(const WgradArgs& a, const WgDst& d, const NsvdOptPtrs& o, size_t base,
+                                          size_t ld, int hi, const f32x16& acc) {
+    float* g = d.g;
+    if (g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wg_st(g, 4u * ((unsigned)base + (unsigned)acc_row(r, hi) * (unsigned)ld), acc[r]);
+    }
+    if (!d.opt) return;
+    if (o.ema) wg_opt16<true>(a, o, (unsigned)base, (unsigned)ld, hi, acc);
+    else wg_opt16<false>(a, o, (unsigned)base, (unsigned)ld, hi, acc);
+}
+
+// stage one 32-row x 32-column (float4 per thread) slab global -> registers
+#define WG_LD(dst, src) dst = *reinterpret_cast<const float4*>(src)
+#define WG_ST(dst, v) *reinterpret_cast<float4*>(dst) = (v)
+
+__device__ __forceinline__ float4 softplus4(float4 v) {
+    return make_float4(nsvd_softplus(v.x), nsvd_softplus(v.y), nsvd_softplus(v.z), nsvd_softplus(v.w));
+}
+
+__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, float* Bs, int unit, int slice) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int nkt = a.F / HID;
+    const int l = unit / nkt;
+    const int kf0 = (unit - l * nkt) * HID;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int s_row = tid >> 3, s_c4 = tid & 7;
+    const float* a_src = a.dz[0] + ((size_t)l * HID + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
+    const float* b_src = a.phiTc + (size_t)(kf0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
+    const size_t step = (size_t)32 * a.B;
+    // Same software pipeline as the forward's layer 0: fragments one q-group ahead, chunk c+1 written to
+    // the other LDS buffer under chunk c's third q-group, chunk c+2 fetched from global under its fourth
+    // (after the barrier), every memory instruction in an MFMA gap, branch-free steady state.
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;  // bias gradient partials (only used when kf0 == 0)
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define WA_LOAD(c)                                                 \
+    {                                                              \
+        const float* pa_ = a_src + (c) * BK;                       \
+        const float* pb_ = b_src + (c) * BK;                       \
+        WG_LD(ra0, pa_);                                           \
+        WG_LD(ra1, pa_ + step);                                    \
+        WG_LD(ra2, pa_ + 2 * step);                                \
+        WG_LD(ra3, pa_ + 3 * step);                                \
+        WG_LD(rb0, pb_);                                           \
+        WG_LD(rb1, pb_ + step);                                    \
+        WG_LD(rb2, pb_ + 2 * step);                                \
+        WG_LD(rb3, pb_ + 3 * step);                                \
+    }
+#define WA_STORE(buf)                                                              \
+    {                                                                              \
+        float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
+        float* Bb_ = Bs + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
+        WG_ST(Ab_, ra0);                                                           \
+        WG_ST(Ab_ + 32 * A_LD, ra1);                                               \
+        WG_ST(Ab_ + 64 * A_LD, ra2);                                               \
+        WG_ST(Ab_ + 96 * A_LD, ra3);                                               \
+        WG_ST(Bb_, rb0);                                                           \
+        WG_ST(Bb_ + 32 * A_LD, rb1);                                               \
+        WG_ST(Bb_ + 64 * A_LD, rb2);                                               \
+        WG_ST(Bb_ + 96 * A_LD, rb3);                                               \
+        rs0 += (ra0.x + ra0.y) + (ra0.z + ra0.w);                                  \
+        rs1 += (ra1.x + ra1.y) + (ra1.z + ra1.w);                                  \
+        rs2 += (ra2.x + ra2.y) + (ra2.z + ra2.w);                                  \
+        rs3 += (ra3.x + ra3.y) + (ra3.z + ra3.w);                                  \
+    }
+    struct F4 {
+        float4 a0, a1, b0, b1;
+    };
+#define WA_READ(f, Ap, Bp, q)                                                      \
+    {                                                                              \
+        f.a0 = *reinterpret_cast<const float4*>((Ap) + 8 * (q));                   \
+        f.a1 = *reinterpret_cast<const float4*>((Ap) + 32 * A_LD + 8 * (q));       \
+        f.b0 = *reinterpret_cast<const float4*>((Bp) + 8 * (q));                   \
+        f.b1 = *reinterpret_cast<const float4*>((Bp) + 32 * A_LD + 8 * (q));       \
+    }
+#define WA_MMA1(f, X)                                                                                   \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0][0], 0, 0, 0);              \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[0][1], 0, 0, 0);              \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[1][0], 0, 0, 0);              \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[1][1], 0, 0, 0);
+#define WA_MMA(f) WA_MMA1(f, x) WA_MMA1(f, y) WA_MMA1(f, z) WA_MMA1(f, w)
+#define WA_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WA_IL(n, mask)                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+        __builtin_amdgcn_sched_group_barrier((mask), 1, 0);        \
+    }
+#define WA_BODY(c, DO_STORE, DO_LOAD)                                                           \
+    {                                                                                           \
+        const int cur = (c) & 1;                                                                \
+        const float* Ap = As + cur * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;               \
+        const float* Bp = Bs + cur * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;               \
+        WA_READ(f1, Ap, Bp, 1);                                                                 \
+        WA_MMA(f0);                                                                             \
+        WA_IL(4, 0x100);                                                                        \
+        WA_FENCE();                                                                             \
+        WA_READ(f0, Ap, Bp, 2);                                                                 \
+        WA_MMA(f1);                                                                             \
+        WA_IL(4, 0x100);                                                                        \
+        WA_FENCE();                                                                             \
+        WA_READ(f1, Ap, Bp, 3);                                                                 \
+        if (DO_STORE) WA_STORE(cur ^ 1);                                                        \
+        WA_MMA(f0);                                                                             \
+        WA_IL(4, 0x100);                                                                        \
+        if (DO_STORE) WA_IL(8, 0x200);                                                          \
+        WA_FENCE();                                                                             \
+        __syncthreads();                                                                        \
+        if (DO_STORE) {                                                                         \
+            const float* An = As + (cur ^ 1) * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;     \
+            const float* Bn = Bs + (cur ^ 1) * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;     \
+            WA_READ(f0, An, Bn, 0);                                                             \
+        }                                                                                       \
+        if (DO_LOAD) WA_LOAD((c) + 2);                                                          \
+        WA_MMA(f1);                                                                             \
+        if (DO_STORE) WA_IL(4, 0x100);                                                          \
+        if (DO_LOAD) WA_IL(8, 0x020);                                                           \
+        WA_FENCE();                                                                             \
+    }
+    const int nch = a.Bs / BK;
+    WG_STAMP(0, 1ull);
+    WG_STAMP(1, wall_clock64());
+    WG_STAMP(2, __builtin_readcyclecounter());
+    WA_LOAD(0);
+    WA_STORE(0);
+    __syncthreads();
+    if (nch > 1) WA_LOAD(1);
+    WG_STAMP(3, __builtin_readcyclecounter());
+    F4 f0, f1;
+    {
+        const float* Ap = As + (64 * wm + li) * A_LD + 4 * hi;
+        const float* Bp = Bs + (64 * wn + li) * A_LD + 4 * hi;
+        WA_READ(f0, Ap, Bp, 0);
+    }
+    {
+        int c = 0;
+        for (; c + 2 < nch; ++c) WA_BODY(c, true, true)
+        if (c + 1 < nch) {
+            WA_BODY(c, true, false)
+            ++c;
+        }
+        WA_BODY(c, false, false)
+    }
+#undef WA_BODY
+#undef WA_IL
+#undef WA_FENCE
+#undef WA_MMA
+#undef WA_MMA1
+#undef WA_READ
+#undef WA_LOAD
+#undef WA_STORE
+    WG_STAMP(4, __builtin_readcyclecounter());
+    const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
+    const WgDst dW = wg_dst(a, a.gW[0], a.poW[0], slice), db = wg_dst(a, a.gb[0], a.pob[0], slice);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            wg_emit16(a, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
+    if (kf0 == 0) {
+        // bias gradient: 8 threads (s_c4) hold partial sums of rows s_row + {0, 32, 64, 96}
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            rs0 += __shfl_xor(rs0, off, 64);
+            rs1 += __shfl_xor(rs1, off, 64);
+            rs2 += __shfl_xor(rs2, off, 64);
+            rs3 += __shfl_xor(rs3, off, 64);
+        }
+        if (s_c4 == 0) {
+            const size_t gb = (size_t)l * HID + s_row;
+            wg_emit1(a, db, a.ob[0], gb, rs0);
+            wg_emit1(a, db, a.ob[0], gb + 32, rs1);
+            wg_emit1(a, db, a.ob[0], gb + 64, rs2);
+            wg_emit1(a, db, a.ob[0], gb + 96, rs3);
+        }
+    }
+    WG_STAMP(5, __builtin_readcyclecounter());
+    WG_STAMP(6, wall_clock64());
+}
+
+// dW_i quadrant through the shared C = A B^T tile routine (tile_nt.h): both operands are plain (L, 128, B) rows now
+// that the forward saves activations - no softplus while staging, loads two chunks ahead, four accumulator chains.
+// Needs the slice length to be a multiple of 64 (the 32-chunk form below takes the rest).
+__device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, float* lds, int unit, int slice) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int quad = unit & 3;
+    const int rest = unit >> 2;
+    const int l = rest % a.L;
+    const int i = 1 + rest / a.L;
+    const int n0 = (quad >> 1) * 64, k0 = (quad & 1) * 64;
+    const float* A = a.dz[i] + ((size_t)l * HID + n0) * a.B;
+    const float* Bm = a.zsave[i - 1] + ((size_t)l * HID + k0) * a.B;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int b0 = slice * a.Bs;
+    if (k0 == 0) nsvd_tile_nt<true>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
+    else nsvd_tile_nt<false>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
+    wg_emit16(a, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
+              ((size_t)l * HID + n0 + 32 * (wv & 1)) * HID + k0 + 32 * (wv >> 1) + li, HID, hi, acc);
+    if (k0 == 0) {
+        // bias gradient: the 16 threads t & 15 of a staging row hold partial sums of rows (t >> 4) + 16 j
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) rs[j] += __shfl_xor(rs[j], off, 64);
+        if ((tid & 15) == 0) {
+            const WgDst db = wg_dst(a, a.gb[i], a.pob[i], slice);
+            const size_t gb = (size_t)l * HID + n0 + (tid >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wg_emit1(a, db, a.ob[i], gb + 16 * j, rs[j]);
+        }
+    }
+}
+
+__device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, float* Bs, int unit, int slice) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int nh = a.nlayers - 1;
+    // unit -> (layer i in 1..nh-1, head l, quadrant)
+    const int quad = unit & 3;
+    const int rest = unit >> 2;
+    const int l = rest % a.L;
+    const int i = 1 + rest / a.L;
+    (void)nh;
+    const int n0 = (quad >> 1) * 64, k0 = (quad & 1) * 64;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4; two slabs per operand (64 rows)
+    const float* a_src = a.dz[i] + ((size_t)l * HID + n0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
+    const float* b_src = a.zsave[i - 1] + ((size_t)l * HID + k0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
+    const size_t step = (size_t)32 * a.B;
+    float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+    float rs0 = 0.f, rs1 = 0.f;
+    constexpr int TS = 64 * A_LD;  // one 64-row tile
+#define WB_LOAD(S, c)                                 \
+    {                                                 \
+        WG_LD(S##a0, a_src + (c) * BK);               \
+        WG_LD(S##a1, a_src + (c) * BK + step);        \
+        WG_LD(S##b0, b_src + (c) * BK);               \
+        WG_LD(S##b1, b_src + (c) * BK + step);        \
+    }
+#define WB_STORE(S, buf)                                                \
+    {                                                                   \
+        float* Ab_ = As + (buf) * TS + s_row * A_LD + 4 * s_c4;         \
+        float* Bb_ = Bs + (buf) * TS + s_row * A_LD + 4 * s_c4;         \
+        WG_ST(Ab_, S##a0);                                              \
+        WG_ST(Ab_ + 32 * A_LD, S##a1);                                  \
+        WG_ST(Bb_, S##b0);                                              \
+        WG_ST(Bb_ + 32 * A_LD, S##b1);                                  \
+        rs0 += (S##a0.x + S##a0.y) + (S##a0.z + S##a0.w);               \
+        rs1 += (S##a1.x + S##a1.y) + (S##a1.z + S##a1.w);               \
+    }
+#define WB_COMPUTE(cur)                                                                        \
+    {                                                                                          \
+        const float* Ap = As + (cur) * TS + (32 * wm + li) * A_LD + 4 * hi;                    \
+        const float* Bp = Bs + (cur) * TS + (32 * wn + li) * A_LD + 4 * hi;                    \
+        _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                   \
+            const float4 av = *reinterpret_cast<const float4*>(Ap + 8 * q);                    \
+            const float4 bv = *reinterpret_cast<const float4*>(Bp + 8 * q);                    \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);              \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);              \
+        }                                                                                      \
+    }
+    const int nch = a.Bs / BK;
+    pa0 = pa1 = pb0 = pb1 = qa0 = qa1 = qb0 = qb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    WB_LOAD(p, 0);
+    if (nch > 1) WB_LOAD(q, 1);
+    WB_STORE(p, 0);
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 2 < nch) WB_LOAD(p, c + 2);
+        WB_COMPUTE(0);
+        if (c + 1 < nch) WB_STORE(q, 1);
+        __syncthreads();
+        if (c + 1 < nch) {
+            if (c + 3 < nch) WB_LOAD(q, c + 3);
+            WB_COMPUTE(1);
+            if (c + 2 < nch) WB_STORE(p, 0);
+            __syncthreads();
+        }
+    }
+#undef WB_COMPUTE
+#undef WB_LOAD
+#undef WB_STORE
+    wg_emit16(a, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
+              ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li, HID, hi, acc);
+    if (k0 == 0) {
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            rs0 += __shfl_xor(rs0, off, 64);
+            rs1 += __shfl_xor(rs1, off, 64);
+        }
+        if (s_c4 == 0) {
+            const size_t gb = (size_t)l * HID + n0 + s_row;
+            const WgDst db = wg_dst(a, a.gb[i], a.pob[i], slice);
+            wg_emit1(a, db, a.ob[i], gb, rs0);
+            wg_emit1(a, db, a.ob[i], gb + 32, rs1);
+        }
+    }
+}
+
+__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int unit, int slice) {
+    const int l = unit >> 2, part = unit & 3;  // 4 workgroups per head: 32 of the 128 rows each
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int nh = a.nlayers - 1;
+    float* red = lds;            // [8]
+    float* dbl = lds + 16;       // [Bs] dbase of this head (Bs <= 2 * 128 * 36 - 16 floats, checked on the host)
+    const size_t row0 = (size_t)l * a.B + (size_t)slice * a.Bs;  // this slice's rows of the head's (B) vectors
+    float sb = 0.f, ss = 0.f;
+    for (int b = tid; b < a.Bs; b += 256) {
+        const float v = a.dbase[row0 + b];
+        dbl[b] = v;
+        sb += v;
+        if (a.dfsc) ss += a.dfsc[row0 + b];
+    }
+    sb = nsvd_wave_sum(sb);
+    ss = nsvd_wave_sum(ss);
+    if (lane == 0) {
+        red[w] = sb;
+        red[4 + w] = ss;
+    }
+    __syncthreads();
+    if (tid == 0 && part == 0) {
+        wg_emit1(a, wg_dst(a, a.gb[nh], a.pob[nh], slice), a.ob[nh], l, (red[0] + red[1]) + (red[2] + red[3]));
+        if (a.dfsc)
+            wg_emit1(a, wg_dst(a, a.gscales, a.poscales, slice), a.oscales, l,
+                     (red[4] + red[5]) + (red[6] + red[7]));
+    }
+    // dW_last[n] = sum_b dbase[b] softplus(z[n][b]): each wave owns 32 rows and walks them 8 at a time so
+    // that 8 independent 16-B loads are in flight per lane (a row-at-a-time loop is pure L2 latency)
+    {
+        const int n0 = 32 * part + 8 * w;  // this wave's 8 rows
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        const float* zrow = a.zsave[nh - 1] + (size_t)slice * a.Bs;
+        for (int b = 4 * lane; b < a.Bs; b += 256) {
+            float4 z[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                z[j] = *reinterpret_cast<const float4*>(zrow + ((size_t)l * HID + n0 + j) * a.B + b);
+            const float4 d = *reinterpret_cast<const float4*>(dbl + b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] = fmaf(d.x, z[j].x, s[j]);
+                s[j] = fmaf(d.y, z[j].y, s[j]);
+                s[j] = fmaf(d.z, z[j].z, s[j]);
+                s[j] = fmaf(d.w, z[j].w, s[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = nsvd_wave_sum(s[j]);
+            if (lane == 0)
+                wg_emit1(a, wg_dst(a, a.gW[nh], a.poW[nh], slice), a.oW[nh], (size_t)l * HID + n0 + j, t);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem_wg[4 * HID * A_LD];  // 72 KB: two blocks per CU
+    static_assert(4 * HID * A_LD >= NSVD_TNT_FLOATS, "tile_nt buffers must fit the weight-gradient LDS");
+    float* As = smem_wg;
+    float* Bs = smem_wg + 2 * HID * A_LD;
+    // grid = S x (nA | nB | 4 L) blocks, kind-major so that the long dW_0 tiles are dispatched first
+    int bid = blockIdx.x + a.bid0;
+    if (bid < a.nA * a.S) {
+        const int slice = bid / a.nA;
+        bid -= slice * a.nA;
+        // heads share an XCD (dz_0[l] stays in that L2) when the tile count allows the remap
+        int unit = bid;
+        if ((a.nA & 7) == 0) unit = (bid & 7) * (a.nA >> 3) + (bid >> 3);
+        wgrad_tile_A(a, As, Bs, unit, slice);
+        return;
+    }
+    bid -= a.nA * a.S;
+    if (bid < a.nB * a.S) {
+        WG_STAMP(0, 2ull);
+        WG_STAMP(1, wall_clock64());
+        if (a.Bs % NSVD_TNT_KC == 0) wgrad_tile_B64(a, smem_wg, bid % a.nB, bid / a.nB);
+        else wgrad_tile_B(a, As, Bs, bid % a.nB, bid / a.nB);
+        WG_STAMP(6, wall_clock64());
+        return;
+    }
+    bid -= a.nB * a.S;
+    WG_STAMP(0, 3ull);
+    WG_STAMP(1, wall_clock64());
+    wgrad_tile_C(a, As, bid % (4 * a.L), bid / (4 * a.L));
+    WG_STAMP(6, wall_clock64());
+}
+
+// Split-K second pass: gradient = sum of the S partial slices (in slice order), then stored and / or applied
+// (RMSprop + EMA) exactly as the S = 1 epilogue does. One launch over all tensors of the model.
+struct ReduceArgs {
+    const float* part;
+    size_t part_stride;
+    int S, ntensors, opt;
+    NsvdHyper h;
+    size_t off[2 * NSVD_MAX_LAYERS + 1], n[2 * NSVD_MAX_LAYERS + 1];  // slice offset / element count (multiples of 4)
+    float* g[2 * NSVD_MAX_LAYERS + 1];
+    NsvdOptPtrs o[2 * NSVD_MAX_LAYERS + 1];
+    size_t total4;  // float4 groups over all tensors
+};
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < a.total4; q += (size_t)gridDim.x * 256) {
+        // tensors are laid out back to back (padded to 4 floats) inside a slice: find the one holding group q
+        int t = 0;
+        size_t e = q * 4;
+        while (t + 1 < a.ntensors && e >= a.off[t + 1]) ++t;
+        e -= a.off[t];
+        if (e >= a.n[t]) continue;  // alignment padding between tensors
+        const float* src = a.part + a.off[t] + e;
+        float4 gsum = *reinterpret_cast<const float4*>(src);
+        for (int sl = 1; sl < a.S; ++sl) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * a.part_stride);
+            gsum.x += v.x; gsum.y += v.y; gsum.z += v.z; gsum.w += v.w;
+        }
+        const int cnt = a.n[t] - e < 4 ? (int)(a.n[t] - e) : 4;
+        const float gv[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+        for (int c = 0; c < cnt; ++c) {
+            if (a.g[t]) a.g[t][e + c] = gv[c];
+            if (a.opt) {
+                const NsvdOptPtrs& o = a.o[t];
+                float pv = o.p[e + c], sv = o.sq[e + c], ev = o.ema ? o.ema[e + c] : 0.f;
+                nsvd_rmsprop_upd(pv, gv[c], sv, ev, o.ema != nullptr, a.h);
+                o.p[e + c] = pv;
+                o.sq[e + c] = sv;
+                if (o.ema) o.ema[e + c] = ev;
+            }
+        }
+    }
+}
+#undef WG_LD
+#undef WG_ST
+
+}  // namespace
+
+
+static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, int B, const float* df,
+                               const NsvdEvdIn* evd, const nsvd_params* gp, const NsvdOptStep* opt, void* ws,
+                               hipStream_t s) {
+    nsvd_params g;
+    memset(&g, 0, sizeof(g));
+    if (gp) g = *gp;
+    const FusedWs w = carve_fused(d, B, ws);
+    const int F = 2 * d.m, nh = d.nlayers - 1;
+
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.df = df;
+    if (evd) a.evd = *evd;
+    a.jac = w.jac;
+    a.dsc = d.has_exp_mask ? w.dsc : nullptr;
+    a.dbase = w.dbase;
+    a.dfsc = d.has_exp_mask ? w.dfsc : nullptr;
+    for (int i = 0; i < d.nlayers; ++i) {
+        a.W[i] = p.W[i];
+        a.zsave[i] = (i < nh) ? w.zsave[i] : nullptr;
+        a.dz[i] = (i < nh) ? w.dz[i] : nullptr;
+    }
+    a.nlayers = d.nlayers; a.B = B; a.L = d.L;
+    hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel, dim3((B / BS) * d.L), dim3(256), 0, s, a);
+    NSVD_CHECK_LAUNCH();
+
+    WgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    for (int i = 0; i < d.nlayers; ++i) {
+        wa.dz[i] = (i < nh) ? w.dz[i] : nullptr;
+        wa.zsave[i] = (i < nh) ? w.zsave[i] : nullptr;
+        wa.gW[i] = g.W[i];
+        wa.gb[i] = g.b[i];
+    }
+    wa.phiTc = w.phiTc;
+    wa.dbase = w.dbase;
+    wa.dfsc = d.has_exp_mask ? w.dfsc : nullptr;
+    wa.gscales = d.has_exp_mask ? g.scales : nullptr;
+    wa.nlayers = d.nlayers; wa.B = B; wa.L = d.L; wa.F = F;
+    if (opt) {
+        wa.opt = 1;
+        wa.h = opt->h;
+        for (int i = 0; i < d.nlayers; ++i) {
+            wa.oW[i] = NsvdOptPtrs{p.W[i], opt->sq.W[i], opt->ema ? opt->ema->W[i] : nullptr};
+            wa.ob[i] = NsvdOptPtrs{p.b[i], opt->sq.b[i], opt->ema ? opt->ema->b[i] : nullptr};
+        }
+        if (d.has_exp_mask) wa.oscales = NsvdOptPtrs{p.scales, opt->sq.scales, opt->ema ? opt->ema->scales : nullptr};
+    }
+    wa.nA = (F / HID) * d.L;
+    wa.nB = 4 * (nh - 1) * d.L;
+    wa.S = wgrad_slices(d, B);
+    wa.Bs = B / wa.S;
+    const PartLayout pl = part_layout(d);
+    if (wa.S > 1) {
+        wa.part = w.gpart;
+        wa.part_stride = pl.stride;
+        for (int i = 0; i < d.nlayers; ++i) {
+            wa.poW[i] = pl.oW[i];
+            wa.pob[i] = pl.ob[i];
+        }
+        wa.poscales = pl.oscales;
+    }
+    // One launch: the dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
+    // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
+    wa.bid0 = 0;
+    hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.S * (wa.nA + wa.nB + 4 * d.L)), dim3(256), 0, s, wa);
+    NSVD_CHECK_LAUNCH();
+    if (wa.S == 1) return 0;
+    ReduceArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.part = w.gpart;
+    ra.part_stride = pl.stride;
+    ra.S = wa.S;
+    ra.opt = wa.opt;
+    ra.h = wa.h;
+    int t = 0;
+    for (int i = 0; i < d.nlayers; ++i, ++t) {
+        ra.off[t] = pl.oW[i]; ra.n[t] = pl.nW[i]; ra.g[t] = g.W[i]; ra.o[t] = wa.oW[i];
+    }
+    for (int i = 0; i < d.nlayers; ++i, ++t) {
+        ra.off[t] = pl.ob[i]; ra.n[t] = pl.nb[i]; ra.g[t] = g.b[i]; ra.o[t] = wa.ob[i];
+    }
+    if (d.has_exp_mask) {
+        ra.off[t] = pl.oscales; ra.n[t] = pl.nscales; ra.g[t] = g.scales; ra.o[t] = wa.oscales;
+        ++t;
+    }
+    ra.ntensors = t;
+    ra.total4 = (pl.oscales + (pl.nscales + 3) / 4 * 4) / 4;
+    size_t blocks = (ra.total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ra);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+#ifdef NSVD_WG_STAMPS
+extern "C" int nsvd_debug_wgrad_stamps(unsigned long long* host, size_t n) {
+    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), n * sizeof(unsigned long long));
+}
+#endif
+
+int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                        int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s) {
+    (void)prob;
+    (void)x;
+    return fused_backward_impl(d, p, B, df, nullptr, &g, nullptr, ws, s);
+}
+
+int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
+                            const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s) {
+    if (!g && !opt) return NSVD_EINVAL;
+    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s);
+}

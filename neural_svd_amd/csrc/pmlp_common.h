@@ -1,0 +1,125 @@
+// Shared by the two translation units of the fused MFMA path (pmlp_fwd.hip, pmlp_bwd.hip): tile constants, the
+// accumulator layout of v_mfma_f32_32x32x2_f32, and the workspace layout.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+#include "nsvd_kernels.h"
+
+namespace nsvd_pmlp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HID = 128;      // hidden width
+constexpr int BS = 32;        // base samples per workgroup
+constexpr int BK = 32;        // layer-0 K chunk
+constexpr int A_LD = BK + 4;  // padded row of the W_0 tile (floats)
+
+// accumulator register r of lane-half hi holds row (r&3) + 8 (r>>2) + 4 hi of the 32-row tile
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// One q-group = 8 consecutive k: fragment loads (one ds_read_b128 per 32-row tile: 4 k's for each of the
+// two lane halves) and the 4 x E MFMAs that consume them.
+template <int E>
+struct Frag {
+    float4 a;
+    float4 b[E];
+};
+
+template <int E>
+__device__ __forceinline__ void load_frag(Frag<E>& f, const float* Ap, const float* Bp, int ldb) {
+    f.a = *reinterpret_cast<const float4*>(Ap);
+#pragma unroll
+    for (int e = 0; e < E; ++e) f.b[e] = *reinterpret_cast<const float4*>(Bp + e * BS * ldb);
+}
+
+template <int E>
+__device__ __forceinline__ void mma_frag(f32x16 (&acc)[E], const Frag<E>& f) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a.x, f.b[e].x, acc[e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a.y, f.b[e].y, acc[e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a.z, f.b[e].z, acc[e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a.w, f.b[e].w, acc[e], 0, 0, 0);
+}
+
+constexpr int H_LD = HID + 4;  // padded row of the activation image [column][k]
+
+struct FusedWs {
+    float* phi;                       // (B, F) sample-major Fourier features of the centre rows
+    float* sctab;                     // (D, 2, m) cos / sin of eps * fourier_B (stencil rows by angle addition)
+    float* phiTc;                     // (F, B) feature-major copy of the centre rows (weight gradient)
+    float* zsave[NSVD_MAX_LAYERS];    // (L, 128, B) per hidden layer
+    float* jac;                       // (B, L)
+    float* dsc;                       // (B, L)
+    float* dz[NSVD_MAX_LAYERS];       // (L, 128, B) per hidden layer
+    float* dbase;                     // (L, B)
+    float* dfsc;                      // (L, B)
+    float* gpart;                     // (S, slice) split-K partial gradients, S = wgrad_slices() > 1 only
+    unsigned short* w0p;              // (3, L, 128, F) bf16 planes of W_0 (NSVD_PATH_FUSED_BF16X3 only)
+    size_t bytes;
+};
+
+// Batch slices of the weight-gradient contraction: doubled while the dW_0 tile count leaves CUs idle and a slice
+
+// keeps at least 256 rows (8 chunks) to amortise a tile's prologue and epilogue.
+inline int wgrad_slices(const nsvd_model_desc& d, int B) {
+    const int nA = (2 * d.m / HID) * d.L;
+    int S = 1;
+    while (S < 16 && nA * S < 256 && (B / (2 * S)) % BK == 0 && B / (2 * S) >= 256) S *= 2;
+    return S;
+}
+
+// per-slice layout of the partial gradients: [W_0 | .. | W_n | b_0 | .. | b_n | scales], each padded to 4 floats
+struct PartLayout {
+    size_t oW[NSVD_MAX_LAYERS], ob[NSVD_MAX_LAYERS], oscales, nW[NSVD_MAX_LAYERS], nb[NSVD_MAX_LAYERS], nscales;
+    size_t stride;
+};
+inline PartLayout part_layout(const nsvd_model_desc& d) {
+    PartLayout p;
+    memset(&p, 0, sizeof(p));
+    size_t off = 0;
+    auto put = [&](size_t n) { const size_t o = off; off += (n + 3) / 4 * 4; return o; };
+    for (int i = 0; i < d.nlayers; ++i) {
+        p.nW[i] = (size_t)d.L * d.dims[i] * (i == 0 ? 2 * (size_t)d.m : (size_t)d.dims[i - 1]);
+        p.oW[i] = put(p.nW[i]);
+    }
+    for (int i = 0; i < d.nlayers; ++i) {
+        p.nb[i] = (size_t)d.L * d.dims[i];
+        p.ob[i] = put(p.nb[i]);
+    }
+    p.nscales = d.has_exp_mask ? (size_t)d.L : 0;
+    p.oscales = put(p.nscales);
+    p.stride = (off + 63) / 64 * 64;
+    return p;
+}
+
+inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
+    FusedWs w;
+    memset(&w, 0, sizeof(w));
+    const size_t F = 2 * (size_t)d.m;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float* q = (float*)(p + off);
+        off += nsvd_align(nfloats * sizeof(float));
+        return q;
+    };
+    w.phi = take(F * B);
+    w.sctab = take((size_t)2 * d.D * d.m);
+    w.phiTc = take(F * B);
+    for (int i = 0; i < d.nlayers - 1; ++i) w.zsave[i] = take((size_t)d.L * HID * B);
+    w.jac = take((size_t)B * d.L);
+    w.dsc = take((size_t)B * d.L);
+    for (int i = 0; i < d.nlayers - 1; ++i) w.dz[i] = take((size_t)d.L * HID * B);
+    w.dbase = take((size_t)B * d.L);
+    w.dfsc = take((size_t)B * d.L);
+    const int S = wgrad_slices(d, B);
+    w.gpart = S > 1 ? take((size_t)S * part_layout(d).stride) : nullptr;
+    w.w0p = (unsigned short*)take(((size_t)3 * d.L * HID * F + 1) / 2);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace nsvd_pmlp

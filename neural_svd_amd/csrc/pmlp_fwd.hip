@@ -1,0 +1,716 @@
+// Fused MFMA path for the headline shapes: every hidden layer 128 wide, B % 32 == 0, F % 32 == 0.
+//
+// FORWARD  (pmlp_fused_fwd_kernel): one workgroup = one head l x one block of 32 base samples x all
+// E = 1+2D stencil points (NC = 32 E sample columns), 4 waves, one per SIMD.  The whole per-head MLP
+// chain runs "transposed" - hidden units on the MFMA M axis, samples on the lane (N) axis:
+//     Z_i^T[n][c] = sum_k W_i[n][k] * A_{i-1}^T[k][c]
+// so a v_mfma_f32_32x32x2_f32 accumulator (column = lane, rows = registers) of layer i is, after
+// bias + softplus in registers, exactly the B operand layout of layer i+1's MFMAs; activations only
+// cross LDS once per layer (each wave owns 32 of the 128 hidden rows and needs all 128 as K).
+//   layer 0: K = F streamed in 32-wide chunks: W_0 tile (128 x 32, rows padded to 36 floats so the
+//            ds_read_b128 fragments are bank-conflict free) + phi^T tile (32 x NC) register-staged
+//            global -> LDS, double buffered, one barrier per chunk, loads for chunk c+1 in flight
+//            under the 80 MFMAs/wave of chunk c;
+//   layers 1..: W_i fragments straight from L2 (16 x 16 B per lane), B operand = LDS activations;
+//   last layer (128 -> 1): register dot product + cross-wave LDS reduction;
+//   epilogue: importance-weighted central-difference Hamiltonian (fd_math.h) -> f, Tf (B, L).
+// Grid = (B/32) * L workgroups (256 at hydrogen L=16, B=512: one per CU), remapped so that the
+// workgroups of one head share an XCD (its 1 MB W_0 stays in that XCD's L2).
+// Reference arithmetic being replaced: examples/models/mlp.py:204-221 x (1+2D) evaluations
+// (diff_ops.py:36-45) + diff_ops.py:9-23 + schrodinger/__init__.py:16-22 + examples/__init__.py:7-9.
+#include <type_traits>
+#include "pmlp_common.h"
+#include "fd_math.h"
+
+using namespace nsvd_pmlp;
+
+namespace {
+
+struct FwdArgs {
+    const float* phiT;   // (B, F) Fourier features of the CENTRE rows, sample-major: [sin(x.B) | cos(x.B)]
+    const float* sctab;  // (D, 2, m): cos(eps B_dj), sin(eps B_dj) - the stencil rows are built from the centre
+                         // features by angle addition while the layer-0 tiles are staged
+    int m;
+    int ldr;
+    const float* W[NSVD_MAX_LAYERS];
+    const float* b[NSVD_MAX_LAYERS];
+    int nlayers;  // weight matrices: nh hidden (128 wide) + the final 128 -> 1
+    const float* x;
+    const float* scales;
+    nsvd_problem prob;
+    float log_norm;
+    int B, D, L, F;
+    float* f;
+    float* Tf;
+    float* jac;
+    float* dsc;
+    float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null: ACTIVATIONS softplus(z) of the centre rows
+    const unsigned short* w0p;  // BF3 only: W_0 pre-split into three bf16 planes, (3, L, 128, F), by w0_split_kernel
+    size_t w0_plane;            // elements per plane
+    int plain;      // E = 1 instance only: out = hard_mul_const * base * mask (WaveFunctions.forward), no Hamiltonian;
+                    // f receives the output, jac / dsc its derivatives w.r.t. base / scales
+    int xcd_remap;  // 0: plain mapping; else HX = number of head groups across the 8 XCDs (1, 2, 4 or 8)
+    unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
+};
+
+
+
+// 16 bytes per lane global -> LDS without passing through VGPRs (global_load_lds_dwordx4). The LDS
+// destination is wave-uniform base + lane * 16; the global source is per lane.
+__device__ __forceinline__ void nsvd_glds16(const float* gsrc, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+#ifdef NSVD_FWD_STAMPS
+#define NSVD_STAMP(i)                                                                   \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define NSVD_STAMP(i)
+#endif
+#include "pmlp_layer0_bf3.h"
+
+// BF3 = 1: layer 0 on the bf16 MFMA with three-way split operands (nsvd_layer0_bf3 above); everything after layer 0 is
+//   the same code. Its stage buffers are larger, so the W tile of the hidden layers aliases their tail (one extra
+//   barrier after the K loop).
+template <int E, int JET, int BF3 = 0>
+__global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
+    constexpr int NC = E * BS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][128][A_LD]   W_0 tile, k contiguous
+    float* Bs = smem + 2 * HID * A_LD;      // [2][NC][A_LD]    phi tile (rows = sample columns), k contiguous
+    float* Hs = smem;                       // [NC][H_LD]       activations, k contiguous (aliases the stage buffers)
+    constexpr int STAGE = 2 * HID * A_LD + 2 * NC * A_LD;
+    constexpr int HSZ = NC * H_LD;
+    constexpr int STAGE3 = (2 * 3 * (HID + NC) * B3_ROW) / 4;  // floats
+    constexpr int WL_OFF = BF3 ? HSZ : (STAGE > HSZ ? STAGE : HSZ);
+    float* Wl = smem + WL_OFF;   // [4 waves][32][128]  next layer's W rows of each wave (XOR-swizzled chunks)
+    constexpr int RED_OFF = BF3 ? (STAGE3 > HSZ + HID * HID ? STAGE3 : HSZ + HID * HID) : WL_OFF + HID * HID;
+    float* red = smem + RED_OFF;                      // [4][NC]
+    float* outs = red + 4 * NC;                       // [NC]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int nsb = a.B / BS;
+    int l, sb;
+    if (a.xcd_remap) {
+        // blocks b and b+8 share an XCD (round-robin dispatch: speed only, never correctness). XCD x gets the
+        // head group x % HX and the sample-block group x / HX, so its L2 sees L/HX W_0 slabs and nsb/SX phi
+        // slabs instead of everything (HX * SX = 8, chosen on the host to minimise bytes per XCD).
+        const int HX = a.xcd_remap, SX = 8 / HX;
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int hpg = a.L / HX, spg = nsb / SX;  // heads / sample blocks per group
+        l = (x % HX) * hpg + slot % hpg;
+        sb = (x / HX) * spg + slot / hpg;
+    } else {
+        l = blockIdx.x / nsb;
+        sb = blockIdx.x - l * nsb;
+    }
+    const int b0 = sb * BS;
+
+    NSVD_STAMP(0)
+    // accumulators start from the bias (z = b + W a): its 16 loads fly under the first chunk's staging instead
+    // of sitting, exposed, between the K loop and the softplus
+    f32x16 acc[E];
+    {
+        const float* bi0 = a.b[0] + (size_t)l * HID + 32 * w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bi0[acc_row(r, hi)];
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e][r] = (JET && e > 0) ? 0.f : bv;
+        }
+    }
+
+    if constexpr (BF3) {
+        nsvd_layer0_bf3<E, JET>(a, acc, reinterpret_cast<char*>(smem), l, b0);
+        __syncthreads();  // the W-tile DMA below lands in the tail of the stage buffers
+    } else {
+    // ------------------------------------------------------------------ layer 0: K = F in chunks of BK
+    // Both operands are k-contiguous rows (W_0[l][n][:] and phi[r][:]): each thread moves one float4 of a
+    // 32-row slab per step, global -> registers -> LDS; chunk c+1 is in flight while chunk c is multiplied.
+    // Named registers, no arrays: hipcc leaves a conditionally written float4 array in scratch.
+    const float* W0 = a.W[0] + (size_t)l * HID * a.F;
+    const int nch = a.F / BK;
+    // K runs over PAIRS of chunks: 32 sin features k in [32 p, 32 p + 32) and their 32 cos partners m + k. The
+    // pair is loaded once (centre row only: 2 float4 per thread + the per-frequency constants) and the E stencil
+    // rows of both chunks are generated in registers by angle addition,
+    //   sin(t +- d) = sin t cos d +- cos t sin d,  cos(t +- d) = cos t cos d -+ sin t sin d,   d = eps B_dj,
+    // with the same float32 expressions the feature kernel used to evaluate: phi(x +- eps e_d) is never stored.
+    // (5x less feature traffic per tile; the feature kernel writes B x F instead of E x B x F.)
+    constexpr int DD = JET ? E - 2 : (E - 1) / 2;  // input dimensions
+    float4 ra0, ra1, ra2, ra3, rs, rc, cd0, sd0, cd1, sd1, cd2, sd2;
+    ra0 = ra1 = ra2 = ra3 = rs = rc = cd0 = sd0 = cd1 = sd1 = cd2 = sd2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4 per slab
+    const float* a_src = W0 + (size_t)s_row * a.F + 4 * s_c4;
+    const float* b_src = a.phiT + (size_t)(b0 + s_row) * a.F + 4 * s_c4;  // centre features, (B, F) row-major
+    const float* t_src = a.sctab + 4 * s_c4;
+    const size_t a_step = (size_t)32 * a.F;
+    const int mm = a.m;
+#define NSVD_LDG(p) (*reinterpret_cast<const float4*>(p))
+// chunk c = pair (c >> 1), half (c & 1): HALF = 0 the sin features, 1 their cos partners
+#define NSVD_LOAD_CHUNK(c, HALF)                                                 \
+    {                                                                            \
+        const int kp_ = ((c) >> 1) * BK;                                         \
+        const float* pa_ = a_src + ((HALF) ? mm : 0) + kp_;                      \
+        ra0 = NSVD_LDG(pa_);                                                     \
+        ra1 = NSVD_LDG(pa_ + a_step);                                            \
+        ra2 = NSVD_LDG(pa_ + 2 * a_step);                                        \
+        ra3 = NSVD_LDG(pa_ + 3 * a_step);                                        \
+        if (!(HALF)) {                                                           \
+            rs = NSVD_LDG(b_src + kp_);                                          \
+            rc = NSVD_LDG(b_src + mm + kp_);                                     \
+            if (DD > 0) cd0 = NSVD_LDG(t_src + kp_);                             \
+            if (DD > 0) sd0 = NSVD_LDG(t_src + mm + kp_);                        \
+            if (DD > 1) cd1 = NSVD_LDG(t_src + 2 * mm + kp_);                    \
+            if (DD > 1) sd1 = NSVD_LDG(t_src + 3 * mm + kp_);                    \
+            if (DD > 2) cd2 = NSVD_LDG(t_src + 4 * mm + kp_);                    \
+            if (DD > 2) sd2 = NSVD_LDG(t_src + 5 * mm + kp_);                    \
+        }                                                                        \
+    }
+#define NSVD_STS(p, v) (*reinterpret_cast<float4*>(p) = (v))
+// u cd + v sd and u cd - v sd, componentwise, as fmaf(u, cd, +-(v * sd)) (the feature kernel's expressions)
+#define NSVD_PM(plus, minus, u, v, cd, sd)                                                         \
+    {                                                                                              \
+        plus = make_float4(fmaf(u.x, cd.x, v.x * sd.x), fmaf(u.y, cd.y, v.y * sd.y),              \
+                           fmaf(u.z, cd.z, v.z * sd.z), fmaf(u.w, cd.w, v.w * sd.w));              \
+        minus = make_float4(fmaf(u.x, cd.x, -(v.x * sd.x)), fmaf(u.y, cd.y, -(v.y * sd.y)),        \
+                            fmaf(u.z, cd.z, -(v.z * sd.z)), fmaf(u.w, cd.w, -(v.w * sd.w)));       \
+    }
+// jet rows of a chunk: value u, derivative streams w * b_d (w = the partner feature, sign folded in), Laplacian -q u
+#define NSVD_MUL4(o, u, k) o = make_float4(u.x * k.x, u.y * k.y, u.z * k.z, u.w * k.w)
+#define NSVD_NMUL4(o, u, k) o = make_float4(-(u.x * k.x), -(u.y * k.y), -(u.z * k.z), -(u.w * k.w))
+#define NSVD_STORE_CHUNK(buf, HALF)                                              \
+    {                                                                            \
+        float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;          \
+        float* Bb_ = Bs + (buf) * NC * A_LD + s_row * A_LD + 4 * s_c4;           \
+        NSVD_STS(Ab_, ra0);                                                      \
+        NSVD_STS(Ab_ + 32 * A_LD, ra1);                                          \
+        NSVD_STS(Ab_ + 64 * A_LD, ra2);                                          \
+        NSVD_STS(Ab_ + 96 * A_LD, ra3);                                          \
+        float4 gp_, gm_;                                                         \
+        if (JET) {      /* table: cd_d = B_dj, sd0 = |B_j|^2 */                  \
+            if (!(HALF)) {  /* sin: d_d = B_d cos, Lap = -|B|^2 sin */           \
+                NSVD_STS(Bb_, rs);                                               \
+                if (DD > 0) { NSVD_MUL4(gp_, rc, cd0); NSVD_STS(Bb_ + 32 * A_LD, gp_); }   \
+                if (DD > 1) { NSVD_MUL4(gp_, rc, cd1); NSVD_STS(Bb_ + 64 * A_LD, gp_); }   \
+                if (DD > 2) { NSVD_MUL4(gp_, rc, cd2); NSVD_STS(Bb_ + 96 * A_LD, gp_); }   \
+                NSVD_NMUL4(gm_, rs, sd0);                                        \
+                NSVD_STS(Bb_ + (DD + 1) * 32 * A_LD, gm_);                       \
+            } else {        /* cos: d_d = -B_d sin, Lap = -|B|^2 cos */          \
+                NSVD_STS(Bb_, rc);                                               \
+                if (DD > 0) { NSVD_NMUL4(gp_, rs, cd0); NSVD_STS(Bb_ + 32 * A_LD, gp_); }  \
+                if (DD > 1) { NSVD_NMUL4(gp_, rs, cd1); NSVD_STS(Bb_ + 64 * A_LD, gp_); }  \
+                if (DD > 2) { NSVD_NMUL4(gp_, rs, cd2); NSVD_STS(Bb_ + 96 * A_LD, gp_); }  \
+                NSVD_NMUL4(gm_, rc, sd0);                                        \
+                NSVD_STS(Bb_ + (DD + 1) * 32 * A_LD, gm_);                       \
+            }                                                                    \
+        } else if (!(HALF)) {  /* sin rows: x + eps e_d -> s cd + c sd, x - eps e_d -> s cd - c sd */ \
+            NSVD_STS(Bb_, rs);                                                   \
+            if (DD > 0) { NSVD_PM(gp_, gm_, rs, rc, cd0, sd0) NSVD_STS(Bb_ + 32 * A_LD, gp_); NSVD_STS(Bb_ + 64 * A_LD, gm_); }   \
+            if (DD > 1) { NSVD_PM(gp_, gm_, rs, rc, cd1, sd1) NSVD_STS(Bb_ + 96 * A_LD, gp_); NSVD_STS(Bb_ + 128 * A_LD, gm_); }  \
+            if (DD > 2) { NSVD_PM(gp_, gm_, rs, rc, cd2, sd2) NSVD_STS(Bb_ + 160 * A_LD, gp_); NSVD_STS(Bb_ + 192 * A_LD, gm_); } \
+        } else {        /* cos rows: x + eps e_d -> c cd - s sd, x - eps e_d -> c cd + s sd */ \
+            NSVD_STS(Bb_, rc);                                                   \
+            if (DD > 0) { NSVD_PM(gp_, gm_, rc, rs, cd0, sd0) NSVD_STS(Bb_ + 32 * A_LD, gm_); NSVD_STS(Bb_ + 64 * A_LD, gp_); }   \
+            if (DD > 1) { NSVD_PM(gp_, gm_, rc, rs, cd1, sd1) NSVD_STS(Bb_ + 96 * A_LD, gm_); NSVD_STS(Bb_ + 128 * A_LD, gp_); }  \
+            if (DD > 2) { NSVD_PM(gp_, gm_, rc, rs, cd2, sd2) NSVD_STS(Bb_ + 160 * A_LD, gm_); NSVD_STS(Bb_ + 192 * A_LD, gp_); } \
+        }                                                                        \
+    }
+
+    // Software pipeline, one barrier per chunk (80 MFMAs per wave between barriers):
+    //   * fragments are read one q-group (8 k) ahead of the MFMAs that use them;
+    //   * the LAST q-group of chunk c is multiplied AFTER the barrier, under the first fragment reads of
+    //     chunk c+1 and the global loads of chunk c+2, so neither latency is exposed;
+    //   * chunk c+1 is written to the other LDS buffer in the shadow of chunk c's third q-group.
+    NSVD_LOAD_CHUNK(0, 0);
+    NSVD_STORE_CHUNK(0, 0);
+    __syncthreads();
+    NSVD_STAMP(1)
+    NSVD_LOAD_CHUNK(1, 1);  // nch = F / 32 is even and >= 4 (F is a multiple of 128)
+    Frag<E> f0, f1;
+    {
+        const float* Ap = As + (32 * w + li) * A_LD + 4 * hi;
+        const float* Bp = Bs + li * A_LD + 4 * hi;
+        load_frag<E>(f0, Ap, Bp, A_LD);
+    }
+    // __builtin_amdgcn_sched_barrier(0) fences pin the phase order below; without them hipcc sinks the
+    // fragment reads next to their first use and parks the LDS stores right in front of the barrier,
+    // which exposes both latencies once per chunk.
+#define NSVD_FENCE() __builtin_amdgcn_sched_barrier(0)
+// n x { 1 MFMA, 1 instruction of class `mask` } in the current scheduling region (LLVM SchedGroupMask:
+// 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
+#define NSVD_INTERLEAVE(n, mask)                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+        __builtin_amdgcn_sched_group_barrier((mask), 1, 0);        \
+    }
+    // each region = 4E MFMAs + the memory instructions of the NEXT stage, interleaved one per MFMA gap
+    // (sched_group_barrier): a memory instruction issued in the shadow of an executing MFMA is free, a
+    // block of 9..15 of them in a row stalls the matrix pipe for ~250..500 cycles per chunk.
+    // The steady-state body is branch free (the last two chunks are peeled) so every region is one
+    // basic block the scheduler can interleave.
+// PAR = parity of c: chunk c+1 (stored here) is the other half of a pair, chunk c+2 (loaded here) the same half
+#define NSVD_CHUNK_BODY(c, DO_STORE, DO_LOAD, PAR)                                              \
+    {                                                                                           \
+        const int cur = (c) & 1;                                                                \
+        const float* Ap = As + cur * HID * A_LD + (32 * w + li) * A_LD + 4 * hi;                \
+        const float* Bp = Bs + cur * NC * A_LD + li * A_LD + 4 * hi;                            \
+        load_frag<E>(f1, Ap + 8, Bp + 8, A_LD);                                                 \
+        mma_frag<E>(acc, f0);                                                                   \
+        NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
+        NSVD_FENCE();                                                                           \
+        load_frag<E>(f0, Ap + 16, Bp + 16, A_LD);                                               \
+        mma_frag<E>(acc, f1);                                                                   \
+        NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
+        NSVD_FENCE();                                                                           \
+        load_frag<E>(f1, Ap + 24, Bp + 24, A_LD);                                               \
+        if (DO_STORE) NSVD_STORE_CHUNK(cur ^ 1, 1 - (PAR));                                     \
+        mma_frag<E>(acc, f0);                                                                   \
+        NSVD_INTERLEAVE(1 + E, 0x100);                                                          \
+        if (DO_STORE) NSVD_INTERLEAVE(4 + E, 0x200);                                            \
+        NSVD_FENCE();                                                                           \
+        __syncthreads();                                                                        \
+        if (DO_STORE) {                                                                         \
+            const float* An = As + (cur ^ 1) * HID * A_LD + (32 * w + li) * A_LD + 4 * hi;      \
+            const float* Bn = Bs + (cur ^ 1) * NC * A_LD + li * A_LD + 4 * hi;                  \
+            load_frag<E>(f0, An, Bn, A_LD);                                                     \
+        }                                                                                       \
+        if (DO_LOAD) NSVD_LOAD_CHUNK((c) + 2, (PAR));                                           \
+        mma_frag<E>(acc, f1);                                                                   \
+        if (DO_STORE) NSVD_INTERLEAVE(1 + E, 0x100);                                            \
+        if (DO_LOAD) NSVD_INTERLEAVE((PAR) ? 4 : 6 + 2 * DD, 0x020);                            \
+        NSVD_FENCE();                                                                           \
+    }
+    {
+        int c = 0;
+        for (; c + 2 < nch; c += 2) {
+            NSVD_CHUNK_BODY(c, true, true, 0)
+            NSVD_CHUNK_BODY(c + 1, true, true, 1)
+        }
+        NSVD_CHUNK_BODY(c, true, false, 0)      // c == nch - 2
+        NSVD_CHUNK_BODY(c + 1, false, false, 1)
+    }
+#undef NSVD_CHUNK_BODY
+#undef NSVD_LOAD_CHUNK
+#undef NSVD_STORE_CHUNK
+#undef NSVD_PM
+#undef NSVD_MUL4
+#undef NSVD_NMUL4
+#undef NSVD_LDG
+#undef NSVD_STS
+
+    }
+    NSVD_STAMP(2)
+    // ------------------------------------------------------------------ hidden layers 1 .. nh-1
+    const int nh = a.nlayers - 1;
+    for (int i = 0; i < nh; ++i) {
+        // next layer's weights for this wave (rows 32w..32w+31, all 128 columns) go global -> LDS by LDS-DMA
+        // (global_load_lds_dwordx4: no VGPRs, no ds_write), issued before the softplus so they land under
+        // it. One instruction moves 2 rows x 512 B; the tile is unpadded, so the 16-B chunks of row r are
+        // stored XOR-swizzled by (r & 15) - applied here on the SOURCE address, and again on the fragment
+        // reads below - which makes the ds_read_b128 fragment reads bank-conflict free.
+        // (Per-lane fragment loads straight from global touch 64 cache lines per instruction: 9k cycles.)
+        const bool has_next = (i + 1 < nh);
+        float* Wt = Wl + w * 32 * HID;
+        // order matters for the wait counters (vmcnt retires in issue order): the loads of the next layer's bias
+        // (or of the last layer's weights) are issued BEFORE the DMA, the pre-activation stores AFTER it, so that
+        // "vmcnt(#stores)" below means "the DMA has landed" without draining the stores. All of them land under
+        // the softplus.
+        float nb[16];  // next layer's bias rows of this lane, or (last hidden layer) the 128 -> 1 weights
+        {
+            const float* src = (has_next ? a.b[i + 1] : a.W[nh]) + (size_t)l * HID + 32 * w;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nb[r] = src[acc_row(r, hi)];
+        }
+        if (has_next) {
+            const float* Wn = a.W[i + 1] + ((size_t)l * HID + 32 * w + hi) * HID;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = 2 * j + hi;
+                nsvd_glds16(Wn + (size_t)(2 * j) * HID + 4 * (li ^ (row & 15)), Wt + 2 * j * HID);
+            }
+        }
+        // softplus in registers; the centre rows' ACTIVATIONS are saved for the backward (its kernels then need
+        // no softplus: sigmoid(z) = 1 - exp(-softplus(z)), and the weight gradients contract activations)
+        float* zs = a.zsave[i] ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
+        if (JET) {
+            // forward-mode jet through the softplus, all streams of a (row, sample) in this lane's registers
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z0 = acc[0][r];
+                const float s1 = nsvd_sigmoid(z0);
+                const float s2 = z0 > NSVD_SOFTPLUS_THRESHOLD ? 0.f : s1 * (1.f - s1);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 1; e < E - 1; ++e) {
+                    q = fmaf(acc[e][r], acc[e][r], q);
+                    acc[e][r] *= s1;
+                }
+                acc[E - 1][r] = fmaf(s1, acc[E - 1][r], s2 * q);
+                acc[0][r] = nsvd_softplus(z0);
+            }
+            if (zs) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = nsvd_softplus(acc[0][r]);
+            if (zs) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int e = 1; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
+        }
+        NSVD_STAMP(3 + 4 * i)
+        if (!has_next) {
+            // ---------------------------------------------------------- last layer 128 -> 1 (weights in nb)
+            float part[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) part[e] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int e = 0; e < E; ++e) part[e] = fmaf(nb[r], acc[e][r], part[e]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                part[e] += __shfl_xor(part[e], 32, 64);
+                if (hi == 0) red[w * NC + e * BS + li] = part[e];
+            }
+            break;
+        }
+        NSVD_STAMP(4 + 4 * i)
+        // raw barriers: __syncthreads() would drain the 16 stores above (vmcnt(0)) before every barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // previous LDS contents are dead
+        // registers 4g..4g+3 of a lane are 4 consecutive hidden rows 8g + 4hi + (0..3): one 16-B store
+        // into the [column][k] image
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float* hcol = Hs + (e * BS + li) * H_LD + 32 * w + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(hcol + 8 * g) =
+                    make_float4(acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]);
+        }
+        if (zs) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // DMA done, the 16 stores may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        NSVD_STAMP(5 + 4 * i)
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][r] = (JET && e > 0) ? 0.f : nb[r];
+        // K = 128 in 16 q-groups, fragments read one q-group ahead, one LDS read per MFMA gap
+        const float* Ap = Wt + li * HID;        // + 4 * ((2q + hi) ^ (li & 15)): swizzled 16-B chunk
+        const int sw = li & 15;
+        const float* Bp = Hs + li * H_LD + 4 * hi;
+        Frag<E> g0, g1;
+        load_frag<E>(g0, Ap + 4 * (hi ^ sw), Bp, H_LD);
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            load_frag<E>(g1, Ap + 4 * ((2 * (q + 1) + hi) ^ sw), Bp + 8 * (q + 1), H_LD);
+            mma_frag<E>(acc, g0);
+            NSVD_INTERLEAVE(1 + E, 0x100);
+            NSVD_FENCE();
+            if (q + 2 < 16) load_frag<E>(g0, Ap + 4 * ((2 * (q + 2) + hi) ^ sw), Bp + 8 * (q + 2), H_LD);
+            mma_frag<E>(acc, g1);
+            if (q + 2 < 16) NSVD_INTERLEAVE(1 + E, 0x100);
+            NSVD_FENCE();
+        }
+        NSVD_STAMP(6 + 4 * i)
+    }
+
+#undef NSVD_INTERLEAVE
+#undef NSVD_FENCE
+    NSVD_STAMP(12)
+    __syncthreads();
+    // ------------------------------------------------------------------ FD Hamiltonian epilogue
+    // one thread per (stencil point, sample): output of the 128 -> 1 layer, then g_e = sqrt p(x_e) c base_e mask(x_e)
+    // (the exp / sqrt heavy part, E x 32 threads wide instead of a 5-point loop on 32 threads)
+    float* gs = outs;         // [NC]   g_e
+    float* cen = red;         // [4][BS] centre: sqrt p, mask, |x|, base   (red is dead once read below)
+    if (E == 1 && a.plain) {
+        // model(x) = c * base * exp(-|x| / scales_l)   (reference pde/__init__.py:15-16), any input dimension
+        if (tid < BS) {
+            const int b = b0 + tid;
+            const float bv = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
+            const float c = a.prob.hard_mul_const;
+            float mk = 1.f, r = 0.f, s_l = 1.f;
+            if (a.scales) {
+                float r2 = 0.f;
+                for (int d = 0; d < a.D; ++d) {
+                    const float xv = a.x[(size_t)b * a.D + d];
+                    r2 = fmaf(xv, xv, r2);
+                }
+                r = sqrtf(r2);
+                s_l = a.scales[l];
+                mk = expf(-r / s_l);
+            }
+            const size_t idx = (size_t)b * a.L + l;
+            a.f[idx] = c * bv * mk;
+            if (a.jac) a.jac[idx] = c * mk;
+            if (a.dsc) a.dsc[idx] = a.scales ? c * bv * mk * r / (s_l * s_l) : 0.f;
+        }
+        NSVD_STAMP(14)
+        return;
+    }
+    if (JET) {
+        // streams of the 128 -> 1 layer (its bias joins the value stream), then the closed-form product rule
+        if (tid < NC)
+            gs[tid] = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + (tid < BS ? a.b[nh][l] : 0.f);
+        __syncthreads();
+        if (tid < BS) {
+            const int b = b0 + tid;
+            float xc[NSVD_FD_MAXD], db[NSVD_FD_MAXD];
+            for (int d = 0; d < a.D; ++d) {
+                xc[d] = a.x[(size_t)b * a.D + d];
+                db[d] = gs[(1 + d) * BS + tid];
+            }
+            const float s_l = a.scales ? a.scales[l] : 0.f;
+            const NsvdFdOut o = nsvd_fd_exact(gs[tid], db, gs[(E - 1) * BS + tid], xc, a.D, a.scales != nullptr, s_l,
+                                              a.prob, a.log_norm);
+            const size_t idx = (size_t)b * a.L + l;
+            a.f[idx] = o.f;
+            a.Tf[idx] = o.Tf;
+            if (a.jac) a.jac[idx] = o.jac;
+            if (a.dsc) a.dsc[idx] = o.dsc;
+        }
+        NSVD_STAMP(14)
+        return;
+    }
+    NsvdFdG og;
+    float bve = 0.f;
+    og.g = og.sp = og.mk = og.r = 0.f;
+    const int e_t = tid / BS, sidx = tid - e_t * BS;
+    if (tid < NC) {
+        bve = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
+        float xc[NSVD_FD_MAXD];
+        for (int d = 0; d < a.D; ++d) xc[d] = a.x[(size_t)(b0 + sidx) * a.D + d];
+        const float s_l = a.scales ? a.scales[l] : 0.f;
+        og = nsvd_fd_g(e_t, bve, xc, a.D, a.scales != nullptr, s_l, a.prob, a.log_norm);
+    }
+    __syncthreads();          // every thread has consumed its red[] inputs before the centre values overwrite them
+    if (tid < NC) {
+        gs[tid] = og.g;
+        if (e_t == 0) {
+            cen[sidx] = og.sp;
+            cen[BS + sidx] = og.mk;
+            cen[2 * BS + sidx] = og.r;
+            cen[3 * BS + sidx] = bve;
+        }
+    }
+    __syncthreads();
+    NSVD_STAMP(13)
+    if (tid < BS) {
+        const int b = b0 + tid;
+        float g[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) g[e] = gs[e * BS + tid];
+        const float s_l = a.scales ? a.scales[l] : 0.f;
+        const NsvdFdOut o = nsvd_fd_combine(g, cen[tid], cen[BS + tid], cen[2 * BS + tid], cen[3 * BS + tid], a.D,
+                                            a.scales != nullptr, s_l, a.prob);
+        const size_t idx = (size_t)b * a.L + l;
+        a.f[idx] = o.f;
+        a.Tf[idx] = o.Tf;
+        if (a.jac) a.jac[idx] = o.jac;
+        if (a.dsc) a.dsc[idx] = o.dsc;
+    }
+    NSVD_STAMP(14)
+}
+
+template <int E, int BF3 = 0>
+size_t fwd_lds_bytes() {
+    constexpr int NC = E * BS;
+    constexpr int STAGE = 2 * HID * A_LD + 2 * NC * A_LD;
+    constexpr int HSZ = NC * H_LD;
+    constexpr int STAGE3 = (2 * 3 * (HID + NC) * B3_ROW) / 4;
+    constexpr int RED_OFF = BF3 ? (STAGE3 > HSZ + HID * HID ? STAGE3 : HSZ + HID * HID)
+                                : (STAGE > HSZ ? STAGE : HSZ) + HID * HID;
+    return (RED_OFF + 5 * NC) * sizeof(float);
+}
+
+template <int E, int JET = 0, int BF3 = 0>
+int launch_fwd(const FwdArgs& a, hipStream_t s) {
+    const size_t lds = fwd_lds_bytes<E, BF3>();
+    static bool attr_done = false;  // idempotent, racing threads set the same value
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)pmlp_fused_fwd_kernel<E, JET, BF3>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    const int grid = (a.B / BS) * a.L;
+    nsvd_prof_begin(s);
+    hipLaunchKernelGGL((pmlp_fused_fwd_kernel<E, JET, BF3>), dim3(grid), dim3(256), lds, s, a);
+    nsvd_prof_end(s);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact) {
+    // E <= 5 columns per sample: the forward's LDS image (155 KB at E = 5). Stencil: E = 1 + 2D, so D <= 2; the
+    // exact-Laplacian jets have E = D + 2, so D <= 3.
+    if (d.D < 1 || d.D > (exact ? 3 : 2)) return false;
+    if (d.nlayers < 2) return false;
+    for (int i = 0; i < d.nlayers - 1; ++i)
+        if (d.dims[i] != HID) return false;
+    if (B % BS != 0 || B > 65536) return false;
+    if (B / wgrad_slices(d, B) > 8192) return false;  // one head's slice of dbase is staged in LDS (wgrad C)
+    if ((2 * d.m) % HID != 0) return false;  // layer-0 weight gradient uses 128-wide feature tiles
+    // the weight-gradient epilogue addresses every tensor with 32-bit byte offsets (W_0 is the largest)
+    if ((size_t)d.L * HID * (size_t)(2 * d.m) * sizeof(float) >= ((size_t)1 << 32)) return false;
+    return true;
+}
+
+size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B) { return carve_fused(d, B, nullptr).bytes; }
+
+int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                        int B, void* ws, int save, hipStream_t s, const NsvdSampler* sampler, float* xout) {
+    const FusedWs w = carve_fused(d, B, ws);
+    return nsvd_fourier_stencil(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, w.sctab, B, d.D, d.m, prob.eps,
+                                sampler, xout, s);
+}
+
+int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
+                       int B, float* f, float* Tf, void* ws, int save, hipStream_t s, int bf3) {
+    const FusedWs w = carve_fused(d, B, ws);
+    const int E = 1 + 2 * d.D, R = E * B, F = 2 * d.m;
+    int rc = 0;
+    if (!(save & 2)) {  // bit 1 of `save`: the features are already in the workspace (nsvd_fused_features)
+        rc = nsvd_fused_features(d, p, prob, x, B, ws, save & 1, s);
+        if (rc) return rc;
+    }
+    save &= 1;
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.phiT = w.phi;
+    a.sctab = w.sctab;
+    a.m = d.m;
+    a.ldr = R;
+    a.nlayers = d.nlayers;
+    for (int i = 0; i < d.nlayers; ++i) {
+        a.W[i] = p.W[i];
+        a.b[i] = p.b[i];
+        a.zsave[i] = (save && i < d.nlayers - 1) ? w.zsave[i] : nullptr;
+    }
+    a.x = x;
+    a.scales = d.has_exp_mask ? p.scales : nullptr;
+    a.prob = prob;
+    a.log_norm = nsvd_gauss_log_norm(d.D, prob.sigma);
+    a.B = B; a.D = d.D; a.L = d.L; a.F = F;
+    a.f = f; a.Tf = Tf;
+    a.jac = save ? w.jac : nullptr;
+    a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
+    // XCD-aware block mapping: split heads into HX groups and sample blocks into 8/HX groups, minimising the
+    // bytes each XCD pulls through its L2: (L/HX) * |W_0 slab| + (nsb/SX) * |phi slab|
+    {
+        const int nsb = B / BS;
+        double best = 1e300;
+        a.xcd_remap = 0;
+        for (int HX = 1; HX <= 8; HX *= 2) {
+            const int SX = 8 / HX;
+            if (d.L % HX != 0 || nsb % SX != 0) continue;
+            // (the feature slab is the centre rows only: the stencil rows are generated in the kernel)
+            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * F;
+            if (bytes < best) {
+                best = bytes;
+                a.xcd_remap = HX;
+            }
+        }
+    }
+#ifdef NSVD_FWD_STAMPS
+    a.stamps = (unsigned long long*)w.dz[0];  // diagnostic build: stamps land in the (then unused) dz_0 scratch
+#endif
+    if (bf3) {  // opt-in: layer 0 on the bf16 MFMA with three-way split operands
+        const size_t n4 = (size_t)d.L * HID * F / 4;
+        hipLaunchKernelGGL(w0_split_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const float4*>(p.W[0]),
+                           reinterpret_cast<uint2*>(w.w0p), n4);
+        NSVD_CHECK_LAUNCH();
+        a.w0p = w.w0p;
+        a.w0_plane = (size_t)d.L * HID * F;
+        if (prob.eps <= 0.f) {
+            switch (d.D) {
+                case 1: return launch_fwd<3, 1, 1>(a, s);
+                case 2: return launch_fwd<4, 1, 1>(a, s);
+                case 3: return launch_fwd<5, 1, 1>(a, s);
+            }
+            return NSVD_EUNSUPPORTED;
+        }
+        switch (E) {
+            case 3: return launch_fwd<3, 0, 1>(a, s);
+            case 5: return launch_fwd<5, 0, 1>(a, s);
+        }
+        return NSVD_EUNSUPPORTED;
+    }
+    if (prob.eps <= 0.f) {  // exact Laplacian: D + 2 jet streams
+        switch (d.D) {
+            case 1: return launch_fwd<3, 1>(a, s);
+            case 2: return launch_fwd<4, 1>(a, s);
+            case 3: return launch_fwd<5, 1>(a, s);
+        }
+        return NSVD_EUNSUPPORTED;
+    }
+    switch (E) {
+        case 3: return launch_fwd<3>(a, s);
+        case 5: return launch_fwd<5>(a, s);
+    }
+    return NSVD_EUNSUPPORTED;
+}
+
+// ---- plain model evaluation on the fused kernels (E = 1): out = c * model(x), any input dimension --------------
+bool nsvd_fused_model_supported(const nsvd_model_desc& d, int B) {
+    if (d.D < 1 || d.D > 64) return false;
+    if (d.nlayers < 2) return false;
+    for (int i = 0; i < d.nlayers - 1; ++i)
+        if (d.dims[i] != HID) return false;
+    if (B % BS != 0 || B > 65536) return false;
+    if (B / wgrad_slices(d, B) > 8192) return false;
+    if ((2 * d.m) % HID != 0) return false;
+    return true;
+}
+
+int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float c,
+                             float* out, void* ws, int save, hipStream_t s) {
+    const FusedWs w = carve_fused(d, B, ws);
+    const int F = 2 * d.m;
+    int rc = nsvd_fourier_plain(x, p.fourier_B, w.phi, save ? w.phiTc : nullptr, B, d.D, d.m, s);
+    if (rc) return rc;
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.phiT = w.phi;
+    a.m = d.m;
+    a.nlayers = d.nlayers;
+    for (int i = 0; i < d.nlayers; ++i) {
+        a.W[i] = p.W[i];
+        a.b[i] = p.b[i];
+        a.zsave[i] = (save && i < d.nlayers - 1) ? w.zsave[i] : nullptr;
+    }
+    a.x = x;
+    a.scales = d.has_exp_mask ? p.scales : nullptr;
+    a.prob.hard_mul_const = c;
+    a.plain = 1;
+    a.B = B; a.D = d.D; a.L = d.L; a.F = F;
+    a.f = out;
+    a.jac = save ? w.jac : nullptr;
+    a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
+    {
+        const int nsb = B / BS;
+        double best = 1e300;
+        for (int HX = 1; HX <= 8; HX *= 2) {
+            const int SX = 8 / HX;
+            if (d.L % HX != 0 || nsb % SX != 0) continue;
+            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * F;
+            if (bytes < best) {
+                best = bytes;
+                a.xcd_remap = HX;
+            }
+        }
+    }
+    return launch_fwd<1>(a, s);
+}

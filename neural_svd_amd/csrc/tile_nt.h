@@ -1,5 +1,5 @@
 // C = A B^T tile routine on the fp32-input MFMA, both operands K-contiguous: one 64 x 64 tile per 256-thread block.
-// Shared by the CDK loss contractions (cdk_loss.hip) and the hidden-layer weight gradients (pmlp_fused.hip).
+// Shared by the CDK loss contractions (cdk_loss.hip) and the hidden-layer weight gradients (pmlp_bwd.hip).
 #pragma once
 #include "nsvd_common.h"
 

@@ -4,6 +4,6 @@
 set -e
 cd "$(dirname "$0")/../neural_svd_amd/csrc"
 make -s
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-fast-math -ffp-contract=on -I../../include -DNSVD_FWD_STAMPS -c pmlp_fused.hip -o build/pmlp_st.o
-objs=$(ls build/*.o | grep -v -e pmlp_fused.o -e pmlp_wgst.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libnsvd_hip_stamps.so $objs
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-fast-math -ffp-contract=on -I../../include -DNSVD_FWD_STAMPS -c pmlp_fwd.hip -o build/diag_fwd_stamps.o
+objs=$(ls build/*.o | grep -v -e build/pmlp_fwd.o -e build/diag_)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libnsvd_hip_stamps.so $objs build/diag_fwd_stamps.o
