@@ -35,3 +35,6 @@ for name, (f, Tf) in out.items():
     kappa = float(np.median(np.abs(Tfr.double().cpu().numpy() - ref.Tf.numpy()) / np.maximum(s, 1e-300)))
     print(f"{name}: f rel err vs float64 {rel(fr, ref.f):.2e}; Tf rel err {rel(Tfr, ref.Tf):.2e}; FD-noise kappa (median) {kappa:.2f}")
 print("bf16x3 vs fp32: f", rel(out["bf16x3"][0], out["fp32"][0].double().cpu()), "Tf", rel(out["bf16x3"][1], out["fp32"][1].double().cpu()))
+import hashlib
+print("bf16x3 checksum f/Tf:", hashlib.sha1(out["bf16x3"][0].cpu().numpy().tobytes()).hexdigest()[:12],
+      hashlib.sha1(out["bf16x3"][1].cpu().numpy().tobytes()).hexdigest()[:12])
