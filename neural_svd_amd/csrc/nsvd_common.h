@@ -146,8 +146,11 @@ __device__ __forceinline__ void nsvd_sample_row(const NsvdSampler& s, int b, int
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
         if (2 * pr >= D) break;
-        const float u1 = ((float)(r[2 * pr] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1): 24 bits, never 0
-        const float u2 = ((float)(r[2 * pr + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        // (0, 1) strictly: 23 random bits + 1/2 is exact in float32 (24 bits); with 24 bits k + 1/2 rounds to even and
+        // k = 2^24 - 1 gives u1 = 1, a radius of exactly 0 - and the hydrogen potential -Z / |x| of that sample is -inf
+        // (it happened at step 4081 of a configs[1] run: once in 2^24 pairs)
+        const float u1 = ((float)(r[2 * pr] >> 9) + 0.5f) * (1.0f / 8388608.0f);
+        const float u2 = ((float)(r[2 * pr + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);
         const float rad = s.sigma * sqrtf(-2.0f * logf(u1));
         float sn, cs;
         sincosf(6.283185307179586f * u2, &sn, &cs);

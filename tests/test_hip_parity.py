@@ -374,6 +374,30 @@ def test_device_sampler(B, hidden):
     assert torch.equal(f1, f2) and torch.equal(Tf1, Tf2)
 
 
+def test_device_sampler_never_draws_the_origin():
+    """Regression: with 24 random bits + 1/2 the Box-Muller uniform rounded to exactly 1 once in 2^24 draws, the radius
+    was exactly 0 and the hydrogen potential of that sample -inf (first seen at batch 4080, row 217 of a configs[1]
+    run with sample key 1: every parameter was NaN one step later). The radius is now bounded below by
+    sigma * sqrt(-2 log(1 - 2^-24)) = 3.45e-4 sigma; that very draw is replayed here."""
+    D, m, sigma, B = 2, 64, 16.0, 512
+    shape = H.ModelShape(L=1, D=D, m=m, hidden=(128,))
+    p = O.init_params(1, D, m, (128,), 0.1, seed=1)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, sigma)
+    ws = H.new_workspace(shape, B, DEV)
+    x = torch.empty(B, D, device=DEV)
+    rmin = sigma * float(np.sqrt(-2.0 * np.log1p(-2.0 ** -24)))
+    H.operator_sample_features(shape, params, prob, 1, 4080, x, ws)
+    r = x.double().norm(dim=1)
+    assert float(r.min()) >= 0.99 * rmin and float(r[217]) < 100 * rmin, (float(r.min()), float(r[217]))
+    f, Tf = H.operator_forward(shape, params, prob, x, ws, features_ready=True)
+    assert torch.isfinite(f).all() and torch.isfinite(Tf).all()
+    for off in range(4000, 4200):
+        H.operator_sample_features(shape, params, prob, 1, off, x, ws)
+        assert float(x.double().norm(dim=1).min()) >= 0.99 * rmin, off
+
+
 @pytest.mark.parametrize("L,B,mask", [(2, 1024, True), (1, 2048, False)])
 def test_backward_split_k_matches_oracle(L, B, mask):
     """Few heads on many rows (what a head-parallel rank sees): the weight-gradient kernel splits the batch
