@@ -343,7 +343,7 @@ class FusedTrainer:
 
     # -- evaluation (methods/spectrum.py:29-102 under EMA weights, operator/__init__.py:108) ----
     @torch.no_grad()
-    def spectrum(self, lim: float, val_eps: float, use_ema: bool = True, chunk: int = 16384):
+    def spectrum(self, lim: float, val_eps: float, use_ema: bool = True, chunk: int = 8192):
         import numpy as np
         D, L = self.shape.D, self.shape.L
         ax = np.arange(-lim, lim, val_eps)

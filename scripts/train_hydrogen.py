@@ -39,8 +39,9 @@ def main():
                       num_iters=a.steps, sampling_scale=16.0, fourier_scale=0.1, seed=a.seed, device=dev, path=path)
     gt = 100.0 * -Hydrogen2D(1.0).get_eigvals(L)  # [100, 11.11 x3, 4 x5, 2.04 x7]
     evals = sorted({int(e) for e in a.evals.split(",") if int(e) <= a.steps} | {a.steps})
-    rec = dict(config="configs[1]: 2D hydrogen L=16 B=512 joint nesting, lr 1e-4 cosine, EMA 0.995, eps=%g, path=%s, seed %d"
-               % (a.laplacian_eps, a.path, a.seed), ground_truth=gt.tolist(), evals=[])
+    rec = dict(config="configs[1]: 2D hydrogen L=16 B=512 %s nesting, lr 1e-4 cosine, EMA 0.995, eps=%g, path=%s, seed %d"
+               % ("sequential" if a.sequential else "joint", a.laplacian_eps, a.path, a.seed),
+               ground_truth=gt.tolist(), evals=[])
     done, t_train = 0, 0.0
     for target in evals:
         torch.cuda.synchronize()
