@@ -355,7 +355,9 @@ class FusedTrainer:
         for i in range(0, grid.shape[0], chunk):
             xb = grid[i:i + chunk].contiguous()
             ws = H.new_workspace(self.shape, xb.shape[0], self.device)
-            f, Tf = H.operator_forward(self.shape, params, self.problem, xb, ws, False, self.path)
+            # a ragged last chunk is outside the MFMA kernels' shapes: let the library choose the path for it
+            path = self.path if xb.shape[0] % 32 == 0 else H.PATH_AUTO
+            f, Tf = H.operator_forward(self.shape, params, self.problem, xb, ws, False, path)
             H.spectrum_accumulate(f, Tf, xb, self.problem.sigma, bool(self.problem.use_importance), lim, cov, quad)
         n = grid.shape[0]
         cov, quad = cov.double().cpu() / n, quad.double().cpu() / n

@@ -232,6 +232,29 @@ def test_fused_trainer_learns_oscillator_mfma_path(eps):
     assert np.isfinite(err).all() and err.mean() < 2e-2, (out["eigvals"], err)
 
 
+@pytest.mark.parametrize("path", ["auto", "bf16x3"])
+def test_headline_config_soak(path):
+    """configs[1] with its own sampler, 6000 optimiser steps (1.6 s): parameters, EMA shadow and optimiser state stay
+    finite and the loss has dropped. (A sample drawn exactly at the origin - one in 2^24 with the first version of the
+    sampler - made every parameter NaN at step 4081 of this very run.)"""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    shape = H.ModelShape(L=16, D=2, m=1024, hidden=(128, 128, 128))
+    prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+    tr = FusedTrainer(shape, prob, 512, sequential=False, step=1, lr=1e-4, num_iters=500000, seed=0, device=DEV,
+                      path=H.PATH_FUSED_BF16X3 if path == "bf16x3" else H.PATH_AUTO)
+    losses = []
+    for i in range(6000):
+        tr.step()
+        if i % 500 == 499:
+            losses.append(float(tr.loss[0]))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), losses
+    for t in (tr.P.flat, tr.P.ema, tr.P.sq, tr.f, tr.Tf):
+        assert bool(torch.isfinite(t).all())
+    assert np.mean(losses[-4:]) < np.mean(losses[:2]) - 500.0, losses
+
+
 def test_model_autograd_and_compute_loss_kernel():
     """method(x) is differentiable (nsvd_model_forward/_backward), and compute_loss_kernel
     (methods/nestedlora.py:230-252, both split_batch modes) runs a user kernel operator built on it."""
