@@ -111,6 +111,43 @@ class NestedLoRALossFunctionEVD(torch.autograd.Function):
         return df, None, None, None, None, None
 
 
+class NestedLoRALossFunctionSVD(torch.autograd.Function):
+    """reference methods/nestedlora.py:114-164 (it has no caller there; the Function itself is complete):
+        loss = -2 mean_b sum_l v_l f_bl Tg_bl + sum(M * lam_f * lam_g),   lam_f = f^T f / B1, lam_g = g^T g / B2
+        d loss / d f = -(2 / B1) v * Tg    + (2 / B1) f @ (M * lam_g)
+        d loss / d g = -(2 / B2) v * Tadjf + (2 / B2) g @ (M * lam_f)
+    On the EVD kernels: with X = [f; g] and TX = [Tg; Tadjf] (B1 = B2 rows each) the two chunks of X are f and g, so
+    the moment kernel yields lam_f, lam_g and the metric term, and nsvd_evd_loss_grad's d loss / d X is exactly
+    [d loss / d f; d loss / d g] (-(4 / 2B1) v TX = -(2 / B1) v TX). Only the VALUE of the operator term differs
+    (the reference leaves g . Tadjf out of it): it is taken from a second moment call on [Tg; 0]."""
+
+    @staticmethod
+    def forward(ctx, f, Tg, g, Tadjf, vector_mask, matrix_mask):
+        if f.dim() != 2 or f.shape != g.shape or Tg.shape != f.shape or Tadjf.shape != g.shape:
+            raise NsvdError("NestedLoRALossFunctionSVD (HIP): f, Tg, g, Tadjf must be (B, L) with B1 == B2")
+        kind = _mask_kind(vector_mask, matrix_mask)
+        dev = f.device
+        v = vector_mask.to(dev).float().contiguous() if kind == H.MASK_CUSTOM else None
+        M = matrix_mask.to(dev).float().contiguous() if kind == H.MASK_CUSTOM else None
+        B1 = f.shape[0]
+        X = torch.cat([f.detach(), g.detach()]).float().contiguous()
+        TX = torch.cat([Tg.detach(), Tadjf.detach()]).float().contiguous()
+        moments = H.evd_moments(X, TX, kind, v)
+        loss3, dX = H.evd_loss_grad(X, TX, kind, v, M, moments, 1.0, True)
+        TX0 = TX.clone()
+        TX0[B1:].zero_()
+        op = H.evd_moments(X, TX0, kind, v)[-1]  # mean over the 2 B1 rows of sum_l v_l f Tg
+        ctx.B1 = B1
+        ctx.save_for_backward(dX)
+        return (-4.0 * op + loss3[2]).to(f.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (dX,) = ctx.saved_tensors
+        dX = dX * grad_output
+        return dX[:ctx.B1], None, dX[ctx.B1:], None, None, None
+
+
 class _OperatorFn(torch.autograd.Function):
     """(Tf, f) = operator(model, x, importance) through nsvd_operator_forward; the backward is
     nsvd_operator_backward (gradient through f only)."""
@@ -165,8 +202,8 @@ class NestedLoRA(nn.Module):
         self.sort_indices = None
 
     def _compute_loss(self, *args, evd=True) -> torch.Tensor:
-        if not evd:
-            raise NotImplementedError("the SVD loss has no caller in the reference and is not on this path")
+        if not evd:  # (f, Tg, g, Tadjf); like the reference, neither compute_loss_* reaches this with evd=False
+            return NestedLoRALossFunctionSVD.apply(*args, self.vector_mask, self.matrix_mask)
         return NestedLoRALossFunctionEVD.apply(*args, self.vector_mask, self.matrix_mask)
 
     def compute_loss_operator(self, operator, x, importance=None, evd: bool = True):

@@ -68,6 +68,17 @@ def evd_loss_forward(f, Tf, v, M):
     return loss_op + loss_metric, lam1, lam2, loss_op, loss_metric
 
 
+def svd_loss(f, Tg, g, Tadjf, v, M):
+    """NestedLoRALossFunctionSVD forward + backward (reference methods/nestedlora.py:114-164): f, Tg (B1, L);
+    g, Tadjf (B2, L). Returns loss, grad_f, grad_g. Pinned by tests/golden/svd_loss.npz."""
+    lam_f = f.T @ f / f.shape[0]              # compute_loss_metric, :57-64
+    lam_g = g.T @ g / g.shape[0]
+    loss = -2.0 * ((f * Tg) @ v).mean() + (M * lam_f * lam_g).sum()                      # :139-141
+    grad_f = -(2.0 / f.shape[0]) * Tg * v.unsqueeze(0) + (2.0 / f.shape[0]) * (f @ (M * lam_g))     # :157-159
+    grad_g = -(2.0 / g.shape[0]) * Tadjf * v.unsqueeze(0) + (2.0 / g.shape[0]) * (g @ (M * lam_f))  # :161-163
+    return loss, grad_f, grad_g
+
+
 def evd_loss_backward(f, Tf, v, M, lam1, lam2, grad_output=1.0):
     """reference methods/nestedlora.py:98-111; returns d loss / d f with the f1/f2 terms summed in.
 

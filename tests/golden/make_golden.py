@@ -302,6 +302,34 @@ def golden_cdk(out):
             out[q + "grad_f"], out[q + "grad_g"] = np64(f.grad), np64(gg.grad)
 
 
+def golden_svd(out):
+    """NestedLoRALossFunctionSVD (methods/nestedlora.py:114-164): loss and gradients w.r.t. f and g. The reference has
+    no caller for it (both compute_loss_* raise for evd=False); the Function itself is complete."""
+    from methods.nestedlora import NestedLoRA, NestedLoRALossFunctionSVD
+    g = torch.Generator().manual_seed(777)
+    cases = dict(a=dict(B=8, L=4, seq=True, step=1), b=dict(B=12, L=6, seq=False, step=1),
+                 c=dict(B=64, L=16, seq=False, step=4), d=dict(B=33, L=7, seq=True, step=1),
+                 e=dict(B=256, L=64, seq=False, step=1))
+    for name, c in cases.items():
+        B, L = c["B"], c["L"]
+        t = [torch.randn(B, L, generator=g, dtype=torch.float64) * s for s in (0.5, 2.0, 0.5, 2.0)]
+        m = NestedLoRA(model=None, neigs=L, step=c["step"], sequential=c["seq"])
+        p = f"svd_{name}_"
+        for k, v in zip(("f", "Tg", "g", "Tadjf"), t):
+            out[p + k] = v.numpy()
+        out[p + "v"], out[p + "M"] = m.vector_mask.numpy(), m.matrix_mask.numpy()
+        out[p + "cfg"] = np.array([B, L, int(c["seq"]), c["step"]])
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            f, Tg, gg, Ta = [x.to(dt).clone() for x in t]
+            f.requires_grad_(True)
+            gg.requires_grad_(True)
+            loss = NestedLoRALossFunctionSVD.apply(f, Tg, gg, Ta, m.vector_mask.to(dt), m.matrix_mask.to(dt))
+            loss.backward()
+            q = p + tag + "_"
+            out[q + "loss"] = np.array([float(loss)])
+            out[q + "grad_f"], out[q + "grad_g"] = np64(f.grad), np64(gg.grad)
+
+
 def golden_ground_truth(out):
     out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
     out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
@@ -311,6 +339,15 @@ def golden_ground_truth(out):
 
 def main():
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "svd":  # only the fixture added last (the others stay byte-identical)
+        o = {}
+        golden_svd(o)
+        np.savez_compressed(os.path.join(HERE, "svd_loss.npz"), **o)
+        print("svd_loss", os.path.getsize(os.path.join(HERE, "svd_loss.npz")) // 1024, "KiB")
+        return
+    o = {}
+    golden_svd(o)
+    np.savez_compressed(os.path.join(HERE, "svd_loss.npz"), **o)
     o = {}
     golden_masks(o)
     np.savez_compressed(os.path.join(HERE, "masks.npz"), **o)
@@ -370,7 +407,7 @@ def main():
                  fourier_scale=1.0, sampling_scale=4.0, batch_size=7, operator_scale=1.0, operator_shift=16.0,
                  apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=0, seed=9)
     np.savez_compressed(os.path.join(HERE, "model_exact.npz"), **o)
-    for fn in ("masks", "evd_loss", "cdk_loss", "misc", "model_small", "model_headline", "model_exact"):
+    for fn in ("masks", "evd_loss", "cdk_loss", "svd_loss", "misc", "model_small", "model_headline", "model_exact"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

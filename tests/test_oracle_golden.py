@@ -218,6 +218,21 @@ def test_cdk_loss(case, tag, dtype, tol):
     assert G.rel(gf, z[p + "grad_f"]) <= tol and G.rel(gg, z[p + "grad_g"]) <= tol
 
 
+# ------------------------------------------------------------------ SVD loss (methods/nestedlora.py:114-164)
+@pytest.mark.parametrize("case", list("abcde"))
+@pytest.mark.parametrize("tag,dtype,tol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 3e-5)])
+def test_svd_loss(case, tag, dtype, tol):
+    z = G.load("svd_loss")
+    B, L, seq, step = [int(t) for t in z[f"svd_{case}_cfg"]]
+    v, M = (O.sequential_nesting_masks(L) if seq else O.joint_nesting_masks(L, step))
+    assert np.allclose(v.numpy(), z[f"svd_{case}_v"]) and np.allclose(M.numpy(), z[f"svd_{case}_M"])
+    f, Tg, g, Ta = [torch.tensor(z[f"svd_{case}_{k}"]).to(dtype) for k in ("f", "Tg", "g", "Tadjf")]
+    loss, gf, gg = O.svd_loss(f, Tg, g, Ta, v.to(dtype), M.to(dtype))
+    p = f"svd_{case}_{tag}_"
+    assert abs(float(loss) - float(z[p + "loss"][0])) <= tol * max(1.0, abs(float(z[p + "loss"][0])))
+    assert G.rel(gf, z[p + "grad_f"]) <= tol and G.rel(gg, z[p + "grad_g"]) <= tol
+
+
 def test_kernel_apply_definition():
     """oracle kernel_apply (parity unpinned: the reference has no kernel operator) against the literal double sum of
     its definition Kf[i, l] = (1 / B2) sum_k K[rows_i, cols_k] f[k, l], duplicates included."""
