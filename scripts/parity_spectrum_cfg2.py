@@ -23,12 +23,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--val-eps", type=float, default=0.4)
+    ap.add_argument("--laplacian-eps", type=float, default=0.01, help="0: exact-Laplacian mode (no stencil noise)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     L = 16
     shape = H.ModelShape(L=L, D=2, m=1024, hidden=(128, 128, 128))
-    prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+    prob = H.make_problem(H.POT_HYDROGEN, 1.0, a.laplacian_eps, 100.0, 0.0, 16.0)
     tr = FusedTrainer(shape, prob, 512, sequential=False, step=1, lr=1e-4, num_iters=a.steps, seed=0, device=dev)
     for _ in range(a.steps):
         tr.step()
@@ -42,7 +43,8 @@ def main():
     p64 = O.Params([sd[f"model.base.ws.{i}"].double().cpu() for i in range(nl)],
                    [sd[f"model.base.bs.{i}"].double().cpu() for i in range(nl)],
                    sd["model.base.feature_map._B"].double().cpu(), None)
-    prob_o = O.Problem(potential=O.POT_HYDROGEN, charge_or_k=1.0, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+    prob_o = O.Problem(potential=O.POT_HYDROGEN, charge_or_k=1.0, eps=a.laplacian_eps, op_scale=100.0, op_shift=0.0,
+                       sigma=16.0)
     ax = np.arange(-50.0, 50.0, a.val_eps)
     xx = np.meshgrid(ax, ax)
     grid = torch.tensor(np.array(list(zip(*[v.flatten() for v in xx])))).float().double()  # the float32 grid values
@@ -56,7 +58,7 @@ def main():
     e32 = np.asarray(O.spectrum_evd(grid.float(), p32, prob_o, 50.0)["eigvals"], dtype=np.float64)
     out["oracle_f32"] = e32
     rec = dict(what="eigenvalues of identical (EMA) weights on an identical grid: HIP float32 vs float64 oracle",
-               steps=a.steps, grid_points=int(grid.shape[0]), val_eps=a.val_eps, oracle_seconds=round(tor, 1),
+               steps=a.steps, laplacian_eps=a.laplacian_eps, grid_points=int(grid.shape[0]), val_eps=a.val_eps, oracle_seconds=round(tor, 1),
                eig_oracle_f64=[float(v) for v in e64])
     for name, e in out.items():
         r = np.abs(e - e64) / np.abs(e64)
