@@ -45,7 +45,7 @@ struct FwdArgs {
     float* jac;
     float* dsc;
     float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null: ACTIVATIONS softplus(z) of the centre rows
-    const unsigned short* w0p;  // BF3 only: W_0 pre-split into three bf16 planes, (3, L, 128, F), by w0_split_kernel
+    const unsigned short* w0p;  // BF3 only: W_0 pre-split into three bf16 planes, chunk-major (3, L, F/32, 128, 32), by w0_split_kernel
     size_t w0_plane;            // elements per plane
     int plain;      // E = 1 instance only: out = hard_mul_const * base * mask (WaveFunctions.forward), no Hamiltonian;
                     // f receives the output, jac / dsc its derivatives w.r.t. base / scales
@@ -628,9 +628,8 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     a.stamps = (unsigned long long*)w.dz[0];  // diagnostic build: stamps land in the (then unused) dz_0 scratch
 #endif
     if (bf3) {  // opt-in: layer 0 on the bf16 MFMA with three-way split operands
-        const size_t n4 = (size_t)d.L * HID * F / 4;
         hipLaunchKernelGGL(w0_split_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const float4*>(p.W[0]),
-                           reinterpret_cast<uint2*>(w.w0p), n4);
+                           reinterpret_cast<uint2*>(w.w0p), d.L, d.m);
         NSVD_CHECK_LAUNCH();
         a.w0p = w.w0p;
         a.w0_plane = (size_t)d.L * HID * F;

@@ -70,13 +70,24 @@ __device__ __forceinline__ void nsvd_rows_from_centre(const float4 rs, const flo
 // W_0 (L, 128, F) float32 -> three bf16 planes (3, L, 128, F): once per forward call (the weights change every step),
 // so that the forward's workgroups - 16 per head, all streaming the same W_0 - load ready-made planes instead of each
 // converting them again (a wave cannot hide its own VALU work under its own MFMAs: measured 2.5-3 of 4 cycles exposed).
-__global__ void __launch_bounds__(256) w0_split_kernel(const float4* __restrict__ W, uint2* __restrict__ P, size_t n4) {
+// Plane layout: CHUNK-MAJOR, (3, L, F/32 chunks, 128 rows, 32 k), chunks in the order the K loop visits them (pair j
+// of 32-wide sin / cos chunks: k = 32 j .. and m + 32 j ..). The 8 KB tile of a chunk is then contiguous - a wave's
+// load instruction covers 8 full 128-byte lines instead of the halves of 16 lines whose other halves belong to a
+// chunk two steps away.
+__global__ void __launch_bounds__(256) w0_split_kernel(const float4* __restrict__ W, uint2* __restrict__ P, int L, int m) {
+    const int F = 2 * m, q4 = F / 4;
+    const size_t n4 = (size_t)L * HID * q4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int k = 4 * (int)(i % q4);
+        const size_t row = i / q4;  // l * 128 + n
+        const int n = (int)(row % HID), l = (int)(row / HID);
+        const int half = k >= m, kk = k - half * m, c = 2 * (kk / BK) + half, within = kk % BK;
+        const size_t o = ((((size_t)l * (F / BK) + c) * HID + n) * BK + within) / 4;  // in units of 4 elements
         uint2 p0, p1, p2;
         nsvd_bf3_split(W[i], p0, p1, p2);
-        P[i] = p0;
-        P[n4 + i] = p1;
-        P[2 * n4 + i] = p2;
+        P[o] = p0;
+        P[n4 + o] = p1;
+        P[2 * n4 + o] = p2;
     }
 }
 
@@ -103,15 +114,16 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
     rs = rc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int d = 0; d < 3; ++d) cd[d] = sd[d] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // W tile of a chunk, per plane 128 rows x 64 B: piece q (16 B) of row r for thread index r * 4 + q (2 per thread)
+    // W tile of a chunk, per plane 128 rows x 64 B, contiguous in the chunk-major plane layout: piece q (16 B) of row r
+    // for thread index r * 4 + q (2 per thread: rows r and r + 64)
     const int w_row = tid >> 2, w_q = tid & 3;
-    const unsigned short* w_src = a.w0p + ((size_t)l * HID + w_row) * a.F + 8 * w_q;
-    const size_t w_half = (size_t)64 * a.F;  // second piece: row + 64
+    const unsigned short* w_src = a.w0p + (size_t)l * HID * a.F + 8 * tid;
+    const size_t w_half = (size_t)64 * BK;  // second piece: row + 64
 
     auto load = [&](int c, auto half) {  // chunk c = pair (c >> 1), half (c & 1)
         constexpr int HALF = decltype(half)::value;
         const int kp = (c >> 1) * BK;
-        const unsigned short* pw = w_src + (HALF ? mm : 0) + kp;
+        const unsigned short* pw = w_src + (size_t)c * (HID * BK);
         rw0 = *reinterpret_cast<const uint4*>(pw);
         rw1 = *reinterpret_cast<const uint4*>(pw + w_half);
         rw2 = *reinterpret_cast<const uint4*>(pw + a.w0_plane);
