@@ -252,6 +252,29 @@ def main():
         out["metric"] += " [developer path: layer 0 as bf16x3 split products, fp32 accumulation]"
         out["config"]["layer0"] = ("bf16 MFMA, operands split into 3 bf16 planes, 6 partial products, fp32 "
                                    "accumulate; roofline.frac stays relative to the fp32 MFMA peak")
+    if world == 1 and args.path == "auto" and args.config == "cfg2" and args.laplacian_eps is None \
+            and not args.batch_size:
+        # side measurement, never the headline: the same K steps with the opt-in forward
+        try:
+            tr2 = FusedTrainer(shape, prob, cfg["B"], parallelism="dp", sequential=cfg["sequential"], lr=cfg["lr"],
+                               rmsprop_decay=cfg["alpha"], ema_decay=cfg["ema_decay"], num_iters=cfg["num_iters"],
+                               sampling_scale=cfg["sigma"], fourier_scale=cfg["fourier_scale"],
+                               exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev, path=H.PATH_FUSED_BF16X3)
+            for _ in range(args.warmup):
+                tr2.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tr2.step()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            out["opt_in_path_bf16x3"] = {
+                "value": round(args.steps / e2, 3), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
+                "final_loss": float(tr2.loss[0]), "params_finite": bool(torch.isfinite(tr2.P.flat).all()),
+                "note": "same workload and step count with NSVD_PATH_FUSED_BF16X3 (first layer as 3-way split bf16 "
+                        "products, fp32 accumulation, float32-accurate: DESIGN.md 3.7); not the headline value"}
+        except Exception as e:  # noqa: BLE001
+            out["opt_in_path_bf16x3"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
         cb = cpu_baseline(cfg)
         out["cpu_baseline"] = cb
