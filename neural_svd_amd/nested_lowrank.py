@@ -71,7 +71,25 @@ def _is_chunk_of(f: torch.Tensor, f1: torch.Tensor, f2: torch.Tensor) -> bool:
             and f1.is_contiguous() and f2.is_contiguous())
 
 
+_MASK_KIND_CACHE: dict = {}
+
+
 def _mask_kind(vector_mask: torch.Tensor, matrix_mask: torch.Tensor) -> int:
+    """Which of the library's built-in nesting masks these are (the kernels then build them in registers). Decided once
+    per (tensor objects, in-place version): the comparison below costs milliseconds on a many-core host."""
+    key = (id(vector_mask), id(matrix_mask), vector_mask._version, matrix_mask._version, vector_mask.numel())
+    hit = _MASK_KIND_CACHE.get(key)
+    if hit is not None and hit[0]() is vector_mask and hit[1]() is matrix_mask:
+        return hit[2]
+    kind = _mask_kind_uncached(vector_mask, matrix_mask)
+    if len(_MASK_KIND_CACHE) > 64:
+        _MASK_KIND_CACHE.clear()
+    import weakref
+    _MASK_KIND_CACHE[key] = (weakref.ref(vector_mask), weakref.ref(matrix_mask), kind)
+    return kind
+
+
+def _mask_kind_uncached(vector_mask: torch.Tensor, matrix_mask: torch.Tensor) -> int:
     L = vector_mask.numel()
     v, M = vector_mask.detach().float().cpu(), matrix_mask.detach().float().cpu()
     if torch.equal(v, torch.ones(L)) and torch.equal(M, torch.triu(torch.ones(L, L))):
