@@ -1,7 +1,13 @@
 """train_operator with the reference's signature (examples/operator/__init__.py:20-153) for
-main_pde.py-style drivers: torch.optim.RMSprop + CosineAnnealingLR + EMA on ordinary nn.Parameters,
-the loss / operator / eval math on the HIP path. Plotting and the local-energy monitor are left out
-(they are not part of the hot path). For maximum step rate use trainer.FusedTrainer instead."""
+main_pde.py-style drivers. Two loop bodies with the same semantics (RMSprop, cosine schedule, torch_ema-style EMA,
+evaluation under the EMA weights, checkpoints with the reference's keys):
+  * the fused one (default whenever the configuration is the one the PDE scripts use: NestedLoRA over WaveFunctions,
+    OperatorWrapper, Gaussian importance, RMSprop without momentum): the steps are taken by trainer.FusedTrainer on the
+    model's own weights - four kernel launches per step - and the nn.Module, the EMA object and the optimiser state are
+    refreshed from it whenever something looks at them (evaluation, checkpoint, return);
+  * the plain one (``args.fused_loop = False``, or any other configuration): torch.optim + torch autograd around the
+    HIP loss / operator Functions, one optimiser kernel per foreach op - about three times slower, host-bound.
+Plotting and the local-energy monitor are left out (they are not part of the hot path)."""
 from __future__ import annotations
 
 import contextlib
@@ -64,27 +70,97 @@ def get_optimizer(args, model):
     raise NotImplementedError
 
 
+def _fused_loop_trainer(args, method, operator, importance_train, device):
+    """A FusedTrainer over the SAME weights when the configuration is one it implements, else None."""
+    from .models import WaveFunctions
+    from .nested_lowrank import NestedLoRA, nesting_masks
+    from .operators import GaussianImportance, OperatorWrapper, fused_problem_of
+    from .trainer import FusedTrainer
+    if not getattr(args, "fused_loop", True):
+        return None
+    if args.optimizer != "rmsprop" or float(getattr(args, "momentum", 0.0)) != 0.0:
+        return None
+    if not (isinstance(method, NestedLoRA) and isinstance(method.model, WaveFunctions)) or method.sort_indices is not None:
+        return None
+    if not isinstance(operator, OperatorWrapper) or not isinstance(importance_train, GaussianImportance):
+        return None
+    if torch.device(device).type != "cuda":
+        return None
+    try:
+        step = int(args.loss.neuralsvd.step)
+    except AttributeError:
+        return None
+    v, M, _ = nesting_masks(method.neigs, bool(method.sequential), step)
+    if not (torch.equal(v.float(), method.vector_mask.float().cpu()) and torch.equal(M.float(), method.matrix_mask.float().cpu())):
+        return None
+    model = method.model
+    dev = torch.device(device)
+    # the trainer's constructor draws (and here discards) initial weights: keep the caller's random streams untouched
+    with torch.random.fork_rng(devices=[dev.index if dev.index is not None else torch.cuda.current_device()]):
+        tr = _make_fused(FusedTrainer, args, method, model, operator, importance_train, step, device,
+                         fused_problem_of)
+    tr.P.load(model.base.feature_map._B.data, [w.data for w in model.base.ws], [b.data for b in model.base.bs],
+              model.boundary_mask.scales.data if model.has_exp_mask else None)
+    return tr
+
+
+def _make_fused(FusedTrainer, args, method, model, operator, importance_train, step, device, fused_problem_of):
+    return FusedTrainer(model.shape, fused_problem_of(operator, importance_train, model), args.batch_size,
+                      sequential=bool(method.sequential), step=step, lr=args.lr, rmsprop_decay=args.rmsprop_decay,
+                      rmsprop_eps=1e-10, ema_decay=args.ema_decay, num_iters=args.num_iters,
+                      use_lr_scheduler=bool(args.use_lr_scheduler), sampling_scale=importance_train.sigma, seed=0,
+                      device=device, path=method.path, device_sampler=False,
+                      exp_mask_init=1.0 if model.has_exp_mask else None)  # initial values: replaced by the caller
+
+
+@torch.no_grad()
+def _refresh_from_trainer(tr, method, ema, optimizer, scheduler):
+    """nn.Module parameters, EMA shadow, RMSprop state and schedule position <- the fused trainer's buffers."""
+    named = dict(method.named_parameters())
+    shadow = {id(p): s for p, s in zip(ema.params, ema.shadow_params)}
+    for n, w, e, q in zip(tr.P.names, tr.P.views(tr.P.flat), tr.P.views(tr.P.ema), tr.P.views(tr.P.sq)):
+        p = named[n]
+        p.data.copy_(w.view_as(p))
+        shadow[id(p)].copy_(e.view_as(p))
+        st = optimizer.state[p]
+        st["step"] = torch.tensor(float(tr.t))
+        st["square_avg"] = q.view_as(p).clone()
+    ema.num_updates = tr.num_updates
+    if tr.use_sched:
+        from .trainer import cosine_lr
+        scheduler.last_epoch = tr.t
+        for g in optimizer.param_groups:
+            g["lr"] = cosine_lr(tr.lr, tr.t, tr.num_iters)
+
+
 def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch_ftn_val, log_writer, log_file,
                    device, importance_train, importance_val, ground_truth_spectrum=None):
     optimizer = get_optimizer(args, method)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.num_iters)
     ema = ExponentialMovingAverage(method.parameters(), decay=args.ema_decay)
+    fused = _fused_loop_trainer(args, method, operator, importance_train, device)
     all_eigvals, all_norms = [], []
     start = time.time()
     total_loss = 0.0
     for it in range(args.num_iters):
-        method.train()
-        optimizer.zero_grad()
-        x = make_batch_ftn_train().to(device)
-        x = x.reshape(x.shape[0], -1)
-        loss, _aux = method.compute_loss_operator(operator, x, importance=importance_train)
-        loss.backward()
-        optimizer.step()
-        if args.use_lr_scheduler:
-            scheduler.step()
-        ema.update()
+        if fused is not None:
+            x = make_batch_ftn_train().to(device)
+            fused.step(x.reshape(x.shape[0], -1).float().contiguous())
+            loss = None
+        else:
+            method.train()
+            optimizer.zero_grad()
+            x = make_batch_ftn_train().to(device)
+            x = x.reshape(x.shape[0], -1)
+            loss, _aux = method.compute_loss_operator(operator, x, importance=importance_train)
+            loss.backward()
+            optimizer.step()
+            if args.use_lr_scheduler:
+                scheduler.step()
+            ema.update()
         if (it + 1) % args.print_freq == 0:
-            li = loss.item()  # the only host sync, and only at print time (the reference syncs every step)
+            # the only host sync, and only at print time (the reference syncs every step)
+            li = float(fused.loss[0]) if fused is not None else loss.item()
             total_loss += li
             row = {"iter": it + 1, "train_loss": li, "avg_train_loss": total_loss / ((it + 1) // args.print_freq),
                    "time": time.time() - start}
@@ -93,6 +169,8 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                 log_writer.writerow(row)
                 log_file.flush()
         if (it + 1) % args.eval_freq == 0:
+            if fused is not None:
+                _refresh_from_trainer(fused, method, ema, optimizer, scheduler)
             method.eval()
             with ema.average_parameters():
                 if batch_ftn_val is not None:
@@ -107,4 +185,6 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                 os.makedirs(args.log_dir, exist_ok=True)
                 torch.save(dict(args=args, method=method.state_dict(), ema=ema.state_dict(),
                                 optimizer=optimizer.state_dict()), os.path.join(args.log_dir, f"{it + 1}.pth"))
+    if fused is not None:
+        _refresh_from_trainer(fused, method, ema, optimizer, scheduler)
     return all_eigvals, all_norms

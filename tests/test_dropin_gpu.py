@@ -100,6 +100,62 @@ def test_foreign_operator_is_refused():
         method.compute_loss_operator(lambda m, xx, importance=None: (xx, xx), x, importance=loaders[3])
 
 
+@pytest.mark.parametrize("iters,lr,tol", [(1, 1e-3, 2e-6), (12, 1e-5, 2e-3)])
+@pytest.mark.parametrize("case", ["hyd_small", "osc_small"])
+def test_train_operator_fused_loop_matches_plain_loop(case, iters, lr, tol):
+    """train_operator's two loop bodies (FusedTrainer on the model's weights vs torch.optim + autograd) from the same
+    seed and batches: parameters, EMA shadow, RMSprop state, learning rate and EMA counter agree - to rounding after
+    one step; after 12 steps to what the sign-like early RMSprop updates make of that rounding (an element whose
+    gradient is near zero can flip the sign of its +-lr/sqrt(1-alpha) update). The caller's random streams are not
+    disturbed by the fused trainer's construction (the batches are the same)."""
+    import neural_svd_amd.drop_in as DI
+    z = G.load("model_small")
+    res = {}
+    for fused in (True, False):
+        cfg, args, operator, gt, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = build(case, z)
+        args.optimizer, args.lr, args.rmsprop_decay, args.momentum = "rmsprop", lr, 0.999, 0.0
+        args.num_iters, args.print_freq, args.eval_freq, args.fused_loop = iters, 10 ** 9, iters, fused
+        captured = {}
+        orig_opt, orig_ema = DI.get_optimizer, DI.ExponentialMovingAverage
+
+        def cap_opt(a, m, _o=orig_opt):
+            captured["opt"] = _o(a, m)
+            return captured["opt"]
+
+        class CapEma(orig_ema):
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                captured["ema"] = self
+
+        DI.get_optimizer, DI.ExponentialMovingAverage = cap_opt, CapEma
+        try:
+            torch.manual_seed(123)
+            eig, norms = DI.train_operator(args, method, operator, make_batch, val_data, batch_ftn_val, None, None, DEV,
+                                           imp_train, imp_val)
+        finally:
+            DI.get_optimizer, DI.ExponentialMovingAverage = orig_opt, orig_ema
+        opt, ema = captured["opt"], captured["ema"]
+        train = [(n, p) for n, p in method.named_parameters() if p.requires_grad]
+        res[fused] = dict(params={n: p.detach().clone() for n, p in train},
+                          sq={n: opt.state[p]["square_avg"].clone() for n, p in train},
+                          sh={n: s.clone() for (n, p), s in zip(train, ema.shadow_params)},
+                          lr=opt.param_groups[0]["lr"], n=ema.num_updates, eig=eig[-1])
+    a, b = res[True], res[False]
+    assert a["n"] == b["n"] == iters and abs(a["lr"] - b["lr"]) < 1e-12 * max(1.0, abs(b["lr"]))
+    upd = iters * lr / np.sqrt(1.0 - 0.999)  # the largest total movement of an element (biases start at zero)
+
+    def close(x, y, t):
+        x, y = x.double(), y.double()
+        return float((x - y).norm()) <= t * (float(y.norm()) + upd * np.sqrt(y.numel()))
+
+    for n in a["params"]:
+        assert close(a["params"][n], b["params"][n], tol), n
+        assert close(a["sh"][n], b["sh"][n], tol), n
+        assert rel(a["sq"][n], b["sq"][n]) < 20 * tol, n
+    # the eigenvalue metric differences Tf on the float32 stencil: 1e-9 of weight difference shows at 1e-3 there
+    assert np.allclose(a["eig"], b["eig"], rtol=1e-2)
+
+
 def test_train_operator_smoke():
     """the reference-signature loop: a few iterations with eval + checkpoint dict, parameters move and stay finite."""
     from neural_svd_amd.drop_in import train_operator
