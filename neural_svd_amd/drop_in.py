@@ -143,15 +143,16 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     start = time.time()
     total_loss = 0.0
     for it in range(args.num_iters):
+        x = make_batch_ftn_train().to(device)
+        x = x.reshape(x.shape[0], -1)
+        if fused is not None and it == 0 and x.shape[0] != fused.B:
+            fused = None  # the sampler does not produce args.batch_size rows: the plain loop takes any batch
         if fused is not None:
-            x = make_batch_ftn_train().to(device)
-            fused.step(x.reshape(x.shape[0], -1).float().contiguous())
+            fused.step(x.float().contiguous())
             loss = None
         else:
             method.train()
             optimizer.zero_grad()
-            x = make_batch_ftn_train().to(device)
-            x = x.reshape(x.shape[0], -1)
             loss, _aux = method.compute_loss_operator(operator, x, importance=importance_train)
             loss.backward()
             optimizer.step()
