@@ -46,6 +46,19 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
     const int b = b0 + li;
     const size_t row0 = ((size_t)l * HID + 32 * w) * a.B + b;
 
+    // the last hidden layer's activations and the 128 -> 1 weights do not depend on d loss / d f: their loads fly
+    // while the moments are taken
+    float zl[16], wlv[16];
+    {
+        const float* zp = a.zsave[nh - 1] + row0;
+        const float* wl = a.W[nh] + (size_t)l * HID + 32 * w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = acc_row(r, hi);
+            zl[r] = zp[(size_t)n * a.B];
+            wlv[r] = wl[n];
+        }
+    }
     float dfv;
     if (a.df) {
         dfv = a.df[(size_t)b * a.L + l];
@@ -102,15 +115,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         if (a.dfsc) a.dfsc[(size_t)l * a.B + b] = dfv * a.dsc[(size_t)b * a.L + l];
     }
     float dz[16];
-    {
-        const float* zp = a.zsave[nh - 1] + row0;
-        const float* wl = a.W[nh] + (size_t)l * HID + 32 * w;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = acc_row(r, hi);
-            dz[r] = wl[n] * dbase * nsvd_sigmoid_from_softplus(zp[(size_t)n * a.B]);
-        }
-    }
+    for (int r = 0; r < 16; ++r) dz[r] = wlv[r] * dbase * nsvd_sigmoid_from_softplus(zl[r]);
     for (int i = nh - 1; i >= 0; --i) {
         float* o = a.dz[i] + row0;
 #pragma unroll
