@@ -299,6 +299,18 @@ int nsvd_cdk_loss_forward(const float* f, const float* g, const float* batch_wei
 int nsvd_cdk_loss_backward(const float* v, int B, int L, int set_first_mode_const, const float* grad_out,
                            float* grad_f, float* grad_g, void* ws, size_t ws_bytes, void* stream);
 
+/* normalize(z, r_up, regularize_mode) applied to the CDK towers' embeddings (examples/models/siam.py:170-183, called
+ * from HeteroNetwork.forward_single :156-166). z, out, dout, dz: (B, L) float32 row-major.
+ *   NSVD_NORMALIZE_L2_BALL:   rows with ||z|| < r_up unchanged, the others r_up * z / max(||z||, 1e-12)
+ *   NSVD_NORMALIZE_L2_SPHERE: every row r_up * z / max(||z||, 1e-12)
+ * Backward of the same expression (the comparison is a constant mask, as in the reference). out may alias z in the
+ * forward; dz may alias dout in the backward. */
+#define NSVD_NORMALIZE_L2_BALL 0
+#define NSVD_NORMALIZE_L2_SPHERE 1
+int nsvd_row_normalize_forward(const float* z, int B, int L, float r_up, int mode, float* out, void* stream);
+int nsvd_row_normalize_backward(const float* z, const float* dout, int B, int L, float r_up, int mode, float* dz,
+                                void* stream);
+
 /* Measurement aid (bench.py): record the two hipEvent_t handles immediately before / after the
  * DOMINANT kernel of the next nsvd_operator_forward call made by this host thread (the fused MFMA
  * forward kernel, or the layer-0 GEMM on the generic path), on that call's stream. One-shot;

@@ -18,6 +18,7 @@ EUNSUPPORTED = -10002
 POT_HYDROGEN, POT_HARMONIC = 0, 1
 MASK_CUSTOM, MASK_SEQUENTIAL, MASK_JOINT = 0, 1, 2
 PATH_AUTO, PATH_GENERIC, PATH_FUSED, PATH_FUSED_BF16X3 = 0, 1, 2, 3
+NORMALIZE_L2_BALL, NORMALIZE_L2_SPHERE = 0, 1
 FEATURES_READY = 0x100
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -83,6 +84,8 @@ SIGNATURES = {
     "nsvd_cdk_loss_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "nsvd_cdk_loss_backward": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "nsvd_spectrum_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
+    "nsvd_row_normalize_forward": (_I, [_P, _I, _I, _F, _I, _P, _P]),
+    "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -6,6 +6,7 @@
     NestedLoRAForCDK(model, neigs, step, sequential, set_first_mode_const).compute_loss(f, g, batch_weights)
                                                                   methods/nestedlora.py:335-378
     get_cdk_method(args, model)                                   methods/cdk.py:4-16
+    normalize(z, r_up, regularize_mode), HeteroNetwork(...)       examples/models/siam.py:132-183
 
 Differences, all deliberate: the arithmetic is float32 on the MFMA whatever the autocast state (the reference's
 un-decorated Function runs its matmuls in half precision under ``torch.cuda.amp.autocast``; half inputs are
@@ -100,3 +101,65 @@ def get_cdk_method(args, model):
                                 sequential=args.loss.neuralsvd.sequential,
                                 set_first_mode_const=args.loss.neuralsvd.set_first_mode_const)
     raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------ towers (examples/models/siam.py)
+class _RowNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, r_up, mode):
+        zd = z.detach().float().contiguous()
+        ctx.r_up, ctx.mode, ctx.dtype = float(r_up), int(mode), z.dtype
+        ctx.save_for_backward(zd)
+        return H.row_normalize(zd, ctx.r_up, ctx.mode).to(z.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (zd,) = ctx.saved_tensors
+        dz = H.row_normalize_backward(zd, dout.detach().float().contiguous(), ctx.r_up, ctx.mode)
+        return dz.to(ctx.dtype), None, None
+
+
+def normalize(z, r_up, regularize_mode):
+    """examples/models/siam.py:170-191 on the HIP path: 'l2_ball' (what the Sketchy script uses, sketchy.sh) and
+    'l2_sphere' are one row-wise kernel each way (nsvd_row_normalize_forward / _backward); 'clip' and 'tanh' are
+    single elementwise torch ops in the reference and stay that."""
+    if not r_up > 0:
+        return z
+    if regularize_mode == "l2_ball":
+        return _RowNormalize.apply(z, r_up, H._lib.NORMALIZE_L2_BALL)
+    if regularize_mode == "l2_sphere":
+        return _RowNormalize.apply(z, r_up, H._lib.NORMALIZE_L2_SPHERE)
+    if regularize_mode == "clip":
+        return torch.clip(z, min=-r_up, max=r_up)
+    if regularize_mode == "tanh":
+        return r_up * torch.tanh(z)
+    raise NotImplementedError(regularize_mode)
+
+
+class HeteroNetwork(nn.Module):
+    """Two towers (backbone -> projector -> normalize), examples/models/siam.py:132-166: same constructor, same
+    ``forward(x, y) -> [x_rep, x_emb, y_rep, y_emb]`` and ``forward_single``. The backbones / projectors are the
+    caller's modules (plain Linear + BatchNorm MLPs in the shipped script: library GEMMs); the embedding's
+    normalisation runs on the HIP kernel above."""
+
+    def __init__(self, backbones, projectors, online_heads=None, mu=1.0, regularize_mode=None):
+        super().__init__()
+        self.mu = mu
+        self.backbones = nn.ModuleDict({"x": backbones[0], "y": backbones[1]})
+        self.projectors = nn.ModuleDict({"x": projectors[0], "y": projectors[1]})
+        self.online_heads = nn.ModuleDict({"x": online_heads[0], "y": online_heads[1]}) if online_heads else None
+        self.output_dims = {k: self.backbones[k].output_dim if isinstance(self.projectors[k], nn.Identity)
+                            else self.projectors[k].output_dim for k in self.projectors}
+        assert regularize_mode in ["l2_ball", "l2_sphere", "clip", "tanh"]
+        self.regularize_mode = regularize_mode
+
+    def forward(self, x, y):
+        return [*self.forward_single(x, "x"), *self.forward_single(y, "y")]
+
+    def forward_single(self, x, x_or_y, classify=False):
+        assert x_or_y in ["x", "y"]
+        rep = self.backbones[x_or_y](x)
+        emb = normalize(self.projectors[x_or_y](rep), float(self.mu) ** 0.5, self.regularize_mode)
+        if classify:
+            return rep, emb, self.online_heads[x_or_y](emb.detach())
+        return rep, emb

@@ -452,3 +452,22 @@ def profile_next_forward(ev_start: "torch.cuda.Event", ev_stop: "torch.cuda.Even
 
 def dominant_kernel_name(shape: ModelShape, B: int, path: int = PATH_AUTO) -> str:
     return "pmlp_fused_fwd_kernel" if path_name(shape, B, path).startswith("fused") else "gemm_generic_kernel[layer0]"
+
+
+# ------------------------------------------------------------------------------ row normalisation (CDK towers)
+def row_normalize(z: torch.Tensor, r_up: float, mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """normalize(z, r_up, 'l2_ball' | 'l2_sphere') of examples/models/siam.py:170-183 on (B, L) float32 rows."""
+    if z.dim() != 2 or z.dtype != torch.float32 or not z.is_contiguous():
+        raise NsvdError("row_normalize: z must be a contiguous (B, L) float32 tensor")
+    if out is None:
+        out = torch.empty_like(z)
+    check(_lib.load().nsvd_row_normalize_forward(_ptr(z, "z"), z.shape[0], z.shape[1], float(r_up), int(mode),
+                                                 _ptr(out, "out"), _stream()), "nsvd_row_normalize_forward")
+    return out
+
+
+def row_normalize_backward(z: torch.Tensor, dout: torch.Tensor, r_up: float, mode: int) -> torch.Tensor:
+    dz = torch.empty_like(z)
+    check(_lib.load().nsvd_row_normalize_backward(_ptr(z, "z"), _ptr(dout, "dout"), z.shape[0], z.shape[1], float(r_up),
+                                                  int(mode), _ptr(dz, "dz"), _stream()), "nsvd_row_normalize_backward")
+    return dz

@@ -158,6 +158,20 @@ def cdk_loss(f, g, v, M, set_first_mode_const=True, batch_weights=None):
     return loss_op + loss_metric, loss_op, loss_metric, gram.diag(), off_diagonal(gram), gf, gg
 
 
+def row_normalize(z, r_up, mode):
+    """normalize(z, r_up, mode) of the CDK towers (reference examples/models/siam.py:170-183), modes 'l2_ball' and
+    'l2_sphere'; F.normalize(z, p=2, dim=1) = z / max(||z||, 1e-12). Differentiable (plain torch ops): the tests take
+    its autograd gradient. Pinned by tests/golden/normalize.npz."""
+    nrm = torch.linalg.vector_norm(z, dim=1, keepdim=True)
+    unit = z / torch.clamp(nrm, min=1e-12)
+    if mode == "l2_sphere":
+        return r_up * unit
+    # a constant of the graph, and float32 as in the reference (`.float()`): `(1 - mask) * r_up` is therefore formed in
+    # float32 - in a float64 run r_up reaches the scaled rows rounded to float32
+    mask = (nrm < r_up).float()
+    return mask * z + (1 - mask) * r_up * unit
+
+
 # ----------------------------------------------------------------------------- model
 @dataclass
 class Params:

@@ -330,6 +330,28 @@ def golden_svd(out):
             out[q + "grad_f"], out[q + "grad_g"] = np64(f.grad), np64(gg.grad)
 
 
+def golden_normalize(out):
+    """normalize(z, r_up, mode) of examples/models/siam.py:170-183 ('l2_ball', 'l2_sphere') and its autograd gradient
+    for a given upstream gradient; rows straddle the radius, one row is exactly zero."""
+    from examples.models.siam import normalize
+    g = torch.Generator().manual_seed(99)
+    for name, (B, L, r) in dict(a=(7, 5, 1.5), b=(12, 512, 4.0), c=(33, 30, 0.7), d=(8, 128, 16.0)).items():
+        z64 = torch.randn(B, L, generator=g, dtype=torch.float64) * (2.0 * r / np.sqrt(L)) * \
+            (0.25 + 1.5 * torch.rand(B, 1, generator=g, dtype=torch.float64))
+        z64[0] = 0.0
+        d64 = torch.randn(B, L, generator=g, dtype=torch.float64)
+        p = f"norm_{name}_"
+        out[p + "z"], out[p + "dout"], out[p + "cfg"] = z64.numpy(), d64.numpy(), np.array([B, L, r])
+        for mode in ("l2_ball", "l2_sphere"):
+            for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+                if tag == "f32" and B * L > 2000:
+                    continue  # the float32 yardstick only for the small cases (fixture size)
+                z = z64.to(dt).clone().requires_grad_(True)
+                y = normalize(z, r, mode)
+                y.backward(d64.to(dt))
+                out[p + f"{mode}_{tag}_out"], out[p + f"{mode}_{tag}_dz"] = np64(y), np64(z.grad)
+
+
 def golden_ground_truth(out):
     out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
     out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
@@ -339,6 +361,12 @@ def golden_ground_truth(out):
 
 def main():
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "normalize":
+        o = {}
+        golden_normalize(o)
+        np.savez_compressed(os.path.join(HERE, "normalize.npz"), **o)
+        print("normalize", os.path.getsize(os.path.join(HERE, "normalize.npz")) // 1024, "KiB")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "svd":  # only the fixture added last (the others stay byte-identical)
         o = {}
         golden_svd(o)
@@ -348,6 +376,9 @@ def main():
     o = {}
     golden_svd(o)
     np.savez_compressed(os.path.join(HERE, "svd_loss.npz"), **o)
+    o = {}
+    golden_normalize(o)
+    np.savez_compressed(os.path.join(HERE, "normalize.npz"), **o)
     o = {}
     golden_masks(o)
     np.savez_compressed(os.path.join(HERE, "masks.npz"), **o)
@@ -407,7 +438,7 @@ def main():
                  fourier_scale=1.0, sampling_scale=4.0, batch_size=7, operator_scale=1.0, operator_shift=16.0,
                  apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=0, seed=9)
     np.savez_compressed(os.path.join(HERE, "model_exact.npz"), **o)
-    for fn in ("masks", "evd_loss", "cdk_loss", "svd_loss", "misc", "model_small", "model_headline", "model_exact"):
+    for fn in ("masks", "evd_loss", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

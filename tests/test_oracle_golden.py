@@ -289,3 +289,16 @@ def test_exact_jets_against_autograd():
             H = torch.autograd.functional.hessian(lambda xx: gfun(xx.view(1, -1))[0, l], x[b])
             assert abs(float(torch.trace(H)) - float(lap[b, l])) < 1e-9 * max(1.0, abs(float(lap[b, l])))
     assert torch.allclose(gfun(x), g, rtol=1e-12, atol=1e-14)
+
+
+# ------------------------------------------------------------------ normalize() of the CDK towers (siam.py:170-183)
+@pytest.mark.parametrize("mode", ["l2_ball", "l2_sphere"])
+@pytest.mark.parametrize("case", list("abcd"))
+def test_row_normalize(case, mode):
+    z = G.load("normalize")
+    B, L, r = z[f"norm_{case}_cfg"]
+    x = torch.tensor(z[f"norm_{case}_z"]).requires_grad_(True)
+    y = O.row_normalize(x, float(r), mode)
+    y.backward(torch.tensor(z[f"norm_{case}_dout"]))
+    assert G.rel(y.detach(), z[f"norm_{case}_{mode}_f64_out"]) <= 1e-14
+    assert G.rel(x.grad, z[f"norm_{case}_{mode}_f64_dz"]) <= 1e-13
