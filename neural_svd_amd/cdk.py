@@ -7,6 +7,7 @@
                                                                   methods/nestedlora.py:335-378
     get_cdk_method(args, model)                                   methods/cdk.py:4-16
     normalize(z, r_up, regularize_mode), HeteroNetwork(...)       examples/models/siam.py:132-183
+    get_mlp(sizes, ...)                                           examples/models/mlp.py:129-164 (torch modules)
 
 Differences, all deliberate: the arithmetic is float32 on the MFMA whatever the autocast state (the reference's
 un-decorated Function runs its matmuls in half precision under ``torch.cuda.amp.autocast``; half inputs are
@@ -163,3 +164,45 @@ class HeteroNetwork(nn.Module):
         if classify:
             return rep, emb, self.online_heads[x_or_y](emb.detach())
         return rep, emb
+
+
+def _activation_factory(name: str):
+    """The activation names the tower builder understands (reference examples/models/mlp.py:65-88; its custom erf /
+    sine activations are not used by the CDK script and are not provided)."""
+    if name == "relu":
+        return lambda: nn.ReLU(inplace=True)
+    if name.startswith("lrelu"):
+        slope = float(name[len("lrelu"):])
+        return lambda: nn.LeakyReLU(negative_slope=slope)
+    if name.startswith("elu"):
+        alpha = float(name[len("elu"):])
+        return lambda: nn.ELU(alpha=alpha)
+    table = {"tanh": nn.Tanh, "linear": nn.Identity, "softplus": nn.Softplus}
+    if name in table:
+        return table[name]
+    raise NotImplementedError(f"activation {name!r}")
+
+
+def get_mlp(sizes, bias=True, nonlinearity="relu", use_bn=True, weight_normalization=False, last_layer_bn=True,
+            feature_map=None):
+    """Tower builder of the Sketchy script (reference examples/models/mlp.py:129-164, used at
+    examples/cdk/sketchy/main_sketchy.py:109-112): Linear (+ BatchNorm1d) (+ activation) per layer, no activation after
+    the last layer, BatchNorm after it only with ``last_layer_bn``; ``output_dim`` attribute. Plain torch modules:
+    these are library GEMMs."""
+    make_act = _activation_factory(nonlinearity)
+    n = len(sizes) - 1
+    if n == 0:
+        model = nn.BatchNorm1d(sizes[0]) if (use_bn and last_layer_bn) else nn.Identity()
+    else:
+        mods = [] if feature_map is None else [feature_map]
+        for i, (d_in, d_out) in enumerate(zip(sizes[:-1], sizes[1:])):
+            lin = nn.Linear(d_in, d_out, bias=bias)
+            mods.append(nn.utils.weight_norm(lin) if weight_normalization else lin)
+            last = i == n - 1
+            if use_bn and (not last or last_layer_bn):
+                mods.append(nn.BatchNorm1d(d_out))
+            if not last:
+                mods.append(make_act())
+        model = nn.Sequential(*mods)
+    model.output_dim = sizes[-1]
+    return model

@@ -80,3 +80,27 @@ def test_hetero_network_mirror_and_other_modes():
     assert torch.equal(normalize(xr, 0.0, "l2_ball"), xr)
     assert torch.equal(normalize(xr, 1.5, "clip"), torch.clip(xr, -1.5, 1.5))
     assert torch.allclose(normalize(xr, 1.5, "tanh"), 1.5 * torch.tanh(xr))
+
+
+def test_sketchy_style_towers_end_to_end():
+    """The model construction of examples/cdk/sketchy/main_sketchy.py:107-116 with this package's names only
+    (get_mlp, HeteroNetwork, get_cdk_method-style NestedLoRAForCDK): one loss + backward, finite gradients everywhere,
+    embeddings inside the ball of radius sqrt(mu)."""
+    import torch.nn as nn
+    from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
+    torch.manual_seed(1)
+    sizes = [64, 256, 32]
+    model = HeteroNetwork(backbones=[get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True),
+                                     get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True)],
+                          projectors=[nn.Identity(), nn.Identity()], mu=16.0, regularize_mode="l2_ball").to(DEV)
+    assert model.output_dims == {"x": 32, "y": 32}
+    kinds = [type(m).__name__ for m in model.backbones["x"]]
+    assert kinds == ["Linear", "BatchNorm1d", "LeakyReLU", "Linear", "BatchNorm1d"]
+    method = NestedLoRAForCDK(model, neigs=32, step=1, sequential=False, set_first_mode_const=True).to(DEV)
+    x, y = torch.randn(128, 64, device=DEV), torch.randn(128, 64, device=DEV)
+    _, fx, _, fy = method(x, y)
+    assert float(fx.detach().norm(dim=1).max()) <= 4.0 * (1 + 1e-6)
+    out = method.compute_loss(fx, fy)
+    loss = out[0] if isinstance(out, (tuple, list)) else out
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
