@@ -8,8 +8,11 @@ initialisation (random weights of the real architecture).
 
 One step = sample x ~ N(0, 16^2 I) on the device -> operator forward (5 stencil evaluations of the
 16-headed MLP + FD Hamiltonian) -> EVD loss -> backward -> RMSprop(+cosine LR) -> EMA, all HIP kernels.
-N > 1: data parallel, every rank draws its own 512 rows (weak scaling, global batch 512 N), one
-all-reduce of the 2L^2+1 moment floats and one of the flat gradient per step over RCCL.
+N > 1: samples sharded (dp), every rank draws its own 512 rows (weak scaling, global batch 512 N), one
+all-reduce of the 2L^2+1 moment floats and a bucketed all-reduce of the flat gradient per step over RCCL; the
+head-sharded split (hp) and configs[2] are timed beside it as side fields of the same JSON line.
+Timing: a declared prewarm (>= 1 s of real steps, whatever the step arguments), W warm-up steps, then several
+blocks of EXACTLY K steps (barrier + synchronize on both sides, max over ranks); `value` is the median block.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -52,9 +55,34 @@ def algorithmic_flops(cfg, B):
     return 2.0 * B * cfg["L"] * (E * M + M + (M - M1)), 2.0 * B * cfg["L"] * E * M
 
 
-def cpu_baseline(cfg, seconds_budget=25.0):
-    """Time oracle/torch_port.py (eager-PyTorch restatement of the reference's op sequence) on the
-    host cores for the SAME workload; bounded sample."""
+def host_cpu_info():
+    """(model name, physical cores, logical CPUs) from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
+def _cpu_port_step(cfg):
+    """one-step closure of oracle/torch_port.py (eager-PyTorch restatement of the reference's op sequence, shown in
+    the build container to run within 10 % of the imported reference: oracle/time_port_vs_reference.py)"""
     from oracle import nsvd_oracle as O
     from oracle import torch_port as TP
     p = O.init_params(cfg["L"], cfg["D"], cfg["m"], cfg["hidden"], cfg["fourier_scale"], seed=0)
@@ -64,37 +92,122 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     st = TP.PortStep(p, prob, v, M, lr=cfg["lr"], alpha=cfg["alpha"], ema_decay=cfg["ema_decay"],
                      num_iters=cfg["num_iters"])
     g = torch.Generator().manual_seed(0)
-    draw = lambda: cfg["sigma"] * torch.randn(cfg["B"], cfg["D"], generator=g)  # noqa: E731
 
     def one_step():
-        x = draw()
+        x = cfg["sigma"] * torch.randn(cfg["B"], cfg["D"], generator=g)
         t0 = time.perf_counter()
         st.step(x)
         return time.perf_counter() - t0
+    return one_step
 
-    # eager PyTorch on a many-core host is fastest well below the logical CPU count: calibrate the
-    # intra-op thread count on one step each (first call per setting also warms the thread pool)
-    ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+
+def cpu_baseline(seconds_budget=28.0, min_steps=24, max_steps=200):
+    """Time the reference's CPU path (its eager-PyTorch op sequence, oracle/torch_port.py) on the host cores:
+    configs[0] (the reference's own CPU-runnable case, B=128 sequential) and configs[1] (the headline workload),
+    3 warm-up + >= 24 timed full optimiser steps each (up to 200, about 10 s per config), median.
+    Bounded sample: ~25 s of CPU work."""
+    model, physical, logical = host_cpu_info()
     t_start = time.perf_counter()
-    best, cores = None, cands[0]
+    step2 = _cpu_port_step(ALT["cfg2"])
+    # eager PyTorch on a many-core host is fastest well below the logical CPU count: calibrate the intra-op
+    # thread count on the headline workload (first call per setting also warms the thread pool)
+    cands = sorted({c for c in (8, 16, 32, 64, physical, logical) if c <= logical})
+    best, threads = None, cands[0]
     for c in cands:
         torch.set_num_threads(c)
-        one_step()
-        t = one_step()
+        step2()
+        t = min(step2(), step2())
         if best is None or t < best:
-            best, cores = t, c
-        if time.perf_counter() - t_start > 0.5 * seconds_budget:
+            best, threads = t, c
+        if time.perf_counter() - t_start > 0.4 * seconds_budget:
             break
-    torch.set_num_threads(cores)
-    left = seconds_budget - (time.perf_counter() - t_start)
-    n = max(3, min(20, int(left / max(best, 1e-3))))
-    times = sorted(one_step() for _ in range(n))
-    med = times[len(times) // 2]
-    return dict(value=1.0 / med, unit="steps/s", cores=cores, kind="port",
-                sample=f"{n} timed full optimiser steps of the same workload (B={cfg['B']}), median, after a "
-                       f"thread-count calibration over {cands} (best: {cores} of {ncpu} logical CPUs); torch "
-                       f"{torch.__version__} CPU eager")
+    torch.set_num_threads(threads)
+    res = {}
+    for name, stepf in (("cfg2", step2), ("cfg1", _cpu_port_step(ALT["cfg1"]))):
+        for _ in range(3):
+            stepf()
+        times, t_cfg = [], time.perf_counter()
+        while len(times) < min_steps or (len(times) < max_steps and
+                                         time.perf_counter() - t_cfg < 0.35 * seconds_budget):
+            times.append(stepf())
+        times.sort()
+        res[name] = dict(steps_per_s=round(1.0 / times[len(times) // 2], 3), timed_steps=len(times),
+                         ms_median=round(1e3 * times[len(times) // 2], 2), ms_min=round(1e3 * times[0], 2),
+                         ms_max=round(1e3 * times[-1], 2))
+    return dict(value=res["cfg2"]["steps_per_s"], unit="steps/s", cores=threads, kind="port",
+                threads=threads, physical_cores=physical, logical_cpus=logical, cpu_model=model,
+                torch_version=torch.__version__,
+                configs={"configs[1] hydrogen L=16 B=512 joint (headline workload)": res["cfg2"],
+                         "configs[0] hydrogen L=16 B=128 sequential (reference CPU case)": res["cfg1"]},
+                sample=f"{res['cfg2']['timed_steps']} / {res['cfg1']['timed_steps']} timed full optimiser steps (after 3 "
+                       f"warm-up) of the headline workload / of configs[0], median; intra-op threads calibrated over {cands} -> {threads} (of {physical} "
+                       f"physical cores / {logical} logical CPUs); torch {torch.__version__} CPU eager")
+
+
+def make_trainer(cfg, par, comm, dev, path):
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    osc = cfg["potential"] == "oscillator"
+    shape = H.ModelShape(L=cfg["L"], D=cfg["D"], m=cfg["m"], hidden=cfg["hidden"], has_exp_mask=osc)
+    prob = H.make_problem(H.POT_HARMONIC if osc else H.POT_HYDROGEN, 1.0, cfg["eps"], cfg["op_scale"], cfg["op_shift"],
+                          cfg["sigma"])
+    tr = FusedTrainer(shape, prob, cfg["B"], parallelism=par, sequential=cfg["sequential"], lr=cfg["lr"],
+                      rmsprop_decay=cfg["alpha"], ema_decay=cfg["ema_decay"], num_iters=cfg["num_iters"],
+                      sampling_scale=cfg["sigma"], fourier_scale=cfg["fourier_scale"],
+                      exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev, path=path, comm=comm)
+    return tr, shape, prob
+
+
+def run_timed(tr, comm, steps, warmup, repeats, prewarm_s, events_every=0):
+    """prewarm (>= prewarm_s seconds of real steps: the GPU clock ramp and every lazy allocation are behind us
+    whatever --steps/--warmup are), `warmup` untimed steps, then `repeats` blocks of EXACTLY `steps` steps, each
+    bracketed by barrier + synchronize on both sides and reduced with MAX over ranks. Returns the per-block
+    seconds, the bracketed kernel durations (ms) and the prewarm actually spent."""
+    from neural_svd_amd import hip_ops as H
+    t0 = time.perf_counter()
+    n_pre = 0
+    while True:
+        for _ in range(50):
+            tr.step()
+        n_pre += 50
+        torch.cuda.synchronize()
+        done = time.perf_counter() - t0 >= prewarm_s
+        if comm is not None:  # every rank must leave the loop after the same number of (collective) steps
+            done = comm.max_float(0.0 if done else 1.0) == 0.0
+        if done:
+            break
+    prewarm = time.perf_counter() - t0
+    for _ in range(warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    n_ev = (steps + events_every - 1) // events_every if events_every else 0
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(n_ev * repeats)]
+    blocks = []
+    for r in range(repeats):
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            if events_every and i % events_every == 0:
+                H.profile_next_forward(*ev[r * n_ev + i // events_every])
+            tr.step()
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+        el = time.perf_counter() - t1
+        blocks.append(comm.max_float(el) if comm is not None else el)
+    kms = sorted(a.elapsed_time(b) for a, b in ev)
+    return blocks, kms, prewarm, n_pre
+
+
+def summarize(blocks, steps, world):
+    b = sorted(blocks)
+    med = b[len(b) // 2] if len(b) % 2 else 0.5 * (b[len(b) // 2 - 1] + b[len(b) // 2])
+    return dict(value=round(world * steps / med, 3), ms_per_step=round(1e3 * med / steps, 4),
+                ms_per_step_min=round(1e3 * b[0] / steps, 4), ms_per_step_max=round(1e3 * b[-1] / steps, 4),
+                blocks=len(b))
 
 
 def main():
@@ -102,23 +215,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="timed blocks of --steps steps each (median reported); default: about 6000 timed steps in "
+                         "total, between 3 and 25 blocks")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.0,
+                    help="real steps run before --warmup, independent of the step arguments (clock ramp)")
     ap.add_argument("--path", default="auto", choices=["auto", "generic", "fused", "bf16x3"],
                     help="bf16x3: developer option, first layer on the bf16 MFMA with three-way split operands "
                          "(NSVD_PATH_FUSED_BF16X3; not the headline path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (bf16x3 / hp / cfg3 lines)")
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--laplacian-eps", type=float, default=None,
                     help="developer option: override the config's finite-difference eps (<= 0: exact Laplacian)")
     ap.add_argument("--config", default="cfg2", choices=sorted(ALT))
-    ap.add_argument("--parallelism", default="auto", choices=["auto", "dp", "hp"],
-                    help="N > 1: dp = samples sharded (moments + gradient all-reduce); hp = heads sharded (one "
-                         "all-gather of f, Tf, no gradient traffic); auto = hp when L %% N == 0")
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "hp"],
+                    help="N > 1: dp = samples sharded (moments + bucketed gradient all-reduce: north_star's split, the "
+                         "headline); hp = heads sharded (one all-gather of f, Tf, no gradient traffic). The other one "
+                         "is reported beside it as a side measurement")
     args = ap.parse_args()
 
     from neural_svd_amd import hip_ops as H
     from neural_svd_amd import parallel
-    from neural_svd_amd.trainer import FusedTrainer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -140,68 +259,86 @@ def main():
         cfg["B"] = args.batch_size
     if args.laplacian_eps is not None:
         cfg["eps"] = args.laplacian_eps
-    osc = cfg["potential"] == "oscillator"
-    shape = H.ModelShape(L=cfg["L"], D=cfg["D"], m=cfg["m"], hidden=cfg["hidden"], has_exp_mask=osc)
-    prob = H.make_problem(H.POT_HARMONIC if osc else H.POT_HYDROGEN, 1.0, cfg["eps"], cfg["op_scale"], cfg["op_shift"],
-                          cfg["sigma"])
+    headline = args.config == "cfg2" and args.laplacian_eps is None and not args.batch_size
     path = {"auto": H.PATH_AUTO, "generic": H.PATH_GENERIC, "fused": H.PATH_FUSED,
             "bf16x3": H.PATH_FUSED_BF16X3}[args.path]
     par = args.parallelism
-    if par == "auto":
-        par = "hp" if (world > 1 and cfg["L"] % world == 0) else "dp"
-    tr = FusedTrainer(shape, prob, cfg["B"], parallelism=par, sequential=cfg["sequential"], lr=cfg["lr"], rmsprop_decay=cfg["alpha"],
-                      ema_decay=cfg["ema_decay"], num_iters=cfg["num_iters"], sampling_scale=cfg["sigma"],
-                      fourier_scale=cfg["fourier_scale"], exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev,
-                      path=path, comm=comm)
-
-    for _ in range(args.warmup):
-        tr.step()
-    torch.cuda.synchronize()
+    if par == "hp" and cfg["L"] % world != 0:
+        raise SystemExit(f"hp needs L ({cfg['L']}) divisible by the world size ({world})")
+    repeats = args.repeats or max(3, min(25, round(6000 / max(args.steps, 1))))
+    tr, shape, prob = make_trainer(cfg, par, comm, dev, path)
 
     use_ev = not args.no_kernel_events
     EV_EVERY = 4  # bracket the dominant kernel on every 4th timed step (two event records cost ~2 us)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)] if use_ev else []
-    if comm is not None:
-        comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if use_ev and i % EV_EVERY == 0:
-            H.profile_next_forward(*ev[i // EV_EVERY])
-        tr.step()
-    torch.cuda.synchronize()
-    if comm is not None:
-        comm.barrier()
-    elapsed = time.perf_counter() - t0
-    if comm is not None:
-        elapsed = comm.max_float(elapsed)
-
+    blocks, kms, prewarm, n_pre = run_timed(tr, comm, args.steps, args.warmup, repeats, args.prewarm_seconds,
+                                            EV_EVERY if use_ev else 0)
+    summ = summarize(blocks, args.steps, world)
     loss = float(tr.loss[0])
     finite = bool(torch.isfinite(tr.P.flat).all())
+    fused_step, tr_hp, n_train, trB, trL = tr.fused_step, tr.hp, tr.P.n_trainable, tr.B, tr.shape.L
+    path_name = H.path_name(tr.shape, tr.B, path, prob)
+    del tr
+    torch.cuda.empty_cache()
+
+    # side measurements (never `value`): same protocol, fewer blocks
+    extras = {}
+
+    def side(name, cfg_s, par_s, path_s, note):
+        try:
+            t, _, _ = make_trainer(cfg_s, par_s, comm, dev, path_s)
+            bl, _, _, _ = run_timed(t, comm, args.steps, args.warmup, max(3, repeats // 3), 0.3, 0)
+            d = summarize(bl, args.steps, world)
+            d.update(unit="steps/s", final_loss=float(t.loss[0]), params_finite=bool(torch.isfinite(t.P.flat).all()),
+                     global_batch=cfg_s["B"] * world, note=note)
+            fl, _ = algorithmic_flops(cfg_s, cfg_s["B"])
+            d["step_tflops_per_gpu"] = round(fl / (d["ms_per_step"] * 1e-3) / 1e12, 3)
+            extras[name] = d
+            del t
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001  (constructor refusals are the same on every rank)
+            extras[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    if not args.no_extras and headline and args.path == "auto":
+        if world == 1:
+            side("opt_in_path_bf16x3", cfg, "dp", H.PATH_FUSED_BF16X3,
+                 "same workload with NSVD_PATH_FUSED_BF16X3 (first layer as 3-way split bf16 products, fp32 "
+                 "accumulation, float32-accurate: DESIGN.md 3.7); not the headline value")
+        else:
+            other = "hp" if par == "dp" else "dp"
+            if other == "dp" or cfg["L"] % world == 0:
+                side(f"sharding_{other}", cfg, other, path,
+                     "same workload and global batch, heads sharded instead of samples: one all-gather of f, Tf per "
+                     "step, no gradient traffic (DESIGN.md 6)" if other == "hp" else
+                     "same workload, samples sharded: moments + bucketed gradient all-reduce")
+            c3 = ALT["cfg3"]
+            side("cfg3_dp", c3, "dp", path,
+                 "configs[2]: 2D harmonic oscillator, L=32, sequential nesting, 512 rows per GPU (global batch 4096 at "
+                 "8 GPUs), samples sharded")
+            if c3["L"] % world == 0:
+                side("cfg3_hp", c3, "hp", path, "configs[2], heads sharded")
+
     if rank != 0:
         if comm is not None:
             comm.close()
         return
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed
+    ms_per_step, value = summ["ms_per_step"], summ["value"]
     flops_step, flops_fwd = algorithmic_flops(cfg, cfg["B"])
     roof = None
-    if use_ev:
-        kms = sorted(a.elapsed_time(b) for a, b in ev)
+    if use_ev and kms:
         kavg = sum(kms) / len(kms)
         kname = H.dominant_kernel_name(shape, cfg["B"], path)
         if kname.startswith("gemm_generic"):  # generic path: the bracketed launch is the layer-0 GEMM only
             flops_fwd = 2.0 * (1 + 2 * cfg["D"]) * cfg["B"] * cfg["L"] * (2 * cfg["m"]) * cfg["hidden"][0]
         ach = flops_fwd / (kavg * 1e-3) / 1e12
         nh = len(cfg["hidden"])
-        alg_mb = 4.0 * (tr.P.n_trainable + cfg["B"] * 2 * cfg["m"] + nh * tr.shape.L * cfg["hidden"][0] * tr.B
-                        + 3 * tr.B * tr.shape.L) / 1e6
-        traffic, traffic_src = None, "profiles/"
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same workload only
+        alg_mb = 4.0 * (n_train + cfg["B"] * 2 * cfg["m"] + nh * trL * cfg["hidden"][0] * trB + 3 * trB * trL) / 1e6
+        traffic, traffic_src, busy = None, "profiles/", None
+        try:  # HBM bytes per launch / MFMA-busy fraction from the committed rocprofv3 --pmc passes, same workload only
             tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
-            if tj.get("workload") == "cfg2" and cfg["B"] == CFG["B"] and kname.startswith("pmlp_fused_fwd"):
-                traffic = int(tj["kernels"]["pmlp_fused_fwd"]["hbm_bytes_corrected"])
+            if tj.get("workload") == "cfg2" and headline and kname.startswith("pmlp_fused_fwd"):
+                k = tj["kernels"]["pmlp_fused_fwd"]
+                traffic = int(k["hbm_bytes_corrected"])
+                busy = k.get("mfma_busy_frac")
                 traffic_src = tj.get("source", "profiles/")
         except Exception:  # noqa: BLE001
             traffic = None
@@ -210,31 +347,38 @@ def main():
                     traffic_note=f"HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) from "
                                  f"{traffic_src}; algorithmic bytes {alg_mb:.1f} MB (parameters + centre features "
                                  f"read once, saved activations + f, Tf, jac written once)",
-                    kernel=kname, kernel_avg_us=round(kavg * 1e3, 2),
-                    kernel_flops=flops_fwd,
+                    mfma_busy_frac=busy,
+                    kernel=kname, kernel_avg_us=round(kavg * 1e3, 2), kernel_med_us=round(kms[len(kms) // 2] * 1e3, 2),
+                    kernel_launches_timed=len(kms), kernel_flops=flops_fwd,
                     step_flops=flops_step, step_tflops=round(flops_step / (ms_per_step * 1e-3) / 1e12, 3),
                     step_frac=round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+    sharding = {"dp": "samples: each GPU draws its own 512 rows; all-reduce of the 2L^2+1 moments, then the flat "
+                      "gradient in buckets on head boundaries, optimiser on bucket k under the all-reduce of k+1",
+                "hp": "heads: each GPU owns L/N heads and evaluates them on the whole global batch; one all-gather "
+                      "of f,Tf per step, no gradient traffic"}
     out = {
         "metric": "training steps/sec, 2D hydrogen L=16 B=512 (NestedLoRA joint nesting, full optimiser step)",
-        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "timing": {"protocol": "prewarm, then --warmup steps, then `blocks` timed blocks of exactly --steps steps "
+                               "(barrier + synchronize on both sides, max over ranks); value = median block",
+                   "blocks": summ["blocks"], "ms_per_step_min": summ["ms_per_step_min"],
+                   "ms_per_step_max": summ["ms_per_step_max"], "prewarm_s": round(prewarm, 3),
+                   "prewarm_steps": n_pre},
         "config": {"workload": "configs[1]: 2D hydrogen, L=16, batch_size=512 per GPU, joint nesting, "
                                "MLP 2048(Fourier m=1024)->128->128->128->1 x16 heads, eps=0.01, RMSprop+cosine+EMA",
                    "global_batch": cfg["B"] * world,
                    "parallelism": (f"{par}{world}" if world > 1 else "dp1"),
-                   "sharding": ("heads: each GPU owns L/N heads and evaluates them on the whole global batch; one "
-                                "all-gather of f,Tf per step, no gradient traffic" if (par == "hp" and world > 1) else
-                                "samples: each GPU draws its own 512 rows; all-reduce of 2L^2+1 moments and of the "
-                                "flat gradient per step" if world > 1 else "single GPU: no exchange"),
-                   "optimiser": ("RMSprop+EMA step fused into the weight-gradient kernel" if tr.fused_step else
-                                 "separate RMSprop+EMA kernel after the gradient all-reduce"),
-                   "path": H.path_name(tr.shape, tr.B, path, prob), "params": tr.P.n_trainable * (world if tr.hp else 1)},
+                   "sharding": sharding[par] if world > 1 else "single GPU: no exchange",
+                   "optimiser": ("RMSprop+EMA step fused into the weight-gradient kernel" if fused_step else
+                                 "separate RMSprop+EMA kernel per gradient bucket after its all-reduce"),
+                   "path": path_name, "params": n_train * (world if tr_hp else 1)},
         "final_loss": loss, "params_finite": finite,
         "roofline": roof,
     }
     try:  # the other half of BASELINE.json's metric: eigenvalue error after the full schedule (committed run records)
-        if args.config != "cfg2" or args.laplacian_eps is not None or args.batch_size:
+        if not headline:
             raise KeyError("headline workload only")
         aj = json.load(open(os.path.join(ROOT, "profiles", "latest_accuracy.json")))
         key = "bf16x3" if args.path == "bf16x3" else "fp32"
@@ -245,38 +389,16 @@ def main():
                                        "reference_published": aj["reference_published"]}
     except Exception:  # noqa: BLE001
         pass
-    if args.config != "cfg2" or args.laplacian_eps is not None or args.batch_size:
+    if not headline:
         out["metric"] = f"training steps/sec, developer config {args.config} (not the headline workload)"
         out["config"]["workload"] = f"{args.config}: {cfg}"
     if args.path == "bf16x3":
         out["metric"] += " [developer path: layer 0 as bf16x3 split products, fp32 accumulation]"
         out["config"]["layer0"] = ("bf16 MFMA, operands split into 3 bf16 planes, 6 partial products, fp32 "
                                    "accumulate; roofline.frac stays relative to the fp32 MFMA peak")
-    if world == 1 and args.path == "auto" and args.config == "cfg2" and args.laplacian_eps is None \
-            and not args.batch_size:
-        # side measurement, never the headline: the same K steps with the opt-in forward
-        try:
-            tr2 = FusedTrainer(shape, prob, cfg["B"], parallelism="dp", sequential=cfg["sequential"], lr=cfg["lr"],
-                               rmsprop_decay=cfg["alpha"], ema_decay=cfg["ema_decay"], num_iters=cfg["num_iters"],
-                               sampling_scale=cfg["sigma"], fourier_scale=cfg["fourier_scale"],
-                               exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev, path=H.PATH_FUSED_BF16X3)
-            for _ in range(args.warmup):
-                tr2.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                tr2.step()
-            torch.cuda.synchronize()
-            e2 = time.perf_counter() - t1
-            out["opt_in_path_bf16x3"] = {
-                "value": round(args.steps / e2, 3), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
-                "final_loss": float(tr2.loss[0]), "params_finite": bool(torch.isfinite(tr2.P.flat).all()),
-                "note": "same workload and step count with NSVD_PATH_FUSED_BF16X3 (first layer as 3-way split bf16 "
-                        "products, fp32 accumulation, float32-accurate: DESIGN.md 3.7); not the headline value"}
-        except Exception as e:  # noqa: BLE001
-            out["opt_in_path_bf16x3"] = {"error": f"{type(e).__name__}: {e}"}
+    out.update(extras)
     if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
-        cb = cpu_baseline(cfg)
+        cb = cpu_baseline()
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
     else:

@@ -30,7 +30,36 @@ def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
 
 
 def _stream() -> int:
+    """The current HIP stream of the CURRENT device; every launching wrapper below runs under `_on_tensor_device`,
+    which makes the tensors' device the current one first (the C library never calls hipSetDevice)."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def _on_tensor_device(fn):
+    """Run ``fn`` with the device of its GPU tensor arguments as the current device (so that `_stream()` is a stream
+    of THAT device and the kernels launch where the pointers live); tensors of one call must share a device."""
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        dev = None
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, (tuple, list)):
+                cand = [t for t in a if isinstance(t, torch.Tensor)]
+            else:
+                cand = [a] if isinstance(a, torch.Tensor) else []
+            for t in cand:
+                if not t.is_cuda:
+                    continue
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise NsvdError(f"{fn.__name__}: tensors on different devices ({dev} and {t.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return guarded
 
 
 @dataclass(frozen=True)
@@ -471,3 +500,13 @@ def row_normalize_backward(z: torch.Tensor, dout: torch.Tensor, r_up: float, mod
     check(_lib.load().nsvd_row_normalize_backward(_ptr(z, "z"), _ptr(dout, "dout"), z.shape[0], z.shape[1], float(r_up),
                                                   int(mode), _ptr(dz, "dz"), _stream()), "nsvd_row_normalize_backward")
     return dz
+
+
+# every wrapper that launches kernels runs on the device of its tensors (see _on_tensor_device)
+for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
+              "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
+              "evd_partial", "operator_backward_evd", "operator_backward_evd_step", "kernel_apply", "cdk_loss_forward",
+              "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
+              "row_normalize_backward"):
+    globals()[_name] = _on_tensor_device(globals()[_name])
+del _name

@@ -3,11 +3,12 @@
 
 Mirrors the body of the reference's ``train_operator`` loop (examples/operator/__init__.py:55-74)
 with the optimiser of examples/utils.py:50-57 and the sampler of main_pde.py:92-93; parameters,
-gradients and optimiser state live in flat float32 buffers (one RCCL all-reduce per step covers
-every gradient) with per-tensor views in the reference's state_dict layout.
+gradients and optimiser state live in flat float32 buffers (the gradient exchange of a sample-sharded
+run is a few bucketed all-reduces over contiguous ranges) with per-tensor views in the reference's
+state_dict layout.
 
-Data parallel (one process per GPU): each rank draws its own B rows; the (2 L^2 + 1)-float moment
-vector and the flat gradient are all-reduced (mean). See parallel.py.
+Multi-GPU (one process per GPU): the exchange sequences live in parallel.py (dp_step / hp_step); this
+class is their HIP compute backend, so a single-GPU step is parallel.dp_step with a world of one.
 """
 from __future__ import annotations
 
@@ -100,13 +101,16 @@ class FlatParams:
 
 
 class FusedTrainer:
+    """The step as one object, and the HIP compute backend of parallel.dp_step / parallel.hp_step (every protocol
+    method below enqueues kernels on the current stream of ``device`` and returns)."""
+
     def __init__(self, shape: H.ModelShape, problem: H.Problem, batch_size: int, sequential: bool, step: int = 1,
                  lr: float = 1e-4, rmsprop_decay: float = 0.999, rmsprop_eps: float = 1e-10, ema_decay: float = 0.995,
                  num_iters: int = 500000, use_lr_scheduler: bool = True, sampling_scale: float = 16.0,
                  fourier_scale: float = 0.1, exp_mask_init: Optional[float] = None, seed: Optional[int] = 0,
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
-                 pipeline: bool = False, parallelism: str = "dp", fused_step: bool = True,
-                 keep_grads: bool = False, device_sampler: bool = True, overlap_gather: bool = True):
+                 parallelism: str = "dp", fused_step: bool = True, keep_grads: bool = False,
+                 device_sampler: bool = True, overlap: bool = True, grad_buckets: int = 4):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
         them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
@@ -115,13 +119,19 @@ class FusedTrainer:
         also stores the gradients (P.grad), which the fused step otherwise never writes.
         device_sampler: draw the batch inside the feature kernel (nsvd_operator_sample_features, counter-based
         Philox) instead of torch's generator + a separate feature launch.
-        overlap_gather (hp): the next batch and its features (they depend on no weight) are produced into a second
-        workspace while the all-gather of f, Tf is in flight, instead of leaving the GPU idle for its latency."""
+        overlap (world > 1, device sampler): the next batch and its features (they depend on no weight) are produced
+        into a second workspace while the step's collective is in flight, instead of leaving the GPU idle.
+        grad_buckets (dp): number of gradient all-reduce buckets (cut on head boundaries of W_0)."""
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise H.NsvdError(f"FusedTrainer needs a GPU device (got {self.device}); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.path = path
         self.comm = comm  # parallel.Communicator or None
         world = comm.world if comm is not None else 1
         rank = comm.rank if comm is not None else 0
+        self.world = world
         self.hp = parallelism == "hp" and world > 1
         if parallelism not in ("dp", "hp"):
             raise ValueError("parallelism must be 'dp' or 'hp'")
@@ -138,6 +148,13 @@ class FusedTrainer:
         self.lr, self.alpha, self.eps = lr, rmsprop_decay, rmsprop_eps
         self.ema_decay, self.num_iters, self.use_sched = ema_decay, num_iters, use_lr_scheduler
         self.sigma = sampling_scale
+        with torch.cuda.device(self.device):
+            self._build(shape, problem, fourier_scale, exp_mask_init, seed, sample_seed, sequential, step, fused_step,
+                        keep_grads, device_sampler, overlap, grad_buckets, world, rank)
+
+    def _build(self, shape, problem, fourier_scale, exp_mask_init, seed, sample_seed, sequential, step, fused_step,
+               keep_grads, device_sampler, overlap, grad_buckets, world, rank):
+        path = self.path
         self.P = FlatParams(shape, self.device)
         fB0, ws0, bs0, sc0 = reference_init(self.full_shape, fourier_scale, exp_mask_init, seed)
         if self.hp:  # this rank's heads of the (identically seeded) full model
@@ -145,6 +162,13 @@ class FusedTrainer:
             ws0, bs0 = [w[sl] for w in ws0], [b[sl] for b in bs0]
             sc0 = sc0[sl] if sc0 is not None else None
         self.P.load(fB0, ws0, bs0, sc0)
+        if world > 1:
+            # replicas must start from identical weights (dp) / share the frozen Fourier matrix (hp) whatever the
+            # ranks' random streams were (seed=None): rank 0's values win
+            self.comm.broadcast(self.P.fourier_B, 0)
+            if not self.hp:
+                self.comm.broadcast(self.P.flat, 0)
+                self.P.ema.copy_(self.P.flat)
         self._params = self.P.pack(self.P.flat, True)
         self._grads = self.P.pack(self.P.grad, False)
         self._ema_params = self.P.pack(self.P.ema, True)
@@ -159,12 +183,15 @@ class FusedTrainer:
         self.M_dev = self.matrix_mask.to(self.device).contiguous()
         L, Lg = shape.L, self.Lg
         self.ws = H.new_workspace(shape, self.B, self.device)
-        # head-parallel overlap: two (workspace, x) sets used alternately; set k holds the features of batch k
-        self.overlap_gather = bool(overlap_gather) and self.hp and bool(device_sampler)
-        self._ws_other = H.new_workspace(shape, self.B, self.device) if self.overlap_gather else None
+        self.device_sampler = bool(device_sampler)
+        # overlap: two (workspace, x) sets used alternately; set k holds the features of batch k
+        self.overlap = bool(overlap) and world > 1 and self.device_sampler
+        self._ws_other = H.new_workspace(shape, self.B, self.device) if self.overlap else None
         self._x_other = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device) \
-            if self.overlap_gather else None
-        self._next_ready = False  # the other set already holds the next batch and its features
+            if self.overlap else None
+        self._next_ready = False     # the other set already holds the next batch and its features
+        self._features_ready = False  # the current set holds the features of the batch being stepped on
+        self._own_batch = False      # the batch being stepped on came from the internal device sampler
         # local (B, L_local) outputs of the forward, packed [f | Tf] so that one all-gather moves both
         self.fTf_loc = torch.empty((2, self.B, L), dtype=torch.float32, device=self.device)
         self.f, self.Tf = self.fTf_loc[0], self.fTf_loc[1]
@@ -184,12 +211,12 @@ class FusedTrainer:
         self._loss_stale = False
         self.scratch = H.evd_scratch(self.B, Lg, self.device)
         self.x = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device)
+        self._x_cur = self.x
         self.gen = torch.Generator(device=self.device)
         # dp: every rank its own stream of samples; hp: all ranks draw the SAME global batch
         srank = 0 if self.hp else rank
         self.sample_key = (sample_seed if sample_seed is not None else (seed or 0)) * 1000003 + 7919 * srank + 1
         self.gen.manual_seed(self.sample_key)
-        self.device_sampler = bool(device_sampler)
         self.batches_drawn = 0
         if self.hp:
             # every rank must draw the SAME global batch: check once that equally seeded generators agree
@@ -200,15 +227,13 @@ class FusedTrainer:
                 raise RuntimeError("head-parallel sharding: ranks draw different samples from equal seeds")
         self.t = 0            # optimiser / scheduler steps taken
         self.num_updates = 0  # torch_ema counter
-        # optional batch pipelining: the sample + Fourier features of step k+1 do not depend on the weights, so
-        # they can be produced on a side stream while step k's (HBM-bound) optimiser kernel runs on the main
-        # stream. Measured on MI355X at cfg2: no gain (312 vs 300 us/step - the two streams do not overlap in
-        # practice and the extra event traffic costs), hence off by default.
-        self.pipeline = bool(pipeline)
-        self._side = torch.cuda.Stream(device=self.device) if self.pipeline else None
-        self._ev_ready = torch.cuda.Event() if self.pipeline else None   # features of the pending batch are in ws
-        self._ev_free = torch.cuda.Event() if self.pipeline else None    # ws features / x may be overwritten
-        self._pending = False
+        self._lr_now, self._decay_now = self.lr, self.ema_decay
+        # dp gradient buckets: W_0 (89 % of the bytes, first in the flat buffer) cut on head boundaries, the small
+        # tensors ride with the last cut
+        nb = max(1, min(int(grad_buckets), shape.L))
+        w0 = shape.dims[0] * 2 * shape.m
+        cuts = [shape.L * i // nb * w0 for i in range(nb)] + [self.P.numel]
+        self._buckets = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
 
     # -- stages -------------------------------------------------------------------------------
     def sample(self) -> torch.Tensor:
@@ -216,38 +241,33 @@ class FusedTrainer:
         self.x.normal_(0.0, self.sigma, generator=self.gen)  # one kernel (randn + scale)
         return self.x
 
-    def forward_backward(self, x: torch.Tensor, features_ready: bool = False, take_step: bool = True) -> None:
-        """forward + loss + backward (+ the optimiser step when fused_step; take_step=False: gradients only)."""
-        H.operator_forward(self.shape, self._params, self.problem, x, self.ws, True, self.path, out=(self.f, self.Tf),
-                           features_ready=features_ready)
+    def _masks(self):
         cust = self.mask_kind == H.MASK_CUSTOM
-        v, M = (self.v_dev, self.M_dev) if cust else (None, None)
-        world = self.comm.world if self.comm is not None else 1
-        reduced = False
-        if self.hp:
-            # the one exchange of the head-parallel step: everybody's (B, L/world) blocks of f and Tf
-            if self.overlap_gather and features_ready and take_step:
-                work = self.comm.all_gather(self.gath, self.fTf_loc, async_op=True)
-                # meanwhile: draw batch t+1 and write its features into the other set
-                H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
-                                           self.batches_drawn, self._x_other, self._ws_other, True, self.path)
-                self.batches_drawn += 1
-                self._next_ready = True
-                work.wait()
-            else:
-                self.comm.all_gather(self.gath, self.fTf_loc)
-            self.fTf_g.view(2, self.B, world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
-        moments, scratch, loss = self._moments, self.scratch, self._loss
-        if self.direct_moments:
+        return (self.v_dev, self.M_dev) if cust else (None, None)
+
+    # -- compute-backend protocol of parallel.dp_step / parallel.hp_step ------------------------
+    def forward(self, x: torch.Tensor) -> None:
+        self._x_cur = x
+        H.operator_forward(self.shape, self._params, self.problem, x, self.ws, True, self.path, out=(self.f, self.Tf),
+                           features_ready=self._features_ready)
+
+    def local_moments(self) -> torch.Tensor:
+        v, _ = self._masks()
+        H.evd_moments(self.f, self.Tf, self.mask_kind, v, self._moments, self.scratch)
+        return self._moments
+
+    def backward(self, reduced_moments: Optional[torch.Tensor], take_step: bool) -> None:
+        """loss + d loss / d f are evaluated inside the backward kernels from the moments."""
+        v, M = self._masks()
+        moments, scratch, loss, reduced = self._moments, self.scratch, self._loss, reduced_moments is not None
+        if reduced:
+            assert reduced_moments is self._moments
+        elif self.direct_moments:
             moments = scratch = loss = None
             self._loss_stale = True
-        elif world > 1 and not self.hp:
-            H.evd_moments(self.f, self.Tf, self.mask_kind, v, self._moments, self.scratch)
-            self.comm.all_reduce_mean(self._moments)
-            reduced = True
         else:
             H.evd_partial(self.f_g, self.Tf_g, self.mask_kind, v, self.scratch)
-        # loss + d loss / d f are evaluated inside the backward kernels from the moments
+        x = self._x_cur
         if self.fused_step and take_step:
             lr, decay = self._advance_schedule()
             opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay)
@@ -259,12 +279,50 @@ class FusedTrainer:
         H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g, self.mask_kind, v, M,
                                 moments, reduced, scratch, loss, self._grads, self.ws, 1.0, self.path,
                                 l_offset=self.l_off)
+        if take_step and (self.world == 1 or self.hp):  # no exchange between backward and optimiser
+            self.begin_apply()
+            self.apply(0, self.P.numel, 1.0)
+
+    def grad_buffer(self) -> torch.Tensor:
+        return self.P.grad
+
+    def grad_buckets(self):
+        return self._buckets
+
+    def begin_apply(self) -> None:
+        self._lr_now, self._decay_now = self._advance_schedule()
+
+    def apply(self, lo: int, hi: int, grad_scale: float) -> None:
+        H.rmsprop_ema_step(self.P.flat[lo:hi], self.P.grad[lo:hi], self.P.sq[lo:hi], self.P.ema[lo:hi], self._lr_now,
+                           self.alpha, self.eps, self._decay_now, grad_scale)
+
+    def gather_buffers(self):
+        return self.gath, self.fTf_loc
+
+    def after_gather(self) -> None:
+        self.fTf_g.view(2, self.B, self.world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
+
+    def prefetch(self) -> None:
+        """Draw batch t+1 and write its features into the other (workspace, x) set - no weight is involved."""
+        if not (self.overlap and self._own_batch):
+            return
+        H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key, self.batches_drawn,
+                                   self._x_other, self._ws_other, True, self.path)
+        self.batches_drawn += 1
+        self._next_ready = True
+
+    # -- the step -----------------------------------------------------------------------------
+    def forward_backward(self, x: torch.Tensor, features_ready: bool = False, take_step: bool = True) -> None:
+        """forward + exchange + loss + backward (+ the optimiser step; take_step=False: gradients only)."""
+        from . import parallel
+        self._features_ready = bool(features_ready)
+        with torch.cuda.device(self.device):
+            (parallel.hp_step if self.hp else parallel.dp_step)(self, self.comm, x, take_step)
 
     def _refresh_loss(self) -> None:
         if self._loss_stale:  # direct-moment steps do not produce them: evaluate for the last batch now
-            cust = self.mask_kind == H.MASK_CUSTOM
-            H.evd_loss_fused(self.f_g, self.Tf_g, self.mask_kind, self.v_dev if cust else None,
-                             self.M_dev if cust else None, self._moments, self._loss, None, self.scratch)
+            v, M = self._masks()
+            H.evd_loss_fused(self.f_g, self.Tf_g, self.mask_kind, v, M, self._moments, self._loss, None, self.scratch)
             self._loss_stale = False
 
     @property
@@ -287,78 +345,49 @@ class FusedTrainer:
         self.t += 1
         return lr, decay
 
-    def optimizer_step(self) -> None:
-        if self.fused_step:
-            return  # already taken inside forward_backward
-        gscale = 1.0
-        if self.comm is not None and self.comm.world > 1 and not self.hp:
-            self.comm.all_reduce_sum(self.P.grad)
-            gscale = 1.0 / self.comm.world
-        lr, decay = self._advance_schedule()
-        H.rmsprop_ema_step(self.P.flat, self.P.grad, self.P.sq, self.P.ema, lr, self.alpha, self.eps, decay, gscale)
-
-    def _prefetch(self) -> None:
-        """Side stream: draw the next batch and write its Fourier features into the workspace."""
-        main = torch.cuda.current_stream(self.device)
-        self._ev_free.record(main)                 # everything that reads x / the features has been enqueued
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(self._ev_free)
-            self.sample()
-            H.operator_features(self.shape, self._params, self.problem, self.x, self.ws, True, self.path)
-            self._ev_ready.record(self._side)
-        self._pending = True
-
     def step(self, x: Optional[torch.Tensor] = None) -> None:
-        """One optimiser step. With ``x`` given (tests, external samplers) nothing is pipelined."""
-        if x is not None or not self.pipeline:
-            if self._pending:  # drop a prefetched batch: its features would be overwritten
-                torch.cuda.current_stream(self.device).wait_event(self._ev_ready)
-                self._pending = False
-            if x is None and self.device_sampler:
-                # one launch draws the batch and writes its features; the forward then skips the feature stage
-                if self._next_ready:  # produced under the previous step's all-gather: switch sets
-                    self.ws, self._ws_other = self._ws_other, self.ws
-                    self.x, self._x_other = self._x_other, self.x
-                    self._next_ready = False
-                else:
+        """One optimiser step on the internal sampler's next batch, or on ``x`` (tests, external samplers)."""
+        self._own_batch = x is None and self.device_sampler
+        if x is not None:
+            self._next_ready = False  # an externally supplied batch: drop any batch prepared ahead
+            self.forward_backward(x)
+        elif self.device_sampler:
+            # one launch draws the batch and writes its features; the forward then skips the feature stage
+            if self._next_ready:  # produced under the previous step's collective: switch sets
+                self.ws, self._ws_other = self._ws_other, self.ws
+                self.x, self._x_other = self._x_other, self.x
+                self._next_ready = False
+            else:
+                with torch.cuda.device(self.device):
                     H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
                                                self.batches_drawn, self.x, self.ws, True, self.path)
-                    self.batches_drawn += 1
-                self.forward_backward(self.x, features_ready=True)
-            else:
-                self._next_ready = False  # an externally supplied batch: drop any batch prepared ahead
-                if x is None:
-                    x = self.sample()
-                self.forward_backward(x)
-            self.optimizer_step()
-            return
-        main = torch.cuda.current_stream(self.device)
-        if not self._pending:
-            self._prefetch()
-        main.wait_event(self._ev_ready)
-        self._pending = False
-        self.forward_backward(self.x, features_ready=True)
-        self._prefetch()          # overlaps with the optimiser below
-        self.optimizer_step()
+                self.batches_drawn += 1
+            self.forward_backward(self.x, features_ready=True)
+        else:
+            self.forward_backward(self.sample())
 
     # -- evaluation (methods/spectrum.py:29-102 under EMA weights, operator/__init__.py:108) ----
     @torch.no_grad()
     def spectrum(self, lim: float, val_eps: float, use_ema: bool = True, chunk: int = 8192):
-        import numpy as np
+        """Rayleigh-quotient spectrum on the uniform grid arange(-lim, lim, val_eps)^D (main_pde.py:121-130)."""
         D, L = self.shape.D, self.shape.L
-        ax = np.arange(-lim, lim, val_eps)
-        xxs = np.meshgrid(*(D * [ax]))
-        grid = torch.tensor(np.array(list(zip(*[xx.flatten() for xx in xxs])))).float().to(self.device)
-        params = self._ema_params if use_ema else self._params
-        cov = torch.zeros((L, L), dtype=torch.float32, device=self.device)
-        quad = torch.zeros_like(cov)
-        for i in range(0, grid.shape[0], chunk):
-            xb = grid[i:i + chunk].contiguous()
-            ws = H.new_workspace(self.shape, xb.shape[0], self.device)
-            # a ragged last chunk is outside the MFMA kernels' shapes: let the library choose the path for it
-            path = self.path if xb.shape[0] % 32 == 0 else H.PATH_AUTO
-            f, Tf = H.operator_forward(self.shape, params, self.problem, xb, ws, False, path)
-            H.spectrum_accumulate(f, Tf, xb, self.problem.sigma, bool(self.problem.use_importance), lim, cov, quad)
+        with torch.cuda.device(self.device):
+            import numpy as np
+            ax = torch.from_numpy(np.arange(-lim, lim, val_eps))  # numpy's arange values (start + i * step)
+            # np.meshgrid's default 'xy' indexing, flattened row-major: the reference's point order
+            grid = torch.stack([g.reshape(-1) for g in torch.meshgrid(*(D * [ax]), indexing="xy" if D > 1 else "ij")],
+                               dim=1).float().to(self.device)
+            params = self._ema_params if use_ema else self._params
+            cov = torch.zeros((L, L), dtype=torch.float32, device=self.device)
+            quad = torch.zeros_like(cov)
+            ws = H.new_workspace(self.shape, min(chunk, grid.shape[0]), self.device)
+            for i in range(0, grid.shape[0], chunk):
+                xb = grid[i:i + chunk]
+                # a ragged last chunk is outside the MFMA kernels' shapes: let the library choose the path for it
+                path = self.path if xb.shape[0] % 32 == 0 else H.PATH_AUTO
+                wsb = ws if xb.shape[0] == chunk else H.new_workspace(self.shape, xb.shape[0], self.device)
+                f, Tf = H.operator_forward(self.shape, params, self.problem, xb, wsb, False, path)
+                H.spectrum_accumulate(f, Tf, xb, self.problem.sigma, bool(self.problem.use_importance), lim, cov, quad)
         n = grid.shape[0]
         cov, quad = cov.double().cpu() / n, quad.double().cpu() / n
         return dict(cov=cov, quad=quad, eigvals=torch.diag(quad) / torch.diag(cov), norms=torch.diag(cov))

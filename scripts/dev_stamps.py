@@ -1,5 +1,5 @@
 """diagnostic (GPU): per-phase cycle shares of the fused forward from s_memtime stamps.
-   NSVD_LIB_PATH=neural_svd_amd/libnsvd_hip_stamps.so python scripts/dev_stamps.py"""
+   NSVD_LIB_PATH=scripts/_diag/libnsvd_hip_stamps.so python scripts/dev_stamps.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np

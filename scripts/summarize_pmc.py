@@ -1,6 +1,12 @@
 """Post-process gpurun_out/<tag>/pmc_*_counter_collection.csv into profiles/<name>_pmc_traffic_cfg2.txt and
 profiles/latest_traffic.json (per-launch HBM-side bytes per kernel, gfx950 corrections of MI355X_MICROARCH.md:
-FETCH_SIZE under-reports wide coalesced reads by 2x, WRITE_SIZE is exact; both in KiB)."""
+FETCH_SIZE under-reports wide coalesced reads by 2x, WRITE_SIZE is exact; both in KiB) and, from the SQ pass,
+the MFMA utilisation per kernel:
+  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES)
+SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (64 cycles per v_mfma_f32_32x32x2_f32: the forward
+kernel reads exactly 64 x its MFMA count); SQ_BUSY_CYCLES is summed over the 32 shader engines, so
+SQ_BUSY_CYCLES / 32 is the dispatch's length in shader cycles (it agrees with End - Start timestamps at the
+~2.1 GHz the chip holds under a profiled run) and 1024 * that the SIMD-cycles on offer."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -25,6 +31,10 @@ lines = [f"# rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --step
          "# units: FETCH_SIZE / WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction",
          "# (MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads; WRITE_SIZE exact for 16-B stores)",
          f"{'kernel':<28}{'launches':>9}{'FETCH_KiB':>13}{'WRITE_KiB':>13}{'L2 hit':>9}{'hbm_MB(corrected)':>20}"]
+lines2 = ["", "# SQ pass: --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE",
+          "# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES) (MFMA-pipe-busy SIMD cycles over all 1024 SIMDs x dispatch cycles);",
+          "# wait_inst / wait_any / active: shares of SQ_WAVE_CYCLES (quad-cycles: issue stall, parked at waitcnt/barrier, issuing)",
+          f"{'kernel':<28}{'launches':>9}{'MFMA_BUSY':>14}{'SQ_BUSY/32':>12}{'mfma_busy_frac':>16}{'wait_inst':>11}{'wait_any':>10}{'active':>8}"]
 out = {"workload": "cfg2", "source": f"profiles/{name}_pmc_traffic_cfg2.txt", "kernels": {}}
 avg = lambda v: sum(v) / len(v) if v else float("nan")
 for _, s in SHORT:
@@ -37,6 +47,15 @@ for _, s in SHORT:
     hbm = (2 * fetch + write) * 1024
     lines.append(f"{s:<28}{len(c.get('FETCH_SIZE', [])):>9}{fetch:>13.1f}{write:>13.1f}{rate:>9.3f}{hbm / 1e6:>20.1f}")
     out["kernels"][s] = dict(fetch_kib=fetch, write_kib=write, l2_hit=rate, hbm_bytes_corrected=hbm)
+    if c.get("SQ_BUSY_CYCLES"):
+        mb, sb, wc = avg(c["SQ_VALU_MFMA_BUSY_CYCLES"]), avg(c["SQ_BUSY_CYCLES"]), avg(c.get("SQ_WAVE_CYCLES", []))
+        fr = mb / (32.0 * sb) if sb > 0 else float("nan")
+        sh = [avg(c.get(k, [])) / wc if wc == wc and wc > 0 else float("nan")
+              for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")]
+        lines2.append(f"{s:<28}{len(c['SQ_BUSY_CYCLES']):>9}{mb:>14.0f}{sb / 32:>12.0f}{fr:>16.3f}{sh[0]:>11.3f}{sh[1]:>10.3f}{sh[2]:>8.3f}")
+        out["kernels"][s].update(mfma_busy_cycles=mb, sq_busy_cycles_per_se=sb / 32, mfma_busy_frac=fr,
+                                 grbm_gui_active=avg(c.get("GRBM_GUI_ACTIVE", [])))
+lines += lines2
 open(os.path.join(root, "profiles", f"{name}_pmc_traffic_cfg2.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(root, "profiles", "latest_traffic.json"), "w"), indent=1)
 print("\n".join(lines))

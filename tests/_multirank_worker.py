@@ -1,0 +1,92 @@
+"""Child process of tests/test_multirank_gpu.py: one rank of a FusedTrainer run over gloo with every rank on ONE
+device (NSVD_FORCE_DEVICE - the GPU box has a single GPU; RCCL refuses two ranks per device, gloo does not care).
+Started as a fresh interpreter (RANK / WORLD_SIZE / MASTER_* in the environment), writes its results to argv[2]."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from neural_svd_amd import hip_ops as H  # noqa: E402
+from neural_svd_amd import parallel  # noqa: E402
+from neural_svd_amd.trainer import FusedTrainer  # noqa: E402
+
+CASE = dict(L=4, D=2, m=64, hidden=(128, 128, 128), B_local=64, steps=3)
+
+
+def make_problem():
+    return H.make_problem(H.POT_HARMONIC, 1.0, 0.01, 1.0, 16.0, 4.0)
+
+
+def make_shape():
+    return H.ModelShape(L=CASE["L"], D=CASE["D"], m=CASE["m"], hidden=CASE["hidden"], has_exp_mask=True)
+
+
+def trainer_kw():
+    return dict(sequential=False, lr=1e-3, num_iters=50, sampling_scale=4.0, fourier_scale=0.15, exp_mask_init=10.0)
+
+
+def global_batches(world):
+    g = torch.Generator().manual_seed(11)
+    return [4.0 * torch.randn(CASE["B_local"] * world, CASE["D"], generator=g) for _ in range(CASE["steps"])]
+
+
+def dp_rows(xg, rank, world):
+    """global batch arranged [f1_0 .. f1_{W-1}, f2_0 .. f2_{W-1}]: rank r's rows of each half"""
+    h = xg.shape[0] // 2
+    q = h // world
+    return torch.cat([xg[rank * q:(rank + 1) * q], xg[h + rank * q:h + (rank + 1) * q]]).contiguous()
+
+
+def main():
+    mode, out_dir = sys.argv[1], sys.argv[2]
+    dev = torch.device("cuda", int(os.environ["NSVD_FORCE_DEVICE"]))
+    torch.cuda.set_device(dev)
+    comm = parallel.Communicator.from_env(dev, backend="gloo")
+    rank, world = comm.rank, comm.world
+    shape, prob, kw = make_shape(), make_problem(), trainer_kw()
+    res = {}
+    if mode in ("dp", "hp"):
+        # external batches: comparable with a single-process run on the global batch
+        tr = FusedTrainer(shape, prob, CASE["B_local"], seed=5, device=dev, comm=comm, parallelism=mode,
+                          keep_grads=True, grad_buckets=3, **kw)
+        assert tr.hp == (mode == "hp") and tr.world == world
+        for i, xg in enumerate(global_batches(world)):
+            x = (xg if mode == "hp" else dp_rows(xg, rank, world)).to(dev)
+            tr.step(x)
+            if i == 0:
+                res["grad0"] = tr.P.grad.clone().cpu()
+                res["loss0"] = tr.loss.clone().cpu()
+                res["mom0"] = tr.moments.clone().cpu()
+        res.update(flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), sq=tr.P.sq.cpu(), t=tr.t, l_off=tr.l_off,
+                   buckets=tr.grad_buckets(), fused_step=tr.fused_step)
+    elif mode in ("dp_overlap", "hp_overlap"):
+        # internal device sampler: the batch prepared under the collective vs the plain ordering, bit for bit;
+        # seed=None: every rank draws different initial weights, rank 0's must win
+        par = mode[:2]
+        runs = []
+        for ov in (True, False):
+            torch.manual_seed(1234)  # same "unseeded" stream for both orderings of this rank
+            torch.randn(rank + 1)    # ... but a different one per rank
+            tr = FusedTrainer(shape, prob, CASE["B_local"], seed=None, sample_seed=9, device=dev, comm=comm,
+                              parallelism=par, overlap=ov, **kw)
+            assert tr.overlap == ov
+            init = tr.P.flat.clone().cpu()
+            for _ in range(6):
+                tr.step()
+            torch.cuda.synchronize()
+            runs.append(dict(init=init, flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), fB=tr.P.fourier_B.cpu(),
+                             loss=tr.loss.cpu(), drawn=tr.batches_drawn, x=tr.x.cpu()))
+        res["runs"] = runs
+    else:
+        raise SystemExit(f"unknown mode {mode}")
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.save(res, os.path.join(out_dir, f"{mode}_r{rank}.pt"))
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,37 +14,70 @@ from oracle import nsvd_oracle as O
 
 
 class OracleBackend:
-    """dp_step's backend protocol implemented with the CPU oracle (test only)."""
+    """The compute-backend protocol of parallel.dp_step / hp_step (the one trainer.FusedTrainer implements on HIP
+    kernels) on the CPU oracle (test only). dp: owns the full model on its rows; hp: owns heads
+    [l_off, l_off + L_loc) on the whole batch."""
 
-    def __init__(self, p, prob, v, M):
+    def __init__(self, p, prob, v, M, l_off=0, world=1, n_buckets=3):
         self.p, self.prob, self.v, self.M = p, prob, v.double(), M.double()
-        self.applied = None
+        self.l_off, self.world, self.n_buckets = l_off, world, n_buckets
+        self.applied, self.calls = None, []
 
+    # -- protocol
     def forward(self, x):
-        c = O.operator_forward(x, self.p, self.prob)
-        return c.f, c.Tf, c
+        self.calls.append("forward")
+        self.ctx = O.operator_forward(x, self.p, self.prob)
+        self.f_loc, self.Tf_loc = self.ctx.f, self.ctx.Tf
+        self.f, self.Tf = self.f_loc, self.Tf_loc
 
-    def moments(self, f, Tf):
-        _, lam1, lam2, loss_op, _ = O.evd_loss_forward(f, Tf, self.v, self.M)
-        return torch.cat([lam1.reshape(-1), lam2.reshape(-1), (loss_op / -2.0).reshape(1)])
+    def local_moments(self):
+        self.calls.append("local_moments")
+        _, lam1, lam2, loss_op, _ = O.evd_loss_forward(self.f, self.Tf, self.v, self.M)
+        self.mom = torch.cat([lam1.reshape(-1), lam2.reshape(-1), (loss_op / -2.0).reshape(1)])
+        return self.mom
 
-    def loss_grad(self, f, Tf, mom):
-        L = f.shape[1]
+    def backward(self, reduced_moments, take_step):
+        self.calls.append(f"backward(reduced={reduced_moments is not None}, take_step={take_step})")
+        mom = reduced_moments if reduced_moments is not None else self.local_moments()
+        L = self.f.shape[1]
         lam1, lam2 = mom[:L * L].view(L, L), mom[L * L:2 * L * L].view(L, L)
-        loss = -2.0 * mom[2 * L * L] + (self.M * lam1 * lam2).sum()
-        return loss, O.evd_loss_backward(f, Tf, self.v, self.M, lam1, lam2)
+        self.loss = -2.0 * mom[2 * L * L] + (self.M * lam1 * lam2).sum()
+        df = O.evd_loss_backward(self.f, self.Tf, self.v, self.M, lam1, lam2)
+        Ll = self.ctx.f.shape[1]
+        df = df[:, self.l_off:self.l_off + Ll].contiguous()
+        self.grad = torch.cat([g.reshape(-1) for g in O.operator_backward(self.ctx, self.p, self.prob, df)])
+        self.applied = torch.full_like(self.grad, float("nan"))
+        if take_step:
+            self.begin_apply()
+            self.apply(0, self.grad.numel(), 1.0)
 
-    def backward(self, c, df):
-        return torch.cat([g.reshape(-1) for g in O.operator_backward(c, self.p, self.prob, df)])
+    def grad_buffer(self):
+        return self.grad
 
-    def apply(self, g, scale):
-        self.applied = g * scale
+    def grad_buckets(self):
+        n = self.grad.numel()
+        cuts = [n * i // self.n_buckets for i in range(self.n_buckets + 1)]
+        return list(zip(cuts[:-1], cuts[1:]))
 
-    def backward_from_moments(self, c, f, Tf, mom):
-        """head-parallel: f, Tf cover all L heads, this backend owns heads [l_off, l_off + L_loc)."""
-        loss, df = self.loss_grad(f, Tf, mom)
-        Ll = c.f.shape[1]
-        return loss, self.backward(c, df[:, self.l_off:self.l_off + Ll].contiguous())
+    def begin_apply(self):
+        self.calls.append("begin_apply")
+
+    def apply(self, lo, hi, scale):
+        self.calls.append("apply")
+        self.applied[lo:hi] = self.grad[lo:hi] * scale
+
+    def gather_buffers(self):
+        B, Ll = self.f_loc.shape
+        self.gath = torch.empty((self.world, 2, B, Ll), dtype=self.f_loc.dtype)
+        return self.gath, torch.stack([self.f_loc, self.Tf_loc]).contiguous()
+
+    def after_gather(self):
+        W, _, B, Ll = self.gath.shape
+        both = self.gath.permute(1, 2, 0, 3).reshape(2, B, W * Ll).contiguous()  # head = rank * Ll + local head
+        self.f, self.Tf = both[0], both[1]
+
+    def prefetch(self):
+        self.calls.append("prefetch")
 
 
 def slice_heads(p, lo, hi):
@@ -73,11 +106,17 @@ def _worker(rank, world, port, tmp):
     q = h // world
     # global arrangement [f1_0, f1_1, f2_0, f2_1]: rank r owns rows r*q..(r+1)*q of each half
     x_local = torch.cat([x[rank * q:(rank + 1) * q], x[h + rank * q:h + (rank + 1) * q]])
-    be = OracleBackend(p, prob, v, M)
-    out = parallel.dp_step(be, comm, x_local, None)
+    be = OracleBackend(p, prob, v, M, world=world)
+    parallel.dp_step(be, comm, x_local)
     assert abs(comm.max_float(float(rank)) - (world - 1)) < 1e-12
     comm.barrier()
-    torch.save(dict(loss=out["loss"], grad=be.applied, mom=out["moments"]), os.path.join(tmp, f"r{rank}.pt"))
+    # the exchange sequence: moments before the backward, buckets issued before the prefetch, one schedule advance
+    assert be.calls == ["forward", "local_moments", "backward(reduced=True, take_step=False)", "prefetch",
+                        "begin_apply"] + ["apply"] * 3, be.calls
+    t = torch.ones(3, dtype=torch.float64) * (rank + 1)
+    comm.broadcast(t, 0)
+    assert float(t[0]) == 1.0
+    torch.save(dict(loss=be.loss, grad=be.applied, mom=be.mom), os.path.join(tmp, f"r{rank}.pt"))
     comm.close()
 
 
@@ -88,10 +127,10 @@ def _worker_hp(rank, world, port, tmp):
     p, prob, v, M, x = _setup()
     L = p.ws[0].shape[0]
     Ll = L // world
-    be = OracleBackend(slice_heads(p, rank * Ll, (rank + 1) * Ll), prob, v, M)
-    be.l_off = rank * Ll
-    out = parallel.hp_step(be, comm, x, None)
-    torch.save(dict(loss=out["loss"], grad=be.applied, f=out["f"]), os.path.join(tmp, f"h{rank}.pt"))
+    be = OracleBackend(slice_heads(p, rank * Ll, (rank + 1) * Ll), prob, v, M, l_off=rank * Ll, world=world)
+    parallel.hp_step(be, comm, x)
+    assert be.calls[:3] == ["forward", "prefetch", "backward(reduced=False, take_step=True)"], be.calls
+    torch.save(dict(loss=be.loss, grad=be.applied, f=be.f), os.path.join(tmp, f"h{rank}.pt"))
     comm.close()
 
 
@@ -124,10 +163,14 @@ def test_dp_step_single_process_is_plain_step():
     from neural_svd_amd import parallel
     p, prob, v, M, x = _setup()
     be = OracleBackend(p, prob, v, M)
-    out = parallel.dp_step(be, None, x, None)
+    parallel.dp_step(be, None, x)
     ref = O.loss_and_grads(x, p, prob, v, M)
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
-    assert out["grad_scale"] == 1.0
+    assert abs(float(be.loss) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
+    gref = torch.cat([g.reshape(-1) for g in ref["grads"]])
+    assert float((be.applied - gref).norm() / gref.norm()) < 1e-12   # one rank: the step is applied unscaled
+    be2 = OracleBackend(p, prob, v, M)
+    parallel.hp_step(be2, None, x)                                  # a world of one: same thing
+    assert torch.equal(be2.applied, be.applied)
 
 
 @pytest.mark.timeout(300)

@@ -1,0 +1,157 @@
+"""The multi-rank PRODUCT path on the GPU: trainer.FusedTrainer as the HIP backend of parallel.dp_step / hp_step,
+two ranks on one device over gloo. What must hold:
+  dp  sharding the global batch arranged [f1_0, f1_1, f2_0, f2_1] over 2 ranks, averaging the 2 L^2 + 1 moments and
+      summing the bucketed gradients reproduces the single-process step on the global batch (float32 summation
+      order aside), and both replicas end bit-identical;
+  hp  each rank's L/2 heads on the whole batch + one all-gather of f, Tf reproduces the single-process step's head
+      slices;
+  overlap  preparing the next batch under the collective changes nothing, bit for bit; unseeded replicas start from
+      rank 0's weights.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_multirank_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_ranks(mode, world, out_dir):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NSVD_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, WORKER, mode, str(out_dir)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-4000:]}"
+    return [torch.load(os.path.join(str(out_dir), f"{mode}_r{r}.pt"), weights_only=False) for r in range(world)]
+
+
+def single_process(world):
+    """the same steps by ONE trainer on the global batches (separate optimiser kernel so that the gradient is kept)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _multirank_worker as W
+    from neural_svd_amd.trainer import FusedTrainer
+    dev = torch.device("cuda:0")
+    tr = FusedTrainer(W.make_shape(), W.make_problem(), W.CASE["B_local"] * world, seed=5, device=dev,
+                      keep_grads=True, **W.trainer_kw())
+    out = {}
+    for i, xg in enumerate(W.global_batches(world)):
+        tr.step(xg.to(dev))
+        if i == 0:
+            out["grad0"], out["loss0"], out["mom0"] = tr.P.grad.clone().cpu(), tr.loss.clone().cpu(), \
+                tr.moments.clone().cpu()
+    torch.cuda.synchronize()
+    out.update(flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), sq=tr.P.sq.cpu())
+    return out
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.timeout(900)
+def test_dp_two_ranks_match_single_process(tmp_path):
+    world = 2
+    rs = run_ranks("dp", world, tmp_path)
+    ref = single_process(world)
+    for r in rs:
+        assert r["t"] == 3 and not r["fused_step"] and len(r["buckets"]) == 3
+        assert r["buckets"][0][0] == 0 and r["buckets"][-1][1] == ref["flat"].numel()
+        # exchange 1: the averaged moments ARE the global batch's moments; loss of the global batch
+        assert rel(r["mom0"], ref["mom0"]) < 2e-6
+        assert rel(r["loss0"], ref["loss0"]) < 2e-6
+        # exchange 2: summed bucket by bucket, scaled 1/world in the optimiser = the global batch's gradient
+        assert rel(r["grad0"] / world, ref["grad0"]) < 1e-5
+        assert rel(r["sq"], ref["sq"]) < 1e-4
+    # identical replicas
+    for name in ("flat", "ema", "sq", "grad0"):
+        assert torch.equal(rs[0][name], rs[1][name]), name
+    # net parameter movement against the single process: the few elements whose gradient is at the float32 noise
+    # floor may step the other way (RMSprop's first steps are +-lr/sqrt(1-alpha) whatever |g| is)
+    from neural_svd_amd.trainer import FusedTrainer
+    import _multirank_worker as W
+    tr0 = FusedTrainer(W.make_shape(), W.make_problem(), 64, seed=5, device="cuda:0", **W.trainer_kw())
+    p0 = tr0.P.flat.cpu()
+    upd, upd_ref = rs[0]["flat"] - p0, ref["flat"] - p0
+    assert float(upd_ref.norm()) > 0
+    assert rel(upd, upd_ref) < 2e-2
+    assert float(((upd - upd_ref).abs() > 1e-4).double().mean()) < 1e-3
+
+
+def _views(flat, L):
+    """per-tensor views of a flat buffer of an L-head model (the layout rule of trainer.FlatParams)"""
+    import math
+    import _multirank_worker as W
+    from neural_svd_amd import hip_ops as H
+    shapes = H.ModelShape(L=L, D=W.CASE["D"], m=W.CASE["m"], hidden=W.CASE["hidden"], has_exp_mask=True).param_shapes()
+    views, off = [], 0
+    for s in shapes:
+        n = math.prod(s)
+        views.append(flat[off:off + n].view(s))
+        off += (n + 63) // 64 * 64
+    return views
+
+
+@pytest.mark.timeout(900)
+def test_hp_two_ranks_match_single_process(tmp_path):
+    world = 2
+    rs = run_ranks("hp", world, tmp_path)
+    ref = single_process(world)
+    import _multirank_worker as W
+    L = W.CASE["L"]
+    Ll = L // world
+    for rank, r in enumerate(rs):
+        assert r["t"] == 3 and r["fused_step"] and r["l_off"] == rank * Ll
+        assert rel(r["loss0"], ref["loss0"]) < 2e-6 and rel(r["mom0"], ref["mom0"]) < 2e-6
+        # this rank's tensors are the head slices [l_off, l_off + Ll) of the single-process tensors
+        for name, tol in (("grad0", 1e-5), ("sq", 1e-4)):
+            want = torch.cat([t[rank * Ll:(rank + 1) * Ll].reshape(-1) for t in _views(ref[name], L)])
+            got = torch.cat([t.reshape(-1) for t in _views(r[name], Ll)])
+            assert rel(got, want) < tol, (name, rel(got, want))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["dp_overlap", "hp_overlap"])
+def test_overlapped_prefetch_is_bit_identical_and_replicas_agree(tmp_path, mode):
+    world = 2
+    rs = run_ranks(mode, world, tmp_path)
+    for r in rs:
+        ov, plain = r["runs"]
+        for k in ("init", "flat", "ema", "fB", "loss", "x"):
+            assert torch.equal(ov[k], plain[k]), k
+        assert ov["drawn"] == plain["drawn"] + 1 == 7  # one batch prepared ahead
+        assert bool(torch.isfinite(ov["flat"]).all())
+    a, b = rs[0]["runs"][0], rs[1]["runs"][0]
+    assert torch.equal(a["fB"], b["fB"])              # the frozen Fourier matrix is shared in both shardings
+    if mode == "dp_overlap":
+        assert torch.equal(a["init"], b["init"]) and torch.equal(a["flat"], b["flat"]) and torch.equal(a["ema"], b["ema"])
+        assert not torch.equal(a["x"], b["x"])        # every rank its own rows
+    else:
+        assert torch.equal(a["x"], b["x"])            # every rank the same global batch
