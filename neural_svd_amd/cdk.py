@@ -17,6 +17,8 @@ inputs are never modified in place (the reference's ``f *= batch_weights`` write
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -138,32 +140,50 @@ def normalize(z, r_up, regularize_mode):
 
 
 class HeteroNetwork(nn.Module):
-    """Two towers (backbone -> projector -> normalize), examples/models/siam.py:132-166: same constructor, same
-    ``forward(x, y) -> [x_rep, x_emb, y_rep, y_emb]`` and ``forward_single``. The backbones / projectors are the
-    caller's modules (plain Linear + BatchNorm MLPs in the shipped script: library GEMMs); the embedding's
-    normalisation runs on the HIP kernel above."""
+    """The two-tower network of the CDK script behind the reference's interface (examples/models/siam.py:132-166:
+    constructor arguments, ``forward(x, y) -> [x_rep, x_emb, y_rep, y_emb]``, ``forward_single(x, side, classify)``,
+    ``output_dims``, and the ``backbones.{x,y}.* / projectors.{x,y}.* / online_heads.{x,y}.*`` state_dict keys).
+    One method, ``embed``, does the work of a side: representation = backbone(input), embedding = the projector's
+    output scaled into the radius-sqrt(mu) ball / sphere by the HIP row kernel (``normalize`` above)."""
+
+    SIDES = ("x", "y")
+    MODES = ("l2_ball", "l2_sphere", "clip", "tanh")
 
     def __init__(self, backbones, projectors, online_heads=None, mu=1.0, regularize_mode=None):
         super().__init__()
-        self.mu = mu
-        self.backbones = nn.ModuleDict({"x": backbones[0], "y": backbones[1]})
-        self.projectors = nn.ModuleDict({"x": projectors[0], "y": projectors[1]})
-        self.online_heads = nn.ModuleDict({"x": online_heads[0], "y": online_heads[1]}) if online_heads else None
-        self.output_dims = {k: self.backbones[k].output_dim if isinstance(self.projectors[k], nn.Identity)
-                            else self.projectors[k].output_dim for k in self.projectors}
-        assert regularize_mode in ["l2_ball", "l2_sphere", "clip", "tanh"]
-        self.regularize_mode = regularize_mode
+        if regularize_mode not in self.MODES:
+            raise AssertionError(f"regularize_mode must be one of {self.MODES}, got {regularize_mode!r}")
+        per_side = lambda mods: nn.ModuleDict(dict(zip(self.SIDES, mods)))  # noqa: E731
+        self.backbones, self.projectors = per_side(backbones), per_side(projectors)
+        self.online_heads = per_side(online_heads) if online_heads else None
+        self.mu, self.regularize_mode = mu, regularize_mode
 
-    def forward(self, x, y):
-        return [*self.forward_single(x, "x"), *self.forward_single(y, "y")]
+    @property
+    def output_dims(self):
+        """embedding width per side: the projector's, or the backbone's behind an Identity projector"""
+        widths = {}
+        for side in self.SIDES:
+            proj = self.projectors[side]
+            widths[side] = (self.backbones[side] if isinstance(proj, nn.Identity) else proj).output_dim
+        return widths
+
+    def embed(self, inp, side):
+        if side not in self.SIDES:
+            raise AssertionError(f"side must be one of {self.SIDES}")
+        rep = self.backbones[side](inp)
+        return rep, normalize(self.projectors[side](rep), math.sqrt(self.mu), self.regularize_mode)
 
     def forward_single(self, x, x_or_y, classify=False):
-        assert x_or_y in ["x", "y"]
-        rep = self.backbones[x_or_y](x)
-        emb = normalize(self.projectors[x_or_y](rep), float(self.mu) ** 0.5, self.regularize_mode)
-        if classify:
-            return rep, emb, self.online_heads[x_or_y](emb.detach())
-        return rep, emb
+        rep, emb = self.embed(x, x_or_y)
+        if not classify:
+            return rep, emb
+        return rep, emb, self.online_heads[x_or_y](emb.detach())  # the probe never trains the tower
+
+    def forward(self, x, y):
+        out = []
+        for side, inp in zip(self.SIDES, (x, y)):
+            out.extend(self.embed(inp, side))
+        return out
 
 
 def _activation_factory(name: str):

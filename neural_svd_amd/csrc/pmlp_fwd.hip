@@ -553,10 +553,8 @@ int launch_fwd(const FwdArgs& a, hipStream_t s) {
 }
 }  // namespace
 
-bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact) {
-    // E <= 5 columns per sample: the forward's LDS image (155 KB at E = 5). Stencil: E = 1 + 2D, so D <= 2; the
-    // exact-Laplacian jets have E = D + 2, so D <= 3.
-    if (d.D < 1 || d.D > (exact ? 3 : 2)) return false;
+// shape conditions shared by the operator path and the plain-model path (both end in the same fused backward)
+static bool fused_shape_ok(const nsvd_model_desc& d, int B) {
     if (d.nlayers < 2) return false;
     for (int i = 0; i < d.nlayers - 1; ++i)
         if (d.dims[i] != HID) return false;
@@ -566,6 +564,13 @@ bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact) {
     // the weight-gradient epilogue addresses every tensor with 32-bit byte offsets (W_0 is the largest)
     if ((size_t)d.L * HID * (size_t)(2 * d.m) * sizeof(float) >= ((size_t)1 << 32)) return false;
     return true;
+}
+
+bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact) {
+    // E <= 5 columns per sample: the forward's LDS image (155 KB at E = 5). Stencil: E = 1 + 2D, so D <= 2; the
+    // exact-Laplacian jets have E = D + 2, so D <= 3.
+    if (d.D < 1 || d.D > (exact ? 3 : 2)) return false;
+    return fused_shape_ok(d, B);
 }
 
 size_t nsvd_fused_workspace_bytes(const nsvd_model_desc& d, int B) { return carve_fused(d, B, nullptr).bytes; }
@@ -665,13 +670,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
 // ---- plain model evaluation on the fused kernels (E = 1): out = c * model(x), any input dimension --------------
 bool nsvd_fused_model_supported(const nsvd_model_desc& d, int B) {
     if (d.D < 1 || d.D > 64) return false;
-    if (d.nlayers < 2) return false;
-    for (int i = 0; i < d.nlayers - 1; ++i)
-        if (d.dims[i] != HID) return false;
-    if (B % BS != 0 || B > 65536) return false;
-    if (B / wgrad_slices(d, B) > 8192) return false;
-    if ((2 * d.m) % HID != 0) return false;
-    return true;
+    return fused_shape_ok(d, B);
 }
 
 int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, float c,

@@ -20,42 +20,90 @@ from .spectrum import compute_spectrum_evd
 
 
 class ExponentialMovingAverage:
-    """torch_ema.ExponentialMovingAverage's behaviour as the reference uses it (update(),
-    average_parameters(), state_dict()): shadow = clone(params); on update n += 1,
-    d = min(decay, (1 + n) / (10 + n)), shadow -= (1 - d) (shadow - param)."""
+    """torch_ema.ExponentialMovingAverage's documented behaviour (the package is not in this image: parity
+    unpinned): shadow = clone(params); on update n += 1, d = min(decay, (1 + n) / (10 + n)),
+    shadow -= (1 - d) (shadow - param); store / restore / copy_to / average_parameters; state_dict with the keys
+    decay, num_updates, shadow_params, collected_params (what torch_ema's load_state_dict reads)."""
 
     def __init__(self, parameters, decay: float, use_num_updates: bool = True):
+        if not 0.0 <= decay <= 1.0:
+            raise ValueError("Decay must be between 0 and 1")
         self.params = [p for p in parameters if p.requires_grad]
         self.decay = decay
         self.num_updates = 0 if use_num_updates else None
         self.shadow_params = [p.detach().clone() for p in self.params]
-        self.collected = None
+        self.collected_params = None
+
+    def _resolve(self, parameters):
+        if parameters is None:
+            return self.params
+        ps = [p for p in parameters if p.requires_grad]
+        if len(ps) != len(self.shadow_params):
+            raise ValueError("Number of parameters passed as argument is different from number of shadow parameters "
+                             "maintained by this ExponentialMovingAverage")
+        return ps
 
     @torch.no_grad()
-    def update(self):
+    def update(self, parameters=None):
+        params = self._resolve(parameters)
         d = self.decay
         if self.num_updates is not None:
             self.num_updates += 1
             d = min(d, (1 + self.num_updates) / (10 + self.num_updates))
-        diffs = torch._foreach_sub(self.shadow_params, [p.detach() for p in self.params])
+        diffs = torch._foreach_sub(self.shadow_params, [p.detach() for p in params])
         torch._foreach_mul_(diffs, 1.0 - d)
         torch._foreach_sub_(self.shadow_params, diffs)
 
+    @torch.no_grad()
+    def copy_to(self, parameters=None):
+        for p, s in zip(self._resolve(parameters), self.shadow_params):
+            p.copy_(s)
+
+    @torch.no_grad()
+    def store(self, parameters=None):
+        self.collected_params = [p.detach().clone() for p in self._resolve(parameters)]
+
+    @torch.no_grad()
+    def restore(self, parameters=None):
+        if self.collected_params is None:
+            raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
+        for p, c in zip(self._resolve(parameters), self.collected_params):
+            p.copy_(c)
+
     @contextlib.contextmanager
-    def average_parameters(self):
-        saved = [p.detach().clone() for p in self.params]
-        with torch.no_grad():
-            for p, s in zip(self.params, self.shadow_params):
-                p.copy_(s)
+    def average_parameters(self, parameters=None):
+        params = self._resolve(parameters)
+        self.store(params)
+        self.copy_to(params)
         try:
             yield
         finally:
-            with torch.no_grad():
-                for p, s in zip(self.params, saved):
-                    p.copy_(s)
+            self.restore(params)
+
+    def to(self, device=None, dtype=None):
+        self.shadow_params = [s.to(device=device, dtype=dtype if s.is_floating_point() else None)
+                              for s in self.shadow_params]
+        if self.collected_params is not None:
+            self.collected_params = [c.to(device=device, dtype=dtype if c.is_floating_point() else None)
+                                     for c in self.collected_params]
 
     def state_dict(self):
-        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
+        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params,
+                    collected_params=self.collected_params)
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        self.decay = sd["decay"]
+        if not 0.0 <= self.decay <= 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.num_updates = sd["num_updates"]
+        shadow = sd["shadow_params"]
+        if len(shadow) != len(self.params):
+            raise ValueError("shadow_params does not match the parameters of this ExponentialMovingAverage")
+        self.shadow_params = [s.detach().clone().to(device=p.device, dtype=p.dtype) for s, p in zip(shadow, self.params)]
+        coll = sd.get("collected_params")
+        self.collected_params = None if coll is None else \
+            [c.detach().clone().to(device=p.device, dtype=p.dtype) for c, p in zip(coll, self.params)]
 
 
 def get_optimizer(args, model):
@@ -135,13 +183,19 @@ def _refresh_from_trainer(tr, method, ema, optimizer, scheduler):
 
 def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch_ftn_val, log_writer, log_file,
                    device, importance_train, importance_val, ground_truth_spectrum=None):
+    if getattr(args, "use_amp", False):
+        # the reference wraps the step in autocast + GradScaler (examples/operator/__init__.py:37-38,62-72); the HIP
+        # path computes in float32 only and the PDE scripts never set the flag: refuse rather than ignore it
+        raise NotImplementedError("use_amp: the HIP path is float32 only (no autocast / GradScaler branch)")
     optimizer = get_optimizer(args, method)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.num_iters)
     ema = ExponentialMovingAverage(method.parameters(), decay=args.ema_decay)
     fused = _fused_loop_trainer(args, method, operator, importance_train, device)
     all_eigvals, all_norms = [], []
     start = time.time()
-    total_loss = 0.0
+    # the reference adds loss.item() to a host total on EVERY step (operator/__init__.py:74,99: a device sync per
+    # step); here the running total lives on the device and is read at print time only
+    total_loss = torch.zeros((), dtype=torch.float64, device=device)
     for it in range(args.num_iters):
         x = make_batch_ftn_train().to(device)
         x = x.reshape(x.shape[0], -1)
@@ -149,7 +203,8 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
             fused = None  # the sampler does not produce args.batch_size rows: the plain loop takes any batch
         if fused is not None:
             fused.step(x.float().contiguous())
-            loss = None
+            loss = fused.loss[0]  # evaluated on the device from this step's f, Tf (no sync)
+            total_loss += loss
         else:
             method.train()
             optimizer.zero_grad()
@@ -159,11 +214,10 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
             if args.use_lr_scheduler:
                 scheduler.step()
             ema.update()
+            total_loss += loss.detach()
         if (it + 1) % args.print_freq == 0:
             # the only host sync, and only at print time (the reference syncs every step)
-            li = float(fused.loss[0]) if fused is not None else loss.item()
-            total_loss += li
-            row = {"iter": it + 1, "train_loss": li, "avg_train_loss": total_loss / ((it + 1) // args.print_freq),
+            row = {"iter": it + 1, "train_loss": float(loss), "avg_train_loss": float(total_loss) / (it + 1),
                    "time": time.time() - start}
             print(row)
             if log_writer is not None:

@@ -94,10 +94,22 @@ class FlatParams:
         d["model.base.feature_map._B"] = self.fourier_B.clone()
         return d
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], ema_sd: Optional[Dict[str, torch.Tensor]] = None,
+                        reset_optimizer: bool = True) -> None:
+        """Weights (and frozen Fourier matrix) from a reference-layout state_dict. The EMA shadow is taken from
+        ``ema_sd`` (same keys) or restarted from the loaded weights (what constructing torch_ema on them does); the
+        RMSprop square averages restart from zero unless ``reset_optimizer`` is False."""
         for n, t in zip(self.names, self.views(self.flat)):
             t.copy_(sd[n].reshape(t.shape))
         self.fourier_B.copy_(sd["model.base.feature_map._B"])
+        if self.ema is not None:
+            if ema_sd is not None:
+                for n, t in zip(self.names, self.views(self.ema)):
+                    t.copy_(ema_sd[n].reshape(t.shape))
+            else:
+                self.ema.copy_(self.flat)
+        if self.sq is not None and reset_optimizer:
+            self.sq.zero_()
 
 
 class FusedTrainer:

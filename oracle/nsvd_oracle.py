@@ -469,6 +469,41 @@ def loss_and_grads(x, p: Params, prob: Problem, v, M):
     return dict(loss=loss, f=c.f, Tf=c.Tf, lam1=lam1, lam2=lam2, df=df, grads=grads)
 
 
+def gaussian_kernel_apply(x, x_ref, f_ref, ell):
+    """The toy kernel operator of tests/golden/kernel_loss.npz (tests/golden/make_golden.py:gaussian_kernel_op_factory):
+    Kf(x) = (1 / B_ref) sum_j exp(-|x - x_ref_j|^2 / (2 ell^2)) f(x_ref_j)."""
+    d2 = ((x[:, None, :] - x_ref[None, :, :]) ** 2).sum(-1)
+    return torch.exp(-d2 / (2.0 * ell ** 2)) @ f_ref / x_ref.shape[0]
+
+
+def kernel_loss_and_grads(x, p: Params, kernel_fn, v, M, split_batch: bool, hard_mul_const: float = 1.0):
+    """NestedLoRA.compute_loss_kernel + backward (reference methods/nestedlora.py:230-252) for an operator of the form
+    Kf = kernel_fn(x_eval, x_ref, model(x_ref)) that carries no gradient (the loss Function returns none for Tf,
+    :108-111). Pinned by tests/golden/kernel_loss.npz. Returns dict(loss, f, Kf, grads in Params.trainable() order).
+      split_batch=False (:246-249): Kf, f on the whole batch; f1, f2 = chunk(f, 2).
+      split_batch=True  (:239-245): x1, x2 = chunk(x, 2); Kf1 = K applied to x1 against the reference batch x2,
+        f2 = model(x2); loss(f1, Kf1, f1, f2): operator term and its gradient carry 1 / B1."""
+    plain = Problem(potential=POT_HARMONIC, eps=0.01, use_importance=False, hard_mul_const=hard_mul_const)
+    v, M = v.to(x.dtype), M.to(x.dtype)
+    if not split_batch:
+        c = operator_forward(x, p, plain)             # c.f = model(x): no importance, the stencil part is unused
+        Kf = kernel_fn(x, x, c.f)
+        loss, lam1, lam2, _, _ = evd_loss_forward(c.f, Kf, v, M)
+        grads = operator_backward(c, p, plain, evd_loss_backward(c.f, Kf, v, M, lam1, lam2))
+        return dict(loss=loss, f=c.f, Kf=Kf, grads=grads)
+    B = x.shape[0]
+    B1 = (B + 1) // 2
+    c1, c2 = operator_forward(x[:B1], p, plain), operator_forward(x[B1:], p, plain)
+    f1, f2 = c1.f, c2.f
+    Kf1 = kernel_fn(x[:B1], x[B1:], f2)
+    lam1, lam2 = f1.T @ f1 / B1, f2.T @ f2 / (B - B1)                                   # :10-11
+    loss = -2.0 * ((f1 * Kf1) @ v).mean() + (M * lam1 * lam2).sum()                     # :92, :64
+    df1 = -(4.0 / B1) * Kf1 * v.unsqueeze(0) + (2.0 / B1) * (f1 @ (M * lam2))           # :108-109
+    df2 = (2.0 / (B - B1)) * (f2 @ (M * lam1))                                          # :110
+    grads = [a + b for a, b in zip(operator_backward(c1, p, plain, df1), operator_backward(c2, p, plain, df2))]
+    return dict(loss=loss, f=f1, Kf=Kf1, grads=grads)
+
+
 # ----------------------------------------------------------------------------- optimiser
 def cosine_lr(base_lr, t, T, eta_min=0.0):
     """closed form of torch.optim.lr_scheduler.CosineAnnealingLR after t scheduler steps

@@ -352,6 +352,72 @@ def golden_normalize(out):
                 out[p + f"{mode}_{tag}_out"], out[p + f"{mode}_{tag}_dz"] = np64(y), np64(z.grad)
 
 
+def gaussian_kernel_op_factory(ell):
+    """A toy `get_approx_kernel_op` for NestedLoRA.compute_loss_kernel (the reference ships none): the Gaussian
+    kernel k(x, y) = exp(-|x - y|^2 / (2 ell^2)) applied by Monte-Carlo quadrature on the reference batch,
+    Kf(x) = (1 / B_ref) sum_j k(x, x_ref_j) f(x_ref_j), f evaluated through the method itself."""
+    def get_approx_kernel_op(x_ref):
+        def op(method, x, importance=None):
+            f = method(x)
+            with torch.no_grad():
+                f_ref = method(x_ref)
+                Kmat = torch.exp(-torch.cdist(x, x_ref) ** 2 / (2.0 * ell ** 2))
+                Kf = Kmat @ f_ref / x_ref.shape[0]
+            return Kf, f
+        return op
+    return get_approx_kernel_op
+
+
+def golden_kernel_loss(out):
+    """NestedLoRA.compute_loss_kernel (methods/nestedlora.py:230-252), both split_batch modes, on the reference's own
+    WaveFunctions model (plain model evaluation: no importance, no stencil) with the toy Gaussian-kernel operator
+    above: loss, f, Kf and every parameter gradient, float64 and float32."""
+    ell = 1.5
+    cases = dict(
+        ka=dict(neigs=4, mlp_hidden_dims="32,32", fourier_mapping_size=16, fourier_scale=0.3, batch_size=24,
+                sequential=1, seed=21),
+        kb=dict(neigs=4, mlp_hidden_dims="128,128,128", fourier_mapping_size=64, fourier_scale=0.3, batch_size=64,
+                sequential=0, step=1, apply_exp_mask=1, exp_mask_init_scale=3.0, seed=22),
+        kc=dict(neigs=5, mlp_hidden_dims="12,20", fourier_mapping_size=5, fourier_scale=0.3, batch_size=33,
+                sequential=0, step=2, seed=23),
+    )
+    for name, over in cases.items():
+        args0 = make_args(**dict(over))
+        torch.manual_seed(args0.seed + 500)
+        x32 = 2.0 * torch.randn(args0.batch_size, args0.ndim)
+        out[f"{name}_x"] = x32.numpy()
+        out[f"{name}_ell"] = np.array(ell)
+        big = "128" in over["mlp_hidden_dims"]
+        for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            args = make_args(**dict(over))
+            _, _, method, *_ = build(args, dtype)
+            if tag == "f64":
+                out[f"{name}_param_names"] = np.array([n for n, _ in method.named_parameters()])
+                out[f"{name}_v"], out[f"{name}_M"] = method.vector_mask.numpy(), method.matrix_mask.numpy()
+                if not big:  # the H=128 case is rebuilt from its seed (same recipe as the cfg1 fixture)
+                    for n, t in method.named_parameters():
+                        out[f"{name}_param0_{n}"] = t.detach().float().numpy()
+            x = x32.to(dtype)
+            for split in (False, True):
+                method.zero_grad()
+                loss, aux = method.compute_loss_kernel(gaussian_kernel_op_factory(ell), x, None, split_batch=split)
+                loss.backward()
+                q = f"{name}_{tag}_split{int(split)}_"
+                out[q + "loss"], out[q + "f"], out[q + "Kf"] = np64(loss), np64(aux["f"]), np64(aux["Tf"])
+                for n, t in method.named_parameters():
+                    if t.grad is None:
+                        continue
+                    g = np64(t.grad)
+                    if big and g.size > 4096:
+                        out[q + f"gradnorm_{n}"] = np.array(np.linalg.norm(g))
+                        out[q + f"gradsample_{n}"] = g.reshape(-1)[::61]
+                    else:
+                        out[q + f"grad_{n}"] = g
+        cfg = {k: v for k, v in vars(make_args(**dict(over))).items() if k != "loss"}
+        cfg["sequential"], cfg["step"] = int(over.get("sequential", 1)), int(over.get("step", 1))
+        out[f"{name}_cfg"] = np.array(repr(cfg))
+
+
 def golden_ground_truth(out):
     out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
     out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
@@ -367,12 +433,21 @@ def main():
         np.savez_compressed(os.path.join(HERE, "normalize.npz"), **o)
         print("normalize", os.path.getsize(os.path.join(HERE, "normalize.npz")) // 1024, "KiB")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "kernel_loss":
+        o = {}
+        golden_kernel_loss(o)
+        np.savez_compressed(os.path.join(HERE, "kernel_loss.npz"), **o)
+        print("kernel_loss", os.path.getsize(os.path.join(HERE, "kernel_loss.npz")) // 1024, "KiB")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "svd":  # only the fixture added last (the others stay byte-identical)
         o = {}
         golden_svd(o)
         np.savez_compressed(os.path.join(HERE, "svd_loss.npz"), **o)
         print("svd_loss", os.path.getsize(os.path.join(HERE, "svd_loss.npz")) // 1024, "KiB")
         return
+    o = {}
+    golden_kernel_loss(o)
+    np.savez_compressed(os.path.join(HERE, "kernel_loss.npz"), **o)
     o = {}
     golden_svd(o)
     np.savez_compressed(os.path.join(HERE, "svd_loss.npz"), **o)
@@ -438,7 +513,7 @@ def main():
                  fourier_scale=1.0, sampling_scale=4.0, batch_size=7, operator_scale=1.0, operator_shift=16.0,
                  apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=0, seed=9)
     np.savez_compressed(os.path.join(HERE, "model_exact.npz"), **o)
-    for fn in ("masks", "evd_loss", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
+    for fn in ("kernel_loss", "masks", "evd_loss", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

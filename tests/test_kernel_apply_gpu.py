@@ -123,3 +123,60 @@ def test_compute_loss_kernel_with_dense_operator():
     assert abs(float(loss.detach()) - float(l64)) < 1e-4 * abs(float(l64))
     for n, gr in zip(names, gref):
         assert rel(got[n].grad, gr) < 1e-4, n
+
+
+@pytest.mark.parametrize("case", ["ka", "kb", "kc"])
+@pytest.mark.parametrize("split", [False, True])
+def test_compute_loss_kernel_matches_reference_golden(case, split):
+    """NestedLoRA.compute_loss_kernel on the HIP path (differentiable model evaluation + EVD loss kernels) against the
+    REFERENCE's own compute_loss_kernel (methods/nestedlora.py:230-252; tests/golden/kernel_loss.npz: its
+    WaveFunctions model, a toy Gaussian-kernel `get_approx_kernel_op`, both split_batch modes): loss, f, Kf and
+    every parameter gradient vs the float64 reference values, held to what the float32 reference itself achieves.
+    kb takes the fused MFMA model kernels (128-wide hidden layers, exponential mask), ka / kc the generic ones."""
+    from tests import _golden as G
+    from tests.test_dropin_gpu import make_args
+    from neural_svd_amd.models import get_wavefunctions
+    from neural_svd_amd.nested_lowrank import get_evd_method
+    z = G.load("kernel_loss")
+    cfg = G.cfg_of(z, case)
+    args = make_args(cfg)
+    torch.manual_seed(cfg["seed"])  # the reference's draw order: same initial weights bit for bit
+    method = get_evd_method(args, "neuralsvd", get_wavefunctions(args)).to(DEV)
+    if f"{case}_param0_model.base.ws.0" in z.files:
+        for n, t in method.named_parameters():
+            assert torch.equal(t.detach().cpu(), torch.tensor(z[f"{case}_param0_{n}"])), n
+    assert torch.equal(method.vector_mask.cpu(), torch.tensor(z[f"{case}_v"]))
+    assert torch.equal(method.matrix_mask.cpu(), torch.tensor(z[f"{case}_M"]))
+    ell = float(z[f"{case}_ell"])
+    x = torch.tensor(z[f"{case}_x"]).to(DEV)
+
+    def get_approx_kernel_op(x_ref):  # the user's operator: arbitrary Python around method(x)
+        def op(m, xe, importance=None):
+            f = m(xe)
+            with torch.no_grad():
+                Kmat = torch.exp(-torch.cdist(xe.double(), x_ref.double()) ** 2 / (2.0 * ell ** 2))
+                Kf = (Kmat @ m(x_ref).double() / x_ref.shape[0]).float()
+            return Kf, f
+        return op
+
+    loss, aux = method.compute_loss_kernel(get_approx_kernel_op, x, None, split_batch=split)
+    loss.backward()
+    q64, q32 = f"{case}_f64_split{int(split)}_", f"{case}_f32_split{int(split)}_"
+
+    def tol(key, floor):  # a few times the float32 reference's own distance from its float64 self
+        return max(4.0 * G.rel(z[q32 + key], z[q64 + key]), floor)
+    assert abs(float(loss) - float(z[q64 + "loss"])) < max(4 * abs(float(z[q32 + "loss"]) - float(z[q64 + "loss"])),
+                                                           2e-6 * abs(float(z[q64 + "loss"])))
+    assert rel(aux["f"].detach(), torch.tensor(z[q64 + "f"])) < tol("f", 2e-6)
+    assert rel(aux["Tf"].detach(), torch.tensor(z[q64 + "Kf"])) < tol("Kf", 2e-6)
+    for n, t in method.named_parameters():
+        if t.grad is None:
+            continue
+        if q64 + f"grad_{n}" in z.files:
+            assert rel(t.grad.reshape(z[q64 + f"grad_{n}"].shape), torch.tensor(z[q64 + f"grad_{n}"])) < \
+                tol(f"grad_{n}", 5e-6), n
+        else:
+            want = float(z[q64 + f"gradnorm_{n}"])
+            assert abs(float(t.grad.double().norm()) - want) < 1e-5 * want, n
+            assert rel(t.grad.reshape(-1)[::61], torch.tensor(z[q64 + f"gradsample_{n}"])) < \
+                tol(f"gradsample_{n}", 5e-6), n

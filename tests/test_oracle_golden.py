@@ -302,3 +302,29 @@ def test_row_normalize(case, mode):
     y.backward(torch.tensor(z[f"norm_{case}_dout"]))
     assert G.rel(y.detach(), z[f"norm_{case}_{mode}_f64_out"]) <= 1e-14
     assert G.rel(x.grad, z[f"norm_{case}_{mode}_f64_dz"]) <= 1e-13
+
+
+# ----------------------------------------------------------------------------- compute_loss_kernel
+@pytest.mark.parametrize("case", ["ka", "kb", "kc"])
+@pytest.mark.parametrize("split", [False, True])
+def test_kernel_loss_matches_reference(case, split):
+    """oracle kernel_loss_and_grads vs the reference's NestedLoRA.compute_loss_kernel (methods/nestedlora.py:230-252)
+    on its own WaveFunctions model with the toy Gaussian-kernel operator of make_golden.py: loss, f, Kf, gradients."""
+    z = G.load("kernel_loss")
+    cfg = G.cfg_of(z, case)
+    p = (G.params_from_golden(z, case) if f"{case}_param0_model.base.ws.0" in z.files else G.params_from_seed(cfg))
+    p = p.to(torch.float64)
+    v, M = G.masks_of(z, case)
+    ell = float(z[f"{case}_ell"])
+    x = torch.tensor(z[f"{case}_x"]).double()
+    r = O.kernel_loss_and_grads(x, p, lambda a, b, fb: O.gaussian_kernel_apply(a, b, fb, ell), v, M, split,
+                                hard_mul_const=cfg["hard_mul_const"])
+    q = f"{case}_f64_split{int(split)}_"
+    assert abs(float(r["loss"]) - float(z[q + "loss"])) < 1e-11 * abs(float(z[q + "loss"]))
+    assert G.rel(r["f"], z[q + "f"]) < 1e-11 and G.rel(r["Kf"], z[q + "Kf"]) < 1e-11
+    for n, g in zip(G.trainable_names(z, case), r["grads"]):
+        if q + f"grad_{n}" in z.files:
+            assert G.rel(g.reshape(z[q + f"grad_{n}"].shape), z[q + f"grad_{n}"]) < 1e-9, n
+        else:
+            assert abs(float(g.norm()) - float(z[q + f"gradnorm_{n}"])) < 1e-9 * float(z[q + f"gradnorm_{n}"]), n
+            assert G.rel(g.reshape(-1)[::61], z[q + f"gradsample_{n}"]) < 1e-9, n
