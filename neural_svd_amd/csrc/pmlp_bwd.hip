@@ -723,6 +723,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
 #undef WG_LD
 #undef WG_ST
 
+#include "pmlp_wgrad_pipe.h"
+
 }  // namespace
 
 
@@ -787,6 +789,34 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
             wa.pob[i] = pl.ob[i];
         }
         wa.poscales = pl.oscales;
+    }
+    // Unsplit contractions: the persistent pipelined kernel (pmlp_wgrad_pipe.h), one 8-wave workgroup per CU.
+    // NSVD_WGRAD_TILES=1 (developer aid, read once) keeps the tile kernel below for A/B timing.
+    static const bool force_tiles = getenv("NSVD_WGRAD_TILES") != nullptr;
+    if (pipe_wgrad_ok(d, B, wa.S) && !force_tiles) {
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+                v = 256;
+            const void* k1 = (const void*)pmlp_wgrad_pipe_kernel<true>;
+            const void* k0 = (const void*)pmlp_wgrad_pipe_kernel<false>;
+            hipError_t e = hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
+            if (e != hipSuccess) return -(int)e;
+            n_cu = v;
+        }
+        const int n_items = 2 * wa.nA + 8 * (d.nlayers - 2) * d.L;
+        const int grid = n_items < n_cu ? n_items : n_cu;
+        const bool ema = opt && opt->ema;
+        if (ema)
+            hipLaunchKernelGGL(pmlp_wgrad_pipe_kernel<true>, dim3(grid), dim3(PIPE_THREADS), PIPE_LDS_BYTES, s, wa);
+        else
+            hipLaunchKernelGGL(pmlp_wgrad_pipe_kernel<false>, dim3(grid), dim3(PIPE_THREADS), PIPE_LDS_BYTES, s, wa);
+        NSVD_CHECK_LAUNCH();
+        return 0;
     }
     // One launch: the dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
     // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
