@@ -790,10 +790,11 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         }
         wa.poscales = pl.oscales;
     }
-    // Unsplit contractions: the persistent pipelined kernel (pmlp_wgrad_pipe.h), one 8-wave workgroup per CU.
-    // NSVD_WGRAD_TILES=1 (developer aid, read once) keeps the tile kernel below for A/B timing.
-    static const bool force_tiles = getenv("NSVD_WGRAD_TILES") != nullptr;
-    if (pipe_wgrad_ok(d, B, wa.S) && !force_tiles) {
+    // Experimental (NSVD_WGRAD_PIPE=1, read once; off by default): the persistent pipelined kernel of
+    // pmlp_wgrad_pipe.h, one 8-wave workgroup per CU. Correct (the whole GPU suite passes with it) but, as measured,
+    // slower than the tile kernel below: see the header and DESIGN.md.
+    static const bool use_pipe = getenv("NSVD_WGRAD_PIPE") != nullptr;
+    if (use_pipe && pipe_wgrad_ok(d, B, wa.S)) {
         static int n_cu = 0;
         if (n_cu == 0) {
             int dev = 0, v = 0;
@@ -808,7 +809,7 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
             if (e != hipSuccess) return -(int)e;
             n_cu = v;
         }
-        const int n_items = 2 * wa.nA + 8 * (d.nlayers - 2) * d.L;
+        const int n_items = wa.nA + 8 * (d.nlayers - 2) * d.L;
         const int grid = n_items < n_cu ? n_items : n_cu;
         const bool ema = opt && opt->ema;
         if (ema)
@@ -854,6 +855,12 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
 #ifdef NSVD_WG_STAMPS
 extern "C" int nsvd_debug_wgrad_stamps(unsigned long long* host, size_t n) {
     return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), n * sizeof(unsigned long long));
+}
+extern "C" int nsvd_debug_pipe_stamps(unsigned long long* host, size_t n) {
+    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe_stamps), n * sizeof(unsigned long long));
+}
+extern "C" int nsvd_debug_pipe_chunk_stamps(unsigned long long* host, size_t n) {
+    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe_chunk_stamps), n * sizeof(unsigned long long));
 }
 #endif
 
