@@ -809,7 +809,7 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
             if (e != hipSuccess) return -(int)e;
             n_cu = v;
         }
-        const int n_items = wa.nA + 8 * (d.nlayers - 2) * d.L;
+        const int n_items = 2 * wa.nA + 8 * (d.nlayers - 2) * d.L;
         const int grid = n_items < n_cu ? n_items : n_cu;
         const bool ema = opt && opt->ema;
         if (ema)

@@ -1,38 +1,40 @@
 // pmlp_wgrad_pipe_kernel: the weight-gradient kernel as a persistent, software-pipelined workgroup per CU.
 // Included by pmlp_bwd.hip (inside its anonymous namespace, after WgradArgs / wg_emit1).
 //
-// Why: in pmlp_fused_wgrad_kernel the dW_i quadrants co-reside with the dW_0 tiles and stretch their K loops from 72 K
-// to 94 K cycles, and the optimiser epilogue of the 256 dW_0 tiles (24 B/parameter: read p, sq, ema, write them back)
-// then runs with the matrix pipes idle. Here a workgroup is 8 waves and every CU walks the same short item list - its
-// 128 x 128 dW_0 tile, then one 64 x 32 piece of a hidden-layer gradient dW_i (contraction split in two halves over the
+// Why: in pmlp_fused_wgrad_kernel every CU runs ONE 128 x 128 dW_0 tile, so all 256 K loops end together and the
+// optimiser epilogue (24 B/parameter: read p, sq, ema, write them back) runs with the matrix pipes idle - 10 us of
+// a 57 us kernel - while the dW_i quadrants that co-reside with the K loops stretch them from 72 K to 94 K cycles.
+// Here a workgroup is 8 waves with three roles, and every CU walks the same short item list - the two 128 x 64 halves
+// of its dW_0 tile, then one 64 x 32 piece of a hidden-layer gradient dW_i (contraction split in two halves over the
 // wave pairs, so that all 256 CUs share that work evenly):
-//   waves 0-3  "MFMA waves": fragment reads and MFMAs only; after an item's K loop they drop the accumulators into an
+//   waves 0-3  MFMA waves: fragment reads and MFMAs only; after an item's K loop they drop the accumulators into an
 //              LDS hand-off tile and go on with the next item;
-//   waves 4-7  "staging / epilogue waves": (a) ALL the staging - the global -> register -> LDS copies of every chunk of
-//              the item list as one continuous stream, two chunks ahead of the multiplications (an item's first chunk
-//              is in LDS before the previous item has been handed off); (b) the PREVIOUS item's epilogue from the
-//              hand-off tile - gradient store and / or RMSprop + EMA step - while the MFMA waves are in the next K loop:
-//              the optimiser traffic of the dW_0 tile flies under the dW_i piece; (c) the bias gradients (row sums of
-//              what they stage) and, at the end, the 128 -> 1 layer, db_last and d scales.
-// Staged bytes per CU are what bounds this kernel's K loops (L2 / Infinity-Cache -> CU at ~8-12 B/clk/CU), which is why
-// the dW_0 tile is NOT cut into halves that would each re-stage dz_0 (tried: 768 KB instead of 512 KB per CU, K loops
-// 1.5x slower, although the epilogue then hides completely).
-// s_barrier is workgroup-wide on gfx950, so the staging waves execute exactly the barriers of the K loop they
-// feed (one per 32-row chunk) and do one slot of epilogue work between two of them: state loads are issued one
-// slot before they are consumed. Correctness depends only on the barrier COUNTS agreeing (both sides derive them from
-// the same item descriptor), never on timing.
+//   waves 4-5  staging waves: the global -> register -> LDS copies of every chunk of the item list as ONE continuous
+//              stream, two chunks ahead of the multiplications (an item's first chunk is in LDS before the previous
+//              item has been handed off). They issue vector LOADS only: on gfx9 loads and stores share vmcnt and
+//              complete out of order with respect to each other, so a wave that mixes them can only wait for
+//              "everything" - which would pin the prefetch distance to one chunk, below the ~4.5 K-cycle loaded memory
+//              latency of this kernel (measured; that is what bounded the two-role versions of this kernel);
+//   waves 6-7  epilogue waves: the PREVIOUS item's tile from LDS -> gradient store and / or RMSprop + EMA step while
+//              the MFMA waves are in the next K loop (the optimiser traffic of half-tile 1 flies under the K loop of
+//              half-tile 2, that of half-tile 2 under the dW_i piece), the bias gradients (row sums handed over by
+//              the staging waves) and, at the end, the 128 -> 1 layer, db_last and d scales.
+// s_barrier is workgroup-wide on gfx950, so all eight waves execute the same barrier sequence (per item: one barrier
+// per 64-row chunk, then "free" and "ready" around the hand-off) and do their role's work between two of them.
+// Correctness depends only on the barrier COUNTS agreeing (every role derives them from the same item descriptors),
+// never on timing.
 // Split-K launches (head-parallel ranks, S > 1) keep the tile kernel above.
 #pragma once
 
 constexpr int PIPE_THREADS = 512;
-constexpr int PIPE_KC = BK;                            // contraction chunk: 32 rows of the batch per barrier
-constexpr int PIPE_LD = A_LD;                          // padded stage row (36 floats): conflict-free ds_read_b128
-constexpr int PIPE_HS_LD = HID + 8;                    // hand-off tile row (floats)
-constexpr int PIPE_SROWS = 256;                        // staged rows per chunk: two 128-row regions
+constexpr int PIPE_KC = 64;                            // contraction chunk (rows of the batch per barrier)
+constexpr int PIPE_LD = PIPE_KC + 4;                   // padded stage row: conflict-free ds_read_b128 over 16 rows
+constexpr int PIPE_HS_LD = 72;                         // hand-off tile row (floats): 64 columns + 8 pad
+constexpr int PIPE_SROWS = 192;                        // staged rows per chunk: a 128-row region + a 64-row region
 constexpr int PIPE_SBUF = PIPE_SROWS * PIPE_LD;        // one stage buffer (floats)
-constexpr int PIPE_HAND = HID * PIPE_HS_LD;            // the hand-off tile (floats)
-constexpr int PIPE_LDS_FLOATS = 2 * PIPE_SBUF + PIPE_HAND;
-constexpr size_t PIPE_LDS_BYTES = (size_t)PIPE_LDS_FLOATS * sizeof(float);  // 143 360 B: one workgroup per CU
+constexpr int PIPE_HAND = 128 * PIPE_HS_LD;            // the hand-off tile (floats)
+constexpr int PIPE_LDS_FLOATS = 2 * PIPE_SBUF + PIPE_HAND + 128;
+constexpr size_t PIPE_LDS_BYTES = (size_t)PIPE_LDS_FLOATS * sizeof(float);  // 141 312 B: one workgroup per CU
 
 #ifdef NSVD_WG_STAMPS
 // diagnostic build: per workgroup, cycle stamps of the MFMA side (thread 0) and of the epilogue side (thread 256)
@@ -44,7 +46,7 @@ __device__ int g_pipe_item;                                    // unused; keeps 
 #define PIPE_STAMP_CH(kk, c)                                                                     \
     if (threadIdx.x == 0 && (kk) < 4 && (c) < 16)                                                \
         g_pipe_chunk_stamps[(size_t)blockIdx.x * 64 + (kk) * 16 + (c)] = __builtin_readcyclecounter()
-#define PIPE_STAMP_E(slot) if (threadIdx.x == 256) PIPE_STAMP(slot)
+#define PIPE_STAMP_E(slot) if (threadIdx.x == 384) PIPE_STAMP(slot)
 #else
 #define PIPE_STAMP_M(slot)
 #define PIPE_STAMP_E(slot)
@@ -60,11 +62,11 @@ __device__ int g_pipe_item;                                    // unused; keeps 
 #endif
 
 struct PipeItem {
-    int kind;   // 0: a dW_0 tile (128 rows x 128 feature columns, K = B);  1: dW_i piece (64 x 32, K = 2 x B/2)
+    int kind;   // 0: half of a dW_0 tile (128 rows x 64 feature columns, K = B);  1: dW_i piece (64 x 32, K = 2 x B/2)
     int l, i;   // head, layer
     int n0, k0; // origin inside W_i[l]: rows n0.., columns k0..
     int ldw;    // row length of W_i[l]
-    int nch;    // 32-row chunks each wave contracts over (one barrier per chunk)
+    int nch;    // 64-row chunks each wave contracts over (the K loop has nch + 1 barriers)
     int bias;   // the item also carries the row sums of its dz rows (the bias gradient)
 };
 
@@ -73,26 +75,25 @@ __device__ __forceinline__ int pipe_xcd_remap(int idx, int n) {
     return (n & 7) == 0 ? (idx & 7) * (n >> 3) + (idx >> 3) : idx;
 }
 
-__device__ __forceinline__ int pipe_num_items(const WgradArgs& a) { return a.nA + 8 * (a.nlayers - 2) * a.L; }
-
 __device__ __forceinline__ PipeItem pipe_decode(const WgradArgs& a, int it) {
     PipeItem p;
     const int nA = a.nA;
-    if (it < nA) {
-        const int unit = pipe_xcd_remap(it, nA);
+    if (it < 2 * nA) {
+        const int half = it / nA;
+        const int unit = pipe_xcd_remap(it - half * nA, nA);
         const int nkt = a.F / HID;
         p.kind = 0;
         p.l = unit / nkt;
         p.i = 0;
         p.n0 = 0;
-        p.k0 = (unit - p.l * nkt) * HID;
+        p.k0 = (unit - p.l * nkt) * HID + 64 * half;
         p.ldw = a.F;
         p.nch = a.B / PIPE_KC;
         p.bias = p.k0 == 0;
         return p;
     }
     const int nP = 8 * (a.nlayers - 2) * a.L;  // 8 pieces per (layer, head)
-    const int q = pipe_xcd_remap(it - nA, nP);
+    const int q = pipe_xcd_remap(it - 2 * nA, nP);
     const int piece = q & 7, rest = q >> 3;
     p.kind = 1;
     p.l = rest % a.L;
@@ -106,20 +107,20 @@ __device__ __forceinline__ PipeItem pipe_decode(const WgradArgs& a, int it) {
 }
 
 // ---- stage layout ------------------------------------------------------------------------------------------------
-// One chunk = 32 rows of the batch; its stage image is 256 rows of PIPE_LD = 36 floats:
-//   kind 0: rows 0..127 = dz_0[l][n][chunk], rows 128..255 = phi^T[k0 + r][chunk]
+// One chunk = 64 rows of the batch; its stage image is 192 rows of PIPE_LD = 68 floats:
+//   kind 0: rows 0..127 = dz_0[l][n][chunk], rows 128..191 = phi^T[k0 + r][chunk]
 //   kind 1: rows 0..63 / 64..127 = dz_i[l][n0 + r][chunk of batch half 0 / 1], rows 128..159 / 160..191 =
-//           a_{i-1}[l][k0 + r][chunk of batch half 0 / 1] (rows 192..255 unused)
-// Staging thread t (of the 256 of the staging waves) moves the float4 (row (t >> 3) + 32 j, columns 4 (t & 7)..) of
-// pass j = 0..7 (passes 0-3: the first region, 4-7: the second).
+//           a_{i-1}[l][k0 + r][chunk of batch half 0 / 1]
+// Staging thread t (of the 128 of the two staging waves) moves the float4 (row (t >> 4) + 8 j, columns 4 (t & 15)..)
+// of pass j = 0..23 (passes 0-15: the 128-row region, 16-23: the 64-row region).
 struct PipeSrc {
-    const float* pa;   // row (t >> 3) of the first region, this thread's columns of chunk 0
-    const float* pb;   // row (t >> 3) of the second region
+    const float* pa;   // row (t >> 4) of the 128-row region, this thread's columns of chunk 0
+    const float* pb;   // row (t >> 4) of the 64-row region
 };
 
 __device__ __forceinline__ PipeSrc pipe_sources(const WgradArgs& a, const PipeItem& p, int ht) {
     PipeSrc s;
-    const int s_row = ht >> 3, s_c4 = ht & 7;
+    const int s_row = ht >> 4, s_c4 = ht & 15;
     const size_t B = (size_t)a.B;
     if (p.kind == 0) {
         s.pa = a.dz[0] + ((size_t)p.l * HID + s_row) * B + 4 * s_c4;
@@ -131,48 +132,40 @@ __device__ __forceinline__ PipeSrc pipe_sources(const WgradArgs& a, const PipeIt
     return s;
 }
 
-// element offset of staging pass j relative to pa (j < 4) / pb (j >= 4); kind 1 has no passes 6, 7 (they re-read
-// pass 4 / 5: the load count per chunk stays fixed, which keeps the compiler's vmcnt bookkeeping exact)
+// element offset of staging pass j relative to pa (j < 16) / pb (j >= 16)
 __device__ __forceinline__ size_t pipe_pass_off(int kind, int j, size_t B) {
-    if (kind == 0) return (size_t)(32 * (j & 3)) * B;
-    if (j < 4) return (size_t)(32 * (j & 1)) * B + (size_t)(j >> 1) * (B / 2);
-    return (size_t)(j & 1) * (B / 2);
+    if (kind == 0) return (size_t)(8 * (j & 15)) * B;
+    if (j < 16) return (size_t)(8 * (j & 7)) * B + (size_t)(j >> 3) * (B / 2);
+    return (size_t)(8 * (j & 3)) * B + (size_t)((j - 16) >> 2) * (B / 2);
 }
 
 // ---- MFMA waves ------------------------------------------------------------------------------------------------
 struct PipeFrag {
-    float4 a0, a1, b0, b1;
+    float4 a0, a1, b0;
 };
 
 // The nch chunks of one item: fragment reads and MFMAs only (the staging waves keep the two stage buffers filled).
 // g = this workgroup's running chunk counter (buffer = g & 1). One barrier per chunk: "chunk g is in LDS"; it sits
 // before the LAST q-group of the previous chunk, whose MFMAs cover the first fragment reads of the new one.
 template <int KIND>
-__device__ __forceinline__ void pipe_mfma_item(const float* stage, int& g, int nch, f32x16 (&acc)[4], int tid, int kk) {
+__device__ __forceinline__ void pipe_mfma_item(const float* stage, int& g, int nch, f32x16 (&acc)[2], int tid, int kk) {
     (void)kk;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    // kind 0: wave (wm, wn) = 64 x 64 of the tile; kind 1: wave (wm, kh) = 32 x 32 of the piece over batch half kh
+    // kind 0: wave (wm, wn) = 64 x 32 of the half tile; kind 1: wave (wm, kh) = 32 x 32 of the piece, batch half kh
     const int arow = KIND == 0 ? 64 * (w >> 1) + li : 64 * (w >> 1) + 32 * (w & 1) + li;
-    const int brow = KIND == 0 ? 128 + 64 * (w & 1) + li : 128 + 32 * (w >> 1) + li;
+    const int brow = KIND == 0 ? 128 + 32 * (w & 1) + li : 128 + 32 * (w >> 1) + li;
     const float* fa = stage + arow * PIPE_LD + 4 * hi;
     const float* fb = stage + brow * PIPE_LD + 4 * hi;
-#define PK_READ(f, buf, q)                                                                                 \
-    {                                                                                                      \
-        f.a0 = *reinterpret_cast<const float4*>(fa + (buf) * PIPE_SBUF + 8 * (q));                         \
-        f.b0 = *reinterpret_cast<const float4*>(fb + (buf) * PIPE_SBUF + 8 * (q));                         \
-        if (KIND == 0) {                                                                                   \
-            f.a1 = *reinterpret_cast<const float4*>(fa + (buf) * PIPE_SBUF + 32 * PIPE_LD + 8 * (q));      \
-            f.b1 = *reinterpret_cast<const float4*>(fb + (buf) * PIPE_SBUF + 32 * PIPE_LD + 8 * (q));      \
-        }                                                                                                  \
+#define PK_READ(f, buf, q)                                                                             \
+    {                                                                                                  \
+        f.b0 = *reinterpret_cast<const float4*>(fb + (buf) * PIPE_SBUF + 8 * (q));                     \
+        f.a0 = *reinterpret_cast<const float4*>(fa + (buf) * PIPE_SBUF + 8 * (q));                     \
+        if (KIND == 0) f.a1 = *reinterpret_cast<const float4*>(fa + (buf) * PIPE_SBUF + 32 * PIPE_LD + 8 * (q)); \
     }
-#define PK_MMA1(f, X)                                                                                      \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0], 0, 0, 0);                        \
-    if (KIND == 0) {                                                                                       \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[1], 0, 0, 0);                    \
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[2], 0, 0, 0);                    \
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[3], 0, 0, 0);                    \
-    }
+#define PK_MMA1(f, X)                                                                                  \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0], 0, 0, 0);                    \
+    if (KIND == 0) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[1], 0, 0, 0);
 #define PK_MMA(f) PK_MMA1(f, x) PK_MMA1(f, y) PK_MMA1(f, z) PK_MMA1(f, w)
 #define PK_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PK_IL(n, mask)                                             \
@@ -180,7 +173,7 @@ __device__ __forceinline__ void pipe_mfma_item(const float* stage, int& g, int n
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
         __builtin_amdgcn_sched_group_barrier((mask), 1, 0);        \
     }
-#define PK_NR (KIND == 0 ? 4 : 2)
+#define PK_NR (KIND == 0 ? 3 : 2)
 #define PK_STEP(fr, fm, buf, q) \
     {                           \
         PK_READ(fr, buf, q);    \
@@ -189,7 +182,7 @@ __device__ __forceinline__ void pipe_mfma_item(const float* stage, int& g, int n
         PK_FENCE();             \
     }
     PipeFrag f0, f1;
-    f0.a1 = f1.a1 = f0.b1 = f1.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f0.a1 = f1.a1 = make_float4(0.f, 0.f, 0.f, 0.f);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk g is staged
     PIPE_STAMP_CH(kk, 0);
     PK_READ(f0, g & 1, 0);
@@ -199,6 +192,10 @@ __device__ __forceinline__ void pipe_mfma_item(const float* stage, int& g, int n
         PK_STEP(f1, f0, cur, 1);
         PK_STEP(f0, f1, cur, 2);
         PK_STEP(f1, f0, cur, 3);
+        PK_STEP(f0, f1, cur, 4);
+        PK_STEP(f1, f0, cur, 5);
+        PK_STEP(f0, f1, cur, 6);
+        PK_STEP(f1, f0, cur, 7);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk g + 1 is staged
         PIPE_STAMP_CH(kk, c + 1);
         PK_READ(f0, cur ^ 1, 0);
@@ -211,6 +208,10 @@ __device__ __forceinline__ void pipe_mfma_item(const float* stage, int& g, int n
         PK_STEP(f1, f0, cur, 1);
         PK_STEP(f0, f1, cur, 2);
         PK_STEP(f1, f0, cur, 3);
+        PK_STEP(f0, f1, cur, 4);
+        PK_STEP(f1, f0, cur, 5);
+        PK_STEP(f0, f1, cur, 6);
+        PK_STEP(f1, f0, cur, 7);
         PK_MMA(f1);
         ++g;
     }
@@ -225,7 +226,7 @@ __device__ __forceinline__ void pipe_mfma_item(const float* stage, int& g, int n
 
 // accumulators -> hand-off tile
 template <int KIND>
-__device__ __forceinline__ void pipe_handoff(const f32x16 (&acc)[4], float* hand, int tid) {
+__device__ __forceinline__ void pipe_handoff(const f32x16 (&acc)[2], float* hand, int tid) {
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     if (KIND == 0) {
@@ -233,10 +234,8 @@ __device__ __forceinline__ void pipe_handoff(const f32x16 (&acc)[4], float* hand
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    hand[(64 * wm + 32 * i + acc_row(r, hi)) * PIPE_HS_LD + 64 * wn + 32 * j + li] = acc[2 * i + j][r];
+            for (int r = 0; r < 16; ++r)
+                hand[(64 * wm + 32 * i + acc_row(r, hi)) * PIPE_HS_LD + 32 * wn + li] = acc[i][r];
     } else {
         const int wm = w & 1, kh = w >> 1;
 #pragma unroll
@@ -272,29 +271,32 @@ __device__ __forceinline__ void pipe_cursor_next(PipeCursor& cu, const WgradArgs
     if (++cu.c >= cu.nch) pipe_cursor_open(cu, a, cu.it + stride, nItems, ht);
 }
 
-// the eight staging registers of one chunk
-struct PipeRegs {
-    float4 r0, r1, r2, r3, r4, r5, r6, r7;
-};
-
-__device__ __forceinline__ void pipe_regs_load(PipeRegs& R, const PipeCursor& cu, size_t B) {
-    const float* pa = cu.src.pa + (size_t)cu.c * PIPE_KC;
-    const float* pb = cu.src.pb + (size_t)cu.c * PIPE_KC;
-    const int k = cu.kind;
-#define PL(R_, j) R_ = *reinterpret_cast<const float4*>(((j) < 4 ? pa : pb) + pipe_pass_off(k, j, B))
-    PL(R.r0, 0); PL(R.r1, 1); PL(R.r2, 2); PL(R.r3, 3); PL(R.r4, 4); PL(R.r5, 5); PL(R.r6, 6); PL(R.r7, 7);
-#undef PL
-}
+// The 24 staging registers of one chunk are 24 NAMED local float4 variables per set (an indexed array, or a struct
+// passed by reference, ends up in scratch): P##0 .. P##23 for the set prefix P.
+#define PIPE_FOR_PASSES(M, P)                                                                                         \
+    M(P, 0) M(P, 1) M(P, 2) M(P, 3) M(P, 4) M(P, 5) M(P, 6) M(P, 7) M(P, 8) M(P, 9) M(P, 10) M(P, 11) M(P, 12)        \
+    M(P, 13) M(P, 14) M(P, 15) M(P, 16) M(P, 17) M(P, 18) M(P, 19) M(P, 20) M(P, 21) M(P, 22) M(P, 23)
+#define PIPE_DECL1(P, j) float4 P##j;
+#define PIPE_LOAD1(P, j) \
+    P##j = *reinterpret_cast<const float4*>(((j) < 16 ? lpa : lpb) + pipe_pass_off(ld.kind, j, B));
+#define PIPE_STORE1(P, j) \
+    *reinterpret_cast<float4*>(sdst + ((j) < 16 ? 8 * (j) : 128 + 8 * ((j) - 16)) * PIPE_LD) = P##j;
+// fetch the cursor's chunk into set P, then advance the cursor (it stops on the last chunk of the stream, which is then
+// fetched again: the load count per step stays fixed, which keeps the compiler's vmcnt bookkeeping exact)
+#define PIPE_FETCH(P)                                                                         \
+    {                                                                                         \
+        const float* lpa = ld.src.pa + (size_t)ld.c * PIPE_KC;                                \
+        const float* lpb = ld.src.pb + (size_t)ld.c * PIPE_KC;                                \
+        PIPE_FOR_PASSES(PIPE_LOAD1, P)                                                        \
+        if (ld.c + 1 < ld.nch || ld.it + stride < nItems) pipe_cursor_next(ld, a, nItems, stride, st); \
+    }
+#define PIPE_PUT(P, buf)                                  \
+    {                                                     \
+        float* sdst = sd + (buf) * PIPE_SBUF;             \
+        PIPE_FOR_PASSES(PIPE_STORE1, P)                   \
+    }
 
 __device__ __forceinline__ float pipe_sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
-
-// registers -> stage buffer; the row sums of the first region accumulate in rs (the bias gradient)
-__device__ __forceinline__ void pipe_regs_store(const PipeRegs& R, float* sd, float (&rs)[4]) {
-#define PS(R_, j) *reinterpret_cast<float4*>(sd + 32 * (j) * PIPE_LD) = R_
-    PS(R.r0, 0); PS(R.r1, 1); PS(R.r2, 2); PS(R.r3, 3); PS(R.r4, 4); PS(R.r5, 5); PS(R.r6, 6); PS(R.r7, 7);
-#undef PS
-    rs[0] += pipe_sum4(R.r0); rs[1] += pipe_sum4(R.r1); rs[2] += pipe_sum4(R.r2); rs[3] += pipe_sum4(R.r3);
-}
 
 // ---- epilogue waves ----------------------------------------------------------------------------------------------
 // where an item's gradient goes
@@ -320,17 +322,18 @@ struct PipeQuad {
     unsigned off;  // element offset inside the tensor
 };
 
-__device__ __forceinline__ int pipe_nquads(const PipeItem& p) { return p.kind == 0 ? 16 : 2; }
+// float4 groups per epilogue thread (128 of them): kind 0: 128 x 64 / 4 / 128 = 16; kind 1: 64 x 32 / 4 / 128 = 4
+__device__ __forceinline__ int pipe_nquads(const PipeItem& p) { return p.kind == 0 ? 16 : 4; }
 
 template <bool EMA>
 __device__ __forceinline__ void pipe_quad_load(PipeQuad& s, const WgradArgs& a, const PipeItem& p, const PipeDst& d,
                                                const float* hand, int q, int ht) {
     if (p.kind == 0) {
-        const int row = 8 * q + (ht >> 5), c4 = ht & 31;
+        const int row = 8 * q + (ht >> 4), c4 = ht & 15;
         s.v = *reinterpret_cast<const float4*>(hand + row * PIPE_HS_LD + 4 * c4);
         s.off = (unsigned)(((size_t)p.l * HID + row) * (size_t)p.ldw + p.k0 + 4 * c4);
     } else {
-        const int row = 32 * q + (ht >> 3), c4 = ht & 7;
+        const int row = 16 * q + (ht >> 3), c4 = ht & 7;
         const float4 v0 = *reinterpret_cast<const float4*>(hand + row * PIPE_HS_LD + 4 * c4);
         const float4 v1 = *reinterpret_cast<const float4*>(hand + (64 + row) * PIPE_HS_LD + 4 * c4);
         s.v = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
@@ -393,57 +396,41 @@ __device__ __forceinline__ void pipe_drain(PipePair& s, int nslots, const WgradA
     }
 }
 
-// bias gradient of the item whose last chunk has just been staged: rs[j] = this thread's share of the row sums of
-// staged rows (t >> 3) + 32 j (the 8 threads t & 7 of a row are lanes of one wave). All state loads are issued
-// before the first one is consumed (dependent load-update-store round trips would stall the staging).
-__device__ __forceinline__ void pipe_emit_bias(const WgradArgs& a, const PipeItem& p, float (&rs)[4], int ht) {
-    if (p.bias) {
+// Bias gradient = row sums of the item's dz rows (the 128-row stage region). The epilogue waves add them up from the
+// stage buffer while the chunk is there (thread et owns stage row et; only items that carry a bias do this), park them
+// in hb[] before the item's "free" barrier and emit them with the item's epilogue.
+__device__ __forceinline__ float pipe_bias_chunk(const float* stage_buf, int et) {
+    const float* r = stage_buf + et * PIPE_LD;
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rs[j] += __shfl_xor(rs[j], off, 64);
-        if ((ht & 7) == 0) {
-            float* g = a.gb[p.i];
-            const NsvdOptPtrs ob = a.ob[p.i];
-            const size_t base = (size_t)p.l * HID + p.n0 + (ht >> 3);
-            const int n = p.kind == 0 ? 4 : 2;
-            float v[4], pv[4], sv[4], ev[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = p.kind == 0 ? rs[j] : rs[j & 1] + rs[(j & 1) + 2];  // kind 1: rows r and 64 + r = batch halves
-                pv[j] = sv[j] = ev[j] = 0.f;
-                if (a.opt && j < n) {
-                    pv[j] = ob.p[base + 32 * j];
-                    sv[j] = ob.sq[base + 32 * j];
-                    if (ob.ema) ev[j] = ob.ema[base + 32 * j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < n) {
-                    if (g) g[base + 32 * j] = v[j];
-                    if (a.opt) {
-                        nsvd_rmsprop_upd(pv[j], v[j], sv[j], ev[j], ob.ema != nullptr, a.h);
-                        ob.p[base + 32 * j] = pv[j];
-                        ob.sq[base + 32 * j] = sv[j];
-                        if (ob.ema) ob.ema[base + 32 * j] = ev[j];
-                    }
-                }
-            }
-        }
+    for (int q = 0; q < PIPE_KC / 8; ++q) {
+        const float4 u = *reinterpret_cast<const float4*>(r + 8 * q);
+        const float4 v = *reinterpret_cast<const float4*>(r + 8 * q + 4);
+        s0 += (u.x + u.y) + (u.z + u.w);
+        s1 += (v.x + v.y) + (v.z + v.w);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rs[j] = 0.f;
+    return s0 + s1;
 }
 
-// the 128 -> 1 layer, db_last and d scales: unit u = (head, 8 rows of the last hidden layer), 2 rows per wave
+// epilogue side: thread et < 128 owns row et of the item's dz rows
+__device__ __forceinline__ void pipe_emit_bias(const WgradArgs& a, const PipeItem& p, const float* hb, int et) {
+    if (!p.bias) return;
+    const WgDst db{a.gb[p.i], a.opt};
+    if (p.kind == 0) {
+        wg_emit1(a, db, a.ob[p.i], (size_t)p.l * HID + et, hb[et]);
+    } else if (et < 64) {  // rows r and 64 + r are the two batch halves of row n0 + r
+        wg_emit1(a, db, a.ob[p.i], (size_t)p.l * HID + p.n0 + et, hb[et] + hb[64 + et]);
+    }
+}
+
+// the 128 -> 1 layer, db_last and d scales: unit u = (head, 4 rows of the last hidden layer), 2 rows per epilogue wave
 __device__ __forceinline__ void pipe_last_layer(const WgradArgs& a, int u, int hw, int lane) {
     const int nh = a.nlayers - 1;
-    const int l = u >> 4, r0 = 8 * (u & 15) + 2 * hw;
+    const int l = u >> 5, r0 = 4 * (u & 31) + 2 * hw;
     const float* db = a.dbase + (size_t)l * a.B;
     const float* z0 = a.zsave[nh - 1] + ((size_t)l * HID + r0) * a.B;
     const float* z1 = z0 + a.B;
-    const bool head_sums = (u & 15) == 0 && hw == 0;
+    const bool head_sums = (u & 31) == 0 && hw == 0;
     float s0 = 0.f, s1 = 0.f, sb = 0.f, ss = 0.f;
     for (int b = 4 * lane; b < a.B; b += 256) {
         const float4 d = *reinterpret_cast<const float4*>(db + b);
@@ -484,7 +471,7 @@ __global__ void __launch_bounds__(PIPE_THREADS, 1) pmlp_wgrad_pipe_kernel(WgradA
     const int tid = threadIdx.x;
     const bool mfma_wave = tid < 256;
     const int ht = tid - 256;
-    const int nItems = pipe_num_items(a);
+    const int nItems = 2 * a.nA + 8 * (a.nlayers - 2) * a.L;
     const int stride = gridDim.x;
     PIPE_STAMP_M(0);
 #ifdef NSVD_WG_STAMPS
@@ -497,9 +484,9 @@ __global__ void __launch_bounds__(PIPE_THREADS, 1) pmlp_wgrad_pipe_kernel(WgradA
         int g = 0, k = 0;
         for (int it = blockIdx.x; it < nItems; it += stride, ++k) {
             const PipeItem p = pipe_decode(a, it);
-            f32x16 acc[4];
+            f32x16 acc[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             if (p.kind == 0) pipe_mfma_item<0>(stage, g, p.nch, acc, tid, k);
@@ -514,86 +501,103 @@ __global__ void __launch_bounds__(PIPE_THREADS, 1) pmlp_wgrad_pipe_kernel(WgradA
         }
         return;
     }
-    // ---- epilogue / staging waves
-    const size_t B = (size_t)a.B;
-    float* sd = stage + (ht >> 3) * PIPE_LD + 4 * (ht & 7);
-    PipeCursor ld;    // next chunk to fetch from global memory
-    PipeRegs Ra, Rb;  // the chunks one and two ahead of the one the MFMA waves are multiplying
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    pipe_cursor_open(ld, a, blockIdx.x, nItems, ht);
-    if (ld.it >= nItems) goto last_layer;  // (grid <= nItems: not reached)
-    // prologue: chunk 0 -> LDS buffer 0, chunks 1 and 2 -> registers (Rb, Ra); the cursor stops on the last chunk
-#define PIPE_ADVANCE() \
-    if (ld.c + 1 < ld.nch || ld.it + stride < nItems) pipe_cursor_next(ld, a, nItems, stride, ht)
-    pipe_regs_load(Ra, ld, B);
-    PIPE_ADVANCE();
-    pipe_regs_load(Rb, ld, B);
-    PIPE_ADVANCE();
-    pipe_regs_store(Ra, sd, rs);
-    pipe_regs_load(Ra, ld, B);
-    PIPE_ADVANCE();
+    float* hb = hand + PIPE_HAND;  // [128] row sums of the item being handed over
+    if (tid < 384) {
+        // ---- staging waves (4, 5): vector loads only
+        const int st = tid - 256;
+        const size_t B = (size_t)a.B;
+        float* sd = stage + (st >> 4) * PIPE_LD + 4 * (st & 15);
+        PipeCursor ld;    // next chunk to fetch from global memory
+        PIPE_FOR_PASSES(PIPE_DECL1, ra)  // the chunks one and two ahead of the one the MFMA waves are multiplying
+        PIPE_FOR_PASSES(PIPE_DECL1, rb)
+        pipe_cursor_open(ld, a, blockIdx.x, nItems, st);
+        // prologue: chunk 0 -> LDS buffer 0, chunks 1 and 2 -> registers (rb, then ra: the same order of outstanding
+        // loads as at the loop's back edge, so that the compiler's vmcnt bookkeeping stays exact inside the loop)
+        PIPE_FETCH(ra);
+        PIPE_PUT(ra, 0);
+        PIPE_FETCH(rb);
+        PIPE_FETCH(ra);
+        PipeItem p = pipe_decode(a, blockIdx.x);
+        int it = blockIdx.x, c = 0, g = 0;
+        bool more = true;
+        // One step = one chunk barrier and the staging behind it: store the set holding chunk g + 1 (the MFMA waves are
+        // done with that buffer), fetch chunk g + 3 into it. The two sets alternate STATICALLY (token pasting).
+#define PIPE_STAGE_STEP(P)                                                                   \
+    {                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* chunk g staged */ \
+        PIPE_STAMP_H(g, 0);                                                                  \
+        const bool last = c == p.nch - 1;                                                    \
+        if (!last || it + stride < nItems) PIPE_PUT(P, (g + 1) & 1);                         \
+        PIPE_STAMP_H(g, 1);                                                                  \
+        PIPE_FETCH(P);                                                                       \
+        PIPE_STAMP_H(g, 2);                                                                  \
+        ++g;                                                                                 \
+        if (!last) {                                                                         \
+            ++c;                                                                             \
+        } else {                                                                             \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* free */       \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* ready */      \
+            it += stride;                                                                    \
+            c = 0;                                                                           \
+            more = it < nItems;                                                              \
+            if (more) p = pipe_decode(a, it);                                                \
+        }                                                                                    \
+    }
+        // (unrolled four deep: the compiler resets its count of outstanding loads to "all of them" at the loop header,
+        //  so only the first step of the body waits for more than it needs)
+        while (more) {
+            PIPE_STAGE_STEP(rb);
+            if (!more) break;
+            PIPE_STAGE_STEP(ra);
+            if (!more) break;
+            PIPE_STAGE_STEP(rb);
+            if (!more) break;
+            PIPE_STAGE_STEP(ra);
+        }
+#undef PIPE_STAGE_STEP
+        return;
+    }
+    // ---- epilogue waves (6, 7)
     {
+        const int et = tid - 384;
         PipeItem p = pipe_decode(a, blockIdx.x), prev;
         prev.kind = -1;
         PipeDst d = pipe_dst(a, p);
         PipePair s0;
-        int it = blockIdx.x, c = 0, np = 0, k = 0, g = 0;
-        // One step = one chunk barrier and the work behind it. R is the register set holding chunk g + 1: the two
-        // call sites below alternate Rb / Ra STATICALLY (a run-time choice between the sets makes the compiler wait
-        // for the youngest loads before every store, i.e. lose the two-chunk prefetch distance).
-        auto step = [&](PipeRegs& R) -> bool {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk g is staged
-            PIPE_STAMP_H(g, 0);
-            const bool last = c == p.nch - 1;
-            if (last) pipe_emit_bias(a, p, rs, ht);  // the item's row sums are complete
-            if (!last || it + stride < nItems) {
-                // stage chunk g + 1 (the MFMA waves are done with that buffer)
-                pipe_regs_store(R, sd + ((g + 1) & 1) * PIPE_SBUF, rs);
-            }
-            PIPE_STAMP_H(g, 1);
-            pipe_slot<EMA>(s0, c, np, a, prev, d, hand, ht);  // one slot of the previous item's epilogue
-            PIPE_STAMP_H(g, 2);
-            // fetch chunk g + 3 into the set just stored. Always eight loads, and the youngest ones of the step (past
-            // the end of the stream the last chunk is fetched again): the wait in front of the next store of the OTHER
-            // set is then exactly vmcnt(8), i.e. the fetch stays two chunk times ahead of its use.
-            pipe_regs_load(R, ld, B);
-            PIPE_ADVANCE();
-            PIPE_STAMP_H(g, 3);
-            ++g;
-            if (!last) {
-                ++c;
-                return true;
+        int np = 0, k = 0, g = 0;
+        for (int it = blockIdx.x; it < nItems; it += stride, ++k) {
+            p = pipe_decode(a, it);
+            float bsum = 0.f;
+            for (int c = 0; c < p.nch; ++c, ++g) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk g is staged
+                if (c == 0 && prev.kind >= 0) pipe_emit_bias(a, prev, hb, et);
+                if (p.bias) bsum += pipe_bias_chunk(stage + (g & 1) * PIPE_SBUF, et);
+                pipe_slot<EMA>(s0, c, np, a, prev, d, hand, et);  // one slot of the previous item's epilogue
             }
             PIPE_STAMP_E(16 + 2 * (k < 4 ? k : 4));
-            if (prev.kind >= 0) pipe_drain<EMA>(s0, p.nch, a, prev, d, hand, ht);
+            if (prev.kind >= 0) pipe_drain<EMA>(s0, p.nch, a, prev, d, hand, et);
             PIPE_STAMP_E(17 + 2 * (k < 4 ? k : 4));
+            hb[et] = bsum;  // (the previous item's sums were consumed at this item's first chunk)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // free: the old tile has been read
             __syncthreads();                                                     // ready: the tile of `it` is in LDS
             prev = p;
             np = pipe_npairs(prev);
             d = pipe_dst(a, prev);
-            it += stride;
-            ++k;
-            c = 0;
-            if (it >= nItems) return false;
-            p = pipe_decode(a, it);
-            return true;
-        };
-        while (step(Rb) && step(Ra)) {
         }
         PIPE_STAMP_E(26);
-        if (prev.kind >= 0) pipe_drain<EMA>(s0, 0, a, prev, d, hand, ht);
-    }
-#undef PIPE_ADVANCE
-last_layer:
-    PIPE_STAMP_E(27);
-    for (int u = blockIdx.x; u < 16 * a.L; u += gridDim.x) pipe_last_layer(a, u, ht >> 6, ht & 63);
-    PIPE_STAMP_E(28);
+        if (prev.kind >= 0) {
+            pipe_emit_bias(a, prev, hb, et);
+            pipe_drain<EMA>(s0, 0, a, prev, d, hand, et);
+        }
+        PIPE_STAMP_E(27);
+        for (int u = blockIdx.x; u < 32 * a.L; u += gridDim.x) pipe_last_layer(a, u, et >> 6, et & 63);
+        PIPE_STAMP_E(28);
 #ifdef NSVD_WG_STAMPS
-    if (threadIdx.x == 256) g_pipe_stamps[(size_t)blockIdx.x * 32 + 30] = wall_clock64();
+        if (threadIdx.x == 384) g_pipe_stamps[(size_t)blockIdx.x * 32 + 30] = wall_clock64();
 #endif
+    }
 }
 
 inline bool pipe_wgrad_ok(const nsvd_model_desc& d, int B, int S) {
-    return S == 1 && B % (2 * BK) == 0 && d.nlayers >= 2;
+    return S == 1 && B % (2 * PIPE_KC) == 0 && d.nlayers >= 2;
 }

@@ -44,8 +44,8 @@ buf2 = (ctypes.c_ulonglong * (G * 64))()
 lib.nsvd_debug_pipe_chunk_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert lib.nsvd_debug_pipe_chunk_stamps(buf2, G * 64) == 0
 cs = np.array(buf2, dtype=np.uint64).reshape(G, 4, 16).astype(np.int64)
-nchs = (int(os.environ.get("B", "512")) // 32, int(os.environ.get("B", "512")) // 64, 0)
-for k in range(2):
+nchs = (int(os.environ.get("B", "512")) // 64, int(os.environ.get("B", "512")) // 64, int(os.environ.get("B", "512")) // 128)
+for k in range(3):
     n = min(nchs[k], 15)
     start = st[:, 0] if k == 0 else st[:, 3 * k]
     print(f"item {k}: start -> barrier 0: {(cs[:, k, 0] - start).mean():.0f}; chunk times (barrier to barrier): "
