@@ -46,6 +46,40 @@ __device__ __forceinline__ void mma_frag(f32x16 (&acc)[E], const Frag<E>& f) {
 
 constexpr int H_LD = HID + 4;  // padded row of the activation image [column][k]
 
+// Workgroup -> (head, sample block) of the forward kernel and of the backward chain kernel. Blocks b and b + 8 share an
+// XCD (round-robin dispatch: speed only, never correctness). XCD x gets the head group x % HX and the sample-block
+// group x / HX, so its L2 sees L / HX weight slabs and nsb / SX feature slabs instead of everything (HX * SX = 8); the
+// chain kernel uses the SAME map, so that the activations a forward workgroup saved are read back through the L2
+// they were written through and a head's hidden-layer weights cross the fabric once per XCD group, not eight times.
+// HX = 0: plain mapping (head-major).
+inline int pick_xcd_remap(int L, int nsb, int F) {
+    double best = 1e300;
+    int pick = 0;
+    for (int HX = 1; HX <= 8; HX *= 2) {
+        const int SX = 8 / HX;
+        if (L % HX != 0 || nsb % SX != 0) continue;
+        // (the feature slab is the centre rows only: the stencil rows are generated in the kernel)
+        const double bytes = (double)(L / HX) * HID * F + (double)(nsb / SX) * BS * F;
+        if (bytes < best) {
+            best = bytes;
+            pick = HX;
+        }
+    }
+    return pick;
+}
+__device__ __forceinline__ void xcd_block_map(int block, int HX, int L, int nsb, int& l, int& sb) {
+    if (HX) {
+        const int SX = 8 / HX;
+        const int x = block & 7, slot = block >> 3;
+        const int hpg = L / HX, spg = nsb / SX;  // heads / sample blocks per group
+        l = (x % HX) * hpg + slot % hpg;
+        sb = (x / HX) * spg + slot / hpg;
+    } else {
+        l = block / nsb;
+        sb = block - l * nsb;
+    }
+}
+
 struct FusedWs {
     float* phi;                       // (B, F) sample-major Fourier features of the centre rows
     float* sctab;                     // (D, 2, m) cos / sin of eps * fourier_B (stencil rows by angle addition)

@@ -94,19 +94,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int li = lane & 31, hi = lane >> 5;
     const int nsb = a.B / BS;
     int l, sb;
-    if (a.xcd_remap) {
-        // blocks b and b+8 share an XCD (round-robin dispatch: speed only, never correctness). XCD x gets the
-        // head group x % HX and the sample-block group x / HX, so its L2 sees L/HX W_0 slabs and nsb/SX phi
-        // slabs instead of everything (HX * SX = 8, chosen on the host to minimise bytes per XCD).
-        const int HX = a.xcd_remap, SX = 8 / HX;
-        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int hpg = a.L / HX, spg = nsb / SX;  // heads / sample blocks per group
-        l = (x % HX) * hpg + slot % hpg;
-        sb = (x / HX) * spg + slot / hpg;
-    } else {
-        l = blockIdx.x / nsb;
-        sb = blockIdx.x - l * nsb;
-    }
+    xcd_block_map(blockIdx.x, a.xcd_remap, a.L, nsb, l, sb);  // pmlp_common.h
     const int b0 = sb * BS;
 
     NSVD_STAMP(0)
@@ -614,21 +602,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
     // XCD-aware block mapping: split heads into HX groups and sample blocks into 8/HX groups, minimising the
     // bytes each XCD pulls through its L2: (L/HX) * |W_0 slab| + (nsb/SX) * |phi slab|
-    {
-        const int nsb = B / BS;
-        double best = 1e300;
-        a.xcd_remap = 0;
-        for (int HX = 1; HX <= 8; HX *= 2) {
-            const int SX = 8 / HX;
-            if (d.L % HX != 0 || nsb % SX != 0) continue;
-            // (the feature slab is the centre rows only: the stencil rows are generated in the kernel)
-            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * F;
-            if (bytes < best) {
-                best = bytes;
-                a.xcd_remap = HX;
-            }
-        }
-    }
+    a.xcd_remap = pick_xcd_remap(d.L, B / BS, F);
 #ifdef NSVD_FWD_STAMPS
     a.stamps = (unsigned long long*)w.dz[0];  // diagnostic build: stamps land in the (then unused) dz_0 scratch
 #endif
@@ -697,18 +671,6 @@ int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, con
     a.f = out;
     a.jac = save ? w.jac : nullptr;
     a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
-    {
-        const int nsb = B / BS;
-        double best = 1e300;
-        for (int HX = 1; HX <= 8; HX *= 2) {
-            const int SX = 8 / HX;
-            if (d.L % HX != 0 || nsb % SX != 0) continue;
-            const double bytes = (double)(d.L / HX) * HID * F + (double)(nsb / SX) * BS * F;
-            if (bytes < best) {
-                best = bytes;
-                a.xcd_remap = HX;
-            }
-        }
-    }
+    a.xcd_remap = pick_xcd_remap(d.L, B / BS, F);
     return launch_fwd<1>(a, s);
 }
