@@ -44,27 +44,36 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-KAPPA_REF_MEDIAN = 10.7  # pooled over every golden case: median |Tf_ref32 - Tf_64| / (scale u |f| / eps^2)
-
-
 def tf_noise_kappa(Tf, Tf64, f64, cfg):
     """FD-noise yardstick (DESIGN.md "Numerics"): a float32 evaluation of the eps-stencil carries
-    an absolute error ~ kappa * op_scale * 2^-23 * |f| / eps^2 per element. The float32 REFERENCE has a
-    median kappa of 5..14 on every golden case (pooled 10.7); we require the HIP path's median kappa to
-    stay within 3x of that. (Medians: elements with f ~ 0 have unbounded kappa by construction.)"""
+    an absolute error ~ kappa * op_scale * 2^-23 * |f| / eps^2 per element; kappa = the median of that ratio
+    (medians: elements with f ~ 0 have unbounded kappa by construction). The float32 REFERENCE itself has a
+    median kappa of 7..12 on the golden cases."""
     u = 2.0 ** -23
     s = cfg["operator_scale"] * u * np.abs(np.asarray(f64)) / cfg["laplacian_eps"] ** 2
     d = np.abs(torch.as_tensor(Tf).double().cpu().numpy() - np.asarray(Tf64))
     return float(np.median(d / np.maximum(s, 1e-300)))
 
 
+def oracle32_kappa(x, p, prob, ref64, kcfg):
+    """the same yardstick where no reference fixture exists: the oracle evaluated in float32 (the reference's arithmetic)
+    on the same inputs, against its float64 self"""
+    c32 = O.operator_forward(x.float(), p.to(torch.float32), prob)
+    return tf_noise_kappa(c32.Tf, ref64.Tf.numpy() if hasattr(ref64, "Tf") else ref64["Tf"].numpy(),
+                          ref64.f.numpy() if hasattr(ref64, "f") else ref64["f"].numpy(), kcfg)
+
+
 def check_tf(Tf, z, case, cfg, step=0):
+    """Tf of the HIP path against the float64 reference, held to what the float32 REFERENCE achieves on the SAME case:
+    median noise factor kappa <= 1.5 x the reference's, relative L2 error <= 2 x the reference's (measured on MI355X:
+    kappa ratio 0.69 .. 1.25, L2 ratio 0.63 .. 1.23 over the five cases and both paths)."""
     pre64, pre32 = f"{case}_f64_step{step}_", f"{case}_f32_step{step}_"
     k = tf_noise_kappa(Tf, z[pre64 + "Tf"], z[pre64 + "f"], cfg)
-    assert k < 3 * KAPPA_REF_MEDIAN, k
+    k_ref = tf_noise_kappa(z[pre32 + "Tf"], z[pre64 + "Tf"], z[pre64 + "f"], cfg)
+    assert k <= 1.5 * k_ref, (k, k_ref)
     ref_err = rel(z[pre32 + "Tf"], z[pre64 + "Tf"])
     got = rel(Tf, z[pre64 + "Tf"])
-    assert got < max(4 * ref_err, 1e-3), (got, ref_err)
+    assert got <= max(2 * ref_err, 1e-3), (got, ref_err)
 
 
 def to_dev(p: O.Params):
@@ -577,8 +586,10 @@ def test_fused_path_one_dimensional(eps, fpath):
     assert r["path"] == "fused_mfma"
     assert rel(r["f"], ref["f"]) < 2e-5
     if eps > 0:
-        k = tf_noise_kappa(r["Tf"], ref["Tf"].numpy(), ref["f"].numpy(), dict(operator_scale=1.0, laplacian_eps=eps))
-        assert k < 3 * KAPPA_REF_MEDIAN, k
+        kcfg = dict(operator_scale=1.0, laplacian_eps=eps)
+        k = tf_noise_kappa(r["Tf"], ref["Tf"].numpy(), ref["f"].numpy(), kcfg)
+        k_ref = oracle32_kappa(x, p, prob, ref, kcfg)
+        assert k <= 1.5 * k_ref, (k, k_ref)
     else:
         assert rel(r["Tf"], ref["Tf"]) < 1e-4
     for i, (g, gr) in enumerate(zip(r["grads"], ref["grads"])):
@@ -764,7 +775,8 @@ def test_headline_size_properties(cfg, fpath):
     ref = O.operator_forward(x[rows.to(DEV)].double().cpu(), p.to(torch.float64), prob_o)
     assert rel(f[rows.to(DEV)], ref.f) < 2e-5
     k = tf_noise_kappa(Tf[rows.to(DEV)], ref.Tf.numpy(), ref.f.numpy(), kcfg)
-    assert k < 3 * KAPPA_REF_MEDIAN, k
+    k_ref = oracle32_kappa(x[rows.to(DEV)].double().cpu(), p, prob_o, ref, kcfg)
+    assert k <= 2.0 * k_ref, (k, k_ref)  # (medians over 8 rows x L elements only: a looser factor than the fixtures')
 
 
 def test_backward_headline_size_sampled_heads():
