@@ -311,6 +311,27 @@ int nsvd_row_normalize_forward(const float* z, int B, int L, float r_up, int mod
 int nsvd_row_normalize_backward(const float* z, const float* dout, int B, int L, float r_up, int mode, float* dz,
                                 void* stream);
 
+/* One CDK tower: Linear(d0 -> d1) -> BatchNorm1d(d1) -> LeakyReLU(slope) -> Linear(d1 -> d2) -> BatchNorm1d(d2), what
+ * get_mlp(sizes=[d0, d1, d2], bias=True, nonlinearity='lrelu<slope>', use_bn=True) builds (examples/models/mlp.py:129-164)
+ * and main_sketchy.py:107-116 uses as the two backbones of HeteroNetwork (examples/models/siam.py:132-166), in
+ * TRAINING mode (batch statistics; running_mean / running_var updated with `momentum` when update_running != 0, as
+ * torch.nn.BatchNorm1d does). Replaces the module's forward and its autograd backward. fp32 MFMA contractions.
+ *   x (B, d0); z (B, d2); dz (B, d2); every parameter / gradient in torch's layout: W1 (d1, d0), b1 (d1), g1 / be1 /
+ *   rm1 / rv1 (d1) = BatchNorm weight / bias / running_mean / running_var, W2 (d2, d1), b2, g2, be2, rm2, rv2 (d2).
+ *   Shapes: B, d0, d1, d2 multiples of 128, B <= 1024 (anything else: NSVD_EINVAL; 0 from the size query).
+ *   The forward leaves what the backward needs in `ws` (nsvd_tower_workspace_bytes): call the backward with the same
+ *   x, parameters and workspace. The gradient w.r.t. x is not produced (the towers' inputs are data). */
+typedef struct nsvd_tower_params {
+    float *W1, *b1, *g1, *be1, *rm1, *rv1;
+    float *W2, *b2, *g2, *be2, *rm2, *rv2;
+} nsvd_tower_params;
+size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2);
+int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, int d0, int d1, int d2, float slope,
+                       float eps, float momentum, int update_running, float* z, void* ws, size_t ws_bytes,
+                       void* stream);
+int nsvd_tower_backward(const float* x, const nsvd_tower_params* params, const float* dz, int B, int d0, int d1,
+                        int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes, void* stream);
+
 /* Measurement aid (bench.py): record the two hipEvent_t handles immediately before / after the
  * DOMINANT kernel of the next nsvd_operator_forward call made by this host thread (the fused MFMA
  * forward kernel, or the layer-0 GEMM on the generic path), on that call's stream. One-shot;

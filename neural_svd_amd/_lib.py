@@ -42,6 +42,10 @@ class Problem(C.Structure):
                 ("hard_mul_const", C.c_float), ("use_importance", C.c_int32)]
 
 
+class TowerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "g1", "be1", "rm1", "rv1", "W2", "b2", "g2", "be2", "rm2", "rv2")]
+
+
 class Rmsprop(C.Structure):
     _fields_ = [("sq", Params), ("ema", Params), ("lr", C.c_double), ("alpha", C.c_double), ("eps", C.c_double),
                 ("ema_decay", C.c_double), ("has_ema", C.c_int32)]
@@ -86,6 +90,10 @@ SIGNATURES = {
     "nsvd_spectrum_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
     "nsvd_row_normalize_forward": (_I, [_P, _I, _I, _F, _I, _P, _P]),
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
+    "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "nsvd_tower_forward": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _P, _P, _Z, _P]),
+    "nsvd_tower_backward": (_I, [_P, C.POINTER(TowerParams), _P, _I, _I, _I, _I, _F, C.POINTER(TowerParams), _P, _Z,
+                                 _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -203,12 +203,74 @@ def _activation_factory(name: str):
     raise NotImplementedError(f"activation {name!r}")
 
 
+class _TowerFn(torch.autograd.Function):
+    """Linear -> BatchNorm1d -> LeakyReLU -> Linear -> BatchNorm1d in training mode on the HIP tower kernels
+    (csrc/tower.hip: five fp32-MFMA contractions and four BatchNorm strip kernels for forward + backward)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, seq):
+        lin1, bn1, act, lin2, bn2 = seq[0], seq[1], seq[2], seq[3], seq[4]
+        xd = x.detach().float().contiguous()
+        t = dict(W1=W1.detach(), b1=b1.detach(), g1=g1.detach(), be1=be1.detach(), rm1=bn1.running_mean,
+                 rv1=bn1.running_var, W2=W2.detach(), b2=b2.detach(), g2=g2.detach(), be2=be2.detach(),
+                 rm2=bn2.running_mean, rv2=bn2.running_var)
+        ws = H.tower_workspace(xd.shape[0], W1.shape[1], W1.shape[0], W2.shape[0], xd.device)
+        track = bn1.track_running_stats and bn1.running_mean is not None
+        z = H.tower_forward(xd, t, seq.slope, bn1.eps, bn1.momentum, track, ws)
+        if track:
+            bn1.num_batches_tracked += 1
+            bn2.num_batches_tracked += 1
+        ctx.t, ctx.ws, ctx.xd, ctx.slope = t, ws, xd, seq.slope
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        g = H.tower_backward(ctx.xd, ctx.t, dz.detach().float().contiguous(), ctx.slope, ctx.ws)
+        return (None, g["W1"], g["b1"], g["g1"], g["be1"], g["W2"], g["b2"], g["g2"], g["be2"], None)
+
+
+class TowerSequential(nn.Sequential):
+    """What get_mlp returns for the CDK script's towers: the same five modules under the same names as the reference's
+    nn.Sequential (state_dict keys 0.weight, 1.running_mean, ... interchange), whose TRAINING forward on a GPU batch
+    of a supported shape (batch and widths multiples of 128, batch <= 1024: BASELINE configs[4] is 1024 x 512 -> 8192
+    -> 512) runs on the HIP tower kernels. Evaluation mode (running statistics) and other shapes use the modules
+    themselves (torch's library kernels)."""
+
+    def __init__(self, *mods, slope: float):
+        super().__init__(*mods)
+        self.slope = float(slope)
+
+    def hip_ready(self, x) -> bool:
+        lin1, bn1, lin2, bn2 = self[0], self[1], self[3], self[4]
+        return (self.training and x.is_cuda and x.dim() == 2 and bn1.momentum is not None and bn1.eps == bn2.eps
+                and bn1.momentum == bn2.momentum and bn1.affine and bn2.affine
+                and lin1.weight.dtype == torch.float32
+                and H.tower_supported(x.shape[0], lin1.in_features, lin1.out_features, lin2.out_features))
+
+    def forward(self, x):
+        if not self.hip_ready(x):
+            return super().forward(x)
+        lin1, bn1, lin2, bn2 = self[0], self[1], self[3], self[4]
+        return _TowerFn.apply(x, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight,
+                              bn2.bias, self)
+
+
+def _tower_slope(nonlinearity: str):
+    """negative-side slope of the activations the tower kernels implement (None: another activation)"""
+    if nonlinearity == "relu":
+        return 0.0
+    if nonlinearity.startswith("lrelu"):
+        return float(nonlinearity[len("lrelu"):])
+    return None
+
+
 def get_mlp(sizes, bias=True, nonlinearity="relu", use_bn=True, weight_normalization=False, last_layer_bn=True,
             feature_map=None):
     """Tower builder of the Sketchy script (reference examples/models/mlp.py:129-164, used at
     examples/cdk/sketchy/main_sketchy.py:109-112): Linear (+ BatchNorm1d) (+ activation) per layer, no activation after
-    the last layer, BatchNorm after it only with ``last_layer_bn``; ``output_dim`` attribute. Plain torch modules:
-    these are library GEMMs."""
+    the last layer, BatchNorm after it only with ``last_layer_bn``; ``output_dim`` attribute. The two-layer form the
+    script builds (Linear, BatchNorm, relu / lrelu, Linear, BatchNorm) comes back as a TowerSequential, whose training
+    step runs on the HIP tower kernels; any other stack is plain torch modules."""
     make_act = _activation_factory(nonlinearity)
     n = len(sizes) - 1
     if n == 0:
@@ -223,6 +285,11 @@ def get_mlp(sizes, bias=True, nonlinearity="relu", use_bn=True, weight_normaliza
                 mods.append(nn.BatchNorm1d(d_out))
             if not last:
                 mods.append(make_act())
-        model = nn.Sequential(*mods)
+        slope = _tower_slope(nonlinearity)
+        if (n == 2 and bias and use_bn and last_layer_bn and not weight_normalization and feature_map is None
+                and slope is not None):
+            model = TowerSequential(*mods, slope=slope)  # Linear, BN, act, Linear, BN: the CDK script's tower
+        else:
+            model = nn.Sequential(*mods)
     model.output_dim = sizes[-1]
     return model

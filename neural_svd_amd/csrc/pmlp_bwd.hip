@@ -4,6 +4,7 @@
 #include "evd_math.h"
 #include "opt_math.h"
 #include "tile_nt.h"
+#include "tile128_nt.h"
 
 using namespace nsvd_pmlp;
 
@@ -30,52 +31,22 @@ struct ChainArgs {
     float* dbase;                // (L, B)  df * d f / d base    (for the last-layer gradient)
     float* dfsc;                 // (L, B)  df * d f / d scales  (exponential mask only)
     int nlayers, B, L;
-    int xcd_remap;               // pick_xcd_remap(): the forward kernel's workgroup -> (head, sample block) map
     // EVD-loss mode (df == null): NestedLoRALossFunctionEVD.backward evaluated per sample right here
     NsvdEvdIn evd;
 };
 
-constexpr int CHAIN_FT = 8192;  // floats of f staged at a time for the direct moments (32 KB)
-
-#ifdef NSVD_WG_STAMPS
-__device__ unsigned long long g_chain_stamps[1024 * 16];
-#define CH_STAMP(slot) if (threadIdx.x == 0) g_chain_stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter()
-#else
-#define CH_STAMP(slot)
-#endif
-
 __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float DZ[BS * H_LD];  // [c][n]  n contiguous
-    __shared__ __attribute__((aligned(16))) float FT[CHAIN_FT];   // a tile of f rows (direct moments)
-    __shared__ __attribute__((aligned(16))) float WS[HID * H_LD];  // W_i[n][k] of the layer being multiplied
-    CH_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int nsb = a.B / BS;
-    int l, sb_;
-#ifdef NSVD_CHAIN_TWICE
-    xcd_block_map(blockIdx.x % (nsb * a.L), a.xcd_remap, a.L, nsb, l, sb_);  // diagnostic: every block runs twice
-#else
-    xcd_block_map(blockIdx.x, a.xcd_remap, a.L, nsb, l, sb_);  // the forward kernel's map (pmlp_common.h)
-#endif
-    const int b0 = sb_ * BS;
+    const int l = blockIdx.x / nsb;
+    const int b0 = (blockIdx.x - l * nsb) * BS;
     const int nh = a.nlayers - 1;
     const int b = b0 + li;
     const size_t row0 = ((size_t)l * HID + 32 * w) * a.B + b;
 
-    // Direct moments, f small enough for one LDS tile (cfg2: 32 KB): its loads are the FIRST of the kernel, so that the
-    // moment phase waits for them alone (vmcnt counts in order) while everything issued below is still in flight.
-    const bool one_tile = !a.df && !(a.evd.moments || a.evd.part) && (a.evd.Lg & 3) == 0 && a.B * a.evd.Lg <= CHAIN_FT;
-    float4 ft[CHAIN_FT / 4 / 256];
-    if (one_tile) {
-        const int n4 = a.B * a.evd.Lg / 4;
-#pragma unroll
-        for (int j = 0; j < CHAIN_FT / 4 / 256; ++j) {
-            const int q = tid + 256 * j;
-            ft[j] = q < n4 ? reinterpret_cast<const float4*>(a.evd.f)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     // the last hidden layer's activations and the 128 -> 1 weights do not depend on d loss / d f: their loads fly
     // while the moments are taken
     float zl[16], wlv[16];
@@ -83,43 +54,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         const float* zp = a.zsave[nh - 1] + row0;
         const float* wl = a.W[nh] + (size_t)l * HID + 32 * w;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zl[r] = zp[(size_t)acc_row(r, hi) * a.B];
-        // rows acc_row(4 g .. 4 g + 3, hi) = 8 g + 4 hi + {0..3} are contiguous: 4 loads instead of 16 (a vector
-        // memory instruction costs the CU's address unit 16 cycles per wave whatever its width)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t = *reinterpret_cast<const float4*>(wl + 8 * g + 4 * hi);
-            wlv[4 * g] = t.x; wlv[4 * g + 1] = t.y; wlv[4 * g + 2] = t.z; wlv[4 * g + 3] = t.w;
+        for (int r = 0; r < 16; ++r) {
+            const int n = acc_row(r, hi);
+            zl[r] = zp[(size_t)n * a.B];
+            wlv[r] = wl[n];
         }
     }
-    // W_i of the first chain layer, global -> registers with 16-byte loads (16 per thread, whole 512-B rows per wave
-    // instruction; it is independent of d loss / d f, so it flies under the moment phase). The MFMA A fragments - this
-    // lane's column k = 32 w + li of four rows - are then read from an LDS copy: as direct 4-byte global loads (64 per
-    // lane and layer, a 256-B wave instruction each) they were address-rate bound and cost 6 K cycles per layer.
-    float4 wreg[16];
-#define CH_LOADW(i)                                                                                     \
-    {                                                                                                   \
-        const float* Wi_ = a.W[i] + (size_t)l * HID * HID + (size_t)(tid >> 5) * HID + 4 * (tid & 31);  \
-        _Pragma("unroll") for (int j = 0; j < 16; ++j)                                                  \
-            wreg[j] = *reinterpret_cast<const float4*>(Wi_ + (size_t)(8 * j) * HID);                    \
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) wreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nh - 1 >= 1) CH_LOADW(nh - 1);
-    // everything else a sample needs that does not depend on the moments: issued now, so that the kernel pays ONE
-    // memory latency (~4 K cycles under load) in front of the chain instead of one per dependent step
-    float zin[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zin[r] = 0.f;
-    if (nh - 1 >= 1) {
-        const float* zp = a.zsave[nh - 2] + row0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zin[r] = zp[(size_t)acc_row(r, hi) * a.B];
-    }
-    const float jacv = a.jac[(size_t)b * a.L + l];
-    const float dscv = a.dfsc ? a.dsc[(size_t)b * a.L + l] : 0.f;
-    const float tfv = a.df ? 0.f : a.evd.Tf[(size_t)b * a.evd.Lg + a.evd.l_off + l];
-    CH_STAMP(8);
     float dfv;
     if (a.df) {
         dfv = a.df[(size_t)b * a.L + l];
@@ -137,174 +77,81 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
             }
             if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, Lg, DZ + 2 * Lg);
         } else {
-            // direct mode: no moment kernel ran - the 2 Lg moments of THIS head's column straight from f.
-            // f (B x Lg, 32 KB at cfg2) is streamed through LDS in tiles of whole rows with coalesced 16-byte loads
-            // (read column-wise from global memory this phase was 18 K of the kernel's 41 K cycles); thread t owns
-            // moment column lp = t % Lg and every S-th row of a tile, S = 256 / Lg row slices, fixed summation order;
-            // the loss scalars are not produced.
-            const int S = 256 / Lg;                      // row slices (Lg <= 256)
-            const int lp = tid % Lg, sl = tid / Lg;
-            const int TR = CHAIN_FT / Lg;                // rows per tile
-            float acc0 = 0.f, acc1 = 0.f;                // this thread's share of lam_f1 / lam_f2 [lp][lg]
-            // (raw barriers in this phase: only LDS data is exchanged, and __syncthreads() would wait for every
-            //  prefetch in flight)
-            for (int base = 0; base < a.B; base += TR) {
-                const int rows = a.B - base < TR ? a.B - base : TR;
-                const int nfl = rows * Lg;
-                const float* src = a.evd.f + (size_t)base * Lg;
-                if (one_tile) {
-#pragma unroll
-                    for (int j = 0; j < CHAIN_FT / 4 / 256; ++j)
-                        if (tid + 256 * j < nfl / 4) reinterpret_cast<float4*>(FT)[tid + 256 * j] = ft[j];
-                } else if ((Lg & 3) == 0) {
-                    for (int q = tid; q < nfl / 4; q += 256)
-                        reinterpret_cast<float4*>(FT)[q] = reinterpret_cast<const float4*>(src)[q];
-                } else {
-                    for (int q = tid; q < nfl; q += 256) FT[q] = src[q];
+            // direct mode: no moment kernel ran - the 2 Lg moments of THIS head's column straight from f
+            // (8 threads per moment, fixed summation order; the loss scalars are not produced)
+            const int sub = tid & 7;
+            for (int t = tid >> 3; t < 2 * Lg; t += 32) {
+                const int h = t / Lg, lp = t - h * Lg;
+                const int r0 = h ? B1 : 0, nr = h ? B2 : B1;
+                const float* fp = a.evd.f + (size_t)r0 * Lg;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int bb = sub;
+                for (; bb + 24 < nr; bb += 32) {
+                    s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
+                    s1 = fmaf(fp[(size_t)(bb + 8) * Lg + lp], fp[(size_t)(bb + 8) * Lg + lg], s1);
+                    s2 = fmaf(fp[(size_t)(bb + 16) * Lg + lp], fp[(size_t)(bb + 16) * Lg + lg], s2);
+                    s3 = fmaf(fp[(size_t)(bb + 24) * Lg + lp], fp[(size_t)(bb + 24) * Lg + lg], s3);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                CH_STAMP(9);
-                if (sl < S) {
-                    // four independent chains per half, four rows in flight (a rolled loop pays the LDS latency per row)
-                    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
-                    int r = sl;
-                    for (; r + 3 * S < rows; r += 4 * S) {
-                        const float x0 = FT[r * Lg + lp] * FT[r * Lg + lg];
-                        const float x1 = FT[(r + S) * Lg + lp] * FT[(r + S) * Lg + lg];
-                        const float x2 = FT[(r + 2 * S) * Lg + lp] * FT[(r + 2 * S) * Lg + lg];
-                        const float x3 = FT[(r + 3 * S) * Lg + lp] * FT[(r + 3 * S) * Lg + lg];
-                        const bool h0 = base + r < B1, h1 = base + r + S < B1, h2 = base + r + 2 * S < B1,
-                                   h3 = base + r + 3 * S < B1;
-                        p0 += h0 ? x0 : 0.f; q0 += h0 ? 0.f : x0;
-                        p1 += h1 ? x1 : 0.f; q1 += h1 ? 0.f : x1;
-                        p2 += h2 ? x2 : 0.f; q2 += h2 ? 0.f : x2;
-                        p3 += h3 ? x3 : 0.f; q3 += h3 ? 0.f : x3;
-                    }
-                    for (; r < rows; r += S) {
-                        const float x0 = FT[r * Lg + lp] * FT[r * Lg + lg];
-                        if (base + r < B1) p0 += x0;
-                        else q0 += x0;
-                    }
-                    acc0 += (p0 + p1) + (p2 + p3);
-                    acc1 += (q0 + q1) + (q2 + q3);
-                }
-                if (base + TR < a.B) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            CH_STAMP(10);
-            // slice partials -> LDS -> the 2 Lg masked moment columns, slices added in order
-            float* red = DZ + 2 * Lg;  // [2][S][Lg] (behind col[]; the tile in FT stays intact for the row reads below)
-            if (sl < S) {
-                red[sl * Lg + lp] = acc0;
-                red[(S + sl) * Lg + lp] = acc1;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (tid < 2 * Lg) {
-                const int h = tid / Lg, lq = tid - h * Lg;
-                float sum = 0.f;
-                for (int k = 0; k < S; ++k) sum += red[(h * S + k) * Lg + lq];
-                col[tid] = nsvd_evd_mask_M(a.evd, lq, lg, Lg) * (sum / (float)(h ? B2 : B1));
+                for (; bb < nr; bb += 8) s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
+                float sum = (s0 + s1) + (s2 + s3);
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                if (sub == 0) col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * (sum / (float)nr);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        CH_STAMP(11);
+        __syncthreads();
         const bool first = b < B1;
         const float* cp = col + (first ? Lg : 0);  // the OTHER half's moments
-        // this sample's row of f: from the LDS tile when the direct-moment phase left the whole of f there
-        const bool f_in_lds = !(a.evd.moments || a.evd.part) && a.B * Lg <= CHAIN_FT;
-        const float* fr = f_in_lds ? FT + b * Lg : a.evd.f + (size_t)b * Lg;
+        const float* fr = a.evd.f + (size_t)b * Lg;
         float acc = 0.f;
         for (int lp = 0; lp < Lg; ++lp) acc = fmaf(fr[lp], cp[lp], acc);
-        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * tfv +
+        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * a.evd.Tf[(size_t)b * Lg + lg] +
                                   (2.f / (float)(first ? B1 : B2)) * acc);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // col[] is dead before DZ is reused
+        __syncthreads();  // col[] is dead before DZ is reused
     }
-    CH_STAMP(1);
-    const float dbase = dfv * jacv;
+    const float dbase = dfv * a.jac[(size_t)b * a.L + l];
     if (w == 0 && hi == 0) {
         a.dbase[(size_t)l * a.B + b] = dbase;
-        if (a.dfsc) a.dfsc[(size_t)l * a.B + b] = dfv * dscv;
+        if (a.dfsc) a.dfsc[(size_t)l * a.B + b] = dfv * a.dsc[(size_t)b * a.L + l];
     }
     float dz[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dz[r] = wlv[r] * dbase * nsvd_sigmoid_from_softplus(zl[r]);
-    // One chain layer: dz (of layer i, in registers) -> global, then dz_{i-1} = (W_i^T dz_i) * sigmoid(z_{i-1}); W_i goes
-    // registers -> LDS next to the transposed dz, and the next layer's W is fetched while this one is multiplied.
-    for (int i = nh - 1; i >= 1; --i) {
-        CH_STAMP(2 + (nh - 1 - i < 4 ? nh - 1 - i : 4));
-        // (raw barriers: __syncthreads() would also wait for the global stores and the prefetches below)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // previous round's LDS reads are done
-        if (i == nh - 1) CH_STAMP(12);
+    for (int i = nh - 1; i >= 0; --i) {
+        float* o = a.dz[i] + row0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
+        if (i == 0) break;
+        // issue the loads the next tile needs before the LDS exchange: sigmoid inputs and W_i columns
+        float zin[16];
+        {
+            const float* zp = a.zsave[i - 1] + row0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zin[r] = zp[(size_t)acc_row(r, hi) * a.B];
+        }
+        __syncthreads();  // previous round's LDS reads are done
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =
                 make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);
-        {
-            float* wd = WS + (tid >> 5) * H_LD + 4 * (tid & 31);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) *reinterpret_cast<float4*>(wd + 8 * j * H_LD) = wreg[j];
-        }
-        if (i == nh - 1) CH_STAMP(13);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (i == nh - 1) CH_STAMP(14);
-        // Behind the barrier and INSIDE the MFMA loop (one store and two loads per group of four MFMAs, pinned by
-        // sched_group_barrier): dz_i -> global and the next layer's W and activations. Issued in a block in front of
-        // the loop these 48 vector-memory instructions hold the wave for ~3 K cycles before its first MFMA.
-        float znext[16];
-        const bool more = i - 1 >= 1;
-        float* o = a.dz[i] + row0;
-        const float* Wn = a.W[more ? i - 1 : i] + (size_t)l * HID * HID + (size_t)(tid >> 5) * HID + 4 * (tid & 31);
-        const float* zn = a.zsave[more ? i - 2 : i - 1] + row0;
+        __syncthreads();
         f32x16 acc1[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+        const float* Wi = a.W[i] + (size_t)l * HID * HID + 32 * w + li;  // W_i[n][k = 32w + li]
         const float* Bp = DZ + li * H_LD + 4 * hi;
-        const float* Ap = WS + (4 * hi) * H_LD + 32 * w + li;  // W_i[n = 8 q + 4 hi + j][k = 32 w + li]
-        // fragments one group ahead of their MFMAs (read right in front of them, each group waits out the LDS latency:
-        // 16 x ~130 cycles on top of the 4 K cycles of MFMAs)
-        Frag<1> fcur, fnxt;
-#define CH_READ(f, q)                                                                  \
-    {                                                                                  \
-        const float* wp = Ap + 8 * (q) * H_LD;                                         \
-        f.a = make_float4(wp[0], wp[H_LD], wp[2 * H_LD], wp[3 * H_LD]);                \
-        f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * (q));                       \
-    }
-        CH_READ(fcur, 0);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            if (q + 1 < 16) CH_READ(fnxt, q + 1);
-            o[(size_t)acc_row(q, hi) * a.B] = dz[q];
-            // (the last layer re-reads its own W / activations into registers nobody uses: branch-free loop body)
-            wreg[q] = *reinterpret_cast<const float4*>(Wn + (size_t)(8 * q) * HID);
-            znext[q] = zn[(size_t)acc_row(q, hi) * a.B];
-            mma_frag<1>(acc1, fcur);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // next group's fragment reads
-            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // store
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // load
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // load
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            fcur = fnxt;
+            Frag<1> f;
+            const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;
+            f.a = make_float4(wp[0], wp[HID], wp[2 * HID], wp[3 * HID]);
+            f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * q);
+            mma_frag<1>(acc1, f);
         }
-#undef CH_READ
-        if (i == nh - 1) CH_STAMP(15);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dz[r] = acc1[0][r] * nsvd_sigmoid_from_softplus(zin[r]);
-            zin[r] = znext[r];
-        }
+        for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * nsvd_sigmoid_from_softplus(zin[r]);
     }
-    {
-        CH_STAMP(6);
-        float* o = a.dz[0] + row0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
-    }
-#undef CH_LOADW
-    CH_STAMP(7);
 }
 
 // ================================================================================================
@@ -459,128 +306,12 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
     const int s_row = tid >> 3, s_c4 = tid & 7;
     const float* a_src = a.dz[0] + ((size_t)l * HID + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
     const float* b_src = a.phiTc + (size_t)(kf0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
-    const size_t step = (size_t)32 * a.B;
-    // Same software pipeline as the forward's layer 0: fragments one q-group ahead, chunk c+1 written to
-    // the other LDS buffer under chunk c's third q-group, chunk c+2 fetched from global under its fourth
-    // (after the barrier), every memory instruction in an MFMA gap, branch-free steady state.
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;  // bias gradient partials (only used when kf0 == 0)
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define WA_LOAD(c)                                                 \
-    {                                                              \
-        const float* pa_ = a_src + (c) * BK;                       \
-        const float* pb_ = b_src + (c) * BK;                       \
-        WG_LD(ra0, pa_);                                           \
-        WG_LD(ra1, pa_ + step);                                    \
-        WG_LD(ra2, pa_ + 2 * step);                                \
-        WG_LD(ra3, pa_ + 3 * step);                                \
-        WG_LD(rb0, pb_);                                           \
-        WG_LD(rb1, pb_ + step);                                    \
-        WG_LD(rb2, pb_ + 2 * step);                                \
-        WG_LD(rb3, pb_ + 3 * step);                                \
-    }
-#define WA_STORE(buf)                                                              \
-    {                                                                              \
-        float* Ab_ = As + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
-        float* Bb_ = Bs + (buf) * HID * A_LD + s_row * A_LD + 4 * s_c4;            \
-        WG_ST(Ab_, ra0);                                                           \
-        WG_ST(Ab_ + 32 * A_LD, ra1);                                               \
-        WG_ST(Ab_ + 64 * A_LD, ra2);                                               \
-        WG_ST(Ab_ + 96 * A_LD, ra3);                                               \
-        WG_ST(Bb_, rb0);                                                           \
-        WG_ST(Bb_ + 32 * A_LD, rb1);                                               \
-        WG_ST(Bb_ + 64 * A_LD, rb2);                                               \
-        WG_ST(Bb_ + 96 * A_LD, rb3);                                               \
-        rs0 += (ra0.x + ra0.y) + (ra0.z + ra0.w);                                  \
-        rs1 += (ra1.x + ra1.y) + (ra1.z + ra1.w);                                  \
-        rs2 += (ra2.x + ra2.y) + (ra2.z + ra2.w);                                  \
-        rs3 += (ra3.x + ra3.y) + (ra3.z + ra3.w);                                  \
-    }
-    struct F4 {
-        float4 a0, a1, b0, b1;
-    };
-#define WA_READ(f, Ap, Bp, q)                                                      \
-    {                                                                              \
-        f.a0 = *reinterpret_cast<const float4*>((Ap) + 8 * (q));                   \
-        f.a1 = *reinterpret_cast<const float4*>((Ap) + 32 * A_LD + 8 * (q));       \
-        f.b0 = *reinterpret_cast<const float4*>((Bp) + 8 * (q));                   \
-        f.b1 = *reinterpret_cast<const float4*>((Bp) + 32 * A_LD + 8 * (q));       \
-    }
-#define WA_MMA1(f, X)                                                                                   \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0][0], 0, 0, 0);              \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[0][1], 0, 0, 0);              \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[1][0], 0, 0, 0);              \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[1][1], 0, 0, 0);
-#define WA_MMA(f) WA_MMA1(f, x) WA_MMA1(f, y) WA_MMA1(f, z) WA_MMA1(f, w)
-#define WA_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define WA_IL(n, mask)                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {           \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
-        __builtin_amdgcn_sched_group_barrier((mask), 1, 0);        \
-    }
-#define WA_BODY(c, DO_STORE, DO_LOAD)                                                           \
-    {                                                                                           \
-        const int cur = (c) & 1;                                                                \
-        const float* Ap = As + cur * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;               \
-        const float* Bp = Bs + cur * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;               \
-        WA_READ(f1, Ap, Bp, 1);                                                                 \
-        WA_MMA(f0);                                                                             \
-        WA_IL(4, 0x100);                                                                        \
-        WA_FENCE();                                                                             \
-        WA_READ(f0, Ap, Bp, 2);                                                                 \
-        WA_MMA(f1);                                                                             \
-        WA_IL(4, 0x100);                                                                        \
-        WA_FENCE();                                                                             \
-        WA_READ(f1, Ap, Bp, 3);                                                                 \
-        if (DO_STORE) WA_STORE(cur ^ 1);                                                        \
-        WA_MMA(f0);                                                                             \
-        WA_IL(4, 0x100);                                                                        \
-        if (DO_STORE) WA_IL(8, 0x200);                                                          \
-        WA_FENCE();                                                                             \
-        __syncthreads();                                                                        \
-        if (DO_STORE) {                                                                         \
-            const float* An = As + (cur ^ 1) * HID * A_LD + (64 * wm + li) * A_LD + 4 * hi;     \
-            const float* Bn = Bs + (cur ^ 1) * HID * A_LD + (64 * wn + li) * A_LD + 4 * hi;     \
-            WA_READ(f0, An, Bn, 0);                                                             \
-        }                                                                                       \
-        if (DO_LOAD) WA_LOAD((c) + 2);                                                          \
-        WA_MMA(f1);                                                                             \
-        if (DO_STORE) WA_IL(4, 0x100);                                                          \
-        if (DO_LOAD) WA_IL(8, 0x020);                                                           \
-        WA_FENCE();                                                                             \
-    }
-    const int nch = a.Bs / BK;
+    float rs[4];
     WG_STAMP(0, 1ull);
     WG_STAMP(1, wall_clock64());
     WG_STAMP(2, __builtin_readcyclecounter());
-    WA_LOAD(0);
-    WA_STORE(0);
-    __syncthreads();
-    if (nch > 1) WA_LOAD(1);
-    WG_STAMP(3, __builtin_readcyclecounter());
-    F4 f0, f1;
-    {
-        const float* Ap = As + (64 * wm + li) * A_LD + 4 * hi;
-        const float* Bp = Bs + (64 * wn + li) * A_LD + 4 * hi;
-        WA_READ(f0, Ap, Bp, 0);
-    }
-    {
-        int c = 0;
-        for (; c + 2 < nch; ++c) WA_BODY(c, true, true)
-        if (c + 1 < nch) {
-            WA_BODY(c, true, false)
-            ++c;
-        }
-        WA_BODY(c, false, false)
-    }
-#undef WA_BODY
-#undef WA_IL
-#undef WA_FENCE
-#undef WA_MMA
-#undef WA_MMA1
-#undef WA_READ
-#undef WA_LOAD
-#undef WA_STORE
+    nsvd_tile128_nt(a_src, b_src, (size_t)32 * a.B, (size_t)32 * a.B, a.Bs / BK, As, Bs, acc, rs);  // tile128_nt.h
+    float rs0 = rs[0], rs1 = rs[1], rs2 = rs[2], rs3 = rs[3];  // bias gradient partials (used when kf0 == 0)
     WG_STAMP(4, __builtin_readcyclecounter());
     const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
     const WgDst dW = wg_dst(a, a.gW[0], a.poW[0], slice), db = wg_dst(a, a.gb[0], a.pob[0], slice);
@@ -905,12 +636,7 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         a.dz[i] = (i < nh) ? w.dz[i] : nullptr;
     }
     a.nlayers = d.nlayers; a.B = B; a.L = d.L;
-    a.xcd_remap = pick_xcd_remap(d.L, B / BS, F);
-#ifdef NSVD_CHAIN_TWICE
-    hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel, dim3(2 * (B / BS) * d.L), dim3(256), 0, s, a);
-#else
     hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel, dim3((B / BS) * d.L), dim3(256), 0, s, a);
-#endif
     NSVD_CHECK_LAUNCH();
 
     WgradArgs wa;
@@ -936,9 +662,9 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         if (d.has_exp_mask) wa.oscales = NsvdOptPtrs{p.scales, opt->sq.scales, opt->ema ? opt->ema->scales : nullptr};
     }
     wa.nA = (F / HID) * d.L;
-    wa.nB = 4 * (nh - 1) * d.L;
     wa.S = wgrad_slices(d, B);
     wa.Bs = B / wa.S;
+    wa.nB = 4 * (nh - 1) * d.L;
     const PartLayout pl = part_layout(d);
     if (wa.S > 1) {
         wa.part = w.gpart;
@@ -1014,9 +740,6 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
 #ifdef NSVD_WG_STAMPS
 extern "C" int nsvd_debug_wgrad_stamps(unsigned long long* host, size_t n) {
     return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), n * sizeof(unsigned long long));
-}
-extern "C" int nsvd_debug_chain_stamps(unsigned long long* host, size_t n) {
-    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chain_stamps), n * sizeof(unsigned long long));
 }
 extern "C" int nsvd_debug_pipe_stamps(unsigned long long* host, size_t n) {
     return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe_stamps), n * sizeof(unsigned long long));

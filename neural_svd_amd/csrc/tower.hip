@@ -1,0 +1,503 @@
+// CDK towers: Linear -> BatchNorm1d -> LeakyReLU -> Linear -> BatchNorm1d, forward and backward,
+// as hand-written gfx950 kernels. Reference: examples/models/mlp.py:129-164 (get_mlp), used as the two backbones of
+// examples/models/siam.py:132-166 (HeteroNetwork) by examples/cdk/sketchy/main_sketchy.py:107-116 with sizes
+// 512 -> 8192 -> 512, lrelu0.2, BatchNorm on every layer, batch 1024 (BASELINE configs[4]).
+//
+// Every contraction is brought into the "NT" form C = A B^T with both operands contraction-contiguous and runs on the
+// 128 x 128 fp32-MFMA tile loop shared with the layer-0 weight gradient (tile128_nt.h); the producers write the
+// transposed copies the backward contractions need (the activations, the pre-activation gradients) so that no GEMM
+// ever stages a strided operand:
+//   forward   Y1 = X W1^T + b1            A = X (B, d0)       B = W1 (d1, d0)          K = d0
+//             A1 = lrelu(BN1(Y1))         strip kernel: also writes A1^T (d1, B)
+//             Y2 = A1 W2^T + b2           A = A1 (B, d1)      B = W2 (d2, d1)          K = d1, split-K partials
+//             Z  = BN2(Y2)                strip kernel: sums the split-K partials, adds the bias
+//   backward  dY2 = BN2'(dZ)              strip kernel: also writes dY2^T (d2, B), db2, dgamma2, dbeta2
+//             dW2 = dY2^T A1              A = dY2^T (d2, B)   B = A1^T (d1, B)         K = B
+//             dA1 = dY2 W2                A = dY2 (B, d2)     B = W2^T (d1, d2)        K = d2   (W2^T: transpose kernel)
+//             dY1 = BN1'(lrelu'(dA1))     strip kernel: writes dY1^T (d1, B) only, db1, dgamma1, dbeta1
+//             dW1 = dY1^T X               A = dY1^T (d1, B)   B = X^T (d0, B)          K = B    (X^T: transpose kernel)
+// BatchNorm is training-mode torch.nn.BatchNorm1d: biased batch variance for the normalisation, unbiased for the
+// running estimate, momentum update of running_mean / running_var (eps 1e-5, momentum 0.1 by default).
+// Shapes: B, d0, d1, d2 multiples of 128, B <= 1024 (a BatchNorm strip of 32 columns x B rows lives in LDS).
+#include "nsvd_common.h"
+#include "tile128_nt.h"
+
+using namespace nsvd_pmlp;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- C = A B^T
+struct GemmNT {
+    const float* A;   // (M, lda) rows contraction-contiguous
+    const float* B;   // (N, ldb)
+    float* C;         // (M, ldc), or split-K slice s at C + s * slice_stride
+    const float* bias;  // per column of C (N) or null (never with split-K: the strip kernel adds it)
+    size_t lda, ldb, ldc, slice_stride;
+    int M, N, K, S;   // S split-K slices of K / S columns each
+};
+
+__global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * HID * A_LD];  // 72 KB: two blocks per CU
+    float* As = smem;
+    float* Bs = smem + 2 * HID * A_LD;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int tn = g.N / 128, tm = g.M / 128;
+    int bid = blockIdx.x;
+    const int slice = bid / (tm * tn);
+    bid -= slice * tm * tn;
+    // tiles that share their A rows (same tile row) are neighbours in block order: blocks b, b + 8, .. share an XCD
+    const int trow = bid / tn, tcol = bid - trow * tn;
+    const int Ks = g.K / g.S;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int s_row = tid >> 3, s_c4 = tid & 7;
+    const float* a_src = g.A + ((size_t)128 * trow + s_row) * g.lda + (size_t)slice * Ks + 4 * s_c4;
+    const float* b_src = g.B + ((size_t)128 * tcol + s_row) * g.ldb + (size_t)slice * Ks + 4 * s_c4;
+    float rs[4];
+    nsvd_tile128_nt(a_src, b_src, 32 * g.lda, 32 * g.ldb, Ks / BK, As, Bs, acc, rs);
+    float* C = g.C + (size_t)slice * g.slice_stride + ((size_t)128 * trow + 64 * wm) * g.ldc + 128 * tcol + 64 * wn + li;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float bv = g.bias ? g.bias[128 * tcol + 64 * wn + 32 * j + li] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(size_t)(32 * i + acc_row(r, hi)) * g.ldc + 32 * j] = acc[i][j][r] + bv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- transposes
+// out (C, R) = in (R, C)^T, 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int R, int Cc) {
+    __shared__ float t[32][33];
+    const int tiles_c = Cc / 32;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;  // 8 rows per pass
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[y + 8 * k][x] = in[(size_t)(32 * tr + y + 8 * k) * Cc + 32 * tc + x];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[(size_t)(32 * tc + y + 8 * k) * R + 32 * tr + x] = t[x][y + 8 * k];
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm strips
+// One workgroup = 32 columns x all B rows (B <= 1024: 132 KB of LDS), 256 threads: thread t owns the four columns
+// 4 (t & 7).. of rows (t >> 3) + 32 k: every global access is a 16-byte load / store of a 128-byte row segment, eight
+// rows in flight per thread (as 4-byte accesses in a rolled loop the forward strip of 1024 x 8192 took 330 us).
+// Column statistics in a fixed order: 32 row groups per column, combined in LDS.
+constexpr int STRIP = 32;
+constexpr int STRIP_LD = STRIP + 1;
+constexpr int STRIP_RG = 32;  // row groups
+
+struct BnFwd {
+    const float* Y;       // (S, B, N) split-K partials of the pre-normalisation output (S = 1: the output itself)
+    size_t slice_stride;
+    int S;
+    const float* bias;    // added to the summed partials (null: already added by the GEMM)
+    const float* gamma;   // BatchNorm weight / bias (N)
+    const float* beta;
+    float* running_mean;  // updated in place (null: no running statistics)
+    float* running_var;
+    float* mean;          // (N) saved for the backward
+    float* invstd;        // (N)
+    float* Ysum;          // (B, N) summed pre-normalisation output, written when S > 1 or bias != null (else null)
+    float* out;           // (B, N)  lrelu(BN(Y))  (slope 1: no activation)
+    float* outT;          // (N, B) transposed copy or null
+    int B, N;
+    float eps, momentum, slope;
+};
+
+__device__ __forceinline__ void strip_put(float* strip, int r, int c0, const float4& v) {
+    float* p = strip + r * STRIP_LD + c0;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
+__device__ __forceinline__ float4 strip_get(const float* strip, int r, int c0) {
+    const float* p = strip + r * STRIP_LD + c0;
+    return make_float4(p[0], p[1], p[2], p[3]);
+}
+// rows r4 .. r4 + 3 of column `col` -> one 16-byte store of the transposed copy
+__device__ __forceinline__ void strip_store_transposed(const float* strip, float* outT, int n0, int B, int tid) {
+    const int col = tid >> 3;
+    for (int r4 = 4 * (tid & 7); r4 < B; r4 += 32) {
+        const float4 v = make_float4(strip[r4 * STRIP_LD + col], strip[(r4 + 1) * STRIP_LD + col],
+                                     strip[(r4 + 2) * STRIP_LD + col], strip[(r4 + 3) * STRIP_LD + col]);
+        *reinterpret_cast<float4*>(outT + (size_t)(n0 + col) * B + r4) = v;
+    }
+}
+// per-column totals of the threads' 4-column partials: red[rg][c], then 32 threads add the row groups in order
+__device__ __forceinline__ void strip_reduce(float (*red)[STRIP], const float4& part, float* total, int tid) {
+    const int c0 = 4 * (tid & 7), rg = tid >> 3;
+    red[rg][c0] = part.x; red[rg][c0 + 1] = part.y; red[rg][c0 + 2] = part.z; red[rg][c0 + 3] = part.w;
+    __syncthreads();
+    if (tid < STRIP) {
+        float t = 0.f;
+        for (int k = 0; k < STRIP_RG; ++k) t += red[k][tid];
+        total[tid] = t;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
+    extern __shared__ __attribute__((aligned(16))) float strip[];  // [B][STRIP_LD]
+    __shared__ float red[STRIP_RG][STRIP];
+    __shared__ float csum[STRIP], cmean[STRIP], cinv[STRIP];
+    const int tid = threadIdx.x;
+    const int c0 = 4 * (tid & 7), rg = tid >> 3;
+    const int n0 = blockIdx.x * STRIP;
+    const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + n0 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // rows in batches of eight per thread: the eight (S x) loads are issued before the first one is consumed (the
+    // optional Ysum store may alias Y as far as the compiler knows, which would serialise a rolled loop)
+    for (int rb = rg; rb < a.B; rb += 8 * STRIP_RG) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rb + k * STRIP_RG;
+            v[k] = bv;
+            if (r < a.B) {
+                for (int s = 0; s < a.S; ++s) {
+                    const float4 t =
+                        *reinterpret_cast<const float4*>(a.Y + (size_t)s * a.slice_stride + (size_t)r * a.N + n0 + c0);
+                    v[k].x += t.x; v[k].y += t.y; v[k].z += t.z; v[k].w += t.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rb + k * STRIP_RG;
+            if (r < a.B) {
+                strip_put(strip, r, c0, v[k]);
+                s1.x += v[k].x; s1.y += v[k].y; s1.z += v[k].z; s1.w += v[k].w;
+                if (a.Ysum) *reinterpret_cast<float4*>(a.Ysum + (size_t)r * a.N + n0 + c0) = v[k];
+            }
+        }
+    }
+    strip_reduce(red, s1, csum, tid);
+    if (tid < STRIP) cmean[tid] = csum[tid] / (float)a.B;
+    __syncthreads();
+    const float4 mu = make_float4(cmean[c0], cmean[c0 + 1], cmean[c0 + 2], cmean[c0 + 3]);
+    float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int r = rg; r < a.B; r += STRIP_RG) {  // two-pass variance: mean first, then the squared deviations
+        const float4 v = strip_get(strip, r, c0);
+        const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+        s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+    }
+    strip_reduce(red, s2, csum, tid);
+    if (tid < STRIP) {
+        const float v = csum[tid];
+        const float inv = 1.0f / sqrtf(v / (float)a.B + a.eps);
+        cinv[tid] = inv;
+        a.mean[n0 + tid] = cmean[tid];
+        a.invstd[n0 + tid] = inv;
+        if (a.running_mean) {
+            const float unb = v / (float)(a.B - 1);
+            a.running_mean[n0 + tid] = (1.f - a.momentum) * a.running_mean[n0 + tid] + a.momentum * cmean[tid];
+            a.running_var[n0 + tid] = (1.f - a.momentum) * a.running_var[n0 + tid] + a.momentum * unb;
+        }
+    }
+    __syncthreads();
+    const float4 inv = make_float4(cinv[c0], cinv[c0 + 1], cinv[c0 + 2], cinv[c0 + 3]);
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + n0 + c0);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + n0 + c0);
+#pragma unroll 8
+    for (int r = rg; r < a.B; r += STRIP_RG) {
+        const float4 v = strip_get(strip, r, c0);
+        float4 o;
+        o.x = fmaf((v.x - mu.x) * inv.x, ga.x, be.x); o.y = fmaf((v.y - mu.y) * inv.y, ga.y, be.y);
+        o.z = fmaf((v.z - mu.z) * inv.z, ga.z, be.z); o.w = fmaf((v.w - mu.w) * inv.w, ga.w, be.w);
+        o.x = o.x > 0.f ? o.x : a.slope * o.x; o.y = o.y > 0.f ? o.y : a.slope * o.y;
+        o.z = o.z > 0.f ? o.z : a.slope * o.z; o.w = o.w > 0.f ? o.w : a.slope * o.w;
+        *reinterpret_cast<float4*>(a.out + (size_t)r * a.N + n0 + c0) = o;
+        if (a.outT) strip_put(strip, r, c0, o);
+    }
+    if (a.outT) {
+        __syncthreads();
+        strip_store_transposed(strip, a.outT, n0, a.B, tid);
+    }
+}
+
+struct BnBwd {
+    const float* dout;    // (B, N) gradient w.r.t. the strip kernel's output (after the activation)
+    const float* Y;       // (B, N) pre-normalisation output (what the forward normalised)
+    const float* mean;    // (N)
+    const float* invstd;  // (N)
+    const float* gamma;
+    const float* beta;    // needed for the activation's sign only (slope != 1)
+    float* dY;            // (B, N) or null
+    float* dYT;           // (N, B) or null
+    float* dgamma;        // (N)
+    float* dbeta;         // (N)
+    float* dbias;         // (N): column sums of dY (the Linear bias in front of the BatchNorm), or null
+    int B, N;
+    float slope;
+};
+
+__global__ void __launch_bounds__(256) tower_bn_backward_kernel(BnBwd a) {
+    extern __shared__ __attribute__((aligned(16))) float strip[];  // [B][STRIP_LD]: dh, then dY
+    __shared__ float red[STRIP_RG][STRIP];
+    __shared__ float c1[STRIP], c2[STRIP], c3[STRIP];
+    const int tid = threadIdx.x;
+    const int c0 = 4 * (tid & 7), rg = tid >> 3;
+    const int n0 = blockIdx.x * STRIP;
+    const float4 mu = *reinterpret_cast<const float4*>(a.mean + n0 + c0);
+    const float4 inv = *reinterpret_cast<const float4*>(a.invstd + n0 + c0);
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + n0 + c0);
+    const float4 be = *reinterpret_cast<const float4*>(a.beta + n0 + c0);
+    // pass 1: dh = dout * act'(h), column sums of dh and dh * yhat
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (int rb = rg; rb < a.B; rb += 8 * STRIP_RG) {
+        float4 yv[8], dv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // sixteen loads in flight per thread
+            const int r = rb + k * STRIP_RG;
+            yv[k] = dv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.B) {
+                yv[k] = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.N + n0 + c0);
+                dv[k] = *reinterpret_cast<const float4*>(a.dout + (size_t)r * a.N + n0 + c0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rb + k * STRIP_RG;
+            if (r >= a.B) continue;
+            const float4 y = yv[k], d = dv[k];
+            const float yx = (y.x - mu.x) * inv.x, yy = (y.y - mu.y) * inv.y, yz = (y.z - mu.z) * inv.z,
+                        yw = (y.w - mu.w) * inv.w;
+            float4 dh;
+            dh.x = d.x * (fmaf(yx, ga.x, be.x) > 0.f ? 1.f : a.slope);
+            dh.y = d.y * (fmaf(yy, ga.y, be.y) > 0.f ? 1.f : a.slope);
+            dh.z = d.z * (fmaf(yz, ga.z, be.z) > 0.f ? 1.f : a.slope);
+            dh.w = d.w * (fmaf(yw, ga.w, be.w) > 0.f ? 1.f : a.slope);
+            strip_put(strip, r, c0, dh);
+            s1.x += dh.x; s1.y += dh.y; s1.z += dh.z; s1.w += dh.w;
+            s2.x = fmaf(dh.x, yx, s2.x); s2.y = fmaf(dh.y, yy, s2.y); s2.z = fmaf(dh.z, yz, s2.z);
+            s2.w = fmaf(dh.w, yw, s2.w);
+        }
+    }
+    strip_reduce(red, s1, c1, tid);
+    strip_reduce(red, s2, c2, tid);
+    if (tid < STRIP) {
+        a.dbeta[n0 + tid] = c1[tid];
+        a.dgamma[n0 + tid] = c2[tid];
+    }
+    // pass 2: dY = gamma * invstd * (dh - mean(dh) - yhat * mean(dh * yhat))
+    const float rB = 1.0f / (float)a.B;
+    const float4 m1 = make_float4(c1[c0] * rB, c1[c0 + 1] * rB, c1[c0 + 2] * rB, c1[c0 + 3] * rB);
+    const float4 m2 = make_float4(c2[c0] * rB, c2[c0 + 1] * rB, c2[c0 + 2] * rB, c2[c0 + 3] * rB);
+    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rb = rg; rb < a.B; rb += 8 * STRIP_RG) {
+        float4 yv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rb + k * STRIP_RG;
+            yv[k] = r < a.B ? *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.N + n0 + c0)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rb + k * STRIP_RG;
+            if (r >= a.B) continue;
+            const float4 y = yv[k];
+            const float4 dh = strip_get(strip, r, c0);
+            float4 dy;
+            dy.x = ga.x * inv.x * (dh.x - m1.x - (y.x - mu.x) * inv.x * m2.x);
+            dy.y = ga.y * inv.y * (dh.y - m1.y - (y.y - mu.y) * inv.y * m2.y);
+            dy.z = ga.z * inv.z * (dh.z - m1.z - (y.z - mu.z) * inv.z * m2.z);
+            dy.w = ga.w * inv.w * (dh.w - m1.w - (y.w - mu.w) * inv.w * m2.w);
+            strip_put(strip, r, c0, dy);
+            sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
+            if (a.dY) *reinterpret_cast<float4*>(a.dY + (size_t)r * a.N + n0 + c0) = dy;
+        }
+    }
+    strip_reduce(red, sb, c3, tid);  // (also the barrier in front of the transposed read-out)
+    if (a.dbias && tid < STRIP) a.dbias[n0 + tid] = c3[tid];
+    if (a.dYT) strip_store_transposed(strip, a.dYT, n0, a.B, tid);
+}
+
+inline int launch_gemm(const GemmNT& g, hipStream_t s) {
+    if (g.M % 128 || g.N % 128 || g.S < 1 || g.K % (32 * g.S)) return NSVD_EINVAL;
+    hipLaunchKernelGGL(tower_gemm_nt_kernel, dim3((g.M / 128) * (g.N / 128) * g.S), dim3(256), 0, s, g);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+inline size_t strip_lds(int B) { return (size_t)B * STRIP_LD * sizeof(float); }
+
+inline int ensure_strip_attr() {
+    static bool done = false;
+    if (done) return 0;
+    const int bytes = (int)strip_lds(1024);
+    hipError_t e = hipFuncSetAttribute((const void*)tower_bn_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)tower_bn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                bytes);
+    if (e != hipSuccess) return -(int)e;
+    done = true;
+    return 0;
+}
+
+// split-K of the second forward GEMM: as many slices as it takes to give every CU a tile (K / S a multiple of 32)
+inline int fwd2_slices(int B, int d1, int d2) {
+    const int tiles = (B / 128) * (d2 / 128);
+    int S = 1;
+    while (S < 16 && tiles * S < 256 && d1 % (64 * S) == 0) S *= 2;
+    return S;
+}
+
+struct TowerWs {
+    float *Y1, *A1, *A1T, *Y2p, *Y2, *XT, *W2T, *dY2, *dY2T, *dA1, *dY1T;
+    float *mean1, *inv1, *mean2, *inv2;
+    size_t bytes;
+};
+
+inline TowerWs carve_tower(int B, int d0, int d1, int d2, void* base) {
+    TowerWs w;
+    memset(&w, 0, sizeof(w));
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float* q = (float*)(p + off);
+        off += nsvd_align(nfloats * sizeof(float));
+        return q;
+    };
+    const int S = fwd2_slices(B, d1, d2);
+    w.Y1 = take((size_t)B * d1);
+    w.A1 = take((size_t)B * d1);
+    w.A1T = take((size_t)B * d1);
+    w.Y2p = take((size_t)S * B * d2);
+    w.Y2 = take((size_t)B * d2);
+    w.XT = take((size_t)B * d0);
+    w.W2T = take((size_t)d1 * d2);
+    w.dY2 = take((size_t)B * d2);
+    w.dY2T = take((size_t)B * d2);
+    w.dA1 = take((size_t)B * d1);
+    w.dY1T = take((size_t)B * d1);
+    w.mean1 = take(d1);
+    w.inv1 = take(d1);
+    w.mean2 = take(d2);
+    w.inv2 = take(d2);
+    w.bytes = off;
+    return w;
+}
+
+inline bool tower_shape_ok(int B, int d0, int d1, int d2) {
+    return B > 0 && B <= 1024 && B % 128 == 0 && d0 > 0 && d0 % 128 == 0 && d1 > 0 && d1 % 128 == 0 && d2 > 0 &&
+           d2 % 128 == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2) {
+    if (!tower_shape_ok(B, d0, d1, d2)) return 0;
+    return carve_tower(B, d0, d1, d2, nullptr).bytes;
+}
+
+int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0, int d1, int d2, float slope,
+                       float eps, float momentum, int update_running, float* z, void* ws, size_t ws_bytes,
+                       void* stream) {
+    if (!x || !p || !z || !ws || !tower_shape_ok(B, d0, d1, d2)) return NSVD_EINVAL;
+    if (!p->W1 || !p->b1 || !p->g1 || !p->be1 || !p->W2 || !p->b2 || !p->g2 || !p->be2) return NSVD_EINVAL;
+    if (update_running && (!p->rm1 || !p->rv1 || !p->rm2 || !p->rv2)) return NSVD_EINVAL;
+    const TowerWs w = carve_tower(B, d0, d1, d2, ws);
+    if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_strip_attr();
+    if (rc) return rc;
+    // Y1 = X W1^T + b1
+    GemmNT g;
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.lda = d0; g.B = p->W1; g.ldb = d0; g.C = w.Y1; g.ldc = d1; g.bias = p->b1;
+    g.M = B; g.N = d1; g.K = d0; g.S = 1;
+    rc = launch_gemm(g, s);
+    if (rc) return rc;
+    // A1 = lrelu(BN1(Y1)), A1^T
+    BnFwd f;
+    memset(&f, 0, sizeof(f));
+    f.Y = w.Y1; f.S = 1; f.gamma = p->g1; f.beta = p->be1;
+    f.running_mean = update_running ? p->rm1 : nullptr; f.running_var = update_running ? p->rv1 : nullptr;
+    f.mean = w.mean1; f.invstd = w.inv1; f.out = w.A1; f.outT = w.A1T; f.B = B; f.N = d1;
+    f.eps = eps; f.momentum = momentum; f.slope = slope;
+    hipLaunchKernelGGL(tower_bn_forward_kernel, dim3(d1 / STRIP), dim3(256), strip_lds(B), s, f);
+    NSVD_CHECK_LAUNCH();
+    // Y2 = A1 W2^T (+ b2 in the strip kernel), split-K partials
+    const int S = fwd2_slices(B, d1, d2);
+    memset(&g, 0, sizeof(g));
+    g.A = w.A1; g.lda = d1; g.B = p->W2; g.ldb = d1; g.C = w.Y2p; g.ldc = d2; g.slice_stride = (size_t)B * d2;
+    g.M = B; g.N = d2; g.K = d1; g.S = S;
+    rc = launch_gemm(g, s);
+    if (rc) return rc;
+    // Z = BN2(Y2)
+    memset(&f, 0, sizeof(f));
+    f.Y = w.Y2p; f.slice_stride = (size_t)B * d2; f.S = S; f.bias = p->b2; f.gamma = p->g2; f.beta = p->be2;
+    f.running_mean = update_running ? p->rm2 : nullptr; f.running_var = update_running ? p->rv2 : nullptr;
+    f.mean = w.mean2; f.invstd = w.inv2; f.Ysum = w.Y2; f.out = z; f.outT = nullptr; f.B = B; f.N = d2;
+    f.eps = eps; f.momentum = momentum; f.slope = 1.0f;
+    hipLaunchKernelGGL(tower_bn_forward_kernel, dim3(d2 / STRIP), dim3(256), strip_lds(B), s, f);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1, int d2,
+                        float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !p || !dz || !grads || !ws || !tower_shape_ok(B, d0, d1, d2)) return NSVD_EINVAL;
+    if (!grads->W1 || !grads->b1 || !grads->g1 || !grads->be1 || !grads->W2 || !grads->b2 || !grads->g2 || !grads->be2)
+        return NSVD_EINVAL;
+    const TowerWs w = carve_tower(B, d0, d1, d2, ws);
+    if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_strip_attr();
+    if (rc) return rc;
+    // dY2 = BN2'(dZ), dY2^T, db2 = column sums of dY2
+    BnBwd b;
+    memset(&b, 0, sizeof(b));
+    b.dout = dz; b.Y = w.Y2; b.mean = w.mean2; b.invstd = w.inv2; b.gamma = p->g2; b.beta = p->be2;
+    b.dY = w.dY2; b.dYT = w.dY2T; b.dgamma = grads->g2; b.dbeta = grads->be2; b.dbias = grads->b2;
+    b.B = B; b.N = d2; b.slope = 1.0f;
+    hipLaunchKernelGGL(tower_bn_backward_kernel, dim3(d2 / STRIP), dim3(256), strip_lds(B), s, b);
+    NSVD_CHECK_LAUNCH();
+    // dW2 = dY2^T A1  (A = dY2^T (d2, B), B = A1^T (d1, B), K = B)
+    GemmNT g;
+    memset(&g, 0, sizeof(g));
+    g.A = w.dY2T; g.lda = B; g.B = w.A1T; g.ldb = B; g.C = grads->W2; g.ldc = d1;
+    g.M = d2; g.N = d1; g.K = B; g.S = 1;
+    rc = launch_gemm(g, s);
+    if (rc) return rc;
+    // W2^T (d1, d2), then dA1 = dY2 W2  (A = dY2 (B, d2), B = W2^T (d1, d2), K = d2)
+    hipLaunchKernelGGL(tower_transpose_kernel, dim3((d2 / 32) * (d1 / 32)), dim3(256), 0, s, p->W2, w.W2T, d2, d1);
+    NSVD_CHECK_LAUNCH();
+    memset(&g, 0, sizeof(g));
+    g.A = w.dY2; g.lda = d2; g.B = w.W2T; g.ldb = d2; g.C = w.dA1; g.ldc = d1;
+    g.M = B; g.N = d1; g.K = d2; g.S = 1;
+    rc = launch_gemm(g, s);
+    if (rc) return rc;
+    // dY1^T = (BN1'(lrelu'(dA1)))^T, db1
+    memset(&b, 0, sizeof(b));
+    b.dout = w.dA1; b.Y = w.Y1; b.mean = w.mean1; b.invstd = w.inv1; b.gamma = p->g1; b.beta = p->be1;
+    b.dY = nullptr; b.dYT = w.dY1T; b.dgamma = grads->g1; b.dbeta = grads->be1; b.dbias = grads->b1;
+    b.B = B; b.N = d1; b.slope = slope;
+    hipLaunchKernelGGL(tower_bn_backward_kernel, dim3(d1 / STRIP), dim3(256), strip_lds(B), s, b);
+    NSVD_CHECK_LAUNCH();
+    // X^T (d0, B), then dW1 = dY1^T X  (A = dY1^T (d1, B), B = X^T (d0, B), K = B)
+    hipLaunchKernelGGL(tower_transpose_kernel, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, w.XT, B, d0);
+    NSVD_CHECK_LAUNCH();
+    memset(&g, 0, sizeof(g));
+    g.A = w.dY1T; g.lda = B; g.B = w.XT; g.ldb = B; g.C = grads->W1; g.ldc = d0;
+    g.M = d1; g.N = d0; g.K = B; g.S = 1;
+    return launch_gemm(g, s);
+}
+
+}  // extern "C"

@@ -502,11 +502,72 @@ def row_normalize_backward(z: torch.Tensor, dout: torch.Tensor, r_up: float, mod
     return dz
 
 
+# ------------------------------------------------------------------------------ CDK towers (Linear-BN-lrelu-Linear-BN)
+TOWER_KEYS = ("W1", "b1", "g1", "be1", "rm1", "rv1", "W2", "b2", "g2", "be2", "rm2", "rv2")
+
+
+def tower_supported(B: int, d0: int, d1: int, d2: int) -> bool:
+    return int(_lib.load().nsvd_tower_workspace_bytes(int(B), int(d0), int(d1), int(d2))) > 0
+
+
+def tower_workspace(B: int, d0: int, d1: int, d2: int, device) -> torch.Tensor:
+    n = int(_lib.load().nsvd_tower_workspace_bytes(int(B), int(d0), int(d1), int(d2)))
+    if n == 0:
+        raise NsvdError(f"tower: unsupported shape B={B}, sizes {(d0, d1, d2)} (multiples of 128, B <= 1024)")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def _tower_struct(t: dict, need_running: bool) -> "_lib.TowerParams":
+    p = _lib.TowerParams()
+    for k in TOWER_KEYS:
+        v = t.get(k)
+        if v is None:
+            if k.startswith("r") and not need_running:
+                continue
+            raise NsvdError(f"tower: tensor {k} missing")
+        setattr(p, k, _ptr(v, k))
+    p._keepalive = dict(t)
+    return p
+
+
+def tower_forward(x: torch.Tensor, params: dict, slope: float, eps: float, momentum: float, update_running: bool,
+                  ws: torch.Tensor) -> torch.Tensor:
+    """z = BN2(Linear2(lrelu(BN1(Linear1(x))))) in training mode; params: dict over TOWER_KEYS (torch layouts)."""
+    B, d0 = x.shape
+    d1, d2 = params["W1"].shape[0], params["W2"].shape[0]
+    if tuple(params["W1"].shape) != (d1, d0) or tuple(params["W2"].shape) != (d2, d1):
+        raise NsvdError("tower_forward: W1 must be (d1, d0), W2 (d2, d1)")
+    for k, n in (("b1", d1), ("g1", d1), ("be1", d1), ("b2", d2), ("g2", d2), ("be2", d2)):
+        if params[k].numel() != n:
+            raise NsvdError(f"tower_forward: {k} must have {n} elements")
+    z = torch.empty((B, d2), dtype=torch.float32, device=x.device)
+    p = _tower_struct(params, bool(update_running))
+    rc = _lib.load().nsvd_tower_forward(_ptr(x, "x"), C.byref(p), B, d0, d1, d2, float(slope), float(eps),
+                                        float(momentum), int(bool(update_running)), _ptr(z, "z"), ws.data_ptr(),
+                                        ws.numel(), _stream())
+    check(rc, "nsvd_tower_forward")
+    return z
+
+
+def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float, ws: torch.Tensor) -> dict:
+    """gradients of sum(dz * z) w.r.t. W1, b1, g1, be1, W2, b2, g2, be2 (same workspace as the forward call)."""
+    B, d0 = x.shape
+    d1, d2 = params["W1"].shape[0], params["W2"].shape[0]
+    if tuple(dz.shape) != (B, d2):
+        raise NsvdError("tower_backward: dz must be (B, d2)")
+    grads = {k: torch.empty_like(params[k]) for k in TOWER_KEYS if not k.startswith("r")}
+    p, g = _tower_struct(params, False), _tower_struct(grads, False)
+    rc = _lib.load().nsvd_tower_backward(_ptr(x, "x"), C.byref(p), _ptr(dz, "dz"), B, d0, d1, d2, float(slope),
+                                         C.byref(g), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "nsvd_tower_backward")
+    return grads
+
+
 # every wrapper that launches kernels runs on the device of its tensors (see _on_tensor_device)
 for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
               "evd_partial", "operator_backward_evd", "operator_backward_evd_step", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
-              "row_normalize_backward"):
+              "row_normalize_backward", "tower_forward", "tower_backward"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

@@ -504,6 +504,38 @@ def kernel_loss_and_grads(x, p: Params, kernel_fn, v, M, split_batch: bool, hard
     return dict(loss=loss, f=f1, Kf=Kf1, grads=grads)
 
 
+# ----------------------------------------------------------------------------- CDK tower
+def tower_forward_backward(x, P, dz, slope, eps=1e-5):
+    """Linear -> BatchNorm1d (training) -> LeakyReLU(slope) -> Linear -> BatchNorm1d (training) and the hand-derived
+    gradient of sum(dz * z): what get_mlp(sizes=[d0, d1, d2], bias=True, nonlinearity='lrelu<slope>', use_bn=True)
+    (reference examples/models/mlp.py:129-164) computes with autograd. P: dict W1 (d1, d0), b1, g1, be1 (d1), W2
+    (d2, d1), b2, g2, be2 (d2) in torch's layouts. Pinned by tests/golden/tower.npz.
+    Returns z, dict of gradients, and the batch statistics (mean, biased var, unbiased var) of both BatchNorms."""
+    B = x.shape[0]
+
+    def bn(y, g, be):
+        mu = y.mean(0)
+        var = ((y - mu) ** 2).mean(0)             # biased: what the normalisation uses
+        inv = 1.0 / torch.sqrt(var + eps)
+        yh = (y - mu) * inv
+        return yh * g + be, yh, inv, (mu, var, var * B / (B - 1))
+
+    def bn_back(dh, yh, inv, g):
+        return g * inv * (dh - dh.mean(0) - yh * (dh * yh).mean(0)), (dh * yh).sum(0), dh.sum(0)
+
+    y1 = x @ P["W1"].T + P["b1"]
+    h1, yh1, inv1, st1 = bn(y1, P["g1"], P["be1"])
+    a1 = torch.where(h1 > 0, h1, slope * h1)
+    y2 = a1 @ P["W2"].T + P["b2"]
+    z, yh2, inv2, st2 = bn(y2, P["g2"], P["be2"])
+    dy2, dg2, dbe2 = bn_back(dz, yh2, inv2, P["g2"])
+    da1 = dy2 @ P["W2"]
+    dh1 = da1 * torch.where(h1 > 0, torch.ones_like(h1), torch.full_like(h1, slope))
+    dy1, dg1, dbe1 = bn_back(dh1, yh1, inv1, P["g1"])
+    grads = dict(W1=dy1.T @ x, b1=dy1.sum(0), g1=dg1, be1=dbe1, W2=dy2.T @ a1, b2=dy2.sum(0), g2=dg2, be2=dbe2)
+    return z, grads, (st1, st2)
+
+
 # ----------------------------------------------------------------------------- optimiser
 def cosine_lr(base_lr, t, T, eta_min=0.0):
     """closed form of torch.optim.lr_scheduler.CosineAnnealingLR after t scheduler steps

@@ -24,6 +24,22 @@ def step(amp):
         scaler.scale(loss).backward(); scaler.step(opt); scaler.update()
     else:
         loss.backward(); opt.step()
+import torch.nn as _nn
+from neural_svd_amd.cdk import TowerSequential
+def tower_time(lib):
+    """forward + backward of ONE tower alone: HIP tower kernels vs torch's modules on the same weights"""
+    t = model.backbones["x"]
+    g = torch.randn(1024, 512, device=dev)
+    f = (lambda: _nn.Sequential.forward(t, x)) if lib else (lambda: t(x))
+    for _ in range(10):
+        opt.zero_grad(set_to_none=True); (f() * g).sum().backward()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100):
+        opt.zero_grad(set_to_none=True); (f() * g).sum().backward()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 100
+print(f"one tower forward + backward: HIP kernels {tower_time(False) * 1e6:.0f} us, torch modules (library GEMMs) {tower_time(True) * 1e6:.0f} us "
+      f"(43 GFLOP of contractions: {43.0 / tower_time(False) / 1e3:.1f} TFLOP/s on the HIP path)")
 for amp in (False, True):
     for _ in range(10): step(amp)
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--laplacian-eps", type=float, default=0.01)
     ap.add_argument("--sequential", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--eval-exact", action="store_true",
+                    help="also evaluate the trained weights with the exact Laplacian (separates the finite-difference "
+                         "noise of the EVALUATION from what training converged to)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -77,6 +80,15 @@ def main():
                  loss=float(tr.loss[0]), eigvals=[round(float(v), 4) for v in ev],
                  rel_err_mean=float(rel.mean()), rel_err_max=float(rel.max()), rel_err_mean_sorted=float(rel_sorted.mean()),
                  rel_err_first4=float(rel[:4].mean()), abs_err_zero_modes=[round(float(v), 4) for v in (ev - gt)[~nz]])
+        if a.eval_exact and a.laplacian_eps > 0:
+            trained = tr.problem
+            tr.problem = H.make_problem(trained.potential, trained.charge_or_k, 0.0, trained.op_scale, trained.op_shift,
+                                        trained.sigma)
+            evx = tr.spectrum(lim, 0.1, use_ema=True)["eigvals"].numpy()
+            tr.problem = trained
+            relx = (np.abs(evx - gt) / np.where(nz, np.abs(gt), 1.0))[nz]
+            e.update(exact_eval_eigvals=[round(float(v), 4) for v in evx], exact_eval_rel_err_mean=float(relx.mean()),
+                     exact_eval_rel_err_max=float(relx.max()))
         rec["evals"].append(e)
         print(json.dumps(e), flush=True)
     if a.out:

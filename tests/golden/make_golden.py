@@ -418,6 +418,47 @@ def golden_kernel_loss(out):
         out[f"{name}_cfg"] = np.array(repr(cfg))
 
 
+def golden_tower(out):
+    """The CDK script's tower (main_sketchy.py:107-116): get_mlp(sizes=[d0, d1, d2], bias=True, nonlinearity='lrelu0.2',
+    use_bn=True) of examples/models/mlp.py:129-164 in training mode: output, autograd gradients of sum(dz * z) and the
+    BatchNorm running statistics after the step, float64 and float32. Case tb (multiples of 128: what the HIP tower
+    kernels take) stores no parameters: torch.manual_seed(seed) + the same constructor calls reproduce them."""
+    from examples.models.mlp import get_mlp
+    for name, (sizes, B, slope, seed) in dict(ta=([8, 12, 6], 10, 0.2, 31), tb=([128, 256, 128], 128, 0.2, 32),
+                                              tc=([16, 24, 8], 20, 0.0, 33)).items():
+        g = torch.Generator().manual_seed(1000 + seed)
+        x64 = torch.randn(B, sizes[0], generator=g, dtype=torch.float64)
+        dz64 = torch.randn(B, sizes[2], generator=g, dtype=torch.float64)
+        out[f"{name}_x"], out[f"{name}_dz"] = x64.numpy(), dz64.numpy()
+        out[f"{name}_cfg"] = np.array([B, sizes[0], sizes[1], sizes[2], seed])
+        out[f"{name}_slope"] = np.array(slope)
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            torch.manual_seed(seed)
+            m = get_mlp(sizes=sizes, bias=True, nonlinearity="relu" if slope == 0.0 else f"lrelu{slope}", use_bn=True)
+            with torch.no_grad():  # non-trivial BatchNorm affine parameters (the constructor's are 1 and 0)
+                gg = torch.Generator().manual_seed(2000 + seed)
+                for k in (1, 4):
+                    m[k].weight.copy_(1.0 + 0.3 * torch.randn(m[k].weight.shape, generator=gg))
+                    m[k].bias.copy_(0.2 * torch.randn(m[k].bias.shape, generator=gg))
+            if tag == "f64" and name != "tb":
+                for k, v in m.state_dict().items():
+                    out[f"{name}_param0_{k}"] = v.detach().double().numpy()
+            m = m.to(dt).train()
+            z = m(x64.to(dt))
+            (z * dz64.to(dt)).sum().backward()
+            q = f"{name}_{tag}_"
+            out[q + "z"] = np64(z)
+            for k, v in m.named_parameters():
+                gr = np64(v.grad)
+                if name == "tb" and tag == "f32":
+                    out[q + f"gradnorm_{k}"] = np.array(np.linalg.norm(gr))
+                else:
+                    out[q + f"grad_{k}"] = gr
+            for k in (1, 4):
+                out[q + f"running_mean_{k}"] = np64(m[k].running_mean)
+                out[q + f"running_var_{k}"] = np64(m[k].running_var)
+
+
 def golden_ground_truth(out):
     out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
     out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
@@ -433,6 +474,12 @@ def main():
         np.savez_compressed(os.path.join(HERE, "normalize.npz"), **o)
         print("normalize", os.path.getsize(os.path.join(HERE, "normalize.npz")) // 1024, "KiB")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "tower":
+        o = {}
+        golden_tower(o)
+        np.savez_compressed(os.path.join(HERE, "tower.npz"), **o)
+        print("tower", os.path.getsize(os.path.join(HERE, "tower.npz")) // 1024, "KiB")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "kernel_loss":
         o = {}
         golden_kernel_loss(o)
@@ -445,6 +492,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, "svd_loss.npz"), **o)
         print("svd_loss", os.path.getsize(os.path.join(HERE, "svd_loss.npz")) // 1024, "KiB")
         return
+    o = {}
+    golden_tower(o)
+    np.savez_compressed(os.path.join(HERE, "tower.npz"), **o)
     o = {}
     golden_kernel_loss(o)
     np.savez_compressed(os.path.join(HERE, "kernel_loss.npz"), **o)
@@ -513,7 +563,7 @@ def main():
                  fourier_scale=1.0, sampling_scale=4.0, batch_size=7, operator_scale=1.0, operator_shift=16.0,
                  apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=0, seed=9)
     np.savez_compressed(os.path.join(HERE, "model_exact.npz"), **o)
-    for fn in ("kernel_loss", "masks", "evd_loss", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
+    for fn in ("tower", "kernel_loss", "masks", "evd_loss", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

@@ -328,3 +328,33 @@ def test_kernel_loss_matches_reference(case, split):
         else:
             assert abs(float(g.norm()) - float(z[q + f"gradnorm_{n}"])) < 1e-9 * float(z[q + f"gradnorm_{n}"]), n
             assert G.rel(g.reshape(-1)[::61], z[q + f"gradsample_{n}"]) < 1e-9, n
+
+
+# ----------------------------------------------------------------------------- CDK tower
+def _tower_params_from_golden(z, case):
+    g = lambda k: torch.tensor(z[f"{case}_param0_{k}"])  # noqa: E731
+    return dict(W1=g("0.weight"), b1=g("0.bias"), g1=g("1.weight"), be1=g("1.bias"), W2=g("3.weight"),
+                b2=g("3.bias"), g2=g("4.weight"), be2=g("4.bias"))
+
+
+@pytest.mark.parametrize("case", ["ta", "tc"])
+def test_tower_matches_reference(case):
+    """oracle tower_forward_backward vs the reference's get_mlp tower (examples/models/mlp.py:129-164) in training mode:
+    output, every parameter gradient, and the BatchNorm running statistics after one step."""
+    z = G.load("tower")
+    P = _tower_params_from_golden(z, case)
+    x, dz, slope = torch.tensor(z[f"{case}_x"]), torch.tensor(z[f"{case}_dz"]), float(z[f"{case}_slope"])
+    out, grads, (st1, st2) = O.tower_forward_backward(x, P, dz, slope)
+    q = f"{case}_f64_"
+    assert G.rel(out, z[q + "z"]) < 1e-12
+    names = {"W1": "0.weight", "b1": "0.bias", "g1": "1.weight", "be1": "1.bias", "W2": "3.weight", "b2": "3.bias",
+             "g2": "4.weight", "be2": "4.bias"}
+    for k, n in names.items():
+        want = z[q + f"grad_{n}"]
+        if k in ("b1", "b2"):  # a bias in front of a BatchNorm has a vanishing gradient: compare absolutely
+            assert np.abs(grads[k].numpy() - want).max() < 1e-12 * max(1.0, float(np.abs(z[q + "grad_0.weight"]).max()))
+        else:
+            assert G.rel(grads[k], want) < 1e-11, k
+    for st, k in ((st1, 1), (st2, 4)):  # running = 0.9 * init + 0.1 * batch (init: mean 0, var 1), unbiased variance
+        assert G.rel(0.1 * st[0], z[q + f"running_mean_{k}"]) < 1e-12
+        assert G.rel(0.9 + 0.1 * st[2], z[q + f"running_var_{k}"]) < 1e-12
