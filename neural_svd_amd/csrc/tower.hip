@@ -18,7 +18,7 @@
 //             dW1 = dY1^T X               A = dY1^T (d1, B)   B = X^T (d0, B)          K = B    (X^T: transpose kernel)
 // BatchNorm is training-mode torch.nn.BatchNorm1d: biased batch variance for the normalisation, unbiased for the
 // running estimate, momentum update of running_mean / running_var (eps 1e-5, momentum 0.1 by default).
-// Shapes: B, d0, d1, d2 multiples of 128, B <= 1024 (a BatchNorm strip of 32 columns x B rows lives in LDS).
+// Shapes: B, d0, d1, d2 multiples of 128, B <= 1024 (a BatchNorm strip's rows live in the registers of one workgroup).
 #include "nsvd_common.h"
 #include "tile128_nt.h"
 
@@ -91,14 +91,12 @@ __global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm strips
-// One workgroup = 32 columns x all B rows (B <= 1024: 132 KB of LDS), 256 threads: thread t owns the four columns
-// 4 (t & 7).. of rows (t >> 3) + 32 k: every global access is a 16-byte load / store of a 128-byte row segment, eight
-// rows in flight per thread (as 4-byte accesses in a rolled loop the forward strip of 1024 x 8192 took 330 us).
-// Column statistics in a fixed order: 32 row groups per column, combined in LDS.
-constexpr int STRIP = 32;
-constexpr int STRIP_LD = STRIP + 1;
-constexpr int STRIP_RG = 32;  // row groups
-
+// One workgroup = STRIP columns x all B rows, held in REGISTERS: thread t owns the four columns 4 (t % CG).. of rows
+// (t / CG) + RG k, k < B / RG (CG = STRIP / 4 column groups, RG = 256 / CG row groups; B <= 1024 gives at most 16 rows
+// of 4 floats per thread). Every row load of the strip is issued before the first is consumed (128 KB in flight per
+// workgroup), nothing but a transpose tile and the reduction scratch lives in LDS, so several workgroups share a CU.
+// (With the strip in LDS - 132 KB, one workgroup per CU - the 1024 x 8192 forward strip took 90 us for 96 MB.)
+// Column statistics in a fixed order: RG row groups per column, combined in LDS.
 struct BnFwd {
     const float* Y;       // (S, B, N) split-K partials of the pre-normalisation output (S = 1: the output itself)
     size_t slice_stride;
@@ -117,91 +115,98 @@ struct BnFwd {
     float eps, momentum, slope;
 };
 
-__device__ __forceinline__ void strip_put(float* strip, int r, int c0, const float4& v) {
-    float* p = strip + r * STRIP_LD + c0;
-    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-}
-__device__ __forceinline__ float4 strip_get(const float* strip, int r, int c0) {
-    const float* p = strip + r * STRIP_LD + c0;
-    return make_float4(p[0], p[1], p[2], p[3]);
-}
-// rows r4 .. r4 + 3 of column `col` -> one 16-byte store of the transposed copy
-__device__ __forceinline__ void strip_store_transposed(const float* strip, float* outT, int n0, int B, int tid) {
-    const int col = tid >> 3;
-    for (int r4 = 4 * (tid & 7); r4 < B; r4 += 32) {
-        const float4 v = make_float4(strip[r4 * STRIP_LD + col], strip[(r4 + 1) * STRIP_LD + col],
-                                     strip[(r4 + 2) * STRIP_LD + col], strip[(r4 + 3) * STRIP_LD + col]);
-        *reinterpret_cast<float4*>(outT + (size_t)(n0 + col) * B + r4) = v;
-    }
-}
-// per-column totals of the threads' 4-column partials: red[rg][c], then 32 threads add the row groups in order
-__device__ __forceinline__ void strip_reduce(float (*red)[STRIP], const float4& part, float* total, int tid) {
-    const int c0 = 4 * (tid & 7), rg = tid >> 3;
-    red[rg][c0] = part.x; red[rg][c0 + 1] = part.y; red[rg][c0 + 2] = part.z; red[rg][c0 + 3] = part.w;
+constexpr int BN_MAXR = 16;  // rows per thread: B / RG with B <= 1024 and RG >= 64
+
+template <int STRIP>
+struct StripGeom {
+    static constexpr int CG = STRIP / 4, RG = 256 / CG;
+};
+
+// per-column totals of the threads' 4-column partials: red[rg][c], then STRIP threads add the row groups in order
+template <int STRIP>
+__device__ __forceinline__ void strip_reduce(float* red, const float4& part, float* total, int tid) {
+    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG;
+    const int c0 = 4 * (tid % CG), rg = tid / CG;
+    float* p = red + rg * STRIP + c0;
+    p[0] = part.x; p[1] = part.y; p[2] = part.z; p[3] = part.w;
     __syncthreads();
     if (tid < STRIP) {
         float t = 0.f;
-        for (int k = 0; k < STRIP_RG; ++k) t += red[k][tid];
+        for (int k = 0; k < RG; ++k) t += red[k * STRIP + tid];
         total[tid] = t;
     }
     __syncthreads();
 }
 
+// rows {rg + RG k} of the strip (one float4 per thread) -> the transposed copy, through a [RG][STRIP + 1] LDS tile:
+// thread t then owns column t / (RG / 4) and rows 4 (t % (RG / 4)).. of the batch: one 16-byte store
+template <int STRIP>
+__device__ __forceinline__ void strip_transpose_out(float* tile, const float4& v, float* outT, int n0, int B, int k,
+                                                    int tid) {
+    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG, LD = STRIP + 1;
+    const int c0 = 4 * (tid % CG), rg = tid / CG;
+    __syncthreads();  // the previous batch has been read out
+    float* p = tile + rg * LD + c0;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    __syncthreads();
+    const int col = tid / (RG / 4), r4 = 4 * (tid % (RG / 4));
+    const float4 o = make_float4(tile[r4 * LD + col], tile[(r4 + 1) * LD + col], tile[(r4 + 2) * LD + col],
+                                 tile[(r4 + 3) * LD + col]);
+    *reinterpret_cast<float4*>(outT + (size_t)(n0 + col) * B + (size_t)RG * k + r4) = o;
+}
+
+template <int STRIP>
 __global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
-    extern __shared__ __attribute__((aligned(16))) float strip[];  // [B][STRIP_LD]
-    __shared__ float red[STRIP_RG][STRIP];
+    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG;
+    __shared__ float red[RG * STRIP];
+    __shared__ float tile[RG * (STRIP + 1)];
     __shared__ float csum[STRIP], cmean[STRIP], cinv[STRIP];
     const int tid = threadIdx.x;
-    const int c0 = 4 * (tid & 7), rg = tid >> 3;
+    const int c0 = 4 * (tid % CG), rg = tid / CG;
     const int n0 = blockIdx.x * STRIP;
+    const int nr = a.B / RG;
     const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + n0 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // rows in batches of eight per thread: the eight (S x) loads are issued before the first one is consumed (the
-    // optional Ysum store may alias Y as far as the compiler knows, which would serialise a rolled loop)
-    for (int rb = rg; rb < a.B; rb += 8 * STRIP_RG) {
-        float4 v[8];
+    float4 v[BN_MAXR];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = rb + k * STRIP_RG;
-            v[k] = bv;
-            if (r < a.B) {
-                for (int s = 0; s < a.S; ++s) {
-                    const float4 t =
-                        *reinterpret_cast<const float4*>(a.Y + (size_t)s * a.slice_stride + (size_t)r * a.N + n0 + c0);
-                    v[k].x += t.x; v[k].y += t.y; v[k].z += t.z; v[k].w += t.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = rb + k * STRIP_RG;
-            if (r < a.B) {
-                strip_put(strip, r, c0, v[k]);
-                s1.x += v[k].x; s1.y += v[k].y; s1.z += v[k].z; s1.w += v[k].w;
-                if (a.Ysum) *reinterpret_cast<float4*>(a.Ysum + (size_t)r * a.N + n0 + c0) = v[k];
+    for (int k = 0; k < BN_MAXR; ++k) {
+        v[k] = bv;
+        if (k < nr) {
+            const float* src = a.Y + (size_t)(rg + RG * k) * a.N + n0 + c0;
+            for (int s = 0; s < a.S; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (size_t)s * a.slice_stride);
+                v[k].x += t.x; v[k].y += t.y; v[k].z += t.z; v[k].w += t.w;
             }
         }
     }
-    strip_reduce(red, s1, csum, tid);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < BN_MAXR; ++k) {
+        if (k < nr) {
+            s1.x += v[k].x; s1.y += v[k].y; s1.z += v[k].z; s1.w += v[k].w;
+            if (a.Ysum) *reinterpret_cast<float4*>(a.Ysum + (size_t)(rg + RG * k) * a.N + n0 + c0) = v[k];
+        }
+    }
+    strip_reduce<STRIP>(red, s1, csum, tid);
     if (tid < STRIP) cmean[tid] = csum[tid] / (float)a.B;
     __syncthreads();
     const float4 mu = make_float4(cmean[c0], cmean[c0 + 1], cmean[c0 + 2], cmean[c0 + 3]);
     float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int r = rg; r < a.B; r += STRIP_RG) {  // two-pass variance: mean first, then the squared deviations
-        const float4 v = strip_get(strip, r, c0);
-        const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
-        s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+#pragma unroll
+    for (int k = 0; k < BN_MAXR; ++k) {  // two-pass variance: mean first, then the squared deviations
+        if (k < nr) {
+            const float dx = v[k].x - mu.x, dy = v[k].y - mu.y, dz = v[k].z - mu.z, dw = v[k].w - mu.w;
+            s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+        }
     }
-    strip_reduce(red, s2, csum, tid);
+    strip_reduce<STRIP>(red, s2, csum, tid);
     if (tid < STRIP) {
-        const float v = csum[tid];
-        const float inv = 1.0f / sqrtf(v / (float)a.B + a.eps);
+        const float var = csum[tid];
+        const float inv = 1.0f / sqrtf(var / (float)a.B + a.eps);
         cinv[tid] = inv;
         a.mean[n0 + tid] = cmean[tid];
         a.invstd[n0 + tid] = inv;
         if (a.running_mean) {
-            const float unb = v / (float)(a.B - 1);
+            const float unb = var / (float)(a.B - 1);
             a.running_mean[n0 + tid] = (1.f - a.momentum) * a.running_mean[n0 + tid] + a.momentum * cmean[tid];
             a.running_var[n0 + tid] = (1.f - a.momentum) * a.running_var[n0 + tid] + a.momentum * unb;
         }
@@ -210,20 +215,26 @@ __global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
     const float4 inv = make_float4(cinv[c0], cinv[c0 + 1], cinv[c0 + 2], cinv[c0 + 3]);
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + n0 + c0);
     const float4 be = *reinterpret_cast<const float4*>(a.beta + n0 + c0);
-#pragma unroll 8
-    for (int r = rg; r < a.B; r += STRIP_RG) {
-        const float4 v = strip_get(strip, r, c0);
-        float4 o;
-        o.x = fmaf((v.x - mu.x) * inv.x, ga.x, be.x); o.y = fmaf((v.y - mu.y) * inv.y, ga.y, be.y);
-        o.z = fmaf((v.z - mu.z) * inv.z, ga.z, be.z); o.w = fmaf((v.w - mu.w) * inv.w, ga.w, be.w);
-        o.x = o.x > 0.f ? o.x : a.slope * o.x; o.y = o.y > 0.f ? o.y : a.slope * o.y;
-        o.z = o.z > 0.f ? o.z : a.slope * o.z; o.w = o.w > 0.f ? o.w : a.slope * o.w;
-        *reinterpret_cast<float4*>(a.out + (size_t)r * a.N + n0 + c0) = o;
-        if (a.outT) strip_put(strip, r, c0, o);
+#pragma unroll
+    for (int k = 0; k < BN_MAXR; ++k) {
+        if (k < nr) {
+            float4 o;
+            o.x = fmaf((v[k].x - mu.x) * inv.x, ga.x, be.x); o.y = fmaf((v[k].y - mu.y) * inv.y, ga.y, be.y);
+            o.z = fmaf((v[k].z - mu.z) * inv.z, ga.z, be.z); o.w = fmaf((v[k].w - mu.w) * inv.w, ga.w, be.w);
+            o.x = o.x > 0.f ? o.x : a.slope * o.x; o.y = o.y > 0.f ? o.y : a.slope * o.y;
+            o.z = o.z > 0.f ? o.z : a.slope * o.z; o.w = o.w > 0.f ? o.w : a.slope * o.w;
+            *reinterpret_cast<float4*>(a.out + (size_t)(rg + RG * k) * a.N + n0 + c0) = o;
+            v[k] = o;
+        }
     }
     if (a.outT) {
-        __syncthreads();
-        strip_store_transposed(strip, a.outT, n0, a.B, tid);
+        for (int k = 0; k < nr; ++k) {
+            float4 o = v[0];
+#pragma unroll
+            for (int j = 1; j < BN_MAXR; ++j)
+                if (j == k) o = v[j];  // (a run-time index into the register array would put it in scratch)
+            strip_transpose_out<STRIP>(tile, o, a.outT, n0, a.B, k, tid);
+        }
     }
 }
 
@@ -243,108 +254,105 @@ struct BnBwd {
     float slope;
 };
 
+template <int STRIP>
 __global__ void __launch_bounds__(256) tower_bn_backward_kernel(BnBwd a) {
-    extern __shared__ __attribute__((aligned(16))) float strip[];  // [B][STRIP_LD]: dh, then dY
-    __shared__ float red[STRIP_RG][STRIP];
+    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG;
+    __shared__ float red[RG * STRIP];
+    __shared__ float tile[RG * (STRIP + 1)];
     __shared__ float c1[STRIP], c2[STRIP], c3[STRIP];
     const int tid = threadIdx.x;
-    const int c0 = 4 * (tid & 7), rg = tid >> 3;
+    const int c0 = 4 * (tid % CG), rg = tid / CG;
     const int n0 = blockIdx.x * STRIP;
+    const int nr = a.B / RG;
     const float4 mu = *reinterpret_cast<const float4*>(a.mean + n0 + c0);
     const float4 inv = *reinterpret_cast<const float4*>(a.invstd + n0 + c0);
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + n0 + c0);
     const float4 be = *reinterpret_cast<const float4*>(a.beta + n0 + c0);
-    // pass 1: dh = dout * act'(h), column sums of dh and dh * yhat
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    for (int rb = rg; rb < a.B; rb += 8 * STRIP_RG) {
-        float4 yv[8], dv[8];
+    float4 yh[BN_MAXR], dh[BN_MAXR];  // normalised pre-activation, gradient behind the activation
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {  // sixteen loads in flight per thread
-            const int r = rb + k * STRIP_RG;
-            yv[k] = dv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < a.B) {
-                yv[k] = *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.N + n0 + c0);
-                dv[k] = *reinterpret_cast<const float4*>(a.dout + (size_t)r * a.N + n0 + c0);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = rb + k * STRIP_RG;
-            if (r >= a.B) continue;
-            const float4 y = yv[k], d = dv[k];
-            const float yx = (y.x - mu.x) * inv.x, yy = (y.y - mu.y) * inv.y, yz = (y.z - mu.z) * inv.z,
-                        yw = (y.w - mu.w) * inv.w;
-            float4 dh;
-            dh.x = d.x * (fmaf(yx, ga.x, be.x) > 0.f ? 1.f : a.slope);
-            dh.y = d.y * (fmaf(yy, ga.y, be.y) > 0.f ? 1.f : a.slope);
-            dh.z = d.z * (fmaf(yz, ga.z, be.z) > 0.f ? 1.f : a.slope);
-            dh.w = d.w * (fmaf(yw, ga.w, be.w) > 0.f ? 1.f : a.slope);
-            strip_put(strip, r, c0, dh);
-            s1.x += dh.x; s1.y += dh.y; s1.z += dh.z; s1.w += dh.w;
-            s2.x = fmaf(dh.x, yx, s2.x); s2.y = fmaf(dh.y, yy, s2.y); s2.z = fmaf(dh.z, yz, s2.z);
-            s2.w = fmaf(dh.w, yw, s2.w);
+    for (int k = 0; k < BN_MAXR; ++k) {
+        yh[k] = dh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < nr) {
+            yh[k] = *reinterpret_cast<const float4*>(a.Y + (size_t)(rg + RG * k) * a.N + n0 + c0);
+            dh[k] = *reinterpret_cast<const float4*>(a.dout + (size_t)(rg + RG * k) * a.N + n0 + c0);
         }
     }
-    strip_reduce(red, s1, c1, tid);
-    strip_reduce(red, s2, c2, tid);
+    // dh = dout * act'(h), column sums of dh and dh * yhat
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int k = 0; k < BN_MAXR; ++k) {
+        if (k < nr) {
+            float4 y = yh[k];
+            y.x = (y.x - mu.x) * inv.x; y.y = (y.y - mu.y) * inv.y; y.z = (y.z - mu.z) * inv.z; y.w = (y.w - mu.w) * inv.w;
+            float4 d = dh[k];
+            d.x *= fmaf(y.x, ga.x, be.x) > 0.f ? 1.f : a.slope;
+            d.y *= fmaf(y.y, ga.y, be.y) > 0.f ? 1.f : a.slope;
+            d.z *= fmaf(y.z, ga.z, be.z) > 0.f ? 1.f : a.slope;
+            d.w *= fmaf(y.w, ga.w, be.w) > 0.f ? 1.f : a.slope;
+            yh[k] = y;
+            dh[k] = d;
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = fmaf(d.x, y.x, s2.x); s2.y = fmaf(d.y, y.y, s2.y); s2.z = fmaf(d.z, y.z, s2.z); s2.w = fmaf(d.w, y.w, s2.w);
+        }
+    }
+    strip_reduce<STRIP>(red, s1, c1, tid);
+    strip_reduce<STRIP>(red, s2, c2, tid);
     if (tid < STRIP) {
         a.dbeta[n0 + tid] = c1[tid];
         a.dgamma[n0 + tid] = c2[tid];
     }
-    // pass 2: dY = gamma * invstd * (dh - mean(dh) - yhat * mean(dh * yhat))
+    // dY = gamma * invstd * (dh - mean(dh) - yhat * mean(dh * yhat))
     const float rB = 1.0f / (float)a.B;
     const float4 m1 = make_float4(c1[c0] * rB, c1[c0 + 1] * rB, c1[c0 + 2] * rB, c1[c0 + 3] * rB);
     const float4 m2 = make_float4(c2[c0] * rB, c2[c0 + 1] * rB, c2[c0 + 2] * rB, c2[c0 + 3] * rB);
     float4 sb = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int rb = rg; rb < a.B; rb += 8 * STRIP_RG) {
-        float4 yv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = rb + k * STRIP_RG;
-            yv[k] = r < a.B ? *reinterpret_cast<const float4*>(a.Y + (size_t)r * a.N + n0 + c0)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = rb + k * STRIP_RG;
-            if (r >= a.B) continue;
-            const float4 y = yv[k];
-            const float4 dh = strip_get(strip, r, c0);
+    for (int k = 0; k < BN_MAXR; ++k) {
+        if (k < nr) {
             float4 dy;
-            dy.x = ga.x * inv.x * (dh.x - m1.x - (y.x - mu.x) * inv.x * m2.x);
-            dy.y = ga.y * inv.y * (dh.y - m1.y - (y.y - mu.y) * inv.y * m2.y);
-            dy.z = ga.z * inv.z * (dh.z - m1.z - (y.z - mu.z) * inv.z * m2.z);
-            dy.w = ga.w * inv.w * (dh.w - m1.w - (y.w - mu.w) * inv.w * m2.w);
-            strip_put(strip, r, c0, dy);
+            dy.x = ga.x * inv.x * (dh[k].x - m1.x - yh[k].x * m2.x);
+            dy.y = ga.y * inv.y * (dh[k].y - m1.y - yh[k].y * m2.y);
+            dy.z = ga.z * inv.z * (dh[k].z - m1.z - yh[k].z * m2.z);
+            dy.w = ga.w * inv.w * (dh[k].w - m1.w - yh[k].w * m2.w);
+            dh[k] = dy;
             sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
-            if (a.dY) *reinterpret_cast<float4*>(a.dY + (size_t)r * a.N + n0 + c0) = dy;
+            if (a.dY) *reinterpret_cast<float4*>(a.dY + (size_t)(rg + RG * k) * a.N + n0 + c0) = dy;
         }
     }
-    strip_reduce(red, sb, c3, tid);  // (also the barrier in front of the transposed read-out)
+    strip_reduce<STRIP>(red, sb, c3, tid);
     if (a.dbias && tid < STRIP) a.dbias[n0 + tid] = c3[tid];
-    if (a.dYT) strip_store_transposed(strip, a.dYT, n0, a.B, tid);
+    if (a.dYT) {
+        for (int k = 0; k < nr; ++k) {
+            float4 o = dh[0];
+#pragma unroll
+            for (int j = 1; j < BN_MAXR; ++j)
+                if (j == k) o = dh[j];
+            strip_transpose_out<STRIP>(tile, o, a.dYT, n0, a.B, k, tid);
+        }
+    }
+}
+
+// 16-column strips for wide layers (two workgroups per CU at 8192 columns), 8-column strips below 4096 columns (a
+// 512-wide layer then spreads over 64 workgroups instead of 16)
+inline int launch_bn_forward(const BnFwd& f, hipStream_t s) {
+    if (f.B % 128 || f.B > 1024 || f.N % 16) return NSVD_EINVAL;
+    if (f.N >= 4096) hipLaunchKernelGGL(tower_bn_forward_kernel<16>, dim3(f.N / 16), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL(tower_bn_forward_kernel<8>, dim3(f.N / 8), dim3(256), 0, s, f);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+inline int launch_bn_backward(const BnBwd& b, hipStream_t s) {
+    if (b.B % 128 || b.B > 1024 || b.N % 16) return NSVD_EINVAL;
+    if (b.N >= 4096) hipLaunchKernelGGL(tower_bn_backward_kernel<16>, dim3(b.N / 16), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(tower_bn_backward_kernel<8>, dim3(b.N / 8), dim3(256), 0, s, b);
+    NSVD_CHECK_LAUNCH();
+    return 0;
 }
 
 inline int launch_gemm(const GemmNT& g, hipStream_t s) {
     if (g.M % 128 || g.N % 128 || g.S < 1 || g.K % (32 * g.S)) return NSVD_EINVAL;
     hipLaunchKernelGGL(tower_gemm_nt_kernel, dim3((g.M / 128) * (g.N / 128) * g.S), dim3(256), 0, s, g);
     NSVD_CHECK_LAUNCH();
-    return 0;
-}
-
-inline size_t strip_lds(int B) { return (size_t)B * STRIP_LD * sizeof(float); }
-
-inline int ensure_strip_attr() {
-    static bool done = false;
-    if (done) return 0;
-    const int bytes = (int)strip_lds(1024);
-    hipError_t e = hipFuncSetAttribute((const void*)tower_bn_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       bytes);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)tower_bn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                bytes);
-    if (e != hipSuccess) return -(int)e;
-    done = true;
     return 0;
 }
 
@@ -415,8 +423,7 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
     const TowerWs w = carve_tower(B, d0, d1, d2, ws);
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    int rc = ensure_strip_attr();
-    if (rc) return rc;
+    int rc = 0;
     // Y1 = X W1^T + b1
     GemmNT g;
     memset(&g, 0, sizeof(g));
@@ -431,8 +438,8 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
     f.running_mean = update_running ? p->rm1 : nullptr; f.running_var = update_running ? p->rv1 : nullptr;
     f.mean = w.mean1; f.invstd = w.inv1; f.out = w.A1; f.outT = w.A1T; f.B = B; f.N = d1;
     f.eps = eps; f.momentum = momentum; f.slope = slope;
-    hipLaunchKernelGGL(tower_bn_forward_kernel, dim3(d1 / STRIP), dim3(256), strip_lds(B), s, f);
-    NSVD_CHECK_LAUNCH();
+    rc = launch_bn_forward(f, s);
+    if (rc) return rc;
     // Y2 = A1 W2^T (+ b2 in the strip kernel), split-K partials
     const int S = fwd2_slices(B, d1, d2);
     memset(&g, 0, sizeof(g));
@@ -446,9 +453,7 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
     f.running_mean = update_running ? p->rm2 : nullptr; f.running_var = update_running ? p->rv2 : nullptr;
     f.mean = w.mean2; f.invstd = w.inv2; f.Ysum = w.Y2; f.out = z; f.outT = nullptr; f.B = B; f.N = d2;
     f.eps = eps; f.momentum = momentum; f.slope = 1.0f;
-    hipLaunchKernelGGL(tower_bn_forward_kernel, dim3(d2 / STRIP), dim3(256), strip_lds(B), s, f);
-    NSVD_CHECK_LAUNCH();
-    return 0;
+    return launch_bn_forward(f, s);
 }
 
 int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1, int d2,
@@ -459,16 +464,15 @@ int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float*
     const TowerWs w = carve_tower(B, d0, d1, d2, ws);
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    int rc = ensure_strip_attr();
-    if (rc) return rc;
+    int rc = 0;
     // dY2 = BN2'(dZ), dY2^T, db2 = column sums of dY2
     BnBwd b;
     memset(&b, 0, sizeof(b));
     b.dout = dz; b.Y = w.Y2; b.mean = w.mean2; b.invstd = w.inv2; b.gamma = p->g2; b.beta = p->be2;
     b.dY = w.dY2; b.dYT = w.dY2T; b.dgamma = grads->g2; b.dbeta = grads->be2; b.dbias = grads->b2;
     b.B = B; b.N = d2; b.slope = 1.0f;
-    hipLaunchKernelGGL(tower_bn_backward_kernel, dim3(d2 / STRIP), dim3(256), strip_lds(B), s, b);
-    NSVD_CHECK_LAUNCH();
+    rc = launch_bn_backward(b, s);
+    if (rc) return rc;
     // dW2 = dY2^T A1  (A = dY2^T (d2, B), B = A1^T (d1, B), K = B)
     GemmNT g;
     memset(&g, 0, sizeof(g));
@@ -489,8 +493,8 @@ int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float*
     b.dout = w.dA1; b.Y = w.Y1; b.mean = w.mean1; b.invstd = w.inv1; b.gamma = p->g1; b.beta = p->be1;
     b.dY = nullptr; b.dYT = w.dY1T; b.dgamma = grads->g1; b.dbeta = grads->be1; b.dbias = grads->b1;
     b.B = B; b.N = d1; b.slope = slope;
-    hipLaunchKernelGGL(tower_bn_backward_kernel, dim3(d1 / STRIP), dim3(256), strip_lds(B), s, b);
-    NSVD_CHECK_LAUNCH();
+    rc = launch_bn_backward(b, s);
+    if (rc) return rc;
     // X^T (d0, B), then dW1 = dY1^T X  (A = dY1^T (d1, B), B = X^T (d0, B), K = B)
     hipLaunchKernelGGL(tower_transpose_kernel, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, w.XT, B, d0);
     NSVD_CHECK_LAUNCH();
