@@ -9,8 +9,9 @@
 // ever stages a strided operand:
 //   forward   Y1 = X W1^T + b1            A = X (B, d0)       B = W1 (d1, d0)          K = d0
 //             A1 = lrelu(BN1(Y1))         strip kernel: also writes A1^T (d1, B)
-//             Y2 = A1 W2^T + b2           A = A1 (B, d1)      B = W2 (d2, d1)          K = d1, split-K partials
-//             Z  = BN2(Y2)                strip kernel: sums the split-K partials, adds the bias
+//             Y2 = A1 W2^T + b2           A = A1 (B, d1)      B = W2 (d2, d1)          K = d1, split-K partials, summed
+//                                         (with the bias) by a coalesced elementwise kernel
+//             Z  = BN2(Y2)                strip kernel
 //   backward  dY2 = BN2'(dZ)              strip kernel: also writes dY2^T (d2, B), db2, dgamma2, dbeta2
 //             dW2 = dY2^T A1              A = dY2^T (d2, B)   B = A1^T (d1, B)         K = B
 //             dA1 = dY2 W2                A = dY2 (B, d2)     B = W2^T (d1, d2)        K = d2   (W2^T: transpose kernel)
@@ -88,6 +89,29 @@ __global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __res
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[(size_t)(32 * tc + y + 8 * k) * R + 32 * tr + x] = t[x][y + 8 * k];
+}
+
+// out (B, N) = bias + sum of the S split-K partial outputs, slices added in order (fully coalesced 16-byte accesses: as
+// part of the narrow BatchNorm strips each row contributed 16-32 bytes of a 128-byte line per slice)
+__global__ void __launch_bounds__(256) tower_sum_slices_kernel(const float* __restrict__ part, size_t slice_stride,
+                                                               int S, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int N, size_t n4) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n4) return;
+    const int c = (int)((q * 4) % (size_t)N);
+    float4 v = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            t[j] = s0 + j < S ? *reinterpret_cast<const float4*>(part + (size_t)(s0 + j) * slice_stride + 4 * q)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w;
+        }
+    }
+    *reinterpret_cast<float4*>(out + 4 * q) = v;
 }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm strips
@@ -172,9 +196,16 @@ __global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
         v[k] = bv;
         if (k < nr) {
             const float* src = a.Y + (size_t)(rg + RG * k) * a.N + n0 + c0;
-            for (int s = 0; s < a.S; ++s) {
-                const float4 t = *reinterpret_cast<const float4*>(src + (size_t)s * a.slice_stride);
-                v[k].x += t.x; v[k].y += t.y; v[k].z += t.z; v[k].w += t.w;
+            for (int s0 = 0; s0 < a.S; s0 += 8) {  // the slices of a row eight at a time, all loads issued first
+                float4 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    t[j] = s0 + j < a.S ? *reinterpret_cast<const float4*>(src + (size_t)(s0 + j) * a.slice_stride)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // slice order: the sum does not depend on the grouping
+                    v[k].x += t[j].x; v[k].y += t[j].y; v[k].z += t[j].z; v[k].w += t[j].w;
+                }
             }
         }
     }
@@ -332,11 +363,12 @@ __global__ void __launch_bounds__(256) tower_bn_backward_kernel(BnBwd a) {
     }
 }
 
-// 16-column strips for wide layers (two workgroups per CU at 8192 columns), 8-column strips below 4096 columns (a
-// 512-wide layer then spreads over 64 workgroups instead of 16)
+// 16-column strips for wide layers (two workgroups per CU at 8192 columns); narrower strips below 4096 columns so that
+// a 512-wide layer spreads over 128 (4 columns, batch a multiple of 256) or 64 (8 columns) workgroups instead of 32
 inline int launch_bn_forward(const BnFwd& f, hipStream_t s) {
     if (f.B % 128 || f.B > 1024 || f.N % 16) return NSVD_EINVAL;
     if (f.N >= 4096) hipLaunchKernelGGL(tower_bn_forward_kernel<16>, dim3(f.N / 16), dim3(256), 0, s, f);
+    else if (f.B % 256 == 0) hipLaunchKernelGGL(tower_bn_forward_kernel<4>, dim3(f.N / 4), dim3(256), 0, s, f);
     else hipLaunchKernelGGL(tower_bn_forward_kernel<8>, dim3(f.N / 8), dim3(256), 0, s, f);
     NSVD_CHECK_LAUNCH();
     return 0;
@@ -344,6 +376,7 @@ inline int launch_bn_forward(const BnFwd& f, hipStream_t s) {
 inline int launch_bn_backward(const BnBwd& b, hipStream_t s) {
     if (b.B % 128 || b.B > 1024 || b.N % 16) return NSVD_EINVAL;
     if (b.N >= 4096) hipLaunchKernelGGL(tower_bn_backward_kernel<16>, dim3(b.N / 16), dim3(256), 0, s, b);
+    else if (b.B % 256 == 0) hipLaunchKernelGGL(tower_bn_backward_kernel<4>, dim3(b.N / 4), dim3(256), 0, s, b);
     else hipLaunchKernelGGL(tower_bn_backward_kernel<8>, dim3(b.N / 8), dim3(256), 0, s, b);
     NSVD_CHECK_LAUNCH();
     return 0;
@@ -447,11 +480,17 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
     g.M = B; g.N = d2; g.K = d1; g.S = S;
     rc = launch_gemm(g, s);
     if (rc) return rc;
-    // Z = BN2(Y2)
+    // Y2 = b2 + sum of the partials, then Z = BN2(Y2)
+    {
+        const size_t n4 = (size_t)B * d2 / 4;
+        hipLaunchKernelGGL(tower_sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w.Y2p,
+                           (size_t)B * d2, S, p->b2, w.Y2, d2, n4);
+        NSVD_CHECK_LAUNCH();
+    }
     memset(&f, 0, sizeof(f));
-    f.Y = w.Y2p; f.slice_stride = (size_t)B * d2; f.S = S; f.bias = p->b2; f.gamma = p->g2; f.beta = p->be2;
+    f.Y = w.Y2; f.S = 1; f.gamma = p->g2; f.beta = p->be2;
     f.running_mean = update_running ? p->rm2 : nullptr; f.running_var = update_running ? p->rv2 : nullptr;
-    f.mean = w.mean2; f.invstd = w.inv2; f.Ysum = w.Y2; f.out = z; f.outT = nullptr; f.B = B; f.N = d2;
+    f.mean = w.mean2; f.invstd = w.inv2; f.out = z; f.outT = nullptr; f.B = B; f.N = d2;
     f.eps = eps; f.momentum = momentum; f.slope = 1.0f;
     return launch_bn_forward(f, s);
 }
