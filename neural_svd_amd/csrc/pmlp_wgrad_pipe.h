@@ -470,7 +470,6 @@ __global__ void __launch_bounds__(PIPE_THREADS, 1) pmlp_wgrad_pipe_kernel(WgradA
     float* hand = pipe_lds + 2 * PIPE_SBUF;
     const int tid = threadIdx.x;
     const bool mfma_wave = tid < 256;
-    const int ht = tid - 256;
     const int nItems = 2 * a.nA + 8 * (a.nlayers - 2) * a.L;
     const int stride = gridDim.x;
     PIPE_STAMP_M(0);
