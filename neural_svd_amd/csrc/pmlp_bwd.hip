@@ -4,7 +4,7 @@
 #include "evd_math.h"
 #include "opt_math.h"
 #include "tile_nt.h"
-#include "tile128_nt.h"
+#include "tile128_dma.h"
 
 using namespace nsvd_pmlp;
 
@@ -158,22 +158,22 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 // BACKWARD, part 2 (pmlp_fused_wgrad_kernel): every parameter gradient, one launch, no atomics.
 // Three kinds of workgroup, told apart by blockIdx:
 //   A  (F/128 * L):      dW_0[l][n][k] = sum_b dz_0[l][n][b] phi^T[k][b]: 128 x 128 tile, K = B, both
-//                        operands b-contiguous, 4 waves as 2 x 2 of 64 x 64; the k = 0 tile of each head
-//                        also writes db_0[l] (row sums of dz_0).
+//                        operands b-contiguous, 4 waves as 2 x 2 of 64 x 64, operands by LDS-DMA through a ring
+//                        of four half-chunk stages (tile128_dma.h).
 //   B  (4 (nh-1) L):     dW_i[l][n][k] = sum_b dz_i[l][n][b] softplus(z_{i-1}[l][k][b]), i >= 1: one
 //                        64 x 64 quadrant of the 128 x 128 result, 4 waves of one 32 x 32 tile; quadrants
 //                        in column 0 also write db_i. (128 x 64 half tiles were measured slower: fewer,
 //                        longer workgroups next to the dW_0 tiles.)
-//   C  (4 L):              dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales.
-// Timeline at cfg2 (NSVD_WG_STAMPS build, scripts/dev_wgrad_stamps.py): A tiles run their K loop in 72-77 K
-// cycles (65.5 K of MFMA issue) and end at 35 us; the B tiles, co-resident with them from t = 0 and latency-
-// bound (single accumulator chain, softplus while staging), end at 49 us; the C tiles at 36 us. With the
-// fused optimiser step the A epilogue moves 112 MB through HBM at once (20 us at 5.6 TB/s, all tiles finish
-// together) and the B tail hides under it: 60 us, vs 50 + 20.5 us for separate backward and optimiser
-// launches. Raising the B / C wave priority (s_setprio 3) shortens them but stretches the A loops by the same
-// amount: no gain.
-// K is streamed in 32-sample chunks through padded LDS tiles (rows of 36 floats, conflict-free
-// ds_read_b128 fragments), register-staged and double buffered, one barrier per chunk.
+//   C  (4 L):            dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales, and
+//                        db_0[l][n] = sum_b dz_0[l][n][b] for the same 32 rows.
+// Timeline at cfg2 (NSVD_WG_STAMPS build, scripts/dev_wgrad_stamps.py), fused optimiser step: the A tiles run
+// their K loop in 70-79 K cycles (65.5 K of MFMA issue; 69.7 K with nothing else on the chip) and their
+// epilogue - RMSprop + EMA on the tile, 112 MB through HBM for the whole kernel, the state of half of each tile
+// already in registers (fetched under the last two chunks of the loop) - in 22-26 K, ending at 38-48 us; the B
+// tiles, co-resident with them from t = 0, end at 46-49 us, the C tiles at 42-45 us; kernel 52 us in rocprof
+// (round 1: 60 us; separate backward and optimiser launches 50 + 20.5 us). Raising the B / C wave priority
+// (s_setprio 3) shortens them but stretches the A loops by the same amount, raising the A priority changes
+// nothing: no gain either way.
 struct WgradArgs {
     const float* dz[NSVD_MAX_LAYERS];     // (L, 128, B)
     const float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B)
@@ -286,7 +286,58 @@ __device__ __forceinline__ float4 softplus4(float4 v) {
     return make_float4(nsvd_softplus(v.x), nsvd_softplus(v.y), nsvd_softplus(v.z), nsvd_softplus(v.w));
 }
 
-__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, float* Bs, int unit, int slice) {
+// Optimiser state (parameter, square average, EMA shadow) of the tile's blocks acc[0][0] and acc[0][1], fetched under
+// the last four half chunks of the K loop (the hook of tile128_dma.h): the epilogue used to start with every wave of the
+// chip asking for its state at once and four serial load -> update -> store round trips per wave.
+template <bool EMA>
+struct OptPrefetch {
+    static constexpr int LOADS = EMA ? 3 : 2;  // per issue<K, PART>: one row of the block
+    const float *P, *S, *E;
+    unsigned base, ld;  // element offset of block (0, 0) at this lane's column; row pitch
+    int hi;
+    float p[2][16], s[2][16], e[2][16];
+    template <int K, int PART>
+    __device__ __forceinline__ void issue() {  // K = 0..7: rows 4 (K % 4) .. + 3 of block (0, K / 4); PART: which of them
+        constexpr int t = K / 4, r = 4 * (K % 4) + PART;
+        const unsigned off = 4u * (base + 32u * t + (unsigned)acc_row(r, hi) * ld);
+        p[t][r] = wg_ld(P, off);
+        s[t][r] = wg_ld(S, off);
+        if (EMA) e[t][r] = wg_ld(E, off);
+    }
+};
+
+template <bool EMA>
+__device__ __forceinline__ void wg_opt16_load(const NsvdOptPtrs& o, unsigned base, unsigned ld, int hi,
+                                              float (&pv)[16], float (&sv)[16], float (&ev)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
+        pv[r] = wg_ld(o.p, off);
+        sv[r] = wg_ld(o.sq, off);
+        ev[r] = EMA ? wg_ld(o.ema, off) : 0.f;
+    }
+}
+
+template <bool EMA>
+__device__ __forceinline__ void wg_opt16_apply(const WgradArgs& a, const NsvdOptPtrs& o, unsigned base, unsigned ld,
+                                               int hi, const f32x16& acc, float (&pv)[16], float (&sv)[16],
+                                               float (&ev)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
+        if (!EMA) ev[r] = 0.f;
+        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], ev[r], EMA, a.h);
+        wg_st(o.p, off, pv[r]);
+        wg_st(o.sq, off, sv[r]);
+        if (EMA) wg_st(o.ema, off, ev[r]);
+    }
+}
+
+// MODE 0: gradients stored (or split-K partials); 1 / 2: optimiser step in the epilogue without / with the EMA
+// shadow, the state of blocks (0, 0), (0, 1) prefetched under the K loop (needs the pipelined loop, i.e. >= 4
+// chunks, and no gradient output). The bias gradient db_0 (row sums of dz_0) is taken by the C workgroups.
+template <int MODE>
+__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* lds, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -303,39 +354,38 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* As, floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int s_row = tid >> 3, s_c4 = tid & 7;
-    const float* a_src = a.dz[0] + ((size_t)l * HID + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
-    const float* b_src = a.phiTc + (size_t)(kf0 + s_row) * a.B + (size_t)slice * a.Bs + 4 * s_c4;
-    float rs[4];
+    const float* a_base = a.dz[0] + (size_t)l * HID * a.B + (size_t)slice * a.Bs;
+    const float* b_base = a.phiTc + (size_t)kf0 * a.B + (size_t)slice * a.Bs;
+    const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
     WG_STAMP(0, 1ull);
     WG_STAMP(1, wall_clock64());
     WG_STAMP(2, __builtin_readcyclecounter());
-    nsvd_tile128_nt(a_src, b_src, (size_t)32 * a.B, (size_t)32 * a.B, a.Bs / BK, As, Bs, acc, rs);  // tile128_nt.h
-    float rs0 = rs[0], rs1 = rs[1], rs2 = rs[2], rs3 = rs[3];  // bias gradient partials (used when kf0 == 0)
-    WG_STAMP(4, __builtin_readcyclecounter());
-    const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
-    const WgDst dW = wg_dst(a, a.gW[0], a.poW[0], slice), db = wg_dst(a, a.gb[0], a.pob[0], slice);
+    if (MODE == 0) {
+        nsvd_tile128_dma(a_base, b_base, (unsigned)a.B, (unsigned)a.B, a.Bs / BK, lds, acc);
+        WG_STAMP(4, __builtin_readcyclecounter());
+        const WgDst dW = wg_dst(a, a.gW[0], a.poW[0], slice);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            wg_emit16(a, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
-    if (kf0 == 0) {
-        // bias gradient: 8 threads (s_c4) hold partial sums of rows s_row + {0, 32, 64, 96}
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            rs0 += __shfl_xor(rs0, off, 64);
-            rs1 += __shfl_xor(rs1, off, 64);
-            rs2 += __shfl_xor(rs2, off, 64);
-            rs3 += __shfl_xor(rs3, off, 64);
-        }
-        if (s_c4 == 0) {
-            const size_t gb = (size_t)l * HID + s_row;
-            wg_emit1(a, db, a.ob[0], gb, rs0);
-            wg_emit1(a, db, a.ob[0], gb + 32, rs1);
-            wg_emit1(a, db, a.ob[0], gb + 64, rs2);
-            wg_emit1(a, db, a.ob[0], gb + 96, rs3);
-        }
+            for (int j = 0; j < 2; ++j)
+                wg_emit16(a, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
+    } else {
+        constexpr bool EMA = MODE == 2;
+        const NsvdOptPtrs& op = a.oW[0];
+        const unsigned ld = (unsigned)a.F, b00 = (unsigned)o, b10 = b00 + 32u * ld;
+        OptPrefetch<EMA> pf;
+        pf.P = op.p; pf.S = op.sq; pf.E = op.ema;
+        pf.base = b00; pf.ld = ld; pf.hi = hi;
+        nsvd_tile128_dma(a_base, b_base, (unsigned)a.B, (unsigned)a.B, a.Bs / BK, lds, acc, pf);
+        WG_STAMP(4, __builtin_readcyclecounter());
+        // blocks (0,0), (0,1) have their state; the loads of (1,0), (1,1) go out behind the stores of the former
+        float p2[16], s2[16], e2[16], p3[16], s3[16], e3[16];
+        wg_opt16_apply<EMA>(a, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
+        wg_opt16_load<EMA>(op, b10, ld, hi, p2, s2, e2);
+        wg_opt16_apply<EMA>(a, op, b00 + 32u, ld, hi, acc[0][1], pf.p[1], pf.s[1], pf.e[1]);
+        wg_opt16_load<EMA>(op, b10 + 32u, ld, hi, p3, s3, e3);
+        wg_opt16_apply<EMA>(a, op, b10, ld, hi, acc[1][0], p2, s2, e2);
+        wg_opt16_apply<EMA>(a, op, b10 + 32u, ld, hi, acc[1][1], p3, s3, e3);
     }
     WG_STAMP(5, __builtin_readcyclecounter());
     WG_STAMP(6, wall_clock64());
@@ -504,15 +554,18 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
     // that 8 independent 16-B loads are in flight per lane (a row-at-a-time loop is pure L2 latency)
     {
         const int n0 = 32 * part + 8 * w;  // this wave's 8 rows
-        float s[8];
+        float s[8], s0[8];  // s0: db_0[n] = sum_b dz_0[n][b], the first layer's bias gradient, for the same rows
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        for (int j = 0; j < 8; ++j) s[j] = s0[j] = 0.f;
         const float* zrow = a.zsave[nh - 1] + (size_t)slice * a.Bs;
+        const float* drow = a.dz[0] + (size_t)slice * a.Bs;
         for (int b = 4 * lane; b < a.Bs; b += 256) {
-            float4 z[8];
+            float4 z[8], g0[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j) {
                 z[j] = *reinterpret_cast<const float4*>(zrow + ((size_t)l * HID + n0 + j) * a.B + b);
+                g0[j] = *reinterpret_cast<const float4*>(drow + ((size_t)l * HID + n0 + j) * a.B + b);
+            }
             const float4 d = *reinterpret_cast<const float4*>(dbl + b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -520,13 +573,17 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
                 s[j] = fmaf(d.y, z[j].y, s[j]);
                 s[j] = fmaf(d.z, z[j].z, s[j]);
                 s[j] = fmaf(d.w, z[j].w, s[j]);
+                s0[j] += (g0[j].x + g0[j].y) + (g0[j].z + g0[j].w);
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float t = nsvd_wave_sum(s[j]);
-            if (lane == 0)
+            const float t0 = nsvd_wave_sum(s0[j]);
+            if (lane == 0) {
                 wg_emit1(a, wg_dst(a, a.gW[nh], a.poW[nh], slice), a.oW[nh], (size_t)l * HID + n0 + j, t);
+                wg_emit1(a, wg_dst(a, a.gb[0], a.pob[0], slice), a.ob[0], (size_t)l * HID + n0 + j, t0);
+            }
         }
     }
 }
@@ -534,6 +591,7 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
 __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float smem_wg[4 * HID * A_LD];  // 72 KB: two blocks per CU
     static_assert(4 * HID * A_LD >= NSVD_TNT_FLOATS, "tile_nt buffers must fit the weight-gradient LDS");
+    static_assert(4 * HID * A_LD >= T128D_LDS_FLOATS, "the dW_0 tile's DMA ring must fit the weight-gradient LDS");
     float* As = smem_wg;
     float* Bs = smem_wg + 2 * HID * A_LD;
     // grid = S x (nA | nB | 4 L) blocks, kind-major so that the long dW_0 tiles are dispatched first
@@ -544,7 +602,12 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
         // heads share an XCD (dz_0[l] stays in that L2) when the tile count allows the remap
         int unit = bid;
         if ((a.nA & 7) == 0) unit = (bid & 7) * (a.nA >> 3) + (bid >> 3);
-        wgrad_tile_A(a, As, Bs, unit, slice);
+        // the optimiser state rides under the K loop when the step is fused, nothing else is written and the
+        // loop has the four peeled chunks the prefetch hangs on
+        const bool pf = a.S == 1 && a.opt && !a.gW[0] && a.Bs >= 4 * BK;
+        if (!pf) wgrad_tile_A<0>(a, smem_wg, unit, slice);
+        else if (a.oW[0].ema) wgrad_tile_A<2>(a, smem_wg, unit, slice);
+        else wgrad_tile_A<1>(a, smem_wg, unit, slice);
         return;
     }
     bid -= a.nA * a.S;

@@ -4,7 +4,7 @@
 // 512 -> 8192 -> 512, lrelu0.2, BatchNorm on every layer, batch 1024 (BASELINE configs[4]).
 //
 // Every contraction is brought into the "NT" form C = A B^T with both operands contraction-contiguous and runs on the
-// 128 x 128 fp32-MFMA tile loop shared with the layer-0 weight gradient (tile128_nt.h); the producers write the
+// 128 x 128 fp32-MFMA tile loop shared with the layer-0 weight gradient (tile128_dma.h); the producers write the
 // transposed copies the backward contractions need (the activations, the pre-activation gradients) so that no GEMM
 // ever stages a strided operand:
 //   forward   Y1 = X W1^T + b1            A = X (B, d0)       B = W1 (d1, d0)          K = d0
@@ -21,7 +21,7 @@
 // running estimate, momentum update of running_mean / running_var (eps 1e-5, momentum 0.1 by default).
 // Shapes: B, d0, d1, d2 multiples of 128, B <= 1024 (a BatchNorm strip's rows live in the registers of one workgroup).
 #include "nsvd_common.h"
-#include "tile128_nt.h"
+#include "tile128_dma.h"
 
 using namespace nsvd_pmlp;
 
@@ -38,9 +38,7 @@ struct GemmNT {
 };
 
 __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * HID * A_LD];  // 72 KB: two blocks per CU
-    float* As = smem;
-    float* Bs = smem + 2 * HID * A_LD;
+    __shared__ __attribute__((aligned(16))) float smem[T128D_LDS_FLOATS];  // 64 KB: two blocks per CU
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -59,11 +57,9 @@ __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int s_row = tid >> 3, s_c4 = tid & 7;
-    const float* a_src = g.A + ((size_t)128 * trow + s_row) * g.lda + (size_t)slice * Ks + 4 * s_c4;
-    const float* b_src = g.B + ((size_t)128 * tcol + s_row) * g.ldb + (size_t)slice * Ks + 4 * s_c4;
-    float rs[4];
-    nsvd_tile128_nt(a_src, b_src, 32 * g.lda, 32 * g.ldb, Ks / BK, As, Bs, acc, rs);
+    const float* a_base = g.A + (size_t)128 * trow * g.lda + (size_t)slice * Ks;
+    const float* b_base = g.B + (size_t)128 * tcol * g.ldb + (size_t)slice * Ks;
+    nsvd_tile128_dma(a_base, b_base, (unsigned)g.lda, (unsigned)g.ldb, Ks / BK, smem, acc);
     float* C = g.C + (size_t)slice * g.slice_stride + ((size_t)128 * trow + 64 * wm) * g.ldc + 128 * tcol + 64 * wn + li;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

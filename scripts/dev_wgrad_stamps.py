@@ -19,9 +19,11 @@ st = np.array(buf, dtype=np.uint64).reshape(448, 8).astype(np.int64)
 t0 = st[:, 1].min()
 for kind, name in ((1, "A"), (2, "B"), (3, "C")):
     m = st[:, 0] == kind
+    if not m.any():
+        continue
     s, e = (st[m, 1] - t0) / 100.0, (st[m, 6] - t0) / 100.0
     print(f"{name}: n={m.sum()} start {s.min():.1f}..{s.max():.1f} us, end {e.min():.1f}..{e.max():.1f} us, dur mean {np.mean(e - s):.1f} max {np.max(e - s):.1f}")
     if kind == 1:
-        pro, loop, epi = st[m, 3] - st[m, 2], st[m, 4] - st[m, 3], st[m, 5] - st[m, 4]
+        pro, loop, epi = 0 * st[m, 2], st[m, 4] - st[m, 2], st[m, 5] - st[m, 4]
         print(f"   cycles: prologue {pro.mean():.0f}, loop {loop.mean():.0f} (min {loop.min()}, max {loop.max()}), epilogue {epi.mean():.0f}; ideal loop 65536")
 print(f"kernel span {(st[:, 6].max() - t0) / 100.0:.1f} us")
