@@ -35,7 +35,12 @@ struct ChainArgs {
     NsvdEvdIn evd;
 };
 
-__global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
+// PRE: the whole chain's weights and sigmoid inputs are fetched at kernel start (two or three hidden layers; ~290
+// VGPRs, one workgroup per CU at a time). Pays only while the grid leaves CUs idle and the kernel is pure latency:
+// measured steps/s with / without at cfg1 (64 workgroups) 4396 / 4260, cfg2 (256) 3778 / 3798, cfg3 per GPU (512)
+// 3991 / 4184 - with every CU busy the 64 KB of W_i per workgroup are a throughput cost either way.
+template <bool PRE>
+__global__ void __launch_bounds__(256, PRE ? 1 : 2) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float DZ[BS * H_LD];  // [c][n]  n contiguous
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -59,6 +64,29 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
             zl[r] = zp[(size_t)n * a.B];
             wlv[r] = wl[n];
         }
+    }
+    // two or three hidden layers (every shipped configuration): the W_i fragments and sigmoid inputs of the whole
+    // chain are fetched now as well - nothing below depends on them arriving, and a step of the chain is then 16 MFMAs
+    // and one LDS exchange instead of a round trip to L2 per layer
+    float wfa[64], wfb[64], zina[16], zinb[16];
+    constexpr bool w1_ready = PRE;
+    if (w1_ready) {
+#define CHAIN_LOAD_TOP(i, WF, ZIN)                                                                      \
+    {                                                                                                   \
+        const float* zp = a.zsave[(i) - 1] + row0;                                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) ZIN[r] = zp[(size_t)acc_row(r, hi) * a.B];       \
+        const float* Wi = a.W[i] + (size_t)l * HID * HID + 32 * w + li;                                 \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                \
+            const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;                                      \
+            WF[4 * q] = wp[0];                                                                          \
+            WF[4 * q + 1] = wp[HID];                                                                    \
+            WF[4 * q + 2] = wp[2 * HID];                                                                \
+            WF[4 * q + 3] = wp[3 * HID];                                                                \
+        }                                                                                               \
+    }
+        CHAIN_LOAD_TOP(nh - 1, wfa, zina)
+        if (nh == 3) CHAIN_LOAD_TOP(1, wfb, zinb)
+#undef CHAIN_LOAD_TOP
     }
     float dfv;
     if (a.df) {
@@ -118,39 +146,77 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
     float dz[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dz[r] = wlv[r] * dbase * nsvd_sigmoid_from_softplus(zl[r]);
-    for (int i = nh - 1; i >= 0; --i) {
-        float* o = a.dz[i] + row0;
+    // one step down the chain: store dz_i, exchange it through LDS, dz_{i-1} = (W_i^T dz_i) * sigmoid(z_{i-1}); the
+    // W_i fragments (WF: 64 floats, W_i[n = 8 q + 4 hi + j][k = 32 w + li] at 4 q + j) and the sigmoid inputs (ZIN)
+    // are in registers already
+#define CHAIN_STEP(i, WF, ZIN)                                                                          \
+    {                                                                                                   \
+        float* o = a.dz[i] + row0;                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];         \
+        __syncthreads(); /* previous round's LDS reads are done */                                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                   \
+            *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =                      \
+                make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);                    \
+        __syncthreads();                                                                                \
+        f32x16 acc1[1];                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;                                \
+        const float* Bp = DZ + li * H_LD + 4 * hi;                                                      \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                \
+            Frag<1> f;                                                                                  \
+            f.a = make_float4(WF[4 * q], WF[4 * q + 1], WF[4 * q + 2], WF[4 * q + 3]);                  \
+            f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * q);                                      \
+            mma_frag<1>(acc1, f);                                                                       \
+        }                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                  \
+            dz[r] = acc1[0][r] * nsvd_sigmoid_from_softplus(ZIN[r]);                                    \
+    }
+    if (PRE) {
+        if (nh == 3) {
+            CHAIN_STEP(2, wfa, zina)
+            CHAIN_STEP(1, wfb, zinb)
+        } else {
+            CHAIN_STEP(1, wfa, zina)
+        }
+    } else {
+        for (int i = nh - 1; i >= 1; --i) {
+            float* o = a.dz[i] + row0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
+            // issue the loads the next tile needs before the LDS exchange: sigmoid inputs and W_i columns
+            float zin[16];
+            {
+                const float* zp = a.zsave[i - 1] + row0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zin[r] = zp[(size_t)acc_row(r, hi) * a.B];
+            }
+            __syncthreads();  // previous round's LDS reads are done
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =
+                    make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);
+            __syncthreads();
+            f32x16 acc1[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+            const float* Wi = a.W[i] + (size_t)l * HID * HID + 32 * w + li;  // W_i[n][k = 32w + li]
+            const float* Bp = DZ + li * H_LD + 4 * hi;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                Frag<1> f;
+                const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;
+                f.a = make_float4(wp[0], wp[HID], wp[2 * HID], wp[3 * HID]);
+                f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * q);
+                mma_frag<1>(acc1, f);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * nsvd_sigmoid_from_softplus(zin[r]);
+        }
+    }
+#undef CHAIN_STEP
+    {
+        float* o = a.dz[0] + row0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
-        if (i == 0) break;
-        // issue the loads the next tile needs before the LDS exchange: sigmoid inputs and W_i columns
-        float zin[16];
-        {
-            const float* zp = a.zsave[i - 1] + row0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zin[r] = zp[(size_t)acc_row(r, hi) * a.B];
-        }
-        __syncthreads();  // previous round's LDS reads are done
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =
-                make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);
-        __syncthreads();
-        f32x16 acc1[1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
-        const float* Wi = a.W[i] + (size_t)l * HID * HID + 32 * w + li;  // W_i[n][k = 32w + li]
-        const float* Bp = DZ + li * H_LD + 4 * hi;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            Frag<1> f;
-            const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;
-            f.a = make_float4(wp[0], wp[HID], wp[2 * HID], wp[3 * HID]);
-            f.b[0] = *reinterpret_cast<const float4*>(Bp + 8 * q);
-            mma_frag<1>(acc1, f);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dz[r] = acc1[0][r] * nsvd_sigmoid_from_softplus(zin[r]);
     }
 }
 
@@ -699,7 +765,11 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         a.dz[i] = (i < nh) ? w.dz[i] : nullptr;
     }
     a.nlayers = d.nlayers; a.B = B; a.L = d.L;
-    hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel, dim3((B / BS) * d.L), dim3(256), 0, s, a);
+    const int chain_grid = (B / BS) * d.L;
+    if ((nh == 2 || nh == 3) && chain_grid <= 128)
+        hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<true>, dim3(chain_grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<false>, dim3(chain_grid), dim3(256), 0, s, a);
     NSVD_CHECK_LAUNCH();
 
     WgradArgs wa;
