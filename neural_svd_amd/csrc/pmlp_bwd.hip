@@ -40,7 +40,7 @@ struct ChainArgs {
 // measured steps/s with / without at cfg1 (64 workgroups) 4396 / 4260, cfg2 (256) 3778 / 3798, cfg3 per GPU (512)
 // 3991 / 4184 - with every CU busy the 64 KB of W_i per workgroup are a throughput cost either way.
 template <bool PRE>
-__global__ void __launch_bounds__(256, PRE ? 1 : 2) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
+__global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float DZ[BS * H_LD];  // [c][n]  n contiguous
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
