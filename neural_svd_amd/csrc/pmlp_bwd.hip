@@ -239,7 +239,10 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 // tiles, co-resident with them from t = 0, end at 46-49 us, the C tiles at 42-45 us; kernel 52 us in rocprof
 // (round 1: 60 us; separate backward and optimiser launches 50 + 20.5 us). Raising the B / C wave priority
 // (s_setprio 3) shortens them but stretches the A loops by the same amount, raising the A priority changes
-// nothing: no gain either way.
+// nothing: no gain either way. Nor does cutting the B quadrants into two batch halves (twice the workgroups, one per
+// CU, the half arriving second adds its partner's partial): they are not shorter - next to a dW_0 tile a small
+// workgroup advances at the pace the tile leaves it, whatever its own work - and every dW_0 loop is slowed instead of
+// half of them: 54.6 us against 52.9.
 struct WgradArgs {
     const float* dz[NSVD_MAX_LAYERS];     // (L, 128, B)
     const float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B)
@@ -642,15 +645,20 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
                 s0[j] += (g0[j].x + g0[j].y) + (g0[j].z + g0[j].w);
             }
         }
+        // the 16 results go out from 16 lanes at once (lane j: dW_last row j, lane 8 + j: db_0 row j): one round trip
+        // of optimiser state instead of 16 dependent ones (these workgroups then end at 35 us instead of 43)
+        float mine = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float t = nsvd_wave_sum(s[j]);
             const float t0 = nsvd_wave_sum(s0[j]);
-            if (lane == 0) {
-                wg_emit1(a, wg_dst(a, a.gW[nh], a.poW[nh], slice), a.oW[nh], (size_t)l * HID + n0 + j, t);
-                wg_emit1(a, wg_dst(a, a.gb[0], a.pob[0], slice), a.ob[0], (size_t)l * HID + n0 + j, t0);
-            }
+            if (lane == j) mine = t;
+            if (lane == 8 + j) mine = t0;
         }
+        if (lane < 8)
+            wg_emit1(a, wg_dst(a, a.gW[nh], a.poW[nh], slice), a.oW[nh], (size_t)l * HID + n0 + lane, mine);
+        else if (lane < 16)
+            wg_emit1(a, wg_dst(a, a.gb[0], a.pob[0], slice), a.ob[0], (size_t)l * HID + n0 + lane - 8, mine);
     }
 }
 
