@@ -47,7 +47,9 @@ struct Tile128NoHook {
 };
 
 // 16 B per lane global -> LDS: source = sbase (uniform) + voff (per lane, bytes), destination = m0 (wave-uniform LDS
-// byte address) + lane * 16
+// byte address) + lane * 16. M0 is a reserved register (never allocated; hipcc rejects it on a clobber list): the
+// compiler writes it itself right in front of each of its own uses, and the kernels that include this header have
+// none (checked in their ISA) - do not mix this routine with the LDS-DMA builtin in one kernel.
 __device__ __forceinline__ void t128d_dma(const float* sbase, unsigned voff, unsigned m0) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0), "v"(voff), "s"(sbase) : "memory");
 }
