@@ -172,7 +172,8 @@ def test_train_operator_smoke():
             assert not torch.equal(p, before[n]), n
 
 
-@pytest.mark.parametrize("hidden,m,B", [((32, 32), 16, 24), ((128, 128, 128), 64, 64)])
+@pytest.mark.parametrize("hidden,m,B", [((32, 32), 16, 24), ((128, 128, 128), 64, 64), ((128, 128), 64, 160),
+                                        ((128, 128), 128, 96)])
 def test_fused_trainer_step_matches_oracle(hidden, m, B):
     """one full optimiser step of FusedTrainer (generic and fused-MFMA shapes) vs the float64 oracle
     on the same batch: loss, gradient, RMSprop update, EMA."""
@@ -219,7 +220,8 @@ def test_fused_trainer_step_matches_oracle(hidden, m, B):
 
 
 @pytest.mark.parametrize("hidden,m,B,mask", [((32, 32), 16, 24, False), ((128, 128, 128), 128, 64, True),
-                                              ((128, 128), 64, 96, False), ((128, 128), 128, 1024, True)])
+                                              ((128, 128), 64, 96, False), ((128, 128), 128, 1024, True),
+                                              ((128, 128), 64, 160, False)])
 def test_optimiser_step_fused_into_backward_is_bit_identical(hidden, m, B, mask):
     """nsvd_operator_backward_evd_step (RMSprop + EMA inside the weight-gradient kernel, gradients never stored)
     vs nsvd_operator_backward_evd + nsvd_rmsprop_ema_step: same parameters, square averages and EMA shadows bit
