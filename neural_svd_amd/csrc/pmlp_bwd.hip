@@ -242,7 +242,10 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 // nothing: no gain either way. Nor does cutting the B quadrants into two batch halves (twice the workgroups, one per
 // CU, the half arriving second adds its partner's partial): they are not shorter - next to a dW_0 tile a small
 // workgroup advances at the pace the tile leaves it, whatever its own work - and every dW_0 loop is slowed instead of
-// half of them: 54.6 us against 52.9.
+// half of them: 54.6 us against 52.9. Holding the small workgroups back (a counter of dW_0 tiles past their K loop,
+// bounded wait) until 50 / 90 / 100 % of the loops are done, with whole or halved quadrants: 272-275 us per step
+// against 263 - the dW_0 loops do get the CU to themselves, but the small workgroups' work then lands on the
+// memory-bound epilogues instead of under the loops.
 struct WgradArgs {
     const float* dz[NSVD_MAX_LAYERS];     // (L, 128, B)
     const float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B)
