@@ -385,3 +385,25 @@ def test_model_autograd_and_compute_loss_kernel():
     assert aux["f"].shape[0] == B1 and rel(aux["Tf"], Kf1) < 1e-4
     for n, g in zip(names, gref):
         assert rel(got[n].grad, g) < 1e-4, n
+
+
+@pytest.mark.gpu
+def test_fused_step_bit_identical_at_headline_size():
+    """configs[1]'s size (every CU holds a dW_0 tile, the optimiser state of half of each tile is prefetched under the
+    K loop): the fused step, the fused step that also stores gradients and backward + separate optimiser kernel stay
+    bit-identical over ten steps of the internal sampler."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    shape = H.ModelShape(L=16, D=2, m=1024, hidden=(128, 128, 128))
+    prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+    kw = dict(sequential=True, seed=0, device=DEV)
+    a = FusedTrainer(shape, prob, 512, fused_step=True, **kw)
+    b = FusedTrainer(shape, prob, 512, fused_step=False, **kw)
+    c = FusedTrainer(shape, prob, 512, fused_step=True, keep_grads=True, **kw)
+    for it in range(10):
+        a.step(); b.step(); c.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.x, b.x)
+    for t in (a, c):
+        assert torch.equal(t.P.flat, b.P.flat) and torch.equal(t.P.ema, b.P.ema) and torch.equal(t.P.sq, b.P.sq)
+    assert torch.equal(c.P.grad, b.P.grad)
