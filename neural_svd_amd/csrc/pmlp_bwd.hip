@@ -257,6 +257,7 @@ struct WgradArgs {
     float* gscales;
     int nlayers, B, L, F;
     int nA, nB;
+    int tw;  // features per dW_0 tile: 128, or 64 when that many tiles would leave half the CUs without one (S == 1)
     int bid0;  // first logical block of this launch (the A tiles and the B/C tiles are launched separately)
     // fused RMSprop + EMA epilogue (opt != 0): every gradient element is applied to its parameter in place
     // the moment it leaves the accumulator, so it never makes the HBM round trip (-8 B/parameter, -1 launch).
@@ -361,7 +362,7 @@ __device__ __forceinline__ float4 softplus4(float4 v) {
 // Optimiser state (parameter, square average, EMA shadow) of the tile's blocks acc[0][0] and acc[0][1], fetched under
 // the last four half chunks of the K loop (the hook of tile128_dma.h): the epilogue used to start with every wave of the
 // chip asking for its state at once and four serial load -> update -> store round trips per wave.
-template <bool EMA>
+template <bool EMA, int NJ>
 struct OptPrefetch {
     static constexpr int LOADS = EMA ? 3 : 2;  // per issue<K, PART>: one row of the block
     const float *P, *S, *E;
@@ -369,9 +370,10 @@ struct OptPrefetch {
     int hi;
     float p[2][16], s[2][16], e[2][16];
     template <int K, int PART>
-    __device__ __forceinline__ void issue() {  // K = 0..7: rows 4 (K % 4) .. + 3 of block (0, K / 4); PART: which of them
+    __device__ __forceinline__ void issue() {  // K = 0..7: rows 4 (K % 4) .. + 3 of prefetched block K / 4; PART: which
         constexpr int t = K / 4, r = 4 * (K % 4) + PART;
-        const unsigned off = 4u * (base + 32u * t + (unsigned)acc_row(r, hi) * ld);
+        // the second prefetched block: (0, 1), or (1, 0) when the tile has no (0, 1)
+        const unsigned off = 4u * (base + (NJ == 2 ? 32u * t : 32u * t * ld) + (unsigned)acc_row(r, hi) * ld);
         p[t][r] = wg_ld(P, off);
         s[t][r] = wg_ld(S, off);
         if (EMA) e[t][r] = wg_ld(E, off);
@@ -406,29 +408,31 @@ __device__ __forceinline__ void wg_opt16_apply(const WgradArgs& a, const NsvdOpt
 }
 
 // MODE 0: gradients stored (or split-K partials); 1 / 2: optimiser step in the epilogue without / with the EMA
-// shadow, the state of blocks (0, 0), (0, 1) prefetched under the K loop (needs the pipelined loop, i.e. >= 4
-// chunks, and no gradient output). The bias gradient db_0 (row sums of dz_0) is taken by the C workgroups.
-template <int MODE>
+// shadow, the state of two blocks prefetched under the K loop (needs the pipelined loop, i.e. >= 4 chunks, and no
+// gradient output). NJ = 2: 128 x 128 tile (hidden units x features); NJ = 1: 128 x 64, chosen by the host when the
+// 128-wide tiles would leave half the CUs without one. The bias gradient db_0 is taken by the C workgroups.
+template <int MODE, int NJ>
 __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* lds, int unit, int slice) {
+    constexpr int TW = 64 * NJ;  // features per tile
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
-    const int nkt = a.F / HID;
+    const int nkt = a.F / TW;
     const int l = unit / nkt;
-    const int kf0 = (unit - l * nkt) * HID;
+    const int kf0 = (unit - l * nkt) * TW;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const float* a_base = a.dz[0] + (size_t)l * HID * a.B + (size_t)slice * a.Bs;
     const float* b_base = a.phiTc + (size_t)kf0 * a.B + (size_t)slice * a.Bs;
-    const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 64 * wn + li;
+    const size_t o = ((size_t)l * HID + 64 * wm) * a.F + kf0 + 32 * NJ * wn + li;
     WG_STAMP(0, 1ull);
     WG_STAMP(1, wall_clock64());
     WG_STAMP(2, __builtin_readcyclecounter());
@@ -439,25 +443,31 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* lds, int
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
                 wg_emit16(a, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
     } else {
         constexpr bool EMA = MODE == 2;
         const NsvdOptPtrs& op = a.oW[0];
         const unsigned ld = (unsigned)a.F, b00 = (unsigned)o, b10 = b00 + 32u * ld;
-        OptPrefetch<EMA> pf;
+        OptPrefetch<EMA, NJ> pf;
         pf.P = op.p; pf.S = op.sq; pf.E = op.ema;
         pf.base = b00; pf.ld = ld; pf.hi = hi;
         nsvd_tile128_dma(a_base, b_base, (unsigned)a.B, (unsigned)a.B, a.Bs / BK, lds, acc, pf);
         WG_STAMP(4, __builtin_readcyclecounter());
-        // blocks (0,0), (0,1) have their state; the loads of (1,0), (1,1) go out behind the stores of the former
-        float p2[16], s2[16], e2[16], p3[16], s3[16], e3[16];
-        wg_opt16_apply<EMA>(a, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
-        wg_opt16_load<EMA>(op, b10, ld, hi, p2, s2, e2);
-        wg_opt16_apply<EMA>(a, op, b00 + 32u, ld, hi, acc[0][1], pf.p[1], pf.s[1], pf.e[1]);
-        wg_opt16_load<EMA>(op, b10 + 32u, ld, hi, p3, s3, e3);
-        wg_opt16_apply<EMA>(a, op, b10, ld, hi, acc[1][0], p2, s2, e2);
-        wg_opt16_apply<EMA>(a, op, b10 + 32u, ld, hi, acc[1][1], p3, s3, e3);
+        if (NJ == 2) {
+            // blocks (0,0), (0,1) have their state; the loads of (1,0), (1,1) go out behind the stores of the former
+            float p2[16], s2[16], e2[16], p3[16], s3[16], e3[16];
+            wg_opt16_apply<EMA>(a, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
+            wg_opt16_load<EMA>(op, b10, ld, hi, p2, s2, e2);
+            wg_opt16_apply<EMA>(a, op, b00 + 32u, ld, hi, acc[0][NJ - 1], pf.p[1], pf.s[1], pf.e[1]);
+            wg_opt16_load<EMA>(op, b10 + 32u, ld, hi, p3, s3, e3);
+            wg_opt16_apply<EMA>(a, op, b10, ld, hi, acc[1][0], p2, s2, e2);
+            wg_opt16_apply<EMA>(a, op, b10 + 32u, ld, hi, acc[1][NJ - 1], p3, s3, e3);
+        } else {
+            // both blocks of the tile have their state
+            wg_opt16_apply<EMA>(a, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
+            wg_opt16_apply<EMA>(a, op, b10, ld, hi, acc[1][0], pf.p[1], pf.s[1], pf.e[1]);
+        }
     }
     WG_STAMP(5, __builtin_readcyclecounter());
     WG_STAMP(6, wall_clock64());
@@ -665,6 +675,9 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
     }
 }
 
+// NJ: the dW_0 tile shape (2: 128 x 128, 1: 128 x 64 = WgradArgs::tw 64); two kernels rather than one with both shapes
+// inside - with all six tile variants in one function the register allocator spills in the 128 x 128 ones
+template <int NJ>
 __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float smem_wg[4 * HID * A_LD];  // 72 KB: two blocks per CU
     static_assert(4 * HID * A_LD >= NSVD_TNT_FLOATS, "tile_nt buffers must fit the weight-gradient LDS");
@@ -682,9 +695,9 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
         // the optimiser state rides under the K loop when the step is fused, nothing else is written and the
         // loop has the four peeled chunks the prefetch hangs on
         const bool pf = a.S == 1 && a.opt && !a.gW[0] && a.Bs >= 4 * BK;
-        if (!pf) wgrad_tile_A<0>(a, smem_wg, unit, slice);
-        else if (a.oW[0].ema) wgrad_tile_A<2>(a, smem_wg, unit, slice);
-        else wgrad_tile_A<1>(a, smem_wg, unit, slice);
+        if (!pf) wgrad_tile_A<0, NJ>(a, smem_wg, unit, slice);
+        else if (a.oW[0].ema) wgrad_tile_A<2, NJ>(a, smem_wg, unit, slice);
+        else wgrad_tile_A<1, NJ>(a, smem_wg, unit, slice);
         return;
     }
     bid -= a.nA * a.S;
@@ -848,10 +861,18 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         NSVD_CHECK_LAUNCH();
         return 0;
     }
+    wa.tw = 128;
+    if (wa.S == 1 && wa.nA <= 128) {  // 128 x 64 tiles: twice as many, half as long
+        wa.tw = 64;
+        wa.nA *= 2;
+    }
     // One launch: the dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
     // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
     wa.bid0 = 0;
-    hipLaunchKernelGGL(pmlp_fused_wgrad_kernel, dim3(wa.S * (wa.nA + wa.nB + 4 * d.L)), dim3(256), 0, s, wa);
+    if (wa.tw == 64)
+        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<1>, dim3(wa.S * (wa.nA + wa.nB + 4 * d.L)), dim3(256), 0, s, wa);
+    else
+        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<2>, dim3(wa.S * (wa.nA + wa.nB + 4 * d.L)), dim3(256), 0, s, wa);
     NSVD_CHECK_LAUNCH();
     if (wa.S == 1) return 0;
     ReduceArgs ra;

@@ -54,43 +54,48 @@ __device__ __forceinline__ void t128d_dma(const float* sbase, unsigned voff, uns
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0), "v"(voff), "s"(sbase) : "memory");
 }
 
-template <class Hook>
+// NJ = 2: the 128 x 128 tile; NJ = 1: 128 rows of A x 64 rows of B (wave (wm, wn): rows 64 wm of A x rows 32 wn of B,
+// acc[i][0] = its block (32 i, 0)) - twice the tiles for outputs that would otherwise leave half the CUs without one
+template <class Hook, int NJ>
 __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const float* b_base, unsigned a_ld, unsigned b_ld,
-                                                 int nch, float* lds, f32x16 (&acc)[2][2], Hook& hook) {
+                                                 int nch, float* lds, f32x16 (&acc)[2][NJ], Hook& hook) {
+    static_assert(NJ == 1 || NJ == 2, "B operand: 64 or 128 rows");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hi = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
-    // DMA: this wave moves rows 32 w .. 32 w + 31 of each operand, 16 rows per instruction
+    // DMA: this wave moves rows 32 w .. 32 w + 31 of A and 16 NJ w .. + 16 NJ - 1 of B, 16 rows per instruction
     const unsigned dq = 4u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3));  // source column (floats) of this lane's slot
     const unsigned va0 = 4u * ((unsigned)(32 * w + (lane >> 2)) * a_ld + dq), va1 = va0 + 64u * a_ld;
-    const unsigned vb0 = 4u * ((unsigned)(32 * w + (lane >> 2)) * b_ld + dq), vb1 = vb0 + 64u * b_ld;
-    const unsigned m0w = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + 2048u * (unsigned)w;
-    // fragments: row 64 wm + li (+ 32) of A, 64 wn + li (+ 32) of B; column quad 2 q + hi of the half chunk
+    const unsigned vb0 = 4u * ((unsigned)(16 * NJ * w + (lane >> 2)) * b_ld + dq), vb1 = vb0 + 64u * b_ld;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const unsigned m0a = lds0 + 2048u * (unsigned)w, m0b = lds0 + 8192u + 1024u * NJ * (unsigned)w;
+    // fragments: row 64 wm + li (+ 32) of A, 32 NJ wn + li (+ 32) of B; column quad 2 q + hi of the half chunk
     const int fz = (li >> 2) & 3;
     const char* ldsb = reinterpret_cast<const char*>(lds);
     const char* fa0 = ldsb + (64 * wm + li) * 64 + ((hi ^ fz) << 4);
     const char* fa1 = ldsb + (64 * wm + li) * 64 + (((2 + hi) ^ fz) << 4);
-    const char* fb0 = ldsb + 8192 + (64 * wn + li) * 64 + ((hi ^ fz) << 4);
-    const char* fb1 = ldsb + 8192 + (64 * wn + li) * 64 + (((2 + hi) ^ fz) << 4);
+    const char* fb0 = ldsb + 8192 + (32 * NJ * wn + li) * 64 + ((hi ^ fz) << 4);
+    const char* fb1 = ldsb + 8192 + (32 * NJ * wn + li) * 64 + (((2 + hi) ^ fz) << 4);
     struct F4 {
         float4 a0, a1, b0, b1;
     };
     F4 f0, f1;
 #define TD_DMA(s, pa, pb)                                          \
     {                                                              \
-        t128d_dma(pa, va0, m0w + (s) * 16384u);                    \
-        t128d_dma(pa, va1, m0w + (s) * 16384u + 1024u);            \
-        t128d_dma(pb, vb0, m0w + (s) * 16384u + 8192u);            \
-        t128d_dma(pb, vb1, m0w + (s) * 16384u + 9216u);            \
+        t128d_dma(pa, va0, m0a + (s) * 16384u);                    \
+        t128d_dma(pa, va1, m0a + (s) * 16384u + 1024u);            \
+        t128d_dma(pb, vb0, m0b + (s) * 16384u);                    \
+        if (NJ == 2) t128d_dma(pb, vb1, m0b + (s) * 16384u + 1024u); \
     }
 #define TD_RD(p, s) (*reinterpret_cast<const float4*>((p) + (s) * 16384))
+#define TD_RDB1(p, s) (NJ == 2 ? TD_RD((p) + 2048, s) : make_float4(0.f, 0.f, 0.f, 0.f))
 #define TD_MMA4(f, X)                                                                                   \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0][0], 0, 0, 0);              \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[0][1], 0, 0, 0);              \
+    if (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[0][NJ - 1], 0, 0, 0); \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[1][0], 0, 0, 0);              \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[1][1], 0, 0, 0);
+    if (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[1][NJ - 1], 0, 0, 0);
 #define TD_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define TD_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
 #define TD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -108,8 +113,8 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
         TD_WAIT_BARRIER(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f0.a0 = TD_RD(fa0, s); f0.a1 = TD_RD(fa0 + 2048, s); f0.b0 = TD_RD(fb0, s); f0.b1 = TD_RD(fb0 + 2048, s);
-            f1.a0 = TD_RD(fa1, s); f1.a1 = TD_RD(fa1 + 2048, s); f1.b0 = TD_RD(fb1, s); f1.b1 = TD_RD(fb1 + 2048, s);
+            f0.a0 = TD_RD(fa0, s); f0.a1 = TD_RD(fa0 + 2048, s); f0.b0 = TD_RD(fb0, s); f0.b1 = TD_RDB1(fb0, s);
+            f1.a0 = TD_RD(fa1, s); f1.a1 = TD_RD(fa1 + 2048, s); f1.b0 = TD_RD(fb1, s); f1.b1 = TD_RDB1(fb1, s);
             TD_MMA4(f0, x) TD_MMA4(f0, y) TD_MMA4(f0, z) TD_MMA4(f0, w)
             TD_MMA4(f1, x) TD_MMA4(f1, y) TD_MMA4(f1, z) TD_MMA4(f1, w)
         }
@@ -130,25 +135,25 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
         TD_MMA4(f0, z) f1.b0 = TD_RD(fb1, s);                                                             \
         if (K0 >= 0) hook.template issue<(K0 >= 0 ? K0 : 0), 2>();                                        \
         TD_FENCE();                                                                                       \
-        TD_MMA4(f0, w) f1.b1 = TD_RD(fb1 + 2048, s);                                                      \
+        TD_MMA4(f0, w) f1.b1 = TD_RDB1(fb1, s);                                                           \
         if (K0 >= 0) hook.template issue<(K0 >= 0 ? K0 : 0), 3>();                                        \
         TD_FENCE();                                                                                       \
         if (!(LAST)) TD_WAIT_BARRIER((WAITN) > 63 ? 63 : (WAITN));                                        \
         TD_MMA4(f1, x) if (!(LAST)) f0.a0 = TD_RD(fa0, ((s) + 1) & 3);                                    \
-        if (DO_DMA) t128d_dma(pa, va0, m0w + (s) * 16384u);                                               \
+        if (DO_DMA) t128d_dma(pa, va0, m0a + (s) * 16384u);                                               \
         if (K1 >= 0) hook.template issue<(K1 >= 0 ? K1 : 0), 0>();                                        \
         TD_FENCE();                                                                                       \
         TD_MMA4(f1, y) if (!(LAST)) f0.a1 = TD_RD(fa0 + 2048, ((s) + 1) & 3);                             \
-        if (DO_DMA) t128d_dma(pa, va1, m0w + (s) * 16384u + 1024u);                                       \
+        if (DO_DMA) t128d_dma(pa, va1, m0a + (s) * 16384u + 1024u);                                       \
         if (K1 >= 0) hook.template issue<(K1 >= 0 ? K1 : 0), 1>();                                        \
         TD_FENCE();                                                                                       \
         TD_MMA4(f1, z) if (!(LAST)) f0.b0 = TD_RD(fb0, ((s) + 1) & 3);                                    \
-        if (DO_DMA) t128d_dma(pb, vb0, m0w + (s) * 16384u + 8192u);                                       \
+        if (DO_DMA) t128d_dma(pb, vb0, m0b + (s) * 16384u);                                               \
         if (K1 >= 0) hook.template issue<(K1 >= 0 ? K1 : 0), 2>();                                        \
         TD_FENCE();                                                                                       \
-        TD_MMA4(f1, w) if (!(LAST)) f0.b1 = TD_RD(fb0 + 2048, ((s) + 1) & 3);                             \
+        TD_MMA4(f1, w) if (!(LAST)) f0.b1 = TD_RDB1(fb0, ((s) + 1) & 3);                                  \
         if (DO_DMA) {                                                                                     \
-            t128d_dma(pb, vb1, m0w + (s) * 16384u + 9216u);                                               \
+            if (NJ == 2) t128d_dma(pb, vb1, m0b + (s) * 16384u + 1024u);                                  \
             pa += 16;                                                                                     \
             pb += 16;                                                                                     \
         }                                                                                                 \
@@ -156,6 +161,7 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
         TD_FENCE();                                                                                       \
     }
     constexpr int HL = Hook::LOADS;
+    constexpr int G = 2 + NJ;  // DMA instructions per wave and half chunk
     if (c0) TD_BARRIER();
     TD_DMA(0, pa, pb);
     TD_DMA(1, pa + 16, pb + 16);
@@ -163,22 +169,23 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
     TD_DMA(3, pa + 48, pb + 48);
     pa += 64;
     pb += 64;
-    TD_WAIT_BARRIER(12);
-    f0.a0 = TD_RD(fa0, 0); f0.a1 = TD_RD(fa0 + 2048, 0); f0.b0 = TD_RD(fb0, 0); f0.b1 = TD_RD(fb0 + 2048, 0);
+    TD_WAIT_BARRIER(3 * G);
+    f0.a0 = TD_RD(fa0, 0); f0.a1 = TD_RD(fa0 + 2048, 0); f0.b0 = TD_RD(fb0, 0); f0.b1 = TD_RDB1(fb0, 0);
     for (int g = n / 2 - 1; g > 0; --g) {
-        TD_HALF(0, true, 8, -1, -1, false)
-        TD_HALF(1, true, 8, -1, -1, false)
-        TD_HALF(2, true, 8, -1, -1, false)
-        TD_HALF(3, true, 8, -1, -1, false)
+        TD_HALF(0, true, 2 * G, -1, -1, false)
+        TD_HALF(1, true, 2 * G, -1, -1, false)
+        TD_HALF(2, true, 2 * G, -1, -1, false)
+        TD_HALF(3, true, 2 * G, -1, -1, false)
     }
     // the last four half chunks: nothing left to fetch; the hook's loads are younger than every DMA
-    TD_HALF(0, false, 8 + 4 * HL, 0, 1, false)
-    TD_HALF(1, false, 4 + 12 * HL, 2, 3, false)
+    TD_HALF(0, false, 2 * G + 4 * HL, 0, 1, false)
+    TD_HALF(1, false, G + 12 * HL, 2, 3, false)
     TD_HALF(2, false, 20 * HL, 4, 5, false)
     TD_HALF(3, false, 0, 6, 7, true)
 #undef TD_HALF
 #undef TD_DMA
 #undef TD_RD
+#undef TD_RDB1
 #undef TD_MMA4
 #undef TD_FENCE
 #undef TD_WAIT_BARRIER
@@ -186,10 +193,11 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
     return true;
 }
 
+template <int NJ>
 __device__ __forceinline__ void nsvd_tile128_dma(const float* a_base, const float* b_base, unsigned a_ld, unsigned b_ld,
-                                                 int nch, float* lds, f32x16 (&acc)[2][2]) {
+                                                 int nch, float* lds, f32x16 (&acc)[2][NJ]) {
     Tile128NoHook none;
-    nsvd_tile128_dma(a_base, b_base, a_ld, b_ld, nch, lds, acc, none);
+    nsvd_tile128_dma<Tile128NoHook, NJ>(a_base, b_base, a_ld, b_ld, nch, lds, acc, none);
 }
 
 }  // namespace nsvd_pmlp
