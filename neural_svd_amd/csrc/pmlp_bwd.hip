@@ -862,7 +862,7 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         return 0;
     }
     wa.tw = 128;
-    if (wa.S == 1 && wa.nA <= 128) {  // 128 x 64 tiles: twice as many, half as long
+    if (wgrad_tile_width(wa.nA, wa.S) == 64) {  // 128 x 64 tiles: twice as many, half as long (pmlp_common.h)
         wa.tw = 64;
         wa.nA *= 2;
     }

@@ -95,20 +95,29 @@ struct FusedWs {
     size_t bytes;
 };
 
-// Batch slices of the weight-gradient contraction (split-K with a second pass, wgrad_reduce_kernel, that adds the
-// slices in order and applies the optimizer). The second pass moves the whole parameter set once more, so a split
-// pays only while it is cheap next to the tiles it parallelises. Measured on MI355X (us per training step at 1 / 2 /
-// 4 slices): 128 dW_0 tiles, B = 512: 237 / 249 / -; 128 tiles, B = 1024: 466 / 472 / -; 64 tiles, B = 512:
-// 142 / 138 / -; 64 tiles, B = 4096: 916 / 824 / 780; 32 tiles, B = 1024: 175 / 145 / 135. Hence: double while
-// fewer than half the CUs have a tile, and beyond that only while a slice still keeps 1024 rows; a slice never
-// drops under 256 rows (8 chunks, to amortise a tile's prologue and epilogue).
+// Shape of the layer-0 weight-gradient work: dW_0 tiles of 128 hidden units x `tw` features, the batch contraction cut
+// into S slices (split-K with a second pass, wgrad_reduce_kernel, that adds the slices in order and applies the
+// optimiser). Measured on MI355X, us per training step (oscillator model, (L, m, B); nA = 128-wide tile count):
+//   (S, tw) =            (1,128) (1,64) (2,128) (2,64) (4,128) (4,64)
+//   (32, 256, 1024) nA 128  462    443    469     473    483     483
+//   (16, 256,  512) nA  64  134    119    139     134    139     143
+//   (16, 256, 4096) nA  64  880    782    822     778    780     784
+//   ( 4, 1024, 1024) nA 64  280    249    258     253    251     257
+//   ( 8, 256, 1024) nA  32  163    133    141     130    137     129
+//   ( 2, 1024, 4096) nA 32  465    351    354     299    301     293
+// Hence: 64-wide tiles whenever that still leaves at most 256 of them (twice the tiles at no cost: no second pass);
+// the batch is doubled into slices only while fewer than half the CUs have a tile, and beyond that only while a slice
+// still keeps 1024 rows (the second pass moves the whole parameter set once more); a slice never drops under 256
+// rows (8 chunks, to amortise a tile's prologue and epilogue).
+inline int wgrad_tile_width(int nA128, int S) { return nA128 * S <= 128 ? 64 : 128; }
 inline int wgrad_slices(const nsvd_model_desc& d, int B) {
     const int nA = (2 * d.m / HID) * d.L;
     int S = 1;
     for (;;) {
         const int rows = B / (2 * S);  // rows per slice after one more doubling
         if (S >= 16 || rows % BK != 0 || rows < 256) break;
-        if (!(nA * S < 128 || (nA * S < 256 && rows >= 1024))) break;
+        const int tiles = nA * S * (128 / wgrad_tile_width(nA, S));
+        if (!(tiles < 128 || (tiles < 256 && rows >= 1024))) break;
         S *= 2;
     }
     return S;
