@@ -105,6 +105,8 @@ struct FusedWs {
 //   ( 4, 1024, 1024) nA 64  280    249    258     253    251     257
 //   ( 8, 256, 1024) nA  32  163    133    141     130    137     129
 //   ( 2, 1024, 4096) nA 32  465    351    354     299    301     293
+// (cfg2 itself, nA 256: 64-wide tiles = 512 of them, two per CU and the small workgroups in a second round: 57.1 us
+// for the kernel against 52.7.)
 // Hence: 64-wide tiles whenever that still leaves at most 256 of them (twice the tiles at no cost: no second pass);
 // the batch is doubled into slices only while fewer than half the CUs have a tile, and beyond that only while a slice
 // still keeps 1024 rows (the second pass moves the whole parameter set once more); a slice never drops under 256
