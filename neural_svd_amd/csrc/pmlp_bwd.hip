@@ -257,6 +257,7 @@ struct WgradArgs {
     float* gscales;
     int nlayers, B, L, F;
     int nA, nB;
+    int hx;  // XCD map of the dW_0 tiles (pick_xcd_remap_wgrad; 0: none)
     int tw;  // features per dW_0 tile: 128, or 64 when that many tiles would leave half the CUs without one (S == 1)
     int bid0;  // first logical block of this launch (the A tiles and the B/C tiles are launched separately)
     // fused RMSprop + EMA epilogue (opt != 0): every gradient element is applied to its parameter in place
@@ -689,9 +690,10 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     if (bid < a.nA * a.S) {
         const int slice = bid / a.nA;
         bid -= slice * a.nA;
-        // heads share an XCD (dz_0[l] stays in that L2) when the tile count allows the remap
-        int unit = bid;
-        if ((a.nA & 7) == 0) unit = (bid & 7) * (a.nA >> 3) + (bid >> 3);
+        // the tiles of an XCD (block id mod 8) share heads and feature tiles: pmlp_common.h
+        int tl, tk;
+        xcd_block_map(bid, a.hx, a.L, a.nA / a.L, tl, tk);
+        const int unit = tl * (a.nA / a.L) + tk;
         // the optimiser state rides under the K loop when the step is fused, nothing else is written and the
         // loop has the four peeled chunks the prefetch hangs on
         const bool pf = a.S == 1 && a.opt && !a.gW[0] && a.Bs >= 4 * BK;
@@ -866,6 +868,7 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         wa.tw = 64;
         wa.nA *= 2;
     }
+    wa.hx = pick_xcd_remap_wgrad(d.L, wa.nA / d.L, wa.tw);
     // One launch: the dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
     // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
     wa.bid0 = 0;

@@ -67,6 +67,23 @@ inline int pick_xcd_remap(int L, int nsb, int F) {
     }
     return pick;
 }
+// the same choice for the dW_0 tiles of the weight-gradient kernel: XCD = (head group) x (feature-tile group); a
+// tile reads dz_0 of its head (128 rows of the batch) and its tw rows of phi^T, and the 32 tiles of an XCD should
+// share as many of those rows as their L2 can keep (cfg2: 4 heads x 8 feature tiles = 3 MB instead of 2 x 16 = 4.5 MB)
+inline int pick_xcd_remap_wgrad(int L, int nkt, int tw) {
+    double best = 1e300;
+    int pick = 0;
+    for (int HX = 1; HX <= 8; HX *= 2) {
+        const int KX = 8 / HX;
+        if (L % HX != 0 || nkt % KX != 0) continue;
+        const double rows = (double)(L / HX) * HID + (double)(nkt / KX) * tw;
+        if (rows < best) {
+            best = rows;
+            pick = HX;
+        }
+    }
+    return pick;
+}
 __device__ __forceinline__ void xcd_block_map(int block, int HX, int L, int nsb, int& l, int& sb) {
     if (HX) {
         const int SX = 8 / HX;
