@@ -257,6 +257,7 @@ struct WgradArgs {
     float* gscales;
     int nlayers, B, L, F;
     int nA, nB;
+    int npp, ipw;  // pmlp_wgrad_pp_kernel: its 8-wave workgroups (one per CU) and their dW_0 tiles each
     int hx;  // XCD map of the dW_0 tiles (pick_xcd_remap_wgrad; 0: none)
     int tw;  // features per dW_0 tile: 128, or 64 when that many tiles would leave half the CUs without one (S == 1)
     int bid0;  // first logical block of this launch (the A tiles and the B/C tiles are launched separately)
@@ -764,6 +765,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
 #undef WG_ST
 
 #include "pmlp_wgrad_pipe.h"
+#include "pmlp_wgrad_pp.h"
 
 }  // namespace
 
@@ -862,6 +864,29 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
             hipLaunchKernelGGL(pmlp_wgrad_pipe_kernel<false>, dim3(grid), dim3(PIPE_THREADS), PIPE_LDS_BYTES, s, wa);
         NSVD_CHECK_LAUNCH();
         return 0;
+    }
+    // the alternating-group kernel (pmlp_wgrad_pp.h): fused step without stored gradients on shapes it takes
+    static const bool use_pp = getenv("NSVD_WGRAD_PP") != nullptr;
+    if (use_pp && opt && !g.W[0]) {
+        static int pp_cu = 0;
+        if (pp_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+                v = 256;
+            pp_cu = v;
+        }
+        const int ipw = pp_items_per_wg(d, B, wa.S, pp_cu);
+        if (ipw) {
+            wa.npp = pp_cu;
+            wa.ipw = ipw;
+            wa.hx = pick_xcd_remap_wgrad(d.L, F / (64 * ipw), 64 * ipw);
+            const dim3 grid(wa.npp + wa.nB + 4 * d.L);
+            if (opt->ema) hipLaunchKernelGGL(pmlp_wgrad_pp_kernel<true>, grid, dim3(PP_THREADS), 0, s, wa);
+            else hipLaunchKernelGGL(pmlp_wgrad_pp_kernel<false>, grid, dim3(PP_THREADS), 0, s, wa);
+            NSVD_CHECK_LAUNCH();
+            return 0;
+        }
     }
     wa.tw = 128;
     if (wgrad_tile_width(wa.nA, wa.S) == 64) {  // 128 x 64 tiles: twice as many, half as long (pmlp_common.h)

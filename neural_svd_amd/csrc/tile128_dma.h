@@ -60,7 +60,7 @@ template <class Hook, int NJ>
 __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const float* b_base, unsigned a_ld, unsigned b_ld,
                                                  int nch, float* lds, f32x16 (&acc)[2][NJ], Hook& hook) {
     static_assert(NJ == 1 || NJ == 2, "B operand: 64 or 128 rows");
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;  // four waves; a larger workgroup may run the routine in one of its wave groups
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hi = lane >> 5;
