@@ -22,8 +22,11 @@
 // routine), NOT faster: 53.2 us against 53.0 at cfg2. Timeline (stamps, us): tile 0's loops 0.6 -> 15.8-17.7 (as
 // projected); tile 1's loops -> 35.2-42.3, i.e. 19-24 us instead of 16.6 - the other group's optimiser traffic and its
 // barrier arrivals cost the loop what the hidden epilogue saved; the last tile's step, alone, -> 38.8-49.4; the dW_i
-// quadrants crawl beside two back-to-back loops and end at 47.8-50.8. What it would take: quadrants on the DMA ring
-// inside 128 VGPRs, the last step split over both groups, and units short enough never to be late at a barrier.
+// quadrants crawl beside two back-to-back loops and end at 47.8-50.8. Without the small workgroups (timing only)
+// this kernel takes 50.0 us where the tile kernel takes 45.5: overlapping half of the optimiser traffic with a K loop
+// slows that loop - its operand stream shares the fabric, and every barrier waits for the storing group - by about
+// what the hidden half saved. The 32 us of the timing-only build without any epilogue is therefore not what an
+// overlap can reach; kept as the measured counter-example, not as a candidate.
 #pragma once
 
 constexpr int PP_THREADS = 512;
