@@ -22,7 +22,7 @@ NORMALIZE_L2_BALL, NORMALIZE_L2_SPHERE = 0, 1
 FEATURES_READY = 0x100
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-# NSVD_LIB_PATH: diagnostic builds only (e.g. the stamped kernels of scripts/dev_stamps.py)
+# NSVD_LIB_PATH: diagnostic builds only (e.g. the stamped kernels of scripts/dev/stamps.py)
 LIB_PATH = os.environ.get("NSVD_LIB_PATH") or os.path.join(_PKG_DIR, "libnsvd_hip.so")
 
 

@@ -236,12 +236,23 @@ class TowerSequential(nn.Sequential):
     -> 512) runs on the HIP tower kernels. Evaluation mode (running statistics) and other shapes use the modules
     themselves (torch's library kernels)."""
 
-    def __init__(self, *mods, slope: float):
+    def __init__(self, *mods, slope: float = 0.0):
         super().__init__(*mods)
         self.slope = float(slope)
 
+    def __getitem__(self, idx):
+        # a slice of the tower is no longer "the tower": plain nn.Sequential over the same modules
+        if isinstance(idx, slice):
+            return nn.Sequential(*list(self._modules.values())[idx])
+        return super().__getitem__(idx)
+
     def hip_ready(self, x) -> bool:
         lin1, bn1, lin2, bn2 = self[0], self[1], self[3], self[4]
+        # the tower kernels produce no gradient for their input (nsvd_tower_backward): behind a trainable module
+        # (a backbone in front of a projector, siam.py:156-166) the torch modules run instead, so that the gradient
+        # reaches everything upstream
+        if torch.is_grad_enabled() and x.requires_grad:
+            return False
         return (self.training and x.is_cuda and x.dim() == 2 and bn1.momentum is not None and bn1.eps == bn2.eps
                 and bn1.momentum == bn2.momentum and bn1.affine and bn2.affine
                 and lin1.weight.dtype == torch.float32

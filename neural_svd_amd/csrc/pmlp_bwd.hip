@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 //                        longer workgroups next to the dW_0 tiles.)
 //   C  (4 L):            dW_last[l][n] = sum_b dbase[b] softplus(z_{nh-1}[l][n][b]), db_last, d scales, and
 //                        db_0[l][n] = sum_b dz_0[l][n][b] for the same 32 rows.
-// Timeline at cfg2 (NSVD_WG_STAMPS build, scripts/dev_wgrad_stamps.py), fused optimiser step: the A tiles run
+// Timeline at cfg2 (NSVD_WG_STAMPS build, scripts/dev/wgrad_stamps.py), fused optimiser step: the A tiles run
 // their K loop in 70-79 K cycles (65.5 K of MFMA issue; 69.7 K with nothing else on the chip) and their
 // epilogue - RMSprop + EMA on the tile, 112 MB through HBM for the whole kernel, the state of half of each tile
 // already in registers (fetched under the last two chunks of the loop) - in 22-26 K, ending at 38-48 us; the B
@@ -257,7 +257,6 @@ struct WgradArgs {
     float* gscales;
     int nlayers, B, L, F;
     int nA, nB;
-    int npp, ipw;  // pmlp_wgrad_pp_kernel: its 8-wave workgroups (one per CU) and their dW_0 tiles each
     int hx;  // XCD map of the dW_0 tiles (pick_xcd_remap_wgrad; 0: none)
     int tw;  // features per dW_0 tile: 128, or 64 when that many tiles would leave half the CUs without one (S == 1)
     int bid0;  // first logical block of this launch (the A tiles and the B/C tiles are launched separately)
@@ -764,9 +763,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
 #undef WG_LD
 #undef WG_ST
 
-#include "pmlp_wgrad_pipe.h"
-#include "pmlp_wgrad_pp.h"
-
 }  // namespace
 
 
@@ -836,58 +832,6 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
         }
         wa.poscales = pl.oscales;
     }
-    // Experimental (NSVD_WGRAD_PIPE=1, read once; off by default): the persistent pipelined kernel of
-    // pmlp_wgrad_pipe.h, one 8-wave workgroup per CU. Correct (the whole GPU suite passes with it) but, as measured,
-    // slower than the tile kernel below: see the header and DESIGN.md.
-    static const bool use_pipe = getenv("NSVD_WGRAD_PIPE") != nullptr;
-    if (use_pipe && pipe_wgrad_ok(d, B, wa.S)) {
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-                v = 256;
-            const void* k1 = (const void*)pmlp_wgrad_pipe_kernel<true>;
-            const void* k0 = (const void*)pmlp_wgrad_pipe_kernel<false>;
-            hipError_t e = hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES);
-            if (e != hipSuccess) return -(int)e;
-            n_cu = v;
-        }
-        const int n_items = 2 * wa.nA + 8 * (d.nlayers - 2) * d.L;
-        const int grid = n_items < n_cu ? n_items : n_cu;
-        const bool ema = opt && opt->ema;
-        if (ema)
-            hipLaunchKernelGGL(pmlp_wgrad_pipe_kernel<true>, dim3(grid), dim3(PIPE_THREADS), PIPE_LDS_BYTES, s, wa);
-        else
-            hipLaunchKernelGGL(pmlp_wgrad_pipe_kernel<false>, dim3(grid), dim3(PIPE_THREADS), PIPE_LDS_BYTES, s, wa);
-        NSVD_CHECK_LAUNCH();
-        return 0;
-    }
-    // the alternating-group kernel (pmlp_wgrad_pp.h): fused step without stored gradients on shapes it takes
-    static const bool use_pp = getenv("NSVD_WGRAD_PP") != nullptr;
-    if (use_pp && opt && !g.W[0]) {
-        static int pp_cu = 0;
-        if (pp_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-                v = 256;
-            pp_cu = v;
-        }
-        const int ipw = pp_items_per_wg(d, B, wa.S, pp_cu);
-        if (ipw) {
-            wa.npp = pp_cu;
-            wa.ipw = ipw;
-            wa.hx = pick_xcd_remap_wgrad(d.L, F / (64 * ipw), 64 * ipw);
-            const dim3 grid(wa.npp + wa.nB + 4 * d.L);
-            if (opt->ema) hipLaunchKernelGGL(pmlp_wgrad_pp_kernel<true>, grid, dim3(PP_THREADS), 0, s, wa);
-            else hipLaunchKernelGGL(pmlp_wgrad_pp_kernel<false>, grid, dim3(PP_THREADS), 0, s, wa);
-            NSVD_CHECK_LAUNCH();
-            return 0;
-        }
-    }
     wa.tw = 128;
     if (wgrad_tile_width(wa.nA, wa.S) == 64) {  // 128 x 64 tiles: twice as many, half as long (pmlp_common.h)
         wa.tw = 64;
@@ -933,12 +877,6 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
 #ifdef NSVD_WG_STAMPS
 extern "C" int nsvd_debug_wgrad_stamps(unsigned long long* host, size_t n) {
     return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), n * sizeof(unsigned long long));
-}
-extern "C" int nsvd_debug_pipe_stamps(unsigned long long* host, size_t n) {
-    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe_stamps), n * sizeof(unsigned long long));
-}
-extern "C" int nsvd_debug_pipe_chunk_stamps(unsigned long long* host, size_t n) {
-    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe_chunk_stamps), n * sizeof(unsigned long long));
 }
 #endif
 

@@ -1,7 +1,6 @@
 // Shared by the two translation units of the fused MFMA path (pmlp_fwd.hip, pmlp_bwd.hip): tile constants, the
 // accumulator layout of v_mfma_f32_32x32x2_f32, and the workspace layout.
 #pragma once
-#include <stdlib.h>
 #include <string.h>
 #include "nsvd_kernels.h"
 

@@ -194,8 +194,13 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     all_eigvals, all_norms = [], []
     start = time.time()
     # the reference adds loss.item() to a host total on EVERY step (operator/__init__.py:74,99: a device sync per
-    # step); here the running total lives on the device and is read at print time only
+    # step); here the running total lives on the device and is read at print time only. The fused loop's backward
+    # kernel does not produce the loss scalars (it takes the moments it needs straight from f), so there the loss is
+    # evaluated (one extra launch) on every `loss_stride`-th step and at print time only: `avg_train_loss` is then the
+    # mean over those sampled steps - args.loss_every_step = True restores the every-step mean at one launch per step
     total_loss = torch.zeros((), dtype=torch.float64, device=device)
+    n_loss = 0
+    loss_stride = 1 if getattr(args, "loss_every_step", False) else max(1, int(args.print_freq) // 16)
     for it in range(args.num_iters):
         x = make_batch_ftn_train().to(device)
         x = x.reshape(x.shape[0], -1)
@@ -203,8 +208,10 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
             fused = None  # the sampler does not produce args.batch_size rows: the plain loop takes any batch
         if fused is not None:
             fused.step(x.float().contiguous())
-            loss = fused.loss[0]  # evaluated on the device from this step's f, Tf (no sync)
-            total_loss += loss
+            if (it + 1) % loss_stride == 0 or (it + 1) % args.print_freq == 0:
+                loss = fused.loss[0]  # evaluated on the device from this step's f, Tf (no sync)
+                total_loss += loss
+                n_loss += 1
         else:
             method.train()
             optimizer.zero_grad()
@@ -215,9 +222,10 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                 scheduler.step()
             ema.update()
             total_loss += loss.detach()
+            n_loss += 1
         if (it + 1) % args.print_freq == 0:
             # the only host sync, and only at print time (the reference syncs every step)
-            row = {"iter": it + 1, "train_loss": float(loss), "avg_train_loss": float(total_loss) / (it + 1),
+            row = {"iter": it + 1, "train_loss": float(loss), "avg_train_loss": float(total_loss) / n_loss,
                    "time": time.time() - start}
             print(row)
             if log_writer is not None:

@@ -325,7 +325,9 @@ class FusedTrainer:
 
     # -- the step -----------------------------------------------------------------------------
     def forward_backward(self, x: torch.Tensor, features_ready: bool = False, take_step: bool = True) -> None:
-        """forward + exchange + loss + backward (+ the optimiser step; take_step=False: gradients only)."""
+        """forward + exchange + loss + backward (+ the optimiser step). take_step=False: gradients only - with
+        samples sharded over several ranks these are THIS RANK'S gradients of the global loss (the moments are
+        exchanged, the gradient buffer is not: sum P.grad over the ranks for the global gradient)."""
         from . import parallel
         self._features_ready = bool(features_ready)
         with torch.cuda.device(self.device):
@@ -361,7 +363,8 @@ class FusedTrainer:
         """One optimiser step on the internal sampler's next batch, or on ``x`` (tests, external samplers)."""
         self._own_batch = x is None and self.device_sampler
         if x is not None:
-            self._next_ready = False  # an externally supplied batch: drop any batch prepared ahead
+            # an externally supplied batch; a batch prepared ahead (overlap) stays in the other set and is consumed by
+            # the next internal step, so that the sampler's stream is the same with and without overlap
             self.forward_backward(x)
         elif self.device_sampler:
             # one launch draws the batch and writes its features; the forward then skips the feature stage

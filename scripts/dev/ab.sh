@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev (GPU box): kernel-level A/B of the backward pair: per-kernel average durations from rocprofv3 --kernel-trace --stats
 # of a short bench run, for the default build and with the environment switches given as arguments, e.g.
-#   bash scripts/dev_ab.sh tag NSVD_WGRAD_TILES=1
+#   bash scripts/dev/ab.sh tag NSVD_WGRAD_TILES=1
 tag=${1:-ab}; shift
 out=/root/repo/gpurun_out/$tag
 mkdir -p $out

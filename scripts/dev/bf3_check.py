@@ -1,6 +1,6 @@
 """dev: bf16x3 layer 0 (NSVD_PATH_FUSED_BF16X3) against the native fp32 MFMA path and the float64 oracle at cfg2."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from neural_svd_amd import hip_ops as H
 from oracle import nsvd_oracle as O

@@ -1,6 +1,6 @@
 """dev: time the CDK loss forward / backward at the reference's size (B=1024, L=512)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from neural_svd_amd import hip_ops as H
 from neural_svd_amd.nested_lowrank import get_joint_nesting_masks, joint_step_weights

@@ -1,6 +1,6 @@
 """dev: time the pieces of the kernel-operator step (cfg4: N=10000 points, B=8192 indices, L=64)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from types import SimpleNamespace as NS
 import torch
 from neural_svd_amd import hip_ops as H

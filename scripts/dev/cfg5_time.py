@@ -2,7 +2,7 @@
 lrelu0.2, mu = 16 l2_ball, L = 512, batch 1024, SGD 5e-3 momentum 0.9) through this package's mirrors, float32 and
 under torch.autocast(float16) (the script's AMP): where the time goes."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn as nn
 from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
 dev = "cuda:0"

@@ -1,7 +1,7 @@
 """dev: steps/s of the reference-style loop (get_problem / get_wavefunctions / get_evd_method / compute_loss_operator /
 torch RMSprop / cosine / EMA, i.e. drop_in.train_operator's body) at configs[1], next to FusedTrainer's."""
 import argparse, os, sys, time, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from neural_svd_amd.drop_in import ExponentialMovingAverage, get_optimizer
 from neural_svd_amd.models import get_wavefunctions

@@ -1,6 +1,6 @@
 """dev helper (GPU): run only the fused forward N times (for rocprofv3 --pmc runs)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from neural_svd_amd import hip_ops as H
 from neural_svd_amd.trainer import reference_init

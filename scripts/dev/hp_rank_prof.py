@@ -1,6 +1,6 @@
 """dev: run the per-rank head-parallel compute for one world size N (argv[1]) for profiling under rocprofv3."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from neural_svd_amd import hip_ops as H
 from neural_svd_amd.trainer import FusedTrainer

@@ -1,6 +1,6 @@
 """dev: per-rank compute of the head-parallel step at world N, emulated on one GPU (L/N heads on 512 N rows)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from neural_svd_amd import hip_ops as H
 from neural_svd_amd.trainer import FusedTrainer

@@ -1,6 +1,6 @@
 """dev: find the first step at which the cfg2 training run produces non-finite values, and where."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from neural_svd_amd import hip_ops as H
 from neural_svd_amd.trainer import FusedTrainer

@@ -2,7 +2,7 @@
 with one rank, but the backend's support for every call the multi-GPU step makes is exercised (ReduceOp.AVG, async
 all-reduce on slices of a flat buffer, all_gather_into_tensor, broadcast, device_id init)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
 import torch
 from neural_svd_amd import parallel

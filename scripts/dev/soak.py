@@ -1,6 +1,6 @@
 """dev: 10 000 optimiser steps on a matrix of configurations; reports finiteness, loss trend and speed."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from neural_svd_amd import hip_ops as H
 from neural_svd_amd.trainer import FusedTrainer

@@ -1,7 +1,7 @@
 """diagnostic (GPU): per-phase cycle shares of the fused forward from s_memtime stamps.
-   NSVD_LIB_PATH=scripts/_diag/libnsvd_hip_stamps.so python scripts/dev_stamps.py"""
+   NSVD_LIB_PATH=scripts/_diag/libnsvd_hip_stamps.so python scripts/dev/stamps.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 from neural_svd_amd import hip_ops as H
 from neural_svd_amd.trainer import reference_init

@@ -1,6 +1,6 @@
 """dev: timeline of the wgrad kernel's blocks from the NSVD_WG_STAMPS diagnostic build."""
 import sys, os, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from neural_svd_amd import hip_ops as H, _lib
 from neural_svd_amd.trainer import FusedTrainer

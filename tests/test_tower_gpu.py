@@ -102,3 +102,29 @@ def test_tower_headline_size_against_oracle_and_library():
     ref = torch.nn.Sequential.forward(m, x)
     assert rel(out, ref.detach()) < 2e-5
     assert not m.eval().hip_ready(x)
+
+
+def test_tower_behind_a_trainable_module_passes_the_gradient_upstream():
+    """A tower used as a projector behind a backbone (reference siam.py:156-166 allows any backbone): its input requires
+    a gradient, which the tower kernels do not produce - the torch modules must run then, and x.grad must be the
+    library's. Slicing the tower gives a plain nn.Sequential."""
+    from neural_svd_amd.cdk import TowerSequential, get_mlp
+    torch.manual_seed(7)
+    m = get_mlp([128, 256, 128], bias=True, nonlinearity="lrelu0.2", use_bn=True).to(DEV).train()
+    assert isinstance(m, TowerSequential)
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randn(128, 128, generator=g).to(DEV)
+    dz = torch.randn(128, 128, generator=g).to(DEV)
+    assert m.hip_ready(x0)
+    x = x0.clone().requires_grad_(True)
+    assert not m.hip_ready(x)
+    (m(x) * dz).sum().backward()
+    got = x.grad.clone()
+    x2 = x0.clone().requires_grad_(True)
+    m.zero_grad()
+    (torch.nn.Sequential.forward(m, x2) * dz).sum().backward()
+    assert got is not None and rel(got, x2.grad) < 1e-6
+    with torch.no_grad():
+        assert m.hip_ready(x)  # no graph is being recorded: nothing to cut
+    head = m[:3]
+    assert type(head) is torch.nn.Sequential and len(head) == 3 and head[0] is m[0]
