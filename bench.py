@@ -3,13 +3,16 @@
 joint nesting (BASELINE.json configs[1]); synthetic Gaussian-sampled coordinate batches, reference
 initialisation (random weights of the real architecture).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N rank processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = sample x ~ N(0, 16^2 I) on the device -> operator forward (5 stencil evaluations of the
 16-headed MLP + FD Hamiltonian) -> EVD loss -> backward -> RMSprop(+cosine LR) -> EMA, all HIP kernels.
 N > 1: samples sharded (dp), every rank draws its own 512 rows (weak scaling, global batch 512 N), one
-all-reduce of the 2L^2+1 moment floats and a bucketed all-reduce of the flat gradient per step over RCCL; the
+all-reduce of the 2L^2+1 moment floats and a bucketed exchange of the flat gradient per step over RCCL (the exchange
+algorithm - all-reduce or reduce-scatter / all-gather, with or without head windows of the backward - is timed briefly
+and the fastest one takes the headline run: `comm.candidates`); the `comm` block carries the exposed wait of every
+collective (events on the compute stream) and the same step with the collectives skipped (`compute_only_ms`); the
 head-sharded split (hp) and configs[2] are timed beside it as side fields of the same JSON line.
 Timing: a declared prewarm (>= 1 s of real steps, whatever the step arguments), W warm-up steps, then several
 blocks of EXACTLY K steps (barrier + synchronize on both sides, max over ranks); `value` is the median block.
@@ -144,7 +147,7 @@ def cpu_baseline(seconds_budget=28.0, min_steps=24, max_steps=200):
                        f"physical cores / {logical} logical CPUs); torch {torch.__version__} CPU eager")
 
 
-def make_trainer(cfg, par, comm, dev, path):
+def make_trainer(cfg, par, comm, dev, path, dp_exchange="allreduce", grad_windows=None):
     from neural_svd_amd import hip_ops as H
     from neural_svd_amd.trainer import FusedTrainer
     osc = cfg["potential"] == "oscillator"
@@ -154,7 +157,8 @@ def make_trainer(cfg, par, comm, dev, path):
     tr = FusedTrainer(shape, prob, cfg["B"], parallelism=par, sequential=cfg["sequential"], lr=cfg["lr"],
                       rmsprop_decay=cfg["alpha"], ema_decay=cfg["ema_decay"], num_iters=cfg["num_iters"],
                       sampling_scale=cfg["sigma"], fourier_scale=cfg["fourier_scale"],
-                      exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev, path=path, comm=comm)
+                      exp_mask_init=cfg["exp_mask_init"], seed=0, device=dev, path=path, comm=comm,
+                      dp_exchange=dp_exchange, grad_windows=grad_windows)
     return tr, shape, prob
 
 
@@ -210,6 +214,188 @@ def summarize(blocks, steps, world):
                 blocks=len(b))
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relay rank 0's JSON line, fail if any rank fails.
+    Runs BEFORE anything touches the GPU in this process (a process that has initialised the GPU must not spawn the
+    ranks by exec, and has no business holding a context on device 0 while they run)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if os.environ.get("NSVD_FORCE_DEVICE") is None:
+        have = torch.cuda.device_count()  # counts devices without creating a context
+        if have < n:
+            raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    raise RuntimeError(f"rank {r} exited with code {code}")
+            if time.time() > deadline:
+                rc = 124
+                raise RuntimeError(f"ranks still running after --launch-timeout {args.launch_timeout:.0f} s")
+            if pending:
+                time.sleep(0.2)  # (rank 0 prints one line at the very end: nothing to drain while it runs)
+    except RuntimeError as e:
+        for q in procs:  # exactly the processes started above
+            if q.poll() is None:
+                q.kill()
+        sys.stderr.write(f"bench.py: {e}\n")
+        raise SystemExit(rc or 1)
+    out = procs[0].stdout.read()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n" + out[-2000:])
+        raise SystemExit(1)
+    print(lines[-1])
+
+
+def _timed_blocks(step, steps, warmup, repeats, prewarm_s, bracket=None, every=4):
+    """the protocol of run_timed for a plain callable: prewarm, warm-up, `repeats` blocks of exactly `steps` steps;
+    bracket(ev0, ev1) arms the one-shot kernel bracket before every `every`-th step"""
+    t0 = time.perf_counter()
+    n_pre = 0
+    while time.perf_counter() - t0 < prewarm_s:
+        for _ in range(10):
+            step()
+        n_pre += 10
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    evs, blocks = [], []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            if bracket is not None and i % every == 0:
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                bracket(*e)
+                evs.append(e)
+            step()
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t1)
+    kms = sorted(a.elapsed_time(b) for a, b in evs)
+    return blocks, kms, n_pre
+
+
+def bench_widened(args):
+    """--config cfg4 / cfg5: the widened rows of SURVEY 8(f), one GPU, through this package's mirrors of the reference
+    API (the step the reference's scripts would run), with the dominant contraction bracketed by events inside the C
+    call. cfg4 = BASELINE configs[3]: dense PSD kernel operator on 10 000 points, L = 64, B = 8192 indices,
+    NestedLoRA.compute_loss_kernel + RMSprop (reference methods/nestedlora.py:230-252; no reference operator exists).
+    cfg5 = BASELINE configs[4]: CDK step on synthetic (1024, 512) features: two towers 512 -> 8192 -> 512
+    (BatchNorm, lrelu0.2), l2_ball normalisation, NestedLoRAForCDK loss L = 512 + constant mode, SGD momentum
+    (reference examples/cdk/sketchy/main_sketchy.py:180-212)."""
+    from types import SimpleNamespace as NS
+    from neural_svd_amd import hip_ops as H
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    steps = min(args.steps, 200)
+    warmup = min(args.warmup, 20)
+    repeats = args.repeats or 5
+    if args.config == "cfg4":
+        from neural_svd_amd.kernel_ops import synthetic_psd_kernel
+        from neural_svd_amd.models import get_wavefunctions
+        from neural_svd_amd.nested_lowrank import get_evd_method
+        N, D, L, B = 10000, 16, 64, args.batch_size or 8192
+        op = synthetic_psd_kernel(N, 256, D, 0, dev)
+        margs = NS(ndim=D, n_particles=1, use_fourier_feature=True, fourier_mapping_size=64, fourier_scale=0.05,
+                   fourier_deterministic=False, fourier_append_raw=False, mlp_hidden_dims="128,128", neigs=L,
+                   parallel=1, nonlinearity="softplus", apply_exp_mask=0, exp_mask_init_scale=1.0, hard_mul_const=1.0,
+                   apply_boundary=0, sort=0, loss=NS(neuralsvd=NS(step=1, sequential=False)))
+        torch.manual_seed(0)
+        method = get_evd_method(margs, "neuralsvd", op.index_model(get_wavefunctions(margs).to(dev))).to(dev)
+        opt = torch.optim.RMSprop(method.parameters(), lr=1e-4)
+        g = torch.Generator(device=dev).manual_seed(1)
+        last = {}
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss, _ = method.compute_loss_kernel(op.get_approx_kernel_op, op.sample_indices(B, g), None,
+                                                 split_batch=False)
+            loss.backward()
+            opt.step()
+            last["loss"] = loss.detach()
+        kflops = 2.0 * B * B * L  # SURVEY 8(d): the B x B . B x L contraction (the kernel runs it as B x N . N x L)
+        kname = "ka_gemm_kernel"
+        workload = (f"configs[3]: dense PSD kernel operator K = A A^T / 256 + 1e-3 I on N = {N} points in R^16, "
+                    f"L = {L}, batch {B} indices with replacement, NestedLoRA.compute_loss_kernel(split_batch=False) "
+                    f"on a 2 x 128 softplus ParallelMLP, torch RMSprop")
+        metric = "training steps/sec, synthetic dense kernel operator L=64 B=8192 (NestedLoRA kernel path)"
+        note = ("Kf = K[x][:, x] f / B by nsvd_kernel_apply (batch scattered into the index space, gathered rows of K "
+                "against it on the fp32 MFMA); model forward / backward on the E = 1 MFMA kernels; loss kernels; "
+                "the loop around them is the reference-style Python loop")
+    else:
+        import torch.nn as nn
+        from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
+        B, d0, d1, d2, L = args.batch_size or 1024, 512, 8192, 512, 512
+        torch.manual_seed(0)
+        sizes = [d0, d1, d2]
+        model = HeteroNetwork([get_mlp(sizes, nonlinearity="lrelu0.2"), get_mlp(sizes, nonlinearity="lrelu0.2")],
+                              [nn.Identity(), nn.Identity()], mu=16.0, regularize_mode="l2_ball").to(dev)
+        method = NestedLoRAForCDK(model, neigs=L, step=1, sequential=False, set_first_mode_const=True).to(dev)
+        opt = torch.optim.SGD(method.parameters(), lr=5e-3, momentum=0.9)
+        x, y = torch.randn(B, d0, device=dev), torch.randn(B, d0, device=dev)
+        last = {}
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            _, fx, _, fy = method(x, y)
+            loss = method.compute_loss(fx, fy)[0]
+            loss.backward()
+            opt.step()
+            last["loss"] = loss.detach()
+        kflops = 2.0 * B * d0 * d1
+        kname = "tower_gemm_nt_kernel"
+        workload = (f"configs[4]: CDK step on synthetic features x, y ~ randn({B}, {d0}): two towers {d0} -> {d1} -> "
+                    f"{d2} (Linear-BatchNorm-lrelu0.2-Linear-BatchNorm), l2_ball mu = 16, NestedLoRAForCDK L = {L} + "
+                    f"constant mode, joint nesting, SGD lr 5e-3 momentum 0.9")
+        metric = "training steps/sec, CDK two-tower step L=512 B=1024 (NestedLoRA CDK path)"
+        note = ("towers on csrc/tower.hip (five fp32-MFMA contractions + BatchNorm strip kernels each, forward + "
+                "backward), normalisation and CDK loss on their HIP kernels; torch autograd + torch.optim.SGD around them")
+    use_ev = not args.no_kernel_events
+    blocks, kms, n_pre = _timed_blocks(step, steps, warmup, repeats, args.prewarm_seconds,
+                                       H.profile_next_forward if use_ev else None)
+    summ = summarize(blocks, steps, 1)
+    roof = None
+    if kms:
+        kavg = sum(kms) / len(kms)
+        ach = kflops / (kavg * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, kernel=kname,
+                    kernel_avg_us=round(kavg * 1e3, 2), kernel_med_us=round(kms[len(kms) // 2] * 1e3, 2),
+                    kernel_launches_timed=len(kms), kernel_flops=kflops)
+    out = {"metric": metric, "value": summ["value"], "unit": "steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "timing": {"blocks": summ["blocks"], "ms_per_step_min": summ["ms_per_step_min"],
+                      "ms_per_step_max": summ["ms_per_step_max"], "prewarm_steps": n_pre},
+           "config": {"workload": workload, "note": note, "developer_config": args.config,
+                      "not_the_headline_workload": True},
+           "final_loss": float(last["loss"]), "roofline": roof, "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,12 +415,29 @@ def main():
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--laplacian-eps", type=float, default=None,
                     help="developer option: override the config's finite-difference eps (<= 0: exact Laplacian)")
-    ap.add_argument("--config", default="cfg2", choices=sorted(ALT))
+    ap.add_argument("--config", default="cfg2", choices=sorted(ALT) + ["cfg4", "cfg5"],
+                    help="cfg2 = the headline workload; cfg1 / cfg3: the other PDE configurations; cfg4 / cfg5: the "
+                         "widened rows (dense kernel operator step; CDK towers + loss step), one GPU")
+    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "allreduce", "rs_ag"],
+                    help="N > 1, dp: gradient exchange (auto: each candidate is timed briefly, the fastest one takes "
+                         "the headline run; all of them are reported in comm.candidates)")
+    ap.add_argument("--grad-windows", type=int, default=None,
+                    help="N > 1, dp: head windows of the backward (default: chosen per candidate)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 without a launcher: seconds before the rank processes are given up on")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "hp"],
                     help="N > 1: dp = samples sharded (moments + bucketed gradient all-reduce: north_star's split, the "
                          "headline); hp = heads sharded (one all-gather of f, Tf, no gradient traffic). The other one "
                          "is reported beside it as a side measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the launcher (nothing has touched the GPU yet) and never computes
+        return self_launch(args, sys.argv[1:])
+    if args.config in ("cfg4", "cfg5"):
+        if args.gpus != 1:
+            raise SystemExit(f"--config {args.config} is a single-GPU measurement")
+        return bench_widened(args)
 
     from neural_svd_amd import hip_ops as H
     from neural_svd_amd import parallel
@@ -242,10 +445,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     # NSVD_FORCE_DEVICE / NSVD_DIST_BACKEND: developer aid to exercise the N > 1 code path on a 1-GPU box
     # (all ranks on one device, gloo instead of RCCL); never set by the driver
     if os.environ.get("NSVD_FORCE_DEVICE") is not None:
@@ -266,7 +467,36 @@ def main():
     if par == "hp" and cfg["L"] % world != 0:
         raise SystemExit(f"hp needs L ({cfg['L']}) divisible by the world size ({world})")
     repeats = args.repeats or max(3, min(25, round(6000 / max(args.steps, 1))))
-    tr, shape, prob = make_trainer(cfg, par, comm, dev, path)
+    # N > 1, samples sharded: which gradient exchange? Every candidate is timed with the same protocol (fewer blocks)
+    # and the fastest takes the headline run - the first hardware contact of this code decides, not a guess
+    exchange, windows, cand_report = "allreduce", args.grad_windows, None
+    if world > 1 and par == "dp":
+        if args.dp_exchange != "auto":
+            exchange = args.dp_exchange
+        else:
+            cands = [("allreduce", None), ("rs_ag", None), ("allreduce", 1), ("rs_ag", 1)]
+            cand_report, best = {}, None
+            for ex, gw in cands:
+                name = f"{ex}/" + ("auto_windows" if gw is None else f"{gw}_window")
+                try:
+                    t, _, _ = make_trainer(cfg, par, comm, dev, path, ex, gw)
+                    nwin = len(t._windows)
+                    if gw is None and nwin == 1:
+                        del t
+                        continue  # same thing as the explicit 1-window candidate
+                    bl, _, _, _ = run_timed(t, comm, args.steps, args.warmup, max(3, repeats // 4), 0.5, 0)
+                    d = summarize(bl, args.steps, world)
+                    cand_report[name] = dict(steps_per_s=d["value"], ms_per_step=d["ms_per_step"], windows=nwin,
+                                             buckets=len(t.grad_buckets()))
+                    if best is None or d["value"] > best[0]:
+                        best = (d["value"], ex, gw)
+                    del t
+                    torch.cuda.empty_cache()
+                except Exception as e:  # noqa: BLE001  (constructor refusals are the same on every rank)
+                    cand_report[name] = {"error": f"{type(e).__name__}: {e}"}
+            if best is not None:
+                exchange, windows = best[1], best[2]
+    tr, shape, prob = make_trainer(cfg, par, comm, dev, path, exchange, windows)
 
     use_ev = not args.no_kernel_events
     EV_EVERY = 4  # bracket the dominant kernel on every 4th timed step (two event records cost ~2 us)
@@ -277,6 +507,41 @@ def main():
     finite = bool(torch.isfinite(tr.P.flat).all())
     fused_step, tr_hp, n_train, trB, trL = tr.fused_step, tr.hp, tr.P.n_trainable, tr.B, tr.shape.L
     path_name = H.path_name(tr.shape, tr.B, path, prob)
+    comm_block = None
+    if world > 1:
+        # where the multi-GPU step's time goes: (1) the exposed wait of every collective, from events on the compute
+        # stream around each wait (parallel.CommProbe), over PROBE_STEPS further steps of the same trainer; (2) the
+        # same step with every collective skipped (compute_only_ms; replicas drift apart, which timing does not mind)
+        PROBE_STEPS = 100
+        tr.probe = parallel.CommProbe(dev)
+        for _ in range(PROBE_STEPS):
+            tr.step()
+        waits = tr.probe.summary()
+        tr.probe = None
+        waits_max = {k: round(comm.max_float(v), 2) for k, v in waits.items()}
+        buckets = [int(4 * (hi - lo)) for lo, hi in tr.grad_buckets()] if not tr_hp else []
+        nwin = len(tr._windows)
+        comm.barrier()
+        comm.stub = True
+        bl, _, _, _ = run_timed(tr, comm, args.steps, args.warmup, max(3, repeats // 4), 0.2, 0)
+        comm.stub = False
+        co = summarize(bl, args.steps, world)
+        comm_block = {
+            "backend": comm.backend, "exchange": ("all_gather of f, Tf" if tr_hp else exchange),
+            "backward_windows": nwin, "grad_bucket_bytes": buckets,
+            "moment_floats": 2 * cfg["L"] * cfg["L"] + 1,
+            "exposed_wait_us_per_step": {k: round(v, 2) for k, v in waits.items()},
+            "exposed_wait_us_per_step_max_over_ranks": waits_max,
+            "exposed_wait_us_total": round(sum(waits.values()), 2),
+            "probe_steps": PROBE_STEPS,
+            "compute_only_ms": co["ms_per_step"], "compute_only_steps_per_s": co["value"],
+            "step_ms": summ["ms_per_step"],
+            "note": "exposed wait = time the compute stream sat idle for that collective (two events around each "
+                    "wait on the compute stream, rank 0; max over ranks beside it); compute_only = the same step "
+                    "with every collective skipped",
+            "candidates": cand_report,
+        }
+        rccl_ranks = comm.count_ranks()
     del tr
     torch.cuda.empty_cache()
 
@@ -353,7 +618,9 @@ def main():
                     step_flops=flops_step, step_tflops=round(flops_step / (ms_per_step * 1e-3) / 1e12, 3),
                     step_frac=round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
     sharding = {"dp": "samples: each GPU draws its own 512 rows; all-reduce of the 2L^2+1 moments, then the flat "
-                      "gradient in buckets on head boundaries, optimiser on bucket k under the all-reduce of k+1",
+                      "gradient in buckets (head windows of the backward), " +
+                      ("optimiser on bucket k under the all-reduce of k+1" if exchange == "allreduce" else
+                       "reduce-scatter, optimiser on this rank's 1/N of each bucket, all-gather of the parameters"),
                 "hp": "heads: each GPU owns L/N heads and evaluates them on the whole global batch; one all-gather "
                       "of f,Tf per step, no gradient traffic"}
     out = {
@@ -377,6 +644,9 @@ def main():
         "final_loss": loss, "params_finite": finite,
         "roofline": roof,
     }
+    if world > 1:
+        out["rccl_ranks"] = rccl_ranks
+        out["comm"] = comm_block
     try:  # the other half of BASELINE.json's metric: eigenvalue error after the full schedule (committed run records)
         if not headline:
             raise KeyError("headline workload only")

@@ -221,6 +221,25 @@ int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsvd_params* p
                                const void* evd_scratch, int L_total, int l_offset, float grad_scale, float* loss,
                                const nsvd_params* grads, void* ws, size_t ws_bytes, int path, void* stream);
 
+/* nsvd_operator_backward_evd for a WINDOW of heads: only the gradients of heads [l_begin, l_begin + l_count) of
+ * this model are produced (all other gradient elements are left untouched). The L heads of ParallelMLP share nothing
+ * but the input (examples/models/mlp.py:187-189, 204-221), so autograd's backward of the step
+ * (examples/operator/__init__.py:68) splits exactly by head; a sample-sharded run calls this once per window and
+ * starts the all-reduce of a window's gradients while the next window is being computed. Calling it for every window
+ * of a partition of [0, L) gives bit for bit the gradients of one nsvd_operator_backward_evd call of the same tile
+ * shape. Every call must be handed the moments (moments_reduced != 0, or the same evd_scratch): the windows of one
+ * step share f, Tf and the workspace of the forward call.
+ * nsvd_backward_head_window_ok: 1 when windows of l_count heads are supported for this shape (MFMA path, no split-K
+ * partial buffers at that head count), else 0 - the caller then uses one window of all L heads. */
+int nsvd_operator_backward_evd_heads(const nsvd_model_desc* desc, const nsvd_params* params,
+                                     const nsvd_problem* prob, const float* x, int B, const float* f,
+                                     const float* Tf, int mask_kind, const float* v, const float* M, float* moments,
+                                     int moments_reduced, const void* evd_scratch, int L_total, int l_offset,
+                                     float grad_scale, float* loss, const nsvd_params* grads, void* ws,
+                                     size_t ws_bytes, int path, int l_begin, int l_count, void* stream);
+int nsvd_backward_head_window_ok(const nsvd_model_desc* desc, const nsvd_problem* prob, int B, int path,
+                                 int l_count);
+
 /* nsvd_operator_backward_evd with the optimiser step of nsvd_rmsprop_ema_step taken inside the
  * weight-gradient kernel: each gradient element updates its parameter (params->W/b/scales, IN PLACE), RMSprop
  * square average (opt->sq) and EMA shadow (opt->ema, when has_ema) as it leaves the accumulator, so gradients
@@ -334,8 +353,10 @@ int nsvd_tower_backward(const float* x, const nsvd_tower_params* params, const f
 
 /* Measurement aid (bench.py): record the two hipEvent_t handles immediately before / after the
  * DOMINANT kernel of the next nsvd_operator_forward call made by this host thread (the fused MFMA
- * forward kernel, or the layer-0 GEMM on the generic path), on that call's stream. One-shot;
- * pass NULLs to clear. Per-thread state; the compute entry points themselves stay stateless. */
+ * forward kernel, or the layer-0 GEMM on the generic path), on that call's stream - or, whichever
+ * comes first, around the first contraction (X W1^T) of the next nsvd_tower_forward / the gathered-row
+ * contraction of the next nsvd_kernel_apply. One-shot; pass NULLs to clear. Per-thread state; the
+ * compute entry points themselves stay stateless. */
 int nsvd_profile_next_forward(void* ev_start, void* ev_stop);
 
 #ifdef __cplusplus

@@ -75,6 +75,10 @@ SIGNATURES = {
     "nsvd_evd_partial": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "nsvd_operator_backward_evd": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _P,
                                         _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params), _P, _Z, _I, _P]),
+    "nsvd_operator_backward_evd_heads": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
+                                              _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params), _P, _Z,
+                                              _I, _I, _I, _P]),
+    "nsvd_backward_head_window_ok": (_I, [C.POINTER(ModelDesc), C.POINTER(Problem), _I, _I, _I]),
     "nsvd_operator_backward_evd_step": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
                                              _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params),
                                              C.POINTER(Rmsprop), _P, _Z, _I, _P]),

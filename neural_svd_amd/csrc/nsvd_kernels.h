@@ -80,8 +80,11 @@ struct NsvdEvdIn;  // evd_math.h
 // epilogue, parameters updated in place (null: no step). At least one of the two.
 struct NsvdOptStep;  // opt_math.h
 struct NsvdHyper;
+// [l_begin, l_begin + l_count): the heads whose gradients this call produces (l_count = 0: all of them)
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
-                            const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s);
+                            const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s, int l_begin = 0,
+                            int l_count = 0);
+bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count);
 // stand-alone optimiser launch over n contiguous floats (optimizer.hip)
 int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,
                         hipStream_t s);

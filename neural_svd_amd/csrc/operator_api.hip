@@ -331,7 +331,8 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
                       const float* x, int B, const float* f, const float* Tf, int mask_kind, const float* v,
                       const float* M, float* moments, int moments_reduced, const void* evd_scratch, int L_total,
                       int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
-                      const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream) {
+                      const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream, int l_begin = 0,
+                      int l_count = 0) {
     int rc = validate(desc);
     if (rc) return rc;
     if (!prob || !x || !f || !Tf || !ws || B <= 0) return NSVD_EINVAL;
@@ -387,8 +388,10 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
             in.part_op = in.part + (size_t)(c.n1 + c.n2) * L * L;
             in.moments_out = moments;
         }
-        return nsvd_fused_backward_evd(*desc, *params, B, in, grads, opt ? &st : nullptr, ws, s);
+        if (l_count < 0 || l_begin < 0 || l_begin + l_count > desc->L) return NSVD_EINVAL;
+        return nsvd_fused_backward_evd(*desc, *params, B, in, grads, opt ? &st : nullptr, ws, s, l_begin, l_count);
     }
+    if (l_count > 0 && l_count != desc->L) return NSVD_EUNSUPPORTED;  // head windows need the fused kernels
     // generic path: finish the loss with the stand-alone kernels, then the layer-by-layer backward
     if (direct) return NSVD_EINVAL;  // needs the partial moments (evd_scratch) or the reduced ones
     if (L_total != desc->L) return NSVD_EUNSUPPORTED;  // head-parallel sharding needs the fused kernels
@@ -431,6 +434,26 @@ extern "C" int nsvd_operator_backward_evd(const nsvd_model_desc* desc, const nsv
     return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
                              evd_scratch, L_total, l_offset, grad_scale, loss, grads, nullptr, ws, ws_bytes, path,
                              stream);
+}
+
+extern "C" int nsvd_operator_backward_evd_heads(const nsvd_model_desc* desc, const nsvd_params* params,
+                                                const nsvd_problem* prob, const float* x, int B, const float* f,
+                                                const float* Tf, int mask_kind, const float* v, const float* M,
+                                                float* moments, int moments_reduced, const void* evd_scratch,
+                                                int L_total, int l_offset, float grad_scale, float* loss,
+                                                const nsvd_params* grads, void* ws, size_t ws_bytes, int path,
+                                                int l_begin, int l_count, void* stream) {
+    if (!grads || l_count <= 0) return NSVD_EINVAL;
+    return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
+                             evd_scratch, L_total, l_offset, grad_scale, loss, grads, nullptr, ws, ws_bytes, path,
+                             stream, l_begin, l_count);
+}
+
+extern "C" int nsvd_backward_head_window_ok(const nsvd_model_desc* desc, const nsvd_problem* prob, int B, int path,
+                                            int l_count) {
+    if (validate(desc) != 0 || !prob || B <= 0) return 0;
+    if (!want_fused(*desc, B, path, !(prob->eps > 0.f))) return l_count == desc->L;
+    return nsvd_fused_backward_window_ok(*desc, B, l_count) ? 1 : 0;
 }
 
 extern "C" int nsvd_operator_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params,

@@ -30,7 +30,8 @@ struct ChainArgs {
     float* dz[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer
     float* dbase;                // (L, B)  df * d f / d base    (for the last-layer gradient)
     float* dfsc;                 // (L, B)  df * d f / d scales  (exponential mask only)
-    int nlayers, B, L;
+    int nlayers, B, L;           // L: heads of THIS launch (the pointers above start at its first head)
+    int ldl, l0;                 // df, jac, dsc are (B, ldl) arrays of the whole model; this launch's heads start at l0
     // EVD-loss mode (df == null): NestedLoRALossFunctionEVD.backward evaluated per sample right here
     NsvdEvdIn evd;
 };
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
     }
     float dfv;
     if (a.df) {
-        dfv = a.df[(size_t)b * a.L + l];
+        dfv = a.df[(size_t)b * a.ldl + a.l0 + l];
     } else {
         // d loss / d f[b][l] = gs * ( -(4/B) v_l Tf[b][l] + (2/B_half) sum_l' f[b][l'] M[l'][l] lam_other[l'][l] )
         // (reference methods/nestedlora.py:98-111 with f1, f2 = chunk(f, 2)); the moments are either the
@@ -138,10 +139,10 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
                                   (2.f / (float)(first ? B1 : B2)) * acc);
         __syncthreads();  // col[] is dead before DZ is reused
     }
-    const float dbase = dfv * a.jac[(size_t)b * a.L + l];
+    const float dbase = dfv * a.jac[(size_t)b * a.ldl + a.l0 + l];
     if (w == 0 && hi == 0) {
         a.dbase[(size_t)l * a.B + b] = dbase;
-        if (a.dfsc) a.dfsc[(size_t)l * a.B + b] = dfv * a.dsc[(size_t)b * a.L + l];
+        if (a.dfsc) a.dfsc[(size_t)l * a.B + b] = dfv * a.dsc[(size_t)b * a.ldl + a.l0 + l];
     }
     float dz[16];
 #pragma unroll
@@ -766,29 +767,43 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
 }  // namespace
 
 
-static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, int B, const float* df,
+// Head window [l0, l0 + Lc) of the model's d.L heads: the heads of ParallelMLP share nothing but the input, so the
+// backward of a window is the same two launches on pointers that start at head l0 (sample-sharded runs cut the
+// backward into windows to start exchanging the first window's gradients while the next one is computed).
+static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& p, int B, const float* df,
                                const NsvdEvdIn* evd, const nsvd_params* gp, const NsvdOptStep* opt, void* ws,
-                               hipStream_t s) {
+                               hipStream_t s, int l0 = 0, int Lc = 0) {
+    if (Lc <= 0) Lc = dfull.L;
+    if (l0 < 0 || l0 + Lc > dfull.L) return NSVD_EINVAL;
     nsvd_params g;
     memset(&g, 0, sizeof(g));
     if (gp) g = *gp;
-    const FusedWs w = carve_fused(d, B, ws);
+    const FusedWs w = carve_fused(dfull, B, ws);
+    nsvd_model_desc d = dfull;
+    d.L = Lc;
     const int F = 2 * d.m, nh = d.nlayers - 1;
+    if (Lc != dfull.L && wgrad_slices(d, B) != 1) return NSVD_EUNSUPPORTED;  // split-K partials are laid out per model
+    // element offsets of head l0 inside the per-head arrays
+    auto offW = [&](int i) { return (size_t)l0 * d.dims[i] * (i == 0 ? (size_t)F : (size_t)d.dims[i - 1]); };
+    auto offb = [&](int i) { return (size_t)l0 * d.dims[i]; };
+    const size_t offz = (size_t)l0 * HID * B, offv = (size_t)l0 * B;
 
     ChainArgs a;
     memset(&a, 0, sizeof(a));
     a.df = df;
     if (evd) a.evd = *evd;
+    a.evd.l_off += l0;
     a.jac = w.jac;
     a.dsc = d.has_exp_mask ? w.dsc : nullptr;
-    a.dbase = w.dbase;
-    a.dfsc = d.has_exp_mask ? w.dfsc : nullptr;
+    a.dbase = w.dbase + offv;
+    a.dfsc = d.has_exp_mask ? w.dfsc + offv : nullptr;
     for (int i = 0; i < d.nlayers; ++i) {
-        a.W[i] = p.W[i];
-        a.zsave[i] = (i < nh) ? w.zsave[i] : nullptr;
-        a.dz[i] = (i < nh) ? w.dz[i] : nullptr;
+        a.W[i] = p.W[i] + offW(i);
+        a.zsave[i] = (i < nh) ? w.zsave[i] + offz : nullptr;
+        a.dz[i] = (i < nh) ? w.dz[i] + offz : nullptr;
     }
     a.nlayers = d.nlayers; a.B = B; a.L = d.L;
+    a.ldl = dfull.L; a.l0 = l0;
     const int chain_grid = (B / BS) * d.L;
     if ((nh == 2 || nh == 3) && chain_grid <= 128)
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<true>, dim3(chain_grid), dim3(256), 0, s, a);
@@ -799,24 +814,25 @@ static int fused_backward_impl(const nsvd_model_desc& d, const nsvd_params& p, i
     WgradArgs wa;
     memset(&wa, 0, sizeof(wa));
     for (int i = 0; i < d.nlayers; ++i) {
-        wa.dz[i] = (i < nh) ? w.dz[i] : nullptr;
-        wa.zsave[i] = (i < nh) ? w.zsave[i] : nullptr;
-        wa.gW[i] = g.W[i];
-        wa.gb[i] = g.b[i];
+        wa.dz[i] = (i < nh) ? w.dz[i] + offz : nullptr;
+        wa.zsave[i] = (i < nh) ? w.zsave[i] + offz : nullptr;
+        wa.gW[i] = g.W[i] ? g.W[i] + offW(i) : nullptr;
+        wa.gb[i] = g.b[i] ? g.b[i] + offb(i) : nullptr;
     }
     wa.phiTc = w.phiTc;
-    wa.dbase = w.dbase;
-    wa.dfsc = d.has_exp_mask ? w.dfsc : nullptr;
-    wa.gscales = d.has_exp_mask ? g.scales : nullptr;
+    wa.dbase = w.dbase + offv;
+    wa.dfsc = d.has_exp_mask ? w.dfsc + offv : nullptr;
+    wa.gscales = (d.has_exp_mask && g.scales) ? g.scales + l0 : nullptr;
     wa.nlayers = d.nlayers; wa.B = B; wa.L = d.L; wa.F = F;
     if (opt) {
         wa.opt = 1;
         wa.h = opt->h;
         for (int i = 0; i < d.nlayers; ++i) {
-            wa.oW[i] = NsvdOptPtrs{p.W[i], opt->sq.W[i], opt->ema ? opt->ema->W[i] : nullptr};
-            wa.ob[i] = NsvdOptPtrs{p.b[i], opt->sq.b[i], opt->ema ? opt->ema->b[i] : nullptr};
+            wa.oW[i] = NsvdOptPtrs{p.W[i] + offW(i), opt->sq.W[i] + offW(i), opt->ema ? opt->ema->W[i] + offW(i) : nullptr};
+            wa.ob[i] = NsvdOptPtrs{p.b[i] + offb(i), opt->sq.b[i] + offb(i), opt->ema ? opt->ema->b[i] + offb(i) : nullptr};
         }
-        if (d.has_exp_mask) wa.oscales = NsvdOptPtrs{p.scales, opt->sq.scales, opt->ema ? opt->ema->scales : nullptr};
+        if (d.has_exp_mask)
+            wa.oscales = NsvdOptPtrs{p.scales + l0, opt->sq.scales + l0, opt->ema ? opt->ema->scales + l0 : nullptr};
     }
     wa.nA = (F / HID) * d.L;
     wa.S = wgrad_slices(d, B);
@@ -888,7 +904,16 @@ int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const ns
 }
 
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
-                            const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s) {
+                            const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s, int l_begin,
+                            int l_count) {
     if (!g && !opt) return NSVD_EINVAL;
-    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s);
+    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s, l_begin, l_count);
+}
+
+bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count) {
+    if (l_count <= 0 || l_count > d.L) return false;
+    if (l_count == d.L) return true;
+    nsvd_model_desc dw = d;
+    dw.L = l_count;
+    return wgrad_slices(dw, B) == 1;
 }

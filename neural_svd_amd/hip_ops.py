@@ -348,6 +348,33 @@ def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: t
     check(rc, "nsvd_operator_backward_evd")
 
 
+def backward_head_window_ok(shape: ModelShape, prob: Problem, B: int, path: int, l_count: int) -> bool:
+    d = shape.desc()
+    return bool(_lib.load().nsvd_backward_head_window_ok(C.byref(d), C.byref(prob), int(B), int(path), int(l_count)))
+
+
+def operator_backward_evd_heads(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, f: torch.Tensor,
+                                Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                                M: Optional[torch.Tensor], moments: torch.Tensor, moments_reduced: bool,
+                                evd_scratch: Optional[torch.Tensor], loss: torch.Tensor, grads: Params,
+                                ws: torch.Tensor, l_begin: int, l_count: int, grad_scale: float = 1.0,
+                                path: int = PATH_AUTO, l_offset: int = 0) -> None:
+    """operator_backward_evd for the heads [l_begin, l_begin + l_count) only (the other gradients are untouched)."""
+    B = x.shape[0]
+    L_total = f.shape[1]
+    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or \
+            (moments is not None and moments.numel() != 2 * L_total * L_total + 1):
+        raise NsvdError("operator_backward_evd_heads: f/Tf must be (B, L_total), moments 2*L_total^2+1")
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_backward_evd_heads(
+        C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
+        _ptr(v, "v"), _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
+        evd_scratch.data_ptr() if evd_scratch is not None else None, int(L_total), int(l_offset),
+        float(grad_scale), _ptr(loss, "loss"), C.byref(grads), ws.data_ptr(), ws.numel(), int(path), int(l_begin),
+        int(l_count), _stream())
+    check(rc, "nsvd_operator_backward_evd_heads")
+
+
 def rmsprop_state(sq: Params, ema: Optional[Params], lr: float, alpha: float, eps: float,
                   ema_decay: float = 0.0) -> _lib.Rmsprop:
     """nsvd_rmsprop for operator_backward_evd_step; sq / ema are pack_params() sets in the parameters' layouts."""
@@ -566,7 +593,7 @@ def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float
 # every wrapper that launches kernels runs on the device of its tensors (see _on_tensor_device)
 for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
-              "evd_partial", "operator_backward_evd", "operator_backward_evd_step", "kernel_apply", "cdk_loss_forward",
+              "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
               "row_normalize_backward", "tower_forward", "tower_backward"):
     globals()[_name] = _on_tensor_device(globals()[_name])

@@ -9,15 +9,22 @@ device - so the exchange sequence the product runs is the one the tests execute.
   "dp"  samples sharded (what BASELINE.json's north_star describes). What crosses ranks per step:
   1. the moment vector [lam_f1 | lam_f2 | mean f.Tf] = 2 L^2 + 1 floats  (all-reduce, mean) - the only
      cross-sample coupling of the loss (methods/nestedlora.py:89);
-  2. the flat gradient buffer, P floats (all-reduce, sum), cut into buckets on head boundaries of W_0 (89 % of the
-     bytes): every bucket's collective is issued asynchronously, the next batch and its features (they depend on
-     no weight) are produced while the first one is in flight, and the optimiser pass over bucket k runs while
-     bucket k+1 is on the wire. Every rank applies the identical RMSprop/EMA update: parameters stay bit-identical.
+  2. the flat gradient buffer, P floats, in buckets. The backend produces the gradient in STAGES (head windows of
+     the backward: the heads of ParallelMLP share nothing but the input), and a bucket's collective is issued the
+     moment the launches that complete it are enqueued, so it runs under the remaining backward launches; the next
+     batch and its features (they depend on no weight) are produced while the first one is in flight. Two exchange
+     algorithms, both leaving every rank with bit-identical parameters:
+       "allreduce"  all-reduce(sum) per bucket, then the identical RMSprop/EMA pass over the whole bucket on every
+                    rank (optimiser on bucket k while bucket k+1 is on the wire);
+       "rs_ag"      reduce-scatter(sum) per bucket, RMSprop/EMA on this rank's 1/world of the bucket only (the
+                    square averages and the EMA shadow stay sharded; `gather` them for evaluation / checkpoints),
+                    then all-gather of the updated parameters: the same bytes on the wire, 1/world of the optimiser
+                    traffic per rank, and the direct (non-ring) form SURVEY 5 asks for on fully connected xGMI.
   "hp"  heads sharded (SURVEY 8(e) "alternative worth measuring"): the L heads of ParallelMLP share nothing but
      the input, so rank r owns heads [r L/W, (r+1) L/W) - weights, gradients and optimiser state are not
      replicated and there is NO gradient traffic; every rank evaluates its heads on the whole global batch and
      the only exchange is one all-gather of 2 B L floats (f and Tf), under which the next batch's features are
-     produced. On xGMI the 18.9 MB gradient all-reduce of "dp" costs about as much as the whole compute step; the
+     produced. On xGMI the 18.9 MB gradient exchange of "dp" costs about as much as the whole compute step; the
      all-gather is ~0.5 MB.
 The reference itself has no live distributed code (tools/generic.py:65-180 is never imported).
 
@@ -27,20 +34,41 @@ Backend protocol (all methods enqueue work and return immediately on the HIP bac
                                    batch is the global batch); take_step=True: the optimiser step may be fused in
   local_moments() -> tensor        dp: (2 L^2 + 1) moments of this rank's rows, to be averaged in place
   grad_buffer() -> tensor          dp: the flat local gradient, to be summed in place
-  grad_buckets() -> [(lo, hi)]     dp: contiguous element ranges of grad_buffer(), exchange order
+  backward_staged(moments)         dp: generator; each item (lo, hi) says "the launches that complete the gradient
+                                   elements [lo, hi) have just been enqueued"; the items partition the buffer
   begin_apply()                    dp: advance the lr / EMA schedules once per step
-  apply(lo, hi, grad_scale)        dp: optimiser step on the elements [lo, hi)
+  apply(lo, hi, grad_scale)        dp: optimiser step on the elements [lo, hi) from grad_buffer()[lo:hi]
+  grad_shard(lo, hi) -> tensor     dp rs_ag: (hi - lo) / world floats receiving this rank's reduced slice of a bucket
+  apply_shard(lo, hi, g, scale)    dp rs_ag: optimiser step on the elements [lo, hi) from the reduced slice g
+  param_buffer() -> tensor         dp rs_ag: the flat parameter buffer (all-gathered in place, bucket by bucket)
   gather_buffers() -> (out, inp)   hp: out (world, *inp.shape) receives every rank's packed [f | Tf] block
   after_gather()                   hp: gathered blocks -> the (B, L) arrays the backward reads
   prefetch()                       work for the NEXT step that depends on no weight (issued under a collective)
+
+Diagnostics (bench.py's `comm` block): `CommProbe` brackets every wait on a collective with two events on the
+compute stream - what they measure is the time the compute stream sat idle for that collective, i.e. its EXPOSED
+cost - and `Communicator.stub = True` turns every collective into a no-op so that the same step can be timed
+compute-only.
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import time
+from collections import OrderedDict
 from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+DP_EXCHANGES = ("allreduce", "rs_ag")
+
+
+class _Done:
+    """work handle of a collective that did not run (stub mode)"""
+
+    def wait(self):
+        return True
 
 
 class Communicator:
@@ -49,6 +77,7 @@ class Communicator:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self.stub = False  # True: collectives are skipped (compute-only timing of the multi-rank code path)
 
     @classmethod
     def from_env(cls, device: Optional[torch.device] = None, backend: Optional[str] = None) -> "Communicator":
@@ -64,6 +93,8 @@ class Communicator:
         return cls()
 
     def all_reduce_mean(self, t: torch.Tensor) -> None:
+        if self.stub:
+            return
         if self.backend == "nccl":  # RCCL averages inside the collective: no extra kernel
             dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
             return
@@ -71,11 +102,30 @@ class Communicator:
         t.div_(self.world)
 
     def all_reduce_sum(self, t: torch.Tensor, async_op: bool = False):
+        if self.stub:
+            return _Done() if async_op else None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def reduce_scatter_sum(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out (n / world) = this rank's slice of the element-wise sum of every rank's inp (n)."""
+        if self.stub:
+            return _Done() if async_op else None
+        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def all_gather_flat(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out (n) = concatenation over ranks of inp (n / world). `inp` may be out's own slice of this rank (in
+        place, what RCCL expects of a sharded-parameter gather); gloo gets a private copy of it."""
+        if self.stub:
+            return _Done() if async_op else None
+        if self.backend != "nccl":
+            inp = inp.clone()
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         """out: (world, *inp.shape) contiguous; out[r] = rank r's inp. async_op: returns the work handle (wait()
         orders the current stream after the collective) so that independent kernels can be enqueued meanwhile."""
+        if self.stub:
+            return _Done() if async_op else None
         # concatenated-along-dim-0 view: the one output shape both RCCL and gloo accept
         return dist.all_gather_into_tensor(out.view(-1, *inp.shape[1:]), inp.contiguous(), group=self.group,
                                            async_op=async_op)
@@ -86,55 +136,149 @@ class Communicator:
     def barrier(self) -> None:
         dist.barrier(group=self.group)
 
+    def _host_device(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
     def max_float(self, v: float) -> float:
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        t = torch.tensor([v], dtype=torch.float64, device=self._host_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
+
+    def count_ranks(self) -> int:
+        """the world size as the collective library itself sees it: a sum of ones over the ranks"""
+        t = torch.ones(1, dtype=torch.float32, device=self._host_device())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(round(float(t.item())))
 
     def close(self) -> None:
         if dist.is_initialized():
             dist.destroy_process_group()
 
 
+class CommProbe:
+    """Stopwatch for the waits on collectives: two events on the compute stream around each wait. The first is
+    reached when everything enqueued before the wait has finished, the second when the collective has, so their
+    distance is the time the compute stream was idle for that collective - its exposed cost (a collective hidden
+    under other kernels reads ~0). On CPU tensors (tests) the host clock is used."""
+
+    def __init__(self, device=None):
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.spans = OrderedDict()
+        self.steps = 0
+
+    @contextlib.contextmanager
+    def span(self, name: str):
+        if self.cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            yield
+            e1.record()
+            self.spans.setdefault(name, []).append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            yield
+            self.spans.setdefault(name, []).append(time.perf_counter() - t0)
+
+    def step_done(self) -> None:
+        self.steps += 1
+
+    def summary(self) -> "OrderedDict[str, float]":
+        """name -> mean exposed microseconds per step"""
+        if self.cuda:
+            torch.cuda.synchronize()
+        out = OrderedDict()
+        n = max(self.steps, 1)
+        for name, v in self.spans.items():
+            tot = sum(a.elapsed_time(b) for a, b in v) * 1e3 if self.cuda else sum(v) * 1e6
+            out[name] = tot / n
+        return out
+
+
+@contextlib.contextmanager
+def _nospan(_name):
+    yield
+
+
 def _world(comm: Optional[Communicator]) -> int:
     return comm.world if comm is not None else 1
 
 
-def dp_step(backend, comm: Optional[Communicator], x_local, take_step: bool = True) -> None:
+def shard_range(lo: int, hi: int, rank: int, world: int):
+    """rank's slice of the bucket [lo, hi) (equal slices: reduce-scatter / all-gather need them)"""
+    n = hi - lo
+    if n % world != 0:
+        raise ValueError(f"bucket of {n} elements does not split over {world} ranks")
+    q = n // world
+    return lo + rank * q, lo + (rank + 1) * q
+
+
+def dp_step(backend, comm: Optional[Communicator], x_local, take_step: bool = True, exchange: str = "allreduce",
+            probe: Optional[CommProbe] = None) -> None:
     """One SAMPLE-SHARDED NestedLoRA step (see the module docstring for the protocol). With one rank this is the
     plain step (the backend is free to fuse the optimiser into its backward)."""
+    span = probe.span if probe is not None else _nospan
     backend.forward(x_local)
     world = _world(comm)
     if world == 1:
         backend.backward(None, take_step)
         return
     mom = backend.local_moments()
-    comm.all_reduce_mean(mom)                      # exchange 1: 2 L^2 + 1 floats
-    backend.backward(mom, False)
+    with span("moments_allreduce"):
+        comm.all_reduce_mean(mom)                  # exchange 1: 2 L^2 + 1 floats
     if not take_step:
+        backend.backward(mom, False)
         return
-    grad = backend.grad_buffer()
-    works = [(lo, hi, comm.all_reduce_sum(grad[lo:hi], async_op=True))   # exchange 2, bucket by bucket
-             for lo, hi in backend.grad_buckets()]
-    backend.prefetch()                             # next batch + features under the first bucket
-    backend.begin_apply()
-    for lo, hi, work in works:
-        work.wait()
-        backend.apply(lo, hi, 1.0 / world)         # optimiser on bucket k while bucket k+1 is on the wire
+    if exchange == "allreduce":
+        # exchange 2: a bucket's all-reduce goes out as soon as the launches completing it are enqueued
+        works = []
+        for lo, hi in backend.backward_staged(mom):
+            works.append((lo, hi, comm.all_reduce_sum(backend.grad_buffer()[lo:hi], async_op=True)))
+        backend.prefetch()                         # next batch + features under the first bucket
+        backend.begin_apply()
+        for k, (lo, hi, work) in enumerate(works):
+            with span(f"grad_bucket{k}_allreduce_wait"):
+                work.wait()
+            backend.apply(lo, hi, 1.0 / world)     # optimiser on bucket k while bucket k+1 is on the wire
+    elif exchange == "rs_ag":
+        rs = []
+        for lo, hi in backend.backward_staged(mom):
+            shard = backend.grad_shard(lo, hi)
+            rs.append((lo, hi, shard, comm.reduce_scatter_sum(shard, backend.grad_buffer()[lo:hi], async_op=True)))
+        backend.prefetch()
+        backend.begin_apply()
+        params = backend.param_buffer()
+        ag = []
+        for k, (lo, hi, shard, work) in enumerate(rs):
+            with span(f"grad_bucket{k}_reduce_scatter_wait"):
+                work.wait()
+            slo, shi = shard_range(lo, hi, comm.rank, world)
+            backend.apply_shard(slo, shi, shard, 1.0 / world)   # 1/world of the optimiser traffic per rank
+            ag.append(comm.all_gather_flat(params[lo:hi], params[slo:shi], async_op=True))
+        for k, work in enumerate(ag):
+            with span(f"param_bucket{k}_all_gather_wait"):
+                work.wait()
+    else:
+        raise ValueError(f"dp exchange must be one of {DP_EXCHANGES}")
+    if probe is not None:
+        probe.step_done()
 
 
-def hp_step(backend, comm: Optional[Communicator], x_global, take_step: bool = True) -> None:
+def hp_step(backend, comm: Optional[Communicator], x_global, take_step: bool = True,
+            probe: Optional[CommProbe] = None) -> None:
     """One HEAD-SHARDED NestedLoRA step: every rank owns L/world heads (weights, gradients, optimiser state:
     nothing is replicated, no gradient traffic) and evaluates them on the WHOLE global batch. The only exchange
     is an all-gather of the rank's (B, L/world) blocks of f and Tf; the moments, the loss and d loss / d f of the
     local heads are then computed locally from the gathered (B, L) arrays."""
+    span = probe.span if probe is not None else _nospan
     backend.forward(x_global)
     if _world(comm) > 1:
         out, inp = backend.gather_buffers()
         work = comm.all_gather(out, inp, async_op=True)
         if take_step:
             backend.prefetch()
-        work.wait()
+        with span("f_Tf_all_gather_wait"):
+            work.wait()
         backend.after_gather()
     backend.backward(None, take_step)
+    if probe is not None:
+        probe.step_done()

@@ -122,7 +122,8 @@ class FusedTrainer:
                  fourier_scale: float = 0.1, exp_mask_init: Optional[float] = None, seed: Optional[int] = 0,
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
                  parallelism: str = "dp", fused_step: bool = True, keep_grads: bool = False,
-                 device_sampler: bool = True, overlap: bool = True, grad_buckets: int = 4):
+                 device_sampler: bool = True, overlap: bool = True, grad_buckets: int = 4,
+                 dp_exchange: str = "allreduce", grad_windows: Optional[int] = None):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
         them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
@@ -133,7 +134,13 @@ class FusedTrainer:
         Philox) instead of torch's generator + a separate feature launch.
         overlap (world > 1, device sampler): the next batch and its features (they depend on no weight) are produced
         into a second workspace while the step's collective is in flight, instead of leaving the GPU idle.
-        grad_buckets (dp): number of gradient all-reduce buckets (cut on head boundaries of W_0)."""
+        grad_buckets (dp): number of gradient exchange buckets (cut on head boundaries of W_0) when the backward is one
+        window.
+        dp_exchange (dp, world > 1): "allreduce" (bucketed all-reduce, identical optimiser pass on every rank) or
+        "rs_ag" (reduce-scatter, optimiser on this rank's 1/world of each bucket, all-gather of the parameters; the
+        RMSprop square averages and the EMA shadow then live sharded - gather_optimizer_state() before reading them).
+        grad_windows (dp, world > 1): head windows the backward is cut into so that a window's gradients go on the
+        wire while the next window is computed (None: as many of 4 / 2 / 1 as still give every CU a dW_0 tile)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise H.NsvdError(f"FusedTrainer needs a GPU device (got {self.device}); there is no CPU path")
@@ -162,10 +169,10 @@ class FusedTrainer:
         self.sigma = sampling_scale
         with torch.cuda.device(self.device):
             self._build(shape, problem, fourier_scale, exp_mask_init, seed, sample_seed, sequential, step, fused_step,
-                        keep_grads, device_sampler, overlap, grad_buckets, world, rank)
+                        keep_grads, device_sampler, overlap, grad_buckets, world, rank, dp_exchange, grad_windows)
 
     def _build(self, shape, problem, fourier_scale, exp_mask_init, seed, sample_seed, sequential, step, fused_step,
-               keep_grads, device_sampler, overlap, grad_buckets, world, rank):
+               keep_grads, device_sampler, overlap, grad_buckets, world, rank, dp_exchange, grad_windows):
         path = self.path
         self.P = FlatParams(shape, self.device)
         fB0, ws0, bs0, sc0 = reference_init(self.full_shape, fourier_scale, exp_mask_init, seed)
@@ -246,6 +253,39 @@ class FusedTrainer:
         w0 = shape.dims[0] * 2 * shape.m
         cuts = [shape.L * i // nb * w0 for i in range(nb)] + [self.P.numel]
         self._buckets = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
+        # dp head windows of the backward (parallel.py): window k's W_0 gradients are a contiguous range of the flat
+        # buffer and go on the wire while window k + 1 is computed; the small tensors (complete after the last
+        # window only) are the last bucket
+        from . import parallel
+        if dp_exchange not in parallel.DP_EXCHANGES:
+            raise ValueError(f"dp_exchange must be one of {parallel.DP_EXCHANGES}")
+        self.dp_exchange = dp_exchange
+        self.probe = None            # parallel.CommProbe while bench.py measures the exposed waits
+        self._windows = [(0, shape.L)]
+        if world > 1 and not self.hp and H.path_name(shape, self.B, path, problem) == "fused_mfma":
+            for G in ((4, 2) if grad_windows is None else (int(grad_windows),)):
+                if G <= 1 or shape.L % G != 0:
+                    continue
+                nA128 = (2 * shape.m // 128) * (shape.L // G)
+                tiles = nA128 * (2 if nA128 <= 128 else 1)  # pmlp_common.h wgrad_tile_width: 64-wide tiles then
+                if grad_windows is None and tiles < 256:
+                    continue  # the window's dW_0 tiles would leave CUs idle
+                if H.backward_head_window_ok(shape, problem, self.B, path, shape.L // G):
+                    self._windows = [(g * (shape.L // G), shape.L // G) for g in range(G)]
+                    break
+        if len(self._windows) > 1:
+            self._stage_buckets = [(l0 * w0, (l0 + lc) * w0) for l0, lc in self._windows] + \
+                [(shape.L * w0, self.P.numel)]
+        else:
+            self._stage_buckets = self._buckets
+        self._state_sharded = False  # rs_ag: sq / ema valid on this rank's shards only
+        self._gshard = None
+        if world > 1 and not self.hp and dp_exchange == "rs_ag":
+            for lo, hi in self._stage_buckets:
+                if (hi - lo) % world != 0:
+                    raise ValueError(f"dp_exchange='rs_ag': bucket of {hi - lo} elements does not split over {world} "
+                                     f"ranks")
+            self._gshard = torch.empty(self.P.numel // world + 64, dtype=torch.float32, device=self.device)
 
     # -- stages -------------------------------------------------------------------------------
     def sample(self) -> torch.Tensor:
@@ -299,7 +339,48 @@ class FusedTrainer:
         return self.P.grad
 
     def grad_buckets(self):
-        return self._buckets
+        return self._stage_buckets
+
+    def backward_staged(self, reduced_moments: torch.Tensor):
+        """the backward, window by window: yields each bucket of the flat gradient as soon as the launches that
+        complete it are enqueued (parallel.dp_step issues its collective right there)"""
+        if len(self._windows) == 1:
+            self.backward(reduced_moments, False)
+            yield from self._stage_buckets
+            return
+        assert reduced_moments is self._moments
+        v, M = self._masks()
+        for k, (l0, lc) in enumerate(self._windows):
+            H.operator_backward_evd_heads(self.shape, self._params, self.problem, self._x_cur, self.f_g, self.Tf_g,
+                                          self.mask_kind, v, M, self._moments, True, self.scratch, self._loss,
+                                          self._grads, self.ws, l0, lc, 1.0, self.path, l_offset=self.l_off)
+            yield self._stage_buckets[k]
+        yield self._stage_buckets[-1]
+
+    def grad_shard(self, lo: int, hi: int) -> torch.Tensor:
+        q = (hi - lo) // self.world
+        off = lo // self.world  # buckets are disjoint and each a multiple of world: the slices do not overlap
+        return self._gshard[off:off + q]
+
+    def apply_shard(self, lo: int, hi: int, g: torch.Tensor, grad_scale: float) -> None:
+        self._state_sharded = True
+        H.rmsprop_ema_step(self.P.flat[lo:hi], g, self.P.sq[lo:hi], self.P.ema[lo:hi], self._lr_now, self.alpha,
+                           self.eps, self._decay_now, grad_scale)
+
+    def param_buffer(self) -> torch.Tensor:
+        return self.P.flat
+
+    def gather_optimizer_state(self) -> None:
+        """rs_ag keeps the RMSprop square averages and the EMA shadow on the rank that updates them (1/world of each
+        bucket): make both complete on every rank (before an evaluation under EMA weights, a checkpoint)."""
+        if not self._state_sharded or self.comm is None:
+            return
+        from .parallel import shard_range
+        for buf in (self.P.ema, self.P.sq):
+            for lo, hi in self._stage_buckets:
+                slo, shi = shard_range(lo, hi, self.comm.rank, self.world)
+                self.comm.all_gather_flat(buf[lo:hi], buf[slo:shi])
+        self._state_sharded = False
 
     def begin_apply(self) -> None:
         self._lr_now, self._decay_now = self._advance_schedule()
@@ -331,7 +412,10 @@ class FusedTrainer:
         from . import parallel
         self._features_ready = bool(features_ready)
         with torch.cuda.device(self.device):
-            (parallel.hp_step if self.hp else parallel.dp_step)(self, self.comm, x, take_step)
+            if self.hp:
+                parallel.hp_step(self, self.comm, x, take_step, probe=self.probe)
+            else:
+                parallel.dp_step(self, self.comm, x, take_step, exchange=self.dp_exchange, probe=self.probe)
 
     def _refresh_loss(self) -> None:
         if self._loss_stale:  # direct-moment steps do not produce them: evaluate for the last batch now
@@ -386,6 +470,8 @@ class FusedTrainer:
     def spectrum(self, lim: float, val_eps: float, use_ema: bool = True, chunk: int = 8192):
         """Rayleigh-quotient spectrum on the uniform grid arange(-lim, lim, val_eps)^D (main_pde.py:121-130)."""
         D, L = self.shape.D, self.shape.L
+        if use_ema:
+            self.gather_optimizer_state()
         with torch.cuda.device(self.device):
             import numpy as np
             ax = torch.from_numpy(np.arange(-lim, lim, val_eps))  # numpy's arange values (start + i * step)

@@ -1,5 +1,6 @@
-"""Post-process gpurun_out/<tag>/pmc_*_counter_collection.csv into profiles/<name>_pmc_traffic_cfg2.txt and
-profiles/latest_traffic.json (per-launch HBM-side bytes per kernel, gfx950 corrections of MI355X_MICROARCH.md:
+"""summarize_pmc.py <tag> <name> [workload = cfg2]
+Post-process gpurun_out/<tag>/pmc_*_counter_collection.csv into profiles/<name>_pmc_traffic_<workload>.txt and - for
+the headline workload cfg2 only - profiles/latest_traffic.json (per-launch HBM-side bytes per kernel, gfx950 corrections of MI355X_MICROARCH.md:
 FETCH_SIZE under-reports wide coalesced reads by 2x, WRITE_SIZE is exact; both in KiB) and, from the SQ pass,
 the MFMA utilisation per kernel:
   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES)
@@ -11,13 +12,19 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 tag, name = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 SHORT = [("pmlp_fused_fwd_kernel<5, 0, 0>", "pmlp_fused_fwd"),  # the headline forward (stencil, native fp32 MFMA)
          ("pmlp_fused_fwd_kernel<5, 0, 1>", "pmlp_fused_fwd_bf16x3"),  # bench.py's side measurement
          ("w0_split", "w0_split_bf16x3"), ("pmlp_fused_wgrad", "pmlp_fused_wgrad"),
          ("pmlp_fused_bwd_chain", "pmlp_fused_bwd_chain"), ("fourier_stencil", "fourier_stencil"),
-         ("evd_partial", "evd_partial"), ("rmsprop_ema", "rmsprop_ema"), ("distribution_elementwise", "torch_randn")]
+         ("evd_partial", "evd_partial"), ("rmsprop_ema", "rmsprop_ema"), ("distribution_elementwise", "torch_randn"),
+         ("pmlp_fused_fwd_kernel<1, 0, 0>", "pmlp_fused_fwd_E1"), ("wgrad_reduce", "wgrad_reduce"),
+         ("tower_gemm_nt", "tower_gemm_nt"), ("tower_bn_forward", "tower_bn_forward"),
+         ("tower_bn_backward", "tower_bn_backward"), ("tower_transpose", "tower_transpose"),
+         ("tower_sum_slices", "tower_sum_slices"), ("cdk_", "cdk_loss_kernels"), ("ka_gemm", "ka_gemm"),
+         ("ka_scatter", "ka_scatter"), ("ka_zero", "ka_zero"), ("ka_reduce", "ka_reduce"), ("row_normalize", "row_normalize")]
 vals = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
@@ -26,8 +33,9 @@ for f in glob.glob(os.path.join(src, "pmc_*counter_collection.csv")):
         if short is None:
             continue
         vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
-lines = [f"# rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-events",
-         "# separate passes for FETCH_SIZE, WRITE_SIZE, (TCC_HIT_sum TCC_MISS_sum); MI355X, cfg2; per-launch averages",
+cfg_arg = "" if workload == "cfg2" else f" --config {workload}"
+lines = [f"# rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-events{cfg_arg}",
+         f"# separate passes for FETCH_SIZE, WRITE_SIZE, (TCC_HIT_sum TCC_MISS_sum); MI355X, {workload}; per-launch averages",
          "# units: FETCH_SIZE / WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction",
          "# (MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads; WRITE_SIZE exact for 16-B stores)",
          f"{'kernel':<28}{'launches':>9}{'FETCH_KiB':>13}{'WRITE_KiB':>13}{'L2 hit':>9}{'hbm_MB(corrected)':>20}"]
@@ -35,7 +43,7 @@ lines2 = ["", "# SQ pass: --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
           "# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES) (MFMA-pipe-busy SIMD cycles over all 1024 SIMDs x dispatch cycles);",
           "# wait_inst / wait_any / active: shares of SQ_WAVE_CYCLES (quad-cycles: issue stall, parked at waitcnt/barrier, issuing)",
           f"{'kernel':<28}{'launches':>9}{'MFMA_BUSY':>14}{'SQ_BUSY/32':>12}{'mfma_busy_frac':>16}{'wait_inst':>11}{'wait_any':>10}{'active':>8}"]
-out = {"workload": "cfg2", "source": f"profiles/{name}_pmc_traffic_cfg2.txt", "kernels": {}}
+out = {"workload": workload, "source": f"profiles/{name}_pmc_traffic_{workload}.txt", "kernels": {}}
 avg = lambda v: sum(v) / len(v) if v else float("nan")
 for _, s in SHORT:
     if s not in vals:
@@ -56,6 +64,7 @@ for _, s in SHORT:
         out["kernels"][s].update(mfma_busy_cycles=mb, sq_busy_cycles_per_se=sb / 32, mfma_busy_frac=fr,
                                  grbm_gui_active=avg(c.get("GRBM_GUI_ACTIVE", [])))
 lines += lines2
-open(os.path.join(root, "profiles", f"{name}_pmc_traffic_cfg2.txt"), "w").write("\n".join(lines) + "\n")
-json.dump(out, open(os.path.join(root, "profiles", "latest_traffic.json"), "w"), indent=1)
+open(os.path.join(root, "profiles", f"{name}_pmc_traffic_{workload}.txt"), "w").write("\n".join(lines) + "\n")
+if workload == "cfg2":
+    json.dump(out, open(os.path.join(root, "profiles", "latest_traffic.json"), "w"), indent=1)
 print("\n".join(lines))

@@ -48,18 +48,27 @@ def main():
     rank, world = comm.rank, comm.world
     shape, prob, kw = make_shape(), make_problem(), trainer_kw()
     res = {}
-    if mode in ("dp", "hp"):
-        # external batches: comparable with a single-process run on the global batch
-        tr = FusedTrainer(shape, prob, CASE["B_local"], seed=5, device=dev, comm=comm, parallelism=mode,
-                          keep_grads=True, grad_buckets=3, **kw)
+    if mode in ("dp", "hp", "dp_win", "dp_rsag"):
+        # external batches: comparable with a single-process run on the global batch.
+        # dp_win: the backward cut into two head windows, each window's bucket all-reduced as it is enqueued;
+        # dp_rsag: the same windows with reduce-scatter -> optimiser on this rank's slices -> all-gather
+        extra = {}
+        if mode != "dp" and mode != "hp":
+            extra = dict(grad_windows=2, dp_exchange="rs_ag" if mode == "dp_rsag" else "allreduce")
+        tr = FusedTrainer(shape, prob, CASE["B_local"], seed=5, device=dev, comm=comm, parallelism=mode[:2],
+                          keep_grads=True, grad_buckets=3, **extra, **kw)
         assert tr.hp == (mode == "hp") and tr.world == world
+        if extra:
+            assert len(tr._windows) == 2 and len(tr.grad_buckets()) == 3
         for i, xg in enumerate(global_batches(world)):
             x = (xg if mode == "hp" else dp_rows(xg, rank, world)).to(dev)
             tr.step(x)
             if i == 0:
+                res["sharded0"] = tr._state_sharded
                 res["grad0"] = tr.P.grad.clone().cpu()
                 res["loss0"] = tr.loss.clone().cpu()
                 res["mom0"] = tr.moments.clone().cpu()
+        tr.gather_optimizer_state()
         res.update(flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), sq=tr.P.sq.cpu(), t=tr.t, l_off=tr.l_off,
                    buckets=tr.grad_buckets(), fused_step=tr.fused_step)
     elif mode in ("dp_overlap", "hp_overlap"):

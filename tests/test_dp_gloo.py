@@ -56,8 +56,32 @@ class OracleBackend:
 
     def grad_buckets(self):
         n = self.grad.numel()
-        cuts = [n * i // self.n_buckets for i in range(self.n_buckets + 1)]
+        # every bucket a multiple of the world size (the reduce-scatter exchange needs equal slices); the tail that
+        # does not divide rides... nowhere: _setup() sizes the model so that it does
+        q = n // (self.n_buckets * self.world) * self.world
+        cuts = [q * i for i in range(self.n_buckets)] + [n]
         return list(zip(cuts[:-1], cuts[1:]))
+
+    def backward_staged(self, reduced_moments):
+        """the oracle has no head windows: one backward, then the buckets (the HIP backend's windows are covered by
+        tests/test_multirank_gpu.py); what this exercises is dp_step's use of the generator"""
+        self.backward(reduced_moments, False)
+        self.params = torch.arange(self.grad.numel(), dtype=self.grad.dtype) * 1e-3  # stand-in parameter buffer
+        self.params0 = self.params.clone()
+        for b in self.grad_buckets():
+            self.calls.append("bucket")
+            yield b
+
+    def grad_shard(self, lo, hi):
+        return torch.empty((hi - lo) // self.world, dtype=self.grad.dtype)
+
+    def apply_shard(self, lo, hi, g, scale):
+        self.calls.append("apply_shard")
+        self.applied[lo:hi] = g * scale
+        self.params[lo:hi] -= 0.5 * g * scale  # a step only the owner of [lo, hi) takes
+
+    def param_buffer(self):
+        return self.params
 
     def begin_apply(self):
         self.calls.append("begin_apply")
@@ -86,6 +110,7 @@ def slice_heads(p, lo, hi):
 
 
 def _setup():
+    # 3 * (12*10 + 10 + 10*8 + 8 + 8 + 1) + 3 = 684 gradient elements: divisible by 2, 3, 4 and 6
     L, D, m, hidden, Bg = 3, 2, 6, (10, 8), 16
     p = O.init_params(L, D, m, hidden, 0.1, exp_mask_init=10.0, seed=3).to(torch.float64)
     prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=4.0)
@@ -95,11 +120,11 @@ def _setup():
     return p, prob, v, M, x
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from neural_svd_amd import parallel
     comm = parallel.Communicator.from_env(device=None, backend="gloo")
-    assert comm.rank == rank and comm.world == world
+    assert comm.rank == rank and comm.world == world and comm.count_ranks() == world
     p, prob, v, M, x = _setup()
     Bg = x.shape[0]
     h = Bg // 2
@@ -107,16 +132,41 @@ def _worker(rank, world, port, tmp):
     # global arrangement [f1_0, f1_1, f2_0, f2_1]: rank r owns rows r*q..(r+1)*q of each half
     x_local = torch.cat([x[rank * q:(rank + 1) * q], x[h + rank * q:h + (rank + 1) * q]])
     be = OracleBackend(p, prob, v, M, world=world)
-    parallel.dp_step(be, comm, x_local)
+    probe = parallel.CommProbe(None)
+    parallel.dp_step(be, comm, x_local, exchange=exchange, probe=probe)
     assert abs(comm.max_float(float(rank)) - (world - 1)) < 1e-12
     comm.barrier()
-    # the exchange sequence: moments before the backward, buckets issued before the prefetch, one schedule advance
-    assert be.calls == ["forward", "local_moments", "backward(reduced=True, take_step=False)", "prefetch",
-                        "begin_apply"] + ["apply"] * 3, be.calls
+    # the exchange sequence: moments before the backward, each bucket's collective issued as the backend hands it
+    # over and before the prefetch, one schedule advance, then the optimiser bucket by bucket
+    head = ["forward", "local_moments", "backward(reduced=True, take_step=False)"] + ["bucket"] * 3 + \
+        ["prefetch", "begin_apply"]
+    spans = list(probe.summary())
+    if exchange == "allreduce":
+        assert be.calls == head + ["apply"] * 3, be.calls
+        assert spans == ["moments_allreduce"] + [f"grad_bucket{k}_allreduce_wait" for k in range(3)], spans
+        extra = {}
+    else:
+        assert be.calls == head + ["apply_shard"] * 3, be.calls
+        assert spans == ["moments_allreduce"] + [f"grad_bucket{k}_reduce_scatter_wait" for k in range(3)] + \
+            [f"param_bucket{k}_all_gather_wait" for k in range(3)], spans
+        # what this rank applied: its own slice of every bucket, nothing else; the parameters came back complete
+        own = torch.zeros(be.grad.numel(), dtype=torch.bool)
+        for lo, hi in be.grad_buckets():
+            slo, shi = parallel.shard_range(lo, hi, rank, world)
+            own[slo:shi] = True
+        assert bool(torch.isnan(be.applied[~own]).all()) and not bool(torch.isnan(be.applied[own]).any())
+        extra = dict(own=own, params=be.params, params0=be.params0)
+    assert probe.steps == 1
+    # compute-only mode: the same call sequence with every collective skipped
+    comm.stub = True
+    be2 = OracleBackend(p, prob, v, M, world=world)
+    parallel.dp_step(be2, comm, x_local, exchange=exchange)
+    comm.stub = False
+    assert be2.calls == be.calls
     t = torch.ones(3, dtype=torch.float64) * (rank + 1)
     comm.broadcast(t, 0)
     assert float(t[0]) == 1.0
-    torch.save(dict(loss=be.loss, grad=be.applied, mom=be.mom), os.path.join(tmp, f"r{rank}.pt"))
+    torch.save(dict(loss=be.loss, grad=be.applied, mom=be.mom, **extra), os.path.join(tmp, f"r{rank}.pt"))
     comm.close()
 
 
@@ -130,6 +180,7 @@ def _worker_hp(rank, world, port, tmp):
     be = OracleBackend(slice_heads(p, rank * Ll, (rank + 1) * Ll), prob, v, M, l_off=rank * Ll, world=world)
     parallel.hp_step(be, comm, x)
     assert be.calls[:3] == ["forward", "prefetch", "backward(reduced=False, take_step=True)"], be.calls
+    assert comm.count_ranks() == world
     torch.save(dict(loss=be.loss, grad=be.applied, f=be.f), os.path.join(tmp, f"h{rank}.pt"))
     comm.close()
 
@@ -157,6 +208,29 @@ def test_dp_two_ranks_equals_single_process(tmp_path):
         assert torch.allclose(o["mom"][:L * L].view(L, L), ref["lam1"], rtol=1e-13, atol=1e-15)
         assert torch.allclose(o["mom"][L * L:2 * L * L].view(L, L), ref["lam2"], rtol=1e-13, atol=1e-15)
     assert torch.equal(outs[0]["grad"], outs[1]["grad"])  # identical update on every rank
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_reduce_scatter_all_gather_equals_single_process(tmp_path, world):
+    """exchange "rs_ag": every rank receives the summed gradient of ITS slice of each bucket (== the single-process
+    gradient there), steps only that slice, and the all-gather leaves every rank with the same, complete parameters."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "rs_ag"), nprocs=world, join=True)
+    p, prob, v, M, x = _setup()
+    ref = O.loss_and_grads(x, p, prob, v, M)
+    gref = torch.cat([g.reshape(-1) for g in ref["grads"]])
+    outs = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(world)]
+    covered = torch.zeros_like(outs[0]["own"])
+    for o in outs:
+        assert abs(float(o["loss"]) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
+        own = o["own"]
+        assert float((o["grad"][own] - gref[own]).norm() / gref[own].norm()) < 1e-12
+        assert not bool((covered & own).any())
+        covered |= own
+        assert torch.equal(o["params"], outs[0]["params"])                    # complete and identical everywhere
+        want = o["params0"] - 0.5 * gref
+        assert float((o["params"] - want).norm() / want.norm()) < 1e-12       # every element stepped exactly once
+    assert bool(covered.all())
 
 
 def test_dp_step_single_process_is_plain_step():
