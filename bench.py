@@ -336,13 +336,18 @@ def bench_widened(args):
             loss.backward()
             opt.step()
             last["loss"] = loss.detach()
-        kflops = 2.0 * B * B * L  # the B x B . B x L contraction (the kernel runs it as B x N . N x L)
-        kname = "ka_gemm_kernel"
+        # the launch nsvd_profile_next_forward brackets first in a step is the model evaluation - which IS this step's
+        # dominant kernel (rocprofv3: 560 us of the 1.6 ms, the gathered-row contraction ka_gemm_kernel 99 us):
+        # 2 B L M flops, M = MACs per sample and head of the 128 -> 128 -> 128 -> 1 network behind 2 x 64 features
+        kflops = 2.0 * B * L * (128 * 128 + 128 * 128 + 128)
+        kname = "pmlp_fused_fwd_kernel<1, 0, 0>"
         workload = (f"configs[3]: dense PSD kernel operator K = A A^T / 256 + 1e-3 I on N = {N} points in R^16, "
                     f"L = {L}, batch {B} indices with replacement, NestedLoRA.compute_loss_kernel(split_batch=False) "
                     f"on a 2 x 128 softplus ParallelMLP, torch RMSprop")
         metric = "training steps/sec, synthetic dense kernel operator L=64 B=8192 (NestedLoRA kernel path)"
-        note = ("Kf = K[x][:, x] f / B by nsvd_kernel_apply (batch scattered into the index space, gathered rows of K "
+        kernel_apply_gflop = 2.0 * B * B * L / 1e9  # the B x B . B x L contraction of this row
+        note = (f"[the row's own contraction: {kernel_apply_gflop:.2f} GFLOP per step in ka_gemm_kernel, "
+                "profiles/*_kernel_stats_cfg4.csv] Kf = K[x][:, x] f / B by nsvd_kernel_apply (batch scattered into the index space, gathered rows of K "
                 "against it on the fp32 MFMA); model forward / backward on the E = 1 MFMA kernels; loss kernels; "
                 "the loop around them is the reference-style Python loop")
     else:

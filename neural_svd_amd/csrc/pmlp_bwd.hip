@@ -106,27 +106,75 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
             }
             if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, Lg, DZ + 2 * Lg);
         } else {
-            // direct mode: no moment kernel ran - the 2 Lg moments of THIS head's column straight from f
-            // (8 threads per moment, fixed summation order; the loss scalars are not produced)
-            const int sub = tid & 7;
-            for (int t = tid >> 3; t < 2 * Lg; t += 32) {
-                const int h = t / Lg, lp = t - h * Lg;
-                const int r0 = h ? B1 : 0, nr = h ? B2 : B1;
-                const float* fp = a.evd.f + (size_t)r0 * Lg;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                int bb = sub;
-                for (; bb + 24 < nr; bb += 32) {
-                    s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
-                    s1 = fmaf(fp[(size_t)(bb + 8) * Lg + lp], fp[(size_t)(bb + 8) * Lg + lg], s1);
-                    s2 = fmaf(fp[(size_t)(bb + 16) * Lg + lp], fp[(size_t)(bb + 16) * Lg + lg], s2);
-                    s3 = fmaf(fp[(size_t)(bb + 24) * Lg + lp], fp[(size_t)(bb + 24) * Lg + lg], s3);
+            // direct mode: no moment kernel ran - the 2 Lg moments of THIS head's column straight from f.
+            // Row-parallel: a thread takes whole rows of f (16 heads = one 64-byte read per row and half), multiplies
+            // them by the row's f[.][lg] and keeps 2 x 16 partial moments; the 256 partial vectors are then summed by
+            // a halving butterfly (32 shuffles instead of 32 x 6), across the waves through LDS, in a fixed order.
+            // (One memory round trip and ~3 K cycles where 8 threads per moment walking the batch took ~8 K.)
+            // The loss scalars are not produced.
+            const int nchunk = (Lg + 15) >> 4;
+            float* red = DZ + 256;  // [nchunk][4 waves][32]   (2 Lg <= 256 floats of col in front of it)
+            const float* fh0 = a.evd.f;
+            const float* fh1 = a.evd.f + (size_t)B1 * Lg;
+            const bool vec = (Lg & 3) == 0;
+            for (int c = 0; c < nchunk; ++c) {
+                const int lp0 = 16 * c;
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = 0.f;
+                for (int r = tid; r < B1; r += 256) {
+                    const bool has1 = r < B2;
+                    const float* r0 = fh0 + (size_t)r * Lg;
+                    const float* r1 = fh1 + (size_t)(has1 ? r : 0) * Lg;
+                    float x0[16], x1[16];
+                    const float g0 = r0[lg], g1 = has1 ? r1[lg] : 0.f;
+                    if (vec && lp0 + 16 <= Lg) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 u0 = *reinterpret_cast<const float4*>(r0 + lp0 + 4 * q);
+                            const float4 u1 = *reinterpret_cast<const float4*>(r1 + lp0 + 4 * q);
+                            x0[4 * q] = u0.x; x0[4 * q + 1] = u0.y; x0[4 * q + 2] = u0.z; x0[4 * q + 3] = u0.w;
+                            x1[4 * q] = u1.x; x1[4 * q + 1] = u1.y; x1[4 * q + 2] = u1.z; x1[4 * q + 3] = u1.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            x0[j] = lp0 + j < Lg ? r0[lp0 + j] : 0.f;
+                            x1[j] = lp0 + j < Lg ? r1[lp0 + j] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        v[j] = fmaf(x0[j], g0, v[j]);
+                        v[16 + j] = fmaf(x1[j], g1, v[16 + j]);
+                    }
                 }
-                for (; bb < nr; bb += 8) s0 = fmaf(fp[(size_t)bb * Lg + lp], fp[(size_t)bb * Lg + lg], s0);
-                float sum = (s0 + s1) + (s2 + s3);
-                sum += __shfl_xor(sum, 1, 64);
-                sum += __shfl_xor(sum, 2, 64);
-                sum += __shfl_xor(sum, 4, 64);
-                if (sub == 0) col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * (sum / (float)nr);
+                // halving butterfly: after the step with partner lane ^ X a lane keeps half of its values, each now
+                // the sum over both lanes; five steps leave ONE value per lane, the sum over its 32-lane half wave
+#define NSVD_BFLY(N, X)                                                         \
+    {                                                                           \
+        const bool up = (lane & (X)) != 0;                                      \
+        _Pragma("unroll") for (int k = 0; k < (N); ++k) {                       \
+            const float send = up ? v[k] : v[k + (N)];                          \
+            const float keep = up ? v[k + (N)] : v[k];                          \
+            v[k] = keep + __shfl_xor(send, (X), 64);                            \
+        }                                                                       \
+    }
+                NSVD_BFLY(16, 1) NSVD_BFLY(8, 2) NSVD_BFLY(4, 4) NSVD_BFLY(2, 8) NSVD_BFLY(1, 16)
+#undef NSVD_BFLY
+                const float tot = v[0] + __shfl_xor(v[0], 32, 64);
+                // which of the 32 values this lane ended up with: bit 4 of the index <- lane bit 0, 3 <- 1, 2 <- 2, ...
+                const int idx = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+                if (lane < 32) red[(c * 4 + w) * 32 + idx] = tot;
+            }
+            __syncthreads();
+            for (int t = tid; t < nchunk * 32; t += 256) {
+                const int c = t >> 5, i = t & 31, h = i >> 4, lp = 16 * c + (i & 15);
+                if (lp < Lg) {
+                    const float* rp = red + c * 128 + i;
+                    const float sum = (rp[0] + rp[32]) + (rp[64] + rp[96]);
+                    col[h * Lg + lp] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * (sum / (float)(h ? B2 : B1));
+                }
             }
         }
         __syncthreads();

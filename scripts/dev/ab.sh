@@ -1,14 +1,14 @@
 #!/bin/bash
 # dev (GPU box): kernel-level A/B of the backward pair: per-kernel average durations from rocprofv3 --kernel-trace --stats
 # of a short bench run, for the default build and with the environment switches given as arguments, e.g.
-#   bash scripts/dev/ab.sh tag NSVD_WGRAD_TILES=1
+#   bash scripts/dev/ab.sh tag NSVD_WGRAD_TILES=1          (BENCH_ARGS="--config cfg3" adds bench.py arguments)
 tag=${1:-ab}; shift
 out=/root/repo/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, env...
   name=$1; shift
-  ( export "$@" _X=1; rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $name -- python3 /root/repo/bench.py --steps 300 --warmup 20 --repeats 3 --no-cpu-baseline --no-extras > $out/$name.json 2> $out/$name.err )
+  ( export "$@" _X=1; rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $name -- python3 /root/repo/bench.py --steps 300 --warmup 20 --repeats 3 --no-cpu-baseline --no-extras $BENCH_ARGS > $out/$name.json 2> $out/$name.err )
   rm -f $out/${name}_kernel_trace.csv
   echo "== $name"; python3 - <<PY
 import csv, json
