@@ -359,25 +359,25 @@ def bench_widened(args):
         model = HeteroNetwork([get_mlp(sizes, nonlinearity="lrelu0.2"), get_mlp(sizes, nonlinearity="lrelu0.2")],
                               [nn.Identity(), nn.Identity()], mu=16.0, regularize_mode="l2_ball").to(dev)
         method = NestedLoRAForCDK(model, neigs=L, step=1, sequential=False, set_first_mode_const=True).to(dev)
-        opt = torch.optim.SGD(method.parameters(), lr=5e-3, momentum=0.9)
+        from neural_svd_amd.cdk import FusedCdkStep
         x, y = torch.randn(B, d0, device=dev), torch.randn(B, d0, device=dev)
         last = {}
+        # the whole step - towers, normalisation, loss, clip_grad_norm_(1.0), SGD momentum, cosine schedule - is ONE C
+        # call (nsvd_cdk_step) on the modules' own parameters
+        fused = FusedCdkStep(method, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=10 * 30, batch_size=B)
 
         def step():
-            opt.zero_grad(set_to_none=True)
-            _, fx, _, fy = method(x, y)
-            loss = method.compute_loss(fx, fy)[0]
-            loss.backward()
-            opt.step()
-            last["loss"] = loss.detach()
+            last["loss"] = fused.step(x, y)[0]
         kflops = 2.0 * B * d0 * d1
         kname = "tower_gemm_nt_kernel"
         workload = (f"configs[4]: CDK step on synthetic features x, y ~ randn({B}, {d0}): two towers {d0} -> {d1} -> "
                     f"{d2} (Linear-BatchNorm-lrelu0.2-Linear-BatchNorm), l2_ball mu = 16, NestedLoRAForCDK L = {L} + "
                     f"constant mode, joint nesting, SGD lr 5e-3 momentum 0.9")
         metric = "training steps/sec, CDK two-tower step L=512 B=1024 (NestedLoRA CDK path)"
-        note = ("towers on csrc/tower.hip (five fp32-MFMA contractions + BatchNorm strip kernels each, forward + "
-                "backward), normalisation and CDK loss on their HIP kernels; torch autograd + torch.optim.SGD around them")
+        note = ("one C call per step (nsvd_cdk_step): towers on csrc/tower.hip (five fp32-MFMA contractions + BatchNorm "
+                "strip kernels each, forward + backward), normalisation, CDK loss, global gradient-norm clip and SGD "
+                "momentum (scripts/exps/sketchy.sh: --optimizer sgd --momentum 0.9 --clip_grad_norm); no torch "
+                "autograd, no torch.optim")
     use_ev = not args.no_kernel_events
     blocks, kms, n_pre = _timed_blocks(step, steps, warmup, repeats, args.prewarm_seconds,
                                        H.profile_next_forward if use_ev else None)

@@ -351,6 +351,36 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, i
 int nsvd_tower_backward(const float* x, const nsvd_tower_params* params, const float* dz, int B, int d0, int d1,
                         int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes, void* stream);
 
+/* One Sketchy-style CDK training step in ONE call: the loop body of examples/cdk/sketchy/main_sketchy.py:180-212 as
+ * scripts/exps/sketchy.sh configures it (sgd, momentum 0.9, --clip_grad_norm), AMP branches off:
+ *     optimizer.zero_grad(); _, fx, _, fy = method(x, y); loss, *_ = method.compute_loss(fx, fy); loss.backward()
+ *     nn.utils.clip_grad_norm_(model.parameters(), max_norm); optimizer.step()
+ * with model = HeteroNetwork(two get_mlp towers, Identity projectors, mu, regularize_mode) (examples/models/siam.py:132-166)
+ * and method = NestedLoRAForCDK(model, neigs = d2, ...) (methods/nestedlora.py:335-378). Stages: nsvd_tower_forward x 2
+ * (running statistics updated), nsvd_row_normalize_forward x 2 (radius sqrt(mu)), nsvd_cdk_loss_forward / _backward,
+ * nsvd_row_normalize_backward x 2, nsvd_tower_backward x 2, then the total gradient norm over all 16 parameter tensors
+ * in a fixed summation order, torch's clip coefficient min(1, max_grad_norm / (norm + 1e-6)) (max_grad_norm <= 0: no
+ * clipping) and torch.optim.SGD's momentum update (no dampening, nesterov or weight decay):
+ *     g <- coef g;  buf <- g (first_step) or momentum buf + g;  p <- p - lr buf
+ * towers[2] (x tower, y tower): parameters and running statistics, UPDATED IN PLACE; momentum_bufs[2]: the optimiser's
+ * momentum buffers in the same layouts (rm / rv fields unused). lr is the already scheduled value. x, y: (B, d0).
+ * v (d2 + first), M ((d2 + first)^2): nesting masks. loss[0..3] = {loss, operator term, metric term, total gradient
+ * norm before clipping}. rs_joint (B) / rs_indep (B (B - 1)): the loss's diagnostics, or NULL. Shapes as for
+ * nsvd_tower_forward. ws: nsvd_cdk_step_workspace_bytes (0 for an unsupported description). */
+typedef struct nsvd_cdk_step_desc {
+    int32_t B, d0, d1, d2;
+    float slope, bn_eps, bn_momentum;
+    float mu;
+    int32_t normalize_mode;       /* NSVD_NORMALIZE_* */
+    int32_t set_first_mode_const;
+    double lr, momentum, max_grad_norm;
+    int32_t first_step;
+} nsvd_cdk_step_desc;
+size_t nsvd_cdk_step_workspace_bytes(const nsvd_cdk_step_desc* desc);
+int nsvd_cdk_step(const nsvd_cdk_step_desc* desc, const float* x, const float* y, const nsvd_tower_params* towers,
+                  const nsvd_tower_params* momentum_bufs, const float* v, const float* M, float* loss,
+                  float* rs_joint, float* rs_indep, void* ws, size_t ws_bytes, void* stream);
+
 /* Measurement aid (bench.py): record the two hipEvent_t handles immediately before / after the
  * DOMINANT kernel of the next nsvd_operator_forward call made by this host thread (the fused MFMA
  * forward kernel, or the layer-0 GEMM on the generic path), on that call's stream - or, whichever

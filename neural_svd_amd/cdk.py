@@ -304,3 +304,108 @@ def get_mlp(sizes, bias=True, nonlinearity="relu", use_bn=True, weight_normaliza
             model = nn.Sequential(*mods)
     model.output_dim = sizes[-1]
     return model
+
+
+# ------------------------------------------------------------------------------ the fused training step
+class FusedCdkStep:
+    """The loop body of the Sketchy script (examples/cdk/sketchy/main_sketchy.py:180-212 with scripts/exps/sketchy.sh's
+    switches: sgd with momentum, --clip_grad_norm, --use_lr_scheduler; AMP off - this library computes in float32) as
+    ONE C call per step, ``nsvd_cdk_step``: both towers forward and backward, normalisation, the NestedLoRAForCDK loss,
+    the global gradient-norm clip and the SGD momentum update, on the modules' OWN parameter tensors (updated in place:
+    ``method.model`` is always current, its BatchNorm running statistics included). Takes the place of
+
+        optimizer.zero_grad(); _, fx, _, fy = method(x, y); loss, *_ = method.compute_loss(fx, fy); loss.backward()
+        nn.utils.clip_grad_norm_(model.parameters(), max_norm); optimizer.step(); lr_scheduler.step()
+
+    for a model that is HeteroNetwork(two TowerSequential towers, Identity projectors, 'l2_ball' / 'l2_sphere') on a
+    batch the tower kernels take; ``supported(method, batch_size)`` says whether it is."""
+
+    def __init__(self, method: "NestedLoRAForCDK", lr: float, momentum: float = 0.9, max_grad_norm: float = 1.0,
+                 t_max: int = 0, batch_size: int = 1024):
+        ok, why = self.supported(method, batch_size)
+        if not ok:
+            raise H.NsvdError(f"FusedCdkStep: {why}")
+        model = method.model
+        self.method, self.model = method, model
+        self.lr0, self.momentum, self.max_grad_norm, self.t_max = float(lr), float(momentum), float(max_grad_norm or 0.0), int(t_max)
+        self.t = 0
+        self._pending = 0
+        tx = model.backbones["x"]
+        self.B, self.d0, self.d1, self.d2 = int(batch_size), tx[0].in_features, tx[0].out_features, tx[3].out_features
+        dev = tx[0].weight.device
+        self.towers, self.bufs = [], []
+        for side in HeteroNetwork.SIDES:
+            t = model.backbones[side]
+            lin1, bn1, lin2, bn2 = t[0], t[1], t[3], t[4]
+            d = dict(W1=lin1.weight.data, b1=lin1.bias.data, g1=bn1.weight.data, be1=bn1.bias.data,
+                     rm1=bn1.running_mean, rv1=bn1.running_var, W2=lin2.weight.data, b2=lin2.bias.data,
+                     g2=bn2.weight.data, be2=bn2.bias.data, rm2=bn2.running_mean, rv2=bn2.running_var)
+            self.towers.append(d)
+            self.bufs.append({k: torch.zeros_like(v) for k, v in d.items() if not k.startswith("r")})
+        self.slope, self.bn_eps, self.bn_momentum = float(tx.slope), float(tx[1].eps), float(tx[1].momentum)
+        self.mode = H._lib.NORMALIZE_L2_BALL if model.regularize_mode == "l2_ball" else H._lib.NORMALIZE_L2_SPHERE
+        self.v = method.vector_mask.detach().float().to(dev).contiguous()
+        self.M = method.matrix_mask.detach().float().to(dev).contiguous()
+        self.first_const = bool(method.set_first_mode_const)
+        self.loss = torch.zeros(4, dtype=torch.float32, device=dev)  # loss, operator term, metric term, grad norm
+        self.ws = H.cdk_step_workspace(self._desc(self.lr0, True), dev)
+
+    @staticmethod
+    def supported(method, batch_size: int):
+        model = getattr(method, "model", None)
+        if not isinstance(method, NestedLoRAForCDK) or not isinstance(model, HeteroNetwork):
+            return False, "needs NestedLoRAForCDK over a HeteroNetwork"
+        if model.regularize_mode not in ("l2_ball", "l2_sphere") or not model.mu > 0:
+            return False, "needs l2_ball / l2_sphere normalisation with mu > 0"
+        shapes = set()
+        for side in HeteroNetwork.SIDES:
+            t, pr = model.backbones[side], model.projectors[side]
+            if not isinstance(t, TowerSequential) or not isinstance(pr, nn.Identity):
+                return False, "needs TowerSequential backbones (get_mlp([d0, d1, d2], use_bn=True)) and Identity projectors"
+            if not t[0].weight.is_cuda or t[1].momentum is None or not t[1].track_running_stats:
+                return False, "needs GPU towers with BatchNorm running statistics"
+            shapes.add((t[0].in_features, t[0].out_features, t[3].out_features, t.slope, t[1].eps, t[1].momentum))
+        if len(shapes) != 1:
+            return False, "both towers must have the same shape"
+        d0, d1, d2 = list(shapes)[0][:3]
+        if method.neigs != d2:
+            return False, "neigs must equal the towers' output width"
+        if not H.tower_supported(batch_size, d0, d1, d2):
+            return False, f"tower shape {(batch_size, d0, d1, d2)} outside the tower kernels (multiples of 128, B <= 1024)"
+        return True, ""
+
+    def _desc(self, lr, first):
+        return H.cdk_step_desc(self.B, self.d0, self.d1, self.d2, self.slope, self.bn_eps, self.bn_momentum,
+                               self.model.mu, self.mode, self.first_const, lr, self.momentum, self.max_grad_norm, first)
+
+    def current_lr(self) -> float:
+        """CosineAnnealingLR(optimizer, t_max) after self.t scheduler steps (t_max = 0: constant)"""
+        if self.t_max <= 0:
+            return self.lr0
+        return self.lr0 * (1.0 + math.cos(math.pi * self.t / self.t_max)) / 2.0
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor, y: torch.Tensor, rs_joint=None, rs_indep=None) -> torch.Tensor:
+        """one training step on the batch (x, y); returns the device tensor (loss, operator term, metric term, total
+        gradient norm before clipping) - no synchronisation"""
+        if not self.model.training:
+            raise H.NsvdError("FusedCdkStep.step: the model must be in training mode")
+        H.cdk_step(self._desc(self.current_lr(), self.t == 0), x.float().contiguous(), y.float().contiguous(),
+                   self.towers, self.bufs, self.v, self.M, self.loss, self.ws, rs_joint, rs_indep)
+        self.t += 1
+        self._pending += 1
+        if self._pending >= 256:
+            self.flush_counters()
+        return self.loss
+
+    @torch.no_grad()
+    def flush_counters(self) -> None:
+        """BatchNorm1d.num_batches_tracked of the four BatchNorm modules (a bookkeeping counter: the running
+        statistics themselves are updated inside the step) is advanced in batches of steps rather than by four one-
+        element kernels per step; call before a checkpoint."""
+        if self._pending:
+            for side in HeteroNetwork.SIDES:
+                t = self.model.backbones[side]
+                t[1].num_batches_tracked += self._pending
+                t[4].num_batches_tracked += self._pending
+            self._pending = 0

@@ -1,0 +1,246 @@
+// One Sketchy-style CDK training step as ONE C call (BASELINE configs[4]):
+//   two towers forward -> normalize -> NestedLoRAForCDK loss -> its backward -> normalize backward -> two towers
+//   backward -> clip_grad_norm_ over all 16 parameter tensors -> SGD with momentum, parameters updated in place.
+// Replaces the loop body of examples/cdk/sketchy/main_sketchy.py:180-212 as scripts/exps/sketchy.sh configures it
+// (--optimizer sgd --momentum 0.9 --clip_grad_norm), with the AMP branches off (this library computes in float32):
+//   optimizer.zero_grad(); _, fx, _, fy = method(x, y); loss, *_ = method.compute_loss(fx, fy); loss.backward();
+//   nn.utils.clip_grad_norm_(model.parameters(), max_norm); optimizer.step()
+// (the scheduler's lr for the step is the caller's: it passes the already scheduled value, as for RMSprop).
+// Composition of the library's own stages (tower.hip, row_normalize.hip, cdk_loss.hip) - no torch autograd, no
+// torch.optim, no per-step allocation - plus the two kernels below: the squared gradient norm in a fixed summation
+// order (per-block partials, then one block in double) and the clipped momentum update over every tensor in one pass.
+#include <string.h>
+#include "nsvd_kernels.h"
+
+namespace {
+
+constexpr int NT = 8;  // tensors per tower: W1 b1 g1 be1 W2 b2 g2 be2
+constexpr int SUMSQ_BLOCKS = 64;    // blocks of the small-tensor pass
+
+struct TensorTable {
+    float* p[2 * NT];
+    float* buf[2 * NT];
+    const float* g[2 * NT];
+    size_t n[2 * NT];
+    size_t start[2 * NT + 1];  // prefix sums in float4 groups (every tensor padded to a multiple of 4 in the tables)
+};
+
+// partial[b] = sum of squares of block b's share of the SMALL gradient tensors (biases, BatchNorm weights: the two
+// weight matrices of a tower arrive as per-tile sums from the epilogues of their contractions, tower.hip)
+__global__ void __launch_bounds__(256) cdk_sumsq_kernel(TensorTable t, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int k = 0; k < 2 * NT; ++k) {
+        if ((k % NT) == 0 || (k % NT) == 4) continue;  // W1, W2: summed by their GEMMs
+        const float* g = t.g[k];
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < t.n[k]; i += (size_t)gridDim.x * 256)
+            s = fmaf(g[i], g[i], s);
+    }
+    s = nsvd_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// scal[0] = total gradient norm, scal[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (torch's clip_grad_norm_)
+__global__ void __launch_bounds__(256) cdk_norm_finish_kernel(const float* __restrict__ partial, int nblocks,
+                                                              float max_norm, float* __restrict__ scal,
+                                                              float* __restrict__ loss_out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        float coef = 1.f;
+        if (max_norm > 0.f) {
+            coef = max_norm / (norm + 1e-6f);
+            coef = coef > 1.f ? 1.f : coef;  // (a NaN norm gives a NaN coefficient, as in torch)
+        }
+        scal[0] = norm;
+        scal[1] = coef;
+        if (loss_out) loss_out[3] = norm;
+    }
+}
+
+// g' = coef g; buf = first ? g' : momentum buf + g'; p -= lr buf   (torch.optim.SGD, no dampening / nesterov / decay)
+__global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float* __restrict__ scal, float lr,
+                                                      float momentum, int first) {
+    const float coef = scal[1];
+    const size_t total4 = t.start[2 * NT];
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (size_t)gridDim.x * 256) {
+        int k = 0;
+        while (q >= t.start[k + 1]) ++k;
+        const size_t e = (q - t.start[k]) * 4;
+        const size_t left = t.n[k] - e;
+        const float* g = t.g[k] + e;
+        float* p = t.p[k] + e;
+        float* b = t.buf[k] + e;
+        if (left >= 4) {
+            const float4 gv = *reinterpret_cast<const float4*>(g);
+            float4 pv = *reinterpret_cast<float4*>(p);
+            float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(b);
+            bv.x = first ? gv.x * coef : fmaf(momentum, bv.x, gv.x * coef);
+            bv.y = first ? gv.y * coef : fmaf(momentum, bv.y, gv.y * coef);
+            bv.z = first ? gv.z * coef : fmaf(momentum, bv.z, gv.z * coef);
+            bv.w = first ? gv.w * coef : fmaf(momentum, bv.w, gv.w * coef);
+            pv.x = fmaf(-lr, bv.x, pv.x); pv.y = fmaf(-lr, bv.y, pv.y);
+            pv.z = fmaf(-lr, bv.z, pv.z); pv.w = fmaf(-lr, bv.w, pv.w);
+            *reinterpret_cast<float4*>(b) = bv;
+            *reinterpret_cast<float4*>(p) = pv;
+        } else {
+            for (size_t c = 0; c < left; ++c) {
+                const float gc = g[c] * coef;
+                const float bc = first ? gc : fmaf(momentum, b[c], gc);
+                b[c] = bc;
+                p[c] = fmaf(-lr, bc, p[c]);
+            }
+        }
+    }
+}
+
+struct StepWs {
+    void* tower[2];
+    void* cdk;
+    float *z[2], *e[2], *ge[2], *dz[2];
+    float* grad[2];  // per tower: [W1 | b1 | g1 | be1 | W2 | b2 | g2 | be2], each padded to 64 floats
+    float* partial;  // [small tensors: SUMSQ_BLOCKS | tower x: per GEMM tile | tower y: per GEMM tile]
+    int npartial;
+    float* scal;
+    size_t tower_bytes, cdk_bytes, bytes;
+    size_t goff[NT], gn[NT];
+};
+
+StepWs carve_step(const nsvd_cdk_step_desc& d, void* base) {
+    StepWs w;
+    memset(&w, 0, sizeof(w));
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* q = p + off;
+        off += nsvd_align(bytes);
+        return q;
+    };
+    w.tower_bytes = nsvd_tower_workspace_bytes(d.B, d.d0, d.d1, d.d2);
+    w.cdk_bytes = nsvd_cdk_workspace_bytes(d.B, d.d2, d.set_first_mode_const);
+    for (int s = 0; s < 2; ++s) w.tower[s] = take(w.tower_bytes);
+    w.cdk = take(w.cdk_bytes);
+    const size_t bl = (size_t)d.B * d.d2 * sizeof(float);
+    for (int s = 0; s < 2; ++s) {
+        w.z[s] = (float*)take(bl);
+        w.e[s] = (float*)take(bl);
+        w.ge[s] = (float*)take(bl);
+        w.dz[s] = (float*)take(bl);
+    }
+    const size_t n[NT] = {(size_t)d.d1 * d.d0, (size_t)d.d1, (size_t)d.d1, (size_t)d.d1,
+                          (size_t)d.d2 * d.d1, (size_t)d.d2, (size_t)d.d2, (size_t)d.d2};
+    size_t g = 0;
+    for (int k = 0; k < NT; ++k) {
+        w.goff[k] = g;
+        w.gn[k] = n[k];
+        g += (n[k] + 63) / 64 * 64;
+    }
+    for (int s = 0; s < 2; ++s) w.grad[s] = (float*)take(g * sizeof(float));
+    w.npartial = SUMSQ_BLOCKS + 2 * nsvd_tower_sumsq_count(d.d0, d.d1, d.d2);
+    w.partial = (float*)take((size_t)w.npartial * sizeof(float));
+    w.scal = (float*)take(256);
+    w.bytes = off;
+    return w;
+}
+
+bool desc_ok(const nsvd_cdk_step_desc* d) {
+    if (!d) return false;
+    if (nsvd_tower_workspace_bytes(d->B, d->d0, d->d1, d->d2) == 0) return false;
+    if (d->normalize_mode != NSVD_NORMALIZE_L2_BALL && d->normalize_mode != NSVD_NORMALIZE_L2_SPHERE) return false;
+    if (!(d->mu > 0.f)) return false;
+    return true;
+}
+
+float* const* tower_fields(const nsvd_tower_params& t, float* out[NT]) {
+    out[0] = t.W1; out[1] = t.b1; out[2] = t.g1; out[3] = t.be1;
+    out[4] = t.W2; out[5] = t.b2; out[6] = t.g2; out[7] = t.be2;
+    return out;
+}
+
+}  // namespace
+
+extern "C" size_t nsvd_cdk_step_workspace_bytes(const nsvd_cdk_step_desc* d) {
+    if (!desc_ok(d)) return 0;
+    return carve_step(*d, nullptr).bytes;
+}
+
+extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const float* y,
+                             const nsvd_tower_params* towers, const nsvd_tower_params* momentum_bufs, const float* v,
+                             const float* M, float* loss, float* rs_joint, float* rs_indep, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (!desc_ok(d) || !x || !y || !towers || !momentum_bufs || !v || !M || !loss || !ws) return NSVD_EINVAL;
+    if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
+    const StepWs w = carve_step(*d, ws);
+    if (ws_bytes < w.bytes) return NSVD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = d->B, L = d->d2;
+    const float r_up = sqrtf(d->mu);
+    const float* in[2] = {x, y};
+    int rc = 0;
+    // forward: towers (BatchNorm running statistics updated, as a training-mode module does), normalisation
+    for (int t = 0; t < 2; ++t) {
+        rc = nsvd_tower_forward(in[t], &towers[t], B, d->d0, d->d1, d->d2, d->slope, d->bn_eps, d->bn_momentum, 1,
+                                w.z[t], w.tower[t], w.tower_bytes, stream);
+        if (rc) return rc;
+        rc = nsvd_row_normalize_forward(w.z[t], B, L, r_up, d->normalize_mode, w.e[t], stream);
+        if (rc) return rc;
+    }
+    // loss and its gradient w.r.t. the two embeddings
+    rc = nsvd_cdk_loss_forward(w.e[0], w.e[1], nullptr, v, M, B, L, d->set_first_mode_const, loss, rs_joint, rs_indep,
+                               w.cdk, w.cdk_bytes, stream);
+    if (rc) return rc;
+    rc = nsvd_cdk_loss_backward(v, B, L, d->set_first_mode_const, nullptr, w.ge[0], w.ge[1], w.cdk, w.cdk_bytes, stream);
+    if (rc) return rc;
+    // backward: normalisation, towers (gradients into the workspace)
+    TensorTable tab;
+    memset(&tab, 0, sizeof(tab));
+    size_t q4 = 0;
+    for (int t = 0; t < 2; ++t) {
+        rc = nsvd_row_normalize_backward(w.z[t], w.ge[t], B, L, r_up, d->normalize_mode, w.dz[t], stream);
+        if (rc) return rc;
+        nsvd_tower_params g;
+        memset(&g, 0, sizeof(g));
+        float* gp[NT];
+        for (int k = 0; k < NT; ++k) gp[k] = w.grad[t] + w.goff[k];
+        g.W1 = gp[0]; g.b1 = gp[1]; g.g1 = gp[2]; g.be1 = gp[3]; g.W2 = gp[4]; g.b2 = gp[5]; g.g2 = gp[6]; g.be2 = gp[7];
+        rc = nsvd_tower_backward_sumsq(in[t], &towers[t], w.dz[t], B, d->d0, d->d1, d->d2, d->slope, &g, w.tower[t],
+                                       w.tower_bytes,
+                                       w.partial + SUMSQ_BLOCKS + t * nsvd_tower_sumsq_count(d->d0, d->d1, d->d2),
+                                       stream);
+        if (rc) return rc;
+        float *pp[NT], *bb[NT];
+        tower_fields(towers[t], pp);
+        tower_fields(momentum_bufs[t], bb);
+        for (int k = 0; k < NT; ++k) {
+            const int i = t * NT + k;
+            if (!pp[k] || !bb[k]) return NSVD_EINVAL;
+            if ((((uintptr_t)pp[k] | (uintptr_t)bb[k]) & 15) != 0) return NSVD_EINVAL;
+            tab.p[i] = pp[k]; tab.buf[i] = bb[k]; tab.g[i] = gp[k]; tab.n[i] = w.gn[k];
+            tab.start[i] = q4;
+            q4 += (w.gn[k] + 3) / 4;
+        }
+    }
+    tab.start[2 * NT] = q4;
+    // clip_grad_norm_ + SGD momentum over all 16 tensors
+    hipLaunchKernelGGL(cdk_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, tab, w.partial);
+    NSVD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cdk_norm_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)w.partial, w.npartial,
+                       (float)d->max_grad_norm, w.scal, loss);
+    NSVD_CHECK_LAUNCH();
+    size_t blocks = (q4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, (const float*)w.scal,
+                       (float)d->lr, (float)d->momentum, d->first_step);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}

@@ -88,3 +88,10 @@ bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count)
 // stand-alone optimiser launch over n contiguous floats (optimizer.hip)
 int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,
                         hipStream_t s);
+
+// ---- CDK towers (tower.hip): the backward with per-workgroup sums of squares of the two weight-gradient contractions
+// (cdk_step.hip clips the global gradient norm without another pass over them)
+int nsvd_tower_sumsq_count(int d0, int d1, int d2);
+int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1,
+                              int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes,
+                              float* sumsq, void* stream);

@@ -33,6 +33,8 @@ struct GemmNT {
     const float* B;   // (N, ldb)
     float* C;         // (M, ldc), or split-K slice s at C + s * slice_stride
     const float* bias;  // per column of C (N) or null (never with split-K: the strip kernel adds it)
+    float* sumsq;       // null, or one float per workgroup: the sum of squares of its tile of C (gradient-norm clipping
+                        // of the fused training step: the norm costs no extra pass over the weight gradients)
     size_t lda, ldb, ldc, slice_stride;
     int M, N, K, S;   // S split-K slices of K / S columns each
 };
@@ -61,14 +63,25 @@ __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
     const float* b_base = g.B + (size_t)128 * tcol * g.ldb + (size_t)slice * Ks;
     nsvd_tile128_dma(a_base, b_base, (unsigned)g.lda, (unsigned)g.ldb, Ks / BK, smem, acc);
     float* C = g.C + (size_t)slice * g.slice_stride + ((size_t)128 * trow + 64 * wm) * g.ldc + 128 * tcol + 64 * wn + li;
+    float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float bv = g.bias ? g.bias[128 * tcol + 64 * wn + 32 * j + li] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                C[(size_t)(32 * i + acc_row(r, hi)) * g.ldc + 32 * j] = acc[i][j][r] + bv;
+            for (int r = 0; r < 16; ++r) {
+                const float cv = acc[i][j][r] + bv;
+                C[(size_t)(32 * i + acc_row(r, hi)) * g.ldc + 32 * j] = cv;
+                ss = fmaf(cv, cv, ss);
+            }
+    }
+    if (g.sumsq) {  // fixed order: lanes of a wave (butterfly), then the four waves
+        ss = nsvd_wave_sum(ss);
+        __syncthreads();  // the tile loop's last fragment reads are done: reuse its LDS
+        if (lane == 0) smem[w] = ss;
+        __syncthreads();
+        if (tid == 0) g.sumsq[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
     }
 }
 
@@ -495,6 +508,18 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
 
 int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1, int d2,
                         float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes, void* stream) {
+    return nsvd_tower_backward_sumsq(x, p, dz, B, d0, d1, d2, slope, grads, ws, ws_bytes, nullptr, stream);
+}
+
+}  // extern "C"
+
+// nsvd_tower_backward that also leaves, per workgroup of the two weight-gradient contractions, the sum of squares of
+// its tile: sumsq[0 .. nsvd_tower_sumsq_count) (dW2's tiles, then dW1's), or nothing when sumsq is null
+int nsvd_tower_sumsq_count(int d0, int d1, int d2) { return (d2 / 128) * (d1 / 128) + (d1 / 128) * (d0 / 128); }
+
+int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1,
+                              int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes,
+                              float* sumsq, void* stream) {
     if (!x || !p || !dz || !grads || !ws || !tower_shape_ok(B, d0, d1, d2)) return NSVD_EINVAL;
     if (!grads->W1 || !grads->b1 || !grads->g1 || !grads->be1 || !grads->W2 || !grads->b2 || !grads->g2 || !grads->be2)
         return NSVD_EINVAL;
@@ -515,6 +540,7 @@ int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float*
     memset(&g, 0, sizeof(g));
     g.A = w.dY2T; g.lda = B; g.B = w.A1T; g.ldb = B; g.C = grads->W2; g.ldc = d1;
     g.M = d2; g.N = d1; g.K = B; g.S = 1;
+    g.sumsq = sumsq;
     rc = launch_gemm(g, s);
     if (rc) return rc;
     // W2^T (d1, d2), then dA1 = dY2 W2  (A = dY2 (B, d2), B = W2^T (d1, d2), K = d2)
@@ -538,7 +564,6 @@ int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float*
     memset(&g, 0, sizeof(g));
     g.A = w.dY1T; g.lda = B; g.B = w.XT; g.ldb = B; g.C = grads->W1; g.ldc = d0;
     g.M = d1; g.N = d0; g.K = B; g.S = 1;
+    g.sumsq = sumsq ? sumsq + (d2 / 128) * (d1 / 128) : nullptr;
     return launch_gemm(g, s);
 }
-
-}  // extern "C"

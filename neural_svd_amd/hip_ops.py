@@ -590,11 +590,49 @@ def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float
     return grads
 
 
+def cdk_step_desc(B: int, d0: int, d1: int, d2: int, slope: float, bn_eps: float, bn_momentum: float, mu: float,
+                  normalize_mode: int, set_first_mode_const: bool, lr: float, momentum: float, max_grad_norm: float,
+                  first_step: bool) -> "_lib.CdkStepDesc":
+    d = _lib.CdkStepDesc()
+    d.B, d.d0, d.d1, d.d2 = int(B), int(d0), int(d1), int(d2)
+    d.slope, d.bn_eps, d.bn_momentum, d.mu = float(slope), float(bn_eps), float(bn_momentum), float(mu)
+    d.normalize_mode, d.set_first_mode_const = int(normalize_mode), int(bool(set_first_mode_const))
+    d.lr, d.momentum, d.max_grad_norm = float(lr), float(momentum), float(max_grad_norm or 0.0)
+    d.first_step = int(bool(first_step))
+    return d
+
+
+def cdk_step_workspace(desc: "_lib.CdkStepDesc", device) -> torch.Tensor:
+    n = int(_lib.load().nsvd_cdk_step_workspace_bytes(C.byref(desc)))
+    if n == 0:
+        raise NsvdError("cdk_step: unsupported description (tower shapes must be multiples of 128, batch <= 1024; "
+                        "l2_ball / l2_sphere normalisation; mu > 0)")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def cdk_step(desc: "_lib.CdkStepDesc", x: torch.Tensor, y: torch.Tensor, towers: Sequence[dict],
+             momentum_bufs: Sequence[dict], v: torch.Tensor, M: torch.Tensor, loss: torch.Tensor, ws: torch.Tensor,
+             rs_joint: Optional[torch.Tensor] = None, rs_indep: Optional[torch.Tensor] = None) -> None:
+    """one CDK training step (nsvd_cdk_step): towers / momentum_bufs are two dicts each over TOWER_KEYS (the momentum
+    dicts without the running statistics), updated in place; loss: (4) = loss, operator term, metric term, grad norm"""
+    if tuple(x.shape) != (desc.B, desc.d0) or tuple(y.shape) != (desc.B, desc.d0) or loss.numel() < 4:
+        raise NsvdError("cdk_step: x, y must be (B, d0) and loss hold 4 floats")
+    Lp = desc.d2 + desc.set_first_mode_const
+    if v.numel() != Lp or tuple(M.shape) != (Lp, Lp):
+        raise NsvdError(f"cdk_step: v ({Lp}), M ({Lp}, {Lp})")
+    tw = (_lib.TowerParams * 2)(_tower_struct(towers[0], True), _tower_struct(towers[1], True))
+    mb = (_lib.TowerParams * 2)(_tower_struct(momentum_bufs[0], False), _tower_struct(momentum_bufs[1], False))
+    rc = _lib.load().nsvd_cdk_step(C.byref(desc), _ptr(x, "x"), _ptr(y, "y"), tw, mb, _ptr(v, "v"), _ptr(M, "M"),
+                                   _ptr(loss, "loss"), _ptr(rs_joint, "rs_joint"), _ptr(rs_indep, "rs_indep"),
+                                   ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "nsvd_cdk_step")
+
+
 # every wrapper that launches kernels runs on the device of its tensors (see _on_tensor_device)
 for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
               "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
-              "row_normalize_backward", "tower_forward", "tower_backward"):
+              "row_normalize_backward", "tower_forward", "tower_backward", "cdk_step"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

@@ -536,6 +536,46 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5):
     return z, grads, (st1, st2)
 
 
+
+def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm, slope, first_step, eps=1e-5,
+                   bn_momentum=0.1):
+    """One Sketchy-style CDK training step (reference examples/cdk/sketchy/main_sketchy.py:180-212 with
+    scripts/exps/sketchy.sh's switches, AMP off): two towers (get_mlp, examples/models/mlp.py:129-164) behind Identity
+    projectors and normalize('l2_ball', sqrt(mu)) (examples/models/siam.py:156-183), NestedLoRAForCDK loss
+    (methods/nestedlora.py:273-332, set_first_mode_const), clip_grad_norm_(max_norm) over all 16 parameter tensors
+    (torch: coefficient min(1, max_norm / (total_norm + 1e-6))), then torch.optim.SGD with momentum (no dampening, no
+    nesterov, no weight decay: buf = g on the first step, else momentum * buf + g; p -= lr * buf). In place on
+    `towers` (two dicts W1 b1 g1 be1 W2 b2 g2 be2), `bufs` (same keys) and `running` (two dicts rm1 rv1 rm2 rv2).
+    Returns (loss, operator term, metric term), total gradient norm. Pinned by tests/golden/cdk_step.npz."""
+    r_up = float(mu) ** 0.5
+    zs, embs = [], []
+    for inp, P in ((x, towers[0]), (y, towers[1])):
+        z, _, _ = tower_forward_backward(inp, P, torch.zeros(inp.shape[0], P["W2"].shape[0], dtype=inp.dtype), slope, eps)
+        zr = z.detach().clone().requires_grad_(True)
+        zs.append(zr)
+        embs.append(row_normalize(zr, r_up, "l2_ball"))
+    loss, lop, lmet, _, _, gf, gg = cdk_loss(embs[0].detach(), embs[1].detach(), v, M, True)
+    grads = []
+    for inp, P, zr, e, ge, run in ((x, towers[0], zs[0], embs[0], gf, running[0]),
+                                   (y, towers[1], zs[1], embs[1], gg, running[1])):
+        (dz,) = torch.autograd.grad(e, zr, ge)
+        _, g, (st1, st2) = tower_forward_backward(inp, P, dz, slope, eps)
+        grads.append(g)
+        for tag, st in (("1", st1), ("2", st2)):
+            run["rm" + tag].mul_(1 - bn_momentum).add_(bn_momentum * st[0])
+            run["rv" + tag].mul_(1 - bn_momentum).add_(bn_momentum * st[2])
+    total = torch.sqrt(sum((g[k].double() ** 2).sum() for g in grads for k in g)).to(x.dtype)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0) if max_norm and max_norm > 0 else torch.ones_like(total)
+    for P, B, g in zip(towers, bufs, grads):
+        for k in g:
+            gk = g[k] * coef
+            if first_step:
+                B[k].copy_(gk)
+            else:
+                B[k].mul_(momentum).add_(gk)
+            P[k].sub_(lr * B[k])
+    return (loss, lop, lmet), total
+
 # ----------------------------------------------------------------------------- optimiser
 def cosine_lr(base_lr, t, T, eta_min=0.0):
     """closed form of torch.optim.lr_scheduler.CosineAnnealingLR after t scheduler steps

@@ -59,6 +59,7 @@ sys.path.insert(0, REF)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
 
 from methods.nestedlora import (  # noqa: E402
     NestedLoRALossFunctionEVD,
@@ -459,6 +460,76 @@ def golden_tower(out):
                 out[q + f"running_var_{k}"] = np64(m[k].running_var)
 
 
+def golden_cdk_step(out):
+    """The Sketchy training step (examples/cdk/sketchy/main_sketchy.py:180-212 as configured by scripts/exps/sketchy.sh:
+    sgd momentum 0.9, --clip_grad_norm (max norm 1), --use_lr_scheduler = CosineAnnealingLR, AMP off here): HeteroNetwork
+    of two get_mlp towers with Identity projectors (main_sketchy.py:107-116, models/siam.py:132-166), l2_ball
+    normalisation, NestedLoRAForCDK loss, clip_grad_norm_, SGD step, scheduler step - three steps on fixed inputs, float64
+    and float32. Stored: inputs, masks, per-step loss triple and total gradient norm, the parameters / momentum buffers /
+    BatchNorm running statistics after the last step (case sb: every 5th element + norms; its initial weights come from
+    torch.manual_seed(seed) + the same constructor calls)."""
+    from examples.models.mlp import get_mlp
+    from examples.models.siam import HeteroNetwork
+    from methods.nestedlora import NestedLoRAForCDK
+    cases = dict(sa=dict(sizes=[8, 12, 6], B=10, mu=4.0, lr=5e-2, seed=41, T=10),
+                 sb=dict(sizes=[128, 256, 128], B=128, mu=16.0, lr=5e-3, seed=42, T=10))
+    NSTEP = 3
+    for name, c in cases.items():
+        sizes, B, L = c["sizes"], c["B"], c["sizes"][-1]
+        g = torch.Generator().manual_seed(3000 + c["seed"])
+        xs = torch.randn(NSTEP, B, sizes[0], generator=g, dtype=torch.float64)
+        ys = torch.randn(NSTEP, B, sizes[0], generator=g, dtype=torch.float64)
+        if name == "sa":  # (sb: the two randn calls above on torch.Generator().manual_seed(3000 + seed) reproduce them)
+            out[f"{name}_x"], out[f"{name}_y"] = xs.numpy(), ys.numpy()
+        out[f"{name}_cfg"] = np.array([B, sizes[0], sizes[1], sizes[2], c["seed"], NSTEP, c["T"]])
+        out[f"{name}_hyper"] = np.array([c["mu"], c["lr"], 0.9, 1.0, 0.2])  # mu, lr, momentum, max_norm, slope
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            torch.manual_seed(c["seed"])
+            model = HeteroNetwork(backbones=[get_mlp(sizes=sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True),
+                                             get_mlp(sizes=sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True)],
+                                  projectors=[nn.Identity(), nn.Identity()], mu=c["mu"], regularize_mode="l2_ball")
+            if tag == "f64" and name == "sa":
+                for k, v in model.state_dict().items():
+                    out[f"{name}_param0_{k}"] = v.detach().double().numpy()
+            model = model.to(dt).train()
+            method = NestedLoRAForCDK(model, neigs=L, step=1, sequential=False, set_first_mode_const=True)
+            if tag == "f64":
+                out[f"{name}_v"], out[f"{name}_M"] = method.vector_mask.numpy(), method.matrix_mask.numpy()
+            method.vector_mask, method.matrix_mask = method.vector_mask.to(dt), method.matrix_mask.to(dt)
+            opt = torch.optim.SGD(model.parameters(), lr=c["lr"], momentum=0.9, weight_decay=0.0)
+            sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, c["T"])
+            losses, norms = [], []
+            for t in range(NSTEP):
+                opt.zero_grad()
+                _, fx, _, fy = method(xs[t].to(dt), ys[t].to(dt))
+                loss, lop, lmet, rj, ri = method.compute_loss(fx, fy)
+                loss.backward()
+                total_norm = nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+                opt.step()
+                sched.step()
+                losses.append([float(loss), float(lop), float(lmet)])
+                norms.append(float(total_norm))
+            q = f"{name}_{tag}_"
+            out[q + "loss"], out[q + "total_norm"] = np.array(losses), np.array(norms)
+            sd = model.state_dict()
+            for k, v in sd.items():
+                if "num_batches" in k:
+                    continue
+                a = np64(v)
+                if name == "sb":
+                    out[q + f"pnorm_{k}"] = np.array(np.linalg.norm(a))
+                    a = a.reshape(-1)[::5]
+                    if tag == "f32":
+                        continue
+                out[q + f"param_{k}"] = a
+            for k, prm in model.named_parameters():
+                a = np64(opt.state[prm]["momentum_buffer"])
+                if name == "sb":
+                    out[q + f"bufnorm_{k}"] = np.array(np.linalg.norm(a))
+                    continue
+                out[q + f"buf_{k}"] = a
+
+
 def golden_ground_truth(out):
     out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
     out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
@@ -473,6 +544,12 @@ def main():
         golden_normalize(o)
         np.savez_compressed(os.path.join(HERE, "normalize.npz"), **o)
         print("normalize", os.path.getsize(os.path.join(HERE, "normalize.npz")) // 1024, "KiB")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cdk_step":
+        o = {}
+        golden_cdk_step(o)
+        np.savez_compressed(os.path.join(HERE, "cdk_step.npz"), **o)
+        print("cdk_step", os.path.getsize(os.path.join(HERE, "cdk_step.npz")) // 1024, "KiB")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "tower":
         o = {}

@@ -43,14 +43,17 @@ def test_host_side_queries_work_without_gpu():
 
 
 def test_struct_layout_matches_header():
-    """sizeof of the three PODs as the C compiler sees them == ctypes' view."""
+    """sizeof (and two field offsets) of the PODs as the C compiler sees them == ctypes' view."""
     import subprocess
     import tempfile
     from neural_svd_amd import _lib
     prog = r'''
     #include <stdio.h>
     #include "nsvd.h"
-    int main(){ printf("%zu %zu %zu\n", sizeof(nsvd_model_desc), sizeof(nsvd_params), sizeof(nsvd_problem)); return 0; }
+    #include <stddef.h>
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nsvd_model_desc), sizeof(nsvd_params),
+                       sizeof(nsvd_problem), sizeof(nsvd_tower_params), sizeof(nsvd_rmsprop), sizeof(nsvd_cdk_step_desc),
+                       offsetof(nsvd_cdk_step_desc, lr), offsetof(nsvd_cdk_step_desc, first_step)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "t.c")
@@ -59,7 +62,9 @@ def test_struct_layout_matches_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         out = subprocess.check_output([exe]).decode().split()
     assert [int(v) for v in out] == [ctypes.sizeof(_lib.ModelDesc), ctypes.sizeof(_lib.Params),
-                                     ctypes.sizeof(_lib.Problem)]
+                                     ctypes.sizeof(_lib.Problem), ctypes.sizeof(_lib.TowerParams),
+                                     ctypes.sizeof(_lib.Rmsprop), ctypes.sizeof(_lib.CdkStepDesc),
+                                     _lib.CdkStepDesc.lr.offset, _lib.CdkStepDesc.first_step.offset]
 
 
 def test_ops_refuse_cpu_tensors():

@@ -1,0 +1,130 @@
+"""nsvd_cdk_step (the whole Sketchy training step in one C call, behind cdk.FusedCdkStep) against
+
+  * the REFERENCE's own step (tests/golden/cdk_step.npz, case sb: 128 -> 256 -> 128 towers, batch 128, three steps of
+    HeteroNetwork + NestedLoRAForCDK + clip_grad_norm_ + SGD momentum + CosineAnnealingLR): losses, total gradient
+    norms, parameters, momentum buffers, running statistics - float64 truth with the reference's float32 run as the
+    yardstick;
+  * this package's module-by-module path (torch autograd around the same HIP stages + torch's clip and SGD) at
+    BASELINE configs[4]'s size, where only the optimiser arithmetic differs (fp32 rounding)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+KEYS = {"W1": "0.weight", "b1": "0.bias", "g1": "1.weight", "be1": "1.bias", "W2": "3.weight", "b2": "3.bias",
+        "g2": "4.weight", "be2": "4.bias"}
+
+
+def _build(sizes, mu, seed):
+    from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
+    torch.manual_seed(seed)  # the reference's constructor calls in the reference's order: same initial weights
+    model = HeteroNetwork([get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True),
+                           get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True)],
+                          [nn.Identity(), nn.Identity()], mu=mu, regularize_mode="l2_ball").to(DEV).train()
+    method = NestedLoRAForCDK(model, neigs=sizes[-1], step=1, sequential=False, set_first_mode_const=True).to(DEV)
+    return model, method
+
+
+def test_cdk_step_matches_reference_golden():
+    from neural_svd_amd.cdk import FusedCdkStep
+    z = G.load("cdk_step")
+    name = "sb"
+    B, d0, d1, d2, seed, nstep, T = [int(v) for v in z[f"{name}_cfg"]]
+    mu, lr0, mom, max_norm, slope = [float(v) for v in z[f"{name}_hyper"]]
+    model, method = _build([d0, d1, d2], mu, seed)
+    assert np.array_equal(method.vector_mask.cpu().numpy().astype(np.float64), z[f"{name}_v"].astype(np.float64))
+    g = torch.Generator().manual_seed(3000 + seed)
+    xs = torch.randn(nstep, B, d0, generator=g, dtype=torch.float64).float().to(DEV)
+    ys = torch.randn(nstep, B, d0, generator=g, dtype=torch.float64).float().to(DEV)
+    fs = FusedCdkStep(method, lr=lr0, momentum=mom, max_grad_norm=max_norm, t_max=T, batch_size=B)
+    q64, q32 = f"{name}_f64_", f"{name}_f32_"
+    for t in range(nstep):
+        out = fs.step(xs[t], ys[t]).cpu().double().numpy()
+        want, ref32 = z[q64 + "loss"][t], z[q32 + "loss"][t]
+        for i in range(3):
+            tol = max(4 * abs(ref32[i] - want[i]), 3e-6 * max(1.0, abs(want[i])))
+            assert abs(out[i] - want[i]) < tol, (t, i, out[i], want[i])
+        wn, rn = z[q64 + "total_norm"][t], z[q32 + "total_norm"][t]
+        assert abs(out[3] - wn) < max(4 * abs(rn - wn), 3e-6 * wn), (t, out[3], wn)
+    fs.flush_counters()
+    torch.cuda.synchronize()
+    sd = model.state_dict()
+    for side in "xy":
+        for k, n in KEYS.items():
+            key = f"backbones.{side}.{n}"
+            got = sd[key].double().cpu().numpy()
+            want_n, ref32_n = float(z[q64 + f"pnorm_{key}"]), float(z[q32 + f"pnorm_{key}"])
+            assert abs(np.linalg.norm(got) - want_n) < max(4 * abs(ref32_n - want_n), 2e-6 * max(1.0, want_n)), key
+            samp = z[q64 + f"param_{key}"]
+            err = np.linalg.norm(got.reshape(-1)[::5] - samp) / max(np.linalg.norm(samp), 1e-30)
+            assert err < (2e-4 if k in ("b1", "b2") else 5e-6), (key, err)  # biases in front of a BatchNorm: ~0 gradients
+            bgot = fs.bufs["xy".index(side)][k].double().cpu().numpy()
+            bw, b32 = float(z[q64 + f"bufnorm_{key}"]), float(z[q32 + f"bufnorm_{key}"])
+            assert abs(np.linalg.norm(bgot) - bw) < max(6 * abs(b32 - bw), 1e-5 * max(bw, 1e-3)), (key, np.linalg.norm(bgot), bw)
+        for n in ("1.running_mean", "1.running_var", "4.running_mean", "4.running_var"):
+            key = f"backbones.{side}.{n}"
+            samp = z[q64 + f"param_{key}"]
+            got = sd[key].double().cpu().numpy().reshape(-1)[::5]
+            assert np.linalg.norm(got - samp) / np.linalg.norm(samp) < 5e-6, key
+        assert int(sd[f"backbones.{side}.1.num_batches_tracked"]) == nstep
+
+
+def test_cdk_step_matches_module_path_at_headline_size():
+    """configs[4]'s shapes (1024 x 512 -> 8192 -> 512, L = 512): three fused steps against three steps of the module-by-
+    module path on an identically initialised copy (same HIP forward / backward stages; torch's clip_grad_norm_ and SGD)"""
+    from neural_svd_amd.cdk import FusedCdkStep
+    sizes, B, mu = [512, 8192, 512], 1024, 16.0
+    ma, meth_a = _build(sizes, mu, 77)
+    mb, meth_b = _build(sizes, mu, 77)
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert torch.equal(pa, pb)
+    g = torch.Generator().manual_seed(78)
+    xs = torch.randn(3, B, sizes[0], generator=g).to(DEV)
+    ys = torch.randn(3, B, sizes[0], generator=g).to(DEV)
+    ok, why = FusedCdkStep.supported(meth_a, B)
+    assert ok, why
+    fs = FusedCdkStep(meth_a, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=100, batch_size=B)
+    opt = torch.optim.SGD(mb.parameters(), lr=5e-3, momentum=0.9)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 100)
+    for t in range(3):
+        la = fs.step(xs[t], ys[t]).clone()
+        opt.zero_grad()
+        _, fx, _, fy = meth_b(xs[t], ys[t])
+        lb = meth_b.compute_loss(fx, fy)
+        lb[0].backward()
+        nb = nn.utils.clip_grad_norm_(mb.parameters(), max_norm=1.0)
+        opt.step()
+        sched.step()
+        assert abs(float(la[0]) - float(lb[0])) < 2e-5 * max(1.0, abs(float(lb[0]))), (t, float(la[0]), float(lb[0]))
+        assert abs(float(la[3]) - float(nb)) < 2e-5 * float(nb), (t, float(la[3]), float(nb))
+        assert abs(fs.current_lr() - sched.get_last_lr()[0]) < 1e-12
+    for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        d = float((pa - pb).double().norm() / pb.double().norm())
+        assert d < (1e-3 if n.endswith(("0.bias", "3.bias")) else 5e-6), (n, d)
+    for k in ("backbones.x.1.running_var", "backbones.y.4.running_mean"):
+        a, b = ma.state_dict()[k], mb.state_dict()[k]
+        assert float((a - b).double().norm() / b.double().norm()) < 2e-6
+    # bit reproducibility of the fused step
+    mc, meth_c = _build(sizes, mu, 77)
+    fc = FusedCdkStep(meth_c, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=100, batch_size=B)
+    for t in range(3):
+        fc.step(xs[t], ys[t])
+    for pa, pc in zip(ma.parameters(), mc.parameters()):
+        assert torch.equal(pa, pc)
+
+
+def test_cdk_step_refuses_what_it_does_not_implement():
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.cdk import FusedCdkStep
+    model, method = _build([128, 256, 128], 16.0, 5)
+    assert not FusedCdkStep.supported(method, 100)[0]           # batch not a multiple of 128
+    with pytest.raises(H.NsvdError):
+        FusedCdkStep(method, lr=1e-3, batch_size=100)
+    fs = FusedCdkStep(method, lr=1e-3, batch_size=128)
+    model.eval()
+    with pytest.raises(H.NsvdError):
+        fs.step(torch.zeros(128, 128, device=DEV), torch.zeros(128, 128, device=DEV))

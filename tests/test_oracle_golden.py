@@ -358,3 +358,74 @@ def test_tower_matches_reference(case):
     for st, k in ((st1, 1), (st2, 4)):  # running = 0.9 * init + 0.1 * batch (init: mean 0, var 1), unbiased variance
         assert G.rel(0.1 * st[0], z[q + f"running_mean_{k}"]) < 1e-12
         assert G.rel(0.9 + 0.1 * st[2], z[q + f"running_var_{k}"]) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------- CDK training step
+CDK_KEYS = {"W1": "0.weight", "b1": "0.bias", "g1": "1.weight", "be1": "1.bias", "W2": "3.weight", "b2": "3.bias",
+            "g2": "4.weight", "be2": "4.bias"}
+
+
+def cdk_step_case(z, name, dtype=torch.float64):
+    """initial state of golden case `name` of cdk_step.npz: towers, momentum buffers, running statistics, inputs"""
+    B, d0, d1, d2, seed, nstep, T = [int(v) for v in z[f"{name}_cfg"]]
+    towers, running = [], []
+    if name == "sa":
+        for side in "xy":
+            p = f"{name}_param0_backbones.{side}."
+            towers.append({k: torch.tensor(z[p + n]).to(dtype).clone() for k, n in CDK_KEYS.items()})
+            running.append({"rm1": torch.tensor(z[p + "1.running_mean"]).to(dtype).clone(),
+                            "rv1": torch.tensor(z[p + "1.running_var"]).to(dtype).clone(),
+                            "rm2": torch.tensor(z[p + "4.running_mean"]).to(dtype).clone(),
+                            "rv2": torch.tensor(z[p + "4.running_var"]).to(dtype).clone()})
+        xs, ys = torch.tensor(z[f"{name}_x"]).to(dtype), torch.tensor(z[f"{name}_y"]).to(dtype)
+    else:
+        # the reference's constructor calls in the reference's order reproduce its initial weights (torch.nn.Linear's
+        # default init draws from the global generator): two towers, x then y
+        torch.manual_seed(seed)
+        for _ in range(2):
+            l1, l2 = torch.nn.Linear(d0, d1), None
+            l2 = torch.nn.Linear(d1, d2)
+            towers.append({"W1": l1.weight.detach().to(dtype).clone(), "b1": l1.bias.detach().to(dtype).clone(),
+                           "g1": torch.ones(d1, dtype=dtype), "be1": torch.zeros(d1, dtype=dtype),
+                           "W2": l2.weight.detach().to(dtype).clone(), "b2": l2.bias.detach().to(dtype).clone(),
+                           "g2": torch.ones(d2, dtype=dtype), "be2": torch.zeros(d2, dtype=dtype)})
+            running.append({"rm1": torch.zeros(d1, dtype=dtype), "rv1": torch.ones(d1, dtype=dtype),
+                            "rm2": torch.zeros(d2, dtype=dtype), "rv2": torch.ones(d2, dtype=dtype)})
+        g = torch.Generator().manual_seed(3000 + seed)
+        xs = torch.randn(nstep, B, d0, generator=g, dtype=torch.float64).to(dtype)
+        ys = torch.randn(nstep, B, d0, generator=g, dtype=torch.float64).to(dtype)
+    bufs = [{k: torch.zeros_like(v) for k, v in t.items()} for t in towers]
+    return towers, bufs, running, xs, ys, nstep, T
+
+
+@pytest.mark.parametrize("name", ["sa", "sb"])
+def test_cdk_train_step_matches_reference(name):
+    """oracle cdk_train_step == the reference's Sketchy step (towers, l2_ball, CDK loss, clip_grad_norm_, SGD momentum,
+    cosine schedule) over three steps: losses, total gradient norms, parameters, momentum buffers, running statistics"""
+    z = G.load("cdk_step")
+    towers, bufs, running, xs, ys, nstep, T = cdk_step_case(z, name)
+    mu, lr0, mom, max_norm, slope = [float(v) for v in z[f"{name}_hyper"]]
+    v, M = torch.tensor(z[f"{name}_v"]).double(), torch.tensor(z[f"{name}_M"]).double()
+    q = f"{name}_f64_"
+    for t in range(nstep):
+        lr = O.cosine_lr(lr0, t, T)
+        (loss, lop, lmet), total = O.cdk_train_step(xs[t], ys[t], towers, bufs, running, v, M, mu, lr, mom, max_norm, slope,
+                                                    first_step=(t == 0))
+        want = z[q + "loss"][t]
+        assert abs(float(loss) - want[0]) < 1e-10 * max(1.0, abs(want[0]))
+        assert abs(float(lop) - want[1]) < 1e-10 * abs(want[1]) and abs(float(lmet) - want[2]) < 1e-10 * abs(want[2])
+        assert abs(float(total) - z[q + "total_norm"][t]) < 1e-10 * z[q + "total_norm"][t]
+    for side, P, Bf, R in (("x", towers[0], bufs[0], running[0]), ("y", towers[1], bufs[1], running[1])):
+        for k, n in CDK_KEYS.items():
+            key = f"backbones.{side}.{n}"
+            got = P[k].numpy()
+            if name == "sb":
+                assert abs(np.linalg.norm(got) - float(z[q + f"pnorm_{key}"])) < 1e-10 * max(1.0, float(z[q + f"pnorm_{key}"]))
+                assert np.allclose(got.reshape(-1)[::5], z[q + f"param_{key}"], rtol=1e-9, atol=1e-12), key
+                assert abs(np.linalg.norm(Bf[k].numpy()) - float(z[q + f"bufnorm_{key}"])) < 1e-9 * max(1e-3, float(z[q + f"bufnorm_{key}"]))
+            else:
+                assert np.allclose(got, z[q + f"param_{key}"], rtol=1e-9, atol=1e-12), key
+                assert np.allclose(Bf[k].numpy(), z[q + f"buf_{key}"], rtol=1e-8, atol=1e-11), key
+        for rk, n in (("rm1", "1.running_mean"), ("rv1", "1.running_var"), ("rm2", "4.running_mean"), ("rv2", "4.running_var")):
+            got, want = R[rk].numpy(), z[q + f"param_backbones.{side}.{n}"]
+            assert np.allclose(got.reshape(-1)[::5] if name == "sb" else got, want, rtol=1e-9, atol=1e-12), rk
