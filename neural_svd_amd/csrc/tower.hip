@@ -150,15 +150,15 @@ struct BnFwd {
 
 constexpr int BN_MAXR = 16;  // rows per thread: B / RG with B <= 1024 and RG >= 64
 
-template <int STRIP>
+template <int STRIP, int NT = 256>
 struct StripGeom {
-    static constexpr int CG = STRIP / 4, RG = 256 / CG;
+    static constexpr int CG = STRIP / 4, RG = NT / CG;
 };
 
 // per-column totals of the threads' 4-column partials: red[rg][c], then STRIP threads add the row groups in order
-template <int STRIP>
+template <int STRIP, int NT>
 __device__ __forceinline__ void strip_reduce(float* red, const float4& part, float* total, int tid) {
-    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG;
+    constexpr int CG = StripGeom<STRIP, NT>::CG, RG = StripGeom<STRIP, NT>::RG;
     const int c0 = 4 * (tid % CG), rg = tid / CG;
     float* p = red + rg * STRIP + c0;
     p[0] = part.x; p[1] = part.y; p[2] = part.z; p[3] = part.w;
@@ -173,10 +173,10 @@ __device__ __forceinline__ void strip_reduce(float* red, const float4& part, flo
 
 // rows {rg + RG k} of the strip (one float4 per thread) -> the transposed copy, through a [RG][STRIP + 1] LDS tile:
 // thread t then owns column t / (RG / 4) and rows 4 (t % (RG / 4)).. of the batch: one 16-byte store
-template <int STRIP>
+template <int STRIP, int NT>
 __device__ __forceinline__ void strip_transpose_out(float* tile, const float4& v, float* outT, int n0, int B, int k,
                                                     int tid) {
-    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG, LD = STRIP + 1;
+    constexpr int CG = StripGeom<STRIP, NT>::CG, RG = StripGeom<STRIP, NT>::RG, LD = STRIP + 1;
     const int c0 = 4 * (tid % CG), rg = tid / CG;
     __syncthreads();  // the previous batch has been read out
     float* p = tile + rg * LD + c0;
@@ -188,9 +188,9 @@ __device__ __forceinline__ void strip_transpose_out(float* tile, const float4& v
     *reinterpret_cast<float4*>(outT + (size_t)(n0 + col) * B + (size_t)RG * k + r4) = o;
 }
 
-template <int STRIP>
-__global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
-    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG;
+template <int STRIP, int NT>
+__global__ void __launch_bounds__(NT) tower_bn_forward_kernel(BnFwd a) {
+    constexpr int CG = StripGeom<STRIP, NT>::CG, RG = StripGeom<STRIP, NT>::RG;
     __shared__ float red[RG * STRIP];
     __shared__ float tile[RG * (STRIP + 1)];
     __shared__ float csum[STRIP], cmean[STRIP], cinv[STRIP];
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
             if (a.Ysum) *reinterpret_cast<float4*>(a.Ysum + (size_t)(rg + RG * k) * a.N + n0 + c0) = v[k];
         }
     }
-    strip_reduce<STRIP>(red, s1, csum, tid);
+    strip_reduce<STRIP, NT>(red, s1, csum, tid);
     if (tid < STRIP) cmean[tid] = csum[tid] / (float)a.B;
     __syncthreads();
     const float4 mu = make_float4(cmean[c0], cmean[c0 + 1], cmean[c0 + 2], cmean[c0 + 3]);
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
             s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
         }
     }
-    strip_reduce<STRIP>(red, s2, csum, tid);
+    strip_reduce<STRIP, NT>(red, s2, csum, tid);
     if (tid < STRIP) {
         const float var = csum[tid];
         const float inv = 1.0f / sqrtf(var / (float)a.B + a.eps);
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) tower_bn_forward_kernel(BnFwd a) {
 #pragma unroll
             for (int j = 1; j < BN_MAXR; ++j)
                 if (j == k) o = v[j];  // (a run-time index into the register array would put it in scratch)
-            strip_transpose_out<STRIP>(tile, o, a.outT, n0, a.B, k, tid);
+            strip_transpose_out<STRIP, NT>(tile, o, a.outT, n0, a.B, k, tid);
         }
     }
 }
@@ -294,9 +294,9 @@ struct BnBwd {
     float slope;
 };
 
-template <int STRIP>
-__global__ void __launch_bounds__(256) tower_bn_backward_kernel(BnBwd a) {
-    constexpr int CG = StripGeom<STRIP>::CG, RG = StripGeom<STRIP>::RG;
+template <int STRIP, int NT>
+__global__ void __launch_bounds__(NT) tower_bn_backward_kernel(BnBwd a) {
+    constexpr int CG = StripGeom<STRIP, NT>::CG, RG = StripGeom<STRIP, NT>::RG;
     __shared__ float red[RG * STRIP];
     __shared__ float tile[RG * (STRIP + 1)];
     __shared__ float c1[STRIP], c2[STRIP], c3[STRIP];
@@ -335,8 +335,8 @@ __global__ void __launch_bounds__(256) tower_bn_backward_kernel(BnBwd a) {
             s2.x = fmaf(d.x, y.x, s2.x); s2.y = fmaf(d.y, y.y, s2.y); s2.z = fmaf(d.z, y.z, s2.z); s2.w = fmaf(d.w, y.w, s2.w);
         }
     }
-    strip_reduce<STRIP>(red, s1, c1, tid);
-    strip_reduce<STRIP>(red, s2, c2, tid);
+    strip_reduce<STRIP, NT>(red, s1, c1, tid);
+    strip_reduce<STRIP, NT>(red, s2, c2, tid);
     if (tid < STRIP) {
         a.dbeta[n0 + tid] = c1[tid];
         a.dgamma[n0 + tid] = c2[tid];
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(256) tower_bn_backward_kernel(BnBwd a) {
             if (a.dY) *reinterpret_cast<float4*>(a.dY + (size_t)(rg + RG * k) * a.N + n0 + c0) = dy;
         }
     }
-    strip_reduce<STRIP>(red, sb, c3, tid);
+    strip_reduce<STRIP, NT>(red, sb, c3, tid);
     if (a.dbias && tid < STRIP) a.dbias[n0 + tid] = c3[tid];
     if (a.dYT) {
         for (int k = 0; k < nr; ++k) {
@@ -367,26 +367,31 @@ __global__ void __launch_bounds__(256) tower_bn_backward_kernel(BnBwd a) {
 #pragma unroll
             for (int j = 1; j < BN_MAXR; ++j)
                 if (j == k) o = dh[j];
-            strip_transpose_out<STRIP>(tile, o, a.dYT, n0, a.B, k, tid);
+            strip_transpose_out<STRIP, NT>(tile, o, a.dYT, n0, a.B, k, tid);
         }
     }
 }
 
-// 16-column strips for wide layers (two workgroups per CU at 8192 columns); narrower strips below 4096 columns so that
-// a 512-wide layer spreads over 128 (4 columns, batch a multiple of 256) or 64 (8 columns) workgroups instead of 32
+// Wide layers (>= 4096 columns): 32-column strips in 512-thread workgroups - a row of the strip is one whole 128-byte
+// line (with 16-column strips the two halves of a line went to two workgroups, as a rule on two XCDs: every line
+// crossed the fabric twice) and 8 waves keep the rows-per-thread count at 16 float4 (8192 columns = 256 workgroups,
+// one per CU). Narrower strips below 4096 columns so that a 512-wide layer spreads over 128 (4 columns, batch a
+// multiple of 256) or 64 (8 columns) workgroups instead of 16.
 inline int launch_bn_forward(const BnFwd& f, hipStream_t s) {
     if (f.B % 128 || f.B > 1024 || f.N % 16) return NSVD_EINVAL;
-    if (f.N >= 4096) hipLaunchKernelGGL(tower_bn_forward_kernel<16>, dim3(f.N / 16), dim3(256), 0, s, f);
-    else if (f.B % 256 == 0) hipLaunchKernelGGL(tower_bn_forward_kernel<4>, dim3(f.N / 4), dim3(256), 0, s, f);
-    else hipLaunchKernelGGL(tower_bn_forward_kernel<8>, dim3(f.N / 8), dim3(256), 0, s, f);
+    if (f.N >= 4096 && f.N % 32 == 0) hipLaunchKernelGGL((tower_bn_forward_kernel<32, 512>), dim3(f.N / 32), dim3(512), 0, s, f);
+    else if (f.N >= 4096) hipLaunchKernelGGL((tower_bn_forward_kernel<16, 256>), dim3(f.N / 16), dim3(256), 0, s, f);
+    else if (f.B % 256 == 0) hipLaunchKernelGGL((tower_bn_forward_kernel<4, 256>), dim3(f.N / 4), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL((tower_bn_forward_kernel<8, 256>), dim3(f.N / 8), dim3(256), 0, s, f);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
 inline int launch_bn_backward(const BnBwd& b, hipStream_t s) {
     if (b.B % 128 || b.B > 1024 || b.N % 16) return NSVD_EINVAL;
-    if (b.N >= 4096) hipLaunchKernelGGL(tower_bn_backward_kernel<16>, dim3(b.N / 16), dim3(256), 0, s, b);
-    else if (b.B % 256 == 0) hipLaunchKernelGGL(tower_bn_backward_kernel<4>, dim3(b.N / 4), dim3(256), 0, s, b);
-    else hipLaunchKernelGGL(tower_bn_backward_kernel<8>, dim3(b.N / 8), dim3(256), 0, s, b);
+    if (b.N >= 4096 && b.N % 32 == 0) hipLaunchKernelGGL((tower_bn_backward_kernel<32, 512>), dim3(b.N / 32), dim3(512), 0, s, b);
+    else if (b.N >= 4096) hipLaunchKernelGGL((tower_bn_backward_kernel<16, 256>), dim3(b.N / 16), dim3(256), 0, s, b);
+    else if (b.B % 256 == 0) hipLaunchKernelGGL((tower_bn_backward_kernel<4, 256>), dim3(b.N / 4), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((tower_bn_backward_kernel<8, 256>), dim3(b.N / 8), dim3(256), 0, s, b);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
