@@ -351,6 +351,22 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, i
 int nsvd_tower_backward(const float* x, const nsvd_tower_params* params, const float* dz, int B, int d0, int d1,
                         int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes, void* stream);
 
+/* nsvd_operator_backward_evd_step that ALSO draws the next batch and writes its Fourier features - what
+ * nsvd_operator_sample_features(next_seed, next_offset, x_next, ws_next) does as a launch of its own - as guest
+ * workgroups of the backward's first kernel: sampling and features (main_pde.py:92-93, examples/utils.py:139-140)
+ * depend on no weight, and that kernel's own workgroups are latency-bound, so the feature launch of the next step and
+ * its kernel boundary disappear. ws_next: a second workspace of nsvd_workspace_bytes(desc, B) bytes, distinct from ws;
+ * the next nsvd_operator_forward is then called on (x_next, ws_next) with NSVD_FEATURES_READY. MFMA path only
+ * (NSVD_EUNSUPPORTED otherwise: call the two entry points separately). Results are bit-identical to the separate calls. */
+int nsvd_operator_backward_evd_step_next(const nsvd_model_desc* desc, const nsvd_params* params,
+                                         const nsvd_problem* prob, const float* x, int B, const float* f,
+                                         const float* Tf, int mask_kind, const float* v, const float* M,
+                                         float* moments, int moments_reduced, const void* evd_scratch, int L_total,
+                                         int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
+                                         const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path,
+                                         unsigned long long next_seed, unsigned long long next_offset, float* x_next,
+                                         void* ws_next, size_t ws_next_bytes, void* stream);
+
 /* One Sketchy-style CDK training step in ONE call: the loop body of examples/cdk/sketchy/main_sketchy.py:180-212 as
  * scripts/exps/sketchy.sh configures it (sgd, momentum 0.9, --clip_grad_norm), AMP branches off:
  *     optimizer.zero_grad(); _, fx, _, fy = method(x, y); loss, *_ = method.compute_loss(fx, fy); loss.backward()

@@ -89,6 +89,10 @@ SIGNATURES = {
     "nsvd_operator_backward_evd_step": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
                                              _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params),
                                              C.POINTER(Rmsprop), _P, _Z, _I, _P]),
+    "nsvd_operator_backward_evd_step_next": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I,
+                                                  _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params),
+                                                  C.POINTER(Rmsprop), _P, _Z, _I, C.c_uint64, C.c_uint64, _P, _P, _Z,
+                                                  _P]),
     "nsvd_evd_loss_fused": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "nsvd_rmsprop_ema_step": (_I, [_P, _P, _P, _P, _Z, _Dbl, _Dbl, _Dbl, _Dbl, _Dbl, _P]),
     "nsvd_profile_next_forward": (_I, [_P, _P]),

@@ -81,9 +81,17 @@ struct NsvdEvdIn;  // evd_math.h
 struct NsvdOptStep;  // opt_math.h
 struct NsvdHyper;
 // [l_begin, l_begin + l_count): the heads whose gradients this call produces (l_count = 0: all of them)
+// next: draw the NEXT batch (sampler, written to next->x) and write its features into the workspace next->ws as guest
+// workgroups of the chain kernel (what nsvd_fused_features(sampler) does as a launch of its own), or null
+struct NsvdNextBatch {
+    NsvdSampler smp;
+    float* x;     // (B, D) receives the drawn coordinates
+    void* ws;     // the other workspace set (same size as the step's)
+    float eps;    // the problem's finite-difference eps (<= 0: exact-Laplacian constants)
+};
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
                             const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s, int l_begin = 0,
-                            int l_count = 0);
+                            int l_count = 0, const NsvdNextBatch* next = nullptr);
 bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count);
 // stand-alone optimiser launch over n contiguous floats (optimizer.hip)
 int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,

@@ -332,7 +332,7 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
                       const float* M, float* moments, int moments_reduced, const void* evd_scratch, int L_total,
                       int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
                       const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream, int l_begin = 0,
-                      int l_count = 0) {
+                      int l_count = 0, const NsvdNextBatch* next = nullptr) {
     int rc = validate(desc);
     if (rc) return rc;
     if (!prob || !x || !f || !Tf || !ws || B <= 0) return NSVD_EINVAL;
@@ -389,8 +389,10 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
             in.moments_out = moments;
         }
         if (l_count < 0 || l_begin < 0 || l_begin + l_count > desc->L) return NSVD_EINVAL;
-        return nsvd_fused_backward_evd(*desc, *params, B, in, grads, opt ? &st : nullptr, ws, s, l_begin, l_count);
+        return nsvd_fused_backward_evd(*desc, *params, B, in, grads, opt ? &st : nullptr, ws, s, l_begin, l_count,
+                                       next);
     }
+    if (next) return NSVD_EUNSUPPORTED;  // guest feature workgroups exist on the fused kernels only
     if (l_count > 0 && l_count != desc->L) return NSVD_EUNSUPPORTED;  // head windows need the fused kernels
     // generic path: finish the loss with the stand-alone kernels, then the layer-by-layer backward
     if (direct) return NSVD_EINVAL;  // needs the partial moments (evd_scratch) or the reduced ones
@@ -467,4 +469,29 @@ extern "C" int nsvd_operator_backward_evd_step(const nsvd_model_desc* desc, cons
     return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
                              evd_scratch, L_total, l_offset, grad_scale, loss, grads, opt, ws, ws_bytes, path,
                              stream);
+}
+
+extern "C" int nsvd_operator_backward_evd_step_next(const nsvd_model_desc* desc, const nsvd_params* params,
+                                                    const nsvd_problem* prob, const float* x, int B, const float* f,
+                                                    const float* Tf, int mask_kind, const float* v, const float* M,
+                                                    float* moments, int moments_reduced, const void* evd_scratch,
+                                                    int L_total, int l_offset, float grad_scale, float* loss,
+                                                    const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
+                                                    size_t ws_bytes, int path, unsigned long long next_seed,
+                                                    unsigned long long next_offset, float* x_next, void* ws_next,
+                                                    size_t ws_next_bytes, void* stream) {
+    if (!opt || !prob || !x_next || !ws_next || ws_next == ws) return NSVD_EINVAL;
+    if (ws_next_bytes < nsvd_workspace_bytes(desc, B) || ((uintptr_t)ws_next & 255) != 0) return NSVD_EINVAL;
+    NsvdNextBatch nb;
+    memset(&nb, 0, sizeof(nb));
+    nb.smp.seed = next_seed;
+    nb.smp.offset = next_offset;
+    nb.smp.sigma = prob->sigma;
+    nb.smp.on = 1;
+    nb.x = x_next;
+    nb.ws = ws_next;
+    nb.eps = prob->eps;
+    return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
+                             evd_scratch, L_total, l_offset, grad_scale, loss, grads, opt, ws, ws_bytes, path,
+                             stream, 0, 0, &nb);
 }

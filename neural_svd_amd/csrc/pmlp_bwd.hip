@@ -5,6 +5,7 @@
 #include "opt_math.h"
 #include "tile_nt.h"
 #include "tile128_dma.h"
+#include "fourier_body.h"
 
 using namespace nsvd_pmlp;
 
@@ -34,6 +35,12 @@ struct ChainArgs {
     int ldl, l0;                 // df, jac, dsc are (B, ldl) arrays of the whole model; this launch's heads start at l0
     // EVD-loss mode (df == null): NestedLoRALossFunctionEVD.backward evaluated per sample right here
     NsvdEvdIn evd;
+    // guest workgroups (blockIdx >= chain_blocks): the NEXT batch's sampling + Fourier features into another workspace.
+    // They depend on no weight and on nothing this launch computes; the chain blocks are latency-bound (one per CU at
+    // cfg2, MFMA pipe 20 % busy), so the double-precision sincos work of the feature tiles rides in their shadow and
+    // the stand-alone feature launch (5.7 us + a kernel boundary per step) disappears.
+    int chain_blocks, feat_nx, feat_blocks;
+    nsvd_feat::StencilArgs feat;
 };
 
 // PRE: the whole chain's weights and sigmoid inputs are fetched at kernel start (two or three hidden layers; ~290
@@ -43,6 +50,17 @@ struct ChainArgs {
 template <bool PRE>
 __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float DZ[BS * H_LD];  // [c][n]  n contiguous
+    static_assert(BS * H_LD >= nsvd_feat::STAGE_FLOATS, "a feature tile's staging must fit the chain kernel's LDS");
+    if ((int)blockIdx.x >= a.chain_blocks) {
+        const int t = (int)blockIdx.x - a.chain_blocks;
+        const int by = t / a.feat_nx, bx = t - by * a.feat_nx;
+        switch (a.feat.D) {
+            case 1: nsvd_feat::stencil_tile<1, 256>(a.feat, bx, by, DZ); break;
+            case 2: nsvd_feat::stencil_tile<2, 256>(a.feat, bx, by, DZ); break;
+            default: nsvd_feat::stencil_tile<3, 256>(a.feat, bx, by, DZ); break;
+        }
+        return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -820,7 +838,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
 // backward into windows to start exchanging the first window's gradients while the next one is computed).
 static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& p, int B, const float* df,
                                const NsvdEvdIn* evd, const nsvd_params* gp, const NsvdOptStep* opt, void* ws,
-                               hipStream_t s, int l0 = 0, int Lc = 0) {
+                               hipStream_t s, int l0 = 0, int Lc = 0, const NsvdNextBatch* next = nullptr) {
     if (Lc <= 0) Lc = dfull.L;
     if (l0 < 0 || l0 + Lc > dfull.L) return NSVD_EINVAL;
     nsvd_params g;
@@ -852,8 +870,21 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     }
     a.nlayers = d.nlayers; a.B = B; a.L = d.L;
     a.ldl = dfull.L; a.l0 = l0;
-    const int chain_grid = (B / BS) * d.L;
-    if ((nh == 2 || nh == 3) && chain_grid <= 128)
+    const int chain_only = (B / BS) * d.L;
+    a.chain_blocks = chain_only;
+    int chain_grid = chain_only;
+    if (next) {  // the next batch's sampling + features as guest workgroups (same arguments as nsvd_fused_features)
+        const FusedWs wn = carve_fused(dfull, B, next->ws);
+        memset(&a.feat, 0, sizeof(a.feat));
+        a.feat.smp = next->smp;
+        a.feat.x = next->x; a.feat.xout = next->x;
+        a.feat.fB = p.fourier_B; a.feat.phi = wn.phi; a.feat.phiTc = wn.phiTc; a.feat.sctab = wn.sctab;
+        a.feat.B = B; a.feat.m = d.m; a.feat.D = d.D; a.feat.eps = next->eps;
+        a.feat_nx = (d.m + nsvd_feat::FJ - 1) / nsvd_feat::FJ;
+        a.feat_blocks = a.feat_nx * ((B + nsvd_feat::FB - 1) / nsvd_feat::FB);
+        chain_grid += a.feat_blocks;
+    }
+    if ((nh == 2 || nh == 3) && chain_only <= 128)
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<true>, dim3(chain_grid), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<false>, dim3(chain_grid), dim3(256), 0, s, a);
@@ -953,9 +984,10 @@ int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const ns
 
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
                             const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s, int l_begin,
-                            int l_count) {
+                            int l_count, const NsvdNextBatch* next) {
     if (!g && !opt) return NSVD_EINVAL;
-    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s, l_begin, l_count);
+    if (next && (d.D < 1 || d.D > 3 || !p.fourier_B || !next->ws || !next->x)) return NSVD_EINVAL;
+    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s, l_begin, l_count, next);
 }
 
 bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count) {

@@ -410,6 +410,30 @@ def operator_backward_evd_step(shape: ModelShape, params: Params, prob: Problem,
     check(rc, "nsvd_operator_backward_evd_step")
 
 
+def operator_backward_evd_step_next(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor,
+                                    f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                                    M: Optional[torch.Tensor], moments: torch.Tensor, moments_reduced: bool,
+                                    evd_scratch: Optional[torch.Tensor], loss: torch.Tensor, grads: Optional[Params],
+                                    opt: "_lib.Rmsprop", ws: torch.Tensor, next_seed: int, next_offset: int,
+                                    x_next: torch.Tensor, ws_next: torch.Tensor, grad_scale: float = 1.0,
+                                    path: int = PATH_AUTO, l_offset: int = 0) -> None:
+    """operator_backward_evd_step + operator_sample_features(next batch) in the same launches (MFMA path only)."""
+    B = x.shape[0]
+    L_total = f.shape[1]
+    if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or tuple(x_next.shape) != tuple(x.shape) or \
+            (moments is not None and moments.numel() != 2 * L_total * L_total + 1):
+        raise NsvdError("operator_backward_evd_step_next: f/Tf (B, L_total), moments 2*L_total^2+1, x_next like x")
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_backward_evd_step_next(
+        C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
+        _ptr(v, "v"), _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
+        evd_scratch.data_ptr() if evd_scratch is not None else None, int(L_total), int(l_offset),
+        float(grad_scale), _ptr(loss, "loss"), C.byref(grads) if grads is not None else None, C.byref(opt),
+        ws.data_ptr(), ws.numel(), int(path), int(next_seed) & (2 ** 64 - 1), int(next_offset) & (2 ** 64 - 1),
+        _ptr(x_next, "x_next"), ws_next.data_ptr(), ws_next.numel(), _stream())
+    check(rc, "nsvd_operator_backward_evd_step_next")
+
+
 def model_workspace(shape: ModelShape, B: int, device) -> torch.Tensor:
     """workspace of model_forward / model_backward alone (no stencil rows; input dimension up to 64)."""
     d = shape.desc()
@@ -631,7 +655,7 @@ def cdk_step(desc: "_lib.CdkStepDesc", x: torch.Tensor, y: torch.Tensor, towers:
 # every wrapper that launches kernels runs on the device of its tensors (see _on_tensor_device)
 for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
-              "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "kernel_apply", "cdk_loss_forward",
+              "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "operator_backward_evd_step_next", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
               "row_normalize_backward", "tower_forward", "tower_backward", "cdk_step"):
     globals()[_name] = _on_tensor_device(globals()[_name])

@@ -205,9 +205,14 @@ class FusedTrainer:
         self.device_sampler = bool(device_sampler)
         # overlap: two (workspace, x) sets used alternately; set k holds the features of batch k
         self.overlap = bool(overlap) and world > 1 and self.device_sampler
-        self._ws_other = H.new_workspace(shape, self.B, self.device) if self.overlap else None
+        # single GPU / head-parallel with the fused step: the NEXT batch is drawn and its features written by guest
+        # workgroups of the backward's chain kernel (nsvd_operator_backward_evd_step_next) - no feature launch per step
+        self.guest_features = bool(overlap) and self.device_sampler and self.fused_step and not self.keep_grads and \
+            H.path_name(shape, self.B, path, problem) == "fused_mfma" and shape.D <= 3
+        two_sets = self.overlap or self.guest_features
+        self._ws_other = H.new_workspace(shape, self.B, self.device) if two_sets else None
         self._x_other = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device) \
-            if self.overlap else None
+            if two_sets else None
         self._next_ready = False     # the other set already holds the next batch and its features
         self._features_ready = False  # the current set holds the features of the batch being stepped on
         self._own_batch = False      # the batch being stepped on came from the internal device sampler
@@ -323,6 +328,17 @@ class FusedTrainer:
         if self.fused_step and take_step:
             lr, decay = self._advance_schedule()
             opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay)
+            if self.guest_features and self._own_batch and not self._next_ready and \
+                    (self.world == 1 or not self.overlap):
+                # the next batch rides in this backward's first launch (hp with overlap prepares it under its
+                # all-gather instead: parallel.hp_step -> prefetch)
+                H.operator_backward_evd_step_next(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
+                                                  self.mask_kind, v, M, moments, reduced, scratch, loss, None, opt,
+                                                  self.ws, self.sample_key, self.batches_drawn, self._x_other,
+                                                  self._ws_other, 1.0, self.path, l_offset=self.l_off)
+                self.batches_drawn += 1
+                self._next_ready = True
+                return
             H.operator_backward_evd_step(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
                                          self.mask_kind, v, M, moments, reduced, scratch, loss,
                                          self._grads if self.keep_grads else None, opt, self.ws, 1.0, self.path,

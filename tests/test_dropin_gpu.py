@@ -407,3 +407,30 @@ def test_fused_step_bit_identical_at_headline_size():
     for t in (a, c):
         assert torch.equal(t.P.flat, b.P.flat) and torch.equal(t.P.ema, b.P.ema) and torch.equal(t.P.sq, b.P.sq)
     assert torch.equal(c.P.grad, b.P.grad)
+
+
+@pytest.mark.parametrize("D,L,m,B", [(2, 4, 64, 64), (1, 2, 128, 32), (2, 16, 1024, 512)])
+def test_next_batch_by_guest_workgroups_is_bit_identical(D, L, m, B):
+    """nsvd_operator_backward_evd_step_next: the next batch drawn and its features written by guest workgroups of the
+    backward's chain kernel give, bit for bit, the run that launches nsvd_operator_sample_features per step - same
+    batches (the sampler is counter-based), same features, same parameters; one batch is prepared ahead."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    shape = H.ModelShape(L=L, D=D, m=m, hidden=(128, 128, 128), has_exp_mask=True)
+    prob = H.make_problem(H.POT_HARMONIC, 1.0, 0.01, 1.0, 16.0, 4.0)
+    kw = dict(sequential=True, seed=3, device=DEV, sampling_scale=4.0, fourier_scale=0.5, exp_mask_init=10.0, lr=1e-3)
+    a = FusedTrainer(shape, prob, B, **kw)
+    b = FusedTrainer(shape, prob, B, overlap=False, **kw)
+    assert a.guest_features and not b.guest_features and a.fused_step and b.fused_step
+    for it in range(7):
+        a.step()
+        b.step()
+        if it == 3:  # an externally supplied batch in between: the prepared one is kept for the next internal step
+            xe = torch.full((B, D), 0.5, device=DEV)
+            a.step(xe)
+            b.step(xe)
+    torch.cuda.synchronize()
+    assert a.batches_drawn == b.batches_drawn + 1 == 8
+    assert torch.equal(a.x, b.x) and torch.equal(a.f, b.f) and torch.equal(a.Tf, b.Tf)
+    assert torch.equal(a.P.flat, b.P.flat) and torch.equal(a.P.ema, b.P.ema) and torch.equal(a.P.sq, b.P.sq)
+    assert torch.equal(a.loss, b.loss)
