@@ -260,10 +260,15 @@ class NestedLoRA(nn.Module):
         """Tf, f = operator(self, x, importance) on the HIP path."""
         from .operators import fused_problem_of
         prob = fused_problem_of(operator, importance, self.model)
-        if self.sort_indices is not None and self.training:
-            raise NsvdError("register_eigvals() column permutation is not supported on the HIP path")
         x = x.reshape(x.shape[0], -1).float().contiguous()
-        return _OperatorFn.apply(x, self, operator, prob, *self.model.trainable_tensors())
+        Tf, f = _OperatorFn.apply(x, self, operator, prob, *self.model.trainable_tensors())
+        if self.sort_indices is not None and self.training:
+            # register_eigvals (reference methods/nestedlora.py:195-210): forward() hands the operator the model's
+            # columns in eigenvalue order, so Tf and f both come out permuted. The operator acts head by head: the
+            # same result is the permutation applied to its two outputs (autograd routes d loss / d f back through it)
+            idx = self.sort_indices.to(f.device)
+            Tf, f = Tf[:, idx].contiguous(), f[:, idx].contiguous()
+        return Tf, f
 
 
 def get_evd_method(args, method_name, model):

@@ -434,3 +434,47 @@ def test_next_batch_by_guest_workgroups_is_bit_identical(D, L, m, B):
     assert torch.equal(a.x, b.x) and torch.equal(a.f, b.f) and torch.equal(a.Tf, b.Tf)
     assert torch.equal(a.P.flat, b.P.flat) and torch.equal(a.P.ema, b.P.ema) and torch.equal(a.P.sq, b.P.sq)
     assert torch.equal(a.loss, b.loss)
+
+
+def test_register_eigvals_permutation_on_the_operator_path():
+    """reference methods/nestedlora.py:195-210: after register_eigvals() the training forward hands out the model's
+    columns sorted by eigenvalue (descending), so the operator's Tf, f - and with them the nesting order of the loss -
+    are permuted. Check against the oracle: loss of the permuted columns, and parameter gradients == the oracle's
+    backward of d loss / d f routed back through the inverse permutation."""
+    z = G.load("model_small")
+    case = "osc_small"
+    cfg, args, operator, gt, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = build(case, z)
+    x = torch.tensor(z[f"{case}_x"][0]).to(DEV)
+    method.train()
+    L = cfg["neigs"]
+    eig = torch.linspace(1.0, 2.0, L)[torch.randperm(L, generator=torch.Generator().manual_seed(1))]
+    method.register_eigvals(eig.numpy())
+    idx = method.sort_indices
+    assert not torch.equal(idx, torch.arange(L))
+    loss, aux = method.compute_loss_operator(operator, x, importance=imp_train)
+    loss.backward()
+    got = {n: p.grad.clone() for n, p in method.named_parameters() if p.grad is not None}
+    # the same thing by hand: unpermuted outputs, permuted columns, oracle loss / gradient
+    method.reset_eigvals()
+    for p in method.parameters():
+        p.grad = None
+    loss0, aux0 = method.compute_loss_operator(operator, x, importance=imp_train)
+    f0, Tf0 = aux0["f"].detach(), aux0["Tf"].detach()
+    assert torch.equal(aux["f"].detach(), f0[:, idx.to(DEV)]) and torch.equal(aux["Tf"].detach(), Tf0[:, idx.to(DEV)])
+    v, M = method.vector_mask.double(), method.matrix_mask.double()
+    fp, Tfp = f0[:, idx.to(DEV)].double().cpu(), Tf0[:, idx.to(DEV)].double().cpu()
+    want_loss, lam1, lam2, _, _ = O.evd_loss_forward(fp, Tfp, v, M)
+    assert abs(float(loss.detach()) - float(want_loss)) < 2e-5 * abs(float(want_loss))
+    dfp = O.evd_loss_backward(fp, Tfp, v, M, lam1, lam2)
+    df = torch.zeros_like(dfp)
+    df[:, idx] = dfp                                   # back through f[:, idx]
+    (f0.double().cpu() * df).sum()                     # (shape check)
+    # gradients of sum(f * df) through the HIP backward == what the permuted loss produced
+    for p in method.parameters():
+        p.grad = None
+    Tf1, f1 = method.apply_operator(operator, x, imp_train)
+    (f1 * df.float().to(DEV)).sum().backward()
+    for n, p in method.named_parameters():
+        if p.grad is None:
+            continue
+        assert rel(got[n], p.grad) < 2e-5, n
