@@ -306,7 +306,6 @@ def bench_widened(args):
     cfg5 = BASELINE configs[4]: CDK step on synthetic (1024, 512) features: two towers 512 -> 8192 -> 512
     (BatchNorm, lrelu0.2), l2_ball normalisation, NestedLoRAForCDK loss L = 512 + constant mode, SGD momentum
     (reference examples/cdk/sketchy/main_sketchy.py:180-212)."""
-    from types import SimpleNamespace as NS
     from neural_svd_amd import hip_ops as H
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -314,28 +313,17 @@ def bench_widened(args):
     warmup = min(args.warmup, 20)
     repeats = args.repeats or 5
     if args.config == "cfg4":
-        from neural_svd_amd.kernel_ops import synthetic_psd_kernel
-        from neural_svd_amd.models import get_wavefunctions
-        from neural_svd_amd.nested_lowrank import get_evd_method
+        from neural_svd_amd.kernel_ops import FusedKernelTrainer, synthetic_psd_kernel
         N, D, L, B = 10000, 16, 64, args.batch_size or 8192
         op = synthetic_psd_kernel(N, 256, D, 0, dev)
-        margs = NS(ndim=D, n_particles=1, use_fourier_feature=True, fourier_mapping_size=64, fourier_scale=0.05,
-                   fourier_deterministic=False, fourier_append_raw=False, mlp_hidden_dims="128,128", neigs=L,
-                   parallel=1, nonlinearity="softplus", apply_exp_mask=0, exp_mask_init_scale=1.0, hard_mul_const=1.0,
-                   apply_boundary=0, sort=0, loss=NS(neuralsvd=NS(step=1, sequential=False)))
-        torch.manual_seed(0)
-        method = get_evd_method(margs, "neuralsvd", op.index_model(get_wavefunctions(margs).to(dev))).to(dev)
-        opt = torch.optim.RMSprop(method.parameters(), lr=1e-4)
-        g = torch.Generator(device=dev).manual_seed(1)
+        # the whole step as a fixed sequence of C-ABI calls on flat buffers (kernel_ops.FusedKernelTrainer): model
+        # evaluation, Kf = K[x][:, x] f / B, moments, then d loss / d f + backward + RMSprop inside the backward kernels
+        fk = FusedKernelTrainer(op, L=L, m=64, hidden=(128, 128), batch_size=B, sequential=False, lr=1e-4,
+                                rmsprop_decay=0.99, rmsprop_eps=1e-8, fourier_scale=0.05, seed=0)
         last = {}
 
         def step():
-            opt.zero_grad(set_to_none=True)
-            loss, _ = method.compute_loss_kernel(op.get_approx_kernel_op, op.sample_indices(B, g), None,
-                                                 split_batch=False)
-            loss.backward()
-            opt.step()
-            last["loss"] = loss.detach()
+            last["loss"] = fk.step()[0]
         # the launch nsvd_profile_next_forward brackets first in a step is the model evaluation - which IS this step's
         # dominant kernel (rocprofv3: 560 us of the 1.6 ms, the gathered-row contraction ka_gemm_kernel 99 us):
         # 2 B L M flops, M = MACs per sample and head of the 128 -> 128 -> 128 -> 1 network behind 2 x 64 features
@@ -343,13 +331,13 @@ def bench_widened(args):
         kname = "pmlp_fused_fwd_kernel<1, 0, 0>"
         workload = (f"configs[3]: dense PSD kernel operator K = A A^T / 256 + 1e-3 I on N = {N} points in R^16, "
                     f"L = {L}, batch {B} indices with replacement, NestedLoRA.compute_loss_kernel(split_batch=False) "
-                    f"on a 2 x 128 softplus ParallelMLP, torch RMSprop")
+                    f"on a 2 x 128 softplus ParallelMLP, RMSprop")
         metric = "training steps/sec, synthetic dense kernel operator L=64 B=8192 (NestedLoRA kernel path)"
         kernel_apply_gflop = 2.0 * B * B * L / 1e9  # the B x B . B x L contraction of this row
         note = (f"[the row's own contraction: {kernel_apply_gflop:.2f} GFLOP per step in ka_gemm_kernel, "
                 "profiles/*_kernel_stats_cfg4.csv] Kf = K[x][:, x] f / B by nsvd_kernel_apply (batch scattered into the index space, gathered rows of K "
-                "against it on the fp32 MFMA); model forward / backward on the E = 1 MFMA kernels; loss kernels; "
-                "the loop around them is the reference-style Python loop")
+                "against it on the fp32 MFMA); model forward / backward on the E = 1 MFMA kernels; d loss / d f and the "
+                "RMSprop step inside the backward kernels (nsvd_model_backward_evd_step): no torch autograd, no torch.optim")
     else:
         import torch.nn as nn
         from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp

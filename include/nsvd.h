@@ -367,6 +367,21 @@ int nsvd_operator_backward_evd_step_next(const nsvd_model_desc* desc, const nsvd
                                          unsigned long long next_seed, unsigned long long next_offset, float* x_next,
                                          void* ws_next, size_t ws_next_bytes, void* stream);
 
+/* The kernel-operator training step's backward half in one call (NestedLoRA.compute_loss_kernel with
+ * split_batch = False, methods/nestedlora.py:230-252, followed by loss.backward(); optimizer.step(); ema.update()):
+ * after nsvd_model_forward(save_for_backward = 1) produced f = model(x) and the caller computed Tf = Kf from it
+ * (nsvd_kernel_apply; no gradient flows through Kf: NestedLoRALossFunctionEVD.backward, methods/nestedlora.py:98-111),
+ * this evaluates d loss / d f per sample inside the backward kernels from the moments (as
+ * nsvd_operator_backward_evd does: same `moments` / `moments_reduced` / `evd_scratch` conventions), runs autograd's
+ * backward of the plain model evaluation and - when opt != NULL - takes the RMSprop (+ EMA) step in the epilogue of
+ * the weight-gradient kernel (grads may then be NULL). Input dimension up to 64; MFMA path only (128-wide hidden
+ * layers, B a multiple of 32): NSVD_EUNSUPPORTED otherwise. ws: the workspace of the nsvd_model_forward call. */
+int nsvd_model_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
+                                 const float* f, const float* Tf, int mask_kind, const float* v, const float* M,
+                                 float* moments, int moments_reduced, const void* evd_scratch, float grad_scale,
+                                 float* loss, const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
+                                 size_t ws_bytes, void* stream);
+
 /* One Sketchy-style CDK training step in ONE call: the loop body of examples/cdk/sketchy/main_sketchy.py:180-212 as
  * scripts/exps/sketchy.sh configures it (sgd, momentum 0.9, --clip_grad_norm), AMP branches off:
  *     optimizer.zero_grad(); _, fx, _, fy = method(x, y); loss, *_ = method.compute_loss(fx, fy); loss.backward()

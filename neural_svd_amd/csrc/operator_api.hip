@@ -332,10 +332,12 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
                       const float* M, float* moments, int moments_reduced, const void* evd_scratch, int L_total,
                       int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
                       const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream, int l_begin = 0,
-                      int l_count = 0, const NsvdNextBatch* next = nullptr) {
-    int rc = validate(desc);
+                      int l_count = 0, const NsvdNextBatch* next = nullptr, bool model_mode = false) {
+    // model_mode: the forward was nsvd_model_forward (plain model evaluation, any input dimension up to 64, no
+    // Hamiltonian): Tf is whatever operator output the caller computed from f (the kernel-operator path)
+    int rc = validate(desc, model_mode ? MODEL_MAX_D : 4);
     if (rc) return rc;
-    if (!prob || !x || !f || !Tf || !ws || B <= 0) return NSVD_EINVAL;
+    if ((!prob && !model_mode) || !x || !f || !Tf || !ws || B <= 0) return NSVD_EINVAL;
     // direct mode (fused path): neither reduced moments nor partial sums - the backward kernel takes the moments it
     // needs from f itself; `moments` and `loss` are then not written
     const bool direct = !moments_reduced && !evd_scratch;
@@ -361,10 +363,11 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
         st.sq = opt->sq;
         st.h = nsvd_make_hyper(opt->lr, opt->alpha, opt->eps, opt->has_ema ? opt->ema_decay : 0.0, 1.0);
     }
-    if (ws_bytes < nsvd_workspace_bytes(desc, B)) return NSVD_EINVAL;
+    if (ws_bytes < (model_mode ? nsvd_model_workspace_bytes(desc, B) : nsvd_workspace_bytes(desc, B))) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = want_fused(*desc, B, path, !(prob->eps > 0.f));
+    const bool fused = model_mode ? nsvd_fused_model_supported(*desc, B) : want_fused(*desc, B, path, !(prob->eps > 0.f));
+    if (model_mode && !fused) return NSVD_EUNSUPPORTED;  // plain-model training steps exist on the MFMA kernels only
     if ((path == NSVD_PATH_FUSED || path == NSVD_PATH_FUSED_BF16X3) && !fused) return NSVD_EUNSUPPORTED;
     if (L_total <= 0) L_total = desc->L;
     if (l_offset < 0 || l_offset + desc->L > L_total || L_total > 128) return NSVD_EINVAL;
@@ -494,4 +497,16 @@ extern "C" int nsvd_operator_backward_evd_step_next(const nsvd_model_desc* desc,
     return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
                              evd_scratch, L_total, l_offset, grad_scale, loss, grads, opt, ws, ws_bytes, path,
                              stream, 0, 0, &nb);
+}
+
+extern "C" int nsvd_model_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params, const float* x,
+                                            int B, const float* f, const float* Tf, int mask_kind, const float* v,
+                                            const float* M, float* moments, int moments_reduced,
+                                            const void* evd_scratch, float grad_scale, float* loss,
+                                            const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    if (!opt && !grads) return NSVD_EINVAL;
+    return backward_evd_impl(desc, params, nullptr, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced, evd_scratch,
+                             0, 0, grad_scale, loss, grads, opt, ws, ws_bytes, NSVD_PATH_AUTO, stream, 0, 0, nullptr,
+                             true);
 }

@@ -254,9 +254,10 @@ def operator_backward(shape: ModelShape, params: Params, prob: Problem, x: torch
 
 
 def model_forward(shape: ModelShape, params: Params, x: torch.Tensor, hard_mul_const: float,
-                  ws: torch.Tensor, save_for_backward: bool = False) -> torch.Tensor:
+                  ws: torch.Tensor, save_for_backward: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B = x.shape[0]
-    out = torch.empty((B, shape.L), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, shape.L), dtype=torch.float32, device=x.device)
     d = shape.desc()
     rc = _lib.load().nsvd_model_forward(C.byref(d), C.byref(params), _ptr(x, "x"), B, float(hard_mul_const),
                                         _ptr(out), ws.data_ptr(), ws.numel(), int(save_for_backward), _stream())
@@ -434,6 +435,26 @@ def operator_backward_evd_step_next(shape: ModelShape, params: Params, prob: Pro
     check(rc, "nsvd_operator_backward_evd_step_next")
 
 
+def model_backward_evd_step(shape: ModelShape, params: Params, x: torch.Tensor, f: torch.Tensor, Tf: torch.Tensor,
+                            mask_kind: int, v: Optional[torch.Tensor], M: Optional[torch.Tensor],
+                            moments: torch.Tensor, moments_reduced: bool, evd_scratch: Optional[torch.Tensor],
+                            loss: torch.Tensor, grads: Optional[Params], opt: Optional["_lib.Rmsprop"],
+                            ws: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """EVD loss gradient + backward of the plain model evaluation (+ the optimiser step when opt is given) after
+    model_forward(save_for_backward=True); Tf is the operator output computed from f (no gradient through it)."""
+    B, L = f.shape
+    if tuple(Tf.shape) != (B, L) or L != shape.L or x.shape[0] != B or moments.numel() != 2 * L * L + 1:
+        raise NsvdError("model_backward_evd_step: f, Tf (B, L); moments 2 L^2 + 1")
+    d = shape.desc()
+    rc = _lib.load().nsvd_model_backward_evd_step(
+        C.byref(d), C.byref(params), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind), _ptr(v, "v"),
+        _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
+        evd_scratch.data_ptr() if evd_scratch is not None else None, float(grad_scale), _ptr(loss, "loss"),
+        C.byref(grads) if grads is not None else None, C.byref(opt) if opt is not None else None, ws.data_ptr(),
+        ws.numel(), _stream())
+    check(rc, "nsvd_model_backward_evd_step")
+
+
 def model_workspace(shape: ModelShape, B: int, device) -> torch.Tensor:
     """workspace of model_forward / model_backward alone (no stencil rows; input dimension up to 64)."""
     d = shape.desc()
@@ -444,7 +465,7 @@ def model_workspace(shape: ModelShape, B: int, device) -> torch.Tensor:
 
 
 def kernel_apply(K: torch.Tensor, N: int, rows: torch.Tensor, cols: torch.Tensor, f: torch.Tensor, scale: float,
-                 ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 ws: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Kf = scale * K[rows][:, cols] @ f on the MFMA. K: (N_rows >= N, ldk) float32 with ldk >= N rounded up to 64;
     rows (B1), cols (B2): int64; f: (B2, L). Returns (B1, L)."""
     if K.dim() != 2 or not K.is_cuda or K.dtype != torch.float32 or K.stride(1) != 1:
@@ -459,7 +480,8 @@ def kernel_apply(K: torch.Tensor, N: int, rows: torch.Tensor, cols: torch.Tensor
     lib = _lib.load()
     if ws is None:
         ws = torch.empty(lib.nsvd_kernel_apply_workspace_bytes(int(N), B1, L), dtype=torch.uint8, device=f.device)
-    out = torch.empty((B1, L), dtype=torch.float32, device=f.device)
+    if out is None:
+        out = torch.empty((B1, L), dtype=torch.float32, device=f.device)
     rc = lib.nsvd_kernel_apply(K.data_ptr(), K.stride(0), int(N), rows.data_ptr(), B1, cols.data_ptr(), B2,
                                _ptr(f, "f"), L, float(scale), _ptr(out, "out"), ws.data_ptr(), ws.numel(), _stream())
     check(rc, "nsvd_kernel_apply")
@@ -655,7 +677,7 @@ def cdk_step(desc: "_lib.CdkStepDesc", x: torch.Tensor, y: torch.Tensor, towers:
 # every wrapper that launches kernels runs on the device of its tensors (see _on_tensor_device)
 for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
-              "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "operator_backward_evd_step_next", "kernel_apply", "cdk_loss_forward",
+              "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "operator_backward_evd_step_next", "model_backward_evd_step", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
               "row_normalize_backward", "tower_forward", "tower_backward", "cdk_step"):
     globals()[_name] = _on_tensor_device(globals()[_name])

@@ -79,3 +79,70 @@ def synthetic_psd_kernel(N: int = 10000, rank: int = 256, dim: int = 16, seed: i
     K = A @ A.T / rank
     K.diagonal().add_(1e-3)
     return DenseKernelOperator(K, z.to(device))
+
+
+class FusedKernelTrainer:
+    """The kernel-operator training step (NestedLoRA.compute_loss_kernel with split_batch = False on a
+    DenseKernelOperator, then loss.backward(); RMSprop (+ cosine schedule); EMA - reference methods/nestedlora.py:230-252
+    with the optimiser of examples/utils.py:50-57) as a fixed sequence of C-ABI calls on flat parameter buffers: index
+    batch -> gather of the coordinates -> model evaluation (nsvd_model_forward) -> Kf = K[x][:, x] f / B
+    (nsvd_kernel_apply) -> moments (nsvd_evd_moments) -> d loss / d f, backward and the optimiser step inside
+    the backward kernels (nsvd_model_backward_evd_step). No torch autograd, no torch.optim; what torch still does is
+    draw the indices and gather the coordinates. The counterpart of trainer.FusedTrainer for BASELINE configs[3]."""
+
+    def __init__(self, op: DenseKernelOperator, L: int, m: int, hidden=(128, 128), batch_size: int = 8192,
+                 sequential: bool = False, step: int = 1, lr: float = 1e-4, rmsprop_decay: float = 0.99,
+                 rmsprop_eps: float = 1e-8, ema_decay: float = 0.0, num_iters: int = 0, fourier_scale: float = 0.05,
+                 hard_mul_const: float = 1.0, seed: int = 0, index_seed: int = 1):
+        from .nested_lowrank import nesting_masks
+        from .trainer import FlatParams, reference_init
+        self.op = op
+        dev = op.K.device
+        self.device = dev
+        D = op.points.shape[1]
+        self.shape = H.ModelShape(L=L, D=D, m=m, hidden=tuple(hidden), has_exp_mask=False)
+        self.B = int(batch_size)
+        if any(h != 128 for h in hidden) or self.B % 32 != 0 or not 1 <= D <= 64 or (2 * m) % 128 != 0:
+            raise H.NsvdError("FusedKernelTrainer needs the MFMA model kernels: 128-wide hidden layers, batch % 32 == 0, "
+                              "2 m % 128 == 0, input dimension <= 64 (nsvd_model_backward_evd_step)")
+        self.P = FlatParams(self.shape, dev)
+        self.P.load(*reference_init(self.shape, fourier_scale, None, seed))
+        self._params = self.P.pack(self.P.flat, True)
+        self._sq = self.P.pack(self.P.sq, False)
+        self._ema = self.P.pack(self.P.ema, True) if ema_decay > 0 else None
+        self.vector_mask, self.matrix_mask, self.mask_kind = nesting_masks(L, sequential, step)
+        cust = self.mask_kind == H.MASK_CUSTOM
+        self.v = self.vector_mask.to(dev) if cust else None
+        self.M = self.matrix_mask.to(dev).contiguous() if cust else None
+        self.lr, self.alpha, self.eps, self.ema_decay, self.num_iters = lr, rmsprop_decay, rmsprop_eps, ema_decay, num_iters
+        self.c = float(hard_mul_const)
+        self.ws = H.model_workspace(self.shape, self.B, dev)
+        self.ka_ws = torch.empty(H._lib.load().nsvd_kernel_apply_workspace_bytes(int(op.N), self.B, L),
+                                 dtype=torch.uint8, device=dev)
+        self.f = torch.empty((self.B, L), dtype=torch.float32, device=dev)
+        self.Kf = torch.empty_like(self.f)
+        self.moments = torch.empty(2 * L * L + 1, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.scratch = H.evd_scratch(self.B, L, dev)
+        self.gen = torch.Generator(device=dev).manual_seed(index_seed)
+        self.t = 0
+
+    def step(self, idx: torch.Tensor = None) -> torch.Tensor:
+        """one optimiser step on the index batch idx (or a fresh draw); returns the device loss triple (no sync)"""
+        from .trainer import cosine_lr
+        if idx is None:
+            idx = self.op.sample_indices(self.B, self.gen)
+        idx = idx.to(torch.int64).contiguous()
+        x = self.op.points.index_select(0, idx)
+        H.model_forward(self.shape, self._params, x, self.c, self.ws, save_for_backward=True, out=self.f)
+        H.kernel_apply(self.op.K, self.op.N, idx, idx, self.f, 1.0 / self.B, ws=self.ka_ws, out=self.Kf)
+        # the reduced moment vector (partials + one reduction launch): at B = 8192 every workgroup of the backward
+        # summing the 128 per-chunk partials of its 2 L moments itself would cost 3 x the reduction
+        H.evd_moments(self.f, self.Kf, self.mask_kind, self.v, self.moments, self.scratch)
+        lr = cosine_lr(self.lr, self.t, self.num_iters) if self.num_iters > 0 else self.lr
+        decay = min(self.ema_decay, (2 + self.t) / (11 + self.t)) if self._ema is not None else 0.0
+        opt = H.rmsprop_state(self._sq, self._ema, lr, self.alpha, self.eps, decay)
+        H.model_backward_evd_step(self.shape, self._params, x, self.f, self.Kf, self.mask_kind, self.v, self.M,
+                                  self.moments, True, None, self.loss, None, opt, self.ws)
+        self.t += 1
+        return self.loss

@@ -36,12 +36,14 @@ def main():
     ap.add_argument("--eval-exact", action="store_true",
                     help="also evaluate the trained weights with the exact Laplacian (separates the finite-difference "
                          "noise of the EVALUATION from what training converged to)")
+    ap.add_argument("--neigs", type=int, default=None, help="oscillator: number of modes (oscillator.sh: 55)")
+    ap.add_argument("--batch-size", type=int, default=None, help="override the configuration's batch size")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if a.problem == "hydrogen":
         a.steps = a.steps or 500000
-        L, B, lim = 16, 512, 50.0
+        L, B, lim = 16, a.batch_size or 512, 50.0
         shape = H.ModelShape(L=L, D=2, m=1024, hidden=(128, 128, 128))
         prob = H.make_problem(H.POT_HYDROGEN, 1.0, a.laplacian_eps, 100.0, 0.0, 16.0)
         kw = dict(sampling_scale=16.0, fourier_scale=0.1)
@@ -50,12 +52,12 @@ def main():
     else:
         a.steps = a.steps or 100000
         a.sequential = True
-        L, B, lim = 32, 4096, 5.0
+        L, B, lim = a.neigs or 32, a.batch_size or 4096, 5.0
         shape = H.ModelShape(L=L, D=2, m=256, hidden=(128, 128, 128), has_exp_mask=True)
         prob = H.make_problem(H.POT_HARMONIC, 1.0, a.laplacian_eps, 1.0, 16.0, 4.0)
         kw = dict(sampling_scale=4.0, fourier_scale=1.0, exp_mask_init=10.0)
         gt = 16.0 - HarmonicOscillator(1.0, 2).get_eigvals(L)[:L]  # [14, 12 x2, 10 x3, ..., 2 x7, 0 x4]
-        label = "configs[2] on one GPU: 2D oscillator L=32 B=4096 sequential nesting, exponential mask"
+        label = "configs[2] on one GPU: 2D oscillator L=%d B=%d sequential nesting, exponential mask" % (L, B)
     path = H.PATH_FUSED_BF16X3 if a.path == "bf16x3" else H.PATH_AUTO
     tr = FusedTrainer(shape, prob, B, sequential=a.sequential, step=1, lr=1e-4, rmsprop_decay=0.999, ema_decay=0.995,
                       num_iters=a.steps, seed=a.seed, device=dev, path=path, **kw)

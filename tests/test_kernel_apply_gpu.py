@@ -180,3 +180,48 @@ def test_compute_loss_kernel_matches_reference_golden(case, split):
             assert abs(float(t.grad.double().norm()) - want) < 1e-5 * want, n
             assert rel(t.grad.reshape(-1)[::61], torch.tensor(z[q64 + f"gradsample_{n}"])) < \
                 tol(f"gradsample_{n}", 5e-6), n
+
+
+def test_fused_kernel_trainer_matches_the_module_loop():
+    """FusedKernelTrainer (model evaluation, kernel_apply, loss, backward and RMSprop inside the C calls) against the
+    reference-style loop on the same index batches: NestedLoRA.compute_loss_kernel on the same DenseKernelOperator,
+    loss.backward(), torch.optim.RMSprop - three steps, parameters and losses."""
+    from types import SimpleNamespace as NS
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.kernel_ops import FusedKernelTrainer, synthetic_psd_kernel
+    from neural_svd_amd.models import get_wavefunctions
+    from neural_svd_amd.nested_lowrank import get_evd_method
+    N, D, L, B, m = 1000, 16, 8, 256, 64
+    op = synthetic_psd_kernel(N, 64, D, 3, DEV)
+    fk = FusedKernelTrainer(op, L=L, m=m, hidden=(128, 128), batch_size=B, sequential=False, lr=1e-3, rmsprop_decay=0.99,
+                            rmsprop_eps=1e-8, fourier_scale=0.05, seed=11)
+    args = NS(ndim=D, n_particles=1, use_fourier_feature=True, fourier_mapping_size=m, fourier_scale=0.05,
+              fourier_deterministic=False, fourier_append_raw=False, mlp_hidden_dims="128,128", neigs=L, parallel=1,
+              nonlinearity="softplus", apply_exp_mask=0, exp_mask_init_scale=1.0, hard_mul_const=1.0, apply_boundary=0,
+              sort=0, loss=NS(neuralsvd=NS(step=1, sequential=False)))
+    net = get_wavefunctions(args).to(DEV)
+    method = get_evd_method(args, "neuralsvd", op.index_model(net)).to(DEV)
+    # same initial weights: the trainer's flat buffers -> the module
+    sd = fk.P.state_dict()
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            key = "model." + n
+            p.copy_(sd[key].reshape(p.shape))
+        net.base.feature_map._B.copy_(sd["model.base.feature_map._B"])
+    opt = torch.optim.RMSprop(method.parameters(), lr=1e-3, alpha=0.99, eps=1e-8)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for t in range(3):
+        idx = op.sample_indices(B, g)
+        la = fk.step(idx).clone()
+        opt.zero_grad()
+        lb, _ = method.compute_loss_kernel(op.get_approx_kernel_op, idx, None, split_batch=False)
+        lb.backward()
+        opt.step()
+        assert abs(float(la[0]) - float(lb)) < 2e-5 * max(1.0, abs(float(lb))), (t, float(la[0]), float(lb))
+    sd = fk.P.state_dict()
+    for n, p in net.named_parameters():
+        got = sd["model." + n].reshape(p.shape)
+        d = float((got - p).double().norm() / p.double().norm().clamp_min(1e-30))
+        # biases start at zero: after three sign-like RMSprop steps they are ~3e-3 and float32 noise in a gradient of
+        # the same magnitude on both sides shows at 1e-5..1e-4 of that
+        assert d < (2e-4 if ".bs." in n else 2e-5), (n, d)
