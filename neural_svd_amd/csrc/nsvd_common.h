@@ -20,17 +20,20 @@ static inline size_t nsvd_align(size_t x, size_t a = 256) { return (x + a - 1) /
 
 // softplus(z) = log(1 + e^z) with torch's threshold. Hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp) plus the
 // first-order log1p correction: with u = fl(1 + t), d = u - 1 (exact), ln(1 + t) = ln(u) + (t - d) / u + ..., and
-// since |t - d| <= 2^-24 a crude 1/u ~ 1 - t/2 is enough (it is exact, = t, in the limit u = 1). 2 transcendental
-// and ~10 VALU instructions instead of the ~60 of ocml log1pf(expf()); max(z,0) + log1p(exp(-|z|)) never
+// since |t - d| <= 2^-24 the factor 1/u is dropped altogether: (t - d)(1 - 1/u) <= 6e-8 t / (1 + t) <= 6e-8 ln(1 + t),
+// half an ulp of the result (and exact in the limit u = 1, where the correction is all there is). 2 transcendental
+// and 7 VALU instructions instead of the ~60 of ocml log1pf(expf()); max(z,0) + log1p(exp(-|z|)) never
 // overflows. Max relative error 1.8e-6 at z = -29 (the float32 rounding of |z| log2 e), checked against float64.
 __device__ __forceinline__ float nsvd_softplus(float z) {
     const float t = __builtin_amdgcn_exp2f(-fabsf(z) * NSVD_LOG2E);  // e^{-|z|} in (0, 1]
     const float u = 1.0f + t;
     const float d = u - 1.0f;
-    const float corr = (t - d) * fmaf(-0.5f, t, 1.0f);
-    const float l = fmaf(__builtin_amdgcn_logf(u), NSVD_LN2, corr);  // ln(1 + t)
-    const float r = fmaxf(z, 0.0f) + l;
-    return z > NSVD_SOFTPLUS_THRESHOLD ? z : r;
+    const float l = fmaf(__builtin_amdgcn_logf(u), NSVD_LN2, t - d);  // ln(1 + t)
+    // max(z, 0) as ONE instruction (v_med3_f32; fmaxf costs a second v_max to quieten NaNs), and no select for torch's
+    // threshold: above z = 20 (NSVD_SOFTPLUS_THRESHOLD) l = e^-z < 2.1e-9 is below half an ulp of z (>= 9.5e-7), so
+    // z + l rounds to z itself - bit for bit what the select returned. Every VALU instruction here costs matrix-pipe
+    // time in the fused forward (scripts/experiments/README.md): 80 of these per lane and layer.
+    return __builtin_amdgcn_fmed3f(z, 0.0f, __builtin_inff()) + l;
 }
 
 // d softplus / dz = sigmoid(z)  (1 above the threshold, like torch's softplus_backward)

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd /root/repo
-NSVD_STAMPS_WS=1 NSVD_LIB_PATH=scripts/_diag/libnsvd_hip_stamps.so python scripts/dev/stamps.py 2>&1 | grep -v amdgpu.ids | tail -10
+timeout 900 python -m pytest tests/test_hip_parity.py tests/test_dropin_gpu.py -m gpu -x -q 2>&1 | tail -3
+for cfg in cfg2 cfg3; do BENCH_ARGS="--config $cfg" bash scripts/dev/ab.sh r03i_$cfg 2>&1 | tail -8; done
