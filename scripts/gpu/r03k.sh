@@ -1,0 +1,3 @@
+#!/bin/bash
+cd /root/repo
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6

@@ -293,7 +293,7 @@ def test_fused_trainer_learns_oscillator_mfma_path(eps):
 @pytest.mark.parametrize("path", ["auto", "bf16x3"])
 def test_headline_config_soak(path):
     """configs[1] with its own sampler, 6000 optimiser steps (1.6 s): parameters, EMA shadow and optimiser state stay
-    finite and the loss has dropped. (A sample drawn exactly at the origin - one in 2^24 with the first version of the
+    finite and the loss has dropped (median over the first 1000 steps' samples against the last 2000 steps'). (A sample drawn exactly at the origin - one in 2^24 with the first version of the
     sampler - made every parameter NaN at step 4081 of this very run.)"""
     from neural_svd_amd import hip_ops as H
     from neural_svd_amd.trainer import FusedTrainer
@@ -304,13 +304,17 @@ def test_headline_config_soak(path):
     losses = []
     for i in range(6000):
         tr.step()
-        if i % 500 == 499:
-            losses.append(float(tr.loss[0]))
+        if i % 25 == 24:
+            losses.append(tr.loss[0].clone())
     torch.cuda.synchronize()
+    losses = [float(v) for v in losses]
     assert all(np.isfinite(losses)), losses
     for t in (tr.P.flat, tr.P.ema, tr.P.sq, tr.f, tr.Tf):
         assert bool(torch.isfinite(t).all())
-    assert np.mean(losses[-4:]) < np.mean(losses[:2]) - 500.0, losses
+    # single-batch losses of the hydrogen problem scatter over +-10^4 (the -Z/r potential: one sample near the origin
+    # moves a batch's operator term by thousands), so the trend is read from medians over 40 / 80 batches, not from
+    # a handful of values
+    assert np.median(losses[-80:]) < np.median(losses[:40]) - 500.0, (np.median(losses[:40]), np.median(losses[-80:]))
 
 
 def test_model_autograd_and_compute_loss_kernel():
