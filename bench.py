@@ -411,7 +411,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(ALT) + ["cfg4", "cfg5"],
                     help="cfg2 = the headline workload; cfg1 / cfg3: the other PDE configurations; cfg4 / cfg5: the "
                          "widened rows (dense kernel operator step; CDK towers + loss step), one GPU")
-    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "allreduce", "rs_ag"],
+    ap.add_argument("--dp-exchange", default="auto", choices=["auto", "allreduce", "rs_ag", "a2a"],
                     help="N > 1, dp: gradient exchange (auto: each candidate is timed briefly, the fastest one takes "
                          "the headline run; all of them are reported in comm.candidates)")
     ap.add_argument("--grad-windows", type=int, default=None,
@@ -467,7 +467,7 @@ def main():
         if args.dp_exchange != "auto":
             exchange = args.dp_exchange
         else:
-            cands = [("allreduce", None), ("rs_ag", None), ("allreduce", 1), ("rs_ag", 1)]
+            cands = [("allreduce", None), ("rs_ag", None), ("a2a", None), ("allreduce", 1), ("rs_ag", 1), ("a2a", 1)]
             cand_report, best = {}, None
             for ex, gw in cands:
                 name = f"{ex}/" + ("auto_windows" if gw is None else f"{gw}_window")
@@ -612,8 +612,10 @@ def main():
                     step_frac=round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
     sharding = {"dp": "samples: each GPU draws its own 512 rows; all-reduce of the 2L^2+1 moments, then the flat "
                       "gradient in buckets (head windows of the backward), " +
-                      ("optimiser on bucket k under the all-reduce of k+1" if exchange == "allreduce" else
-                       "reduce-scatter, optimiser on this rank's 1/N of each bucket, all-gather of the parameters"),
+                      {"allreduce": "optimiser on bucket k under the all-reduce of k+1",
+                       "rs_ag": "reduce-scatter, optimiser on this rank's 1/N of each bucket, all-gather of the parameters",
+                       "a2a": "slice j of each bucket straight to rank j (all-to-all), optimiser on this rank's 1/N, "
+                              "updated slices straight to every rank (all-to-all)"}[exchange],
                 "hp": "heads: each GPU owns L/N heads and evaluates them on the whole global batch; one all-gather "
                       "of f,Tf per step, no gradient traffic"}
     out = {

@@ -19,7 +19,12 @@ device - so the exchange sequence the product runs is the one the tests execute.
        "rs_ag"      reduce-scatter(sum) per bucket, RMSprop/EMA on this rank's 1/world of the bucket only (the
                     square averages and the EMA shadow stay sharded; `gather` them for evaluation / checkpoints),
                     then all-gather of the updated parameters: the same bytes on the wire, 1/world of the optimiser
-                    traffic per rank, and the direct (non-ring) form SURVEY 5 asks for on fully connected xGMI.
+                    traffic per rank, and the two-phase form SURVEY 5 asks for on fully connected xGMI.
+       "a2a"        the same two phases spelled as all-to-alls: every rank sends slice j of the bucket straight to
+                    rank j (point-to-point over the link the two share: all seven links of a rank at once, no ring),
+                    adds the `world` slices it received in rank order, steps its slice, and sends the updated slice
+                    straight to every rank. Whatever RCCL's reduce-scatter / all-gather do internally, this one IS
+                    the direct algorithm.
   "hp"  heads sharded (SURVEY 8(e) "alternative worth measuring"): the L heads of ParallelMLP share nothing but
      the input, so rank r owns heads [r L/W, (r+1) L/W) - weights, gradients and optimiser state are not
      replicated and there is NO gradient traffic; every rank evaluates its heads on the whole global batch and
@@ -40,7 +45,10 @@ Backend protocol (all methods enqueue work and return immediately on the HIP bac
   apply(lo, hi, grad_scale)        dp: optimiser step on the elements [lo, hi) from grad_buffer()[lo:hi]
   grad_shard(lo, hi) -> tensor     dp rs_ag: (hi - lo) / world floats receiving this rank's reduced slice of a bucket
   apply_shard(lo, hi, g, scale)    dp rs_ag: optimiser step on the elements [lo, hi) from the reduced slice g
-  param_buffer() -> tensor         dp rs_ag: the flat parameter buffer (all-gathered in place, bucket by bucket)
+  param_buffer() -> tensor         dp rs_ag / a2a: the flat parameter buffer (gathered in place, bucket by bucket)
+  a2a_buffers(lo, hi) -> (r, s)    dp a2a: two (world, (hi - lo) / world) staging buffers of a bucket (received gradient
+                                   slices; the updated slice replicated once per destination)
+  sum_slices(recv, out)            dp a2a: out = recv[0] + recv[1] + ... (rank order)
   gather_buffers() -> (out, inp)   hp: out (world, *inp.shape) receives every rank's packed [f | Tf] block
   after_gather()                   hp: gathered blocks -> the (B, L) arrays the backward reads
   prefetch()                       work for the NEXT step that depends on no weight (issued under a collective)
@@ -61,7 +69,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-DP_EXCHANGES = ("allreduce", "rs_ag")
+DP_EXCHANGES = ("allreduce", "rs_ag", "a2a")
 
 
 class _Done:
@@ -120,6 +128,12 @@ class Communicator:
         if self.backend != "nccl":
             inp = inp.clone()
         return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out[j] = rank j's inp[self.rank]; inp, out: (world, q) contiguous."""
+        if self.stub:
+            return _Done() if async_op else None
+        return dist.all_to_all_single(out.view(-1), inp.reshape(-1), group=self.group, async_op=async_op)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         """out: (world, *inp.shape) contiguous; out[r] = rank r's inp. async_op: returns the work handle (wait()
@@ -256,6 +270,30 @@ def dp_step(backend, comm: Optional[Communicator], x_local, take_step: bool = Tr
             ag.append(comm.all_gather_flat(params[lo:hi], params[slo:shi], async_op=True))
         for k, work in enumerate(ag):
             with span(f"param_bucket{k}_all_gather_wait"):
+                work.wait()
+    elif exchange == "a2a":
+        stages = []
+        for lo, hi in backend.backward_staged(mom):
+            recv, send = backend.a2a_buffers(lo, hi)
+            q = (hi - lo) // world
+            stages.append((lo, hi, recv, send,
+                           comm.all_to_all(recv, backend.grad_buffer()[lo:hi].view(world, q), async_op=True)))
+        backend.prefetch()
+        backend.begin_apply()
+        params = backend.param_buffer()
+        gathers = []
+        for k, (lo, hi, recv, send, work) in enumerate(stages):
+            with span(f"grad_bucket{k}_all_to_all_wait"):
+                work.wait()
+            slo, shi = shard_range(lo, hi, comm.rank, world)
+            shard = backend.grad_shard(lo, hi)
+            backend.sum_slices(recv, shard)                      # rank order: the same sum wherever it is formed
+            backend.apply_shard(slo, shi, shard, 1.0 / world)
+            send.copy_(params[slo:shi].unsqueeze(0).expand_as(send))
+            q = (hi - lo) // world
+            gathers.append(comm.all_to_all(params[lo:hi].view(world, q), send, async_op=True))
+        for k, work in enumerate(gathers):
+            with span(f"param_bucket{k}_all_to_all_wait"):
                 work.wait()
     else:
         raise ValueError(f"dp exchange must be one of {DP_EXCHANGES}")

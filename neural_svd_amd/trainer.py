@@ -138,7 +138,8 @@ class FusedTrainer:
         window.
         dp_exchange (dp, world > 1): "allreduce" (bucketed all-reduce, identical optimiser pass on every rank) or
         "rs_ag" (reduce-scatter, optimiser on this rank's 1/world of each bucket, all-gather of the parameters; the
-        RMSprop square averages and the EMA shadow then live sharded - gather_optimizer_state() before reading them).
+        RMSprop square averages and the EMA shadow then live sharded - gather_optimizer_state() before reading them)
+        or "a2a" (the same two phases as point-to-point all-to-alls; parallel.py).
         grad_windows (dp, world > 1): head windows the backward is cut into so that a window's gradients go on the
         wire while the next window is computed (None: as many of 4 / 2 / 1 as still give every CU a dW_0 tile)."""
         self.device = torch.device(device)
@@ -285,12 +286,15 @@ class FusedTrainer:
             self._stage_buckets = self._buckets
         self._state_sharded = False  # rs_ag: sq / ema valid on this rank's shards only
         self._gshard = None
-        if world > 1 and not self.hp and dp_exchange == "rs_ag":
+        if world > 1 and not self.hp and dp_exchange in ("rs_ag", "a2a"):
             for lo, hi in self._stage_buckets:
                 if (hi - lo) % world != 0:
-                    raise ValueError(f"dp_exchange='rs_ag': bucket of {hi - lo} elements does not split over {world} "
-                                     f"ranks")
+                    raise ValueError(f"dp_exchange={dp_exchange!r}: bucket of {hi - lo} elements does not split over "
+                                     f"{world} ranks")
             self._gshard = torch.empty(self.P.numel // world + 64, dtype=torch.float32, device=self.device)
+            if dp_exchange == "a2a":  # staging of the two all-to-alls: received slices, replicated updated slice
+                self._a2a_recv = torch.empty(self.P.numel, dtype=torch.float32, device=self.device)
+                self._a2a_send = torch.empty(self.P.numel, dtype=torch.float32, device=self.device)
 
     # -- stages -------------------------------------------------------------------------------
     def sample(self) -> torch.Tensor:
@@ -385,6 +389,13 @@ class FusedTrainer:
 
     def param_buffer(self) -> torch.Tensor:
         return self.P.flat
+
+    def a2a_buffers(self, lo: int, hi: int):
+        q = (hi - lo) // self.world
+        return self._a2a_recv[lo:hi].view(self.world, q), self._a2a_send[lo:hi].view(self.world, q)
+
+    def sum_slices(self, recv: torch.Tensor, out: torch.Tensor) -> None:
+        torch.sum(recv, dim=0, out=out)
 
     def gather_optimizer_state(self) -> None:
         """rs_ag keeps the RMSprop square averages and the EMA shadow on the rank that updates them (1/world of each

@@ -48,13 +48,14 @@ def main():
     rank, world = comm.rank, comm.world
     shape, prob, kw = make_shape(), make_problem(), trainer_kw()
     res = {}
-    if mode in ("dp", "hp", "dp_win", "dp_rsag"):
+    if mode in ("dp", "hp", "dp_win", "dp_rsag", "dp_a2a"):
         # external batches: comparable with a single-process run on the global batch.
         # dp_win: the backward cut into two head windows, each window's bucket all-reduced as it is enqueued;
         # dp_rsag: the same windows with reduce-scatter -> optimiser on this rank's slices -> all-gather
+        # dp_a2a: the same two phases as all-to-alls
         extra = {}
         if mode != "dp" and mode != "hp":
-            extra = dict(grad_windows=2, dp_exchange="rs_ag" if mode == "dp_rsag" else "allreduce")
+            extra = dict(grad_windows=2, dp_exchange={"dp_rsag": "rs_ag", "dp_a2a": "a2a"}.get(mode, "allreduce"))
         tr = FusedTrainer(shape, prob, CASE["B_local"], seed=5, device=dev, comm=comm, parallelism=mode[:2],
                           keep_grads=True, grad_buckets=3, **extra, **kw)
         assert tr.hp == (mode == "hp") and tr.world == world

@@ -55,7 +55,7 @@ def test_bench_two_ranks_exactly_as_the_driver_calls_it():
     assert d["value"] > 0 and d["params_finite"] and d["scaling"] == "weak"
     assert d["rccl_ranks"] == 2
     c = d["comm"]
-    assert c["backend"] == "gloo" and c["exchange"] in ("allreduce", "rs_ag")
+    assert c["backend"] == "gloo" and c["exchange"] in ("allreduce", "rs_ag", "a2a")
     assert c["compute_only_ms"] > 0 and c["step_ms"] == d["ms_per_step"]
     w = c["exposed_wait_us_per_step"]
     assert "moments_allreduce" in w and any(k.startswith("grad_bucket0") for k in w)
@@ -63,7 +63,7 @@ def test_bench_two_ranks_exactly_as_the_driver_calls_it():
     assert sum(c["grad_bucket_bytes"]) >= 4 * d["config"]["params"]
     # every exchange candidate was timed (or says why not) and the winner is the one the headline ran with
     cands = c["candidates"]
-    assert any(k.startswith("allreduce/") for k in cands) and any(k.startswith("rs_ag/") for k in cands)
+    assert all(any(k.startswith(ex + "/") for k in cands) for ex in ("allreduce", "rs_ag", "a2a"))
     ok = {k: v for k, v in cands.items() if "steps_per_s" in v}
     assert ok, cands
     best = max(ok, key=lambda k: ok[k]["steps_per_s"])

@@ -83,6 +83,14 @@ class OracleBackend:
     def param_buffer(self):
         return self.params
 
+    def a2a_buffers(self, lo, hi):
+        q = (hi - lo) // self.world
+        return torch.empty((self.world, q), dtype=self.grad.dtype), torch.empty((self.world, q), dtype=self.grad.dtype)
+
+    def sum_slices(self, recv, out):
+        self.calls.append("sum_slices")
+        torch.sum(recv, dim=0, out=out)
+
     def begin_apply(self):
         self.calls.append("begin_apply")
 
@@ -146,9 +154,14 @@ def _worker(rank, world, port, tmp, exchange="allreduce"):
         assert spans == ["moments_allreduce"] + [f"grad_bucket{k}_allreduce_wait" for k in range(3)], spans
         extra = {}
     else:
-        assert be.calls == head + ["apply_shard"] * 3, be.calls
-        assert spans == ["moments_allreduce"] + [f"grad_bucket{k}_reduce_scatter_wait" for k in range(3)] + \
-            [f"param_bucket{k}_all_gather_wait" for k in range(3)], spans
+        if exchange == "a2a":
+            assert be.calls == head + ["sum_slices", "apply_shard"] * 3, be.calls
+            assert spans == ["moments_allreduce"] + [f"grad_bucket{k}_all_to_all_wait" for k in range(3)] + \
+                [f"param_bucket{k}_all_to_all_wait" for k in range(3)], spans
+        else:
+            assert be.calls == head + ["apply_shard"] * 3, be.calls
+            assert spans == ["moments_allreduce"] + [f"grad_bucket{k}_reduce_scatter_wait" for k in range(3)] + \
+                [f"param_bucket{k}_all_gather_wait" for k in range(3)], spans
         # what this rank applied: its own slice of every bucket, nothing else; the parameters came back complete
         own = torch.zeros(be.grad.numel(), dtype=torch.bool)
         for lo, hi in be.grad_buckets():
@@ -211,11 +224,12 @@ def test_dp_two_ranks_equals_single_process(tmp_path):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
-def test_dp_reduce_scatter_all_gather_equals_single_process(tmp_path, world):
-    """exchange "rs_ag": every rank receives the summed gradient of ITS slice of each bucket (== the single-process
-    gradient there), steps only that slice, and the all-gather leaves every rank with the same, complete parameters."""
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "rs_ag"), nprocs=world, join=True)
+@pytest.mark.parametrize("world,exchange", [(2, "rs_ag"), (4, "rs_ag"), (2, "a2a"), (4, "a2a")])
+def test_dp_reduce_scatter_all_gather_equals_single_process(tmp_path, world, exchange):
+    """exchanges "rs_ag" and "a2a": every rank receives the summed gradient of ITS slice of each bucket (== the
+    single-process gradient there), steps only that slice, and the gather leaves every rank with the same, complete
+    parameters."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
     p, prob, v, M, x = _setup()
     ref = O.loss_and_grads(x, p, prob, v, M)
     gref = torch.cat([g.reshape(-1) for g in ref["grads"]])

@@ -109,21 +109,24 @@ def test_dp_two_ranks_match_single_process(tmp_path):
 def test_dp_head_windows_and_reduce_scatter_match_plain_dp(tmp_path):
     """The backward cut into two head windows (bucket k on the wire while window k + 1 is computed) gives the plain dp
     run's gradients and parameters BIT FOR BIT (same tiles, same summation order; with two ranks a + b is
-    commutative); so does the reduce-scatter / sharded-optimiser / all-gather exchange once its sharded RMSprop and
-    EMA state has been gathered."""
+    commutative); so do the reduce-scatter / sharded-optimiser / all-gather exchange and its all-to-all spelling once
+    their sharded RMSprop and EMA state has been gathered."""
     world = 2
     plain = run_ranks("dp", world, tmp_path)
     win = run_ranks("dp_win", world, tmp_path)
     rsag = run_ranks("dp_rsag", world, tmp_path)
+    a2a = run_ranks("dp_a2a", world, tmp_path)
     for r in range(world):
-        assert not plain[r]["sharded0"] and not win[r]["sharded0"] and rsag[r]["sharded0"]
+        assert not plain[r]["sharded0"] and not win[r]["sharded0"] and rsag[r]["sharded0"] and a2a[r]["sharded0"]
         assert len(win[r]["buckets"]) == 3 and win[r]["buckets"][0][0] == 0
         for name in ("mom0", "loss0", "flat", "ema", "sq"):
             assert torch.equal(win[r][name], plain[r][name]), ("windows", name)
             assert torch.equal(rsag[r][name], plain[r][name]), ("rs_ag", name)
+            assert torch.equal(a2a[r][name], plain[r][name]), ("a2a", name)
         assert torch.equal(win[r]["grad0"], plain[r]["grad0"])  # the all-reduced gradient itself
     for name in ("flat", "ema", "sq"):
         assert torch.equal(rsag[0][name], rsag[1][name]), name
+        assert torch.equal(a2a[0][name], a2a[1][name]), name
 
 
 def _views(flat, L):
