@@ -108,6 +108,7 @@ struct FusedWs {
     float* dfsc;                      // (L, B)
     float* gpart;                     // (S, slice) split-K partial gradients, S = wgrad_slices() > 1 only
     unsigned short* w0p;              // (3, L, 128, F) bf16 planes of W_0 (NSVD_PATH_FUSED_BF16X3 only)
+    float* base_raw;                  // (L, (1 + 2D) B) head outputs per stencil point (split-stencil forward only)
     size_t bytes;
 };
 
@@ -188,6 +189,7 @@ inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     const int S = wgrad_slices(d, B);
     w.gpart = S > 1 ? take((size_t)S * part_layout(d).stride) : nullptr;
     w.w0p = (unsigned short*)take(((size_t)3 * d.L * HID * F + 1) / 2);
+    w.base_raw = take((size_t)d.L * (1 + 2 * (size_t)d.D) * B);
     w.bytes = off;
     return w;
 }

@@ -50,6 +50,13 @@ struct FwdArgs {
     int plain;      // E = 1 instance only: out = hard_mul_const * base * mask (WaveFunctions.forward), no Hamiltonian;
                     // f receives the output, jac / dsc its derivatives w.r.t. base / scales
     int xcd_remap;  // 0: plain mapping; else HX = number of head groups across the 8 XCDs (1, 2, 4 or 8)
+    // split-stencil form (E = 3 instance only): the launch holds `split` = D groups of (B / 32) L workgroups; group g
+    // evaluates the centre and the two points x +- eps e_g and writes the RAW head outputs of its two shifted points
+    // (group 0: of the centre too, and it alone saves the centre activations) into base_raw (L, ldr) at rows e B + b,
+    // stencil order [x, x + eps e_0, x - eps e_0, x + eps e_1, ...]; fd_epilogue_kernel then forms f, Tf. Twice (three
+    // times) the workgroups for batches that leave CUs idle, and the only way 7 stencil columns (D = 3) fit at all.
+    int split;
+    float* base_raw;
     unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
 
@@ -93,8 +100,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int nsb = a.B / BS;
-    int l, sb;
-    xcd_block_map(blockIdx.x, a.xcd_remap, a.L, nsb, l, sb);  // pmlp_common.h
+    int l, sb, grp = 0, bid = blockIdx.x;
+    if (E == 3 && !JET && !BF3 && a.split) {  // split-stencil form: which direction's points this workgroup evaluates
+        grp = bid / (nsb * a.L);
+        bid -= grp * nsb * a.L;
+    }
+    xcd_block_map(bid, a.xcd_remap, a.L, nsb, l, sb);  // pmlp_common.h
     const int b0 = sb * BS;
 
     NSVD_STAMP(0)
@@ -133,7 +144,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4 per slab
     const float* a_src = W0 + (size_t)s_row * a.F + 4 * s_c4;
     const float* b_src = a.phiT + (size_t)(b0 + s_row) * a.F + 4 * s_c4;  // centre features, (B, F) row-major
-    const float* t_src = a.sctab + 4 * s_c4;
+    const float* t_src = a.sctab + 4 * s_c4 + (size_t)grp * 2 * a.m;  // (D, 2, m): this group's direction first
     const size_t a_step = (size_t)32 * a.F;
     const int mm = a.m;
 #define NSVD_LDG(p) (*reinterpret_cast<const float4*>(p))
@@ -322,7 +333,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         }
         // softplus in registers; the centre rows' ACTIVATIONS are saved for the backward (its kernels then need
         // no softplus: sigmoid(z) = 1 - exp(-softplus(z)), and the weight gradients contract activations)
-        float* zs = a.zsave[i] ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
+        float* zs = (a.zsave[i] && grp == 0) ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
         if (JET) {
             // forward-mode jet through the softplus, all streams of a (row, sample) in this lane's registers
 #pragma unroll
@@ -417,6 +428,18 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #undef NSVD_FENCE
     NSVD_STAMP(12)
     __syncthreads();
+    if (E == 3 && !JET && !BF3 && a.split) {
+        // split-stencil form: raw outputs of the 128 -> 1 layer, one thread per (point, sample)
+        if (tid < NC) {
+            const int e_t = tid / BS, sidx = tid - e_t * BS;
+            if (e_t > 0 || grp == 0) {
+                const float bve = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
+                const int eg = e_t == 0 ? 0 : 2 * grp + e_t;  // x + eps e_g at 1 + 2 g, x - eps e_g at 2 + 2 g
+                a.base_raw[(size_t)l * a.ldr + (size_t)eg * a.B + b0 + sidx] = bve;
+            }
+        }
+        return;
+    }
     // ------------------------------------------------------------------ FD Hamiltonian epilogue
     // one thread per (stencil point, sample): output of the 128 -> 1 layer, then g_e = sqrt p(x_e) c base_e mask(x_e)
     // (the exp / sqrt heavy part, E x 32 threads wide instead of a 5-point loop on 32 threads)
@@ -532,7 +555,7 @@ int launch_fwd(const FwdArgs& a, hipStream_t s) {
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    const int grid = (a.B / BS) * a.L;
+    const int grid = (a.B / BS) * a.L * (a.split > 0 ? a.split : 1);
     nsvd_prof_begin(s);
     hipLaunchKernelGGL((pmlp_fused_fwd_kernel<E, JET, BF3>), dim3(grid), dim3(256), lds, s, a);
     nsvd_prof_end(s);
@@ -555,9 +578,11 @@ static bool fused_shape_ok(const nsvd_model_desc& d, int B) {
 }
 
 bool nsvd_fused_supported(const nsvd_model_desc& d, int B, bool exact) {
-    // E <= 5 columns per sample: the forward's LDS image (155 KB at E = 5). Stencil: E = 1 + 2D, so D <= 2; the
+    // E <= 5 columns per sample: the forward's LDS image (155 KB at E = 5). Stencil: E = 1 + 2D columns for D <= 2,
+    // and the split form (one direction's two points + the centre per workgroup, FwdArgs::split) for D = 3; the
     // exact-Laplacian jets have E = D + 2, so D <= 3.
-    if (d.D < 1 || d.D > (exact ? 3 : 2)) return false;
+    (void)exact;
+    if (d.D < 1 || d.D > 3) return false;
     return fused_shape_ok(d, B);
 }
 
@@ -633,6 +658,16 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
             case 3: return launch_fwd<5, 1>(a, s);
         }
         return NSVD_EUNSUPPORTED;
+    }
+    // split-stencil form: D = 3 (7 stencil columns do not fit one workgroup's LDS image), and D = 2 when the plain grid
+    // would leave at least half of the CUs without a workgroup (cfg1: 64 -> 128 workgroups of three column tiles)
+    if (d.D == 3 || (d.D == 2 && (B / BS) * d.L <= 128)) {
+        a.split = d.D;
+        a.base_raw = w.base_raw;
+        rc = launch_fwd<3>(a, s);
+        if (rc) return rc;
+        return nsvd_fd_epilogue(w.base_raw, R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
+                                save ? w.jac : nullptr, (save && d.has_exp_mask) ? w.dsc : nullptr, s);
     }
     switch (E) {
         case 3: return launch_fwd<3>(a, s);

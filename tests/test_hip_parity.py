@@ -598,8 +598,8 @@ def test_fused_path_one_dimensional(eps, fpath):
 
 @pytest.mark.parametrize("fpath", FPATHS)
 def test_exact_mode_three_dimensional(fpath):
-    """D = 3 fits the MFMA path in exact mode only (5 jet streams; the stencil would need 7 columns per sample):
-    f, Tf and the gradients against the float64 oracle, hydrogen potential with the exponential mask."""
+    """D = 3 in exact mode (5 jet streams in one workgroup): f, Tf and the gradients against the float64 oracle,
+    hydrogen potential with the exponential mask; the stencil mode of the same model (7 columns per sample) runs too."""
     L, D, m, hidden, B = 2, 3, 64, (128, 128, 128), 64
     p = O.init_params(L, D, m, hidden, 0.2, exp_mask_init=4.0, seed=33)
     prob = O.Problem(potential=O.POT_HYDROGEN, eps=0.0, op_scale=10.0, op_shift=1.0, sigma=3.0, hard_mul_const=0.9)
@@ -611,10 +611,34 @@ def test_exact_mode_three_dimensional(fpath):
     assert rel(r["Tf"], ref["Tf"]) < 1e-4
     for i, (g, gr) in enumerate(zip(r["grads"], ref["grads"])):
         assert rel(g.view(-1), gr.reshape(-1)) < 3e-5, i
-    # ... and the stencil mode of the same model still runs, on the generic kernels
+    # ... and the stencil mode of the same model (since round 3 on the MFMA kernels too: split-stencil form below)
     prob_fd = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=10.0, op_shift=1.0, sigma=3.0, hard_mul_const=0.9)
     r2 = run_hip(p, prob_fd, x, v, M, H.PATH_AUTO)
     assert rel(r2["f"], ref["f"]) < 2e-5
+
+
+@pytest.mark.parametrize("D,L,B", [(3, 3, 96), (2, 16, 128)])
+def test_split_stencil_form(D, L, B):
+    """The split-stencil form of the fused forward (one direction's two shifted points + the centre per workgroup, raw
+    head outputs combined by the generic FD epilogue): the only way the 7 stencil columns of a 3-D problem fit the
+    MFMA kernels, and what small batches (configs[0]: 64 workgroups of the plain form on 256 CUs) take to fill the chip.
+    f, the FD-noise yardstick on Tf, and every gradient against the float64 oracle; f and the saved state bit-identical
+    to ... nothing else computes them, so: the generic kernels as a second witness at float32 level."""
+    m, hidden = 64, (128, 128, 128)
+    p = O.init_params(L, D, m, hidden, 0.2, exp_mask_init=4.0, seed=44)
+    prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=3.0)
+    v, M = O.sequential_nesting_masks(L)
+    x = (3.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(9), dtype=torch.float64)).float().double()
+    shape = shape_of(p)
+    assert H.path_name(shape, B, H.PATH_AUTO, hip_problem(prob)) == "fused_mfma"
+    ref = O.loss_and_grads(x, p.to(torch.float64), prob, v, M)
+    r = run_hip(p, prob, x, v, M, H.PATH_FUSED, df_override=ref["df"])
+    g = run_hip(p, prob, x, v, M, H.PATH_GENERIC, df_override=ref["df"])
+    assert rel(r["f"], ref["f"]) < 2e-5 and rel(g["f"], ref["f"]) < 2e-5
+    # Tf: float32 finite differences - the MFMA path no further from float64 than 2 x the generic kernels are
+    assert rel(r["Tf"], ref["Tf"]) < max(2.0 * rel(g["Tf"], ref["Tf"]), 1e-3)
+    for i, (a, b) in enumerate(zip(r["grads"], ref["grads"])):
+        assert rel(a.view(-1), b.reshape(-1)) < 3e-5, i
 
 
 @pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True)])
