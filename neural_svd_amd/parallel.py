@@ -86,14 +86,29 @@ class Communicator:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.stub = False  # True: collectives are skipped (compute-only timing of the multi-rank code path)
+        # True: a world of ONE still runs the whole exchange sequence (every collective a one-rank call into the
+        # library) instead of the plain single-GPU step: how a box with one GPU exercises the RCCL calls, their
+        # argument shapes and their stream ordering (tests/test_multirank_gpu.py)
+        self.force_exchange = False
+
+    @property
+    def multi(self) -> bool:
+        """does a step go through the exchange sequence?"""
+        return self.world > 1 or self.force_exchange
 
     @classmethod
-    def from_env(cls, device: Optional[torch.device] = None, backend: Optional[str] = None) -> "Communicator":
-        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment (torch.distributed.run)."""
+    def from_env(cls, device: Optional[torch.device] = None, backend: Optional[str] = None,
+                 timeout_s: Optional[float] = None) -> "Communicator":
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment (torch.distributed.run).
+        timeout_s: the process group's collective timeout (a rank stuck in a collective exits instead of waiting for
+        the library's default of ten minutes or more)."""
         if not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
             kw = {}
+            if timeout_s is not None:
+                import datetime
+                kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
             if backend == "nccl" and device is not None:
                 kw["device_id"] = device
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -217,6 +232,10 @@ def _world(comm: Optional[Communicator]) -> int:
     return comm.world if comm is not None else 1
 
 
+def _multi(comm: Optional[Communicator]) -> bool:
+    return comm is not None and comm.multi
+
+
 def shard_range(lo: int, hi: int, rank: int, world: int):
     """rank's slice of the bucket [lo, hi) (equal slices: reduce-scatter / all-gather need them)"""
     n = hi - lo
@@ -227,13 +246,16 @@ def shard_range(lo: int, hi: int, rank: int, world: int):
 
 
 def dp_step(backend, comm: Optional[Communicator], x_local, take_step: bool = True, exchange: str = "allreduce",
-            probe: Optional[CommProbe] = None) -> None:
+            probe: Optional[CommProbe] = None, sync: bool = False) -> None:
     """One SAMPLE-SHARDED NestedLoRA step (see the module docstring for the protocol). With one rank this is the
-    plain step (the backend is free to fuse the optimiser into its backward)."""
+    plain step (the backend is free to fuse the optimiser into its backward).
+    sync: every collective is a blocking call (torch runs those on the CURRENT stream: no second stream, no
+    cross-stream event per bucket - each of which idles the compute stream for ~10 us on this runtime - and no overlap
+    either); the default issues them asynchronously and waits as late as possible."""
     span = probe.span if probe is not None else _nospan
     backend.forward(x_local)
     world = _world(comm)
-    if world == 1:
+    if not _multi(comm):
         backend.backward(None, take_step)
         return
     mom = backend.local_moments()
@@ -242,80 +264,96 @@ def dp_step(backend, comm: Optional[Communicator], x_local, take_step: bool = Tr
     if not take_step:
         backend.backward(mom, False)
         return
+    if exchange not in DP_EXCHANGES:
+        raise ValueError(f"dp exchange must be one of {DP_EXCHANGES}")
+
+    def issue(name, fn, *a):
+        """the collective now: blocking inside its own span (sync), or asynchronous -> (span name, work handle)"""
+        if sync:
+            with span(name):
+                fn(*a)
+            return None
+        return name, fn(*a, async_op=True)
+
+    def wait(h):
+        if h is not None:
+            with span(h[0]):
+                h[1].wait()
+
     if exchange == "allreduce":
         # exchange 2: a bucket's all-reduce goes out as soon as the launches completing it are enqueued
         works = []
-        for lo, hi in backend.backward_staged(mom):
-            works.append((lo, hi, comm.all_reduce_sum(backend.grad_buffer()[lo:hi], async_op=True)))
+        for k, (lo, hi) in enumerate(backend.backward_staged(mom)):
+            works.append((lo, hi, issue(f"grad_bucket{k}_allreduce_wait", comm.all_reduce_sum,
+                                        backend.grad_buffer()[lo:hi])))
         backend.prefetch()                         # next batch + features under the first bucket
         backend.begin_apply()
-        for k, (lo, hi, work) in enumerate(works):
-            with span(f"grad_bucket{k}_allreduce_wait"):
-                work.wait()
+        for lo, hi, h in works:
+            wait(h)
             backend.apply(lo, hi, 1.0 / world)     # optimiser on bucket k while bucket k+1 is on the wire
     elif exchange == "rs_ag":
         rs = []
-        for lo, hi in backend.backward_staged(mom):
+        for k, (lo, hi) in enumerate(backend.backward_staged(mom)):
             shard = backend.grad_shard(lo, hi)
-            rs.append((lo, hi, shard, comm.reduce_scatter_sum(shard, backend.grad_buffer()[lo:hi], async_op=True)))
+            rs.append((lo, hi, shard, issue(f"grad_bucket{k}_reduce_scatter_wait", comm.reduce_scatter_sum, shard,
+                                            backend.grad_buffer()[lo:hi])))
         backend.prefetch()
         backend.begin_apply()
         params = backend.param_buffer()
         ag = []
-        for k, (lo, hi, shard, work) in enumerate(rs):
-            with span(f"grad_bucket{k}_reduce_scatter_wait"):
-                work.wait()
+        for k, (lo, hi, shard, h) in enumerate(rs):
+            wait(h)
             slo, shi = shard_range(lo, hi, comm.rank, world)
             backend.apply_shard(slo, shi, shard, 1.0 / world)   # 1/world of the optimiser traffic per rank
-            ag.append(comm.all_gather_flat(params[lo:hi], params[slo:shi], async_op=True))
-        for k, work in enumerate(ag):
-            with span(f"param_bucket{k}_all_gather_wait"):
-                work.wait()
-    elif exchange == "a2a":
+            ag.append(issue(f"param_bucket{k}_all_gather_wait", comm.all_gather_flat, params[lo:hi], params[slo:shi]))
+        for h in ag:
+            wait(h)
+    else:  # "a2a"
         stages = []
-        for lo, hi in backend.backward_staged(mom):
+        for k, (lo, hi) in enumerate(backend.backward_staged(mom)):
             recv, send = backend.a2a_buffers(lo, hi)
             q = (hi - lo) // world
-            stages.append((lo, hi, recv, send,
-                           comm.all_to_all(recv, backend.grad_buffer()[lo:hi].view(world, q), async_op=True)))
+            stages.append((lo, hi, recv, send, issue(f"grad_bucket{k}_all_to_all_wait", comm.all_to_all, recv,
+                                                     backend.grad_buffer()[lo:hi].view(world, q))))
         backend.prefetch()
         backend.begin_apply()
         params = backend.param_buffer()
         gathers = []
-        for k, (lo, hi, recv, send, work) in enumerate(stages):
-            with span(f"grad_bucket{k}_all_to_all_wait"):
-                work.wait()
+        for k, (lo, hi, recv, send, h) in enumerate(stages):
+            wait(h)
             slo, shi = shard_range(lo, hi, comm.rank, world)
             shard = backend.grad_shard(lo, hi)
             backend.sum_slices(recv, shard)                      # rank order: the same sum wherever it is formed
             backend.apply_shard(slo, shi, shard, 1.0 / world)
             send.copy_(params[slo:shi].unsqueeze(0).expand_as(send))
             q = (hi - lo) // world
-            gathers.append(comm.all_to_all(params[lo:hi].view(world, q), send, async_op=True))
-        for k, work in enumerate(gathers):
-            with span(f"param_bucket{k}_all_to_all_wait"):
-                work.wait()
-    else:
-        raise ValueError(f"dp exchange must be one of {DP_EXCHANGES}")
+            gathers.append(issue(f"param_bucket{k}_all_to_all_wait", comm.all_to_all, params[lo:hi].view(world, q),
+                                 send))
+        for h in gathers:
+            wait(h)
     if probe is not None:
         probe.step_done()
 
 
 def hp_step(backend, comm: Optional[Communicator], x_global, take_step: bool = True,
-            probe: Optional[CommProbe] = None) -> None:
+            probe: Optional[CommProbe] = None, sync: bool = False) -> None:
     """One HEAD-SHARDED NestedLoRA step: every rank owns L/world heads (weights, gradients, optimiser state:
     nothing is replicated, no gradient traffic) and evaluates them on the WHOLE global batch. The only exchange
     is an all-gather of the rank's (B, L/world) blocks of f and Tf; the moments, the loss and d loss / d f of the
     local heads are then computed locally from the gathered (B, L) arrays."""
     span = probe.span if probe is not None else _nospan
     backend.forward(x_global)
-    if _world(comm) > 1:
+    if _multi(comm):
         out, inp = backend.gather_buffers()
-        work = comm.all_gather(out, inp, async_op=True)
-        if take_step:
-            backend.prefetch()
-        with span("f_Tf_all_gather_wait"):
-            work.wait()
+        if sync:  # blocking call on the current stream (see dp_step); the next batch then rides in the backward
+            with span("f_Tf_all_gather_wait"):
+                comm.all_gather(out, inp)
+        else:
+            work = comm.all_gather(out, inp, async_op=True)
+            if take_step:
+                backend.prefetch()
+            with span("f_Tf_all_gather_wait"):
+                work.wait()
         backend.after_gather()
     backend.backward(None, take_step)
     if probe is not None:

@@ -123,7 +123,7 @@ class FusedTrainer:
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
                  parallelism: str = "dp", fused_step: bool = True, keep_grads: bool = False,
                  device_sampler: bool = True, overlap: bool = True, grad_buckets: int = 4,
-                 dp_exchange: str = "allreduce", grad_windows: Optional[int] = None):
+                 dp_exchange: str = "allreduce", grad_windows: Optional[int] = None, sync_collectives: bool = False):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
         them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
@@ -141,7 +141,9 @@ class FusedTrainer:
         RMSprop square averages and the EMA shadow then live sharded - gather_optimizer_state() before reading them)
         or "a2a" (the same two phases as point-to-point all-to-alls; parallel.py).
         grad_windows (dp, world > 1): head windows the backward is cut into so that a window's gradients go on the
-        wire while the next window is computed (None: as many of 4 / 2 / 1 as still give every CU a dW_0 tile)."""
+        wire while the next window is computed (None: as many of 4 / 2 / 1 as still give every CU a dW_0 tile).
+        sync_collectives (world > 1): blocking collectives on the compute stream instead of asynchronous ones with late
+        waits (parallel.dp_step); nothing is then prepared under a collective (hp: the next batch rides in the backward)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise H.NsvdError(f"FusedTrainer needs a GPU device (got {self.device}); there is no CPU path")
@@ -152,7 +154,11 @@ class FusedTrainer:
         world = comm.world if comm is not None else 1
         rank = comm.rank if comm is not None else 0
         self.world = world
-        self.hp = parallelism == "hp" and world > 1
+        # the step goes through an exchange sequence (always with world > 1; a world of one only on request:
+        # Communicator.force_exchange)
+        self.multi = multi = comm is not None and comm.multi
+        self.sync_collectives = bool(sync_collectives) and multi
+        self.hp = parallelism == "hp" and multi
         if parallelism not in ("dp", "hp"):
             raise ValueError("parallelism must be 'dp' or 'hp'")
         self.full_shape = shape
@@ -174,7 +180,7 @@ class FusedTrainer:
 
     def _build(self, shape, problem, fourier_scale, exp_mask_init, seed, sample_seed, sequential, step, fused_step,
                keep_grads, device_sampler, overlap, grad_buckets, world, rank, dp_exchange, grad_windows):
-        path = self.path
+        path, multi = self.path, self.multi
         self.P = FlatParams(shape, self.device)
         fB0, ws0, bs0, sc0 = reference_init(self.full_shape, fourier_scale, exp_mask_init, seed)
         if self.hp:  # this rank's heads of the (identically seeded) full model
@@ -182,7 +188,7 @@ class FusedTrainer:
             ws0, bs0 = [w[sl] for w in ws0], [b[sl] for b in bs0]
             sc0 = sc0[sl] if sc0 is not None else None
         self.P.load(fB0, ws0, bs0, sc0)
-        if world > 1:
+        if multi:
             # replicas must start from identical weights (dp) / share the frozen Fourier matrix (hp) whatever the
             # ranks' random streams were (seed=None): rank 0's values win
             self.comm.broadcast(self.P.fourier_B, 0)
@@ -193,7 +199,7 @@ class FusedTrainer:
         self._grads = self.P.pack(self.P.grad, False)
         self._ema_params = self.P.pack(self.P.ema, True)
         self._sq_params = self.P.pack(self.P.sq, False)
-        self.fused_step = bool(fused_step) and (world == 1 or self.hp)
+        self.fused_step = bool(fused_step) and (not multi or self.hp)
         # the generic (non-MFMA) path takes the step with per-tensor optimiser launches and needs the gradients
         self.keep_grads = bool(keep_grads) or H.path_name(shape, self.B, path, problem) != "fused_mfma"
         # nesting masks (methods/nestedlora.py:183-192)
@@ -205,7 +211,7 @@ class FusedTrainer:
         self.ws = H.new_workspace(shape, self.B, self.device)
         self.device_sampler = bool(device_sampler)
         # overlap: two (workspace, x) sets used alternately; set k holds the features of batch k
-        self.overlap = bool(overlap) and world > 1 and self.device_sampler
+        self.overlap = bool(overlap) and multi and self.device_sampler and not self.sync_collectives
         # single GPU / head-parallel with the fused step: the NEXT batch is drawn and its features written by guest
         # workgroups of the backward's chain kernel (nsvd_operator_backward_evd_step_next) - no feature launch per step
         self.guest_features = bool(overlap) and self.device_sampler and self.fused_step and not self.keep_grads and \
@@ -231,7 +237,7 @@ class FusedTrainer:
         # "direct" moments: with no exchange between forward and backward and a batch of <= 1024 rows, the backward
         # kernel takes the 2 L moments each head needs from f itself and no moment kernel runs; the loss scalars
         # (logging only) and the moment vector are then evaluated on demand (properties below)
-        self.direct_moments = (world == 1 or self.hp) and self.B <= 1024 and \
+        self.direct_moments = (not multi or self.hp) and self.B <= 1024 and \
             H.path_name(shape, self.B, path, problem) == "fused_mfma"
         self._loss_stale = False
         self.scratch = H.evd_scratch(self.B, Lg, self.device)
@@ -268,7 +274,7 @@ class FusedTrainer:
         self.dp_exchange = dp_exchange
         self.probe = None            # parallel.CommProbe while bench.py measures the exposed waits
         self._windows = [(0, shape.L)]
-        if world > 1 and not self.hp and H.path_name(shape, self.B, path, problem) == "fused_mfma":
+        if multi and not self.hp and H.path_name(shape, self.B, path, problem) == "fused_mfma":
             for G in ((4, 2) if grad_windows is None else (int(grad_windows),)):
                 if G <= 1 or shape.L % G != 0:
                     continue
@@ -286,7 +292,7 @@ class FusedTrainer:
             self._stage_buckets = self._buckets
         self._state_sharded = False  # rs_ag: sq / ema valid on this rank's shards only
         self._gshard = None
-        if world > 1 and not self.hp and dp_exchange in ("rs_ag", "a2a"):
+        if multi and not self.hp and dp_exchange in ("rs_ag", "a2a"):
             for lo, hi in self._stage_buckets:
                 if (hi - lo) % world != 0:
                     raise ValueError(f"dp_exchange={dp_exchange!r}: bucket of {hi - lo} elements does not split over "
@@ -333,7 +339,7 @@ class FusedTrainer:
             lr, decay = self._advance_schedule()
             opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay)
             if self.guest_features and self._own_batch and not self._next_ready and \
-                    (self.world == 1 or not self.overlap):
+                    (not self.multi or not self.overlap):
                 # the next batch rides in this backward's first launch (hp with overlap prepares it under its
                 # all-gather instead: parallel.hp_step -> prefetch)
                 H.operator_backward_evd_step_next(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
@@ -351,7 +357,7 @@ class FusedTrainer:
         H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g, self.mask_kind, v, M,
                                 moments, reduced, scratch, loss, self._grads, self.ws, 1.0, self.path,
                                 l_offset=self.l_off)
-        if take_step and (self.world == 1 or self.hp):  # no exchange between backward and optimiser
+        if take_step and (not self.multi or self.hp):  # no exchange between backward and optimiser
             self.begin_apply()
             self.apply(0, self.P.numel, 1.0)
 
@@ -440,9 +446,10 @@ class FusedTrainer:
         self._features_ready = bool(features_ready)
         with torch.cuda.device(self.device):
             if self.hp:
-                parallel.hp_step(self, self.comm, x, take_step, probe=self.probe)
+                parallel.hp_step(self, self.comm, x, take_step, probe=self.probe, sync=self.sync_collectives)
             else:
-                parallel.dp_step(self, self.comm, x, take_step, exchange=self.dp_exchange, probe=self.probe)
+                parallel.dp_step(self, self.comm, x, take_step, exchange=self.dp_exchange, probe=self.probe,
+                                 sync=self.sync_collectives)
 
     def _refresh_loss(self) -> None:
         if self._loss_stale:  # direct-moment steps do not produce them: evaluate for the last batch now

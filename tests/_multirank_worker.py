@@ -44,7 +44,7 @@ def main():
     mode, out_dir = sys.argv[1], sys.argv[2]
     dev = torch.device("cuda", int(os.environ["NSVD_FORCE_DEVICE"]))
     torch.cuda.set_device(dev)
-    comm = parallel.Communicator.from_env(dev, backend="gloo")
+    comm = parallel.Communicator.from_env(dev, backend=os.environ.get("NSVD_DIST_BACKEND", "gloo"))
     rank, world = comm.rank, comm.world
     shape, prob, kw = make_shape(), make_problem(), trainer_kw()
     res = {}
@@ -90,6 +90,43 @@ def main():
             runs.append(dict(init=init, flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), fB=tr.P.fourier_B.cpu(),
                              loss=tr.loss.cpu(), drawn=tr.batches_drawn, x=tr.x.cpu()))
         res["runs"] = runs
+    elif mode == "rccl1":
+        # ONE rank on the real collective library (backend "nccl" = RCCL): the exchange sequences forced on in a world
+        # of one, so that every RCCL call of the product path - argument views, in-place gathers, AVG, async work
+        # handles and their stream ordering against the HIP kernels - runs on the one GPU this box has
+        assert world == 1 and comm.backend == "nccl"
+        comm.force_exchange = True
+        res["rccl_ranks"] = comm.count_ranks()
+        batches = [x.to(dev) for x in global_batches(1)]
+
+        def run(c, internal=False, probe=False, **kw2):
+            tr = FusedTrainer(shape, prob, CASE["B_local"], seed=5, sample_seed=9, device=dev, comm=c,
+                              keep_grads=not internal, grad_buckets=3, **kw2, **kw)
+            if probe:
+                tr.probe = parallel.CommProbe(dev)
+            for i in range(CASE["steps"]):
+                tr.step(None if internal else batches[i])
+            tr.gather_optimizer_state()
+            torch.cuda.synchronize()
+            out = dict(flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), sq=tr.P.sq.cpu(), loss=tr.loss.cpu(), multi=tr.multi,
+                       windows=len(tr._windows), fused_step=tr.fused_step, hp=tr.hp, overlap=tr.overlap)
+            if probe:
+                out["waits"] = dict(tr.probe.summary())
+            return out
+
+        res["plain"] = run(None)
+        res["allreduce"] = run(comm, grad_windows=1, probe=True)
+        res["allreduce_windows"] = run(comm, grad_windows=2)
+        res["rs_ag"] = run(comm, grad_windows=2, dp_exchange="rs_ag", probe=True)
+        res["a2a"] = run(comm, grad_windows=2, dp_exchange="a2a", probe=True)
+        res["hp"] = run(comm, parallelism="hp", probe=True)
+        res["allreduce_blocking"] = run(comm, grad_windows=1, sync_collectives=True, probe=True)
+        res["rs_ag_blocking"] = run(comm, grad_windows=2, dp_exchange="rs_ag", sync_collectives=True)
+        res["hp_blocking"] = run(comm, parallelism="hp", sync_collectives=True)
+        res["plain_internal"] = run(None, internal=True)
+        res["dp_internal"] = run(comm, internal=True, dp_exchange="rs_ag")
+        res["hp_internal"] = run(comm, internal=True, parallelism="hp")
+        res["hp_internal_blocking"] = run(comm, internal=True, parallelism="hp", sync_collectives=True)
     else:
         raise SystemExit(f"unknown mode {mode}")
     torch.cuda.synchronize()

@@ -51,24 +51,35 @@ def test_bench_two_ranks_exactly_as_the_driver_calls_it():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
-    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 1024
+    par = d["config"]["parallelism"]
+    assert par in ("dp2", "hp2") and d["config"]["global_batch"] == 1024
+    tuned = d["config"]["parallelism_tuned"]  # --parallelism auto: both shardings timed, the faster is the headline
+    assert set(tuned) == {"dp2", "hp2"} and par == max(tuned, key=tuned.get)
     assert d["value"] > 0 and d["params_finite"] and d["scaling"] == "weak"
-    assert d["rccl_ranks"] == 2
+    assert d["rccl_ranks"] == 2 and "launcher_retry" not in d
     c = d["comm"]
-    assert c["backend"] == "gloo" and c["exchange"] in ("allreduce", "rs_ag", "a2a")
+    assert c["backend"] == "gloo"
     assert c["compute_only_ms"] > 0 and c["step_ms"] == d["ms_per_step"]
     w = c["exposed_wait_us_per_step"]
-    assert "moments_allreduce" in w and any(k.startswith("grad_bucket0") for k in w)
     assert abs(sum(w.values()) - c["exposed_wait_us_total"]) < 0.1
-    assert sum(c["grad_bucket_bytes"]) >= 4 * d["config"]["params"]
-    # every exchange candidate was timed (or says why not) and the winner is the one the headline ran with
-    cands = c["candidates"]
-    assert all(any(k.startswith(ex + "/") for k in cands) for ex in ("allreduce", "rs_ag", "a2a"))
-    ok = {k: v for k, v in cands.items() if "steps_per_s" in v}
-    assert ok, cands
-    best = max(ok, key=lambda k: ok[k]["steps_per_s"])
-    assert best.startswith(c["exchange"] + "/")
-    # the side lines of the same JSON: the head-sharded split and configs[2] under both shardings
-    for k in ("sharding_hp", "cfg3_dp", "cfg3_hp"):
+    # every candidate of both shardings was timed (or says why not) and each winner is the one that ran
+    other = "hp" if par == "dp2" else "dp"
+    side = d[f"sharding_{other}"]
+    dp_c, hp_c = (c["candidates"], side["candidates"]) if par == "dp2" else (side["candidates"], c["candidates"])
+    assert all(any(k.startswith(ex + "/") for k in dp_c) for ex in ("allreduce", "rs_ag", "a2a"))
+    ok = {k: v for k, v in dp_c.items() if isinstance(v, dict) and "steps_per_s" in v}
+    assert ok and any(k.endswith("/blocking") for k in ok) and any(k.endswith("/1_bucket") for k in ok)
+    assert dp_c["chosen"] == max(ok, key=lambda k: ok[k]["steps_per_s"])
+    assert set(hp_c) == {"all_gather/async", "all_gather/blocking", "chosen"}
+    if par == "dp2":
+        assert c["exchange"] in ("allreduce", "rs_ag", "a2a") and dp_c["chosen"].startswith(c["exchange"] + "/")
+        assert "moments_allreduce" in w and any(k.startswith("grad_bucket0") for k in w)
+        assert sum(c["grad_bucket_bytes"]) >= 4 * d["config"]["params"]
+        assert c["collectives"].startswith("blocking" if dp_c["chosen"].endswith("/blocking") else "asynchronous")
+    else:
+        assert list(w) == ["f_Tf_all_gather_wait"]
+        assert c["collectives"].startswith("blocking" if hp_c["chosen"].endswith("/blocking") else "asynchronous")
+    # the side lines of the same JSON: the other sharding and configs[2] under both
+    for k in (f"sharding_{other}", "cfg3_dp", "cfg3_hp"):
         assert k in d and "error" not in d[k] and d[k]["value"] > 0 and d[k]["params_finite"], (k, d.get(k))
     assert d["cfg3_dp"]["global_batch"] == 1024

@@ -30,12 +30,13 @@ def _free_port():
     return port
 
 
-def run_ranks(mode, world, out_dir):
+def run_ranks(mode, world, out_dir, backend="gloo"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), NSVD_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), NSVD_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   NSVD_DIST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, WORKER, mode, str(out_dir)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -179,3 +180,46 @@ def test_overlapped_prefetch_is_bit_identical_and_replicas_agree(tmp_path, mode)
         assert not torch.equal(a["x"], b["x"])        # every rank its own rows
     else:
         assert torch.equal(a["x"], b["x"])            # every rank the same global batch
+
+
+def test_every_exchange_on_rccl_in_a_world_of_one(tmp_path):
+    """The box has one GPU and RCCL refuses two ranks per device, so the two-rank tests above run over gloo. This one
+    runs the SAME exchange sequences on the real library: one rank, backend "nccl", Communicator.force_exchange - every
+    collective of dp (all-reduce buckets with and without head windows, reduce-scatter / all-gather, all-to-all;
+    asynchronous with late waits, and blocking) and of hp (all-gather of f, Tf) is an RCCL call, ordered against the
+    HIP kernels by the work handles / the stream. With one rank every sum has one term and the 1/world scale is 1, so:
+    every dp variant must give the SAME BITS as every other (a missing stream dependency would show up right here),
+    and those agree with the plain single-GPU trainer up to the summation order of the moments (the plain step takes
+    them inside the backward kernel, dp from the moment kernel's vector); hp reproduces the plain trainer bit for bit."""
+    r, = run_ranks("rccl1", 1, tmp_path, backend="nccl")
+    assert r["rccl_ranks"] == 1
+    plain = r["plain"]
+    assert not plain["multi"] and plain["fused_step"]
+    dp = ("allreduce", "allreduce_windows", "rs_ag", "a2a", "allreduce_blocking", "rs_ag_blocking")
+    for name in dp + ("hp", "hp_blocking"):
+        v = r[name]
+        hp = name.startswith("hp")
+        assert v["multi"] and v["hp"] == hp and v["fused_step"] == hp, name
+        assert v["windows"] == (1 if name in ("allreduce", "allreduce_blocking") or hp else 2), name
+        for k in ("flat", "ema", "sq", "loss"):
+            if hp:
+                assert torch.equal(v[k], plain[k]), (name, k)
+            else:
+                assert torch.equal(v[k], r["allreduce"][k]), (name, k)
+                assert rel(v[k], plain[k]) < (1e-3 if k == "sq" else 1e-4), (name, k, rel(v[k], plain[k]))
+    w = r["allreduce"]["waits"]
+    assert "moments_allreduce" in w and sum(k.endswith("_allreduce_wait") for k in w) == 3
+    assert set(r["allreduce_blocking"]["waits"]) == set(w)
+    w = r["rs_ag"]["waits"]
+    assert sum(k.endswith("_reduce_scatter_wait") for k in w) == 3 and sum(k.endswith("_all_gather_wait") for k in w) == 3
+    w = r["a2a"]["waits"]
+    assert sum(k.endswith("_all_to_all_wait") for k in w) == 6
+    assert list(r["hp"]["waits"]) == ["f_Tf_all_gather_wait"]
+    # the internal device sampler: next batch prepared under the collectives (dp, hp) / riding in the backward (blocking)
+    for name in ("dp_internal", "hp_internal", "hp_internal_blocking"):
+        assert r[name]["overlap"] == (not name.endswith("blocking")) and r[name]["multi"]
+        for k in ("flat", "ema", "sq"):
+            if name.startswith("hp"):
+                assert torch.equal(r[name][k], r["plain_internal"][k]), (name, k)
+            else:
+                assert rel(r[name][k], r["plain_internal"][k]) < (1e-3 if k == "sq" else 1e-4), (name, k)
