@@ -106,8 +106,8 @@ int nsvd_abi_version(void);
 
 /* Name of the implementation nsvd_operator_forward would take ("fused_h128x3", "generic"). host */
 const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int path);
-/* The same for a given problem: the exact-Laplacian mode (prob->eps <= 0) exists on the MFMA path only and takes
- * shapes the stencil mode does not (D = 3); "unsupported" when it has no path. */
+/* The same for a given problem: the exact-Laplacian mode (prob->eps <= 0) exists on the MFMA path only (D <= 3, as the
+ * stencil mode: its 3-D form runs one direction per workgroup); "unsupported" when it has no path. */
 const char* nsvd_path_name_for(const nsvd_model_desc* desc, const nsvd_problem* prob, int B, int path);
 
 /* Bytes of scratch nsvd_operator_forward / _backward need for batches of up to B rows. */
