@@ -98,18 +98,31 @@ __device__ __forceinline__ void stencil_tile(const StencilArgs& a, int bx, int b
             sctab[(size_t)m + j] = q;
         }
     }
-    for (int bl = tid / FJ; bl < FB; bl += FT / FJ) {
+    // the batch is DRAWN here (counter-based: every frequency block regenerates the same values, the first one stores
+    // them for the epilogue and the backward). A wave walks RPW rows, all its lanes on the same row: lane k draws row k
+    // ONCE (Philox + Box-Muller: ~200 instructions, six times the feature's own arithmetic) and the row loop reads it
+    // with a scalar lane read, instead of every lane redoing it for every row.
+    static_assert(FJ == 64 && FT % FJ == 0 && FB % (FT / FJ) == 0, "one wave per 64 frequencies, whole rows per wave");
+    constexpr int NW = FT / FJ, RPW = FB / NW;
+    const int wv = tid / FJ;
+    float xmine[4] = {0.f, 0.f, 0.f, 0.f};
+    if (smp.on && jl < RPW && b0 + wv + jl * NW < B) {
+        const int b = b0 + wv + jl * NW;
+        nsvd_sample_row(smp, b, D, xmine);
+        if (bx == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xout[(size_t)b * D + d] = xmine[d];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int bl = wv + k * NW;
         const int b = b0 + bl;
         if (b >= B) break;
         float xr[4];
         if (smp.on) {
-            // the batch is DRAWN here (every frequency block regenerates the same counter-based values; the first
-            // one stores them for the epilogue and the backward)
-            nsvd_sample_row(smp, b, D, xr);
-            if (bx == 0 && jl == 0) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) xout[(size_t)b * D + d] = xr[d];
-            }
+            for (int d = 0; d < D; ++d) xr[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xmine[d]), k));
         } else {
 #pragma unroll
             for (int d = 0; d < D; ++d) xr[d] = x[(size_t)b * D + d];
