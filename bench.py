@@ -215,7 +215,7 @@ def summarize(blocks, steps, world):
                 blocks=len(b))
 
 
-def _launch_ranks(n, argv, timeout):
+def _launch_ranks(n, argv, timeout, extra_env=None):
     """start n rank processes of this script, wait for all of them; -> (return code, rank 0's stdout, error text)"""
     import socket
     import subprocess
@@ -228,6 +228,7 @@ def _launch_ranks(n, argv, timeout):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     deadline = time.time() + timeout
@@ -253,7 +254,10 @@ def _launch_ranks(n, argv, timeout):
         for q in procs:
             q.wait()
         return rc, "", err
-    return 0, procs[0].stdout.read(), None
+    out = procs[0].stdout.read()
+    if not [ln for ln in out.splitlines() if ln.startswith("{")]:
+        return 1, out, "rank 0 printed no JSON line"
+    return 0, out, None
 
 
 def self_launch(args, argv):
@@ -261,41 +265,41 @@ def self_launch(args, argv):
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relay rank 0's JSON line, fail if any rank fails.
     Runs BEFORE anything touches the GPU in this process (a process that has initialised the GPU must not spawn the
     ranks by exec, and has no business holding a context on device 0 while they run).
-    If the run with the auto-tuned exchange fails (a rank dies or hangs in a collective: the process group's timeout
-    turns a hang into an exit), the ranks are started ONCE more with the plainest sequence - one backward window,
-    bucketed all-reduce, no side measurements - and the line says so (`launcher_retry`): a number from the plain
-    exchange plus the reason beats no line."""
+    If the run with the auto-tuned sharding / exchange fails (a rank dies, or hangs in a collective: the process
+    group's timeout turns a hang into an exit), the ranks are started again, at most twice: with the plainest RCCL
+    sequence (samples sharded, one backward window, one bucketed all-reduce, no side measurements), then with the
+    head-sharded step over gloo (0.5 MB per step through the host: RCCL itself is what failed). The line then carries
+    `launcher_retry` with the reasons: a number from a plain exchange plus the reason beats no line."""
     n = args.gpus
     if os.environ.get("NSVD_FORCE_DEVICE") is None:
         have = torch.cuda.device_count()  # counts devices without creating a context
         if have < n:
             raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible")
-    can_retry = args.dp_exchange == "auto" and args.parallelism in ("auto", "dp")
-    t_first = args.launch_timeout * (0.6 if can_retry else 1.0)
-    rc, out, err = _launch_ranks(n, argv, t_first)
-    retry = None
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    if (err is not None or not lines) and can_retry:
-        retry = err or "rank 0 printed no JSON line"
-        sys.stderr.write(f"bench.py: {retry}; starting the ranks again with --parallelism dp --dp-exchange allreduce "
-                         f"--grad-windows 1 --no-extras\n")
-        rc, out, err = _launch_ranks(n, argv + ["--parallelism", "dp", "--dp-exchange", "allreduce", "--grad-windows", "1",
-                                                    "--no-extras"],
-                                     args.launch_timeout - t_first)
-        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    if err is not None:
-        sys.stderr.write(f"bench.py: {err}\n")
-        raise SystemExit(rc or 1)
-    if not lines:
-        sys.stderr.write("bench.py: rank 0 printed no JSON line\n" + out[-2000:])
-        raise SystemExit(1)
-    line = lines[-1]
-    if retry is not None:
-        d = json.loads(line)
-        d["launcher_retry"] = {"first_attempt": "auto-tuned exchange (comm.candidates)", "failed_with": retry,
-                               "this_line": "--parallelism dp --dp-exchange allreduce --grad-windows 1 --no-extras"}
-        line = json.dumps(d)
-    print(line)
+    ladder = [("as given: " + " ".join(argv), [], {})]
+    if args.dp_exchange == "auto" and args.parallelism in ("auto", "dp"):
+        plain = ["--parallelism", "dp", "--dp-exchange", "allreduce", "--grad-windows", "1", "--grad-buckets", "1",
+                 "--sync", "--no-extras"]
+        ladder.append((" ".join(plain), plain, {}))
+        if os.environ.get("NSVD_DIST_BACKEND", "nccl") != "gloo":
+            hp_gloo = ["--parallelism", "hp", "--sync", "--no-extras"]
+            ladder.append((" ".join(hp_gloo) + "  [NSVD_DIST_BACKEND=gloo]", hp_gloo, {"NSVD_DIST_BACKEND": "gloo"}))
+    shares = {1: [1.0], 2: [0.6, 0.4], 3: [0.5, 0.25, 0.25]}[len(ladder)]
+    failures = []
+    for (label, extra, env), share in zip(ladder, shares):
+        if failures:
+            sys.stderr.write(f"bench.py: {failures[-1]['failed_with']}; starting the ranks again: {label}\n")
+        rc, out, err = _launch_ranks(n, argv + extra, args.launch_timeout * share, env)
+        if err is None:
+            line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
+            if failures:
+                d = json.loads(line)
+                d["launcher_retry"] = {"failed_attempts": failures, "this_line": label}
+                line = json.dumps(d)
+            print(line)
+            return
+        failures.append({"attempt": label, "failed_with": err})
+    sys.stderr.write(f"bench.py: {failures[-1]['failed_with']}\n" + (out[-2000:] if out else ""))
+    raise SystemExit(rc or 1)
 
 
 def _timed_blocks(step, steps, warmup, repeats, prewarm_s, bracket=None, every=4):
@@ -488,6 +492,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_exchange
+    if os.environ.get("NSVD_BENCH_INJECT_FAILURE") == "tuned" and args.dp_exchange == "auto" and rank == world - 1:
+        raise SystemExit(3)  # test hook: the auto-tuned attempt dies on the last rank (tests/test_bench_launch.py)
     if args.force_exchange:
         if world != 1:
             raise SystemExit("--force-exchange is a one-GPU developer option")

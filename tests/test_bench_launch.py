@@ -83,3 +83,25 @@ def test_bench_two_ranks_exactly_as_the_driver_calls_it():
     for k in (f"sharding_{other}", "cfg3_dp", "cfg3_hp"):
         assert k in d and "error" not in d[k] and d[k]["value"] > 0 and d[k]["params_finite"], (k, d.get(k))
     assert d["cfg3_dp"]["global_batch"] == 1024
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_launcher_retries_with_the_plain_exchange_when_the_tuned_run_dies():
+    """the auto-tuned attempt is made to die on one rank (NSVD_BENCH_INJECT_FAILURE): the launcher must start the ranks
+    again with the plainest sequence and still deliver ONE line, marked with what failed"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=_env(NSVD_FORCE_DEVICE="0", NSVD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                NSVD_BENCH_INJECT_FAILURE="tuned"),
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    lr = d["launcher_retry"]
+    assert len(lr["failed_attempts"]) == 1 and "rank 1 exited with code 3" in lr["failed_attempts"][0]["failed_with"]
+    assert "--dp-exchange allreduce" in lr["this_line"]
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0 and d["params_finite"]
+    c = d["comm"]
+    assert c["exchange"] == "allreduce" and c["collectives"].startswith("blocking") and c["candidates"] is None
+    assert len(c["grad_bucket_bytes"]) == 1 and "sharding_hp" not in d

@@ -145,8 +145,9 @@ def _views(flat, L):
 
 
 @pytest.mark.timeout(900)
-def test_hp_two_ranks_match_single_process(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_hp_ranks_match_single_process(tmp_path, world):
+    """world 4: ONE head per rank on four times the local batch - the extreme of the head split"""
     rs = run_ranks("hp", world, tmp_path)
     ref = single_process(world)
     import _multirank_worker as W
