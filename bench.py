@@ -276,7 +276,7 @@ def self_launch(args, argv):
         if have < n:
             raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible")
     ladder = [("as given: " + " ".join(argv), [], {})]
-    if args.dp_exchange == "auto" and args.parallelism in ("auto", "dp"):
+    if args.config in ALT and args.dp_exchange == "auto" and args.parallelism in ("auto", "dp"):
         plain = ["--parallelism", "dp", "--dp-exchange", "allreduce", "--grad-windows", "1", "--grad-buckets", "1",
                  "--sync", "--no-extras"]
         ladder.append((" ".join(plain), plain, {}))
@@ -302,21 +302,29 @@ def self_launch(args, argv):
     raise SystemExit(rc or 1)
 
 
-def _timed_blocks(step, steps, warmup, repeats, prewarm_s, bracket=None, every=4):
-    """the protocol of run_timed for a plain callable: prewarm, warm-up, `repeats` blocks of exactly `steps` steps;
-    bracket(ev0, ev1) arms the one-shot kernel bracket before every `every`-th step"""
+def _timed_blocks(step, steps, warmup, repeats, prewarm_s, bracket=None, every=4, comm=None):
+    """the protocol of run_timed for a plain callable: prewarm, warm-up, `repeats` blocks of exactly `steps` steps
+    (comm: barrier + synchronize on both sides of a block, max over ranks); bracket(ev0, ev1) arms the one-shot kernel
+    bracket before every `every`-th step"""
     t0 = time.perf_counter()
     n_pre = 0
-    while time.perf_counter() - t0 < prewarm_s:
+    while True:
         for _ in range(10):
             step()
         n_pre += 10
         torch.cuda.synchronize()
+        done = time.perf_counter() - t0 >= prewarm_s
+        if comm is not None:  # every rank must leave the loop after the same number of (collective) steps
+            done = comm.max_float(0.0 if done else 1.0) == 0.0
+        if done:
+            break
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     evs, blocks = [], []
     for _ in range(repeats):
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(steps):
@@ -326,7 +334,10 @@ def _timed_blocks(step, steps, warmup, repeats, prewarm_s, bracket=None, every=4
                 evs.append(e)
             step()
         torch.cuda.synchronize()
-        blocks.append(time.perf_counter() - t1)
+        if comm is not None:
+            comm.barrier()
+        el = time.perf_counter() - t1
+        blocks.append(comm.max_float(el) if comm is not None else el)
     kms = sorted(a.elapsed_time(b) for a, b in evs)
     return blocks, kms, n_pre
 
@@ -340,19 +351,29 @@ def bench_widened(args):
     (BatchNorm, lrelu0.2), l2_ball normalisation, NestedLoRAForCDK loss L = 512 + constant mode, SGD momentum
     (reference examples/cdk/sketchy/main_sketchy.py:180-212)."""
     from neural_svd_amd import hip_ops as H
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    from neural_svd_amd import parallel
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
+    rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
+    local_rank = int(os.environ.get("NSVD_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if world > 1 else 0
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = parallel.Communicator.from_env(dev, backend=os.environ.get("NSVD_DIST_BACKEND"),
+                                          timeout_s=args.collective_timeout) if world > 1 else None
     steps = min(args.steps, 200)
     warmup = min(args.warmup, 20)
     repeats = args.repeats or 5
+    comm_block = None
     if args.config == "cfg4":
         from neural_svd_amd.kernel_ops import FusedKernelTrainer, synthetic_psd_kernel
-        N, D, L, B = 10000, 16, 64, args.batch_size or 8192
+        N, D, L = 10000, 16, 64
+        B = (args.batch_size or 8192) * world  # weak scaling: 8192 indices per GPU; heads sharded over the ranks
         op = synthetic_psd_kernel(N, 256, D, 0, dev)
         # the whole step as a fixed sequence of C-ABI calls on flat buffers (kernel_ops.FusedKernelTrainer): model
         # evaluation, Kf = K[x][:, x] f / B, moments, then d loss / d f + backward + RMSprop inside the backward kernels
         fk = FusedKernelTrainer(op, L=L, m=64, hidden=(128, 128), batch_size=B, sequential=False, lr=1e-4,
-                                rmsprop_decay=0.99, rmsprop_eps=1e-8, fourier_scale=0.05, seed=0)
+                                rmsprop_decay=0.99, rmsprop_eps=1e-8, fourier_scale=0.05, seed=0, comm=comm)
         last = {}
 
         def step():
@@ -360,7 +381,7 @@ def bench_widened(args):
         # the launch nsvd_profile_next_forward brackets first in a step is the model evaluation - which IS this step's
         # dominant kernel (rocprofv3: 560 us of the 1.6 ms, the gathered-row contraction ka_gemm_kernel 99 us):
         # 2 B L M flops, M = MACs per sample and head of the 128 -> 128 -> 128 -> 1 network behind 2 x 64 features
-        kflops = 2.0 * B * L * (128 * 128 + 128 * 128 + 128)
+        kflops = 2.0 * B * (L // world) * (128 * 128 + 128 * 128 + 128)
         kname = "pmlp_fused_fwd_kernel<1, 0, 0>"
         workload = (f"configs[3]: dense PSD kernel operator K = A A^T / 256 + 1e-3 I on N = {N} points in R^16, "
                     f"L = {L}, batch {B} indices with replacement, NestedLoRA.compute_loss_kernel(split_batch=False) "
@@ -372,6 +393,9 @@ def bench_widened(args):
                 "against it on the fp32 MFMA); model forward / backward on the E = 1 MFMA kernels; d loss / d f and the "
                 "RMSprop step inside the backward kernels (nsvd_model_backward_evd_step): no torch autograd, no torch.optim")
     else:
+        if world != 1:
+            raise SystemExit("--config cfg5 is a single-GPU measurement (the towers' BatchNorm takes its statistics "
+                             "over the whole batch: DESIGN.md 6)")
         import torch.nn as nn
         from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
         B, d0, d1, d2, L = args.batch_size or 1024, 512, 8192, 512, 512
@@ -401,8 +425,27 @@ def bench_widened(args):
                 "autograd, no torch.optim")
     use_ev = not args.no_kernel_events
     blocks, kms, n_pre = _timed_blocks(step, steps, warmup, repeats, args.prewarm_seconds,
-                                       H.profile_next_forward if use_ev else None)
-    summ = summarize(blocks, steps, 1)
+                                       H.profile_next_forward if use_ev else None, comm=comm)
+    summ = summarize(blocks, steps, world)
+    if comm is not None:  # where the sharded step's time goes: the exposed all-gather, and the step without it
+        fk.probe = parallel.CommProbe(dev)
+        for _ in range(50):
+            step()
+        waits = fk.probe.summary()
+        fk.probe = None
+        comm.barrier()
+        comm.stub = True
+        bl, _, _ = _timed_blocks(step, steps, warmup, 3, 0.2, None, comm=comm)
+        comm.stub = False
+        co = summarize(bl, steps, world)
+        comm_block = {"backend": comm.backend, "exchange": "one blocking all-gather of [f | Kf] per step",
+                      "all_gather_bytes": 2 * B * L * 4,
+                      "exposed_wait_us_per_step": {k: round(v, 2) for k, v in waits.items()},
+                      "compute_only_ms": co["ms_per_step"], "step_ms": summ["ms_per_step"],
+                      "rccl_ranks": comm.count_ranks()}
+    if rank != 0:
+        comm.close()
+        return
     roof = None
     if kms:
         kavg = sum(kms) / len(kms)
@@ -411,7 +454,7 @@ def bench_widened(args):
                     frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, kernel=kname,
                     kernel_avg_us=round(kavg * 1e3, 2), kernel_med_us=round(kms[len(kms) // 2] * 1e3, 2),
                     kernel_launches_timed=len(kms), kernel_flops=kflops)
-    out = {"metric": metric, "value": summ["value"], "unit": "steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+    out = {"metric": metric, "value": summ["value"], "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "timing": {"blocks": summ["blocks"], "ms_per_step_min": summ["ms_per_step_min"],
@@ -419,7 +462,14 @@ def bench_widened(args):
            "config": {"workload": workload, "note": note, "developer_config": args.config,
                       "not_the_headline_workload": True},
            "final_loss": float(last["loss"]), "roofline": roof, "cpu_baseline": None}
+    if comm is not None:
+        out["config"].update(global_batch=B, parallelism=f"hp{world}",
+                             sharding="heads: each GPU owns L/N heads, evaluates them and applies K to them on the "
+                                      "whole global batch; one all-gather of f, Kf per step, no gradient traffic")
+        out["comm"] = comm_block
     print(json.dumps(out))
+    if comm is not None:
+        comm.close()
 
 
 def main():
@@ -469,12 +519,13 @@ def main():
                          "headline run and the other is reported beside it (`other_sharding`)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and args.config == "cfg5":
+        raise SystemExit("--config cfg5 is a single-GPU measurement (the towers' BatchNorm takes its statistics over "
+                         "the whole batch: DESIGN.md 6)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the launcher (nothing has touched the GPU yet) and never computes
         return self_launch(args, sys.argv[1:])
     if args.config in ("cfg4", "cfg5"):
-        if args.gpus != 1:
-            raise SystemExit(f"--config {args.config} is a single-GPU measurement")
         return bench_widened(args)
 
     from neural_svd_amd import hip_ops as H

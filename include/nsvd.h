@@ -374,13 +374,16 @@ int nsvd_operator_backward_evd_step_next(const nsvd_model_desc* desc, const nsvd
  * this evaluates d loss / d f per sample inside the backward kernels from the moments (as
  * nsvd_operator_backward_evd does: same `moments` / `moments_reduced` / `evd_scratch` conventions), runs autograd's
  * backward of the plain model evaluation and - when opt != NULL - takes the RMSprop (+ EMA) step in the epilogue of
- * the weight-gradient kernel (grads may then be NULL). Input dimension up to 64; MFMA path only (128-wide hidden
- * layers, B a multiple of 32): NSVD_EUNSUPPORTED otherwise. ws: the workspace of the nsvd_model_forward call. */
+ * the weight-gradient kernel (grads may then be NULL). L_total / l_offset as in nsvd_operator_backward_evd: desc
+ * describes the heads [l_offset, l_offset + desc->L) of a model of L_total heads whose f, Tf (B, L_total), moments and
+ * masks are global (heads sharded over processes); 0, 0 = all heads. Input dimension up to 64; MFMA path only
+ * (128-wide hidden layers, B a multiple of 32): NSVD_EUNSUPPORTED otherwise. ws: the workspace of the
+ * nsvd_model_forward call. */
 int nsvd_model_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
                                  const float* f, const float* Tf, int mask_kind, const float* v, const float* M,
-                                 float* moments, int moments_reduced, const void* evd_scratch, float grad_scale,
-                                 float* loss, const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
-                                 size_t ws_bytes, void* stream);
+                                 float* moments, int moments_reduced, const void* evd_scratch, int L_total,
+                                 int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
+                                 const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, void* stream);
 
 /* One Sketchy-style CDK training step in ONE call: the loop body of examples/cdk/sketchy/main_sketchy.py:180-212 as
  * scripts/exps/sketchy.sh configures it (sgd, momentum 0.9, --clip_grad_norm), AMP branches off:

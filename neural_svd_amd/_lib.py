@@ -77,7 +77,7 @@ SIGNATURES = {
     "nsvd_model_forward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), _P, _I, _F, _P, _P, _Z, _I, _P]),
     "nsvd_model_backward": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), _P, _I, _P, C.POINTER(Params), _P, _Z, _P]),
     "nsvd_model_backward_evd_step": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), _P, _I, _P, _P, _I, _P, _P, _P, _I, _P,
-                                          _F, _P, C.POINTER(Params), C.POINTER(Rmsprop), _P, _Z, _P]),
+                                          _I, _I, _F, _P, C.POINTER(Params), C.POINTER(Rmsprop), _P, _Z, _P]),
     "nsvd_evd_scratch_bytes": (_Z, [_I, _I]),
     "nsvd_evd_moments": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "nsvd_evd_loss_grad": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P]),

@@ -502,11 +502,11 @@ extern "C" int nsvd_operator_backward_evd_step_next(const nsvd_model_desc* desc,
 extern "C" int nsvd_model_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params, const float* x,
                                             int B, const float* f, const float* Tf, int mask_kind, const float* v,
                                             const float* M, float* moments, int moments_reduced,
-                                            const void* evd_scratch, float grad_scale, float* loss,
-                                            const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
+                                            const void* evd_scratch, int L_total, int l_offset, float grad_scale,
+                                            float* loss, const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
                                             size_t ws_bytes, void* stream) {
     if (!opt && !grads) return NSVD_EINVAL;
     return backward_evd_impl(desc, params, nullptr, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced, evd_scratch,
-                             0, 0, grad_scale, loss, grads, opt, ws, ws_bytes, NSVD_PATH_AUTO, stream, 0, 0, nullptr,
-                             true);
+                             L_total, l_offset, grad_scale, loss, grads, opt, ws, ws_bytes, NSVD_PATH_AUTO, stream, 0, 0,
+                             nullptr, true);
 }

@@ -439,19 +439,20 @@ def model_backward_evd_step(shape: ModelShape, params: Params, x: torch.Tensor, 
                             mask_kind: int, v: Optional[torch.Tensor], M: Optional[torch.Tensor],
                             moments: torch.Tensor, moments_reduced: bool, evd_scratch: Optional[torch.Tensor],
                             loss: torch.Tensor, grads: Optional[Params], opt: Optional["_lib.Rmsprop"],
-                            ws: torch.Tensor, grad_scale: float = 1.0) -> None:
+                            ws: torch.Tensor, grad_scale: float = 1.0, l_offset: int = 0) -> None:
     """EVD loss gradient + backward of the plain model evaluation (+ the optimiser step when opt is given) after
-    model_forward(save_for_backward=True); Tf is the operator output computed from f (no gradient through it)."""
+    model_forward(save_for_backward=True); Tf is the operator output computed from f (no gradient through it).
+    f, Tf: (B, L_total) over ALL heads; shape describes the heads [l_offset, l_offset + shape.L) (head sharding)."""
     B, L = f.shape
-    if tuple(Tf.shape) != (B, L) or L != shape.L or x.shape[0] != B or moments.numel() != 2 * L * L + 1:
-        raise NsvdError("model_backward_evd_step: f, Tf (B, L); moments 2 L^2 + 1")
+    if tuple(Tf.shape) != (B, L) or L < l_offset + shape.L or x.shape[0] != B or moments.numel() != 2 * L * L + 1:
+        raise NsvdError("model_backward_evd_step: f, Tf (B, L_total); moments 2 L_total^2 + 1")
     d = shape.desc()
     rc = _lib.load().nsvd_model_backward_evd_step(
         C.byref(d), C.byref(params), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind), _ptr(v, "v"),
         _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
-        evd_scratch.data_ptr() if evd_scratch is not None else None, float(grad_scale), _ptr(loss, "loss"),
-        C.byref(grads) if grads is not None else None, C.byref(opt) if opt is not None else None, ws.data_ptr(),
-        ws.numel(), _stream())
+        evd_scratch.data_ptr() if evd_scratch is not None else None, int(L), int(l_offset), float(grad_scale),
+        _ptr(loss, "loss"), C.byref(grads) if grads is not None else None, C.byref(opt) if opt is not None else None,
+        ws.data_ptr(), ws.numel(), _stream())
     check(rc, "nsvd_model_backward_evd_step")
 
 

@@ -88,25 +88,44 @@ class FusedKernelTrainer:
     batch -> gather of the coordinates -> model evaluation (nsvd_model_forward) -> Kf = K[x][:, x] f / B
     (nsvd_kernel_apply) -> moments (nsvd_evd_moments) -> d loss / d f, backward and the optimiser step inside
     the backward kernels (nsvd_model_backward_evd_step). No torch autograd, no torch.optim; what torch still does is
-    draw the indices and gather the coordinates. The counterpart of trainer.FusedTrainer for BASELINE configs[3]."""
+    draw the indices and gather the coordinates. The counterpart of trainer.FusedTrainer for BASELINE configs[3].
+
+    Multi-GPU (comm: parallel.Communicator with world > 1): HEADS sharded, as trainer.FusedTrainer's "hp". Rank r owns
+    the heads [r L / W, (r + 1) L / W) - weights, gradients, optimiser state: nothing replicated, no gradient traffic.
+    Every rank draws the same index batch (equal generator seeds), evaluates its heads on it, and applies K to ITS
+    columns of f only (Kf[:, l] = K[x][:, x] f[:, l] / B needs no other head): the MFMA work of the step is split W
+    ways. One all-gather of the packed (2, B, L / W) block [f | Kf] per step (2 B L floats in total: 4 MB at cfg4) is
+    the only exchange; moments, loss gradient and backward of the local heads are then local."""
 
     def __init__(self, op: DenseKernelOperator, L: int, m: int, hidden=(128, 128), batch_size: int = 8192,
                  sequential: bool = False, step: int = 1, lr: float = 1e-4, rmsprop_decay: float = 0.99,
                  rmsprop_eps: float = 1e-8, ema_decay: float = 0.0, num_iters: int = 0, fourier_scale: float = 0.05,
-                 hard_mul_const: float = 1.0, seed: int = 0, index_seed: int = 1):
+                 hard_mul_const: float = 1.0, seed: int = 0, index_seed: int = 1, comm=None):
         from .nested_lowrank import nesting_masks
         from .trainer import FlatParams, reference_init
         self.op = op
         dev = op.K.device
         self.device = dev
         D = op.points.shape[1]
-        self.shape = H.ModelShape(L=L, D=D, m=m, hidden=tuple(hidden), has_exp_mask=False)
+        self.comm = comm if comm is not None and comm.multi else None
+        world = self.comm.world if self.comm is not None else 1
+        rank = self.comm.rank if self.comm is not None else 0
+        if L % world != 0:
+            raise ValueError(f"head sharding needs L ({L}) divisible by the world size ({world})")
+        self.world, self.Lg, Ll = world, L, L // world
+        self.l_off = rank * Ll
+        self.full_shape = H.ModelShape(L=L, D=D, m=m, hidden=tuple(hidden), has_exp_mask=False)
+        self.shape = H.ModelShape(L=Ll, D=D, m=m, hidden=tuple(hidden), has_exp_mask=False)
         self.B = int(batch_size)
         if any(h != 128 for h in hidden) or self.B % 32 != 0 or not 1 <= D <= 64 or (2 * m) % 128 != 0:
             raise H.NsvdError("FusedKernelTrainer needs the MFMA model kernels: 128-wide hidden layers, batch % 32 == 0, "
                               "2 m % 128 == 0, input dimension <= 64 (nsvd_model_backward_evd_step)")
         self.P = FlatParams(self.shape, dev)
-        self.P.load(*reference_init(self.shape, fourier_scale, None, seed))
+        fB0, ws0, bs0, _ = reference_init(self.full_shape, fourier_scale, None, seed)
+        sl = slice(self.l_off, self.l_off + Ll)  # this rank's heads of the (identically seeded) full model
+        self.P.load(fB0, [w[sl] for w in ws0], [b[sl] for b in bs0], None)
+        if self.comm is not None:
+            self.comm.broadcast(self.P.fourier_B, 0)  # the frozen Fourier matrix is shared whatever the ranks drew
         self._params = self.P.pack(self.P.flat, True)
         self._sq = self.P.pack(self.P.sq, False)
         self._ema = self.P.pack(self.P.ema, True) if ema_decay > 0 else None
@@ -117,25 +136,41 @@ class FusedKernelTrainer:
         self.lr, self.alpha, self.eps, self.ema_decay, self.num_iters = lr, rmsprop_decay, rmsprop_eps, ema_decay, num_iters
         self.c = float(hard_mul_const)
         self.ws = H.model_workspace(self.shape, self.B, dev)
-        self.ka_ws = torch.empty(H._lib.load().nsvd_kernel_apply_workspace_bytes(int(op.N), self.B, L),
+        self.ka_ws = torch.empty(H._lib.load().nsvd_kernel_apply_workspace_bytes(int(op.N), self.B, Ll),
                                  dtype=torch.uint8, device=dev)
-        self.f = torch.empty((self.B, L), dtype=torch.float32, device=dev)
-        self.Kf = torch.empty_like(self.f)
+        # this rank's outputs packed [f | Kf] so that one all-gather moves both
+        self.fKf_loc = torch.empty((2, self.B, Ll), dtype=torch.float32, device=dev)
+        self.f_loc, self.Kf_loc = self.fKf_loc[0], self.fKf_loc[1]
+        if self.comm is not None:
+            self.gath = torch.empty((world, 2, self.B, Ll), dtype=torch.float32, device=dev)
+            self.fKf = torch.empty((2, self.B, L), dtype=torch.float32, device=dev)
+            self.f, self.Kf = self.fKf[0], self.fKf[1]
+        else:
+            self.f, self.Kf = self.f_loc, self.Kf_loc
         self.moments = torch.empty(2 * L * L + 1, dtype=torch.float32, device=dev)
         self.loss = torch.zeros(3, dtype=torch.float32, device=dev)
         self.scratch = H.evd_scratch(self.B, L, dev)
-        self.gen = torch.Generator(device=dev).manual_seed(index_seed)
+        self.gen = torch.Generator(device=dev).manual_seed(index_seed)  # the same stream on every rank
+        self.probe = None  # parallel.CommProbe while bench.py measures the exposed wait of the all-gather
         self.t = 0
 
     def step(self, idx: torch.Tensor = None) -> torch.Tensor:
-        """one optimiser step on the index batch idx (or a fresh draw); returns the device loss triple (no sync)"""
+        """one optimiser step on the index batch idx (or a fresh draw; sharded runs: the SAME batch on every rank);
+        returns the device loss triple (no sync)"""
         from .trainer import cosine_lr
         if idx is None:
             idx = self.op.sample_indices(self.B, self.gen)
         idx = idx.to(torch.int64).contiguous()
         x = self.op.points.index_select(0, idx)
-        H.model_forward(self.shape, self._params, x, self.c, self.ws, save_for_backward=True, out=self.f)
-        H.kernel_apply(self.op.K, self.op.N, idx, idx, self.f, 1.0 / self.B, ws=self.ka_ws, out=self.Kf)
+        H.model_forward(self.shape, self._params, x, self.c, self.ws, save_for_backward=True, out=self.f_loc)
+        H.kernel_apply(self.op.K, self.op.N, idx, idx, self.f_loc, 1.0 / self.B, ws=self.ka_ws, out=self.Kf_loc)
+        if self.comm is not None:
+            if self.probe is not None:
+                with self.probe.span("f_Kf_all_gather_wait"):
+                    self.comm.all_gather(self.gath, self.fKf_loc)  # blocking: on the compute stream (parallel.dp_step)
+            else:
+                self.comm.all_gather(self.gath, self.fKf_loc)
+            self.fKf.view(2, self.B, self.world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
         # the reduced moment vector (partials + one reduction launch): at B = 8192 every workgroup of the backward
         # summing the 128 per-chunk partials of its 2 L moments itself would cost 3 x the reduction
         H.evd_moments(self.f, self.Kf, self.mask_kind, self.v, self.moments, self.scratch)
@@ -143,6 +178,8 @@ class FusedKernelTrainer:
         decay = min(self.ema_decay, (2 + self.t) / (11 + self.t)) if self._ema is not None else 0.0
         opt = H.rmsprop_state(self._sq, self._ema, lr, self.alpha, self.eps, decay)
         H.model_backward_evd_step(self.shape, self._params, x, self.f, self.Kf, self.mask_kind, self.v, self.M,
-                                  self.moments, True, None, self.loss, None, opt, self.ws)
+                                  self.moments, True, None, self.loss, None, opt, self.ws, l_offset=self.l_off)
+        if self.probe is not None:
+            self.probe.step_done()
         self.t += 1
         return self.loss

@@ -40,6 +40,16 @@ def dp_rows(xg, rank, world):
     return torch.cat([xg[rank * q:(rank + 1) * q], xg[h + rank * q:h + (rank + 1) * q]]).contiguous()
 
 
+def ko_case(dev, world):
+    """a small dense kernel operator, the trainer keywords and three index batches (the same on every rank)"""
+    from neural_svd_amd.kernel_ops import synthetic_psd_kernel
+    op = synthetic_psd_kernel(N=700, rank=48, dim=5, seed=3, device=dev)
+    kw = dict(L=8, m=64, hidden=(128, 128), batch_size=128 * world, sequential=True, lr=1e-3, seed=2)
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.randint(700, (128 * world,), generator=g) for _ in range(3)]
+    return op, kw, batches
+
+
 def main():
     mode, out_dir = sys.argv[1], sys.argv[2]
     dev = torch.device("cuda", int(os.environ["NSVD_FORCE_DEVICE"]))
@@ -90,6 +100,19 @@ def main():
             runs.append(dict(init=init, flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), fB=tr.P.fourier_B.cpu(),
                              loss=tr.loss.cpu(), drawn=tr.batches_drawn, x=tr.x.cpu()))
         res["runs"] = runs
+    elif mode == "ko_hp":
+        # the kernel-operator step (kernel_ops.FusedKernelTrainer) with heads sharded: every rank the same index batches
+        from neural_svd_amd.kernel_ops import FusedKernelTrainer
+        op, kw_ko, batches = ko_case(dev, world)
+        fk = FusedKernelTrainer(op, comm=comm, **kw_ko)
+        assert fk.world == world and fk.shape.L == kw_ko["L"] // world and fk.l_off == rank * fk.shape.L
+        for i, idx in enumerate(batches):
+            loss = fk.step(idx.to(dev))
+            if i == 0:
+                res["loss0"], res["mom0"] = loss.clone().cpu(), fk.moments.clone().cpu()
+                res["f0"], res["Kf0"] = fk.f.clone().cpu(), fk.Kf.clone().cpu()
+        res.update(views=[v.cpu() for v in fk.P.views(fk.P.flat)], sq=[v.cpu() for v in fk.P.views(fk.P.sq)],
+                   l_off=fk.l_off, t=fk.t)
     elif mode == "rccl1":
         # ONE rank on the real collective library (backend "nccl" = RCCL): the exchange sequences forced on in a world
         # of one, so that every RCCL call of the product path - argument views, in-place gathers, AVG, async work

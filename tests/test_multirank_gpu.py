@@ -224,3 +224,34 @@ def test_every_exchange_on_rccl_in_a_world_of_one(tmp_path):
                 assert torch.equal(r[name][k], r["plain_internal"][k]), (name, k)
             else:
                 assert rel(r[name][k], r["plain_internal"][k]) < (1e-3 if k == "sq" else 1e-4), (name, k)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_kernel_operator_step_with_heads_sharded_matches_single_process(tmp_path, world):
+    """BASELINE configs[3]'s step (kernel_ops.FusedKernelTrainer) with the heads sharded over `world` ranks: each rank
+    evaluates its L / world heads and applies K to its own columns of f on the whole batch, one all-gather of [f | Kf];
+    after three steps every rank's weights are the head slices of the single-process trainer's."""
+    rs = run_ranks("ko_hp", world, tmp_path)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _multirank_worker as W
+    from neural_svd_amd.kernel_ops import FusedKernelTrainer
+    dev = torch.device("cuda:0")
+    op, kw, batches = W.ko_case(dev, world)
+    fk = FusedKernelTrainer(op, **kw)
+    ref = {}
+    for i, idx in enumerate(batches):
+        loss = fk.step(idx.to(dev))
+        if i == 0:
+            ref.update(loss0=loss.clone().cpu(), mom0=fk.moments.clone().cpu(), f0=fk.f.clone().cpu(),
+                       Kf0=fk.Kf.clone().cpu())
+    views, sq = [v.cpu() for v in fk.P.views(fk.P.flat)], [v.cpu() for v in fk.P.views(fk.P.sq)]
+    Ll = kw["L"] // world
+    for rank, r in enumerate(rs):
+        assert r["t"] == 3 and r["l_off"] == rank * Ll
+        # the gathered (B, L) arrays are the single-process ones: same kernels on the same columns
+        assert torch.equal(r["f0"], ref["f0"]) and rel(r["Kf0"], ref["Kf0"]) < 1e-6
+        assert rel(r["mom0"], ref["mom0"]) < 2e-6 and rel(r["loss0"], ref["loss0"]) < 2e-6
+        for got, want, s_got, s_want in zip(r["views"], views, r["sq"], sq):
+            sl = slice(rank * Ll, (rank + 1) * Ll)
+            assert rel(got, want[sl]) < 1e-5 and rel(s_got, s_want[sl]) < 1e-4
