@@ -21,6 +21,7 @@ struct KaWs {
     float* ST;      // (Lp, Np) scattered batch, zero padded
     float* part;    // (S, B1p, Lp) split-K partial tiles
     int Np, Lp, B1p, S;
+    int all_rows;   // 1: the contraction runs over ALL N rows of K once and the output rows are gathered from it
     size_t bytes;
 };
 
@@ -28,7 +29,11 @@ KaWs carve(void* base, int N, int B1, int L) {
     KaWs w;
     w.Np = nsvd_cdiv(N, KC) * KC;
     w.Lp = nsvd_cdiv(L, T) * T;
-    w.B1p = nsvd_cdiv(B1, T) * T;
+    // more output rows than points (head-sharded runs: the batch grows with the world size, the point set does not):
+    // rows drawn with replacement repeat, and the gathered rows of K are what the kernel streams from HBM - multiply
+    // every row of K once (N rows) and gather the B1 output rows from the product
+    w.all_rows = B1 > N ? 1 : 0;
+    w.B1p = nsvd_cdiv(w.all_rows ? N : B1, T) * T;
     const int tiles = (w.B1p / T) * (w.Lp / T), chunks = w.Np / KC;
     int S = 1;
     while (tiles * S < 512 && chunks / (2 * S) >= 8) S *= 2;  // enough blocks for two per CU, >= 8 chunks per slice
@@ -69,7 +74,8 @@ __global__ void __launch_bounds__(256, 2) ka_gemm_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = tb * T + lr0 + 16 * i;
-        long long g = r < B1 ? rows[r] : 0;  // padding rows of the tile read row 0; their results are never used
+        // padding rows of the tile read row 0; their results are never used. rows == nullptr: row r of K itself
+        long long g = r < B1 ? (rows ? rows[r] : (long long)r) : 0;
         if (g < 0 || g >= N) g = 0;
         ap[i] = K + g * ldk + lc + (long)c0 * KC;
     }
@@ -92,10 +98,15 @@ __global__ void __launch_bounds__(256) ka_reduce_kernel(KaWs w, const long long*
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B1 * L) return;
     const int b = i / L, l = i - b * L;
-    float s = 0.f;
-    for (int sl = 0; sl < w.S; ++sl) s += w.part[((size_t)sl * w.B1p + b) * w.Lp + l];
     const long long g = rows[b];
-    out[i] = (g < 0 || g >= N) ? 0.f : scale * s;
+    if (g < 0 || g >= N) {
+        out[i] = 0.f;
+        return;
+    }
+    const size_t pr = w.all_rows ? (size_t)g : (size_t)b;  // product row: of K's row g, or of this output row
+    float s = 0.f;
+    for (int sl = 0; sl < w.S; ++sl) s += w.part[((size_t)sl * w.B1p + pr) * w.Lp + l];
+    out[i] = scale * s;
 }
 
 size_t ka_lds_bytes() {
@@ -129,7 +140,9 @@ extern "C" int nsvd_kernel_apply(const float* K, size_t ldk, int N, const long l
     ka_scatter_kernel<<<nsvd_cdiv(B2 * L, 256), 256, 0, s>>>(f, cols, B2, L, N, w.ST, w.Np);
     NSVD_CHECK_LAUNCH();
     nsvd_prof_begin(s);  // bench.py --config cfg4 brackets the contraction (nsvd_profile_next_forward)
-    ka_gemm_kernel<<<dim3(w.B1p / T, w.Lp / T, w.S), 256, ka_lds_bytes(), s>>>(K, (long)ldk, N, rows, B1, w);
+    ka_gemm_kernel<<<dim3(w.B1p / T, w.Lp / T, w.S), 256, ka_lds_bytes(), s>>>(K, (long)ldk, N,
+                                                                                w.all_rows ? nullptr : rows,
+                                                                                w.all_rows ? N : B1, w);
     nsvd_prof_end(s);
     NSVD_CHECK_LAUNCH();
     ka_reduce_kernel<<<nsvd_cdiv(B1 * L, 256), 256, 0, s>>>(w, rows, N, B1, L, scale, out);

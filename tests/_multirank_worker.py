@@ -43,10 +43,12 @@ def dp_rows(xg, rank, world):
 def ko_case(dev, world):
     """a small dense kernel operator, the trainer keywords and three index batches (the same on every rank)"""
     from neural_svd_amd.kernel_ops import synthetic_psd_kernel
-    op = synthetic_psd_kernel(N=700, rank=48, dim=5, seed=3, device=dev)
+    # 300 points: the batch of two ranks (256) is smaller, that of four ranks (512) larger than the point set (the
+    # latter takes nsvd_kernel_apply's multiply-every-row-once form)
+    op = synthetic_psd_kernel(N=300, rank=48, dim=5, seed=3, device=dev)
     kw = dict(L=8, m=64, hidden=(128, 128), batch_size=128 * world, sequential=True, lr=1e-3, seed=2)
     g = torch.Generator().manual_seed(21)
-    batches = [torch.randint(700, (128 * world,), generator=g) for _ in range(3)]
+    batches = [torch.randint(300, (128 * world,), generator=g) for _ in range(3)]
     return op, kw, batches
 
 

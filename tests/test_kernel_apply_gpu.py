@@ -18,8 +18,11 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize("N,B1,B2,L", [(300, 64, 64, 8), (1000, 193, 70, 33), (130, 5, 400, 1), (2048, 512, 512, 64)])
+@pytest.mark.parametrize("N,B1,B2,L", [(300, 64, 64, 8), (1000, 193, 70, 33), (130, 5, 400, 1), (2048, 512, 512, 64),
+                                       (130, 401, 90, 5), (300, 1024, 1024, 8)])
 def test_kernel_apply_matches_float64(N, B1, B2, L):
+    """the last two cases have more output rows than points: every row of K is multiplied once and the output rows
+    are gathered from the product (head-sharded runs: the batch grows with the world size, the point set does not)"""
     from neural_svd_amd import hip_ops as H
     g = torch.Generator().manual_seed(N + B1)
     A = torch.randn(N, 32, generator=g, dtype=torch.float64)
