@@ -54,6 +54,9 @@ def ko_case(dev, world):
 
 def main():
     mode, out_dir = sys.argv[1], sys.argv[2]
+    if mode.endswith("_big"):  # batches beyond 1024 rows: the backward takes partial moment sums instead of f itself
+        CASE["B_local"] = 640
+        mode = mode[:-4]
     dev = torch.device("cuda", int(os.environ["NSVD_FORCE_DEVICE"]))
     torch.cuda.set_device(dev)
     comm = parallel.Communicator.from_env(dev, backend=os.environ.get("NSVD_DIST_BACKEND", "gloo"))
@@ -156,7 +159,7 @@ def main():
         raise SystemExit(f"unknown mode {mode}")
     torch.cuda.synchronize()
     comm.barrier()
-    torch.save(res, os.path.join(out_dir, f"{mode}_r{rank}.pt"))
+    torch.save(res, os.path.join(out_dir, f"{sys.argv[1]}_r{rank}.pt"))
     comm.close()
 
 

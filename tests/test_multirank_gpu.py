@@ -53,10 +53,11 @@ def run_ranks(mode, world, out_dir, backend="gloo"):
     return [torch.load(os.path.join(str(out_dir), f"{mode}_r{r}.pt"), weights_only=False) for r in range(world)]
 
 
-def single_process(world):
+def single_process(world, b_local=None):
     """the same steps by ONE trainer on the global batches (separate optimiser kernel so that the gradient is kept)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _multirank_worker as W
+    W.CASE["B_local"] = b_local or 64  # (module state: set on every call)
     from neural_svd_amd.trainer import FusedTrainer
     dev = torch.device("cuda:0")
     tr = FusedTrainer(W.make_shape(), W.make_problem(), W.CASE["B_local"] * world, seed=5, device=dev,
@@ -145,11 +146,13 @@ def _views(flat, L):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 4])
-def test_hp_ranks_match_single_process(tmp_path, world):
-    """world 4: ONE head per rank on four times the local batch - the extreme of the head split"""
-    rs = run_ranks("hp", world, tmp_path)
-    ref = single_process(world)
+@pytest.mark.parametrize("world,big", [(2, False), (4, False), (2, True)])
+def test_hp_ranks_match_single_process(tmp_path, world, big):
+    """world 4: ONE head per rank on four times the local batch - the extreme of the head split; big: a global batch of
+    1280 rows, beyond the 1024 up to which the backward takes its moments from f itself - the partial-sum form with a
+    head offset, which is what every rank of an 8-GPU run of configs[1] (4096 rows) executes"""
+    rs = run_ranks("hp_big" if big else "hp", world, tmp_path)
+    ref = single_process(world, 640 if big else 64)
     import _multirank_worker as W
     L = W.CASE["L"]
     Ll = L // world
