@@ -106,7 +106,11 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         bid -= grp * nsb * a.L;
     }
     xcd_block_map(bid, a.xcd_remap, a.L, nsb, l, sb);  // pmlp_common.h
-    const int b0 = sb * BS;
+    // (the map divides by run-time values: computed on the vector ALU although uniform - pin the results to scalar
+    // registers so that every address derived from them is scalar too)
+    l = __builtin_amdgcn_readfirstlane(l);
+    const int b0 = __builtin_amdgcn_readfirstlane(sb * BS);
+    grp = __builtin_amdgcn_readfirstlane(grp);
 
     NSVD_STAMP(0)
     // accumulators start from the bias (z = b + W a): its 16 loads fly under the first chunk's staging instead
@@ -139,43 +143,54 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // with the same float32 expressions the feature kernel used to evaluate: phi(x +- eps e_d) is never stored.
     // (5x less feature traffic per tile; the feature kernel writes B x F instead of E x B x F.)
     constexpr int DD = JET ? E - 2 : (E - 1) / 2;  // input dimensions
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     float4 ra0, ra1, ra2, ra3, rs, rc, cd0, sd0, cd1, sd1, cd2, sd2;
     ra0 = ra1 = ra2 = ra3 = rs = rc = cd0 = sd0 = cd1 = sd1 = cd2 = sd2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4 per slab
-    const float* a_src = W0 + (size_t)s_row * a.F + 4 * s_c4;
-    const float* b_src = a.phiT + (size_t)(b0 + s_row) * a.F + 4 * s_c4;  // centre features, (B, F) row-major
-    const float* t_src = a.sctab + 4 * s_c4 + (size_t)grp * 2 * a.m;  // (D, 2, m): this group's direction first
+    // Addresses as UNIFORM base (scalar registers, advanced per chunk by scalar adds) + one 32-bit byte offset per
+    // thread, the same for W_0's slabs and the feature rows: the loads take the scalar-base form and the loop carries
+    // no 64-bit vector address arithmetic (it did: 10 v_lshl_add_u64 per chunk - and every vector-ALU instruction in
+    // this loop costs matrix-pipe time, see the header).
+    const unsigned offA = (unsigned)(s_row * a.F + 4 * s_c4) * 4u;
+    const unsigned offT = (unsigned)(4 * s_c4) * 4u;
+    const float* a_u = W0;
+    const float* b_u = a.phiT + (size_t)b0 * a.F;               // centre features, (B, F) row-major
+    const float* t_u = a.sctab + (size_t)grp * 2 * a.m;         // (D, 2, m): this group's direction first
     const size_t a_step = (size_t)32 * a.F;
     const int mm = a.m;
-#define NSVD_LDG(p) (*reinterpret_cast<const float4*>(p))
+#define NSVD_LDGU(ub, off) (*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ub) + (off)))
 // chunk c = pair (c >> 1), half (c & 1): HALF = 0 the sin features, 1 their cos partners
 #define NSVD_LOAD_CHUNK(c, HALF)                                                 \
     {                                                                            \
         const int kp_ = ((c) >> 1) * BK;                                         \
-        const float* pa_ = a_src + ((HALF) ? mm : 0) + kp_;                      \
-        ra0 = NSVD_LDG(pa_);                                                     \
-        ra1 = NSVD_LDG(pa_ + a_step);                                            \
-        ra2 = NSVD_LDG(pa_ + 2 * a_step);                                        \
-        ra3 = NSVD_LDG(pa_ + 3 * a_step);                                        \
+        const float* pa_ = a_u + ((HALF) ? mm : 0) + kp_;                        \
+        ra0 = NSVD_LDGU(pa_, offA);                                              \
+        ra1 = NSVD_LDGU(pa_ + a_step, offA);                                     \
+        ra2 = NSVD_LDGU(pa_ + 2 * a_step, offA);                                 \
+        ra3 = NSVD_LDGU(pa_ + 3 * a_step, offA);                                 \
         if (!(HALF)) {                                                           \
-            rs = NSVD_LDG(b_src + kp_);                                          \
-            rc = NSVD_LDG(b_src + mm + kp_);                                     \
-            if (DD > 0) cd0 = NSVD_LDG(t_src + kp_);                             \
-            if (DD > 0) sd0 = NSVD_LDG(t_src + mm + kp_);                        \
-            if (DD > 1) cd1 = NSVD_LDG(t_src + 2 * mm + kp_);                    \
-            if (DD > 1) sd1 = NSVD_LDG(t_src + 3 * mm + kp_);                    \
-            if (DD > 2) cd2 = NSVD_LDG(t_src + 4 * mm + kp_);                    \
-            if (DD > 2) sd2 = NSVD_LDG(t_src + 5 * mm + kp_);                    \
+            rs = NSVD_LDGU(b_u + kp_, offA);                                     \
+            rc = NSVD_LDGU(b_u + mm + kp_, offA);                                \
+            if (DD > 0) cd0 = NSVD_LDGU(t_u + kp_, offT);                        \
+            if (DD > 0) sd0 = NSVD_LDGU(t_u + mm + kp_, offT);                   \
+            if (DD > 1) cd1 = NSVD_LDGU(t_u + 2 * mm + kp_, offT);               \
+            if (DD > 1) sd1 = NSVD_LDGU(t_u + 3 * mm + kp_, offT);               \
+            if (DD > 2) cd2 = NSVD_LDGU(t_u + 4 * mm + kp_, offT);               \
+            if (DD > 2) sd2 = NSVD_LDGU(t_u + 5 * mm + kp_, offT);               \
         }                                                                        \
     }
 #define NSVD_STS(p, v) (*reinterpret_cast<float4*>(p) = (v))
-// u cd + v sd and u cd - v sd, componentwise, as fmaf(u, cd, +-(v * sd)) (the feature kernel's expressions)
+// u cd + v sd and u cd - v sd, componentwise, as fmaf(u, cd, +-(v * sd)) (the feature kernel's expressions), written
+// on vector types: outside MFMA shadows hipcc emits v_pk_mul_f32 / v_pk_fma_f32 for them, inside it unpacks them again
+// (packed fp32 cannot co-issue with an MFMA on this part). Measured upper bound for this arithmetic: with it removed
+// altogether the cfg2 kernel runs 176.0 us instead of 178.9 - the loop's overhead over its MFMA issue is barrier skew
+// and LDS traffic, not the vector ALU.
 #define NSVD_PM(plus, minus, u, v, cd, sd)                                                         \
     {                                                                                              \
-        plus = make_float4(fmaf(u.x, cd.x, v.x * sd.x), fmaf(u.y, cd.y, v.y * sd.y),              \
-                           fmaf(u.z, cd.z, v.z * sd.z), fmaf(u.w, cd.w, v.w * sd.w));              \
-        minus = make_float4(fmaf(u.x, cd.x, -(v.x * sd.x)), fmaf(u.y, cd.y, -(v.y * sd.y)),        \
-                            fmaf(u.z, cd.z, -(v.z * sd.z)), fmaf(u.w, cd.w, -(v.w * sd.w)));       \
+        const f32x4 u_ = __builtin_bit_cast(f32x4, u), c_ = __builtin_bit_cast(f32x4, cd);         \
+        const f32x4 t_ = __builtin_bit_cast(f32x4, v) * __builtin_bit_cast(f32x4, sd);             \
+        plus = __builtin_bit_cast(float4, __builtin_elementwise_fma(u_, c_, t_));                  \
+        minus = __builtin_bit_cast(float4, __builtin_elementwise_fma(u_, c_, -t_));                \
     }
 // jet rows of a chunk: value u, derivative streams w * b_d (w = the partner feature, sign folded in), Laplacian -q u
 #define NSVD_MUL4(o, u, k) o = make_float4(u.x * k.x, u.y * k.y, u.z * k.z, u.w * k.w)
@@ -297,7 +312,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #undef NSVD_PM
 #undef NSVD_MUL4
 #undef NSVD_NMUL4
-#undef NSVD_LDG
+#undef NSVD_LDGU
 #undef NSVD_STS
 
     }

@@ -21,4 +21,4 @@ except Exception as e: print("bench json:", e, open("$out/$name.err").read()[-15
 PY
 }
 run new
-for e in "$@"; do run "$(echo $e | tr '=' '_')" "$e"; done
+for e in "$@"; do run "$(echo $e | tr '=/' '__' | tail -c 40)" "$e"; done
