@@ -118,7 +118,18 @@ def get_optimizer(args, model):
     raise NotImplementedError
 
 
-def _fused_loop_trainer(args, method, operator, importance_train, device):
+def _comm_from_env(device):
+    """torch.distributed.run (or any launcher that sets RANK / WORLD_SIZE / MASTER_*) started this script on several
+    GPUs: the Communicator of this rank, else None. The reference has no live distributed path (tools/generic.py:65-180
+    is never imported): with this package the same main_pde.py scales by `torchrun --nproc-per-node N main_pde.py ...`."""
+    import os
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or torch.device(device).type != "cuda":
+        return None
+    from .parallel import Communicator
+    return Communicator.from_env(torch.device(device), backend=os.environ.get("NSVD_DIST_BACKEND"))
+
+
+def _fused_loop_trainer(args, method, operator, importance_train, device, comm=None):
     """A FusedTrainer over the SAME weights when the configuration is one it implements, else None."""
     from .models import WaveFunctions
     from .nested_lowrank import NestedLoRA, nesting_masks
@@ -144,21 +155,29 @@ def _fused_loop_trainer(args, method, operator, importance_train, device):
     model = method.model
     dev = torch.device(device)
     # the trainer's constructor draws (and here discards) initial weights: keep the caller's random streams untouched
+    par = "dp"
+    if comm is not None:
+        # several ranks: heads sharded when they divide (no gradient traffic, one all-gather of f, Tf per step:
+        # parallel.py), samples sharded otherwise; args.parallelism overrides
+        par = getattr(args, "parallelism", None) or ("hp" if model.shape.L % comm.world == 0 else "dp")
     with torch.random.fork_rng(devices=[dev.index if dev.index is not None else torch.cuda.current_device()]):
         tr = _make_fused(FusedTrainer, args, method, model, operator, importance_train, step, device,
-                         fused_problem_of)
-    tr.P.load(model.base.feature_map._B.data, [w.data for w in model.base.ws], [b.data for b in model.base.bs],
-              model.boundary_mask.scales.data if model.has_exp_mask else None)
+                         fused_problem_of, comm, par)
+    sl = slice(tr.l_off, tr.l_off + tr.shape.L)  # this rank's heads (all of them unless heads are sharded)
+    tr.P.load(model.base.feature_map._B.data, [w.data[sl] for w in model.base.ws], [b.data[sl] for b in model.base.bs],
+              model.boundary_mask.scales.data[sl] if model.has_exp_mask else None)
     return tr
 
 
-def _make_fused(FusedTrainer, args, method, model, operator, importance_train, step, device, fused_problem_of):
+def _make_fused(FusedTrainer, args, method, model, operator, importance_train, step, device, fused_problem_of,
+                comm=None, parallelism="dp"):
     return FusedTrainer(model.shape, fused_problem_of(operator, importance_train, model), args.batch_size,
-                      sequential=bool(method.sequential), step=step, lr=args.lr, rmsprop_decay=args.rmsprop_decay,
-                      rmsprop_eps=1e-10, ema_decay=args.ema_decay, num_iters=args.num_iters,
-                      use_lr_scheduler=bool(args.use_lr_scheduler), sampling_scale=importance_train.sigma, seed=0,
-                      device=device, path=method.path, device_sampler=False,
-                      exp_mask_init=1.0 if model.has_exp_mask else None)  # initial values: replaced by the caller
+                        sequential=bool(method.sequential), step=step, lr=args.lr, rmsprop_decay=args.rmsprop_decay,
+                        rmsprop_eps=1e-10, ema_decay=args.ema_decay, num_iters=args.num_iters,
+                        use_lr_scheduler=bool(args.use_lr_scheduler), sampling_scale=importance_train.sigma, seed=0,
+                        device=device, path=method.path, device_sampler=False, comm=comm, parallelism=parallelism,
+                        sync_collectives=True,
+                        exp_mask_init=1.0 if model.has_exp_mask else None)  # initial values: replaced by the caller
 
 
 @torch.no_grad()
@@ -166,7 +185,18 @@ def _refresh_from_trainer(tr, method, ema, optimizer, scheduler):
     """nn.Module parameters, EMA shadow, RMSprop state and schedule position <- the fused trainer's buffers."""
     named = dict(method.named_parameters())
     shadow = {id(p): s for p, s in zip(ema.params, ema.shadow_params)}
+    tr.gather_optimizer_state()  # (samples sharded with a sharded optimiser: make the state whole first)
+
+    def whole(v):
+        """heads sharded: every rank's (L / world, ...) slice of a tensor -> the (L, ...) tensor, on every rank"""
+        if not tr.hp:
+            return v
+        out = torch.empty((tr.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+        tr.comm.all_gather(out, v.contiguous())
+        return out.view((tr.world * v.shape[0],) + tuple(v.shape[1:]))
+
     for n, w, e, q in zip(tr.P.names, tr.P.views(tr.P.flat), tr.P.views(tr.P.ema), tr.P.views(tr.P.sq)):
+        w, e, q = whole(w), whole(e), whole(q)
         p = named[n]
         p.data.copy_(w.view_as(p))
         shadow[id(p)].copy_(e.view_as(p))
@@ -190,7 +220,18 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     optimizer = get_optimizer(args, method)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.num_iters)
     ema = ExponentialMovingAverage(method.parameters(), decay=args.ema_decay)
-    fused = _fused_loop_trainer(args, method, operator, importance_train, device)
+    comm = _comm_from_env(device)
+    fused = _fused_loop_trainer(args, method, operator, importance_train, device, comm)
+    if comm is not None and fused is None:
+        raise NotImplementedError("several ranks (WORLD_SIZE > 1) need the fused loop: this configuration is not one "
+                                  "it implements (rmsprop without momentum, NestedLoRA on WaveFunctions, GPU)")
+    rank0 = comm is None or comm.rank == 0
+    # per-GPU batch = args.batch_size (weak scaling). Heads sharded: every rank steps on the SAME global batch of
+    # world x batch_size rows - the sampler is called world times per step, and equally seeded ranks draw equal rows.
+    # Samples sharded: every rank needs its OWN rows - its generator is re-seeded by rank once the model is built.
+    draws = comm.world if (comm is not None and fused.hp) else 1
+    if comm is not None and not fused.hp:
+        torch.manual_seed(torch.initial_seed() * 1000003 + 7919 * comm.rank + 1)
     all_eigvals, all_norms = [], []
     start = time.time()
     # the reference adds loss.item() to a host total on EVERY step (operator/__init__.py:74,99: a device sync per
@@ -202,9 +243,13 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     n_loss = 0
     loss_stride = 1 if getattr(args, "loss_every_step", False) else max(1, int(args.print_freq) // 16)
     for it in range(args.num_iters):
-        x = make_batch_ftn_train().to(device)
+        x = make_batch_ftn_train() if draws == 1 else torch.cat([make_batch_ftn_train() for _ in range(draws)])
+        x = x.to(device)
         x = x.reshape(x.shape[0], -1)
         if fused is not None and it == 0 and x.shape[0] != fused.B:
+            if comm is not None:
+                raise ValueError(f"the sampler returns {x.shape[0] // draws} rows, args.batch_size says "
+                                 f"{args.batch_size}: several ranks need them equal")
             fused = None  # the sampler does not produce args.batch_size rows: the plain loop takes any batch
         if fused is not None:
             fused.step(x.float().contiguous())
@@ -227,8 +272,9 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
             # the only host sync, and only at print time (the reference syncs every step)
             row = {"iter": it + 1, "train_loss": float(loss), "avg_train_loss": float(total_loss) / n_loss,
                    "time": time.time() - start}
-            print(row)
-            if log_writer is not None:
+            if rank0:
+                print(row)
+            if log_writer is not None and rank0:
                 log_writer.writerow(row)
                 log_file.flush()
         if (it + 1) % args.eval_freq == 0:
@@ -240,11 +286,12 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                     outputs = compute_spectrum_evd(method, dataloader=batch_ftn_val(), operator=operator,
                                                    importance_train=importance_train, importance_val=importance_val,
                                                    normalize=True, set_first_mode_const=False, device=device)
-                    print(f"it{it + 1} eigvals: {outputs['eigvals']}")
-                    print(f"it{it + 1} norms: {outputs['norms']}")
+                    if rank0:
+                        print(f"it{it + 1} eigvals: {outputs['eigvals']}")
+                        print(f"it{it + 1} norms: {outputs['norms']}")
                     all_eigvals.append(outputs["eigvals"])
                     all_norms.append(outputs["norms"])
-            if getattr(args, "log_dir", None):
+            if getattr(args, "log_dir", None) and rank0:
                 os.makedirs(args.log_dir, exist_ok=True)
                 torch.save(dict(args=args, method=method.state_dict(), ema=ema.state_dict(),
                                 optimizer=optimizer.state_dict()), os.path.join(args.log_dir, f"{it + 1}.pth"))

@@ -52,6 +52,35 @@ def ko_case(dev, world):
     return op, kw, batches
 
 
+def dropin_case(world_rows, dev):
+    """the reference-style objects of a small oscillator problem on the MFMA kernels (128-wide layers), built through
+    this package's mirrors of the reference API exactly as main_pde.py builds them; batch_size = world_rows"""
+    import argparse
+    from tests import _golden as G
+    from neural_svd_amd.models import get_wavefunctions
+    from neural_svd_amd.nested_lowrank import get_evd_method
+    from neural_svd_amd.operators import get_dataloader, get_problem
+    cfg = dict(G.cfg_of(G.load("model_small"), "osc_small"), mlp_hidden_dims="128,128,128", fourier_mapping_size=64,
+               neigs=4, batch_size=world_rows, num_iters=4, lr=1e-3)
+    a = argparse.Namespace(**{k: v for k, v in cfg.items() if k not in ("sequential", "step")})
+    a.loss = argparse.Namespace(name="neuralsvd",
+                                neuralsvd=argparse.Namespace(step=cfg["step"], sequential=cfg["sequential"]))
+    a.adam_eps, a.use_lr_scheduler, a.ema_decay, a.log_dir = 1e-7, True, 0.995, None
+    a.print_freq, a.eval_freq = 10 ** 9, cfg["num_iters"]
+    torch.manual_seed(cfg["seed"])
+    operator, _ = get_problem(a, dev)
+    model = get_wavefunctions(a)
+    loaders = get_dataloader(a, dev)
+    method = get_evd_method(a, "neuralsvd", model).to(dev)
+    return a, operator, method, loaders
+
+
+def dropin_blocks():
+    """32-row blocks of coordinates, the same in every process: a step of `world` ranks consumes `world` of them"""
+    g = torch.Generator().manual_seed(31)
+    return [4.0 * torch.randn(32, 2, generator=g) for _ in range(16)]
+
+
 def main():
     mode, out_dir = sys.argv[1], sys.argv[2]
     if mode.endswith("_big"):  # batches beyond 1024 rows: the backward takes partial moment sums instead of f itself
@@ -118,6 +147,23 @@ def main():
                 res["f0"], res["Kf0"] = fk.f.clone().cpu(), fk.Kf.clone().cpu()
         res.update(views=[v.cpu() for v in fk.P.views(fk.P.flat)], sq=[v.cpu() for v in fk.P.views(fk.P.sq)],
                    l_off=fk.l_off, t=fk.t)
+    elif mode in ("dropin_hp", "dropin_dp"):
+        # the reference-signature training loop (drop_in.train_operator) started on several ranks by a launcher: it
+        # finds RANK / WORLD_SIZE itself, shards heads (or samples) and leaves the WHOLE model in `method` on every rank
+        import neural_svd_amd.drop_in as DI
+        comm.close()  # train_operator makes its own communicator from the environment
+        os.environ["NSVD_DIST_BACKEND"] = "gloo"
+        args, operator, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = dropin_case(32, dev)
+        args.parallelism = mode[-2:]
+        blocks = iter(dropin_blocks())
+        if mode == "dropin_dp":  # every rank its own rows: rank r takes block world * step + r
+            allb = dropin_blocks()
+            blocks = iter(allb[rank::world])
+        eig, norms = DI.train_operator(args, method, operator, lambda: next(blocks), val_data, batch_ftn_val, None, None,
+                                       dev, imp_train, imp_val)
+        res.update(sd={k: v.detach().cpu() for k, v in method.state_dict().items()}, eig=eig[-1], norms=norms[-1])
+        torch.save(res, os.path.join(out_dir, f"{sys.argv[1]}_r{rank}.pt"))
+        return
     elif mode == "rccl1":
         # ONE rank on the real collective library (backend "nccl" = RCCL): the exchange sequences forced on in a world
         # of one, so that every RCCL call of the product path - argument views, in-place gathers, AVG, async work

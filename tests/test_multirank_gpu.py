@@ -258,3 +258,38 @@ def test_kernel_operator_step_with_heads_sharded_matches_single_process(tmp_path
         for got, want, s_got, s_want in zip(r["views"], views, r["sq"], sq):
             sl = slice(rank * Ll, (rank + 1) * Ll)
             assert rel(got, want[sl]) < 1e-5 and rel(s_got, s_want[sl]) < 1e-4
+
+
+@pytest.mark.timeout(900)
+def test_reference_style_loop_on_two_ranks(tmp_path):
+    """drop_in.train_operator - the reference's train_operator signature - started on two ranks by a launcher (RANK /
+    WORLD_SIZE in the environment, nothing else changed): heads sharded, every rank steps on the global batch of
+    2 x batch_size rows (the sampler called twice per step) and ends with the WHOLE model in `method`, equal on both
+    ranks and equal to one process training on 64-row batches made of the same blocks. Samples sharded
+    (args.parallelism = "dp"): replicas identical, finite, and moved."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _multirank_worker as W
+    import neural_svd_amd.drop_in as DI
+    hp = run_ranks("dropin_hp", 2, tmp_path)
+    dev = torch.device("cuda:0")
+    args, operator, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = W.dropin_case(64, dev)
+    init = {k: v.detach().cpu().clone() for k, v in method.state_dict().items()}
+    blocks = iter(W.dropin_blocks())
+    eig, _ = DI.train_operator(args, method, operator, lambda: torch.cat([next(blocks), next(blocks)]), val_data,
+                               batch_ftn_val, None, None, dev, imp_train, imp_val)
+    ref = {k: v.detach().cpu() for k, v in method.state_dict().items()}
+    moved = 0.0
+    for k in ref:
+        assert torch.equal(hp[0]["sd"][k], hp[1]["sd"][k]), k
+        d = float((hp[0]["sd"][k].double() - ref[k].double()).norm())
+        step = float((ref[k].double() - init[k].double()).norm())
+        moved += step
+        assert d <= 2e-2 * step + 1e-6 * float(ref[k].double().norm()), (k, d, step)
+    assert moved > 0
+    assert np.allclose(hp[0]["eig"], eig[-1], rtol=2e-2) and np.allclose(hp[0]["eig"], hp[1]["eig"])
+    dp = run_ranks("dropin_dp", 2, tmp_path)
+    for k in ref:
+        assert torch.equal(dp[0]["sd"][k], dp[1]["sd"][k]), k
+        assert bool(torch.isfinite(dp[0]["sd"][k]).all())
+    assert any(not torch.equal(dp[0]["sd"][k], init[k]) for k in ref)
