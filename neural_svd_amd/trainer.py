@@ -415,6 +415,22 @@ class FusedTrainer:
                 self.comm.all_gather_flat(buf[lo:hi], buf[slo:shi])
         self._state_sharded = False
 
+    def state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
+        """The WHOLE model in the reference's state_dict layout (keys model.base.ws.{i}, ...), on every rank: with
+        heads sharded each rank's (L / world, ...) slices are gathered; with a sharded optimiser (dp rs_ag / a2a) the EMA
+        shadow is made whole first. ema=True: the EMA weights (what the reference evaluates and checkpoints)."""
+        if ema:
+            self.gather_optimizer_state()
+        sd = self.P.state_dict(ema)
+        if not self.hp:
+            return sd
+        for n in self.P.names:
+            v = sd[n].contiguous()
+            out = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+            self.comm.all_gather(out, v)
+            sd[n] = out.view((self.world * v.shape[0],) + tuple(v.shape[1:]))
+        return sd
+
     def begin_apply(self) -> None:
         self._lr_now, self._decay_now = self._advance_schedule()
 

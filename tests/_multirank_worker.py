@@ -115,7 +115,9 @@ def main():
                 res["mom0"] = tr.moments.clone().cpu()
         tr.gather_optimizer_state()
         res.update(flat=tr.P.flat.cpu(), ema=tr.P.ema.cpu(), sq=tr.P.sq.cpu(), t=tr.t, l_off=tr.l_off,
-                   buckets=tr.grad_buckets(), fused_step=tr.fused_step)
+                   buckets=tr.grad_buckets(), fused_step=tr.fused_step,
+                   sd={k: v.cpu() for k, v in tr.state_dict().items()},
+                   sd_ema={k: v.cpu() for k, v in tr.state_dict(ema=True).items()})
     elif mode in ("dp_overlap", "hp_overlap"):
         # internal device sampler: the batch prepared under the collective vs the plain ordering, bit for bit;
         # seed=None: every rank draws different initial weights, rank 0's must win

@@ -156,6 +156,16 @@ def test_hp_ranks_match_single_process(tmp_path, world, big):
     import _multirank_worker as W
     L = W.CASE["L"]
     Ll = L // world
+    # FusedTrainer.state_dict(): the WHOLE model in the reference's layout, the same on every rank
+    for k in rs[0]["sd"]:
+        assert all(torch.equal(r["sd"][k], rs[0]["sd"][k]) and torch.equal(r["sd_ema"][k], rs[0]["sd_ema"][k])
+                   for r in rs), k
+        if k.endswith("_B"):
+            continue
+        assert rs[0]["sd"][k].shape[0] == L
+        for rank, r in enumerate(rs):
+            i = [n for n in rs[0]["sd"] if not n.endswith("_B")].index(k)
+            assert torch.equal(rs[0]["sd"][k][rank * Ll:(rank + 1) * Ll], _views(r["flat"], Ll)[i]), k
     for rank, r in enumerate(rs):
         assert r["t"] == 3 and r["fused_step"] and r["l_off"] == rank * Ll
         assert rel(r["loss0"], ref["loss0"]) < 2e-6 and rel(r["mom0"], ref["mom0"]) < 2e-6
