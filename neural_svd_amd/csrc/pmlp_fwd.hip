@@ -80,8 +80,11 @@ __device__ __forceinline__ void nsvd_glds16(const float* gsrc, float* lds_base) 
 // BF3 = 1: layer 0 on the bf16 MFMA with three-way split operands (nsvd_layer0_bf3 above); everything after layer 0 is
 //   the same code. Its stage buffers are larger, so the W tile of the hidden layers aliases their tail (one extra
 //   barrier after the K loop).
-template <int E, int JET, int BF3 = 0>
+// PL = 1: plain model evaluation (nsvd_model_forward): the E column tiles of a workgroup are E consecutive 32-sample
+// tiles of the batch (no stencil, no jets), so that a head's weight tiles are fetched once per 32 E samples
+template <int E, int JET, int BF3 = 0, int PL = 0>
 __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
+    static_assert(!PL || (!JET && !BF3 && E <= 4), "plain tiles: native fp32 layer 0, at most four sample tiles");
     constexpr int NC = E * BS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][128][A_LD]   W_0 tile, k contiguous
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    const int nsb = a.B / BS;
+    const int nsb = a.B / (PL ? NC : BS);
     int l, sb, grp = 0, bid = blockIdx.x;
     if (E == 3 && !JET && !BF3 && a.split) {  // split-stencil form: which direction's points this workgroup evaluates
         grp = bid / (nsb * a.L);
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // (the map divides by run-time values: computed on the vector ALU although uniform - pin the results to scalar
     // registers so that every address derived from them is scalar too)
     l = __builtin_amdgcn_readfirstlane(l);
-    const int b0 = __builtin_amdgcn_readfirstlane(sb * BS);
+    const int b0 = __builtin_amdgcn_readfirstlane(sb * (PL ? NC : BS));
     grp = __builtin_amdgcn_readfirstlane(grp);
 
     NSVD_STAMP(0)
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     //   sin(t +- d) = sin t cos d +- cos t sin d,  cos(t +- d) = cos t cos d -+ sin t sin d,   d = eps B_dj,
     // with the same float32 expressions the feature kernel used to evaluate: phi(x +- eps e_d) is never stored.
     // (5x less feature traffic per tile; the feature kernel writes B x F instead of E x B x F.)
-    constexpr int DD = JET ? E - 2 : (E - 1) / 2;  // input dimensions
+    constexpr int DD = PL ? 0 : (JET ? E - 2 : (E - 1) / 2);  // input dimensions
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     float4 ra0, ra1, ra2, ra3, rs, rc, cd0, sd0, cd1, sd1, cd2, sd2;
     ra0 = ra1 = ra2 = ra3 = rs = rc = cd0 = sd0 = cd1 = sd1 = cd2 = sd2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -168,7 +171,13 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         ra1 = NSVD_LDGU(pa_ + a_step, offA);                                     \
         ra2 = NSVD_LDGU(pa_ + 2 * a_step, offA);                                 \
         ra3 = NSVD_LDGU(pa_ + 3 * a_step, offA);                                 \
-        if (!(HALF)) {                                                           \
+        if (PL) {       /* this chunk's features of the E sample tiles (rows 32 e + s_row of the block) */ \
+            const float* pb_ = b_u + ((HALF) ? mm : 0) + kp_;                    \
+            rs = NSVD_LDGU(pb_, offA);                                           \
+            if (E > 1) rc = NSVD_LDGU(pb_ + a_step, offA);                       \
+            if (E > 2) cd0 = NSVD_LDGU(pb_ + 2 * a_step, offA);                  \
+            if (E > 3) sd0 = NSVD_LDGU(pb_ + 3 * a_step, offA);                  \
+        } else if (!(HALF)) {                                                    \
             rs = NSVD_LDGU(b_u + kp_, offA);                                     \
             rc = NSVD_LDGU(b_u + mm + kp_, offA);                                \
             if (DD > 0) cd0 = NSVD_LDGU(t_u + kp_, offT);                        \
@@ -204,7 +213,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         NSVD_STS(Ab_ + 64 * A_LD, ra2);                                          \
         NSVD_STS(Ab_ + 96 * A_LD, ra3);                                          \
         float4 gp_, gm_;                                                         \
-        if (JET) {      /* table: cd_d = B_dj, sd0 = |B_j|^2 */                  \
+        if (PL) {                                                                \
+            NSVD_STS(Bb_, rs);                                                   \
+            if (E > 1) NSVD_STS(Bb_ + 32 * A_LD, rc);                            \
+            if (E > 2) NSVD_STS(Bb_ + 64 * A_LD, cd0);                           \
+            if (E > 3) NSVD_STS(Bb_ + 96 * A_LD, sd0);                           \
+        } else if (JET) {      /* table: cd_d = B_dj, sd0 = |B_j|^2 */           \
             if (!(HALF)) {  /* sin: d_d = B_d cos, Lap = -|B|^2 sin */           \
                 NSVD_STS(Bb_, rs);                                               \
                 if (DD > 0) { NSVD_MUL4(gp_, rc, cd0); NSVD_STS(Bb_ + 32 * A_LD, gp_); }   \
@@ -294,7 +308,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         if (DO_LOAD) NSVD_LOAD_CHUNK((c) + 2, (PAR));                                           \
         mma_frag<E>(acc, f1);                                                                   \
         if (DO_STORE) NSVD_INTERLEAVE(1 + E, 0x100);                                            \
-        if (DO_LOAD) NSVD_INTERLEAVE((PAR) ? 4 : 6 + 2 * DD, 0x020);                            \
+        if (DO_LOAD) NSVD_INTERLEAVE(PL ? 4 + E : ((PAR) ? 4 : 6 + 2 * DD), 0x020);             \
         NSVD_FENCE();                                                                           \
     }
     {
@@ -380,6 +394,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             for (int r = 0; r < 16; ++r)
 #pragma unroll
                 for (int e = 1; e < E; ++e) acc[e][r] = nsvd_softplus(acc[e][r]);
+            if (PL && zs) {  // every tile is a tile of samples: all of them are saved
+#pragma unroll
+                for (int e = 1; e < E; ++e)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B + e * BS] = acc[e][r];
+            }
         }
         NSVD_STAMP(3 + 4 * i)
         if (!has_next) {
@@ -411,7 +431,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 *reinterpret_cast<float4*>(hcol + 8 * g) =
                     make_float4(acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]);
         }
-        if (zs) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // DMA done, the 16 stores may still fly
+        // DMA done, the 16 stores may still fly (16 E of them with plain tiles: beyond the 6-bit counter from E = 4)
+        if (zs && !(PL && E > 1)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         NSVD_STAMP(5 + 4 * i)
@@ -460,9 +481,9 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // (the exp / sqrt heavy part, E x 32 threads wide instead of a 5-point loop on 32 threads)
     float* gs = outs;         // [NC]   g_e
     float* cen = red;         // [4][BS] centre: sqrt p, mask, |x|, base   (red is dead once read below)
-    if (E == 1 && a.plain) {
+    if (PL) {
         // model(x) = c * base * exp(-|x| / scales_l)   (reference pde/__init__.py:15-16), any input dimension
-        if (tid < BS) {
+        if (tid < NC) {
             const int b = b0 + tid;
             const float bv = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
             const float c = a.prob.hard_mul_const;
@@ -560,19 +581,19 @@ size_t fwd_lds_bytes() {
     return (RED_OFF + 5 * NC) * sizeof(float);
 }
 
-template <int E, int JET = 0, int BF3 = 0>
+template <int E, int JET = 0, int BF3 = 0, int PL = 0>
 int launch_fwd(const FwdArgs& a, hipStream_t s) {
     const size_t lds = fwd_lds_bytes<E, BF3>();
     static bool attr_done = false;  // idempotent, racing threads set the same value
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)pmlp_fused_fwd_kernel<E, JET, BF3>,
+        hipError_t e = hipFuncSetAttribute((const void*)pmlp_fused_fwd_kernel<E, JET, BF3, PL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    const int grid = (a.B / BS) * a.L * (a.split > 0 ? a.split : 1);
+    const int grid = (a.B / (PL ? E * BS : BS)) * a.L * (a.split > 0 ? a.split : 1);
     nsvd_prof_begin(s);
-    hipLaunchKernelGGL((pmlp_fused_fwd_kernel<E, JET, BF3>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((pmlp_fused_fwd_kernel<E, JET, BF3, PL>), dim3(grid), dim3(256), lds, s, a);
     nsvd_prof_end(s);
     NSVD_CHECK_LAUNCH();
     return 0;
@@ -721,6 +742,13 @@ int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, con
     a.f = out;
     a.jac = save ? w.jac : nullptr;
     a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
+    // four sample tiles per workgroup (a head's W_0 / W_i tiles fetched once per 128 samples, the fixed costs of a
+    // workgroup - first-chunk latency, weight DMA, epilogue - paid once per 128) whenever that still leaves every CU
+    // two workgroups; one tile otherwise
+    if (B % (4 * BS) == 0 && (B / (4 * BS)) * d.L >= 512) {
+        a.xcd_remap = pick_xcd_remap(d.L, B / (4 * BS), F);
+        return launch_fwd<4, 0, 0, 1>(a, s);
+    }
     a.xcd_remap = pick_xcd_remap(d.L, B / BS, F);
-    return launch_fwd<1>(a, s);
+    return launch_fwd<1, 0, 0, 1>(a, s);
 }

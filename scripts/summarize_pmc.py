@@ -15,12 +15,12 @@ tag, name = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-SHORT = [("pmlp_fused_fwd_kernel<5, 0, 0>", "pmlp_fused_fwd"),  # the headline forward (stencil, native fp32 MFMA)
-         ("pmlp_fused_fwd_kernel<5, 0, 1>", "pmlp_fused_fwd_bf16x3"),  # bench.py's side measurement
+SHORT = [("pmlp_fused_fwd_kernel<5, 0, 0", "pmlp_fused_fwd"),  # the headline forward (stencil, native fp32 MFMA)
+         ("pmlp_fused_fwd_kernel<5, 0, 1", "pmlp_fused_fwd_bf16x3"),  # bench.py's side measurement
          ("w0_split", "w0_split_bf16x3"), ("pmlp_fused_wgrad", "pmlp_fused_wgrad"),
          ("pmlp_fused_bwd_chain", "pmlp_fused_bwd_chain"), ("fourier_stencil", "fourier_stencil"),
          ("evd_partial", "evd_partial"), ("rmsprop_ema", "rmsprop_ema"), ("distribution_elementwise", "torch_randn"),
-         ("pmlp_fused_fwd_kernel<1, 0, 0>", "pmlp_fused_fwd_E1"), ("wgrad_reduce", "wgrad_reduce"),
+         ("pmlp_fused_fwd_kernel<1, 0, 0", "pmlp_fused_fwd_E1"), ("pmlp_fused_fwd_kernel<4, 0, 0, 1>", "pmlp_fused_fwd_plain4"), ("wgrad_reduce", "wgrad_reduce"),
          ("tower_gemm_nt", "tower_gemm_nt"), ("tower_bn_forward", "tower_bn_forward"),
          ("tower_bn_backward", "tower_bn_backward"), ("tower_transpose", "tower_transpose"),
          ("tower_sum_slices", "tower_sum_slices"), ("cdk_", "cdk_loss_kernels"), ("ka_gemm", "ka_gemm"),

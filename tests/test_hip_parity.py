@@ -641,11 +641,13 @@ def test_split_stencil_form(D, L, B):
         assert rel(a.view(-1), b.reshape(-1)) < 3e-5, i
 
 
-@pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True)])
+@pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True), (16, 64, 1024, False),
+                                        (5, 32, 2048, True)])
 def test_model_forward_backward_mfma(D, L, B, mask):
-    """Plain model evaluation with 128-wide hidden layers takes the E = 1 instance of the fused MFMA forward (any
-    input dimension up to 64) and the fused backward: c * model(x) and the parameter gradients of sum(dout * out)
-    against the float64 oracle."""
+    """Plain model evaluation with 128-wide hidden layers takes the plain-tile instances of the fused MFMA forward (any
+    input dimension up to 64; one 32-sample tile per workgroup, or - the last two cases: at least 512 workgroups of
+    128 samples - four) and the fused backward: c * model(x) and the parameter gradients of sum(dout * out) against the
+    float64 oracle."""
     m, hidden, c = 64, (128, 128), 0.7
     p = O.init_params(L, D, m, hidden, 0.05, exp_mask_init=6.0 if mask else None, seed=D)
     p64 = p.to(torch.float64)
