@@ -345,11 +345,17 @@ typedef struct nsvd_tower_params {
     float *W2, *b2, *g2, *be2, *rm2, *rv2;
 } nsvd_tower_params;
 size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2);
+/*   gemm_bf16 != 0: MIXED PRECISION - the operands of the five contractions are rounded to bfloat16 (round to
+ *   nearest even) and multiplied on the bf16 MFMA with float32 accumulation; BatchNorm, activation, gradients,
+ *   statistics and every stored tensor stay float32. The role of the reference's autocast branch
+ *   (examples/cdk/sketchy/main_sketchy.py:161,182, on by default there) without its float16 / GradScaler dynamics:
+ *   not bit-comparable with it, pinned to the float64 oracle of the same rounding instead. */
 int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, int d0, int d1, int d2, float slope,
-                       float eps, float momentum, int update_running, float* z, void* ws, size_t ws_bytes,
-                       void* stream);
+                       float eps, float momentum, int update_running, int gemm_bf16, float* z, void* ws,
+                       size_t ws_bytes, void* stream);
 int nsvd_tower_backward(const float* x, const nsvd_tower_params* params, const float* dz, int B, int d0, int d1,
-                        int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes, void* stream);
+                        int d2, float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* nsvd_operator_backward_evd_step that ALSO draws the next batch and writes its Fourier features - what
  * nsvd_operator_sample_features(next_seed, next_offset, x_next, ws_next) does as a launch of its own - as guest
@@ -409,6 +415,7 @@ typedef struct nsvd_cdk_step_desc {
     int32_t set_first_mode_const;
     double lr, momentum, max_grad_norm;
     int32_t first_step;
+    int32_t gemm_bf16;            /* != 0: the towers' contractions in mixed precision (nsvd_tower_forward) */
 } nsvd_cdk_step_desc;
 size_t nsvd_cdk_step_workspace_bytes(const nsvd_cdk_step_desc* desc);
 int nsvd_cdk_step(const nsvd_cdk_step_desc* desc, const float* x, const float* y, const nsvd_tower_params* towers,

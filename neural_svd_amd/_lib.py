@@ -50,7 +50,7 @@ class CdkStepDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("slope", C.c_float),
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("mu", C.c_float), ("normalize_mode", C.c_int32),
                 ("set_first_mode_const", C.c_int32), ("lr", C.c_double), ("momentum", C.c_double),
-                ("max_grad_norm", C.c_double), ("first_step", C.c_int32)]
+                ("max_grad_norm", C.c_double), ("first_step", C.c_int32), ("gemm_bf16", C.c_int32)]
 
 
 class Rmsprop(C.Structure):
@@ -108,12 +108,12 @@ SIGNATURES = {
     "nsvd_row_normalize_forward": (_I, [_P, _I, _I, _F, _I, _P, _P]),
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
     "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),
-    "nsvd_tower_forward": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _P, _P, _Z, _P]),
+    "nsvd_tower_forward": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _P, _P, _Z, _P]),
     "nsvd_cdk_step_workspace_bytes": (_Z, [C.POINTER(CdkStepDesc)]),
     "nsvd_cdk_step": (_I, [C.POINTER(CdkStepDesc), _P, _P, C.POINTER(TowerParams), C.POINTER(TowerParams), _P, _P, _P,
                            _P, _P, _P, _Z, _P]),
-    "nsvd_tower_backward": (_I, [_P, C.POINTER(TowerParams), _P, _I, _I, _I, _I, _F, C.POINTER(TowerParams), _P, _Z,
-                                 _P]),
+    "nsvd_tower_backward": (_I, [_P, C.POINTER(TowerParams), _P, _I, _I, _I, _I, _F, _I, C.POINTER(TowerParams), _P,
+                                 _Z, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

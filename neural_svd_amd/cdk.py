@@ -309,7 +309,7 @@ def get_mlp(sizes, bias=True, nonlinearity="relu", use_bn=True, weight_normaliza
 # ------------------------------------------------------------------------------ the fused training step
 class FusedCdkStep:
     """The loop body of the Sketchy script (examples/cdk/sketchy/main_sketchy.py:180-212 with scripts/exps/sketchy.sh's
-    switches: sgd with momentum, --clip_grad_norm, --use_lr_scheduler; AMP off - this library computes in float32) as
+    switches: sgd with momentum, --clip_grad_norm, --use_lr_scheduler; ``use_amp`` below) as
     ONE C call per step, ``nsvd_cdk_step``: both towers forward and backward, normalisation, the NestedLoRAForCDK loss,
     the global gradient-norm clip and the SGD momentum update, on the modules' OWN parameter tensors (updated in place:
     ``method.model`` is always current, its BatchNorm running statistics included). Takes the place of
@@ -318,10 +318,18 @@ class FusedCdkStep:
         nn.utils.clip_grad_norm_(model.parameters(), max_norm); optimizer.step(); lr_scheduler.step()
 
     for a model that is HeteroNetwork(two TowerSequential towers, Identity projectors, 'l2_ball' / 'l2_sphere') on a
-    batch the tower kernels take; ``supported(method, batch_size)`` says whether it is."""
+    batch the tower kernels take; ``supported(method, batch_size)`` says whether it is.
+
+    use_amp: the script runs its step under ``torch.cuda.amp.autocast`` + ``GradScaler`` unless ``--disable_amp``
+    (main_sketchy.py:161,182). True selects this library's MIXED-PRECISION mode, the counterpart of that branch: the ten
+    tower contractions of a step multiply bfloat16-rounded operands on the bf16 MFMA with float32 accumulation;
+    BatchNorm, activations, loss, gradients, clipping and the update stay float32, so there is no loss scaling and no
+    skipped step. It is NOT bit-comparable with float16 autocast (different 16-bit format, different set of
+    reduced-precision ops); it is pinned to the float64 oracle with the same operand rounding. False (default): float32
+    throughout - the script's --disable_amp."""
 
     def __init__(self, method: "NestedLoRAForCDK", lr: float, momentum: float = 0.9, max_grad_norm: float = 1.0,
-                 t_max: int = 0, batch_size: int = 1024):
+                 t_max: int = 0, batch_size: int = 1024, use_amp: bool = False):
         ok, why = self.supported(method, batch_size)
         if not ok:
             raise H.NsvdError(f"FusedCdkStep: {why}")
@@ -330,6 +338,7 @@ class FusedCdkStep:
         self.lr0, self.momentum, self.max_grad_norm, self.t_max = float(lr), float(momentum), float(max_grad_norm or 0.0), int(t_max)
         self.t = 0
         self._pending = 0
+        self.use_amp = bool(use_amp)
         tx = model.backbones["x"]
         self.B, self.d0, self.d1, self.d2 = int(batch_size), tx[0].in_features, tx[0].out_features, tx[3].out_features
         dev = tx[0].weight.device
@@ -376,7 +385,8 @@ class FusedCdkStep:
 
     def _desc(self, lr, first):
         return H.cdk_step_desc(self.B, self.d0, self.d1, self.d2, self.slope, self.bn_eps, self.bn_momentum,
-                               self.model.mu, self.mode, self.first_const, lr, self.momentum, self.max_grad_norm, first)
+                               self.model.mu, self.mode, self.first_const, lr, self.momentum, self.max_grad_norm, first,
+                               gemm_bf16=self.use_amp)
 
     def current_lr(self) -> float:
         """CosineAnnealingLR(optimizer, t_max) after self.t scheduler steps (t_max = 0: constant)"""

@@ -190,7 +190,7 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     // forward: towers (BatchNorm running statistics updated, as a training-mode module does), normalisation
     for (int t = 0; t < 2; ++t) {
         rc = nsvd_tower_forward(in[t], &towers[t], B, d->d0, d->d1, d->d2, d->slope, d->bn_eps, d->bn_momentum, 1,
-                                w.z[t], w.tower[t], w.tower_bytes, stream);
+                                d->gemm_bf16, w.z[t], w.tower[t], w.tower_bytes, stream);
         if (rc) return rc;
         rc = nsvd_row_normalize_forward(w.z[t], B, L, r_up, d->normalize_mode, w.e[t], stream);
         if (rc) return rc;
@@ -213,8 +213,8 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
         float* gp[NT];
         for (int k = 0; k < NT; ++k) gp[k] = w.grad[t] + w.goff[k];
         g.W1 = gp[0]; g.b1 = gp[1]; g.g1 = gp[2]; g.be1 = gp[3]; g.W2 = gp[4]; g.b2 = gp[5]; g.g2 = gp[6]; g.be2 = gp[7];
-        rc = nsvd_tower_backward_sumsq(in[t], &towers[t], w.dz[t], B, d->d0, d->d1, d->d2, d->slope, &g, w.tower[t],
-                                       w.tower_bytes,
+        rc = nsvd_tower_backward_sumsq(in[t], &towers[t], w.dz[t], B, d->d0, d->d1, d->d2, d->slope, d->gemm_bf16, &g,
+                                       w.tower[t], w.tower_bytes,
                                        w.partial + SUMSQ_BLOCKS + t * nsvd_tower_sumsq_count(d->d0, d->d1, d->d2),
                                        stream);
         if (rc) return rc;

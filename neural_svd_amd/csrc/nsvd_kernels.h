@@ -101,5 +101,5 @@ int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size
 // (cdk_step.hip clips the global gradient norm without another pass over them)
 int nsvd_tower_sumsq_count(int d0, int d1, int d2);
 int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1,
-                              int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes,
-                              float* sumsq, void* stream);
+                              int d2, float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws,
+                              size_t ws_bytes, float* sumsq, void* stream);

@@ -56,7 +56,13 @@ __device__ __forceinline__ void t128d_dma(const float* sbase, unsigned voff, uns
 
 // NJ = 2: the 128 x 128 tile; NJ = 1: 128 rows of A x 64 rows of B (wave (wm, wn): rows 64 wm of A x rows 32 wn of B,
 // acc[i][0] = its block (32 i, 0)) - twice the tiles for outputs that would otherwise leave half the CUs without one
-template <class Hook, int NJ>
+// BF = true: the operands are bfloat16 (the pointers, leading dimensions and chunk counts stay in FLOAT units: a row
+// of K bf16 values is K / 2 floats, a chunk 64 of them). The bytes move exactly as for float32 - same DMA, same
+// swizzle, same 16-byte fragment reads - and a fragment (8 bf16 per lane, lanes 0-31 / 32-63 the two halves of 16
+// contraction indices) feeds ONE v_mfma_f32_32x32x16_bf16 where four float32 fragments' components fed four
+// v_mfma_f32_32x32x2_f32: the loop turns from MFMA-bound into staging-bound (mixed-precision tower GEMMs, tower.hip).
+typedef __bf16 nsvd_bf16x8 __attribute__((ext_vector_type(8)));
+template <class Hook, int NJ, bool BF = false>
 __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const float* b_base, unsigned a_ld, unsigned b_ld,
                                                  int nch, float* lds, f32x16 (&acc)[2][NJ], Hook& hook) {
     static_assert(NJ == 1 || NJ == 2, "B operand: 64 or 128 rows");
@@ -91,11 +97,24 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
     }
 #define TD_RD(p, s) (*reinterpret_cast<const float4*>((p) + (s) * 16384))
 #define TD_RDB1(p, s) (NJ == 2 ? TD_RD((p) + 2048, s) : make_float4(0.f, 0.f, 0.f, 0.f))
+#define TD_BFR(v) __builtin_bit_cast(nsvd_bf16x8, v)
+#define TD_FIRST_x 1
+#define TD_FIRST_y 0
+#define TD_FIRST_z 0
+#define TD_FIRST_w 0
+// float32: component X of the four fragments; bfloat16: the whole fragments, once (at X = x)
 #define TD_MMA4(f, X)                                                                                   \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0][0], 0, 0, 0);              \
-    if (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[0][NJ - 1], 0, 0, 0); \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[1][0], 0, 0, 0);              \
-    if (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[1][NJ - 1], 0, 0, 0);
+    if (!BF) {                                                                                          \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b0.X, acc[0][0], 0, 0, 0);          \
+        if (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.X, f.b1.X, acc[0][NJ - 1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b0.X, acc[1][0], 0, 0, 0);          \
+        if (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.X, f.b1.X, acc[1][NJ - 1], 0, 0, 0); \
+    } else if (TD_FIRST_##X) {                                                                          \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TD_BFR(f.a0), TD_BFR(f.b0), acc[0][0], 0, 0, 0); \
+        if (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TD_BFR(f.a0), TD_BFR(f.b1), acc[0][NJ - 1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TD_BFR(f.a1), TD_BFR(f.b0), acc[1][0], 0, 0, 0); \
+        if (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TD_BFR(f.a1), TD_BFR(f.b1), acc[1][NJ - 1], 0, 0, 0); \
+    }
 #define TD_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define TD_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
 #define TD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -187,17 +206,22 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
 #undef TD_RD
 #undef TD_RDB1
 #undef TD_MMA4
+#undef TD_BFR
+#undef TD_FIRST_x
+#undef TD_FIRST_y
+#undef TD_FIRST_z
+#undef TD_FIRST_w
 #undef TD_FENCE
 #undef TD_WAIT_BARRIER
 #undef TD_BARRIER
     return true;
 }
 
-template <int NJ>
+template <int NJ, bool BF = false>
 __device__ __forceinline__ void nsvd_tile128_dma(const float* a_base, const float* b_base, unsigned a_ld, unsigned b_ld,
                                                  int nch, float* lds, f32x16 (&acc)[2][NJ]) {
     Tile128NoHook none;
-    nsvd_tile128_dma<Tile128NoHook, NJ>(a_base, b_base, a_ld, b_ld, nch, lds, acc, none);
+    nsvd_tile128_dma<Tile128NoHook, NJ, BF>(a_base, b_base, a_ld, b_ld, nch, lds, acc, none);
 }
 
 }  // namespace nsvd_pmlp

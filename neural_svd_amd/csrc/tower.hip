@@ -39,6 +39,9 @@ struct GemmNT {
     int M, N, K, S;   // S split-K slices of K / S columns each
 };
 
+// BF: A and B hold bfloat16 values (K of them per row; lda / ldb in bf16 elements): the mixed-precision mode of the
+// towers - operands rounded to bfloat16, float32 accumulation, C float32 as ever
+template <bool BF>
 __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) float smem[T128D_LDS_FLOATS];  // 64 KB: two blocks per CU
     const int tid = threadIdx.x;
@@ -51,7 +54,8 @@ __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
     bid -= slice * tm * tn;
     // tiles that share their A rows (same tile row) are neighbours in block order: blocks b, b + 8, .. share an XCD
     const int trow = bid / tn, tcol = bid - trow * tn;
-    const int Ks = g.K / g.S;
+    constexpr int EL = BF ? 2 : 1;  // operand elements per float
+    const int Ks = g.K / g.S / EL;  // floats per row and slice
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -59,9 +63,9 @@ __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float* a_base = g.A + (size_t)128 * trow * g.lda + (size_t)slice * Ks;
-    const float* b_base = g.B + (size_t)128 * tcol * g.ldb + (size_t)slice * Ks;
-    nsvd_tile128_dma(a_base, b_base, (unsigned)g.lda, (unsigned)g.ldb, Ks / BK, smem, acc);
+    const float* a_base = g.A + (size_t)128 * trow * (g.lda / EL) + (size_t)slice * Ks;
+    const float* b_base = g.B + (size_t)128 * tcol * (g.ldb / EL) + (size_t)slice * Ks;
+    nsvd_tile128_dma<2, BF>(a_base, b_base, (unsigned)(g.lda / EL), (unsigned)(g.ldb / EL), Ks / BK, smem, acc);
     float* C = g.C + (size_t)slice * g.slice_stride + ((size_t)128 * trow + 64 * wm) * g.ldc + 128 * tcol + 64 * wn + li;
     float ss = 0.f;
 #pragma unroll
@@ -87,7 +91,18 @@ __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
 
 // ---------------------------------------------------------------------------------------------- transposes
 // out (C, R) = in (R, C)^T, 32 x 32 tiles through LDS
-__global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+// float32 -> bfloat16, round to nearest even (v_cvt_pk_bf16_f32)
+typedef __bf16 nsvd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float nsvd_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((nsvd_f32x2){a, b}, nsvd_bf16x2));
+}
+__device__ __forceinline__ uint2 bf16_pack4(const float4& v) { return make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w)); }
+__device__ __forceinline__ unsigned short bf16_one(float a) { return (unsigned short)(bf16_pack2(a, 0.f) & 0xffffu); }
+
+// BF: the transposed copy is written as bfloat16 (an operand of a mixed-precision contraction)
+template <bool BF>
+__global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __restrict__ in, void* __restrict__ outv,
                                                               int R, int Cc) {
     __shared__ float t[32][33];
     const int tiles_c = Cc / 32;
@@ -97,7 +112,11 @@ __global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __res
     for (int k = 0; k < 4; ++k) t[y + 8 * k][x] = in[(size_t)(32 * tr + y + 8 * k) * Cc + 32 * tc + x];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[(size_t)(32 * tc + y + 8 * k) * R + 32 * tr + x] = t[x][y + 8 * k];
+    for (int k = 0; k < 4; ++k) {
+        const size_t o = (size_t)(32 * tc + y + 8 * k) * R + 32 * tr + x;
+        if (BF) reinterpret_cast<unsigned short*>(outv)[o] = bf16_one(t[x][y + 8 * k]);
+        else reinterpret_cast<float*>(outv)[o] = t[x][y + 8 * k];
+    }
 }
 
 // out (B, N) = bias + sum of the S split-K partial outputs, slices added in order (fully coalesced 16-byte accesses: as
@@ -146,6 +165,7 @@ struct BnFwd {
     float* outT;          // (N, B) transposed copy or null
     int B, N;
     float eps, momentum, slope;
+    int bf16_out;         // out / outT hold bfloat16 values (operands of mixed-precision contractions)
 };
 
 constexpr int BN_MAXR = 16;  // rows per thread: B / RG with B <= 1024 and RG >= 64
@@ -175,7 +195,7 @@ __device__ __forceinline__ void strip_reduce(float* red, const float4& part, flo
 // thread t then owns column t / (RG / 4) and rows 4 (t % (RG / 4)).. of the batch: one 16-byte store
 template <int STRIP, int NT>
 __device__ __forceinline__ void strip_transpose_out(float* tile, const float4& v, float* outT, int n0, int B, int k,
-                                                    int tid) {
+                                                    int tid, bool bf16 = false) {
     constexpr int CG = StripGeom<STRIP, NT>::CG, RG = StripGeom<STRIP, NT>::RG, LD = STRIP + 1;
     const int c0 = 4 * (tid % CG), rg = tid / CG;
     __syncthreads();  // the previous batch has been read out
@@ -185,7 +205,9 @@ __device__ __forceinline__ void strip_transpose_out(float* tile, const float4& v
     const int col = tid / (RG / 4), r4 = 4 * (tid % (RG / 4));
     const float4 o = make_float4(tile[r4 * LD + col], tile[(r4 + 1) * LD + col], tile[(r4 + 2) * LD + col],
                                  tile[(r4 + 3) * LD + col]);
-    *reinterpret_cast<float4*>(outT + (size_t)(n0 + col) * B + (size_t)RG * k + r4) = o;
+    const size_t off = (size_t)(n0 + col) * B + (size_t)RG * k + r4;
+    if (bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(outT) + off) = bf16_pack4(o);
+    else *reinterpret_cast<float4*>(outT + off) = o;
 }
 
 template <int STRIP, int NT>
@@ -263,7 +285,9 @@ __global__ void __launch_bounds__(NT) tower_bn_forward_kernel(BnFwd a) {
             o.z = fmaf((v[k].z - mu.z) * inv.z, ga.z, be.z); o.w = fmaf((v[k].w - mu.w) * inv.w, ga.w, be.w);
             o.x = o.x > 0.f ? o.x : a.slope * o.x; o.y = o.y > 0.f ? o.y : a.slope * o.y;
             o.z = o.z > 0.f ? o.z : a.slope * o.z; o.w = o.w > 0.f ? o.w : a.slope * o.w;
-            *reinterpret_cast<float4*>(a.out + (size_t)(rg + RG * k) * a.N + n0 + c0) = o;
+            const size_t off = (size_t)(rg + RG * k) * a.N + n0 + c0;
+            if (a.bf16_out) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out) + off) = bf16_pack4(o);
+            else *reinterpret_cast<float4*>(a.out + off) = o;
             v[k] = o;
         }
     }
@@ -273,7 +297,7 @@ __global__ void __launch_bounds__(NT) tower_bn_forward_kernel(BnFwd a) {
 #pragma unroll
             for (int j = 1; j < BN_MAXR; ++j)
                 if (j == k) o = v[j];  // (a run-time index into the register array would put it in scratch)
-            strip_transpose_out<STRIP, NT>(tile, o, a.outT, n0, a.B, k, tid);
+            strip_transpose_out<STRIP, NT>(tile, o, a.outT, n0, a.B, k, tid, a.bf16_out != 0);
         }
     }
 }
@@ -292,6 +316,7 @@ struct BnBwd {
     float* dbias;         // (N): column sums of dY (the Linear bias in front of the BatchNorm), or null
     int B, N;
     float slope;
+    int bf16_out;         // dY / dYT hold bfloat16 values (operands of mixed-precision contractions)
 };
 
 template <int STRIP, int NT>
@@ -356,7 +381,11 @@ __global__ void __launch_bounds__(NT) tower_bn_backward_kernel(BnBwd a) {
             dy.w = ga.w * inv.w * (dh[k].w - m1.w - yh[k].w * m2.w);
             dh[k] = dy;
             sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
-            if (a.dY) *reinterpret_cast<float4*>(a.dY + (size_t)(rg + RG * k) * a.N + n0 + c0) = dy;
+            if (a.dY) {
+                const size_t off = (size_t)(rg + RG * k) * a.N + n0 + c0;
+                if (a.bf16_out) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dY) + off) = bf16_pack4(dy);
+                else *reinterpret_cast<float4*>(a.dY + off) = dy;
+            }
         }
     }
     strip_reduce<STRIP, NT>(red, sb, c3, tid);
@@ -367,7 +396,7 @@ __global__ void __launch_bounds__(NT) tower_bn_backward_kernel(BnBwd a) {
 #pragma unroll
             for (int j = 1; j < BN_MAXR; ++j)
                 if (j == k) o = dh[j];
-            strip_transpose_out<STRIP, NT>(tile, o, a.dYT, n0, a.B, k, tid);
+            strip_transpose_out<STRIP, NT>(tile, o, a.dYT, n0, a.B, k, tid, a.bf16_out != 0);
         }
     }
 }
@@ -396,24 +425,71 @@ inline int launch_bn_backward(const BnBwd& b, hipStream_t s) {
     return 0;
 }
 
-inline int launch_gemm(const GemmNT& g, hipStream_t s) {
-    if (g.M % 128 || g.N % 128 || g.S < 1 || g.K % (32 * g.S)) return NSVD_EINVAL;
-    hipLaunchKernelGGL(tower_gemm_nt_kernel, dim3((g.M / 128) * (g.N / 128) * g.S), dim3(256), 0, s, g);
+// float32 -> bfloat16 (round to nearest even: v_cvt_pk_bf16_f32), 8 values per thread and pass
+__global__ void __launch_bounds__(256) tower_to_bf16_kernel(const float4* __restrict__ in, uint4* __restrict__ out,
+                                                            size_t n8) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const float4 a = in[2 * i], b = in[2 * i + 1];
+        uint4 o;
+        o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a.x, a.y}, bf2));
+        o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a.z, a.w}, bf2));
+        o.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){b.x, b.y}, bf2));
+        o.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){b.z, b.w}, bf2));
+        out[i] = o;
+    }
+}
+
+// Mixed precision (Mixed::on): the operands are bfloat16. An operand some kernel has already written as bfloat16
+// (BatchNorm strips, transposes) is `ready`; a float32 one (inputs, master weights) is rounded into the scratch copy
+// hA / hB (M K and N K values) by a cast launch first. prof: bracket the contraction for bench.py.
+struct Mixed {
+    bool on = false, a_ready = false, b_ready = false;
+    void *hA = nullptr, *hB = nullptr;
+};
+inline int launch_gemm(const GemmNT& g0, hipStream_t s, const Mixed& mx = Mixed(), bool prof = false) {
+    GemmNT g = g0;
+    if (g.M % 128 || g.N % 128 || g.S < 1 || g.K % ((mx.on ? 64 : 32) * g.S)) return NSVD_EINVAL;
+    const dim3 grid((g.M / 128) * (g.N / 128) * g.S);
+    if (mx.on) {
+        if (g.lda != (size_t)g.K || g.ldb != (size_t)g.K) return NSVD_EINVAL;  // the copies are dense
+        const size_t na = (size_t)g.M * g.K / 8, nb = (size_t)g.N * g.K / 8;
+        if (!mx.a_ready) {
+            hipLaunchKernelGGL(tower_to_bf16_kernel, dim3((unsigned)((na + 255) / 256 > 4096 ? 4096 : (na + 255) / 256)),
+                               dim3(256), 0, s, (const float4*)g.A, (uint4*)mx.hA, na);
+            NSVD_CHECK_LAUNCH();
+            g.A = (const float*)mx.hA;
+        }
+        if (!mx.b_ready) {
+            hipLaunchKernelGGL(tower_to_bf16_kernel, dim3((unsigned)((nb + 255) / 256 > 4096 ? 4096 : (nb + 255) / 256)),
+                               dim3(256), 0, s, (const float4*)g.B, (uint4*)mx.hB, nb);
+            NSVD_CHECK_LAUNCH();
+            g.B = (const float*)mx.hB;
+        }
+    }
+    if (prof) nsvd_prof_begin(s);
+    if (mx.on) hipLaunchKernelGGL(tower_gemm_nt_kernel<true>, grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(tower_gemm_nt_kernel<false>, grid, dim3(256), 0, s, g);
+    if (prof) nsvd_prof_end(s);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
 
 // split-K of the second forward GEMM: as many slices as it takes to give every CU a tile (K / S a multiple of 32)
-inline int fwd2_slices(int B, int d1, int d2) {
+// (bf16 operands: a chunk is 64 values, so slices are at least twice as long - never more slices than float32 takes,
+// which is what the workspace is carved for)
+inline int fwd2_slices(int B, int d1, int d2, bool bf16 = false) {
     const int tiles = (B / 128) * (d2 / 128);
     int S = 1;
-    while (S < 16 && tiles * S < 256 && d1 % (64 * S) == 0) S *= 2;
+    while (S < 16 && tiles * S < 256 && d1 % ((bf16 ? 128 : 64) * S) == 0) S *= 2;
     return S;
 }
 
 struct TowerWs {
     float *Y1, *A1, *A1T, *Y2p, *Y2, *XT, *W2T, *dY2, *dY2T, *dA1, *dY1T;
     float *mean1, *inv1, *mean2, *inv2;
+    void *hA, *hB;  // bfloat16 copies of a contraction's two operands (mixed-precision mode), reused by all five
     size_t bytes;
 };
 
@@ -443,6 +519,11 @@ inline TowerWs carve_tower(int B, int d0, int d1, int d2, void* base) {
     w.inv1 = take(d1);
     w.mean2 = take(d2);
     w.inv2 = take(d2);
+    {   // the largest operand of the five contractions: max(B, d0, d2) rows of d1 values; two bytes per value
+        const size_t mx = (size_t)(B > d0 ? (B > d2 ? B : d2) : (d0 > d2 ? d0 : d2)) * d1;
+        w.hA = take((mx + 1) / 2);
+        w.hB = take((mx + 1) / 2);
+    }
     w.bytes = off;
     return w;
 }
@@ -462,23 +543,25 @@ size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2) {
 }
 
 int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0, int d1, int d2, float slope,
-                       float eps, float momentum, int update_running, float* z, void* ws, size_t ws_bytes,
-                       void* stream) {
+                       float eps, float momentum, int update_running, int gemm_bf16, float* z, void* ws,
+                       size_t ws_bytes, void* stream) {
     if (!x || !p || !z || !ws || !tower_shape_ok(B, d0, d1, d2)) return NSVD_EINVAL;
     if (!p->W1 || !p->b1 || !p->g1 || !p->be1 || !p->W2 || !p->b2 || !p->g2 || !p->be2) return NSVD_EINVAL;
     if (update_running && (!p->rm1 || !p->rv1 || !p->rm2 || !p->rv2)) return NSVD_EINVAL;
     const TowerWs w = carve_tower(B, d0, d1, d2, ws);
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    // mixed precision: the contractions' operands rounded to bfloat16. X and the master weights are cast per call;
+    // the activations are WRITTEN as bfloat16 by the BatchNorm strips (into the float32 buffers' storage: A1, A1^T)
+    Mixed mx;
+    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB;
     int rc = 0;
     // Y1 = X W1^T + b1
     GemmNT g;
     memset(&g, 0, sizeof(g));
     g.A = x; g.lda = d0; g.B = p->W1; g.ldb = d0; g.C = w.Y1; g.ldc = d1; g.bias = p->b1;
     g.M = B; g.N = d1; g.K = d0; g.S = 1;
-    nsvd_prof_begin(s);  // bench.py --config cfg5 brackets this contraction (nsvd_profile_next_forward)
-    rc = launch_gemm(g, s);
-    nsvd_prof_end(s);
+    rc = launch_gemm(g, s, mx, true);  // bench.py --config cfg5 brackets this contraction (nsvd_profile_next_forward)
     if (rc) return rc;
     // A1 = lrelu(BN1(Y1)), A1^T
     BnFwd f;
@@ -486,15 +569,16 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
     f.Y = w.Y1; f.S = 1; f.gamma = p->g1; f.beta = p->be1;
     f.running_mean = update_running ? p->rm1 : nullptr; f.running_var = update_running ? p->rv1 : nullptr;
     f.mean = w.mean1; f.invstd = w.inv1; f.out = w.A1; f.outT = w.A1T; f.B = B; f.N = d1;
-    f.eps = eps; f.momentum = momentum; f.slope = slope;
+    f.eps = eps; f.momentum = momentum; f.slope = slope; f.bf16_out = mx.on;
     rc = launch_bn_forward(f, s);
     if (rc) return rc;
     // Y2 = A1 W2^T (+ b2 in the strip kernel), split-K partials
-    const int S = fwd2_slices(B, d1, d2);
+    const int S = fwd2_slices(B, d1, d2, gemm_bf16 != 0);
     memset(&g, 0, sizeof(g));
     g.A = w.A1; g.lda = d1; g.B = p->W2; g.ldb = d1; g.C = w.Y2p; g.ldc = d2; g.slice_stride = (size_t)B * d2;
     g.M = B; g.N = d2; g.K = d1; g.S = S;
-    rc = launch_gemm(g, s);
+    mx.a_ready = true;  // A1 as the strip kernel wrote it
+    rc = launch_gemm(g, s, mx);
     if (rc) return rc;
     // Y2 = b2 + sum of the partials, then Z = BN2(Y2)
     {
@@ -512,8 +596,9 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
 }
 
 int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1, int d2,
-                        float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes, void* stream) {
-    return nsvd_tower_backward_sumsq(x, p, dz, B, d0, d1, d2, slope, grads, ws, ws_bytes, nullptr, stream);
+                        float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws, size_t ws_bytes,
+                        void* stream) {
+    return nsvd_tower_backward_sumsq(x, p, dz, B, d0, d1, d2, slope, gemm_bf16, grads, ws, ws_bytes, nullptr, stream);
 }
 
 }  // extern "C"
@@ -523,21 +608,23 @@ int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float*
 int nsvd_tower_sumsq_count(int d0, int d1, int d2) { return (d2 / 128) * (d1 / 128) + (d1 / 128) * (d0 / 128); }
 
 int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1,
-                              int d2, float slope, const nsvd_tower_params* grads, void* ws, size_t ws_bytes,
-                              float* sumsq, void* stream) {
+                              int d2, float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws,
+                              size_t ws_bytes, float* sumsq, void* stream) {
     if (!x || !p || !dz || !grads || !ws || !tower_shape_ok(B, d0, d1, d2)) return NSVD_EINVAL;
     if (!grads->W1 || !grads->b1 || !grads->g1 || !grads->be1 || !grads->W2 || !grads->b2 || !grads->g2 || !grads->be2)
         return NSVD_EINVAL;
     const TowerWs w = carve_tower(B, d0, d1, d2, ws);
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    Mixed mx;
+    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB;
     int rc = 0;
     // dY2 = BN2'(dZ), dY2^T, db2 = column sums of dY2
     BnBwd b;
     memset(&b, 0, sizeof(b));
     b.dout = dz; b.Y = w.Y2; b.mean = w.mean2; b.invstd = w.inv2; b.gamma = p->g2; b.beta = p->be2;
     b.dY = w.dY2; b.dYT = w.dY2T; b.dgamma = grads->g2; b.dbeta = grads->be2; b.dbias = grads->b2;
-    b.B = B; b.N = d2; b.slope = 1.0f;
+    b.B = B; b.N = d2; b.slope = 1.0f; b.bf16_out = mx.on;
     rc = launch_bn_backward(b, s);
     if (rc) return rc;
     // dW2 = dY2^T A1  (A = dY2^T (d2, B), B = A1^T (d1, B), K = B)
@@ -546,29 +633,32 @@ int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const 
     g.A = w.dY2T; g.lda = B; g.B = w.A1T; g.ldb = B; g.C = grads->W2; g.ldc = d1;
     g.M = d2; g.N = d1; g.K = B; g.S = 1;
     g.sumsq = sumsq;
-    rc = launch_gemm(g, s);
+    mx.a_ready = mx.b_ready = true;  // dY2^T and A1^T as the strip kernels wrote them
+    rc = launch_gemm(g, s, mx);
     if (rc) return rc;
     // W2^T (d1, d2), then dA1 = dY2 W2  (A = dY2 (B, d2), B = W2^T (d1, d2), K = d2)
-    hipLaunchKernelGGL(tower_transpose_kernel, dim3((d2 / 32) * (d1 / 32)), dim3(256), 0, s, p->W2, w.W2T, d2, d1);
+    if (mx.on) hipLaunchKernelGGL(tower_transpose_kernel<true>, dim3((d2 / 32) * (d1 / 32)), dim3(256), 0, s, p->W2, (void*)w.W2T, d2, d1);
+    else hipLaunchKernelGGL(tower_transpose_kernel<false>, dim3((d2 / 32) * (d1 / 32)), dim3(256), 0, s, p->W2, (void*)w.W2T, d2, d1);
     NSVD_CHECK_LAUNCH();
     memset(&g, 0, sizeof(g));
     g.A = w.dY2; g.lda = d2; g.B = w.W2T; g.ldb = d2; g.C = w.dA1; g.ldc = d1;
     g.M = B; g.N = d1; g.K = d2; g.S = 1;
-    rc = launch_gemm(g, s);
+    rc = launch_gemm(g, s, mx);
     if (rc) return rc;
     // dY1^T = (BN1'(lrelu'(dA1)))^T, db1
     memset(&b, 0, sizeof(b));
     b.dout = w.dA1; b.Y = w.Y1; b.mean = w.mean1; b.invstd = w.inv1; b.gamma = p->g1; b.beta = p->be1;
     b.dY = nullptr; b.dYT = w.dY1T; b.dgamma = grads->g1; b.dbeta = grads->be1; b.dbias = grads->b1;
-    b.B = B; b.N = d1; b.slope = slope;
+    b.B = B; b.N = d1; b.slope = slope; b.bf16_out = mx.on;
     rc = launch_bn_backward(b, s);
     if (rc) return rc;
     // X^T (d0, B), then dW1 = dY1^T X  (A = dY1^T (d1, B), B = X^T (d0, B), K = B)
-    hipLaunchKernelGGL(tower_transpose_kernel, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, w.XT, B, d0);
+    if (mx.on) hipLaunchKernelGGL(tower_transpose_kernel<true>, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, (void*)w.XT, B, d0);
+    else hipLaunchKernelGGL(tower_transpose_kernel<false>, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, (void*)w.XT, B, d0);
     NSVD_CHECK_LAUNCH();
     memset(&g, 0, sizeof(g));
     g.A = w.dY1T; g.lda = B; g.B = w.XT; g.ldb = B; g.C = grads->W1; g.ldc = d0;
     g.M = d1; g.N = d0; g.K = B; g.S = 1;
     g.sumsq = sumsq ? sumsq + (d2 / 128) * (d1 / 128) : nullptr;
-    return launch_gemm(g, s);
+    return launch_gemm(g, s, mx);
 }

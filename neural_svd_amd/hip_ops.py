@@ -605,8 +605,9 @@ def _tower_struct(t: dict, need_running: bool) -> "_lib.TowerParams":
 
 
 def tower_forward(x: torch.Tensor, params: dict, slope: float, eps: float, momentum: float, update_running: bool,
-                  ws: torch.Tensor) -> torch.Tensor:
-    """z = BN2(Linear2(lrelu(BN1(Linear1(x))))) in training mode; params: dict over TOWER_KEYS (torch layouts)."""
+                  ws: torch.Tensor, gemm_bf16: bool = False) -> torch.Tensor:
+    """z = BN2(Linear2(lrelu(BN1(Linear1(x))))) in training mode; params: dict over TOWER_KEYS (torch layouts).
+    gemm_bf16: mixed precision - the contractions' operands rounded to bfloat16, float32 accumulation (nsvd.h)."""
     B, d0 = x.shape
     d1, d2 = params["W1"].shape[0], params["W2"].shape[0]
     if tuple(params["W1"].shape) != (d1, d0) or tuple(params["W2"].shape) != (d2, d1):
@@ -617,13 +618,14 @@ def tower_forward(x: torch.Tensor, params: dict, slope: float, eps: float, momen
     z = torch.empty((B, d2), dtype=torch.float32, device=x.device)
     p = _tower_struct(params, bool(update_running))
     rc = _lib.load().nsvd_tower_forward(_ptr(x, "x"), C.byref(p), B, d0, d1, d2, float(slope), float(eps),
-                                        float(momentum), int(bool(update_running)), _ptr(z, "z"), ws.data_ptr(),
-                                        ws.numel(), _stream())
+                                        float(momentum), int(bool(update_running)), int(bool(gemm_bf16)),
+                                        _ptr(z, "z"), ws.data_ptr(), ws.numel(), _stream())
     check(rc, "nsvd_tower_forward")
     return z
 
 
-def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float, ws: torch.Tensor) -> dict:
+def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float, ws: torch.Tensor,
+                   gemm_bf16: bool = False) -> dict:
     """gradients of sum(dz * z) w.r.t. W1, b1, g1, be1, W2, b2, g2, be2 (same workspace as the forward call)."""
     B, d0 = x.shape
     d1, d2 = params["W1"].shape[0], params["W2"].shape[0]
@@ -632,20 +634,21 @@ def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float
     grads = {k: torch.empty_like(params[k]) for k in TOWER_KEYS if not k.startswith("r")}
     p, g = _tower_struct(params, False), _tower_struct(grads, False)
     rc = _lib.load().nsvd_tower_backward(_ptr(x, "x"), C.byref(p), _ptr(dz, "dz"), B, d0, d1, d2, float(slope),
-                                         C.byref(g), ws.data_ptr(), ws.numel(), _stream())
+                                         int(bool(gemm_bf16)), C.byref(g), ws.data_ptr(), ws.numel(), _stream())
     check(rc, "nsvd_tower_backward")
     return grads
 
 
 def cdk_step_desc(B: int, d0: int, d1: int, d2: int, slope: float, bn_eps: float, bn_momentum: float, mu: float,
                   normalize_mode: int, set_first_mode_const: bool, lr: float, momentum: float, max_grad_norm: float,
-                  first_step: bool) -> "_lib.CdkStepDesc":
+                  first_step: bool, gemm_bf16: bool = False) -> "_lib.CdkStepDesc":
     d = _lib.CdkStepDesc()
     d.B, d.d0, d.d1, d.d2 = int(B), int(d0), int(d1), int(d2)
     d.slope, d.bn_eps, d.bn_momentum, d.mu = float(slope), float(bn_eps), float(bn_momentum), float(mu)
     d.normalize_mode, d.set_first_mode_const = int(normalize_mode), int(bool(set_first_mode_const))
     d.lr, d.momentum, d.max_grad_norm = float(lr), float(momentum), float(max_grad_norm or 0.0)
     d.first_step = int(bool(first_step))
+    d.gemm_bf16 = int(bool(gemm_bf16))
     return d
 
 

@@ -505,13 +505,22 @@ def kernel_loss_and_grads(x, p: Params, kernel_fn, v, M, split_batch: bool, hard
 
 
 # ----------------------------------------------------------------------------- CDK tower
-def tower_forward_backward(x, P, dz, slope, eps=1e-5):
+def _bf16_round(t):
+    """round to nearest even to bfloat16 and back to t's dtype (the operand rounding of the mixed-precision mode)"""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
     """Linear -> BatchNorm1d (training) -> LeakyReLU(slope) -> Linear -> BatchNorm1d (training) and the hand-derived
     gradient of sum(dz * z): what get_mlp(sizes=[d0, d1, d2], bias=True, nonlinearity='lrelu<slope>', use_bn=True)
     (reference examples/models/mlp.py:129-164) computes with autograd. P: dict W1 (d1, d0), b1, g1, be1 (d1), W2
     (d2, d1), b2, g2, be2 (d2) in torch's layouts. Pinned by tests/golden/tower.npz.
-    Returns z, dict of gradients, and the batch statistics (mean, biased var, unbiased var) of both BatchNorms."""
+    Returns z, dict of gradients, and the batch statistics (mean, biased var, unbiased var) of both BatchNorms.
+    gemm_bf16: the build's mixed-precision mode (no reference counterpart to pin it to: the reference's autocast is
+    float16 and covers more ops) - both operands of each of the five contractions rounded to bfloat16, products and
+    sums exact in this dtype; everything else unchanged."""
     B = x.shape[0]
+    r = _bf16_round if gemm_bf16 else (lambda t: t)
 
     def bn(y, g, be):
         mu = y.mean(0)
@@ -523,22 +532,23 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5):
     def bn_back(dh, yh, inv, g):
         return g * inv * (dh - dh.mean(0) - yh * (dh * yh).mean(0)), (dh * yh).sum(0), dh.sum(0)
 
-    y1 = x @ P["W1"].T + P["b1"]
+    y1 = r(x) @ r(P["W1"]).T + P["b1"]
     h1, yh1, inv1, st1 = bn(y1, P["g1"], P["be1"])
     a1 = torch.where(h1 > 0, h1, slope * h1)
-    y2 = a1 @ P["W2"].T + P["b2"]
+    y2 = r(a1) @ r(P["W2"]).T + P["b2"]
     z, yh2, inv2, st2 = bn(y2, P["g2"], P["be2"])
     dy2, dg2, dbe2 = bn_back(dz, yh2, inv2, P["g2"])
-    da1 = dy2 @ P["W2"]
+    da1 = r(dy2) @ r(P["W2"])
     dh1 = da1 * torch.where(h1 > 0, torch.ones_like(h1), torch.full_like(h1, slope))
     dy1, dg1, dbe1 = bn_back(dh1, yh1, inv1, P["g1"])
-    grads = dict(W1=dy1.T @ x, b1=dy1.sum(0), g1=dg1, be1=dbe1, W2=dy2.T @ a1, b2=dy2.sum(0), g2=dg2, be2=dbe2)
+    grads = dict(W1=r(dy1).T @ r(x), b1=dy1.sum(0), g1=dg1, be1=dbe1, W2=r(dy2).T @ r(a1), b2=dy2.sum(0), g2=dg2,
+                 be2=dbe2)
     return z, grads, (st1, st2)
 
 
 
 def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm, slope, first_step, eps=1e-5,
-                   bn_momentum=0.1):
+                   bn_momentum=0.1, gemm_bf16=False):
     """One Sketchy-style CDK training step (reference examples/cdk/sketchy/main_sketchy.py:180-212 with
     scripts/exps/sketchy.sh's switches, AMP off): two towers (get_mlp, examples/models/mlp.py:129-164) behind Identity
     projectors and normalize('l2_ball', sqrt(mu)) (examples/models/siam.py:156-183), NestedLoRAForCDK loss
@@ -550,7 +560,8 @@ def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm
     r_up = float(mu) ** 0.5
     zs, embs = [], []
     for inp, P in ((x, towers[0]), (y, towers[1])):
-        z, _, _ = tower_forward_backward(inp, P, torch.zeros(inp.shape[0], P["W2"].shape[0], dtype=inp.dtype), slope, eps)
+        z, _, _ = tower_forward_backward(inp, P, torch.zeros(inp.shape[0], P["W2"].shape[0], dtype=inp.dtype), slope, eps,
+                                         gemm_bf16)
         zr = z.detach().clone().requires_grad_(True)
         zs.append(zr)
         embs.append(row_normalize(zr, r_up, "l2_ball"))
@@ -559,7 +570,7 @@ def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm
     for inp, P, zr, e, ge, run in ((x, towers[0], zs[0], embs[0], gf, running[0]),
                                    (y, towers[1], zs[1], embs[1], gg, running[1])):
         (dz,) = torch.autograd.grad(e, zr, ge)
-        _, g, (st1, st2) = tower_forward_backward(inp, P, dz, slope, eps)
+        _, g, (st1, st2) = tower_forward_backward(inp, P, dz, slope, eps, gemm_bf16)
         grads.append(g)
         for tag, st in (("1", st1), ("2", st2)):
             run["rm" + tag].mul_(1 - bn_momentum).add_(bn_momentum * st[0])

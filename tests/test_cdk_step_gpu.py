@@ -128,3 +128,48 @@ def test_cdk_step_refuses_what_it_does_not_implement():
     model.eval()
     with pytest.raises(H.NsvdError):
         fs.step(torch.zeros(128, 128, device=DEV), torch.zeros(128, 128, device=DEV))
+
+
+def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding():
+    """FusedCdkStep(use_amp=True): three training steps with the towers' contractions on bfloat16-rounded operands,
+    against oracle.cdk_train_step(gemm_bf16=True) in float64 from the same initial weights and batches - losses, total
+    gradient norms, parameters and momentum buffers - and the float32 mode beside it (close, not equal)."""
+    from oracle import nsvd_oracle as O
+    from neural_svd_amd.cdk import FusedCdkStep
+    sizes, B, mu, lr, mom, max_norm, slope = [128, 256, 128], 128, 16.0, 5e-3, 0.9, 1.0, 0.2
+    g = torch.Generator().manual_seed(77)
+    xs = torch.randn(3, B, sizes[0], generator=g)
+    ys = torch.randn(3, B, sizes[0], generator=g)
+    runs = {}
+    for amp in (True, False):
+        model, method = _build(sizes, mu, 11)
+        if amp:
+            sd0 = {k: v.detach().double().cpu().clone() for k, v in model.state_dict().items()}
+        fs = FusedCdkStep(method, lr=lr, momentum=mom, max_grad_norm=max_norm, t_max=0, batch_size=B, use_amp=amp)
+        outs = [fs.step(xs[t].to(DEV), ys[t].to(DEV)).cpu().double().clone() for t in range(3)]
+        fs.flush_counters()
+        runs[amp] = (outs, {k: v.detach().double().cpu() for k, v in model.state_dict().items()},
+                     [{k: b.double().cpu() for k, b in bb.items()} for bb in fs.bufs], method)
+    # the float64 oracle with the same operand rounding
+    method = runs[True][3]
+    towers = [{k: sd0[f"backbones.{s}.{n}"].clone() for k, n in KEYS.items()} for s in "xy"]
+    bufs = [{k: torch.zeros_like(v) for k, v in t.items()} for t in towers]
+    running = [dict(rm1=sd0[f"backbones.{s}.1.running_mean"].clone(), rv1=sd0[f"backbones.{s}.1.running_var"].clone(),
+                    rm2=sd0[f"backbones.{s}.4.running_mean"].clone(), rv2=sd0[f"backbones.{s}.4.running_var"].clone())
+               for s in "xy"]
+    v, M = method.vector_mask.double().cpu(), method.matrix_mask.double().cpu()
+    for t in range(3):
+        (loss, lop, lmet), total = O.cdk_train_step(xs[t].double(), ys[t].double(), towers, bufs, running, v, M, mu, lr,
+                                                    mom, max_norm, slope, t == 0, gemm_bf16=True)
+        got = runs[True][0][t]
+        assert abs(float(got[0]) - float(loss)) < 2e-4 * max(1.0, abs(float(loss))), (t, float(got[0]), float(loss))
+        assert abs(float(got[3]) - float(total)) < 2e-3 * float(total), (t, float(got[3]), float(total))
+    sd = runs[True][1]
+    for si, s in enumerate("xy"):
+        for k, n in KEYS.items():
+            got, want = sd[f"backbones.{s}.{n}"], towers[si][k]
+            move = float((want - sd0[f"backbones.{s}.{n}"]).norm())
+            assert float((got - want).norm()) < 5e-3 * move + 1e-6 * float(want.norm()), (s, k)
+    # float32 mode: the same trajectory up to the bfloat16 operand rounding
+    l_amp, l_32 = float(runs[True][0][2][0]), float(runs[False][0][2][0])
+    assert l_amp != l_32 and abs(l_amp - l_32) < 2e-2 * max(1.0, abs(l_32)), (l_amp, l_32)

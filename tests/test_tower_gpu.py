@@ -128,3 +128,43 @@ def test_tower_behind_a_trainable_module_passes_the_gradient_upstream():
         assert m.hip_ready(x)  # no graph is being recorded: nothing to cut
     head = m[:3]
     assert type(head) is torch.nn.Sequential and len(head) == 3 and head[0] is m[0]
+
+
+@pytest.mark.parametrize("B,d0,d1,d2", [(128, 128, 256, 128), (1024, 512, 8192, 512)])
+def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, d1, d2):
+    """gemm_bf16 (the counterpart of the reference's autocast branch, main_sketchy.py:161,182): both operands of each of
+    the five contractions rounded to bfloat16, float32 accumulation, everything else float32. Against the float64 oracle
+    that rounds the same operands (its own intermediates differ from the float32 ones by 1e-7, which moves a few
+    values in 10^5 across a bfloat16 rounding boundary: the tolerances below, not float32 noise level) - and against the
+    float32 mode, from which it must differ by about the bfloat16 rounding (2^-9 per operand), no more."""
+    from neural_svd_amd import hip_ops as H
+    g = torch.Generator().manual_seed(B + d1)
+    P = dict(W1=torch.randn(d1, d0, generator=g) / d0 ** 0.5, b1=0.1 * torch.randn(d1, generator=g),
+             g1=1.0 + 0.3 * torch.randn(d1, generator=g), be1=0.2 * torch.randn(d1, generator=g),
+             W2=torch.randn(d2, d1, generator=g) / d1 ** 0.5, b2=0.1 * torch.randn(d2, generator=g),
+             g2=1.0 + 0.3 * torch.randn(d2, generator=g), be2=0.2 * torch.randn(d2, generator=g))
+    x = torch.randn(B, d0, generator=g)
+    dz = torch.randn(B, d2, generator=g)
+    zo, go, _ = O.tower_forward_backward(x.double(), {k: v.double() for k, v in P.items()}, dz.double(), 0.2,
+                                         gemm_bf16=True)
+    Pd = {k: v.to(DEV).contiguous() for k, v in P.items()}
+    for k, n in (("rm1", d1), ("rv1", d1), ("rm2", d2), ("rv2", d2)):
+        Pd[k] = torch.zeros(n, device=DEV) if k.startswith("rm") else torch.ones(n, device=DEV)
+    ws = H.tower_workspace(B, d0, d1, d2, DEV)
+    xd, dzd = x.to(DEV), dz.to(DEV)
+    res = {}
+    for mixed in (True, False):
+        z = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=mixed)
+        res[mixed] = (z.clone(), H.tower_backward(xd, Pd, dzd, 0.2, ws, gemm_bf16=mixed))
+    torch.cuda.synchronize()
+    z, grads = res[True]
+    assert rel(z, zo) < 2e-4, rel(z, zo)
+    for k in ("W1", "g1", "be1", "W2", "g2", "be2"):
+        assert rel(grads[k], go[k]) < 2e-3, (k, rel(grads[k], go[k]))
+    # the two modes: different by the operand rounding, and only by that
+    z32, g32 = res[False]
+    assert 1e-4 < rel(z, z32) < 2e-2, rel(z, z32)
+    assert 1e-4 < rel(grads["W2"], g32["W2"]) < 5e-2
+    # bit reproducibility
+    z2 = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=True)
+    assert torch.equal(z, z2)
