@@ -205,7 +205,11 @@ def _activation_factory(name: str):
 
 class _TowerFn(torch.autograd.Function):
     """Linear -> BatchNorm1d -> LeakyReLU -> Linear -> BatchNorm1d in training mode on the HIP tower kernels
-    (csrc/tower.hip: five fp32-MFMA contractions and four BatchNorm strip kernels for forward + backward)."""
+    (csrc/tower.hip: five fp32-MFMA contractions and four BatchNorm strip kernels for forward + backward).
+    Under ``torch.autocast`` (the reference's Sketchy loop wraps ``method(x, y)`` in it unless --disable_amp,
+    main_sketchy.py:182) the contractions run in this library's mixed-precision mode - bfloat16-rounded operands,
+    float32 accumulation, float32 everything else (nsvd.h: gemm_bf16) - and the output stays float32; a GradScaler
+    around it is harmless (float32 gradients neither overflow nor underflow under its scale)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, seq):
@@ -216,16 +220,17 @@ class _TowerFn(torch.autograd.Function):
                  rm2=bn2.running_mean, rv2=bn2.running_var)
         ws = H.tower_workspace(xd.shape[0], W1.shape[1], W1.shape[0], W2.shape[0], xd.device)
         track = bn1.track_running_stats and bn1.running_mean is not None
-        z = H.tower_forward(xd, t, seq.slope, bn1.eps, bn1.momentum, track, ws)
+        mixed = bool(torch.is_autocast_enabled())
+        z = H.tower_forward(xd, t, seq.slope, bn1.eps, bn1.momentum, track, ws, gemm_bf16=mixed)
         if track:
             bn1.num_batches_tracked += 1
             bn2.num_batches_tracked += 1
-        ctx.t, ctx.ws, ctx.xd, ctx.slope = t, ws, xd, seq.slope
+        ctx.t, ctx.ws, ctx.xd, ctx.slope, ctx.mixed = t, ws, xd, seq.slope, mixed
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        g = H.tower_backward(ctx.xd, ctx.t, dz.detach().float().contiguous(), ctx.slope, ctx.ws)
+        g = H.tower_backward(ctx.xd, ctx.t, dz.detach().float().contiguous(), ctx.slope, ctx.ws, gemm_bf16=ctx.mixed)
         return (None, g["W1"], g["b1"], g["g1"], g["be1"], g["W2"], g["b2"], g["g2"], g["be2"], None)
 
 

@@ -168,3 +168,33 @@ def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, 
     # bit reproducibility
     z2 = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=True)
     assert torch.equal(z, z2)
+
+
+def test_tower_module_under_autocast_runs_the_mixed_precision_mode():
+    """the reference's Sketchy loop wraps method(x, y) in torch.cuda.amp.autocast (+ GradScaler) unless --disable_amp:
+    inside autocast the tower module takes the mixed-precision mode (same bits as the C call with gemm_bf16 = 1), its
+    output stays float32, and a GradScaler-style scaled backward gives the unscaled gradients back exactly (the scale is
+    a power of two)."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.cdk import get_mlp
+    torch.manual_seed(3)
+    m = get_mlp([128, 256, 128], bias=True, nonlinearity="lrelu0.2", use_bn=True).to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(128, 128, generator=g).to(DEV)
+    dz = torch.randn(128, 128, generator=g).to(DEV)
+    P = {k: dict(m.named_parameters())[n].detach().clone() for k, n in NAMES.items()}
+    for k, mod, attr in (("rm1", m[1], "running_mean"), ("rv1", m[1], "running_var"), ("rm2", m[4], "running_mean"),
+                         ("rv2", m[4], "running_var")):
+        P[k] = getattr(mod, attr).detach().clone()
+    ws = H.tower_workspace(128, 128, 256, 128, DEV)
+    want = H.tower_forward(x, P, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=True)
+    gwant = H.tower_backward(x, P, dz, 0.2, ws, gemm_bf16=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = m(x)
+    assert out.dtype == torch.float32 and torch.equal(out, want)
+    (out * dz * 65536.0).sum().backward()
+    for k, n in NAMES.items():
+        assert torch.equal(dict(m.named_parameters())[n].grad / 65536.0, gwant[k]), k
+    m.zero_grad()
+    out32 = m(x)  # outside autocast: float32 contractions
+    assert not torch.equal(out32, out) and rel(out32.detach(), out.detach()) < 2e-2
