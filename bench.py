@@ -231,6 +231,12 @@ def _launch_ranks(n, argv, timeout, extra_env=None):
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's output is drained while the ranks run: a chatty library (NCCL_DEBUG=INFO writes to stdout) must not fill
+    # the pipe and block the rank that holds the result
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = time.time() + timeout
     rc, err = 0, None
     pending = set(range(n))
@@ -246,7 +252,7 @@ def _launch_ranks(n, argv, timeout, extra_env=None):
         if err is None and time.time() > deadline:
             rc, err = 124, f"ranks still running after {timeout:.0f} s"
         if pending and err is None:
-            time.sleep(0.2)  # (rank 0 prints one line at the very end: nothing to drain while it runs)
+            time.sleep(0.2)
     if err is not None:
         for q in procs:  # exactly the processes started above
             if q.poll() is None:
@@ -254,7 +260,8 @@ def _launch_ranks(n, argv, timeout, extra_env=None):
         for q in procs:
             q.wait()
         return rc, "", err
-    out = procs[0].stdout.read()
+    reader.join(timeout=30)
+    out = "".join(chunks)
     if not [ln for ln in out.splitlines() if ln.startswith("{")]:
         return 1, out, "rank 0 printed no JSON line"
     return 0, out, None
