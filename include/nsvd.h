@@ -349,7 +349,8 @@ size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2);
  *   nearest even) and multiplied on the bf16 MFMA with float32 accumulation; BatchNorm, activation, gradients,
  *   statistics and every stored tensor stay float32. The role of the reference's autocast branch
  *   (examples/cdk/sketchy/main_sketchy.py:161,182, on by default there) without its float16 / GradScaler dynamics:
- *   not bit-comparable with it, pinned to the float64 oracle of the same rounding instead. */
+ *   not bit-comparable with it, pinned to the float64 oracle of the same rounding instead. The backward must be called
+ *   with the flag of its forward (the workspace then holds bfloat16 activations where it otherwise holds float32). */
 int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, int d0, int d1, int d2, float slope,
                        float eps, float momentum, int update_running, int gemm_bf16, float* z, void* ws,
                        size_t ws_bytes, void* stream);

@@ -231,7 +231,7 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     # Samples sharded: every rank needs its OWN rows - its generator is re-seeded by rank once the model is built.
     draws = comm.world if (comm is not None and fused.hp) else 1
     if comm is not None and not fused.hp:
-        torch.manual_seed(torch.initial_seed() * 1000003 + 7919 * comm.rank + 1)
+        torch.manual_seed((torch.initial_seed() * 1000003 + 7919 * comm.rank + 1) % (1 << 62))
     all_eigvals, all_norms = [], []
     start = time.time()
     # the reference adds loss.item() to a host total on EVERY step (operator/__init__.py:74,99: a device sync per
