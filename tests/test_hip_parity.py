@@ -825,3 +825,46 @@ def test_backward_headline_size_sampled_heads():
         for i in range(nl):
             assert rel(r["grads"][i][l], gref[i][0]) < 3e-5, (l, i, rel(r["grads"][i][l], gref[i][0]))
             assert rel(r["grads"][nl + i][l], gref[nl + i][0]) < 3e-5, (l, i)
+
+
+@pytest.mark.parametrize("world,rank", [(8, 7), (4, 1)])
+def test_head_sharded_backward_at_the_multi_gpu_rank_shape(world, rank):
+    """What one rank of an N-GPU head-sharded run of configs[1] executes (L / N heads of 16 on the global batch of
+    512 N rows, partial-moment backward with a head offset), at FULL size on one GPU: f, Tf of the rank's heads are the
+    unsharded run's columns bit for bit, and its gradients (EVD loss of the global (B, 16) arrays, moments included)
+    are the unsharded backward's head slices - the same kernels on the same columns; the freedom is float32 summation
+    order (the rank's weight gradients take their split-K form over the 512 N rows): 5e-6."""
+    L, D, m, hidden = 16, 2, 1024, (128, 128, 128)
+    B, Ll = 512 * world, L // world
+    l0 = rank * Ll
+    p = O.init_params(L, D, m, hidden, 0.1, seed=0)
+    prob = hip_problem(O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0))
+    x = (16.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(world))).to(DEV)
+
+    def run(pp, f_g=None, Tf_g=None, l_offset=0):
+        shape = shape_of(pp)
+        ws_t, bs_t, fB, sc = to_dev(pp)
+        params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+        gw, gb = [torch.zeros_like(w) for w in ws_t], [torch.zeros_like(b) for b in bs_t]
+        grads = H.pack_params(shape, gw, gb, None, None)
+        ws = H.new_workspace(shape, B, DEV)
+        f, Tf = H.operator_forward(shape, params, prob, x, ws, True, H.PATH_FUSED)
+        if f_g is None:
+            f_g, Tf_g = f, Tf
+        scratch = H.evd_scratch(B, L, DEV)
+        moments = torch.empty(2 * L * L + 1, device=DEV)
+        loss = torch.zeros(3, device=DEV)
+        H.evd_partial(f_g, Tf_g, H.MASK_JOINT, None, scratch)
+        H.operator_backward_evd(shape, params, prob, x, f_g, Tf_g, H.MASK_JOINT, None, None, moments, False, scratch, loss,
+                                grads, ws, 1.0, H.PATH_FUSED, l_offset=l_offset)
+        torch.cuda.synchronize()
+        return f, Tf, gw + gb, loss.clone()
+
+    f, Tf, g_full, loss_full = run(p)
+    sl = slice(l0, l0 + Ll)
+    p_loc = O.Params([w[sl] for w in p.ws], [b[sl] for b in p.bs], p.fourier_B, None)
+    f_l, Tf_l, g_loc, loss_loc = run(p_loc, f, Tf, l0)
+    assert torch.equal(f_l, f[:, sl]) and torch.equal(Tf_l, Tf[:, sl])
+    assert rel(loss_loc, loss_full) < 1e-6
+    for i, (a, b) in enumerate(zip(g_loc, g_full)):
+        assert torch.isfinite(a).all() and rel(a, b[sl]) < 5e-6, (i, rel(a, b[sl]))
