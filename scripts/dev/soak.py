@@ -17,9 +17,11 @@ cases = [
     ("hydrogen L=16 B=512 jnt step=4", dict(L=16, m=1024, hidden=(128,) * 3, B=512, seq=False, pot="h", eps=0.01, step=4)),
     ("hydrogen L=1 B=512", dict(L=1, m=1024, hidden=(128,) * 3, B=512, seq=True, pot="h", eps=0.01)),
     ("hydrogen L=128 B=64 m=64", dict(L=128, m=64, hidden=(128,) * 3, B=64, seq=True, pot="h", eps=0.01)),
+    ("3-D oscillator, split-stencil form, L=8 B=256", dict(L=8, m=256, hidden=(128,) * 3, B=256, seq=True, pot="o", eps=0.01, D=3)),
+    ("3-D oscillator exact L=8 B=256", dict(L=8, m=256, hidden=(128,) * 3, B=256, seq=True, pot="o", eps=0.0, D=3)),
 ]
 for name, c in cases:
-    shape = H.ModelShape(L=c["L"], D=2, m=c["m"], hidden=c["hidden"], has_exp_mask=c["pot"] == "o")
+    shape = H.ModelShape(L=c["L"], D=c.get("D", 2), m=c["m"], hidden=c["hidden"], has_exp_mask=c["pot"] == "o")
     if c["pot"] == "h":
         prob = H.make_problem(H.POT_HYDROGEN, 1.0, c["eps"], 100.0, 0.0, 16.0); kw = dict(sampling_scale=16.0, fourier_scale=c.get("fs", 0.1))
     else:
