@@ -570,6 +570,9 @@ def main():
         print("svd_loss", os.path.getsize(os.path.join(HERE, "svd_loss.npz")) // 1024, "KiB")
         return
     o = {}
+    golden_cdk_step(o)
+    np.savez_compressed(os.path.join(HERE, "cdk_step.npz"), **o)
+    o = {}
     golden_tower(o)
     np.savez_compressed(os.path.join(HERE, "tower.npz"), **o)
     o = {}
