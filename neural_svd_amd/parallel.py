@@ -53,6 +53,12 @@ Backend protocol (all methods enqueue work and return immediately on the HIP bac
   after_gather()                   hp: gathered blocks -> the (B, L) arrays the backward reads
   prefetch()                       work for the NEXT step that depends on no weight (issued under a collective)
 
+Collectives are asynchronous with late waits by default (a bucket on the wire under the remaining backward launches)
+or blocking on the compute stream (`sync=True`: no second stream and no cross-stream event - each of which idles the
+compute stream for ~10 us on this runtime - and no overlap either); what an RCCL world of one measures for both, and
+why bench.py lets the first hardware contact choose: DESIGN.md 6. `Communicator.force_exchange` runs the whole exchange
+sequence in a world of ONE (every collective a one-rank library call): how a one-GPU box exercises the RCCL calls.
+
 Diagnostics (bench.py's `comm` block): `CommProbe` brackets every wait on a collective with two events on the
 compute stream - what they measure is the time the compute stream sat idle for that collective, i.e. its EXPOSED
 cost - and `Communicator.stub = True` turns every collective into a no-op so that the same step can be timed
