@@ -198,6 +198,39 @@ def _worker_hp(rank, world, port, tmp):
     comm.close()
 
 
+def _worker_forced(rank, world, port, tmp):
+    """a world of ONE with Communicator.force_exchange: every exchange sequence, asynchronous and blocking, must run
+    its collectives (probe spans present) and reproduce the plain single-process step"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from neural_svd_amd import parallel
+    comm = parallel.Communicator.from_env(device=None, backend="gloo")
+    assert comm.world == 1 and not comm.multi
+    comm.force_exchange = True
+    assert comm.multi
+    p, prob, v, M, x = _setup()
+    ref = O.loss_and_grads(x, p, prob, v, M)
+    gref = torch.cat([g.reshape(-1) for g in ref["grads"]])
+    for exchange in parallel.DP_EXCHANGES:
+        for sync in (False, True):
+            be = OracleBackend(p, prob, v, M, world=1)
+            probe = parallel.CommProbe(None)
+            parallel.dp_step(be, comm, x, exchange=exchange, probe=probe, sync=sync)
+            spans = list(probe.summary())
+            assert spans[0] == "moments_allreduce" and len(spans) == (4 if exchange == "allreduce" else 7), spans
+            assert "backward(reduced=True, take_step=False)" in be.calls
+            assert abs(float(be.loss) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
+            assert float((be.applied - gref).norm() / gref.norm()) < 1e-12, (exchange, sync)
+    for sync in (False, True):
+        be = OracleBackend(p, prob, v, M, world=1)
+        probe = parallel.CommProbe(None)
+        parallel.hp_step(be, comm, x, probe=probe, sync=sync)
+        assert list(probe.summary()) == ["f_Tf_all_gather_wait"]
+        assert ("prefetch" in be.calls) == (not sync)
+        assert float((be.applied - gref).norm() / gref.norm()) < 1e-12
+    torch.save(dict(ok=True), os.path.join(tmp, "forced.pt"))
+    comm.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -245,6 +278,12 @@ def test_dp_reduce_scatter_all_gather_equals_single_process(tmp_path, world, exc
         want = o["params0"] - 0.5 * gref
         assert float((o["params"] - want).norm() / want.norm()) < 1e-12       # every element stepped exactly once
     assert bool(covered.all())
+
+
+@pytest.mark.timeout(300)
+def test_forced_exchange_in_a_world_of_one(tmp_path):
+    mp.spawn(_worker_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert torch.load(os.path.join(str(tmp_path), "forced.pt"))["ok"]
 
 
 def test_dp_step_single_process_is_plain_step():
