@@ -105,3 +105,21 @@ def test_launcher_retries_with_the_plain_exchange_when_the_tuned_run_dies():
     c = d["comm"]
     assert c["exchange"] == "allreduce" and c["collectives"].startswith("blocking") and c["candidates"] is None
     assert len(c["grad_bucket_bytes"]) == 1 and "sharding_hp" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_as_a_rank_under_torch_distributed_run():
+    """the other way a driver may start it: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`
+    (RANK / WORLD_SIZE from the launcher: bench.py is then a rank, not a launcher) - one JSON line from rank 0"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", BENCH, "--gpus", "2", "--steps", "20",
+                        "--warmup", "5", "--no-cpu-baseline", "--no-extras"],
+                       env=_env(NSVD_FORCE_DEVICE="0", NSVD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] in ("dp2", "hp2") and d["value"] > 0 and d["params_finite"]
+    assert d["rccl_ranks"] == 2 and "launcher_retry" not in d
