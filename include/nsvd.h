@@ -203,6 +203,14 @@ int nsvd_evd_loss_fused(const float* f, const float* Tf, int B, int L, int mask_
 int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, int mask_kind, const float* v, void* scratch,
                      void* stream);
 
+/* Heads sharded over `world` processes: gathered = the ranks' packed blocks as an all-gather leaves them,
+ * (world, 2, B, L_local) = [rank][f | Tf][row][local head]; writes the (B, world * L_local) arrays f and Tf every
+ * other entry point reads and - scratch != NULL - the per-chunk partial moments exactly as nsvd_evd_partial(f, Tf)
+ * would (same bits), in the same launch. (The reference has no sharded form: methods/nestedlora.py:70-94 sees the
+ * whole (B, L) f.) */
+int nsvd_evd_gather_heads(const float* gathered, int world, int B, int L_local, int mask_kind, const float* v,
+                          float* f, float* Tf, void* scratch, void* stream);
+
 /* nsvd_evd_loss_grad + nsvd_operator_backward in ONE call: d loss / d f (methods/nestedlora.py:98-111) is
  * evaluated per sample inside the backward kernels and never stored. `moments` (2L^2+1 floats) is
  *   - an INPUT when moments_reduced != 0 (e.g. after the data-parallel all-reduce of nsvd_evd_moments), or

@@ -56,6 +56,48 @@ __global__ void __launch_bounds__(256) evd_partial_kernel(const float* __restric
     if (threadIdx.x == 0) part_op[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Head-sharded runs: the ranks' packed [f | Tf] blocks as the all-gather leaves them, gath (W, 2, B, Ll), -> the
+// (B, W Ll) arrays every consumer reads, and (part != null) the per-chunk partial moments of evd_partial_kernel in the
+// same pass - the same loop, the same accumulation order: bit-identical to a permuting copy followed by that kernel.
+__global__ void __launch_bounds__(256) evd_gather_heads_kernel(const float* __restrict__ gath, int W, int B, int Ll,
+                                                               int kind, const float* __restrict__ v,
+                                                               float* __restrict__ f, float* __restrict__ Tf,
+                                                               float* __restrict__ part, float* __restrict__ part_op) {
+    extern __shared__ __attribute__((aligned(16))) float fs[];  // [CH][L]
+    __shared__ float red[4];
+    const int L = W * Ll;
+    const Chunking c = chunking(B);
+    int r0, r1;
+    chunk_rows(c, blockIdx.x, r0, r1);
+    const int nr = r1 - r0;
+    float op = 0.f;
+    for (int i = threadIdx.x; i < nr * L; i += 256) {
+        const int r = i / L, l = i - r * L;
+        const int w = l / Ll, ll = l - w * Ll;
+        const size_t src = ((size_t)(2 * w) * B + (size_t)(r0 + r)) * Ll + ll;
+        const float fv = gath[src];
+        const float tv = gath[src + (size_t)B * Ll];
+        f[(size_t)r0 * L + i] = fv;
+        Tf[(size_t)r0 * L + i] = tv;
+        if (part) {
+            fs[i] = fv;
+            op = fmaf(mask_v(kind, v, l, L) * fv, tv, op);
+        }
+    }
+    if (!part) return;
+    __syncthreads();
+    for (int o = threadIdx.x; o < L * L; o += 256) {
+        const int i = o / L, j = o - i * L;
+        float s = 0.f;
+        for (int r = 0; r < nr; ++r) s = fmaf(fs[r * L + i], fs[r * L + j], s);
+        part[(size_t)blockIdx.x * L * L + o] = s;
+    }
+    op = nsvd_wave_sum(op);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = op;
+    __syncthreads();
+    if (threadIdx.x == 0) part_op[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 __global__ void __launch_bounds__(256) evd_reduce_kernel(const float* __restrict__ part,
                                                          const float* __restrict__ part_op, int B, int L,
                                                          float* __restrict__ moments) {
@@ -295,6 +337,23 @@ extern "C" int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, i
     float* part_op = part + (size_t)nch * L * L;
     hipLaunchKernelGGL(evd_partial_kernel, dim3(nch), dim3(256), (size_t)CH * L * sizeof(float), (hipStream_t)stream,
                        f, Tf, B, L, mask_kind, v, part, part_op);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nsvd_evd_gather_heads(const float* gathered, int world, int B, int L_local, int mask_kind,
+                                     const float* v, float* f, float* Tf, void* scratch, void* stream) {
+    if (!gathered || !f || !Tf || world <= 0 || B <= 0 || L_local <= 0) return NSVD_EINVAL;
+    const int L = world * L_local;
+    if (L > MAXL) return NSVD_EUNSUPPORTED;
+    if (scratch && mask_kind == NSVD_MASK_CUSTOM && !v) return NSVD_EINVAL;
+    if (mask_kind < 0 || mask_kind > NSVD_MASK_JOINT) return NSVD_EINVAL;
+    const Chunking c = chunking(B);
+    const int nch = c.n1 + c.n2;
+    float* part = (float*)scratch;
+    float* part_op = part ? part + (size_t)nch * L * L : nullptr;
+    hipLaunchKernelGGL(evd_gather_heads_kernel, dim3(nch), dim3(256), (size_t)CH * L * sizeof(float),
+                       (hipStream_t)stream, gathered, world, B, L_local, mask_kind, v, f, Tf, part, part_op);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

@@ -327,6 +327,19 @@ def evd_partial(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[t
     check(rc, "nsvd_evd_partial")
 
 
+def evd_gather_heads(gathered: torch.Tensor, f: torch.Tensor, Tf: torch.Tensor, mask_kind: int,
+                     v: Optional[torch.Tensor], scratch: Optional[torch.Tensor] = None) -> None:
+    """gathered (world, 2, B, L_local) packed [f | Tf] blocks of the ranks -> f, Tf (B, world * L_local); with
+    scratch also the partial moments of evd_partial(f, Tf) (same bits), in one launch."""
+    W, two, B, Ll = gathered.shape
+    if two != 2 or tuple(f.shape) != (B, W * Ll) or tuple(Tf.shape) != (B, W * Ll):
+        raise NsvdError("evd_gather_heads: gathered (world, 2, B, L_local), f / Tf (B, world * L_local)")
+    rc = _lib.load().nsvd_evd_gather_heads(_ptr(gathered, "gathered"), int(W), int(B), int(Ll), int(mask_kind),
+                                           _ptr(v, "v"), _ptr(f, "f"), _ptr(Tf, "Tf"),
+                                           scratch.data_ptr() if scratch is not None else None, _stream())
+    check(rc, "nsvd_evd_gather_heads")
+
+
 def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, f: torch.Tensor,
                           Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor], M: Optional[torch.Tensor],
                           moments: torch.Tensor, moments_reduced: bool, evd_scratch: Optional[torch.Tensor],

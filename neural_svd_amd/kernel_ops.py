@@ -170,7 +170,7 @@ class FusedKernelTrainer:
                     self.comm.all_gather(self.gath, self.fKf_loc)  # blocking: on the compute stream (parallel.dp_step)
             else:
                 self.comm.all_gather(self.gath, self.fKf_loc)
-            self.fKf.view(2, self.B, self.world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
+            H.evd_gather_heads(self.gath, self.f, self.Kf, self.mask_kind, self.v)
         # the reduced moment vector (partials + one reduction launch): at B = 8192 every workgroup of the backward
         # summing the 128 per-chunk partials of its 2 L moments itself would cost 3 x the reduction
         H.evd_moments(self.f, self.Kf, self.mask_kind, self.v, self.moments, self.scratch)

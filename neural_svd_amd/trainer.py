@@ -220,6 +220,7 @@ class FusedTrainer:
         self._ws_other = H.new_workspace(shape, self.B, self.device) if two_sets else None
         self._x_other = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device) \
             if two_sets else None
+        self._partials_ready = False  # the scratch already holds the partial moments of the current f_g, Tf_g
         self._next_ready = False     # the other set already holds the next batch and its features
         self._features_ready = False  # the current set holds the features of the batch being stepped on
         self._own_batch = False      # the batch being stepped on came from the internal device sampler
@@ -332,6 +333,8 @@ class FusedTrainer:
         elif self.direct_moments:
             moments = scratch = loss = None
             self._loss_stale = True
+        elif self._partials_ready:
+            self._partials_ready = False  # left by after_gather (heads sharded), for this f, Tf
         else:
             H.evd_partial(self.f_g, self.Tf_g, self.mask_kind, v, self.scratch)
         x = self._x_cur
@@ -442,7 +445,12 @@ class FusedTrainer:
         return self.gath, self.fTf_loc
 
     def after_gather(self) -> None:
-        self.fTf_g.view(2, self.B, self.world, self.shape.L).copy_(self.gath.permute(1, 2, 0, 3))
+        """the ranks' gathered [f | Tf] blocks -> the (B, L) arrays the backward reads; beyond 1024 rows (where the
+        backward wants per-chunk partial moments) those leave the same launch (nsvd_evd_gather_heads)"""
+        v, _ = self._masks()
+        want_partials = not self.direct_moments
+        H.evd_gather_heads(self.gath, self.f_g, self.Tf_g, self.mask_kind, v, self.scratch if want_partials else None)
+        self._partials_ready = want_partials
 
     def prefetch(self) -> None:
         """Draw batch t+1 and write its features into the other (workspace, x) set - no weight is involved."""

@@ -868,3 +868,27 @@ def test_head_sharded_backward_at_the_multi_gpu_rank_shape(world, rank):
     assert rel(loss_loc, loss_full) < 1e-6
     for i, (a, b) in enumerate(zip(g_loc, g_full)):
         assert torch.isfinite(a).all() and rel(a, b[sl]) < 5e-6, (i, rel(a, b[sl]))
+
+
+@pytest.mark.parametrize("W,B,Ll,kind", [(4, 96, 3, "seq"), (8, 4096, 2, "joint"), (2, 1280, 5, "custom"), (1, 64, 4, "seq")])
+def test_gather_heads_is_the_permuting_copy_plus_evd_partial(W, B, Ll, kind):
+    """nsvd_evd_gather_heads: the all-gathered (world, 2, B, L_local) blocks -> f, Tf (B, L) bit for bit what a permuting
+    copy gives, and its partial moments bit for bit those of nsvd_evd_partial on that f, Tf."""
+    L = W * Ll
+    g = torch.Generator().manual_seed(W * B)
+    gath = torch.randn(W, 2, B, Ll, generator=g).to(DEV)
+    want = gath.permute(1, 2, 0, 3).reshape(2, B, L).contiguous()
+    v, M = (O.sequential_nesting_masks(L) if kind != "joint" else O.joint_nesting_masks(L, 1))
+    mk = {"seq": H.MASK_SEQUENTIAL, "joint": H.MASK_JOINT, "custom": H.MASK_CUSTOM}[kind]
+    vd = v.float().to(DEV) if kind == "custom" else None
+    f, Tf = torch.empty(B, L, device=DEV), torch.empty(B, L, device=DEV)
+    s1, s2 = H.evd_scratch(B, L, DEV), H.evd_scratch(B, L, DEV)
+    s1.zero_(); s2.zero_()
+    H.evd_gather_heads(gath, f, Tf, mk, vd, s1)
+    H.evd_partial(want[0], want[1], mk, vd, s2)
+    torch.cuda.synchronize()
+    assert torch.equal(f, want[0]) and torch.equal(Tf, want[1])
+    assert torch.equal(s1, s2)
+    f2, Tf2 = torch.zeros(B, L, device=DEV), torch.zeros(B, L, device=DEV)
+    H.evd_gather_heads(gath, f2, Tf2, mk, vd, None)  # copy only
+    assert torch.equal(f2, want[0]) and torch.equal(Tf2, want[1])
