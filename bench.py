@@ -822,7 +822,7 @@ def main():
         "config": {"workload": "configs[1]: 2D hydrogen, L=16, batch_size=512 per GPU, joint nesting, "
                                "MLP 2048(Fourier m=1024)->128->128->128->1 x16 heads, eps=0.01, RMSprop+cosine+EMA",
                    "global_batch": cfg["B"] * world,
-                   "parallelism": (f"{par}{world}" if world > 1 else "dp1"),
+                   "parallelism": (f"{par}{world}" if multi else "dp1"),
                    "sharding": sharding[par] if multi else "single GPU: no exchange",
                    "optimiser": ("RMSprop+EMA step fused into the weight-gradient kernel" if fused_step else
                                  "separate RMSprop+EMA kernel per gradient bucket after its all-reduce"),
