@@ -365,6 +365,17 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, i
 int nsvd_tower_backward(const float* x, const nsvd_tower_params* params, const float* dz, int B, int d0, int d1,
                         int d2, float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws, size_t ws_bytes,
                         void* stream);
+/* A tower whose HIDDEN width is sharded over processes (rank r holds rows [r d1/W, (r+1) d1/W) of W1, b1 and the
+ * first BatchNorm, and the same columns of W2; b2 and the second BatchNorm are replicated): d1 is the LOCAL width.
+ * BatchNorm statistics are per column, so the first half needs no exchange and the arithmetic is the unsharded tower's
+ * (the reference's is single-process: examples/models/mlp.py:129-164). phase 1: Linear1, BatchNorm1, activation and this
+ * rank's PARTIAL product A1 W2^T (no bias) into the workspace at nsvd_tower_y2_offset - (B, d2) floats the caller sums
+ * over the ranks in place (one all-reduce); phase 2: + b2, BatchNorm2 -> z. phase 0 = nsvd_tower_forward. The
+ * backward (nsvd_tower_backward with the local d1) needs no exchange: dz is replicated, every other quantity local. */
+size_t nsvd_tower_y2_offset(int B, int d0, int d1, int d2);
+int nsvd_tower_forward_phase(const float* x, const nsvd_tower_params* params, int B, int d0, int d1, int d2,
+                             float slope, float eps, float momentum, int update_running, int gemm_bf16, int phase,
+                             float* z, void* ws, size_t ws_bytes, void* stream);
 
 /* nsvd_operator_backward_evd_step that ALSO draws the next batch and writes its Fourier features - what
  * nsvd_operator_sample_features(next_seed, next_offset, x_next, ws_next) does as a launch of its own - as guest

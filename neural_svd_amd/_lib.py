@@ -110,6 +110,8 @@ SIGNATURES = {
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
     "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "nsvd_tower_forward": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _P, _P, _Z, _P]),
+    "nsvd_tower_forward_phase": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _P, _P, _Z, _P]),
+    "nsvd_tower_y2_offset": (_Z, [_I, _I, _I, _I]),
     "nsvd_cdk_step_workspace_bytes": (_Z, [C.POINTER(CdkStepDesc)]),
     "nsvd_cdk_step": (_I, [C.POINTER(CdkStepDesc), _P, _P, C.POINTER(TowerParams), C.POINTER(TowerParams), _P, _P, _P,
                            _P, _P, _P, _Z, _P]),

@@ -424,3 +424,153 @@ class FusedCdkStep:
                 t[1].num_batches_tracked += self._pending
                 t[4].num_batches_tracked += self._pending
             self._pending = 0
+
+
+class ShardedCdkStep:
+    """The Sketchy training step on several GPUs with the towers' HIDDEN width sharded (one process per GPU,
+    ``comm`` = parallel.Communicator): rank r holds rows [r d1/W, (r+1) d1/W) of Linear1 / BatchNorm1 and the same
+    columns of Linear2 of BOTH towers; Linear2's bias and BatchNorm2 are replicated. BatchNorm statistics are per column,
+    so the arithmetic is the single-process step's on the same batch (the reference is single-process:
+    examples/cdk/sketchy/main_sketchy.py:180-212) with TWO collectives per step:
+      1. all-reduce(sum) of the two towers' partial products A1 W2^T, packed (2, B, d2) floats (4 MB at configs[4]);
+      2. all-reduce(sum) of one float: the squared gradient norm of the sharded tensors (the replicated ones counted once)
+         for clip_grad_norm_.
+    No gradient traffic: every weight gradient is local to the rank that owns the slice; the replicated parameters get
+    identical gradients on every rank. The batch is the same on every rank (strong scaling: the work of one step is
+    split W ways). Stage calls of the C ABI (nsvd_tower_forward_phase, nsvd_row_normalize_*, nsvd_cdk_loss_*,
+    nsvd_tower_backward) + torch for the clip coefficient and the momentum update of the local tensors.
+    ``gather_into_model()`` writes the whole parameters and running statistics back into ``method.model``."""
+
+    SHARDED = ("W1", "b1", "g1", "be1", "rm1", "rv1")   # rows of the hidden width
+    REPLICATED = ("b2", "g2", "be2", "rm2", "rv2")
+
+    def __init__(self, method: "NestedLoRAForCDK", comm, lr: float, momentum: float = 0.9, max_grad_norm: float = 1.0,
+                 t_max: int = 0, batch_size: int = 1024, use_amp: bool = False):
+        ok, why = FusedCdkStep.supported(method, batch_size)
+        if not ok:
+            raise H.NsvdError(f"ShardedCdkStep: {why}")
+        self.method, self.model, self.comm = method, method.model, comm
+        W, r = comm.world, comm.rank
+        tx = self.model.backbones["x"]
+        self.B, self.d0, d1, self.d2 = int(batch_size), tx[0].in_features, tx[0].out_features, tx[3].out_features
+        if d1 % (128 * W) != 0:
+            raise H.NsvdError(f"ShardedCdkStep: hidden width {d1} must split into multiples of 128 over {W} ranks")
+        self.d1_full, self.d1 = d1, d1 // W
+        self.lo, self.hi = r * self.d1, (r + 1) * self.d1
+        self.lr0, self.momentum, self.max_grad_norm, self.t_max = float(lr), float(momentum), float(max_grad_norm or 0.0), int(t_max)
+        self.use_amp, self.t = bool(use_amp), 0
+        dev = tx[0].weight.device
+        self.towers, self.bufs = [], []
+        for side in HeteroNetwork.SIDES:
+            t = self.model.backbones[side]
+            lin1, bn1, lin2, bn2 = t[0], t[1], t[3], t[4]
+            sl = slice(self.lo, self.hi)
+            d = dict(W1=lin1.weight.data[sl].clone(), b1=lin1.bias.data[sl].clone(), g1=bn1.weight.data[sl].clone(),
+                     be1=bn1.bias.data[sl].clone(), rm1=bn1.running_mean[sl].clone(), rv1=bn1.running_var[sl].clone(),
+                     W2=lin2.weight.data[:, sl].contiguous(), b2=lin2.bias.data.clone(), g2=bn2.weight.data.clone(),
+                     be2=bn2.bias.data.clone(), rm2=bn2.running_mean.clone(), rv2=bn2.running_var.clone())
+            self.towers.append(d)
+            self.bufs.append({k: torch.zeros_like(v) for k, v in d.items() if not k.startswith("r")})
+        self.slope, self.bn_eps, self.bn_momentum = float(tx.slope), float(tx[1].eps), float(tx[1].momentum)
+        self.mode = H._lib.NORMALIZE_L2_BALL if self.model.regularize_mode == "l2_ball" else H._lib.NORMALIZE_L2_SPHERE
+        self.r_up = float(self.model.mu) ** 0.5
+        self.v = method.vector_mask.detach().float().to(dev).contiguous()
+        self.M = method.matrix_mask.detach().float().to(dev).contiguous()
+        self.first_const = bool(method.set_first_mode_const)
+        self.loss = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.ws = [H.tower_workspace(self.B, self.d0, self.d1, self.d2, dev) for _ in HeteroNetwork.SIDES]
+        self.y2 = [H.tower_y2(w, self.B, self.d0, self.d1, self.d2) for w in self.ws]
+        self.y2_packed = torch.empty((2, self.B, self.d2), dtype=torch.float32, device=dev)
+        self.cdk_ws = H.cdk_workspace(self.B, self.d2, self.first_const, dev)
+        self.ge = [torch.empty((self.B, self.d2), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.norm2 = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.probe = None  # parallel.CommProbe while bench.py measures the exposed waits
+
+    def current_lr(self) -> float:
+        if self.t_max <= 0:
+            return self.lr0
+        return self.lr0 * (1.0 + math.cos(math.pi * self.t / self.t_max)) / 2.0
+
+    def _span(self, name):
+        import contextlib
+        return self.probe.span(name) if self.probe is not None else contextlib.nullcontext()
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """one training step on the batch (x, y) - the SAME batch on every rank; returns the device tensor (loss,
+        operator term, metric term, total gradient norm before clipping)"""
+        B, d0, d1, d2 = self.B, self.d0, self.d1, self.d2
+        xs = (x.float().contiguous(), y.float().contiguous())
+        for t in range(2):  # Linear1, BatchNorm1, activation, this rank's partial A1 W2^T
+            H.tower_forward(xs[t], self.towers[t], self.slope, self.bn_eps, self.bn_momentum, True, self.ws[t],
+                            gemm_bf16=self.use_amp, phase=1)
+            self.y2_packed[t].copy_(self.y2[t])
+        with self._span("y2_partials_allreduce"):
+            self.comm.all_reduce_sum(self.y2_packed)          # collective 1: (2, B, d2) floats
+        zs, es = [], []
+        for t in range(2):  # + b2, BatchNorm2, normalisation
+            self.y2[t].copy_(self.y2_packed[t])
+            z = H.tower_forward(xs[t], self.towers[t], self.slope, self.bn_eps, self.bn_momentum, True, self.ws[t],
+                                gemm_bf16=self.use_amp, phase=2)
+            zs.append(z)
+            es.append(H.row_normalize(z, self.r_up, self.mode))
+        H.cdk_loss_forward(es[0], es[1], None, self.v, self.M, self.first_const, self.loss, None, None, self.cdk_ws)
+        H.cdk_loss_backward(self.v, B, d2, self.first_const, None, self.ge[0], self.ge[1], self.cdk_ws)
+        grads = []
+        for t in range(2):
+            dz = H.row_normalize_backward(zs[t], self.ge[t], self.r_up, self.mode)
+            grads.append(H.tower_backward(xs[t], self.towers[t], dz, self.slope, self.ws[t], gemm_bf16=self.use_amp))
+        # total gradient norm: the sharded tensors' squares summed over the ranks, the replicated ones counted once
+        sharded = [g[k] for g in grads for k in ("W1", "b1", "g1", "be1", "W2")]
+        repl = [g[k] for g in grads for k in ("b2", "g2", "be2")]
+        n2 = torch.stack([t.double().pow(2).sum() for t in sharded]).sum()
+        if self.comm.rank == 0:
+            n2 = n2 + torch.stack([t.double().pow(2).sum() for t in repl]).sum()
+        self.norm2.copy_(n2.reshape(1))
+        with self._span("grad_norm_allreduce"):
+            self.comm.all_reduce_sum(self.norm2)                # collective 2: one float64
+        total = self.norm2.sqrt().float()
+        coef = torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0) if self.max_grad_norm > 0 else torch.ones_like(total)
+        lr = self.current_lr()
+        for P, Bf, g in zip(self.towers, self.bufs, grads):
+            keys = list(g.keys())
+            gs = [g[k] * coef for k in keys]
+            bs = [Bf[k] for k in keys]
+            if self.t == 0:
+                torch._foreach_copy_(bs, gs)
+            else:
+                torch._foreach_mul_(bs, self.momentum)
+                torch._foreach_add_(bs, gs)
+            torch._foreach_add_([P[k] for k in keys], bs, alpha=-lr)
+        self.loss[3:4].copy_(total)
+        self.t += 1
+        if self.probe is not None:
+            self.probe.step_done()
+        return self.loss
+
+    @torch.no_grad()
+    def gather_into_model(self) -> None:
+        """the whole parameters, momentum-free, and running statistics -> method.model on every rank"""
+        W = self.comm.world
+        for side, P in zip(HeteroNetwork.SIDES, self.towers):
+            t = self.model.backbones[side]
+            lin1, bn1, lin2, bn2 = t[0], t[1], t[3], t[4]
+
+            def rows(v):
+                out = torch.empty((W,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+                self.comm.all_gather(out, v.contiguous())
+                return out.view((W * v.shape[0],) + tuple(v.shape[1:]))
+            lin1.weight.data.copy_(rows(P["W1"]))
+            lin1.bias.data.copy_(rows(P["b1"]))
+            bn1.weight.data.copy_(rows(P["g1"]))
+            bn1.bias.data.copy_(rows(P["be1"]))
+            bn1.running_mean.copy_(rows(P["rm1"]))
+            bn1.running_var.copy_(rows(P["rv1"]))
+            lin2.weight.data.copy_(rows(P["W2"].t().contiguous()).t())  # columns of W2 = rows of W2^T
+            lin2.bias.data.copy_(P["b2"])
+            bn2.weight.data.copy_(P["g2"])
+            bn2.bias.data.copy_(P["be2"])
+            bn2.running_mean.copy_(P["rm2"])
+            bn2.running_var.copy_(P["rv2"])
+            bn1.num_batches_tracked.fill_(self.t)
+            bn2.num_batches_tracked.fill_(self.t)

@@ -542,10 +542,24 @@ size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2) {
     return carve_tower(B, d0, d1, d2, nullptr).bytes;
 }
 
+size_t nsvd_tower_y2_offset(int B, int d0, int d1, int d2) {
+    if (!tower_shape_ok(B, d0, d1, d2)) return 0;
+    const TowerWs w = carve_tower(B, d0, d1, d2, nullptr);
+    return (size_t)((char*)w.Y2 - (char*)nullptr);
+}
+
 int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0, int d1, int d2, float slope,
                        float eps, float momentum, int update_running, int gemm_bf16, float* z, void* ws,
                        size_t ws_bytes, void* stream) {
-    if (!x || !p || !z || !ws || !tower_shape_ok(B, d0, d1, d2)) return NSVD_EINVAL;
+    return nsvd_tower_forward_phase(x, p, B, d0, d1, d2, slope, eps, momentum, update_running, gemm_bf16, 0, z, ws,
+                                    ws_bytes, stream);
+}
+
+int nsvd_tower_forward_phase(const float* x, const nsvd_tower_params* p, int B, int d0, int d1, int d2, float slope,
+                             float eps, float momentum, int update_running, int gemm_bf16, int phase, float* z,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (phase < 0 || phase > 2) return NSVD_EINVAL;
+    if (!x || !p || (!z && phase != 1) || !ws || !tower_shape_ok(B, d0, d1, d2)) return NSVD_EINVAL;
     if (!p->W1 || !p->b1 || !p->g1 || !p->be1 || !p->W2 || !p->b2 || !p->g2 || !p->be2) return NSVD_EINVAL;
     if (update_running && (!p->rm1 || !p->rv1 || !p->rm2 || !p->rv2)) return NSVD_EINVAL;
     const TowerWs w = carve_tower(B, d0, d1, d2, ws);
@@ -556,15 +570,25 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
     Mixed mx;
     mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB;
     int rc = 0;
-    // Y1 = X W1^T + b1
     GemmNT g;
+    BnFwd f;
+    if (phase == 2) {
+        // second half of a hidden-width-sharded tower: w.Y2 holds the SUM over the ranks of the partial products (the
+        // caller all-reduced it in place); the bias joins here and the biased sum is written back for the backward
+        memset(&f, 0, sizeof(f));
+        f.Y = w.Y2; f.S = 1; f.bias = p->b2; f.Ysum = w.Y2; f.gamma = p->g2; f.beta = p->be2;
+        f.running_mean = update_running ? p->rm2 : nullptr; f.running_var = update_running ? p->rv2 : nullptr;
+        f.mean = w.mean2; f.invstd = w.inv2; f.out = z; f.outT = nullptr; f.B = B; f.N = d2;
+        f.eps = eps; f.momentum = momentum; f.slope = 1.0f;
+        return launch_bn_forward(f, s);
+    }
+    // Y1 = X W1^T + b1
     memset(&g, 0, sizeof(g));
     g.A = x; g.lda = d0; g.B = p->W1; g.ldb = d0; g.C = w.Y1; g.ldc = d1; g.bias = p->b1;
     g.M = B; g.N = d1; g.K = d0; g.S = 1;
     rc = launch_gemm(g, s, mx, true);  // bench.py --config cfg5 brackets this contraction (nsvd_profile_next_forward)
     if (rc) return rc;
     // A1 = lrelu(BN1(Y1)), A1^T
-    BnFwd f;
     memset(&f, 0, sizeof(f));
     f.Y = w.Y1; f.S = 1; f.gamma = p->g1; f.beta = p->be1;
     f.running_mean = update_running ? p->rm1 : nullptr; f.running_var = update_running ? p->rv1 : nullptr;
@@ -584,9 +608,10 @@ int nsvd_tower_forward(const float* x, const nsvd_tower_params* p, int B, int d0
     {
         const size_t n4 = (size_t)B * d2 / 4;
         hipLaunchKernelGGL(tower_sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w.Y2p,
-                           (size_t)B * d2, S, p->b2, w.Y2, d2, n4);
+                           (size_t)B * d2, S, phase == 1 ? nullptr : p->b2, w.Y2, d2, n4);
         NSVD_CHECK_LAUNCH();
     }
+    if (phase == 1) return 0;  // this rank's partial Y2 (no bias) is in the workspace: nsvd_tower_y2_offset
     memset(&f, 0, sizeof(f));
     f.Y = w.Y2; f.S = 1; f.gamma = p->g2; f.beta = p->be2;
     f.running_mean = update_running ? p->rm2 : nullptr; f.running_var = update_running ? p->rv2 : nullptr;

@@ -617,10 +617,19 @@ def _tower_struct(t: dict, need_running: bool) -> "_lib.TowerParams":
     return p
 
 
+def tower_y2(ws: torch.Tensor, B: int, d0: int, d1: int, d2: int) -> torch.Tensor:
+    """the (B, d2) float32 view of a tower workspace where phase 1 leaves this rank's partial A1 W2^T (hidden width
+    sharded over processes): all-reduce it in place between tower_forward(phase=1) and tower_forward(phase=2)"""
+    off = int(_lib.load().nsvd_tower_y2_offset(int(B), int(d0), int(d1), int(d2)))
+    return ws[off:off + 4 * B * d2].view(torch.float32).view(B, d2)
+
+
 def tower_forward(x: torch.Tensor, params: dict, slope: float, eps: float, momentum: float, update_running: bool,
-                  ws: torch.Tensor, gemm_bf16: bool = False) -> torch.Tensor:
+                  ws: torch.Tensor, gemm_bf16: bool = False, phase: int = 0) -> Optional[torch.Tensor]:
     """z = BN2(Linear2(lrelu(BN1(Linear1(x))))) in training mode; params: dict over TOWER_KEYS (torch layouts).
-    gemm_bf16: mixed precision - the contractions' operands rounded to bfloat16, float32 accumulation (nsvd.h)."""
+    gemm_bf16: mixed precision - the contractions' operands rounded to bfloat16, float32 accumulation (nsvd.h).
+    phase (hidden width sharded over processes, params = this rank's slices): 1 = up to the partial product in
+    tower_y2(ws, ...) (returns None), 2 = bias + second BatchNorm from the all-reduced tower_y2; 0 = the whole tower."""
     B, d0 = x.shape
     d1, d2 = params["W1"].shape[0], params["W2"].shape[0]
     if tuple(params["W1"].shape) != (d1, d0) or tuple(params["W2"].shape) != (d2, d1):
@@ -628,11 +637,11 @@ def tower_forward(x: torch.Tensor, params: dict, slope: float, eps: float, momen
     for k, n in (("b1", d1), ("g1", d1), ("be1", d1), ("b2", d2), ("g2", d2), ("be2", d2)):
         if params[k].numel() != n:
             raise NsvdError(f"tower_forward: {k} must have {n} elements")
-    z = torch.empty((B, d2), dtype=torch.float32, device=x.device)
+    z = torch.empty((B, d2), dtype=torch.float32, device=x.device) if phase != 1 else None
     p = _tower_struct(params, bool(update_running))
-    rc = _lib.load().nsvd_tower_forward(_ptr(x, "x"), C.byref(p), B, d0, d1, d2, float(slope), float(eps),
-                                        float(momentum), int(bool(update_running)), int(bool(gemm_bf16)),
-                                        _ptr(z, "z"), ws.data_ptr(), ws.numel(), _stream())
+    rc = _lib.load().nsvd_tower_forward_phase(_ptr(x, "x"), C.byref(p), B, d0, d1, d2, float(slope), float(eps),
+                                              float(momentum), int(bool(update_running)), int(bool(gemm_bf16)),
+                                              int(phase), _ptr(z, "z"), ws.data_ptr(), ws.numel(), _stream())
     check(rc, "nsvd_tower_forward")
     return z
 

@@ -81,6 +81,22 @@ def dropin_blocks():
     return [4.0 * torch.randn(32, 2, generator=g) for _ in range(16)]
 
 
+def cdk_case(dev):
+    """the Sketchy-style CDK objects (two towers 128 -> 512 -> 128, l2_ball, NestedLoRAForCDK) and three (x, y) batches"""
+    import torch.nn as nn
+    from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
+    torch.manual_seed(17)
+    sizes = [128, 512, 128]
+    model = HeteroNetwork([get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True),
+                           get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True)],
+                          [nn.Identity(), nn.Identity()], mu=16.0, regularize_mode="l2_ball").to(dev).train()
+    method = NestedLoRAForCDK(model, neigs=sizes[-1], step=1, sequential=False, set_first_mode_const=True).to(dev)
+    g = torch.Generator().manual_seed(18)
+    xs = [torch.randn(128, 128, generator=g).to(dev) for _ in range(3)]
+    ys = [torch.randn(128, 128, generator=g).to(dev) for _ in range(3)]
+    return model, method, xs, ys
+
+
 def main():
     mode, out_dir = sys.argv[1], sys.argv[2]
     if mode.endswith("_big"):  # batches beyond 1024 rows: the backward takes partial moment sums instead of f itself
@@ -166,6 +182,16 @@ def main():
         res.update(sd={k: v.detach().cpu() for k, v in method.state_dict().items()}, eig=eig[-1], norms=norms[-1])
         torch.save(res, os.path.join(out_dir, f"{sys.argv[1]}_r{rank}.pt"))
         return
+    elif mode in ("cdk_tp", "cdk_tp_amp"):
+        # the CDK training step with the towers' hidden width sharded over the ranks (cdk.ShardedCdkStep)
+        from neural_svd_amd.cdk import ShardedCdkStep
+        model, method, xs, ys = cdk_case(dev)
+        st = ShardedCdkStep(method, comm, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=0, batch_size=128,
+                            use_amp=mode.endswith("amp"))
+        res["losses"] = [st.step(xs[t], ys[t]).clone().cpu() for t in range(3)]
+        st.gather_into_model()
+        res["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        res["d1_local"] = st.d1
     elif mode == "rccl1":
         # ONE rank on the real collective library (backend "nccl" = RCCL): the exchange sequences forced on in a world
         # of one, so that every RCCL call of the product path - argument views, in-place gathers, AVG, async work

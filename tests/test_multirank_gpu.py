@@ -303,3 +303,36 @@ def test_reference_style_loop_on_two_ranks(tmp_path):
         assert torch.equal(dp[0]["sd"][k], dp[1]["sd"][k]), k
         assert bool(torch.isfinite(dp[0]["sd"][k]).all())
     assert any(not torch.equal(dp[0]["sd"][k], init[k]) for k in ref)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,amp", [(2, False), (4, False), (2, True)])
+def test_cdk_step_with_the_hidden_width_sharded_matches_single_process(tmp_path, world, amp):
+    """cdk.ShardedCdkStep: both towers' hidden width split over `world` ranks (BatchNorm statistics are per column: no
+    exchange for them), one all-reduce of the partial second-layer products and one of a scalar per step - three
+    training steps reproduce the single-process FusedCdkStep on the same batches: losses, gradient norms and, after
+    gather_into_model(), every parameter and running statistic, identical on all ranks. amp: the mixed-precision mode."""
+    rs = run_ranks("cdk_tp_amp" if amp else "cdk_tp", world, tmp_path)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _multirank_worker as W
+    from neural_svd_amd.cdk import FusedCdkStep
+    dev = torch.device("cuda:0")
+    model, method, xs, ys = W.cdk_case(dev)
+    init = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    fs = FusedCdkStep(method, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=0, batch_size=128, use_amp=amp)
+    losses = [fs.step(xs[t], ys[t]).clone().cpu() for t in range(3)]
+    fs.flush_counters()
+    ref = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    tol = 2e-3 if amp else 2e-5  # (mixed: a partial sum that differs in the last bit moves a bfloat16 rounding now and then)
+    for r in rs:
+        assert r["d1_local"] == 512 // world
+        for t in range(3):
+            assert rel(r["losses"][t][:3], losses[t][:3]) < tol and rel(r["losses"][t][3:], losses[t][3:]) < tol
+        for k in ref:
+            assert torch.equal(r["sd"][k], rs[0]["sd"][k]), k
+            if ref[k].dtype.is_floating_point:
+                moved = float((ref[k].double() - init[k].double()).norm())
+                d = float((r["sd"][k].double() - ref[k].double()).norm())
+                assert d <= 10 * tol * moved + 1e-6 * float(ref[k].double().norm()), (k, d, moved)
+            else:
+                assert torch.equal(r["sd"][k], ref[k]), k
