@@ -372,6 +372,7 @@ def bench_widened(args):
     warmup = min(args.warmup, 20)
     repeats = args.repeats or 5
     comm_block = None
+    strong = False  # cfg5 on several ranks splits the work of ONE step: value = steps / time, not N x that
     if args.config == "cfg4":
         from neural_svd_amd.kernel_ops import FusedKernelTrainer, synthetic_psd_kernel
         N, D, L = 10000, 16, 64
@@ -400,9 +401,6 @@ def bench_widened(args):
                 "against it on the fp32 MFMA); model forward / backward on the E = 1 MFMA kernels; d loss / d f and the "
                 "RMSprop step inside the backward kernels (nsvd_model_backward_evd_step): no torch autograd, no torch.optim")
     else:
-        if world != 1:
-            raise SystemExit("--config cfg5 is a single-GPU measurement (the towers' BatchNorm takes its statistics "
-                             "over the whole batch: DESIGN.md 6)")
         import torch.nn as nn
         from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
         B, d0, d1, d2, L = args.batch_size or 1024, 512, 8192, 512, 512
@@ -416,12 +414,20 @@ def bench_widened(args):
         last = {}
         # the whole step - towers, normalisation, loss, clip_grad_norm_(1.0), SGD momentum, cosine schedule - is ONE C
         # call (nsvd_cdk_step) on the modules' own parameters
-        fused = FusedCdkStep(method, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=10 * 30, batch_size=B,
-                             use_amp=args.amp)
+        if comm is None:
+            fused = FusedCdkStep(method, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=10 * 30, batch_size=B,
+                                 use_amp=args.amp)
+        else:
+            # several ranks: the towers' hidden width sharded (cdk.ShardedCdkStep): the SAME batch and the same
+            # arithmetic, the work of a step split N ways - strong scaling; two collectives per step
+            from neural_svd_amd.cdk import ShardedCdkStep
+            strong = True
+            fused = fk = ShardedCdkStep(method, comm, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=10 * 30,
+                                        batch_size=B, use_amp=args.amp)
 
         def step():
             last["loss"] = fused.step(x, y)[0]
-        kflops = 2.0 * B * d0 * d1
+        kflops = 2.0 * B * d0 * (d1 // world)
         kname = "tower_gemm_nt_kernel"
         workload = (f"configs[4]: CDK step on synthetic features x, y ~ randn({B}, {d0}): two towers {d0} -> {d1} -> "
                     f"{d2} (Linear-BatchNorm-lrelu0.2-Linear-BatchNorm), l2_ball mu = 16, NestedLoRAForCDK L = {L} + "
@@ -436,8 +442,8 @@ def bench_widened(args):
     use_ev = not args.no_kernel_events
     blocks, kms, n_pre = _timed_blocks(step, steps, warmup, repeats, args.prewarm_seconds,
                                        H.profile_next_forward if use_ev else None, comm=comm)
-    summ = summarize(blocks, steps, world)
-    if comm is not None:  # where the sharded step's time goes: the exposed all-gather, and the step without it
+    summ = summarize(blocks, steps, 1 if strong else world)
+    if comm is not None:  # where the sharded step's time goes: the exposed collectives, and the step without them
         fk.probe = parallel.CommProbe(dev)
         for _ in range(50):
             step()
@@ -447,9 +453,12 @@ def bench_widened(args):
         comm.stub = True
         bl, _, _ = _timed_blocks(step, steps, warmup, 3, 0.2, None, comm=comm)
         comm.stub = False
-        co = summarize(bl, steps, world)
-        comm_block = {"backend": comm.backend, "exchange": "one blocking all-gather of [f | Kf] per step",
-                      "all_gather_bytes": 2 * B * L * 4,
+        co = summarize(bl, steps, 1 if strong else world)
+        comm_block = {"backend": comm.backend,
+                      "exchange": ("all-reduce of the two towers' partial second-layer products (2, B, d2) + all-reduce "
+                                   "of one float (gradient norm) per step" if strong else
+                                   "one blocking all-gather of [f | Kf] per step"),
+                      "exchange_bytes": (2 * B * d2 * 4 + 8) if strong else 2 * B * L * 4,
                       "exposed_wait_us_per_step": {k: round(v, 2) for k, v in waits.items()},
                       "compute_only_ms": co["ms_per_step"], "step_ms": summ["ms_per_step"],
                       "rccl_ranks": comm.count_ranks()}
@@ -466,7 +475,8 @@ def bench_widened(args):
                     kernel_avg_us=round(kavg * 1e3, 2), kernel_med_us=round(kms[len(kms) // 2] * 1e3, 2),
                     kernel_launches_timed=len(kms), kernel_flops=kflops)
     out = {"metric": metric, "value": summ["value"], "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-           "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
+           "vs_baseline": None,
            "dtype": "bf16 operands / f32 accumulation (tower contractions), f32 elsewhere"
                     if (args.config == "cfg5" and args.amp) else "f32", "data": "synthetic",
            "timing": {"blocks": summ["blocks"], "ms_per_step_min": summ["ms_per_step_min"],
@@ -474,10 +484,15 @@ def bench_widened(args):
            "config": {"workload": workload, "note": note, "developer_config": args.config,
                       "not_the_headline_workload": True},
            "final_loss": float(last["loss"]), "roofline": roof, "cpu_baseline": None}
-    if comm is not None:
+    if comm is not None and strong:
+        out["config"].update(global_batch=B, parallelism=f"tp{world}",
+                             sharding="hidden width of both towers: each GPU owns d1/N rows of Linear1 / BatchNorm1 and "
+                                      "the same columns of Linear2; the same batch on every GPU, no gradient traffic")
+    elif comm is not None:
         out["config"].update(global_batch=B, parallelism=f"hp{world}",
                              sharding="heads: each GPU owns L/N heads, evaluates them and applies K to them on the "
                                       "whole global batch; one all-gather of f, Kf per step, no gradient traffic")
+    if comm is not None:
         out["comm"] = comm_block
     print(json.dumps(out))
     if comm is not None:
@@ -535,9 +550,6 @@ def main():
                          "headline run and the other is reported beside it (`other_sharding`)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and args.config == "cfg5":
-        raise SystemExit("--config cfg5 is a single-GPU measurement (the towers' BatchNorm takes its statistics over "
-                         "the whole batch: DESIGN.md 6)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the launcher (nothing has touched the GPU yet) and never computes
         return self_launch(args, sys.argv[1:])

@@ -123,3 +123,24 @@ def test_bench_as_a_rank_under_torch_distributed_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] in ("dp2", "hp2") and d["value"] > 0 and d["params_finite"]
     assert d["rccl_ranks"] == 2 and "launcher_retry" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_bench_widened_rows_on_two_ranks(cfg):
+    """`bench.py --config cfg4 | cfg5 --gpus 2`: the kernel-operator step with heads sharded (weak scaling) and the CDK
+    step with the towers' hidden width sharded (strong scaling), self-launched, one line with its `comm` block"""
+    r = subprocess.run([sys.executable, BENCH, "--config", cfg, "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--collective-timeout", "120"],
+                       env=_env(NSVD_FORCE_DEVICE="0", NSVD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["final_loss"] == d["final_loss"]
+    assert d["scaling"] == ("weak" if cfg == "cfg4" else "strong")
+    assert d["config"]["parallelism"] == ("hp2" if cfg == "cfg4" else "tp2")
+    c = d["comm"]
+    assert c["rccl_ranks"] == 2 and c["compute_only_ms"] > 0 and len(c["exposed_wait_us_per_step"]) == (1 if cfg == "cfg4" else 2)
