@@ -139,12 +139,13 @@ def main():
         # seed=None: every rank draws different initial weights, rank 0's must win
         par = mode[:2]
         runs = []
-        for ov in (True, False):
-            torch.manual_seed(1234)  # same "unseeded" stream for both orderings of this rank
+        for ov, sy in ((True, False), (False, False), (True, True)):
+            # (the third ordering: blocking collectives - nothing prepared under them, hp's next batch rides in the backward)
+            torch.manual_seed(1234)  # same "unseeded" stream for every ordering of this rank
             torch.randn(rank + 1)    # ... but a different one per rank
             tr = FusedTrainer(shape, prob, CASE["B_local"], seed=None, sample_seed=9, device=dev, comm=comm,
-                              parallelism=par, overlap=ov, **kw)
-            assert tr.overlap == ov
+                              parallelism=par, overlap=ov, sync_collectives=sy, **kw)
+            assert tr.overlap == (ov and not sy) and tr.guest_features == (ov and par == "hp")
             init = tr.P.flat.clone().cpu()
             for _ in range(6):
                 tr.step()

@@ -182,9 +182,10 @@ def test_overlapped_prefetch_is_bit_identical_and_replicas_agree(tmp_path, mode)
     world = 2
     rs = run_ranks(mode, world, tmp_path)
     for r in rs:
-        ov, plain = r["runs"]
-        for k in ("init", "flat", "ema", "fB", "loss", "x"):
-            assert torch.equal(ov[k], plain[k]), k
+        ov, plain, blocking = r["runs"]
+        for k in ("init", "flat", "ema", "fB", "loss"):
+            assert torch.equal(ov[k], plain[k]) and torch.equal(blocking[k], plain[k]), k
+        assert torch.equal(ov["x"], plain["x"])
         assert ov["drawn"] == plain["drawn"] + 1 == 7  # one batch prepared ahead
         assert bool(torch.isfinite(ov["flat"]).all())
     a, b = rs[0]["runs"][0], rs[1]["runs"][0]
