@@ -17,7 +17,11 @@
  *   - the caller owns every buffer, including the workspace (size: nsvd_workspace_bytes);
  *     nothing here allocates, frees or synchronises;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), is safe to capture in
- *     a HIP graph, and keeps no global mutable state (re-entrant across streams / devices);
+ *     a HIP graph (no allocation, no synchronisation, no host read-back: tests/test_graph_gpu.py captures and
+ *     replays the training step), and keeps no global mutable state (re-entrant across streams / devices).
+ *     The scalars that change from step to step (scheduled learning rate, EMA decay, sampler counter) are kernel
+ *     ARGUMENTS in the plain entry points - a captured step replays them frozen - and live in device memory
+ *     when the caller passes a nsvd_step_state (below): that form replays a moving schedule;
  *   - return value: 0 on success, negative on error (-(int)hipError_t for HIP failures,
  *     NSVD_EINVAL / NSVD_EUNSUPPORTED for argument errors); no C++ exception crosses the ABI.
  *
@@ -42,7 +46,7 @@
 extern "C" {
 #endif
 
-#define NSVD_ABI_VERSION 1
+#define NSVD_ABI_VERSION 2
 #define NSVD_MAX_LAYERS 8
 
 #define NSVD_EINVAL (-10001)
@@ -104,7 +108,7 @@ typedef struct nsvd_problem {
 
 int nsvd_abi_version(void);
 
-/* Name of the implementation nsvd_operator_forward would take ("fused_h128x3", "generic"). host */
+/* Name of the implementation nsvd_operator_forward would take ("fused_mfma", "generic"). host */
 const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int path);
 /* The same for a given problem: the exact-Laplacian mode (prob->eps <= 0) exists on the MFMA path only (D <= 3, as the
  * stencil mode: its 3-D form runs one direction per workgroup); "unsupported" when it has no path. */
@@ -218,7 +222,9 @@ int nsvd_evd_gather_heads(const float* gathered, int world, int B, int L_local, 
  *     same f, Tf) are reduced on the fly and the reduced vector is stored here.
  *   - ignored (may be NULL) when moments_reduced == 0 and evd_scratch == NULL ("direct" form, MFMA path only):
  *     every workgroup of the backward takes the 2 L moments of its own head from f itself, no moment kernel
- *     runs at all, and neither `moments` nor `loss` is written (use nsvd_evd_loss_fused when the value is wanted).
+ *     runs at all and `moments` is not written. `loss` (when not NULL, all heads local, one head window) IS: the
+ *     workgroups leave per-head partial sums of the two loss terms and the weight-gradient kernel adds them in head
+ *     order - the loss value of every step (the reference's loss.item(), examples/operator/__init__.py:74) at no launch.
  * loss[0..2] = {loss, operator term, metric term}. Gradients are overwritten as in nsvd_operator_backward.
  * Head-parallel sharding: f, Tf, v, M and the moments may cover L_total >= desc->L heads, of which this
  * model owns [l_offset, l_offset + desc->L) (f, Tf are then (B, L_total), gathered from all ranks); pass
@@ -256,11 +262,18 @@ int nsvd_backward_head_window_ok(const nsvd_model_desc* desc, const nsvd_problem
  * calls. grads may be NULL on the fused path (gradients are then not stored at all); on the generic path grads
  * is required and the step is taken by per-tensor optimiser launches. lr / ema_decay are the already scheduled
  * values, as for nsvd_rmsprop_ema_step. Not for data-parallel runs (gradients must be all-reduced first). */
+typedef struct nsvd_step_state nsvd_step_state;  /* device-resident schedule state, declared below */
 typedef struct nsvd_rmsprop {
     nsvd_params sq;                  /* RMSprop square averages, parameter layouts      */
     nsvd_params ema;                 /* EMA shadow parameters (ignored unless has_ema)  */
     double lr, alpha, eps, ema_decay;
     int32_t has_ema;
+    /* NULL: lr / ema_decay above are the already scheduled values of this step (kernel arguments).
+     * Non-NULL (DEVICE pointer, nsvd_step_state_init): lr, alpha, eps, ema_decay above are ignored; the first
+     * backward kernel of the step derives the step's values from state->step, the optimiser epilogue reads them from
+     * the device, and the last kernel of the step increments state->step - the call can be captured in a HIP graph
+     * and replayed along the schedule. Fused MFMA path only (NSVD_EUNSUPPORTED otherwise). */
+    nsvd_step_state* state;
 } nsvd_rmsprop;
 int nsvd_operator_backward_evd_step(const nsvd_model_desc* desc, const nsvd_params* params,
                                     const nsvd_problem* prob, const float* x, int B, const float* f,
@@ -268,6 +281,47 @@ int nsvd_operator_backward_evd_step(const nsvd_model_desc* desc, const nsvd_para
                                     float* moments, int moments_reduced, const void* evd_scratch, int L_total,
                                     int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
                                     const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream);
+
+/* ---- device-resident schedule state --------------------------------------------------------------------------
+ * What changes from one iteration of the loop body examples/operator/__init__.py:55-74 to the next besides the
+ * tensors: CosineAnnealingLR's learning rate (:35,71-72; closed form eta_min + (lr0 - eta_min)(1 + cos(pi t / T)) / 2
+ * after t scheduler steps), torch_ema's warmed-up decay min(decay, (1 + n) / (10 + n)) at its n-th update (:36,73),
+ * and - for the device sampler - the batch counter. A training step whose kernels take these as launch arguments
+ * cannot be replayed from a captured HIP graph. This struct lives in DEVICE memory (the caller allocates
+ * sizeof(nsvd_step_state) bytes, 8-byte aligned, and fills it with nsvd_step_state_init); kernels read the step's
+ * values from `cur` and the last kernel of a step increments `step`.
+ * Arithmetic: the same double-precision expressions the host path evaluates (Python floats), rounded to float32
+ * where torch rounds; the device cosine may differ from libm's in the last bit of the DOUBLE, i.e. the float32
+ * learning rate agrees with the host path's except with probability ~2^-29 per step. */
+struct nsvd_step_state {
+    uint64_t step;                   /* optimiser steps taken = scheduler steps = torch_ema.num_updates          */
+    uint64_t T_max;                  /* CosineAnnealingLR T_max (--num_iters); 0: constant learning rate          */
+    double lr0, eta_min;             /* base learning rate (--lr), CosineAnnealingLR eta_min (0 in the scripts)    */
+    double alpha, eps;               /* RMSprop alpha (--rmsprop_decay), eps (1e-10: examples/utils.py:52)         */
+    double ema_decay;                /* --ema_decay; the warm-up of torch_ema (use_num_updates=True) is applied    */
+    /* the values of the step being taken, derived from `step` by the step's first kernel (or nsvd_step_state_begin): */
+    struct {
+        float lr, alpha, one_minus_alpha, eps, one_minus_decay, grad_scale;
+    } cur;
+    uint64_t reserved;
+};
+/* Fill a device-resident state (one tiny launch on `stream`): counters at `step`, `cur` = the values of step `step`. */
+int nsvd_step_state_init(nsvd_step_state* state, double lr0, double eta_min, unsigned long long T_max, double alpha,
+                         double eps, double ema_decay, unsigned long long step, void* stream);
+/* state->cur <- the values of step state->step (one tiny launch). For loop bodies whose first kernel does not do it:
+ * i.e. everything except nsvd_operator_backward_evd_step[_next] with opt->state set. */
+int nsvd_step_state_begin(nsvd_step_state* state, void* stream);
+/* nsvd_rmsprop_ema_step with the scheduled values read from state->cur (optimizer.step() + scheduler.step() +
+ * ema.update() of examples/operator/__init__.py:69-73 in capturable form); advance != 0: this is the last optimiser
+ * launch of the step - one thread increments state->step when the kernel is done with it. */
+int nsvd_rmsprop_ema_step_dev(float* p, const float* grad, float* sq, float* ema, size_t n, nsvd_step_state* state,
+                              double grad_scale, int advance, void* stream);
+/* nsvd_operator_sample_features whose batch counter is offset_base + state->step, read on the device: the draw of a
+ * captured step moves along with the schedule. */
+int nsvd_operator_sample_features_dev(const nsvd_model_desc* desc, const nsvd_params* params,
+                                      const nsvd_problem* prob, unsigned long long seed,
+                                      unsigned long long offset_base, const nsvd_step_state* state, float* x, int B,
+                                      void* ws, size_t ws_bytes, int save_for_backward, int path, void* stream);
 
 /* torch.optim.RMSprop(alpha, eps, momentum=0, centered=False) step + torch_ema update, fused
  * (examples/utils.py:50-57, examples/operator/__init__.py:69-73):

@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 NSVD_MAX_LAYERS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EINVAL = -10001
 EUNSUPPORTED = -10002
@@ -55,7 +55,18 @@ class CdkStepDesc(C.Structure):
 
 class Rmsprop(C.Structure):
     _fields_ = [("sq", Params), ("ema", Params), ("lr", C.c_double), ("alpha", C.c_double), ("eps", C.c_double),
-                ("ema_decay", C.c_double), ("has_ema", C.c_int32)]
+                ("ema_decay", C.c_double), ("has_ema", C.c_int32), ("state", C.c_void_p)]
+
+
+class StepStateCur(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("lr", "alpha", "one_minus_alpha", "eps", "one_minus_decay", "grad_scale")]
+
+
+class StepState(C.Structure):
+    """host mirror of the DEVICE-resident nsvd_step_state (sizes / offsets only: the library fills and advances it)"""
+    _fields_ = [("step", C.c_uint64), ("T_max", C.c_uint64), ("lr0", C.c_double), ("eta_min", C.c_double),
+                ("alpha", C.c_double), ("eps", C.c_double), ("ema_decay", C.c_double), ("cur", StepStateCur),
+                ("reserved", C.c_uint64)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/nsvd.h
@@ -98,6 +109,11 @@ SIGNATURES = {
                                                   _P]),
     "nsvd_evd_loss_fused": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "nsvd_rmsprop_ema_step": (_I, [_P, _P, _P, _P, _Z, _Dbl, _Dbl, _Dbl, _Dbl, _Dbl, _P]),
+    "nsvd_step_state_init": (_I, [_P, _Dbl, _Dbl, C.c_uint64, _Dbl, _Dbl, _Dbl, C.c_uint64, _P]),
+    "nsvd_step_state_begin": (_I, [_P, _P]),
+    "nsvd_rmsprop_ema_step_dev": (_I, [_P, _P, _P, _P, _Z, _P, _Dbl, _I, _P]),
+    "nsvd_operator_sample_features_dev": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), C.c_uint64,
+                                               C.c_uint64, _P, _P, _I, _P, _Z, _I, _I, _P]),
     "nsvd_profile_next_forward": (_I, [_P, _P]),
     "nsvd_model_workspace_bytes": (_Z, [C.POINTER(ModelDesc), _I]),
     "nsvd_kernel_apply_workspace_bytes": (_Z, [_I, _I, _I]),

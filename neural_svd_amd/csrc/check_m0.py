@@ -4,7 +4,7 @@
 t128d_dma() writes M0 from inline assembly (`s_mov_b32 m0, sN ; s_nop 0 ; global_load_lds_dwordx4`) without being able
 to tell the compiler (M0 is reserved: hipcc rejects it on a clobber list). That is only sound while the compiler emits
 no M0 use of its own in those kernels (movrel register-array indexing, the LDS-DMA builtin, ds_*_addtid, s_sendmsg with
-an M0 payload ...). This script disassembles the gfx950 code object inside each given .o and fails the build unless
+an M0 payload ...). This script disassembles the code object of the build's architecture (NSVD_ARCH, default gfx950) inside each given .o and fails the build unless
 
   * every instruction that mentions m0 is `s_mov_b32 m0, <sgpr>`, and
   * each of them is followed by `s_nop 0` and then `global_load_lds_dwordx4`, and
@@ -20,6 +20,7 @@ import sys
 import tempfile
 
 OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+ARCH = os.environ.get("NSVD_ARCH", "gfx950")  # the Makefile passes its ARCH
 
 
 def device_isa(obj):
@@ -27,9 +28,9 @@ def device_isa(obj):
         local = os.path.join(tmp, os.path.basename(obj))
         shutil.copy(obj, local)
         subprocess.run([OBJDUMP, "--offloading", local], check=True, stdout=subprocess.DEVNULL, cwd=tmp)
-        cos = [f for f in os.listdir(tmp) if "amdgcn" in f and "gfx950" in f]
+        cos = [f for f in os.listdir(tmp) if "amdgcn" in f and ARCH in f]
         if not cos:
-            raise SystemExit(f"check_m0: no gfx950 code object in {obj}")
+            raise SystemExit(f"check_m0: no {ARCH} code object in {obj}")
         out = []
         for co in sorted(cos):
             out.append(subprocess.run([OBJDUMP, "-d", os.path.join(tmp, co)], check=True, capture_output=True,

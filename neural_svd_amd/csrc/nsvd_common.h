@@ -122,6 +122,9 @@ struct NsvdSampler {
     unsigned long long offset;  // call counter (one per batch)
     float sigma;
     int on;                     // 0: coordinates are read from x
+    // device counter added to `offset` (nsvd_step_state::step), or null: the batch counter of a step captured in a
+    // HIP graph lives on the device, `offset` is then the constant base
+    const unsigned long long* offset_add;
 };
 
 __host__ __device__ __forceinline__ void nsvd_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
@@ -144,7 +147,8 @@ __host__ __device__ __forceinline__ void nsvd_philox4x32_10(unsigned c0, unsigne
 // up to 4 coordinates of sample b (D <= 4): two Box-Muller pairs from one Philox block
 __device__ __forceinline__ void nsvd_sample_row(const NsvdSampler& s, int b, int D, float* xr) {
     unsigned r[4];
-    nsvd_philox4x32_10((unsigned)b, (unsigned)s.offset, (unsigned)(s.offset >> 32), 0x6e737664u, (unsigned)s.seed,
+    const unsigned long long off = s.offset + (s.offset_add ? *s.offset_add : 0ull);
+    nsvd_philox4x32_10((unsigned)b, (unsigned)off, (unsigned)(off >> 32), 0x6e737664u, (unsigned)s.seed,
                        (unsigned)(s.seed >> 32), r);
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {

@@ -95,7 +95,7 @@ int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int 
 bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count);
 // stand-alone optimiser launch over n contiguous floats (optimizer.hip)
 int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,
-                        hipStream_t s);
+                        hipStream_t s, nsvd_step_state* state = nullptr, int advance = 0);
 
 // ---- CDK towers (tower.hip): the backward with per-workgroup sums of squares of the two weight-gradient contractions
 // (cdk_step.hip clips the global gradient norm without another pass over them)

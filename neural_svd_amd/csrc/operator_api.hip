@@ -239,10 +239,10 @@ extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_pa
     return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
 }
 
-extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const nsvd_params* params,
-                                             const nsvd_problem* prob, unsigned long long seed,
-                                             unsigned long long offset, float* x, int B, void* ws, size_t ws_bytes,
-                                             int save_for_backward, int path, void* stream) {
+namespace {
+int sample_features_impl(const nsvd_model_desc* desc, const nsvd_params* params, const nsvd_problem* prob,
+                         unsigned long long seed, unsigned long long offset, const nsvd_step_state* state, float* x,
+                         int B, void* ws, size_t ws_bytes, int save_for_backward, int path, void* stream) {
     int rc = validate(desc);
     if (rc) return rc;
     if (!prob || !x || !ws || !params || !params->fourier_B || B <= 0) return NSVD_EINVAL;
@@ -255,6 +255,7 @@ extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const 
     smp.offset = offset;
     smp.sigma = prob->sigma;
     smp.on = 1;
+    smp.offset_add = state ? (const unsigned long long*)&state->step : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (fused) return nsvd_fused_features(*desc, *params, *prob, x, B, ws, save_for_backward & 1, s, &smp, x);
     if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;
@@ -263,6 +264,25 @@ extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const 
     const GenericWs w = carve(*desc, B, ws);
     const int E = 1 + 2 * desc->D;
     return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
+}
+}  // namespace
+
+extern "C" int nsvd_operator_sample_features(const nsvd_model_desc* desc, const nsvd_params* params,
+                                             const nsvd_problem* prob, unsigned long long seed,
+                                             unsigned long long offset, float* x, int B, void* ws, size_t ws_bytes,
+                                             int save_for_backward, int path, void* stream) {
+    return sample_features_impl(desc, params, prob, seed, offset, nullptr, x, B, ws, ws_bytes, save_for_backward, path,
+                                stream);
+}
+
+extern "C" int nsvd_operator_sample_features_dev(const nsvd_model_desc* desc, const nsvd_params* params,
+                                                 const nsvd_problem* prob, unsigned long long seed,
+                                                 unsigned long long offset_base, const nsvd_step_state* state,
+                                                 float* x, int B, void* ws, size_t ws_bytes, int save_for_backward,
+                                                 int path, void* stream) {
+    if (!state || ((uintptr_t)state & 7) != 0) return NSVD_EINVAL;
+    return sample_features_impl(desc, params, prob, seed, offset_base, state, x, B, ws, ws_bytes, save_for_backward,
+                                path, stream);
 }
 
 extern "C" int nsvd_model_forward(const nsvd_model_desc* desc, const nsvd_params* params, const float* x, int B,
@@ -362,6 +382,8 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
         }
         st.sq = opt->sq;
         st.h = nsvd_make_hyper(opt->lr, opt->alpha, opt->eps, opt->has_ema ? opt->ema_decay : 0.0, 1.0);
+        st.state = opt->state;
+        if (st.state && ((uintptr_t)st.state & 7) != 0) return NSVD_EINVAL;
     }
     if (ws_bytes < (model_mode ? nsvd_model_workspace_bytes(desc, B) : nsvd_workspace_bytes(desc, B))) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
@@ -383,7 +405,7 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
         in.Lg = L_total;
         in.l_off = l_offset;
         if (direct) {
-            in.loss = nullptr;
+            // (the loss scalars come from per-head partials of the chain kernel, added by the weight-gradient kernel)
         } else if (moments_reduced) {
             in.moments = moments;
         } else {
@@ -396,6 +418,7 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
                                        next);
     }
     if (next) return NSVD_EUNSUPPORTED;  // guest feature workgroups exist on the fused kernels only
+    if (opt && opt->state) return NSVD_EUNSUPPORTED;  // the device-resident schedule is read by the fused kernels only
     if (l_count > 0 && l_count != desc->L) return NSVD_EUNSUPPORTED;  // head windows need the fused kernels
     // generic path: finish the loss with the stand-alone kernels, then the layer-by-layer backward
     if (direct) return NSVD_EINVAL;  // needs the partial moments (evd_scratch) or the reduced ones

@@ -21,7 +21,36 @@ struct NsvdOptStep {
     NsvdHyper h;
     nsvd_params sq;
     const nsvd_params* ema;  // null: no EMA
+    nsvd_step_state* state;  // device-resident schedule (nsvd.h): h is then read from state->cur on the device
 };
+
+static_assert(sizeof(((nsvd_step_state*)0)->cur) == sizeof(NsvdHyper), "nsvd_step_state::cur is an NsvdHyper");
+__device__ __forceinline__ const NsvdHyper* nsvd_state_hyper(const nsvd_step_state* st) {
+    return reinterpret_cast<const NsvdHyper*>(&st->cur);
+}
+
+// cur <- the scheduled values of step st->step: CosineAnnealingLR's closed form after `step` scheduler steps
+// (torch/optim/lr_scheduler.py; examples/operator/__init__.py:35,71-72) and torch_ema's decay at its (step + 1)-th
+// update (:36,73), in the double-precision expressions trainer.cosine_lr / FusedTrainer._advance_schedule evaluate on
+// the host, rounded to float32 where nsvd_make_hyper rounds. Called by ONE thread.
+__device__ inline void nsvd_step_state_derive(nsvd_step_state* st) {
+#pragma clang fp contract(off)
+    const unsigned long long t = st->step;
+    double lr = st->lr0;
+    if (st->T_max) {
+        const double c = cos((3.141592653589793 * (double)t) / (double)st->T_max);
+        lr = st->eta_min + ((st->lr0 - st->eta_min) * (1.0 + c)) / 2.0;
+    }
+    const double n = (double)(t + 1);
+    const double warm = (1.0 + n) / (10.0 + n);
+    const double decay = st->ema_decay < warm ? st->ema_decay : warm;
+    st->cur.lr = (float)lr;
+    st->cur.alpha = (float)st->alpha;
+    st->cur.one_minus_alpha = (float)(1.0 - st->alpha);
+    st->cur.eps = (float)st->eps;
+    st->cur.one_minus_decay = (float)(1.0 - decay);
+    st->cur.grad_scale = 1.0f;
+}
 
 // host scalars are doubles (Python floats), rounded to float32 exactly where torch rounds them
 static inline NsvdHyper nsvd_make_hyper(double lr, double alpha, double eps, double ema_decay, double grad_scale) {

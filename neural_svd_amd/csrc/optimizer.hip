@@ -3,6 +3,7 @@
 //              momentum 0, not centred), stepped at examples/operator/__init__.py:69-70;
 //              torch_ema update at examples/operator/__init__.py:73.
 // HBM-bound: reads p, g, sq, ema and writes p, sq, ema = 28 B per parameter.
+#include <string.h>
 #include "nsvd_kernels.h"
 #include "opt_math.h"
 
@@ -17,7 +18,12 @@ __device__ __forceinline__ void upd(float& p, float g, float& sq, float* ema, co
 template <bool HAS_EMA>
 __global__ void __launch_bounds__(256) rmsprop_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ sq, float* __restrict__ ema, size_t n4,
-                                                          size_t n, Hyper h) {
+                                                          size_t n, Hyper h, nsvd_step_state* state, int advance) {
+    if (state) {  // device-resident schedule: the step's values from state->cur (grad_scale stays the caller's)
+        const float gs = h.grad_scale;
+        h = *nsvd_state_hyper(state);
+        h.grad_scale = gs;
+    }
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -40,12 +46,21 @@ __global__ void __launch_bounds__(256) rmsprop_ema_kernel(float* __restrict__ p,
         sq[t] = sv;
         if (HAS_EMA) ema[t] = ev;
     }
+    // last optimiser launch of the step: nothing in this kernel reads `step` (only `cur`, which the NEXT step's first
+    // kernel rewrites after the kernel boundary)
+    if (state && advance && blockIdx.x == 0 && threadIdx.x == 0) state->step += 1;
 }
+
+__global__ void step_state_init_kernel(nsvd_step_state* st, nsvd_step_state v) {
+    *st = v;
+    nsvd_step_state_derive(st);
+}
+__global__ void step_state_begin_kernel(nsvd_step_state* st) { nsvd_step_state_derive(st); }
 
 }  // namespace
 
 int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,
-                        hipStream_t s) {
+                        hipStream_t s, nsvd_step_state* state, int advance) {
     if (n == 0) return 0;
     const uintptr_t al = (uintptr_t)p | (uintptr_t)grad | (uintptr_t)sq | (uintptr_t)ema;
     const size_t n4 = (al & 15) ? 0 : n / 4;  // unaligned (never with torch allocations): scalar path
@@ -53,9 +68,9 @@ int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size
     size_t blocks = (work + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (ema) hipLaunchKernelGGL(rmsprop_ema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p, grad, sq, ema,
-                                n4, n, h);
+                                n4, n, h, state, advance);
     else hipLaunchKernelGGL(rmsprop_ema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p, grad, sq,
-                            (float*)nullptr, n4, n, h);
+                            (float*)nullptr, n4, n, h, state, advance);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
@@ -66,4 +81,32 @@ extern "C" int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, flo
     if (!p || !grad || !sq) return NSVD_EINVAL;
     return nsvd_rmsprop_launch(p, grad, sq, ema, n, nsvd_make_hyper(lr, alpha, eps, ema_decay, grad_scale),
                                (hipStream_t)stream);
+}
+
+extern "C" int nsvd_rmsprop_ema_step_dev(float* p, const float* grad, float* sq, float* ema, size_t n,
+                                         nsvd_step_state* state, double grad_scale, int advance, void* stream) {
+    if (!p || !grad || !sq || !state || ((uintptr_t)state & 7) != 0) return NSVD_EINVAL;
+    return nsvd_rmsprop_launch(p, grad, sq, ema, n, nsvd_make_hyper(0.0, 0.0, 0.0, 0.0, grad_scale),
+                               (hipStream_t)stream, state, advance);
+}
+
+extern "C" int nsvd_step_state_init(nsvd_step_state* state, double lr0, double eta_min, unsigned long long T_max,
+                                    double alpha, double eps, double ema_decay, unsigned long long step,
+                                    void* stream) {
+    if (!state || ((uintptr_t)state & 7) != 0) return NSVD_EINVAL;
+    nsvd_step_state v;
+    memset(&v, 0, sizeof(v));
+    v.step = step;
+    v.T_max = T_max;
+    v.lr0 = lr0; v.eta_min = eta_min; v.alpha = alpha; v.eps = eps; v.ema_decay = ema_decay;
+    hipLaunchKernelGGL(step_state_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, v);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nsvd_step_state_begin(nsvd_step_state* state, void* stream) {
+    if (!state || ((uintptr_t)state & 7) != 0) return NSVD_EINVAL;
+    hipLaunchKernelGGL(step_state_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    NSVD_CHECK_LAUNCH();
+    return 0;
 }

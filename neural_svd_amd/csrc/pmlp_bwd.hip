@@ -41,6 +41,15 @@ struct ChainArgs {
     // the stand-alone feature launch (5.7 us + a kernel boundary per step) disappears.
     int chain_blocks, feat_nx, feat_blocks;
     nsvd_feat::StencilArgs feat;
+    // device-resident schedule (nsvd.h: nsvd_step_state), or null. One extra block (the last of the grid) derives the
+    // step's learning rate / EMA decay from state->step for the weight-gradient kernel's optimiser epilogue, and the
+    // guests' batch counter is feat.smp.offset + state->step (feat.smp.offset_add): nothing that changes from step to step is a launch
+    // argument, so the captured launch replays along the schedule.
+    nsvd_step_state* state;
+    // direct mode only, or null: partial sums of the loss, added by the weight-gradient kernel in a fixed order:
+    // [L][B / 32] operator term v_l sum_b f Tf over the workgroup's 32 rows, then [L] metric term
+    // sum_l' M lam_f1 lam_f2 of column l (left by each head's first workgroup)
+    float* loss_part;
 };
 
 // PRE: the whole chain's weights and sigmoid inputs are fetched at kernel start (two or three hidden layers; ~290
@@ -53,8 +62,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
     static_assert(BS * H_LD >= nsvd_feat::STAGE_FLOATS, "a feature tile's staging must fit the chain kernel's LDS");
     if ((int)blockIdx.x >= a.chain_blocks) {
         const int t = (int)blockIdx.x - a.chain_blocks;
+        if (t >= a.feat_blocks) {  // the schedule block (only launched with a.state)
+            if (threadIdx.x == 0) nsvd_step_state_derive(a.state);
+            return;
+        }
         const int by = t / a.feat_nx, bx = t - by * a.feat_nx;
-        switch (a.feat.D) {
+        switch (a.feat.D) {  // (feat.smp.offset_add = &state->step: `step` is not written by this kernel)
             case 1: nsvd_feat::stencil_tile<1, 256>(a.feat, bx, by, DZ); break;
             case 2: nsvd_feat::stencil_tile<2, 256>(a.feat, bx, by, DZ); break;
             default: nsvd_feat::stencil_tile<3, 256>(a.feat, bx, by, DZ); break;
@@ -115,6 +128,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         // (reference methods/nestedlora.py:98-111 with f1, f2 = chunk(f, 2)); the moments are either the
         // reduced / all-reduced vector or this rank's per-chunk partial sums (reduced here, in a fixed order)
         float* col = DZ;  // [2][Lg] masked moment columns of (global) head lg (LDS scratch, free until the first exchange)
+        float* red_mt = DZ + 256 + 1024;  // [4 waves] metric-term partials of the step's loss value (direct mode)
         const int Lg = a.evd.Lg, lg = a.evd.l_off + l;
         const int B1 = (a.B + 1) / 2, B2 = a.B - B1;
         if (a.evd.moments || a.evd.part) {
@@ -194,15 +208,40 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
                     col[h * Lg + lp] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * (sum / (float)(h ? B2 : B1));
                 }
             }
+            if (a.loss_part && b0 == 0) {
+                // the metric term of this head's column, sum_l' (M lam_f1)[l'][l] lam_f2[l'][l] (reference:
+                // methods/nestedlora.py:57-64): the thread of (h = 0, l') holds lam_f1, lane ^ 16 the lam_f2 of the same l'
+                float mt = 0.f;
+                for (int t = tid; t < ((nchunk * 32 + 63) & ~63); t += 256) {
+                    const int c = t >> 5, i = t & 31, h = i >> 4, lp = 16 * c + (i & 15);
+                    float lam = 0.f;
+                    if (t < nchunk * 32 && lp < Lg) {
+                        const float* rp = red + c * 128 + i;
+                        lam = ((rp[0] + rp[32]) + (rp[64] + rp[96])) / (float)(h ? B2 : B1);
+                    }
+                    const float other = __shfl_xor(lam, 16, 64);
+                    if (h == 0 && lp < Lg) mt = fmaf(nsvd_evd_mask_M(a.evd, lp, lg, Lg) * lam, other, mt);
+                }
+                mt = nsvd_wave_sum(mt);
+                if (lane == 0) red_mt[w] = mt;
+            }
         }
         __syncthreads();
+        if (a.loss_part && b0 == 0 && tid == 0 && !(a.evd.moments || a.evd.part))
+            a.loss_part[(size_t)a.L * nsb + l] = (red_mt[0] + red_mt[1]) + (red_mt[2] + red_mt[3]);
         const bool first = b < B1;
         const float* cp = col + (first ? Lg : 0);  // the OTHER half's moments
         const float* fr = a.evd.f + (size_t)b * Lg;
         float acc = 0.f;
         for (int lp = 0; lp < Lg; ++lp) acc = fmaf(fr[lp], cp[lp], acc);
-        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * a.evd.Tf[(size_t)b * Lg + lg] +
+        const float tfv = a.evd.Tf[(size_t)b * Lg + lg];
+        dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * tfv +
                                   (2.f / (float)(first ? B1 : B2)) * acc);
+        if (a.loss_part && w == 0) {
+            // the operator term of the loss over this workgroup's 32 rows: v_l sum_b f[b][l] Tf[b][l]
+            const float part = nsvd_wave_sum(hi == 0 ? fr[lg] * tfv : 0.f);
+            if (lane == 0) a.loss_part[(size_t)l * nsb + (b0 / BS)] = nsvd_evd_mask_v(a.evd, lg, Lg) * part;
+        }
         __syncthreads();  // col[] is dead before DZ is reused
     }
     const float dbase = dfv * a.jac[(size_t)b * a.ldl + a.l0 + l];
@@ -341,6 +380,13 @@ struct WgradArgs {
     float* part;
     size_t part_stride;                                        // floats per slice
     size_t poW[NSVD_MAX_LAYERS], pob[NSVD_MAX_LAYERS], poscales;  // tensor offsets inside a slice
+    // device-resident schedule (or null): `h` is read from state->cur (written by the chain kernel's schedule block)
+    // and ONE thread of the last kernel of the step increments state->step
+    nsvd_step_state* state;
+    // the step's loss from the chain kernel's per-head partials (direct mode), or null
+    const float* loss_part;  // [loss_L][B / 32] operator-term partials, then [loss_L] metric-term partials
+    float* loss;             // {loss, operator term, metric term}
+    int loss_L;
 };
 
 // where a gradient element goes: the caller's gradient tensor (+ fused optimiser) or this slice's partial buffer
@@ -362,13 +408,13 @@ __device__ unsigned long long g_wg_stamps[1024 * 8];
 #endif
 
 // one gradient element: store it and / or take the optimiser step on its parameter
-__device__ __forceinline__ void wg_emit1(const WgradArgs& a, const WgDst& d, const NsvdOptPtrs& o, size_t off,
+__device__ __forceinline__ void wg_emit1(const NsvdHyper& h, const WgDst& d, const NsvdOptPtrs& o, size_t off,
                                          float val) {
     float* g = d.g;
     if (g) g[off] = val;
     if (d.opt) {
         float pv = o.p[off], sv = o.sq[off], ev = o.ema ? o.ema[off] : 0.f;
-        nsvd_rmsprop_upd(pv, val, sv, ev, o.ema != nullptr, a.h);
+        nsvd_rmsprop_upd(pv, val, sv, ev, o.ema != nullptr, h);
         o.p[off] = pv;
         o.sq[off] = sv;
         if (o.ema) o.ema[off] = ev;
@@ -387,7 +433,7 @@ __device__ __forceinline__ void wg_st(float* p, unsigned byte_off, float v) {
 }
 
 template <bool EMA>
-__device__ __forceinline__ void wg_opt16(const WgradArgs& a, const NsvdOptPtrs& o, unsigned base, unsigned ld, int hi,
+__device__ __forceinline__ void wg_opt16(const NsvdHyper& h, const NsvdOptPtrs& o, unsigned base, unsigned ld, int hi,
                                          const f32x16& acc) {
     float pv[16], sv[16], ev[16];
 #pragma unroll
@@ -400,14 +446,14 @@ __device__ __forceinline__ void wg_opt16(const WgradArgs& a, const NsvdOptPtrs& 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
-        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], ev[r], EMA, a.h);
+        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], ev[r], EMA, h);
         wg_st(o.p, off, pv[r]);
         wg_st(o.sq, off, sv[r]);
         if (EMA) wg_st(o.ema, off, ev[r]);
     }
 }
 
-__device__ __forceinline__ void wg_emit16(const WgradArgs& a, const WgDst& d, const NsvdOptPtrs& o, size_t base,
+__device__ __forceinline__ void wg_emit16(const NsvdHyper& h, const WgDst& d, const NsvdOptPtrs& o, size_t base,
                                           size_t ld, int hi, const f32x16& acc) {
     float* g = d.g;
     if (g) {
@@ -415,8 +461,8 @@ __device__ __forceinline__ void wg_emit16(const WgradArgs& a, const WgDst& d, co
         for (int r = 0; r < 16; ++r) wg_st(g, 4u * ((unsigned)base + (unsigned)acc_row(r, hi) * (unsigned)ld), acc[r]);
     }
     if (!d.opt) return;
-    if (o.ema) wg_opt16<true>(a, o, (unsigned)base, (unsigned)ld, hi, acc);
-    else wg_opt16<false>(a, o, (unsigned)base, (unsigned)ld, hi, acc);
+    if (o.ema) wg_opt16<true>(h, o, (unsigned)base, (unsigned)ld, hi, acc);
+    else wg_opt16<false>(h, o, (unsigned)base, (unsigned)ld, hi, acc);
 }
 
 // stage one 32-row x 32-column (float4 per thread) slab global -> registers
@@ -461,14 +507,14 @@ __device__ __forceinline__ void wg_opt16_load(const NsvdOptPtrs& o, unsigned bas
 }
 
 template <bool EMA>
-__device__ __forceinline__ void wg_opt16_apply(const WgradArgs& a, const NsvdOptPtrs& o, unsigned base, unsigned ld,
+__device__ __forceinline__ void wg_opt16_apply(const NsvdHyper& h, const NsvdOptPtrs& o, unsigned base, unsigned ld,
                                                int hi, const f32x16& acc, float (&pv)[16], float (&sv)[16],
                                                float (&ev)[16]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
         if (!EMA) ev[r] = 0.f;
-        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], ev[r], EMA, a.h);
+        nsvd_rmsprop_upd(pv[r], acc[r], sv[r], ev[r], EMA, h);
         wg_st(o.p, off, pv[r]);
         wg_st(o.sq, off, sv[r]);
         if (EMA) wg_st(o.ema, off, ev[r]);
@@ -480,7 +526,7 @@ __device__ __forceinline__ void wg_opt16_apply(const WgradArgs& a, const NsvdOpt
 // gradient output). NJ = 2: 128 x 128 tile (hidden units x features); NJ = 1: 128 x 64, chosen by the host when the
 // 128-wide tiles would leave half the CUs without one. The bias gradient db_0 is taken by the C workgroups.
 template <int MODE, int NJ>
-__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* lds, int unit, int slice) {
+__device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, const NsvdHyper& h, float* lds, int unit, int slice) {
     constexpr int TW = 64 * NJ;  // features per tile
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -512,7 +558,7 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* lds, int
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                wg_emit16(a, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
+                wg_emit16(h, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
     } else {
         constexpr bool EMA = MODE == 2;
         const NsvdOptPtrs& op = a.oW[0];
@@ -525,16 +571,16 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* lds, int
         if (NJ == 2) {
             // blocks (0,0), (0,1) have their state; the loads of (1,0), (1,1) go out behind the stores of the former
             float p2[16], s2[16], e2[16], p3[16], s3[16], e3[16];
-            wg_opt16_apply<EMA>(a, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
+            wg_opt16_apply<EMA>(h, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
             wg_opt16_load<EMA>(op, b10, ld, hi, p2, s2, e2);
-            wg_opt16_apply<EMA>(a, op, b00 + 32u, ld, hi, acc[0][NJ - 1], pf.p[1], pf.s[1], pf.e[1]);
+            wg_opt16_apply<EMA>(h, op, b00 + 32u, ld, hi, acc[0][NJ - 1], pf.p[1], pf.s[1], pf.e[1]);
             wg_opt16_load<EMA>(op, b10 + 32u, ld, hi, p3, s3, e3);
-            wg_opt16_apply<EMA>(a, op, b10, ld, hi, acc[1][0], p2, s2, e2);
-            wg_opt16_apply<EMA>(a, op, b10 + 32u, ld, hi, acc[1][NJ - 1], p3, s3, e3);
+            wg_opt16_apply<EMA>(h, op, b10, ld, hi, acc[1][0], p2, s2, e2);
+            wg_opt16_apply<EMA>(h, op, b10 + 32u, ld, hi, acc[1][NJ - 1], p3, s3, e3);
         } else {
             // both blocks of the tile have their state
-            wg_opt16_apply<EMA>(a, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
-            wg_opt16_apply<EMA>(a, op, b10, ld, hi, acc[1][0], pf.p[1], pf.s[1], pf.e[1]);
+            wg_opt16_apply<EMA>(h, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
+            wg_opt16_apply<EMA>(h, op, b10, ld, hi, acc[1][0], pf.p[1], pf.s[1], pf.e[1]);
         }
     }
     WG_STAMP(5, __builtin_readcyclecounter());
@@ -544,7 +590,7 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, float* lds, int
 // dW_i quadrant through the shared C = A B^T tile routine (tile_nt.h): both operands are plain (L, 128, B) rows now
 // that the forward saves activations - no softplus while staging, loads two chunks ahead, four accumulator chains.
 // Needs the slice length to be a multiple of 64 (the 32-chunk form below takes the rest).
-__device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, float* lds, int unit, int slice) {
+__device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, const NsvdHyper& h, float* lds, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -562,7 +608,7 @@ __device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, float* lds, i
     const int b0 = slice * a.Bs;
     if (k0 == 0) nsvd_tile_nt<true>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
     else nsvd_tile_nt<false>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
-    wg_emit16(a, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
+    wg_emit16(h, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
               ((size_t)l * HID + n0 + 32 * (wv & 1)) * HID + k0 + 32 * (wv >> 1) + li, HID, hi, acc);
     if (k0 == 0) {
         // bias gradient: the 16 threads t & 15 of a staging row hold partial sums of rows (t >> 4) + 16 j
@@ -574,12 +620,12 @@ __device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, float* lds, i
             const WgDst db = wg_dst(a, a.gb[i], a.pob[i], slice);
             const size_t gb = (size_t)l * HID + n0 + (tid >> 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wg_emit1(a, db, a.ob[i], gb + 16 * j, rs[j]);
+            for (int j = 0; j < 4; ++j) wg_emit1(h, db, a.ob[i], gb + 16 * j, rs[j]);
         }
     }
 }
 
-__device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, float* Bs, int unit, int slice) {
+__device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, const NsvdHyper& h, float* As, float* Bs, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -655,7 +701,7 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
 #undef WB_COMPUTE
 #undef WB_LOAD
 #undef WB_STORE
-    wg_emit16(a, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
+    wg_emit16(h, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
               ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li, HID, hi, acc);
     if (k0 == 0) {
 #pragma unroll
@@ -666,13 +712,13 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, float* As, floa
         if (s_c4 == 0) {
             const size_t gb = (size_t)l * HID + n0 + s_row;
             const WgDst db = wg_dst(a, a.gb[i], a.pob[i], slice);
-            wg_emit1(a, db, a.ob[i], gb, rs0);
-            wg_emit1(a, db, a.ob[i], gb + 32, rs1);
+            wg_emit1(h, db, a.ob[i], gb, rs0);
+            wg_emit1(h, db, a.ob[i], gb + 32, rs1);
         }
     }
 }
 
-__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int unit, int slice) {
+__device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, const NsvdHyper& h, float* lds, int unit, int slice) {
     const int l = unit >> 2, part = unit & 3;  // 4 workgroups per head: 32 of the 128 rows each
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -695,10 +741,29 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
     }
     __syncthreads();
     if (tid == 0 && part == 0) {
-        wg_emit1(a, wg_dst(a, a.gb[nh], a.pob[nh], slice), a.ob[nh], l, (red[0] + red[1]) + (red[2] + red[3]));
+        wg_emit1(h, wg_dst(a, a.gb[nh], a.pob[nh], slice), a.ob[nh], l, (red[0] + red[1]) + (red[2] + red[3]));
         if (a.dfsc)
-            wg_emit1(a, wg_dst(a, a.gscales, a.poscales, slice), a.oscales, l,
+            wg_emit1(h, wg_dst(a, a.gscales, a.poscales, slice), a.oscales, l,
                      (red[4] + red[5]) + (red[6] + red[7]));
+    }
+    if (a.loss_part && unit == 0 && slice == 0 && w == 0) {
+        // the step's loss from the chain kernel's partial sums (direct mode), in a fixed order: lane q adds the
+        // entries q, q + 64, ...; then the butterfly
+        const int nop = a.loss_L * (a.B / BS);
+        float op = 0.f, mt = 0.f;
+        for (int q = lane; q < nop; q += 64) op += a.loss_part[q];
+        for (int q = lane; q < a.loss_L; q += 64) mt += a.loss_part[nop + q];
+        op = -2.f * (nsvd_wave_sum(op) / (float)a.B);
+        mt = nsvd_wave_sum(mt);
+        if (lane == 0) {
+            a.loss[0] = op + mt;
+            a.loss[1] = op;
+            a.loss[2] = mt;
+        }
+    }
+    if (tid == 0 && unit == 0 && slice == 0) {
+        // last kernel of the step (no second pass): nothing in this launch reads `step`
+        if (a.state && a.S == 1) a.state->step += 1;
     }
     // dW_last[n] = sum_b dbase[b] softplus(z[n][b]): each wave owns 32 rows and walks them 8 at a time so
     // that 8 independent 16-B loads are in flight per lane (a row-at-a-time loop is pure L2 latency)
@@ -737,9 +802,9 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, float* lds, int
             if (lane == 8 + j) mine = t0;
         }
         if (lane < 8)
-            wg_emit1(a, wg_dst(a, a.gW[nh], a.poW[nh], slice), a.oW[nh], (size_t)l * HID + n0 + lane, mine);
+            wg_emit1(h, wg_dst(a, a.gW[nh], a.poW[nh], slice), a.oW[nh], (size_t)l * HID + n0 + lane, mine);
         else if (lane < 16)
-            wg_emit1(a, wg_dst(a, a.gb[0], a.pob[0], slice), a.ob[0], (size_t)l * HID + n0 + lane - 8, mine);
+            wg_emit1(h, wg_dst(a, a.gb[0], a.pob[0], slice), a.ob[0], (size_t)l * HID + n0 + lane - 8, mine);
     }
 }
 
@@ -752,6 +817,9 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     static_assert(4 * HID * A_LD >= T128D_LDS_FLOATS, "the dW_0 tile's DMA ring must fit the weight-gradient LDS");
     float* As = smem_wg;
     float* Bs = smem_wg + 2 * HID * A_LD;
+    // the step's optimiser scalars: launch arguments, or read from the device-resident schedule (uniform loads)
+    NsvdHyper h = a.h;
+    if (a.state) h = *nsvd_state_hyper(a.state);
     // grid = S x (nA | nB | 4 L) blocks, kind-major so that the long dW_0 tiles are dispatched first
     int bid = blockIdx.x + a.bid0;
     if (bid < a.nA * a.S) {
@@ -764,24 +832,24 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
         // the optimiser state rides under the K loop when the step is fused, nothing else is written and the
         // loop has the four peeled chunks the prefetch hangs on
         const bool pf = a.S == 1 && a.opt && !a.gW[0] && a.Bs >= 4 * BK;
-        if (!pf) wgrad_tile_A<0, NJ>(a, smem_wg, unit, slice);
-        else if (a.oW[0].ema) wgrad_tile_A<2, NJ>(a, smem_wg, unit, slice);
-        else wgrad_tile_A<1, NJ>(a, smem_wg, unit, slice);
+        if (!pf) wgrad_tile_A<0, NJ>(a, h, smem_wg, unit, slice);
+        else if (a.oW[0].ema) wgrad_tile_A<2, NJ>(a, h, smem_wg, unit, slice);
+        else wgrad_tile_A<1, NJ>(a, h, smem_wg, unit, slice);
         return;
     }
     bid -= a.nA * a.S;
     if (bid < a.nB * a.S) {
         WG_STAMP(0, 2ull);
         WG_STAMP(1, wall_clock64());
-        if (a.Bs % NSVD_TNT_KC == 0) wgrad_tile_B64(a, smem_wg, bid % a.nB, bid / a.nB);
-        else wgrad_tile_B(a, As, Bs, bid % a.nB, bid / a.nB);
+        if (a.Bs % NSVD_TNT_KC == 0) wgrad_tile_B64(a, h, smem_wg, bid % a.nB, bid / a.nB);
+        else wgrad_tile_B(a, h, As, Bs, bid % a.nB, bid / a.nB);
         WG_STAMP(6, wall_clock64());
         return;
     }
     bid -= a.nB * a.S;
     WG_STAMP(0, 3ull);
     WG_STAMP(1, wall_clock64());
-    wgrad_tile_C(a, As, bid % (4 * a.L), bid / (4 * a.L));
+    wgrad_tile_C(a, h, As, bid % (4 * a.L), bid / (4 * a.L));
     WG_STAMP(6, wall_clock64());
 }
 
@@ -796,9 +864,12 @@ struct ReduceArgs {
     float* g[2 * NSVD_MAX_LAYERS + 1];
     NsvdOptPtrs o[2 * NSVD_MAX_LAYERS + 1];
     size_t total4;  // float4 groups over all tensors
+    nsvd_step_state* state;  // device-resident schedule (or null): h from state->cur, step incremented here
 };
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
+    NsvdHyper h = a.h;
+    if (a.state) h = *nsvd_state_hyper(a.state);
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < a.total4; q += (size_t)gridDim.x * 256) {
         // tensors are laid out back to back (padded to 4 floats) inside a slice: find the one holding group q
         int t = 0;
@@ -819,13 +890,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
             if (a.opt) {
                 const NsvdOptPtrs& o = a.o[t];
                 float pv = o.p[e + c], sv = o.sq[e + c], ev = o.ema ? o.ema[e + c] : 0.f;
-                nsvd_rmsprop_upd(pv, gv[c], sv, ev, o.ema != nullptr, a.h);
+                nsvd_rmsprop_upd(pv, gv[c], sv, ev, o.ema != nullptr, h);
                 o.p[e + c] = pv;
                 o.sq[e + c] = sv;
                 if (o.ema) o.ema[e + c] = ev;
             }
         }
     }
+    if (a.state && blockIdx.x == 0 && threadIdx.x == 0) a.state->step += 1;  // last kernel of the step
 }
 #undef WG_LD
 #undef WG_ST
@@ -873,6 +945,12 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     const int chain_only = (B / BS) * d.L;
     a.chain_blocks = chain_only;
     int chain_grid = chain_only;
+    nsvd_step_state* state = opt ? opt->state : nullptr;
+    a.state = state;
+    // the loss of the step in direct mode (no moment kernel): only when this launch sees every head of the loss
+    const bool direct = evd && !evd->moments && !evd->part;
+    const bool step_loss = direct && evd->loss && B / BS <= 32 && Lc == dfull.L && evd->l_off == 0 && evd->Lg == dfull.L && !df;
+    a.loss_part = step_loss ? w.loss_part : nullptr;
     if (next) {  // the next batch's sampling + features as guest workgroups (same arguments as nsvd_fused_features)
         const FusedWs wn = carve_fused(dfull, B, next->ws);
         memset(&a.feat, 0, sizeof(a.feat));
@@ -880,10 +958,12 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
         a.feat.x = next->x; a.feat.xout = next->x;
         a.feat.fB = p.fourier_B; a.feat.phi = wn.phi; a.feat.phiTc = wn.phiTc; a.feat.sctab = wn.sctab;
         a.feat.B = B; a.feat.m = d.m; a.feat.D = d.D; a.feat.eps = next->eps;
+        if (opt && opt->state) a.feat.smp.offset_add = (const unsigned long long*)&opt->state->step;
         a.feat_nx = (d.m + nsvd_feat::FJ - 1) / nsvd_feat::FJ;
         a.feat_blocks = a.feat_nx * ((B + nsvd_feat::FB - 1) / nsvd_feat::FB);
         chain_grid += a.feat_blocks;
     }
+    if (state) chain_grid += 1;  // the schedule block
     if ((nh == 2 || nh == 3) && chain_only <= 128)
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<true>, dim3(chain_grid), dim3(256), 0, s, a);
     else
@@ -912,6 +992,12 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
         }
         if (d.has_exp_mask)
             wa.oscales = NsvdOptPtrs{p.scales + l0, opt->sq.scales + l0, opt->ema ? opt->ema->scales + l0 : nullptr};
+    }
+    wa.state = state;
+    if (step_loss) {
+        wa.loss_part = w.loss_part;
+        wa.loss = evd->loss;
+        wa.loss_L = dfull.L;
     }
     wa.nA = (F / HID) * d.L;
     wa.S = wgrad_slices(d, B);
@@ -949,6 +1035,7 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     ra.S = wa.S;
     ra.opt = wa.opt;
     ra.h = wa.h;
+    ra.state = state;
     int t = 0;
     for (int i = 0; i < d.nlayers; ++i, ++t) {
         ra.off[t] = pl.oW[i]; ra.n[t] = pl.nW[i]; ra.g[t] = g.W[i]; ra.o[t] = wa.oW[i];

@@ -109,6 +109,7 @@ struct FusedWs {
     float* gpart;                     // (S, slice) split-K partial gradients, S = wgrad_slices() > 1 only
     unsigned short* w0p;              // (3, L, 128, F) bf16 planes of W_0 (NSVD_PATH_FUSED_BF16X3 only)
     float* base_raw;                  // (L, (1 + 2D) B) head outputs per stencil point (split-stencil forward only)
+    float* loss_part;                 // (L, 32 + 1) partial sums of the loss (direct-moment backward, B <= 1024)
     size_t bytes;
 };
 
@@ -190,6 +191,7 @@ inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     w.gpart = S > 1 ? take((size_t)S * part_layout(d).stride) : nullptr;
     w.w0p = (unsigned short*)take(((size_t)3 * d.L * HID * F + 1) / 2);
     w.base_raw = take((size_t)d.L * (1 + 2 * (size_t)d.D) * B);
+    w.loss_part = take(33 * (size_t)d.L);
     w.bytes = off;
     return w;
 }

@@ -447,6 +447,7 @@ __global__ void __launch_bounds__(256) tower_to_bf16_kernel(const float4* __rest
 struct Mixed {
     bool on = false, a_ready = false, b_ready = false;
     void *hA = nullptr, *hB = nullptr;
+    size_t capA = 0, capB = 0;  // capacity of hA / hB in bfloat16 values
 };
 inline int launch_gemm(const GemmNT& g0, hipStream_t s, const Mixed& mx = Mixed(), bool prof = false) {
     GemmNT g = g0;
@@ -455,6 +456,7 @@ inline int launch_gemm(const GemmNT& g0, hipStream_t s, const Mixed& mx = Mixed(
     if (mx.on) {
         if (g.lda != (size_t)g.K || g.ldb != (size_t)g.K) return NSVD_EINVAL;  // the copies are dense
         const size_t na = (size_t)g.M * g.K / 8, nb = (size_t)g.N * g.K / 8;
+        if ((!mx.a_ready && 8 * na > mx.capA) || (!mx.b_ready && 8 * nb > mx.capB)) return NSVD_EINVAL;
         if (!mx.a_ready) {
             hipLaunchKernelGGL(tower_to_bf16_kernel, dim3((unsigned)((na + 255) / 256 > 4096 ? 4096 : (na + 255) / 256)),
                                dim3(256), 0, s, (const float4*)g.A, (uint4*)mx.hA, na);
@@ -489,7 +491,8 @@ inline int fwd2_slices(int B, int d1, int d2, bool bf16 = false) {
 struct TowerWs {
     float *Y1, *A1, *A1T, *Y2p, *Y2, *XT, *W2T, *dY2, *dY2T, *dA1, *dY1T;
     float *mean1, *inv1, *mean2, *inv2;
-    void *hA, *hB;  // bfloat16 copies of a contraction's two operands (mixed-precision mode), reused by all five
+    void *hA, *hB;  // bfloat16 copies of the operands that are cast per call (mixed-precision mode)
+    size_t capA, capB;  // their capacities in bfloat16 values
     size_t bytes;
 };
 
@@ -519,10 +522,12 @@ inline TowerWs carve_tower(int B, int d0, int d1, int d2, void* base) {
     w.inv1 = take(d1);
     w.mean2 = take(d2);
     w.inv2 = take(d2);
-    {   // the largest operand of the five contractions: max(B, d0, d2) rows of d1 values; two bytes per value
-        const size_t mx = (size_t)(B > d0 ? (B > d2 ? B : d2) : (d0 > d2 ? d0 : d2)) * d1;
-        w.hA = take((mx + 1) / 2);
-        w.hB = take((mx + 1) / 2);
+    {   // the operands cast per call (every other one is written as bfloat16 by its producer): X (B, d0) on the A
+        // side; the master weights W1 (d1, d0) and W2 (d2, d1), one after the other, on the B side. Two bytes per value.
+        w.capA = (size_t)B * d0;
+        w.capB = (size_t)d1 * (d0 > d2 ? d0 : d2);
+        w.hA = take((w.capA + 1) / 2);
+        w.hB = take((w.capB + 1) / 2);
     }
     w.bytes = off;
     return w;
@@ -568,7 +573,7 @@ int nsvd_tower_forward_phase(const float* x, const nsvd_tower_params* p, int B, 
     // mixed precision: the contractions' operands rounded to bfloat16. X and the master weights are cast per call;
     // the activations are WRITTEN as bfloat16 by the BatchNorm strips (into the float32 buffers' storage: A1, A1^T)
     Mixed mx;
-    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB;
+    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB; mx.capA = w.capA; mx.capB = w.capB;
     int rc = 0;
     GemmNT g;
     BnFwd f;
@@ -642,7 +647,7 @@ int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const 
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     Mixed mx;
-    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB;
+    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB; mx.capA = w.capA; mx.capB = w.capB;
     int rc = 0;
     // dY2 = BN2'(dZ), dY2^T, db2 = column sums of dY2
     BnBwd b;

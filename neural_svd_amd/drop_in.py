@@ -163,6 +163,15 @@ def _fused_loop_trainer(args, method, operator, importance_train, device, comm=N
     with torch.random.fork_rng(devices=[dev.index if dev.index is not None else torch.cuda.current_device()]):
         tr = _make_fused(FusedTrainer, args, method, model, operator, importance_train, step, device,
                          fused_problem_of, comm, par)
+    if comm is not None:
+        # every rank must train the SAME model: rank 0's weights (and frozen Fourier matrix) win, whatever the ranks'
+        # random streams were when the script built the module (per-rank seeds are a common DDP habit; unseeded runs
+        # differ anyway). Without this the replicas of a sample-sharded run start apart and a head-sharded run gathers
+        # f / Tf columns computed with different Fourier matrices.
+        with torch.no_grad():
+            for t in [model.base.feature_map._B] + list(model.base.ws) + list(model.base.bs) + \
+                    ([model.boundary_mask.scales] if model.has_exp_mask else []):
+                comm.broadcast(t.data, 0)
     sl = slice(tr.l_off, tr.l_off + tr.shape.L)  # this rank's heads (all of them unless heads are sharded)
     tr.P.load(model.base.feature_map._B.data, [w.data[sl] for w in model.base.ws], [b.data[sl] for b in model.base.bs],
               model.boundary_mask.scales.data[sl] if model.has_exp_mask else None)
@@ -236,12 +245,20 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     start = time.time()
     # the reference adds loss.item() to a host total on EVERY step (operator/__init__.py:74,99: a device sync per
     # step); here the running total lives on the device and is read at print time only. The fused loop's backward
-    # kernel does not produce the loss scalars (it takes the moments it needs straight from f), so there the loss is
-    # evaluated (one extra launch) on every `loss_stride`-th step and at print time only: `avg_train_loss` is then the
-    # mean over those sampled steps - args.loss_every_step = True restores the every-step mean at one launch per step
+    # kernels leave the loss scalars themselves on one GPU with batches of <= 1024 rows; otherwise (heads sharded, larger
+    # batches) the loss is evaluated (one extra launch) on every `loss_stride`-th step and at print time only, and the
+    # logged column is then called `avg_train_loss_sampled` (the mean over those sampled steps: a different quantity
+    # from the reference's every-step mean) - args.loss_every_step = True restores the every-step mean at one launch per
+    # step
     total_loss = torch.zeros((), dtype=torch.float64, device=device)
     n_loss = 0
-    loss_stride = 1 if getattr(args, "loss_every_step", False) else max(1, int(args.print_freq) // 16)
+    # (single GPU, batches of <= 1024 rows: the step's own kernels leave the loss value every step - no extra launch -
+    # and the every-step mean is the default, as in the reference's log column)
+    every = getattr(args, "loss_every_step", None)
+    if every is None:
+        every = fused is not None and fused._direct_loss
+    loss_stride = 1 if every else max(1, int(args.print_freq) // 16)
+    loss_key = "avg_train_loss" if (loss_stride == 1 or fused is None) else "avg_train_loss_sampled"
     for it in range(args.num_iters):
         x = make_batch_ftn_train() if draws == 1 else torch.cat([make_batch_ftn_train() for _ in range(draws)])
         x = x.to(device)
@@ -251,6 +268,15 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                 raise ValueError(f"the sampler returns {x.shape[0] // draws} rows, args.batch_size says "
                                  f"{args.batch_size}: several ranks need them equal")
             fused = None  # the sampler does not produce args.batch_size rows: the plain loop takes any batch
+        if fused is not None and it == 0 and comm is not None and fused.hp:
+            # heads sharded: every rank must step on the SAME global batch (equally seeded samplers): compare the first
+            # one across the ranks instead of trusting the script's seeding
+            probe = x.float().reshape(-1)[:256].contiguous()
+            allp = torch.empty((comm.world, probe.numel()), dtype=torch.float32, device=probe.device)
+            comm.all_gather(allp, probe)
+            if not bool((allp == allp[0:1]).all()):
+                raise RuntimeError("heads sharded over several ranks: the ranks' samplers draw different batches "
+                                   "(seed every rank identically, or pass args.parallelism = 'dp')")
         if fused is not None:
             fused.step(x.float().contiguous())
             if (it + 1) % loss_stride == 0 or (it + 1) % args.print_freq == 0:
@@ -270,7 +296,7 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
             n_loss += 1
         if (it + 1) % args.print_freq == 0:
             # the only host sync, and only at print time (the reference syncs every step)
-            row = {"iter": it + 1, "train_loss": float(loss), "avg_train_loss": float(total_loss) / n_loss,
+            row = {"iter": it + 1, "train_loss": float(loss), loss_key: float(total_loss) / n_loss,
                    "time": time.time() - start}
             if rank0:
                 print(row)

@@ -241,6 +241,19 @@ def operator_sample_features(shape: ModelShape, params: Params, prob: Problem, s
     check(rc, "nsvd_operator_sample_features")
 
 
+def operator_sample_features_dev(shape: ModelShape, params: Params, prob: Problem, seed: int, offset_base: int,
+                                 state: "StepState", x: torch.Tensor, ws: torch.Tensor,
+                                 save_for_backward: bool = True, path: int = PATH_AUTO) -> None:
+    """operator_sample_features whose batch counter is offset_base + state.step, read on the device."""
+    B = x.shape[0]
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_sample_features_dev(C.byref(d), C.byref(params), C.byref(prob),
+                                                       int(seed) & (2 ** 64 - 1), int(offset_base) & (2 ** 64 - 1),
+                                                       state.ptr, _ptr(x, "x"), B, ws.data_ptr(), ws.numel(),
+                                                       int(bool(save_for_backward)), int(path), _stream())
+    check(rc, "nsvd_operator_sample_features_dev")
+
+
 def operator_backward(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, df: torch.Tensor,
                       grads: Params, ws: torch.Tensor, path: int = PATH_AUTO) -> None:
     B = x.shape[0]
@@ -389,16 +402,50 @@ def operator_backward_evd_heads(shape: ModelShape, params: Params, prob: Problem
     check(rc, "nsvd_operator_backward_evd_heads")
 
 
+class StepState:
+    """The device-resident schedule state (include/nsvd.h: nsvd_step_state): step counter, CosineAnnealingLR /
+    RMSprop / torch_ema constants and the scheduled values of the step being taken, in DEVICE memory - what lets a
+    captured training step replay along the schedule (examples/operator/__init__.py:69-73)."""
+
+    def __init__(self, device, lr0: float, T_max: int, alpha: float, eps: float, ema_decay: float, eta_min: float = 0.0,
+                 step: int = 0):
+        self.buf = torch.zeros(C.sizeof(_lib.StepState) // 8, dtype=torch.int64, device=device)
+        self.args = (float(lr0), float(eta_min), int(T_max), float(alpha), float(eps), float(ema_decay))
+        self.reset(step)
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def reset(self, step: int) -> None:
+        lr0, eta_min, T_max, alpha, eps, ema_decay = self.args
+        with torch.cuda.device(self.buf.device):
+            check(_lib.load().nsvd_step_state_init(self.ptr, lr0, eta_min, T_max, alpha, eps, ema_decay, int(step),
+                                                   _stream()), "nsvd_step_state_init")
+
+    def begin(self) -> None:
+        """cur <- the scheduled values of step `step` (loop bodies whose first backward kernel does not do it)"""
+        with torch.cuda.device(self.buf.device):
+            check(_lib.load().nsvd_step_state_begin(self.ptr, _stream()), "nsvd_step_state_begin")
+
+    def read(self) -> "_lib.StepState":
+        """host copy (synchronises)"""
+        raw = self.buf.cpu().numpy().tobytes()
+        return _lib.StepState.from_buffer_copy(raw)
+
+
 def rmsprop_state(sq: Params, ema: Optional[Params], lr: float, alpha: float, eps: float,
-                  ema_decay: float = 0.0) -> _lib.Rmsprop:
-    """nsvd_rmsprop for operator_backward_evd_step; sq / ema are pack_params() sets in the parameters' layouts."""
+                  ema_decay: float = 0.0, state: Optional[StepState] = None) -> _lib.Rmsprop:
+    """nsvd_rmsprop for operator_backward_evd_step; sq / ema are pack_params() sets in the parameters' layouts.
+    state: the device-resident schedule - lr / ema_decay are then read (and advanced) on the device."""
     o = _lib.Rmsprop()
     o.sq = sq
     if ema is not None:
         o.ema = ema
     o.lr, o.alpha, o.eps, o.ema_decay = float(lr), float(alpha), float(eps), float(ema_decay)
     o.has_ema = int(ema is not None)
-    o._keepalive = (sq, ema)
+    o.state = state.ptr if state is not None else None
+    o._keepalive = (sq, ema, state)
     return o
 
 
@@ -546,6 +593,18 @@ def rmsprop_ema_step(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, ema:
                                            float(lr), float(alpha), float(eps), float(ema_decay), float(grad_scale),
                                            _stream())
     check(rc, "nsvd_rmsprop_ema_step")
+
+
+def rmsprop_ema_step_dev(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, ema: Optional[torch.Tensor],
+                         state: "StepState", grad_scale: float = 1.0, advance: bool = True) -> None:
+    """rmsprop_ema_step with lr / EMA decay read from the device-resident schedule; advance: last optimiser launch of
+    the step (state.step += 1 on the device)."""
+    n = p.numel()
+    if grad.numel() != n or sq.numel() != n or (ema is not None and ema.numel() != n):
+        raise NsvdError("rmsprop_ema_step_dev: size mismatch")
+    rc = _lib.load().nsvd_rmsprop_ema_step_dev(_ptr(p, "p"), _ptr(grad, "grad"), _ptr(sq, "sq"), _ptr(ema, "ema"), n,
+                                               state.ptr, float(grad_scale), int(bool(advance)), _stream())
+    check(rc, "nsvd_rmsprop_ema_step_dev")
 
 
 def spectrum_accumulate(f: torch.Tensor, Tf: torch.Tensor, x: torch.Tensor, sigma: float, use_importance: bool,
@@ -702,6 +761,7 @@ def cdk_step(desc: "_lib.CdkStepDesc", x: torch.Tensor, y: torch.Tensor, towers:
 
 # every wrapper that launches kernels runs on the device of its tensors (see _on_tensor_device)
 for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
+              "operator_sample_features_dev", "rmsprop_ema_step_dev",
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
               "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "operator_backward_evd_step_next", "model_backward_evd_step", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",

@@ -66,6 +66,7 @@ class FlatParams:
         self.sq = torch.zeros_like(self.flat) if with_state else None
         self.ema = torch.zeros_like(self.flat) if with_state else None
         self.fourier_B = torch.zeros((shape.D, shape.m), dtype=torch.float32, device=self.device)
+        self.state_sharded = False  # set by the trainer while sq / ema are valid on this rank's shards only
         nl = len(shape.dims)
         self.names = [f"model.base.ws.{i}" for i in range(nl)] + [f"model.base.bs.{i}" for i in range(nl)]
         if shape.has_exp_mask:
@@ -89,6 +90,9 @@ class FlatParams:
             self.ema.copy_(self.flat)  # torch_ema: shadow = clone of the parameters at construction
 
     def state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
+        if ema and self.state_sharded:
+            raise RuntimeError("the EMA shadow is valid on this rank's optimiser shards only (dp_exchange rs_ag / a2a): "
+                               "call FusedTrainer.gather_optimizer_state() on EVERY rank first")
         src = self.ema if ema else self.flat
         d = {n: t.clone() for n, t in zip(self.names, self.views(src))}
         d["model.base.feature_map._B"] = self.fourier_B.clone()
@@ -123,7 +127,8 @@ class FusedTrainer:
                  device="cuda:0", path: int = H.PATH_AUTO, comm=None, sample_seed: Optional[int] = None,
                  parallelism: str = "dp", fused_step: bool = True, keep_grads: bool = False,
                  device_sampler: bool = True, overlap: bool = True, grad_buckets: int = 4,
-                 dp_exchange: str = "allreduce", grad_windows: Optional[int] = None, sync_collectives: bool = False):
+                 dp_exchange: str = "allreduce", grad_windows: Optional[int] = None, sync_collectives: bool = False,
+                 device_schedule: bool = False):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
         them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
@@ -143,7 +148,12 @@ class FusedTrainer:
         grad_windows (dp, world > 1): head windows the backward is cut into so that a window's gradients go on the
         wire while the next window is computed (None: as many of 4 / 2 / 1 as still give every CU a dW_0 tile).
         sync_collectives (world > 1): blocking collectives on the compute stream instead of asynchronous ones with late
-        waits (parallel.dp_step); nothing is then prepared under a collective (hp: the next batch rides in the backward)."""
+        waits (parallel.dp_step); nothing is then prepared under a collective (hp: the next batch rides in the backward).
+        device_schedule (fused step on the MFMA path): the scheduled learning rate, the warmed-up EMA decay and the
+        sampler's batch counter live in DEVICE memory (hip_ops.StepState; the backward's first kernel derives the step's
+        values, its last one advances the counter) instead of travelling as launch arguments - what makes a step
+        replayable from a captured HIP graph (capture_graph). The values are the host path's except that the device
+        cosine may differ from libm's in the last bit of the double (include/nsvd.h)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise H.NsvdError(f"FusedTrainer needs a GPU device (got {self.device}); there is no CPU path")
@@ -174,6 +184,7 @@ class FusedTrainer:
         self.lr, self.alpha, self.eps = lr, rmsprop_decay, rmsprop_eps
         self.ema_decay, self.num_iters, self.use_sched = ema_decay, num_iters, use_lr_scheduler
         self.sigma = sampling_scale
+        self.device_schedule = bool(device_schedule)
         with torch.cuda.device(self.device):
             self._build(shape, problem, fourier_scale, exp_mask_init, seed, sample_seed, sequential, step, fused_step,
                         keep_grads, device_sampler, overlap, grad_buckets, world, rank, dp_exchange, grad_windows)
@@ -241,6 +252,10 @@ class FusedTrainer:
         self.direct_moments = (not multi or self.hp) and self.B <= 1024 and \
             H.path_name(shape, self.B, path, problem) == "fused_mfma"
         self._loss_stale = False
+        self._moments_stale = False
+        # direct moments AND every head local: the backward's kernels also leave the loss value of the step
+        # (include/nsvd.h, nsvd_operator_backward_evd: per-head partial sums added in the weight-gradient kernel)
+        self._direct_loss = self.direct_moments and not self.hp and self.B <= 1024
         self.scratch = H.evd_scratch(self.B, Lg, self.device)
         self.x = torch.empty((self.B, shape.D), dtype=torch.float32, device=self.device)
         self._x_cur = self.x
@@ -260,6 +275,13 @@ class FusedTrainer:
         self.t = 0            # optimiser / scheduler steps taken
         self.num_updates = 0  # torch_ema counter
         self._lr_now, self._decay_now = self.lr, self.ema_decay
+        self.state = None     # hip_ops.StepState: the schedule on the device
+        if self.device_schedule:
+            if not (self.fused_step and H.path_name(shape, self.B, path, problem) == "fused_mfma"):
+                raise H.NsvdError("device_schedule needs the fused optimiser step on the MFMA path (single GPU or "
+                                  "heads sharded, 128-wide hidden layers)")
+            self.state = H.StepState(self.device, self.lr, self.num_iters if self.use_sched else 0, self.alpha,
+                                     self.eps, self.ema_decay)
         # dp gradient buckets: W_0 (89 % of the bytes, first in the flat buffer) cut on head boundaries, the small
         # tensors ride with the last cut
         nb = max(1, min(int(grad_buckets), shape.L))
@@ -331,24 +353,29 @@ class FusedTrainer:
         if reduced:
             assert reduced_moments is self._moments
         elif self.direct_moments:
-            moments = scratch = loss = None
-            self._loss_stale = True
+            moments = scratch = None
+            loss = self._loss if self._direct_loss else None
+            self._loss_stale = loss is None
+            self._moments_stale = True
         elif self._partials_ready:
             self._partials_ready = False  # left by after_gather (heads sharded), for this f, Tf
         else:
             H.evd_partial(self.f_g, self.Tf_g, self.mask_kind, v, self.scratch)
         x = self._x_cur
         if self.fused_step and take_step:
+            t_before = self.t
             lr, decay = self._advance_schedule()
-            opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay)
+            # (device schedule: lr / decay are read on the device, the host values only keep the counters in step)
+            opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay, self.state)
             if self.guest_features and self._own_batch and not self._next_ready and \
                     (not self.multi or not self.overlap):
                 # the next batch rides in this backward's first launch (hp with overlap prepares it under its
                 # all-gather instead: parallel.hp_step -> prefetch)
                 H.operator_backward_evd_step_next(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
                                                   self.mask_kind, v, M, moments, reduced, scratch, loss, None, opt,
-                                                  self.ws, self.sample_key, self.batches_drawn, self._x_other,
-                                                  self._ws_other, 1.0, self.path, l_offset=self.l_off)
+                                                  self.ws, self.sample_key,
+                                                  self.batches_drawn - (t_before if self.state is not None else 0),
+                                                  self._x_other, self._ws_other, 1.0, self.path, l_offset=self.l_off)
                 self.batches_drawn += 1
                 self._next_ready = True
                 return
@@ -392,7 +419,7 @@ class FusedTrainer:
         return self._gshard[off:off + q]
 
     def apply_shard(self, lo: int, hi: int, g: torch.Tensor, grad_scale: float) -> None:
-        self._state_sharded = True
+        self._state_sharded = self.P.state_sharded = True
         H.rmsprop_ema_step(self.P.flat[lo:hi], g, self.P.sq[lo:hi], self.P.ema[lo:hi], self._lr_now, self.alpha,
                            self.eps, self._decay_now, grad_scale)
 
@@ -416,16 +443,17 @@ class FusedTrainer:
             for lo, hi in self._stage_buckets:
                 slo, shi = shard_range(lo, hi, self.comm.rank, self.world)
                 self.comm.all_gather_flat(buf[lo:hi], buf[slo:shi])
-        self._state_sharded = False
+        self._state_sharded = self.P.state_sharded = False
 
-    def state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
-        """The WHOLE model in the reference's state_dict layout (keys model.base.ws.{i}, ...), on every rank: with
-        heads sharded each rank's (L / world, ...) slices are gathered; with a sharded optimiser (dp rs_ag / a2a) the EMA
-        shadow is made whole first. ema=True: the EMA weights (what the reference evaluates and checkpoints)."""
-        if ema:
-            self.gather_optimizer_state()
+    def state_dict(self, ema: bool = False, gather: bool = True) -> Dict[str, torch.Tensor]:
+        """The model in the reference's state_dict layout (keys model.base.ws.{i}, ...). ema=True: the EMA weights (what
+        the reference evaluates and checkpoints).
+        COLLECTIVES ARE EXPLICIT: with heads sharded (hp) the whole model is gathered - call on EVERY rank
+        (`if rank == 0: tr.state_dict()` would wait for the other ranks forever) - or pass gather=False for this rank's
+        (L / world, ...) slices only; with a sharded optimiser state (dp, rs_ag / a2a) ema=True raises until
+        gather_optimizer_state() has been called (on every rank: it is the collective)."""
         sd = self.P.state_dict(ema)
-        if not self.hp:
+        if not self.hp or not gather:
             return sd
         for n in self.P.names:
             v = sd[n].contiguous()
@@ -475,22 +503,28 @@ class FusedTrainer:
                 parallel.dp_step(self, self.comm, x, take_step, exchange=self.dp_exchange, probe=self.probe,
                                  sync=self.sync_collectives)
 
-    def _refresh_loss(self) -> None:
-        if self._loss_stale:  # direct-moment steps do not produce them: evaluate for the last batch now
+    def _refresh_loss(self, want_moments: bool = False) -> None:
+        # direct-moment steps do not produce the moment vector (and, with heads sharded, not the loss either):
+        # evaluate for the last batch now
+        if self._loss_stale or (want_moments and self._moments_stale):
             v, M = self._masks()
+            keep = self._loss.clone() if not self._loss_stale else None
             H.evd_loss_fused(self.f_g, self.Tf_g, self.mask_kind, v, M, self._moments, self._loss, None, self.scratch)
-            self._loss_stale = False
+            if keep is not None:
+                self._loss.copy_(keep)  # the value the step's own kernels left stays the one reported
+            self._loss_stale = self._moments_stale = False
 
     @property
     def loss(self) -> torch.Tensor:
-        """{loss, operator term, metric term} of the last step's batch."""
+        """{loss, operator term, metric term} of the last step's batch (single GPU, batches of <= 1024 rows: written by
+        the step's own kernels every step, as the reference computes it every step: methods/nestedlora.py:92-94)."""
         self._refresh_loss()
         return self._loss
 
     @property
     def moments(self) -> torch.Tensor:
         """(2 L^2 + 1) moment vector of the last step's batch."""
-        self._refresh_loss()
+        self._refresh_loss(want_moments=True)
         return self._moments
 
     def _advance_schedule(self):
@@ -516,37 +550,113 @@ class FusedTrainer:
                 self._next_ready = False
             else:
                 with torch.cuda.device(self.device):
-                    H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
-                                               self.batches_drawn, self.x, self.ws, True, self.path)
+                    if self.state is not None:  # the batch counter is read on the device: base + state.step
+                        H.operator_sample_features_dev(self.shape, self._params, self.problem, self.sample_key,
+                                                       self.batches_drawn - self.t, self.state, self.x, self.ws, True,
+                                                       self.path)
+                    else:
+                        H.operator_sample_features(self.shape, self._params, self.problem, self.sample_key,
+                                                   self.batches_drawn, self.x, self.ws, True, self.path)
                 self.batches_drawn += 1
             self.forward_backward(self.x, features_ready=True)
         else:
             self.forward_backward(self.sample())
 
+    # -- HIP-graph replay -------------------------------------------------------------------------
+    def capture_graph(self, steps: int = 2) -> "GraphedSteps":
+        """Capture `steps` consecutive step() calls (internal device sampler) into one HIP graph and return the
+        replayable object. Needs device_schedule=True (otherwise the captured launches would carry one step's learning
+        rate, EMA decay and batch counter as frozen arguments) and a single process (no collective inside). With the
+        next batch prepared by the backward's guest workgroups the two (workspace, x) sets alternate, so `steps` must be
+        even; one eager step is taken first when no batch is prepared yet."""
+        return GraphedSteps(self, steps)
+
     # -- evaluation (methods/spectrum.py:29-102 under EMA weights, operator/__init__.py:108) ----
     @torch.no_grad()
     def spectrum(self, lim: float, val_eps: float, use_ema: bool = True, chunk: int = 8192):
-        """Rayleigh-quotient spectrum on the uniform grid arange(-lim, lim, val_eps)^D (main_pde.py:121-130)."""
-        D, L = self.shape.D, self.shape.L
-        if use_ema:
-            self.gather_optimizer_state()
-        with torch.cuda.device(self.device):
-            import numpy as np
-            ax = torch.from_numpy(np.arange(-lim, lim, val_eps))  # numpy's arange values (start + i * step)
-            # np.meshgrid's default 'xy' indexing, flattened row-major: the reference's point order
-            grid = torch.stack([g.reshape(-1) for g in torch.meshgrid(*(D * [ax]), indexing="xy" if D > 1 else "ij")],
-                               dim=1).float().to(self.device)
-            params = self._ema_params if use_ema else self._params
-            cov = torch.zeros((L, L), dtype=torch.float32, device=self.device)
-            quad = torch.zeros_like(cov)
-            ws = H.new_workspace(self.shape, min(chunk, grid.shape[0]), self.device)
-            for i in range(0, grid.shape[0], chunk):
-                xb = grid[i:i + chunk]
-                # a ragged last chunk is outside the MFMA kernels' shapes: let the library choose the path for it
-                path = self.path if xb.shape[0] % 32 == 0 else H.PATH_AUTO
-                wsb = ws if xb.shape[0] == chunk else H.new_workspace(self.shape, xb.shape[0], self.device)
-                f, Tf = H.operator_forward(self.shape, params, self.problem, xb, wsb, False, path)
-                H.spectrum_accumulate(f, Tf, xb, self.problem.sigma, bool(self.problem.use_importance), lim, cov, quad)
-        n = grid.shape[0]
-        cov, quad = cov.double().cpu() / n, quad.double().cpu() / n
-        return dict(cov=cov, quad=quad, eigvals=torch.diag(quad) / torch.diag(cov), norms=torch.diag(cov))
+        """Rayleigh-quotient spectrum on the uniform grid arange(-lim, lim, val_eps)^D (main_pde.py:121-130), over ALL
+        heads of the model (heads sharded: a collective - call on every rank)."""
+        if use_ema and self._state_sharded:
+            raise RuntimeError("spectrum(use_ema=True): the EMA shadow is sharded over the ranks (dp_exchange rs_ag / "
+                               "a2a); call gather_optimizer_state() on every rank first")
+        if self.hp:
+            # heads sharded: the metric needs every head (cov / quad are (L, L) over ALL heads) - gather the model (a
+            # collective: call on every rank) and evaluate all heads here
+            sd = self.state_dict(ema=use_ema)
+            full = FlatParams(self.full_shape, self.device, with_state=False)
+            full.load_state_dict(sd)
+            return _spectrum_of(self.full_shape, full.pack(full.flat, True), self.problem, self.device, self.path, lim,
+                                val_eps, chunk)
+        return _spectrum_of(self.shape, self._ema_params if use_ema else self._params, self.problem, self.device,
+                            self.path, lim, val_eps, chunk)
+
+
+@torch.no_grad()
+def _spectrum_of(shape, params, problem, device, path, lim, val_eps, chunk):
+    """compute_spectrum_evd's accumulation (methods/spectrum.py:56-86) for one parameter set on the uniform grid
+    arange(-lim, lim, val_eps)^D (main_pde.py:121-130)."""
+    import numpy as np
+    D, L = shape.D, shape.L
+    with torch.cuda.device(device):
+        ax = torch.from_numpy(np.arange(-lim, lim, val_eps))  # numpy's arange values (start + i * step)
+        # np.meshgrid's default 'xy' indexing, flattened row-major: the reference's point order
+        grid = torch.stack([g.reshape(-1) for g in torch.meshgrid(*(D * [ax]), indexing="xy" if D > 1 else "ij")],
+                           dim=1).float().to(device)
+        cov = torch.zeros((L, L), dtype=torch.float32, device=device)
+        quad = torch.zeros_like(cov)
+        ws = H.new_workspace(shape, min(chunk, grid.shape[0]), device)
+        for i in range(0, grid.shape[0], chunk):
+            xb = grid[i:i + chunk]
+            # a ragged last chunk is outside the MFMA kernels' shapes: let the library choose the path for it
+            pth = path if xb.shape[0] % 32 == 0 else H.PATH_AUTO
+            wsb = ws if xb.shape[0] == chunk else H.new_workspace(shape, xb.shape[0], device)
+            f, Tf = H.operator_forward(shape, params, problem, xb, wsb, False, pth)
+            H.spectrum_accumulate(f, Tf, xb, problem.sigma, bool(problem.use_importance), lim, cov, quad)
+    n = grid.shape[0]
+    cov, quad = cov.double().cpu() / n, quad.double().cpu() / n
+    return dict(cov=cov, quad=quad, eigvals=torch.diag(quad) / torch.diag(cov), norms=torch.diag(cov))
+
+
+class GraphedSteps:
+    """`steps` training steps of a FusedTrainer as ONE captured HIP graph: the loop body of
+    examples/operator/__init__.py:55-74 (sample, forward, loss, backward, RMSprop, cosine schedule, EMA) replayed
+    with one host call per `steps` steps and no launch arguments that depend on the step (hip_ops.StepState)."""
+
+    def __init__(self, tr: FusedTrainer, steps: int = 2):
+        if tr.state is None:
+            raise H.NsvdError("capture_graph needs FusedTrainer(device_schedule=True)")
+        if tr.multi:
+            raise H.NsvdError("capture_graph: single-process steps only (no collective inside the graph)")
+        if not tr.device_sampler:
+            raise H.NsvdError("capture_graph needs the device sampler (the batch must be drawn inside the graph)")
+        if steps < 1 or (tr.guest_features and steps % 2):
+            raise ValueError("steps must be positive, and even when the workspace sets alternate (guest features)")
+        self.tr, self.steps = tr, int(steps)
+        with torch.cuda.device(tr.device):
+            if tr.guest_features and not tr._next_ready:
+                tr.step()  # the first batch is drawn by a launch of its own; from then on by the previous backward
+            # without guest features every step draws its batch with nsvd_operator_sample_features_dev (below)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            self.graph = torch.cuda.CUDAGraph()
+            before = (tr.t, tr.num_updates, tr.batches_drawn)
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(self.graph, stream=side):
+                    for _ in range(self.steps):
+                        tr.step()
+            torch.cuda.current_stream().wait_stream(side)
+            # capture only recorded the launches: the host counters go back, replay() advances them
+            tr.t, tr.num_updates, tr.batches_drawn = before
+
+    def replay(self, n: int = 1) -> None:
+        """n replays = n * steps optimiser steps"""
+        tr = self.tr
+        for _ in range(n):
+            self.graph.replay()
+        k = n * self.steps
+        tr.t += k
+        tr.num_updates += k
+        tr.batches_drawn += k
+        tr._loss_stale = not tr._direct_loss
+        tr._moments_stale = True

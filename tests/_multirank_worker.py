@@ -52,7 +52,7 @@ def ko_case(dev, world):
     return op, kw, batches
 
 
-def dropin_case(world_rows, dev):
+def dropin_case(world_rows, dev, seed_offset=0):
     """the reference-style objects of a small oscillator problem on the MFMA kernels (128-wide layers), built through
     this package's mirrors of the reference API exactly as main_pde.py builds them; batch_size = world_rows"""
     import argparse
@@ -67,7 +67,7 @@ def dropin_case(world_rows, dev):
                                 neuralsvd=argparse.Namespace(step=cfg["step"], sequential=cfg["sequential"]))
     a.adam_eps, a.use_lr_scheduler, a.ema_decay, a.log_dir = 1e-7, True, 0.995, None
     a.print_freq, a.eval_freq = 10 ** 9, cfg["num_iters"]
-    torch.manual_seed(cfg["seed"])
+    torch.manual_seed(cfg["seed"] + seed_offset)  # seed_offset: a rank that seeds itself differently (a DDP habit)
     operator, _ = get_problem(a, dev)
     model = get_wavefunctions(a)
     loaders = get_dataloader(a, dev)
@@ -166,13 +166,17 @@ def main():
                 res["f0"], res["Kf0"] = fk.f.clone().cpu(), fk.Kf.clone().cpu()
         res.update(views=[v.cpu() for v in fk.P.views(fk.P.flat)], sq=[v.cpu() for v in fk.P.views(fk.P.sq)],
                    l_off=fk.l_off, t=fk.t)
-    elif mode in ("dropin_hp", "dropin_dp"):
+    elif mode in ("dropin_hp", "dropin_dp", "dropin_hp_perrank", "dropin_dp_perrank"):
         # the reference-signature training loop (drop_in.train_operator) started on several ranks by a launcher: it
         # finds RANK / WORLD_SIZE itself, shards heads (or samples) and leaves the WHOLE model in `method` on every rank
         import neural_svd_amd.drop_in as DI
         comm.close()  # train_operator makes its own communicator from the environment
         os.environ["NSVD_DIST_BACKEND"] = "gloo"
-        args, operator, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = dropin_case(32, dev)
+        # *_perrank: every rank builds its model from its own seed - rank 0's weights and Fourier matrix must win
+        perrank = mode.endswith("_perrank")
+        args, operator, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = \
+            dropin_case(32, dev, seed_offset=100 * rank if perrank else 0)
+        mode = mode.replace("_perrank", "")
         args.parallelism = mode[-2:]
         blocks = iter(dropin_blocks())
         if mode == "dropin_dp":  # every rank its own rows: rank r takes block world * step + r

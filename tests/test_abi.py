@@ -51,9 +51,11 @@ def test_struct_layout_matches_header():
     #include <stdio.h>
     #include "nsvd.h"
     #include <stddef.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nsvd_model_desc), sizeof(nsvd_params),
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nsvd_model_desc), sizeof(nsvd_params),
                        sizeof(nsvd_problem), sizeof(nsvd_tower_params), sizeof(nsvd_rmsprop), sizeof(nsvd_cdk_step_desc),
-                       offsetof(nsvd_cdk_step_desc, lr), offsetof(nsvd_cdk_step_desc, gemm_bf16)); return 0; }
+                       offsetof(nsvd_cdk_step_desc, lr), offsetof(nsvd_cdk_step_desc, gemm_bf16),
+                       offsetof(nsvd_rmsprop, state), sizeof(nsvd_step_state), offsetof(nsvd_step_state, cur),
+                       offsetof(nsvd_step_state, ema_decay)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "t.c")
@@ -64,7 +66,9 @@ def test_struct_layout_matches_header():
     assert [int(v) for v in out] == [ctypes.sizeof(_lib.ModelDesc), ctypes.sizeof(_lib.Params),
                                      ctypes.sizeof(_lib.Problem), ctypes.sizeof(_lib.TowerParams),
                                      ctypes.sizeof(_lib.Rmsprop), ctypes.sizeof(_lib.CdkStepDesc),
-                                     _lib.CdkStepDesc.lr.offset, _lib.CdkStepDesc.gemm_bf16.offset]
+                                     _lib.CdkStepDesc.lr.offset, _lib.CdkStepDesc.gemm_bf16.offset,
+                                     _lib.Rmsprop.state.offset, ctypes.sizeof(_lib.StepState), _lib.StepState.cur.offset,
+                                     _lib.StepState.ema_decay.offset]
 
 
 def test_ops_refuse_cpu_tensors():

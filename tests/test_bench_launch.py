@@ -57,6 +57,14 @@ def test_bench_two_ranks_exactly_as_the_driver_calls_it():
     assert set(tuned) == {"dp2", "hp2"} and par == max(tuned, key=tuned.get)
     assert d["value"] > 0 and d["params_finite"] and d["scaling"] == "weak"
     assert d["rccl_ranks"] == 2 and "launcher_retry" not in d
+    # what `value` is at N > 1, spelled out, with the two unambiguous rates beside it
+    assert d["global_batch"] == 1024 and "per-GPU batches" in d["value_is"]
+    assert abs(d["optimizer_steps_per_s"] * 2 - d["value"]) < 1e-2 * d["value"]
+    assert abs(d["samples_per_s"] - d["optimizer_steps_per_s"] * 1024) < 1e-2 * d["samples_per_s"]
+    # north_star's literal split (dp, one moments all-reduce + one gradient all-reduce, blocking) is always on the line
+    ns = d["north_star_split"]
+    assert ns["parallelism"] == "dp2" and ns["value"] > 0 and ns["params_finite"] and "--sync" in ns["flags"]
+    assert ns["global_batch"] == 1024 and abs(ns["optimizer_steps_per_s"] * 2 - ns["value"]) < 1e-2 * ns["value"]
     c = d["comm"]
     assert c["backend"] == "gloo"
     assert c["compute_only_ms"] > 0 and c["step_ms"] == d["ms_per_step"]
@@ -88,11 +96,12 @@ def test_bench_two_ranks_exactly_as_the_driver_calls_it():
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_launcher_retries_with_the_plain_exchange_when_the_tuned_run_dies():
-    """the auto-tuned attempt is made to die on one rank (NSVD_BENCH_INJECT_FAILURE): the launcher must start the ranks
-    again with the plainest sequence and still deliver ONE line, marked with what failed"""
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
-                       env=_env(NSVD_FORCE_DEVICE="0", NSVD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
-                                NSVD_BENCH_INJECT_FAILURE="tuned"),
+    """the auto-tuned attempt is made to die on one rank (tests/_bench_failing_rank.py wraps bench.py: the launcher
+    starts its ranks as the script it was started as): the launcher must start the ranks again with the plainest
+    sequence and still deliver ONE line, marked with what failed"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_bench_failing_rank.py"), "--gpus", "2", "--steps",
+                        "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=_env(NSVD_FORCE_DEVICE="0", NSVD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"),
                        capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -413,6 +413,65 @@ def test_fused_step_bit_identical_at_headline_size():
     assert torch.equal(c.P.grad, b.P.grad)
 
 
+def test_three_step_trajectory_at_the_headline_shape_against_the_oracle():
+    """configs[1]'s shape (hydrogen, L = 16, B = 512, m = 1024, 128 x 3, joint nesting): three consecutive
+    FusedTrainer.step() calls - device sampler, forward, loss, backward, RMSprop with a moving cosine learning rate,
+    EMA with its warm-up - each checked against the float64 oracle (loss_and_grads' pieces + rmsprop_step + ema_update,
+    i.e. the loop body of examples/operator/__init__.py:55-74) on two sampled heads, all 512 rows.
+    The oracle is re-started from the trainer's own state at the beginning of every step: RMSprop's first steps are
+    sign-like (|update| = lr / sqrt(1 - alpha) whatever |g|), so free-running float32 and float64 trajectories separate
+    at the elements whose gradient is at the rounding level - what is compared is every step of the trajectory, with
+    the state (parameters, square averages, EMA shadow, schedule position) carried by the trainer."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    L, D, m, hidden, B, T = 16, 2, 1024, (128, 128, 128), 512, 10
+    shape = H.ModelShape(L=L, D=D, m=m, hidden=hidden)
+    prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+    tr = FusedTrainer(shape, prob, B, sequential=False, lr=1e-4, num_iters=T, seed=0, device=DEV)
+    assert tr.fused_step and tr.guest_features and tr.direct_moments
+    prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+    v, M = O.joint_nesting_masks(L, 1)
+    v, M = v.double(), M.double()
+    nl = len(hidden) + 1
+    heads = (3, 12)
+    for t in range(3):
+        before = {k: [u.clone() for u in tr.P.views(getattr(tr.P, k))] for k in ("flat", "sq", "ema")}
+        tr.step()
+        torch.cuda.synchronize()
+        x, f64, Tf64 = tr.x.double().cpu(), tr.f.double().cpu(), tr.Tf.double().cpu()
+        loss64, lam1, lam2, _, _ = O.evd_loss_forward(f64, Tf64, v, M)
+        assert abs(float(tr.loss[0]) - float(loss64)) < 2e-5 * float(tr.loss[1:].abs().max())
+        df64 = O.evd_loss_backward(f64, Tf64, v, M, lam1, lam2)
+        lr = O.cosine_lr(1e-4, t, T)
+        after = {k: tr.P.views(getattr(tr.P, k)) for k in ("flat", "sq", "ema")}
+        for l in heads:
+            ph = O.Params([before["flat"][i][l:l + 1].double().cpu() for i in range(nl)],
+                          [before["flat"][nl + i][l:l + 1].double().cpu() for i in range(nl)],
+                          tr.P.fourier_B.double().cpu(), None)
+            c = O.operator_forward(x, ph, prob_o)
+            assert rel(tr.f[:, l], c.f[:, 0]) < 2e-5
+            g = O.operator_backward(c, ph, prob_o, df64[:, l:l + 1])
+            ps = ph.trainable()
+            sq = [before["sq"][i][l:l + 1].double().cpu() for i in range(2 * nl)]
+            sh = [before["ema"][i][l:l + 1].double().cpu() for i in range(2 * nl)]
+            p0 = [q.clone() for q in ps]
+            O.rmsprop_step(ps, g, sq, lr, alpha=0.999, eps=1e-10)
+            assert O.ema_update(sh, ps, 0.995, t) == t + 1
+            for i in range(2 * nl):
+                got_p, got_sq, got_e = (after[k][i][l:l + 1].double().cpu() for k in ("flat", "sq", "ema"))
+                assert rel(got_sq, sq[i]) < 2e-4, (t, l, i, rel(got_sq, sq[i]))
+                strong = g[i].abs() > 0.05 * g[i].abs().mean()
+                upd_ref, upd_got = (ps[i] - p0[i])[strong], (got_p - p0[i])[strong]
+                assert float((upd_got - upd_ref).norm() / upd_ref.norm()) < 2e-3, (t, l, i)
+                # EMA: shadow - (1 - d)(shadow - p) with d = min(0.995, (1 + n) / (10 + n)), n = t + 1
+                d = min(0.995, (2 + t) / (11 + t))
+                want_e = before["ema"][i][l:l + 1].double().cpu()
+                want_e = want_e - (1 - d) * (want_e - got_p)
+                assert rel(got_e, want_e) < 1e-6, (t, l, i)
+                assert float((got_e - sh[i])[strong].norm()) <= 2e-3 * float((ps[i] - p0[i])[strong].norm()) + 1e-12
+    assert tr.t == tr.num_updates == 3
+
+
 @pytest.mark.parametrize("D,L,m,B", [(2, 4, 64, 64), (1, 2, 128, 32), (2, 16, 1024, 512)])
 def test_next_batch_by_guest_workgroups_is_bit_identical(D, L, m, B):
     """nsvd_operator_backward_evd_step_next: the next batch drawn and its features written by guest workgroups of the

@@ -1,0 +1,191 @@
+"""HIP-graph capture of the training step ("graph-replayed steps"; the loop body being
+replayed is examples/operator/__init__.py:55-74): the per-step scalars - CosineAnnealingLR's learning rate, torch_ema's
+warmed-up decay, the sampler's batch counter - live in a device-resident nsvd_step_state, so a captured step replays
+ALONG the schedule. Every comparison here is bit for bit."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _trainer(L, m, B, device_schedule, num_iters=60, seed=4, potential="hydrogen", **kw):
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import FusedTrainer
+    if potential == "hydrogen":
+        shape = H.ModelShape(L=L, D=2, m=m, hidden=(128, 128, 128))
+        prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+        extra = dict(sampling_scale=16.0, fourier_scale=0.1)
+    else:
+        shape = H.ModelShape(L=L, D=2, m=m, hidden=(128, 128, 128), has_exp_mask=True)
+        prob = H.make_problem(H.POT_HARMONIC, 1.0, 0.01, 1.0, 16.0, 4.0)
+        extra = dict(sampling_scale=4.0, fourier_scale=1.0, exp_mask_init=10.0)
+    return FusedTrainer(shape, prob, B, sequential=False, lr=1e-3, num_iters=num_iters, seed=seed, device=DEV,
+                        device_schedule=device_schedule, **extra, **kw)
+
+
+def _same(a, b):
+    for name in ("flat", "sq", "ema"):
+        assert torch.equal(getattr(a.P, name), getattr(b.P, name)), name
+    assert torch.equal(a.x, b.x) and torch.equal(a.f, b.f) and torch.equal(a.Tf, b.Tf)
+    assert torch.equal(a.loss, b.loss)
+
+
+def test_device_schedule_values_match_the_host_schedule():
+    """state.cur after nsvd_step_state_init(step = t) against the host expressions of FusedTrainer._advance_schedule /
+    trainer.cosine_lr rounded where nsvd_make_hyper rounds: CosineAnnealingLR's closed form and torch_ema's warm-up
+    (examples/operator/__init__.py:35-36,71-73). The device cosine may differ from libm's in the last bit of the
+    double: at most one float32 ulp on the learning rate, and rarely (asserted: < 1 % of the sampled steps)."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import cosine_lr
+    T, lr0, decay = 500000, 1e-4, 0.995
+    st = H.StepState(DEV, lr0, T, 0.999, 1e-10, decay)
+    rng = np.random.default_rng(0)
+    ts = [0, 1, 2, 8, 9, 10, 1789, 1790, 1791, T // 2, T - 1, T] + [int(t) for t in rng.integers(0, T, 300)]
+    off = 0
+    for t in ts:
+        st.reset(t)
+        h = st.read()
+        assert h.step == t and h.T_max == T
+        want_lr = np.float32(cosine_lr(lr0, t, T))
+        n = t + 1
+        want_omd = np.float32(1.0 - min(decay, (1 + n) / (10 + n)))
+        got_lr = np.float32(h.cur.lr)
+        assert np.float32(h.cur.one_minus_decay) == want_omd, t
+        assert np.float32(h.cur.alpha) == np.float32(0.999) and np.float32(h.cur.one_minus_alpha) == np.float32(1.0 - 0.999)
+        assert np.float32(h.cur.eps) == np.float32(1e-10) and h.cur.grad_scale == 1.0
+        if got_lr != want_lr:
+            off += 1
+            assert abs(float(got_lr) - float(want_lr)) <= float(np.spacing(want_lr)), (t, got_lr, want_lr)
+    assert off <= 0.01 * len(ts), off
+    # no scheduler: constant learning rate
+    st2 = H.StepState(DEV, 3e-4, 0, 0.99, 1e-8, 0.9, step=12345)
+    h = st2.read()
+    assert np.float32(h.cur.lr) == np.float32(3e-4) and np.float32(h.cur.one_minus_decay) == np.float32(1.0 - 0.9)
+
+
+@pytest.mark.parametrize("L,m,B,potential", [(4, 64, 64, "hydrogen"), (8, 128, 128, "oscillator")])
+def test_device_schedule_step_is_the_host_schedule_step(L, m, B, potential):
+    """the same trainer with the schedule on the device (eager launches, no graph) against the plain one: identical
+    batches, parameters, square averages, EMA shadows and losses after 40 steps of a 60-step cosine schedule - and the
+    device counter has advanced by itself."""
+    a = _trainer(L, m, B, False, potential=potential)
+    b = _trainer(L, m, B, True, potential=potential)
+    assert b.state is not None and a.state is None and a.guest_features and b.guest_features
+    for _ in range(40):
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    _same(a, b)
+    h = b.state.read()
+    assert h.step == 40 == b.t == a.t
+    # without guest workgroups (one feature launch per step, its batch counter read on the device)
+    c = _trainer(L, m, B, True, potential=potential, overlap=False)
+    assert not c.guest_features
+    for _ in range(40):
+        c.step()
+    torch.cuda.synchronize()
+    _same(a, c)
+
+
+@pytest.mark.parametrize("L,m,B,steps", [(4, 64, 64, 2), (4, 64, 64, 4), (16, 1024, 512, 2)])
+def test_graph_replay_is_bit_identical_to_eager_steps(L, m, B, steps):
+    """torch.cuda.CUDAGraph capture of `steps` FusedTrainer.step() calls, replayed 25 times, against the same number
+    of eager steps (host schedule AND device schedule): every buffer bit-identical, the schedule has moved (the last
+    learning rate differs from the first), the host counters follow. The last case is configs[1]'s shape."""
+    from neural_svd_amd.trainer import cosine_lr
+    n_replay = 25
+    g = _trainer(L, m, B, True)
+    gs = g.capture_graph(steps)
+    pre = g.t  # one eager step was taken to prepare the first batch
+    assert pre == 1
+    gs.replay(n_replay)
+    torch.cuda.synchronize()
+    total = pre + n_replay * steps
+    assert g.t == g.num_updates == total and g.state.read().step == total
+    e_host = _trainer(L, m, B, False)
+    e_dev = _trainer(L, m, B, True)
+    for _ in range(total):
+        e_host.step()
+        e_dev.step()
+    torch.cuda.synchronize()
+    _same(e_dev, g)
+    _same(e_host, g)
+    # the schedule moved inside the graph: the values of the LAST step taken
+    h = g.state.read()
+    assert np.float32(h.cur.lr) == np.float32(cosine_lr(1e-3, total - 1, 60)) != np.float32(1e-3)
+    # eager steps continue seamlessly after a replay, and a replay after them
+    g.step(); e_host.step()
+    g.step(); e_host.step()
+    gs.replay()
+    for _ in range(steps):
+        e_host.step()
+    torch.cuda.synchronize()
+    _same(e_host, g)
+
+
+def test_graph_of_the_plain_optimiser_launch():
+    """the capturable form of optimizer.step() + scheduler.step() + ema.update() for loop bodies that keep their own
+    backward (examples/operator/__init__.py:69-73): nsvd_step_state_begin + nsvd_rmsprop_ema_step_dev captured once,
+    replayed along the schedule, against nsvd_rmsprop_ema_step with host-scheduled scalars."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.trainer import cosine_lr
+    n, T = 100003, 30
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    p0 = torch.randn(n, device=DEV, generator=gen)
+    grads = [torch.randn(n, device=DEV, generator=gen) for _ in range(12)]
+    pa, sqa, ema_a = p0.clone(), torch.zeros_like(p0), p0.clone()
+    pb, sqb, ema_b = p0.clone(), torch.zeros_like(p0), p0.clone()
+    for t, g in enumerate(grads):
+        nup = t + 1
+        H.rmsprop_ema_step(pa, g, sqa, ema_a, cosine_lr(1e-3, t, T), 0.999, 1e-10, min(0.995, (1 + nup) / (10 + nup)))
+    st = H.StepState(DEV, 1e-3, T, 0.999, 1e-10, 0.995)
+    gbuf = torch.empty_like(p0)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            st.begin()
+            H.rmsprop_ema_step_dev(pb, gbuf, sqb, ema_b, st, 1.0, True)
+    torch.cuda.current_stream().wait_stream(side)
+    for g in grads:
+        gbuf.copy_(g)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert st.read().step == len(grads)
+    assert torch.equal(pa, pb) and torch.equal(sqa, sqb) and torch.equal(ema_a, ema_b)
+
+
+def test_loss_value_of_every_step_comes_from_the_step_s_own_kernels():
+    """single GPU, batch <= 1024 rows: the backward takes its moments straight from f (no moment kernel) and ALSO
+    leaves the loss value - the reference computes it every step (methods/nestedlora.py:92-94) - as per-head partial
+    sums the weight-gradient kernel adds; against the stand-alone loss kernels on the same f, Tf and the float64
+    oracle formula."""
+    from neural_svd_amd import hip_ops as H
+    from oracle import nsvd_oracle as O
+    for L, m, B, seq in ((16, 1024, 512, False), (16, 256, 1024, True), (4, 64, 96, False), (32, 128, 512, True)):
+        from neural_svd_amd.trainer import FusedTrainer
+        shape = H.ModelShape(L=L, D=2, m=m, hidden=(128, 128, 128))
+        prob = H.make_problem(H.POT_HYDROGEN, 1.0, 0.01, 100.0, 0.0, 16.0)
+        tr = FusedTrainer(shape, prob, B, sequential=seq, seed=1, device=DEV)
+        assert tr.direct_moments and tr._direct_loss
+        for _ in range(3):
+            tr.step()
+        got = tr._loss.clone()
+        assert not tr._loss_stale
+        ref = torch.empty(3, device=DEV)
+        mom = torch.empty(2 * L * L + 1, device=DEV)
+        H.evd_loss_fused(tr.f, tr.Tf, tr.mask_kind, None, None, mom, ref, None, tr.scratch)
+        v, M = (O.sequential_nesting_masks(L) if seq else O.joint_nesting_masks(L, 1))
+        l64, *_ = O.evd_loss_forward(tr.f.double().cpu(), tr.Tf.double().cpu(), v.double(), M.double())
+        torch.cuda.synchronize()
+        scale = float(ref[1:].abs().max())
+        assert float((got - ref).abs().max()) < 2e-6 * scale, (L, B, got, ref)
+        assert abs(float(got[0]) - float(l64)) < 2e-5 * scale
+        assert torch.equal(tr.moments, mom)  # on demand, and the reported loss stays the step's own
+        assert torch.equal(tr.loss, got)

@@ -827,6 +827,76 @@ def test_backward_headline_size_sampled_heads():
             assert rel(r["grads"][nl + i][l], gref[nl + i][0]) < 3e-5, (l, i)
 
 
+def test_configs2_at_its_global_batch_on_one_gpu():
+    """BASELINE.json configs[2] at its OWN batch on one GPU - 2D harmonic oscillator, L = 32, B = 4096, sequential
+    nesting, exponential mask, m = 256 (scripts/exps/pde/oscillator.sh:12-53) - the N = 1 end of the 1 -> 8 curve and a
+    different code path from the 512-row per-GPU shape: 16 rounds of chain workgroups, partial-moment backward (batches
+    beyond 1024 rows), split weight-gradient tiles.
+      * forward: bit reproducibility, row equivariance, homogeneity, 8 sampled rows x all heads against float64;
+      * loss: moments, loss and d loss / d f from (f, Tf) against the float64 formulas (methods/nestedlora.py:70-111);
+      * backward (nsvd_operator_backward_evd on the partial moments): every gradient of two sampled heads, all 4096
+        rows, against the float64 oracle's backward with the float64 d loss / d f of the same (f, Tf)."""
+    L, D, m, hidden, B = 32, 2, 256, (128, 128, 128), 4096
+    p = O.init_params(L, D, m, hidden, 1.0, exp_mask_init=10.0, seed=0)
+    prob_o = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=4.0)
+    kcfg = dict(operator_scale=1.0, laplacian_eps=0.01)
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    prob = hip_problem(prob_o)
+    x = (prob_o.sigma * torch.randn(B, D, generator=torch.Generator().manual_seed(5))).to(DEV)
+    ws = H.new_workspace(shape, B, DEV)
+    assert H.path_name(shape, B, H.PATH_AUTO, prob) == "fused_mfma"
+    f, Tf = H.operator_forward(shape, params, prob, x, ws)
+    f2, Tf2 = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV))
+    assert torch.equal(f, f2) and torch.equal(Tf, Tf2)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(6)).to(DEV)
+    fp, Tfp = H.operator_forward(shape, params, prob, x[perm].contiguous(), H.new_workspace(shape, B, DEV))
+    assert torch.equal(fp, f[perm]) and torch.equal(Tfp, Tf[perm])
+    c = 2.0
+    fc, Tfc = H.operator_forward(shape, H.pack_params(shape, list(ws_t[:-1]) + [ws_t[-1] * c],
+                                                      list(bs_t[:-1]) + [bs_t[-1] * c], fB, sc), prob, x,
+                                 H.new_workspace(shape, B, DEV))
+    assert torch.equal(fc, c * f) and torch.equal(Tfc, c * Tf)
+    rows = torch.tensor([0, 31, 32, 1023, 1024, 2047, 2048, 4095])
+    p64 = p.to(torch.float64)
+    ref = O.operator_forward(x[rows.to(DEV)].double().cpu(), p64, prob_o)
+    assert rel(f[rows.to(DEV)], ref.f) < 2e-5
+    k = tf_noise_kappa(Tf[rows.to(DEV)], ref.Tf.numpy(), ref.f.numpy(), kcfg)
+    k_ref = oracle32_kappa(x[rows.to(DEV)].double().cpu(), p, prob_o, ref, kcfg)
+    assert k <= 2.0 * k_ref, (k, k_ref)
+    # loss + backward through the C call the trainer makes for batches beyond 1024 rows
+    v, M = O.sequential_nesting_masks(L)
+    scratch = H.evd_scratch(B, L, DEV)
+    H.evd_partial(f, Tf, H.MASK_SEQUENTIAL, None, scratch)
+    gw = [torch.full_like(w, float("nan")) for w in ws_t]
+    gb = [torch.full_like(b, float("nan")) for b in bs_t]
+    gs = torch.full_like(sc, float("nan"))
+    grads = H.pack_params(shape, gw, gb, None, gs)
+    mom = torch.empty(2 * L * L + 1, device=DEV)
+    loss = torch.empty(3, device=DEV)
+    H.operator_backward_evd(shape, params, prob, x, f, Tf, H.MASK_SEQUENTIAL, None, None, mom, False, scratch, loss,
+                            grads, ws)
+    torch.cuda.synchronize()
+    f64, Tf64 = f.double().cpu(), Tf.double().cpu()
+    l64, lam1, lam2 = O.evd_loss_forward(f64, Tf64, v.double(), M.double())[:3]
+    assert abs(float(loss[0]) - float(l64)) < 2e-5 * max(abs(float(loss[1])), abs(float(loss[2])))
+    assert rel(mom[:L * L], lam1.reshape(-1)) < 2e-6 and rel(mom[L * L:2 * L * L], lam2.reshape(-1)) < 2e-6
+    df64 = O.evd_loss_backward(f64, Tf64, v.double(), M.double(), lam1, lam2)
+    xc = x.double().cpu()
+    nl = len(p.ws)
+    for l in (0, 31):
+        ph = O.Params([w[l:l + 1] for w in p.ws], [b[l:l + 1] for b in p.bs], p.fourier_B,
+                      p.scales[l:l + 1]).to(torch.float64)
+        ch = O.operator_forward(xc, ph, prob_o)
+        assert rel(f[:, l], ch.f[:, 0]) < 2e-5  # the head's whole column, all 4096 rows
+        gref = O.operator_backward(ch, ph, prob_o, df64[:, l:l + 1])
+        for i in range(nl):
+            assert rel(gw[i][l], gref[i][0]) < 3e-5, (l, i, rel(gw[i][l], gref[i][0]))
+            assert rel(gb[i][l], gref[nl + i][0]) < 3e-5, (l, i, rel(gb[i][l], gref[nl + i][0]))
+        assert rel(gs[l], gref[2 * nl][0]) < 3e-5, (l, rel(gs[l], gref[2 * nl][0]))
+
+
 @pytest.mark.parametrize("world,rank", [(8, 7), (4, 1)])
 def test_head_sharded_backward_at_the_multi_gpu_rank_shape(world, rank):
     """What one rank of an N-GPU head-sharded run of configs[1] executes (L / N heads of 16 on the global batch of

@@ -304,6 +304,13 @@ def test_reference_style_loop_on_two_ranks(tmp_path):
         assert torch.equal(dp[0]["sd"][k], dp[1]["sd"][k]), k
         assert bool(torch.isfinite(dp[0]["sd"][k]).all())
     assert any(not torch.equal(dp[0]["sd"][k], init[k]) for k in ref)
+    # ranks that seeded themselves differently before building the model (a common DDP habit): rank 0's weights and
+    # Fourier matrix are broadcast before the first step, so the runs are the equally seeded ones, bit for bit
+    for mode, same in (("dropin_hp_perrank", hp), ("dropin_dp_perrank", dp)):
+        pr = run_ranks(mode, 2, tmp_path)
+        for k in ref:
+            assert torch.equal(pr[0]["sd"][k], pr[1]["sd"][k]), (mode, k)
+            assert torch.equal(pr[0]["sd"][k], same[0]["sd"][k]), (mode, k)
 
 
 @pytest.mark.timeout(900)

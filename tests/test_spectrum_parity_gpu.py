@@ -59,6 +59,19 @@ def test_eigenvalue_parity_stencil_against_float32_yardstick(path):
     assert np.all(np.isfinite(got))
     assert r_hip.mean() <= 1.5 * r_ref.mean() + 1e-4, (r_hip.mean(), r_ref.mean())
     assert r_hip.max() <= 2.5 * r_ref.max() + 1e-4, (r_hip.max(), r_ref.max())
+    # the same statement as NUMBERS (north_star asks for 1e-4; in the scripts' default mode, eps = 0.01 in float32,
+    # neither this path nor the reference's own float32 arithmetic reaches it - the exact-Laplacian test below does):
+    # default mode, this grid: HIP float32 within 2e-2 of float64 on average, the float32 oracle likewise.
+    # Measured values go to gpurun_out/ (bench.py quotes the 62 500-point run of scripts/parity_spectrum_cfg2.py).
+    import json
+    import os
+    rec = dict(grid_points=int(grid.shape[0]), path=path, hip_f32_vs_f64_mean=float(r_hip.mean()),
+               hip_f32_vs_f64_max=float(r_hip.max()), oracle_f32_vs_f64_mean=float(r_ref.mean()),
+               oracle_f32_vs_f64_max=float(r_ref.max()), north_star_tolerance=1e-4)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rec, open(os.path.join(out, f"parity_test_stencil_{path}.json"), "w"), indent=1)
+    assert r_hip.mean() < 2e-2 and r_hip.max() < 1e-1, rec
 
 
 @pytest.mark.timeout(900)

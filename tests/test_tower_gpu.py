@@ -130,7 +130,10 @@ def test_tower_behind_a_trainable_module_passes_the_gradient_upstream():
     assert type(head) is torch.nn.Sequential and len(head) == 3 and head[0] is m[0]
 
 
-@pytest.mark.parametrize("B,d0,d1,d2", [(128, 128, 256, 128), (1024, 512, 8192, 512)])
+@pytest.mark.parametrize("B,d0,d1,d2", [(128, 128, 256, 128), (1024, 512, 8192, 512),
+                                        # bottleneck towers (d1 < d0): the per-call bfloat16 copy of X is the largest
+                                        # cast operand there (round 3's scratch was sized by d1 only and overran)
+                                        (512, 512, 128, 128), (256, 1024, 128, 256)])
 def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, d1, d2):
     """gemm_bf16 (the counterpart of the reference's autocast branch, main_sketchy.py:161,182): both operands of each of
     the five contractions rounded to bfloat16, float32 accumulation, everything else float32. Against the float64 oracle
@@ -150,13 +153,17 @@ def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, 
     Pd = {k: v.to(DEV).contiguous() for k, v in P.items()}
     for k, n in (("rm1", d1), ("rv1", d1), ("rm2", d2), ("rv2", d2)):
         Pd[k] = torch.zeros(n, device=DEV) if k.startswith("rm") else torch.ones(n, device=DEV)
-    ws = H.tower_workspace(B, d0, d1, d2, DEV)
+    # the workspace followed by a canary: nothing may be written past nsvd_tower_workspace_bytes
+    nws = H.tower_workspace(B, d0, d1, d2, DEV).numel()
+    buf = torch.full((nws + 4096,), 0xA5, dtype=torch.uint8, device=DEV)
+    ws = buf[:nws]
     xd, dzd = x.to(DEV), dz.to(DEV)
     res = {}
     for mixed in (True, False):
         z = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=mixed)
         res[mixed] = (z.clone(), H.tower_backward(xd, Pd, dzd, 0.2, ws, gemm_bf16=mixed))
     torch.cuda.synchronize()
+    assert bool((buf[nws:] == 0xA5).all()), "a tower kernel wrote past its workspace"
     z, grads = res[True]
     assert rel(z, zo) < 2e-4, rel(z, zo)
     for k in ("W1", "g1", "be1", "W2", "g2", "be2"):
