@@ -5,8 +5,10 @@ evaluation under the EMA weights, checkpoints with the reference's keys):
     OperatorWrapper, Gaussian importance, RMSprop without momentum): the steps are taken by trainer.FusedTrainer on the
     model's own weights - four kernel launches per step - and the nn.Module, the EMA object and the optimiser state are
     refreshed from it whenever something looks at them (evaluation, checkpoint, return);
-  * the plain one (``args.fused_loop = False``, or any other configuration): torch.optim + torch autograd around the
-    HIP loss / operator Functions, one optimiser kernel per foreach op - about three times slower, host-bound.
+  * the plain one (``args.fused_loop = False``, or any other configuration): torch autograd around the HIP loss /
+    operator Functions; with RMSprop (no momentum) the whole body - backward, optimiser, scheduler, EMA - is captured
+    into a HIP graph after three eager iterations and replayed (CapturedPlainStep; ``args.graph_loop = False`` keeps it
+    eager: torch.optim + the foreach EMA, host-bound).
 Plotting and the local-energy monitor are left out (they are not part of the hot path)."""
 from __future__ import annotations
 
@@ -189,6 +191,108 @@ def _make_fused(FusedTrainer, args, method, model, operator, importance_train, s
                         exp_mask_init=1.0 if model.has_exp_mask else None)  # initial values: replaced by the caller
 
 
+class CapturedPlainStep:
+    """The PLAIN loop body of the reference (examples/operator/__init__.py:55-74) - zero_grad, compute_loss_operator,
+    loss.backward(), optimizer.step(), scheduler.step(), ema.update() - captured once into a HIP graph and replayed:
+    torch autograd around the HIP Functions as in the eager plain loop, but the optimiser / scheduler / EMA triple is
+    ONE capturable launch per parameter tensor (nsvd_rmsprop_ema_step_dev) that reads the step's learning rate and EMA
+    decay from a device-resident nsvd_step_state and advances it, so nothing host-side changes between replays.
+    The torch objects stay the owners of the state: the RMSprop square averages are optimizer.state[p]['square_avg'],
+    the EMA shadow is ema.shadow_params, the gradients are p.grad - all updated in place; their Python counters
+    (optimizer step, scheduler.last_epoch, param_group lr, ema.num_updates) are brought up to date by sync_counters().
+    The first WARMUP calls run the same body eagerly (torch needs a few eager iterations before capturing autograd);
+    eager and replayed steps are the same launches with the same arguments."""
+    WARMUP = 3
+
+    def __init__(self, args, method, operator, importance_train, optimizer, scheduler, ema, device):
+        from . import hip_ops as H
+        self.H = H
+        self.args, self.method, self.operator, self.importance = args, method, operator, importance_train
+        self.optimizer, self.scheduler, self.ema = optimizer, scheduler, ema
+        self.device = torch.device(device)
+        self.params = [p for p in method.parameters() if p.requires_grad]
+        assert len(self.params) == len(ema.shadow_params)
+        self.state = H.StepState(self.device, args.lr, args.num_iters if args.use_lr_scheduler else 0,
+                                 args.rmsprop_decay, 1e-10, args.ema_decay)
+        for p in self.params:  # torch.optim.RMSprop's state layout, created up front (it is lazy)
+            st = optimizer.state[p]
+            if "square_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        self.sq = [optimizer.state[p]["square_avg"] for p in self.params]
+        self.x = None
+        self.graph = None
+        self.loss = None
+        self.total = torch.zeros((), dtype=torch.float64, device=self.device)
+        self.steps = 0
+
+    def _body(self):
+        H = self.H
+        self.state.begin()
+        self.method.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, _aux = self.method.compute_loss_operator(self.operator, self.x, importance=self.importance)
+        loss.backward()
+        n = len(self.params)
+        for i, (p, sq, sh) in enumerate(zip(self.params, self.sq, self.ema.shadow_params)):
+            H.rmsprop_ema_step_dev(p.data.view(-1), p.grad.view(-1), sq.view(-1), sh.view(-1), self.state, 1.0,
+                                   advance=(i == n - 1))
+        self.total += loss.detach()
+        return loss.detach()
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        """one optimiser step on the batch x; returns the (device) loss of that step"""
+        if self.x is None:
+            self.x = torch.empty_like(x)
+        self.x.copy_(x)
+        with torch.cuda.device(self.device):
+            if self.steps < self.WARMUP:
+                self.loss = self._body()
+            else:
+                if self.graph is None:
+                    torch.cuda.synchronize()
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(self.graph, stream=side):
+                            self.loss = self._body()
+                    torch.cuda.current_stream().wait_stream(side)
+                self.graph.replay()
+        self.steps += 1
+        return self.loss
+
+    def sync_counters(self) -> None:
+        """the torch objects' Python-side counters <- the steps taken (their tensors were updated in place)"""
+        from .trainer import cosine_lr
+        for p in self.params:
+            self.optimizer.state[p]["step"] = torch.tensor(float(self.steps))
+        self.ema.num_updates = self.steps
+        if self.args.use_lr_scheduler:
+            self.scheduler.last_epoch = self.steps
+            for g in self.optimizer.param_groups:
+                g["lr"] = cosine_lr(self.args.lr, self.steps, self.args.num_iters)
+
+
+def _captured_plain_step(args, method, operator, importance_train, optimizer, scheduler, ema, device):
+    """A CapturedPlainStep when the plain loop can be captured (RMSprop without momentum, this package's NestedLoRA /
+    OperatorWrapper with a generated nesting mask, GPU, float32), else None: the eager plain loop takes over."""
+    from . import hip_ops as H
+    from .nested_lowrank import NestedLoRA, _mask_kind
+    from .operators import OperatorWrapper
+    if not getattr(args, "graph_loop", True) or torch.device(device).type != "cuda":
+        return None
+    if args.optimizer != "rmsprop" or float(getattr(args, "momentum", 0.0)) != 0.0:
+        return None
+    if not isinstance(method, NestedLoRA) or not isinstance(operator, OperatorWrapper):
+        return None
+    if _mask_kind(method.vector_mask, method.matrix_mask) == H.MASK_CUSTOM:
+        return None  # custom masks are copied to the device per call: a host copy cannot be captured
+    if any(p.dtype != torch.float32 or not p.is_contiguous() for p in method.parameters()):
+        return None
+    return CapturedPlainStep(args, method, operator, importance_train, optimizer, scheduler, ema, device)
+
+
 @torch.no_grad()
 def _refresh_from_trainer(tr, method, ema, optimizer, scheduler):
     """nn.Module parameters, EMA shadow, RMSprop state and schedule position <- the fused trainer's buffers."""
@@ -231,6 +335,9 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     ema = ExponentialMovingAverage(method.parameters(), decay=args.ema_decay)
     comm = _comm_from_env(device)
     fused = _fused_loop_trainer(args, method, operator, importance_train, device, comm)
+    captured = None
+    if fused is None and comm is None:
+        captured = _captured_plain_step(args, method, operator, importance_train, optimizer, scheduler, ema, device)
     if comm is not None and fused is None:
         raise NotImplementedError("several ranks (WORLD_SIZE > 1) need the fused loop: this configuration is not one "
                                   "it implements (rmsprop without momentum, NestedLoRA on WaveFunctions, GPU)")
@@ -268,6 +375,7 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                 raise ValueError(f"the sampler returns {x.shape[0] // draws} rows, args.batch_size says "
                                  f"{args.batch_size}: several ranks need them equal")
             fused = None  # the sampler does not produce args.batch_size rows: the plain loop takes any batch
+            captured = _captured_plain_step(args, method, operator, importance_train, optimizer, scheduler, ema, device)
         if fused is not None and it == 0 and comm is not None and fused.hp:
             # heads sharded: every rank must step on the SAME global batch (equally seeded samplers): compare the first
             # one across the ranks instead of trusting the script's seeding
@@ -283,6 +391,10 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                 loss = fused.loss[0]  # evaluated on the device from this step's f, Tf (no sync)
                 total_loss += loss
                 n_loss += 1
+        elif captured is not None:
+            # the plain loop body replayed from a HIP graph (CapturedPlainStep): same launches, no host work per step
+            loss = captured.step(x.float().contiguous())
+            n_loss += 1
         else:
             method.train()
             optimizer.zero_grad()
@@ -296,6 +408,8 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
             n_loss += 1
         if (it + 1) % args.print_freq == 0:
             # the only host sync, and only at print time (the reference syncs every step)
+            if captured is not None:
+                total_loss = captured.total
             row = {"iter": it + 1, "train_loss": float(loss), loss_key: float(total_loss) / n_loss,
                    "time": time.time() - start}
             if rank0:
@@ -306,6 +420,8 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
         if (it + 1) % args.eval_freq == 0:
             if fused is not None:
                 _refresh_from_trainer(fused, method, ema, optimizer, scheduler)
+            if captured is not None:
+                captured.sync_counters()
             method.eval()
             with ema.average_parameters():
                 if batch_ftn_val is not None:
@@ -323,4 +439,6 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                                 optimizer=optimizer.state_dict()), os.path.join(args.log_dir, f"{it + 1}.pth"))
     if fused is not None:
         _refresh_from_trainer(fused, method, ema, optimizer, scheduler)
+    if captured is not None:
+        captured.sync_counters()
     return all_eigvals, all_norms

@@ -37,13 +37,18 @@ torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"reference-style loop: {n / dt:.0f} steps/s ({1e3 * dt / n:.3f} ms/step)")
 # the same through drop_in.train_operator, whose default loop body is the fused trainer on the model's weights
 from neural_svd_amd.drop_in import train_operator
-for fused in (True, False):
-    a.num_iters, a.print_freq, a.eval_freq, a.fused_loop, a.log_dir = 3000, 10 ** 9, 10 ** 9, fused, None
+import json
+rec = {"reference_style_loop_eager_torch_optim_steps_per_s": round(n / dt, 1)}
+for fused, graph in ((True, True), (False, True), (False, False)):
+    a.num_iters, a.print_freq, a.eval_freq, a.fused_loop, a.graph_loop, a.log_dir = 6000, 10 ** 9, 10 ** 9, fused, graph, None
     torch.cuda.synchronize(); t0 = time.perf_counter()
     train_operator(a, method, operator, make_batch, val_data, batch_ftn_val, None, None, dev, imp_train, imp_val)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"train_operator(fused_loop={fused}): {a.num_iters / dt:.0f} steps/s ({1e3 * dt / a.num_iters:.3f} ms/step, "
-          f"construction included)")
+    name = "fused_loop" if fused else ("plain_loop_hip_graph" if graph else "plain_loop_eager")
+    rec["train_operator_" + name + "_steps_per_s"] = round(a.num_iters / dt, 1)
+    print(f"train_operator(fused_loop={fused}, graph_loop={graph}): {a.num_iters / dt:.0f} steps/s "
+          f"({1e3 * dt / a.num_iters:.3f} ms/step, construction / capture included)")
+print("RECORD " + json.dumps(rec))
 a.num_iters = 500000
 pr = cProfile.Profile(); pr.enable()
 for _ in range(100): step()

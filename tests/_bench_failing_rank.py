@@ -3,7 +3,6 @@ exchange is still to be tuned (no --dp-exchange on its command line) exits with 
 launcher's retry passes --dp-exchange and goes through. The launcher starts its ranks as the script it was itself started
 as, so this wrapper is what every rank runs - bench.py carries no test hook."""
 import os
-import runpy
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,4 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "WORLD_SIZE" in os.environ and "--dp-exchange" not in sys.argv and \
         int(os.environ.get("RANK", "0")) == int(os.environ["WORLD_SIZE"]) - 1:
     raise SystemExit(3)
-runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
+# (not runpy.run_path: it rewrites sys.argv[0] to bench.py's path, and the launcher starts the ranks as sys.argv[0])
+BENCH = os.path.join(ROOT, "bench.py")
+exec(compile(open(BENCH).read(), BENCH, "exec"), {"__name__": "__main__", "__file__": BENCH})

@@ -156,6 +156,74 @@ def test_train_operator_fused_loop_matches_plain_loop(case, iters, lr, tol):
     assert np.allclose(a["eig"], b["eig"], rtol=1e-2)
 
 
+@pytest.mark.parametrize("case", ["hyd_small", "osc_small"])
+def test_train_operator_plain_loop_replayed_from_a_graph(case):
+    """the plain loop body (compute_loss_operator + loss.backward() + optimiser / scheduler / EMA) captured into a HIP
+    graph after three eager iterations (drop_in.CapturedPlainStep) against the eager plain loop with torch.optim.RMSprop,
+    CosineAnnealingLR and the foreach EMA on the same batches: after ONE step the parameters, square averages and EMA
+    shadow agree to rounding (two implementations of the same float32 update); after 9 steps (3 eager + capture + 5
+    replays, a moving cosine schedule of 9 steps) to what the sign-like early RMSprop updates make of that rounding; the
+    torch objects' counters are in step (checkpoints written from them are the reference's)."""
+    import neural_svd_amd.drop_in as DI
+    z = G.load("model_small")
+    for iters, tol in ((1, 2e-6), (9, 2e-3)):
+        res = {}
+        for graph in (True, False):
+            cfg, args, operator, gt, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = build(case, z)
+            args.optimizer, args.lr, args.rmsprop_decay, args.momentum = "rmsprop", 1e-5, 0.999, 0.0
+            args.num_iters, args.print_freq, args.eval_freq = iters, 10 ** 9, iters
+            args.fused_loop, args.graph_loop = False, graph
+            box = {}
+            orig_opt, orig_ema, orig_cap = DI.get_optimizer, DI.ExponentialMovingAverage, DI.CapturedPlainStep
+
+            def cap_opt(a, m, _o=orig_opt):
+                box["opt"] = _o(a, m)
+                return box["opt"]
+
+            class CapEma(orig_ema):
+                def __init__(self, *a, **k):
+                    super().__init__(*a, **k)
+                    box["ema"] = self
+
+            class CapStep(orig_cap):
+                def __init__(self, *a, **k):
+                    super().__init__(*a, **k)
+                    box["step"] = self
+
+            DI.get_optimizer, DI.ExponentialMovingAverage, DI.CapturedPlainStep = cap_opt, CapEma, CapStep
+            try:
+                torch.manual_seed(123)
+                eig, _ = DI.train_operator(args, method, operator, make_batch, val_data, batch_ftn_val, None, None, DEV,
+                                           imp_train, imp_val)
+            finally:
+                DI.get_optimizer, DI.ExponentialMovingAverage, DI.CapturedPlainStep = orig_opt, orig_ema, orig_cap
+            opt, ema = box["opt"], box["ema"]
+            assert ("step" in box) == graph
+            if graph:
+                assert box["step"].steps == iters and (box["step"].graph is not None) == (iters > 3)
+                assert box["step"].state.read().step == iters
+            train = [(n, p) for n, p in method.named_parameters() if p.requires_grad]
+            res[graph] = dict(params={n: p.detach().clone() for n, p in train},
+                              sq={n: opt.state[p]["square_avg"].clone() for n, p in train},
+                              sh={n: s.clone() for (n, p), s in zip(train, ema.shadow_params)},
+                              lr=opt.param_groups[0]["lr"], n=ema.num_updates, eig=eig[-1],
+                              ostep=float(opt.state[train[0][1]]["step"]))
+        a, b = res[True], res[False]
+        assert a["n"] == b["n"] == iters == int(a["ostep"]) == int(b["ostep"])
+        assert abs(a["lr"] - b["lr"]) < 1e-12 * max(1.0, abs(b["lr"]))
+        upd = iters * 1e-5 / np.sqrt(1.0 - 0.999)
+
+        def close(x, y, t):
+            x, y = x.double(), y.double()
+            return float((x - y).norm()) <= t * (float(y.norm()) + upd * np.sqrt(y.numel()))
+
+        for n in a["params"]:
+            assert close(a["params"][n], b["params"][n], tol), (iters, n)
+            assert close(a["sh"][n], b["sh"][n], tol), (iters, n)
+            assert rel(a["sq"][n], b["sq"][n]) < 20 * tol, (iters, n)
+        assert np.allclose(a["eig"], b["eig"], rtol=1e-2)
+
+
 def test_train_operator_smoke():
     """the reference-signature loop: a few iterations with eval + checkpoint dict, parameters move and stay finite."""
     from neural_svd_amd.drop_in import train_operator
