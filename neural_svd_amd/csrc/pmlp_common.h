@@ -107,7 +107,8 @@ struct FusedWs {
     float* dbase;                     // (L, B)
     float* dfsc;                      // (L, B)
     float* gpart;                     // (S, slice) split-K partial gradients, S = wgrad_slices() > 1 only
-    unsigned short* w0p;              // (3, L, 128, F) bf16 planes of W_0 (NSVD_PATH_FUSED_BF16X3 only)
+    unsigned short* w0p;              // (3, L, 128, F) bf16 planes of W_0, fragment-major (NSVD_PATH_FUSED_BF16X3 only)
+    unsigned short* whp;              // (nlayers - 2, 3, L, 128, 128) bf16 planes of W_1 .. (the same path)
     float* base_raw;                  // (L, (1 + 2D) B) head outputs per stencil point (split-stencil forward only)
     float* loss_part;                 // (L, 32 + 1) partial sums of the loss (direct-moment backward, B <= 1024)
     size_t bytes;
@@ -190,6 +191,7 @@ inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     const int S = wgrad_slices(d, B);
     w.gpart = S > 1 ? take((size_t)S * part_layout(d).stride) : nullptr;
     w.w0p = (unsigned short*)take(((size_t)3 * d.L * HID * F + 1) / 2);
+    w.whp = (unsigned short*)take(((size_t)(d.nlayers > 2 ? d.nlayers - 2 : 0) * 3 * d.L * HID * HID + 1) / 2);
     w.base_raw = take((size_t)d.L * (1 + 2 * (size_t)d.D) * B);
     w.loss_part = take(33 * (size_t)d.L);
     w.bytes = off;

@@ -45,8 +45,8 @@ struct FwdArgs {
     float* jac;
     float* dsc;
     float* zsave[NSVD_MAX_LAYERS];  // (L, 128, B) per hidden layer, or null: ACTIVATIONS softplus(z) of the centre rows
-    const unsigned short* w0p;  // BF3 only: W_0 pre-split into three bf16 planes, chunk-major (3, L, F/32, 128, 32), by w0_split_kernel
-    size_t w0_plane;            // elements per plane
+    const unsigned short* w0p;  // BF3 only: W_0 pre-split into three bf16 planes, fragment-major (w0_split_kernel)
+    const unsigned short* whp;  // BF3 only: the hidden layers' W_1 .. likewise
     int plain;      // E = 1 instance only: out = hard_mul_const * base * mask (WaveFunctions.forward), no Hamiltonian;
                     // f receives the output, jac / dsc its derivatives w.r.t. base / scales
     int xcd_remap;  // 0: plain mapping; else HX = number of head groups across the 8 XCDs (1, 2, 4 or 8)
@@ -78,8 +78,7 @@ __device__ __forceinline__ void nsvd_glds16(const float* gsrc, float* lds_base) 
 #include "pmlp_layer0_bf3.h"
 
 // BF3 = 1: layer 0 on the bf16 MFMA with three-way split operands (nsvd_layer0_bf3 above); everything after layer 0 is
-//   the same code. Its stage buffers are larger, so the W tile of the hidden layers aliases their tail (one extra
-//   barrier after the K loop).
+//   the same code (one extra barrier after the K loop: the hidden layers' W tile DMA lands in the stage buffers).
 // PL = 1: plain model evaluation (nsvd_model_forward): the E column tiles of a workgroup are E consecutive 32-sample
 // tiles of the batch (no stencil, no jets), so that a head's weight tiles are fetched once per 32 E samples
 template <int E, int JET, int BF3 = 0, int PL = 0>
@@ -92,7 +91,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     float* Hs = smem;                       // [NC][H_LD]       activations, k contiguous (aliases the stage buffers)
     constexpr int STAGE = 2 * HID * A_LD + 2 * NC * A_LD;
     constexpr int HSZ = NC * H_LD;
-    constexpr int STAGE3 = (2 * 3 * (HID + NC) * B3_ROW) / 4;  // floats
+    constexpr int STAGE3 = (2 * 3 * NC * B3_ROW) / 4;  // floats: the sample-column planes of two chunks
     constexpr int WL_OFF = BF3 ? HSZ : (STAGE > HSZ ? STAGE : HSZ);
     float* Wl = smem + WL_OFF;   // [4 waves][32][128]  next layer's W rows of each wave (XOR-swizzled chunks)
     constexpr int RED_OFF = BF3 ? (STAGE3 > HSZ + HID * HID ? STAGE3 : HSZ + HID * HID) : WL_OFF + HID * HID;
@@ -352,7 +351,22 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) nb[r] = src[acc_row(r, hi)];
         }
-        if (has_next) {
+        // BF3: the next layer on the bf16 MFMA as well (three-way split operands, six partial products: the arithmetic
+        // of layer 0). A wave multiplies its own 32 rows of W_{i+1} only: its A fragments - 8 k-steps x 3 planes, pre-split
+        // fragment-major by w0_split_kernel - come straight from global into registers, requested here so that they land
+        // under the softplus; no weight tile in LDS, no DMA.
+        uint4 wa[8][3];
+        if constexpr (BF3) {
+            if (has_next) {
+                const char* wp = reinterpret_cast<const char*>(a.whp) +
+                                 ((((size_t)i * a.L + l) * 4 + w) * (8 * 3 * 64) + lane) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wa[ks][p] = *reinterpret_cast<const uint4*>(wp + (ks * 3 + p) * 1024);
+            }
+        }
+        if (!BF3 && has_next) {
             const float* Wn = a.W[i + 1] + ((size_t)l * HID + 32 * w + hi) * HID;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -419,6 +433,67 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             break;
         }
         NSVD_STAMP(4 + 4 * i)
+        if constexpr (BF3) {
+            // activations -> three bf16 planes in LDS, [plane][column][128 k + 16 B pad] (272-B rows: the ds_read_b128
+            // fragment reads of 16 consecutive columns hit 16 distinct 4-bank groups); registers 4g .. 4g+3 of a lane
+            // are 4 consecutive k = 32 w + 8 g + 4 hi + (0..3): one 8-byte store per plane
+            constexpr int HB_ROW = 2 * HID + 16, HB_PL = NC * HB_ROW;  // bytes
+            char* Hb = reinterpret_cast<char*>(smem);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // previous LDS contents are dead
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                char* hcol = Hb + (e * BS + li) * HB_ROW + 2 * (32 * w + 4 * hi);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 p0, p1, p2;
+                    nsvd_bf3_split(make_float4(acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]),
+                                   p0, p1, p2);
+                    *reinterpret_cast<uint2*>(hcol + 16 * g) = p0;
+                    *reinterpret_cast<uint2*>(hcol + 16 * g + HB_PL) = p1;
+                    *reinterpret_cast<uint2*>(hcol + 16 * g + 2 * HB_PL) = p2;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            NSVD_STAMP(5 + 4 * i)
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[e][r] = (JET && e > 0) ? 0.f : nb[r];
+            // K = 128 in 8 k-steps of 16: fragments of k-step ks + 1 are read under the 6 E MFMAs of k-step ks
+            const char* Bp = Hb + li * HB_ROW + 16 * hi;
+            nsvd_bf16x8 hb[2][E][3];
+            auto hfrags = [&](int buf, int ks) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        hb[buf][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + p * HB_PL + e * BS * HB_ROW + 32 * ks);
+            };
+            hfrags(0, 0);
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // (A plane, B plane), smallest first
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) hfrags((ks + 1) & 1, ks + 1);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nsvd_bf16x8, wa[ks][TA[t]]),
+                                                                         hb[ks & 1][e][TB[t]], acc[e], 0, 0, 0);
+                }
+                // one fragment read per two MFMAs (3 E reads under 6 E MFMAs)
+                if (ks + 1 < 8) {
+#pragma unroll
+                    for (int q = 0; q < 3 * E; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                NSVD_FENCE();
+            }
+            NSVD_STAMP(6 + 4 * i)
+            continue;
+        }
         // raw barriers: __syncthreads() would drain the 16 stores above (vmcnt(0)) before every barrier
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // previous LDS contents are dead
         // registers 4g..4g+3 of a lane are 4 consecutive hidden rows 8g + 4hi + (0..3): one 16-B store
@@ -575,7 +650,7 @@ size_t fwd_lds_bytes() {
     constexpr int NC = E * BS;
     constexpr int STAGE = 2 * HID * A_LD + 2 * NC * A_LD;
     constexpr int HSZ = NC * H_LD;
-    constexpr int STAGE3 = (2 * 3 * (HID + NC) * B3_ROW) / 4;
+    constexpr int STAGE3 = (2 * 3 * NC * B3_ROW) / 4;
     constexpr int RED_OFF = BF3 ? (STAGE3 > HSZ + HID * HID ? STAGE3 : HSZ + HID * HID)
                                 : (STAGE > HSZ ? STAGE : HSZ) + HID * HID;
     return (RED_OFF + 5 * NC) * sizeof(float);
@@ -668,11 +743,18 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     a.stamps = (unsigned long long*)w.dz[0];  // diagnostic build: stamps land in the (then unused) dz_0 scratch
 #endif
     if (bf3) {  // opt-in: layer 0 on the bf16 MFMA with three-way split operands
-        hipLaunchKernelGGL(w0_split_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const float4*>(p.W[0]),
-                           reinterpret_cast<uint2*>(w.w0p), d.L, d.m);
+        W0SplitArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.W = reinterpret_cast<const float4*>(p.W[0]);
+        sa.P = reinterpret_cast<uint4*>(w.w0p);
+        sa.nhid = d.nlayers - 2;
+        for (int i = 0; i < sa.nhid; ++i) sa.Wh[i] = reinterpret_cast<const float4*>(p.W[i + 1]);
+        sa.Ph = reinterpret_cast<uint4*>(w.whp);
+        sa.L = d.L; sa.m = d.m;
+        hipLaunchKernelGGL(w0_split_kernel, dim3(2048), dim3(256), 0, s, sa);
         NSVD_CHECK_LAUNCH();
         a.w0p = w.w0p;
-        a.w0_plane = (size_t)d.L * HID * F;
+        a.whp = w.whp;
         if (prob.eps <= 0.f) {
             switch (d.D) {
                 case 1: return launch_fwd<3, 1, 1>(a, s);

@@ -9,8 +9,20 @@
 // accumulated in float32 by v_mfma_f32_32x32x16_bf16, smallest terms first. Each partial product of two 8-bit
 // significands is exact in the MFMA, so the only errors are the dropped terms and the float32 accumulation - no
 // larger than the native fp32 MFMA's own rounding (DESIGN.md 3.7 for the measured parity), at 16/6 of its rate.
-// LDS image of a chunk (32 k): per plane [row][32 bf16 + 16 B pad] = 80-B rows (conflict-free ds_read_b128 fragment
-// reads: 20-dword stride), planes x buffers: W tile 2 x 3 x 128 rows, sample columns 2 x 3 x NC rows.
+//
+// Round 4 form. What bounded the round-1 loop (3200 cycles per 32-wide chunk against 1920 of MFMA issue) was the refill
+// of its double-buffered LDS stage: 54 KB per chunk through registers and ds_write with one chunk of lead, less than
+// the loaded memory latency. Two observations remove most of it:
+//   * a wave multiplies ITS OWN 32 rows of W_0 only - the A fragments are shared with no other wave - so the W planes
+//     need no LDS at all: w0_split_kernel writes them FRAGMENT-MAJOR ((L, F/32 chunks, 4 waves, 3 planes, 2 k-steps,
+//     64 lanes) x 16 B: the six 1 KB fragments of a wave and chunk are 6 KB contiguous) and the K loop loads them
+//     straight into registers, four register sets deep: a fragment is requested 2.5 chunks before its MFMAs;
+//   * the centre features (8 KB per pair of chunks) are requested 2.5 chunks ahead into a second register set.
+// LDS then holds the sample-column planes only (generated in the MFMA shadow from the centre features by angle
+// addition, as before): per chunk 30 KB written + 120 KB of fragment reads instead of 54 + 147 KB, and every global
+// request of the loop is an ordinary load the compiler counts exactly (no LDS-DMA, no manual vmcnt).
+// LDS image of a chunk's sample columns (32 k): per plane [row][32 bf16 + 16 B pad] = 80-B rows (conflict-free
+// ds_read_b128 fragment reads: 20-dword stride), 3 planes x NC rows x 2 buffers.
 typedef __bf16 nsvd_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int B3_ROW = 80;  // bytes
 
@@ -21,6 +33,9 @@ __device__ __forceinline__ unsigned nsvd_cvt_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, h);
 }
 // the three planes of 4 consecutive-k floats, 8 bytes each
+// (tried: v_dot2c_f32_bf16 with (-1, 0) / (0, -1) for "x - element of the packed pair" in one instruction instead of
+// shift / mask + subtract: 117 fewer VALU instructions per four chunks, no faster - and the compiler folds the packed
+// constant into an inline -1.0 that the instruction applies to both halves: wrong results)
 __device__ __forceinline__ void nsvd_bf3_split(const float4 x, uint2& p0, uint2& p1, uint2& p2) {
     p0.x = nsvd_cvt_pk_bf16(x.x, x.y);
     p0.y = nsvd_cvt_pk_bf16(x.z, x.w);
@@ -67,132 +82,156 @@ __device__ __forceinline__ void nsvd_rows_from_centre(const float4 rs, const flo
     }
 }
 
-// W_0 (L, 128, F) float32 -> three bf16 planes (3, L, 128, F): once per forward call (the weights change every step),
-// so that the forward's workgroups - 16 per head, all streaming the same W_0 - load ready-made planes instead of each
-// converting them again (a wave cannot hide its own VALU work under its own MFMAs: measured 2.5-3 of 4 cycles exposed).
-// Plane layout: CHUNK-MAJOR, (3, L, F/32 chunks, 128 rows, 32 k), chunks in the order the K loop visits them (pair j
-// of 32-wide sin / cos chunks: k = 32 j .. and m + 32 j ..). The 8 KB tile of a chunk is then contiguous - a wave's
-// load instruction covers 8 full 128-byte lines instead of the halves of 16 lines whose other halves belong to a
-// chunk two steps away.
-__global__ void __launch_bounds__(256) w0_split_kernel(const float4* __restrict__ W, uint2* __restrict__ P, int L, int m) {
-    const int F = 2 * m, q4 = F / 4;
-    const size_t n4 = (size_t)L * HID * q4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const int k = 4 * (int)(i % q4);
-        const size_t row = i / q4;  // l * 128 + n
-        const int n = (int)(row % HID), l = (int)(row / HID);
-        const int half = k >= m, kk = k - half * m, c = 2 * (kk / BK) + half, within = kk % BK;
-        const size_t o = ((((size_t)l * (F / BK) + c) * HID + n) * BK + within) / 4;  // in units of 4 elements
-        uint2 p0, p1, p2;
-        nsvd_bf3_split(W[i], p0, p1, p2);
-        P[o] = p0;
-        P[n4 + o] = p1;
-        P[2 * n4 + o] = p2;
+// W_0 (L, 128, F) float32 -> three bf16 planes, FRAGMENT-MAJOR: for head l, chunk c (the order the K loop visits them:
+// pair j of 32-wide sin / cos chunks, k = 32 j .. and m + 32 j ..), wave w (hidden rows 32 w ..), plane p, k-step ks,
+// lane (li, hi): the 16 bytes the lane feeds v_mfma_f32_32x32x16_bf16 as its A fragment,
+//     P[((((l nch + c) 4 + w) 3 + p) 2 + ks) 64 + lane] = plane_p(W_0[l][32 w + li][k0(c) + 16 ks + 8 hi .. + 7]).
+// The hidden layers' weights W_1 .. W_{nh-1} (L, 128, 128) go the same way in the same launch (Wh[j], Ph):
+//     Ph[(((((j L + l) 4 + w) 8 + ks) 3 + p) 64 + lane] = plane_p(W_{j+1}[l][32 w + li][16 ks + 8 hi .. + 7]).
+// Once per forward call (the weights change every step): the 16 workgroups of a head would otherwise each redo the
+// conversion (a wave cannot hide its own VALU work under its own MFMAs: measured 2.5-3 of 4 cycles exposed).
+struct W0SplitArgs {
+    const float4* W;   // W_0
+    uint4* P;
+    const float4* Wh[NSVD_MAX_LAYERS];  // W_1 .. (nhid of them)
+    uint4* Ph;
+    int L, m, nhid;
+};
+__global__ void __launch_bounds__(256) w0_split_kernel(W0SplitArgs a) {
+    const float4* __restrict__ W = a.W;
+    uint4* __restrict__ P = a.P;
+    const int L = a.L, m = a.m;
+    const int F = 2 * m, nch = F / BK;
+    const size_t n = (size_t)L * nch * 4 * 2 * 64;  // (l, c, w, ks, lane): one thread item = 8 consecutive k of one row
+    // hidden layers: (j, l, w, ks, lane) items
+    const size_t nhid_items = (size_t)a.nhid * L * 4 * 8 * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nhid_items; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), ks = (int)((i >> 6) & 7), w = (int)((i >> 9) & 3);
+        const size_t jl = i >> 11;  // j * L + l
+        const int l = (int)(jl % L), j = (int)(jl / L);
+        const int li = lane & 31, hi = lane >> 5;
+        const float4* src = a.Wh[j] + (((size_t)l * HID + 32 * w + li) * HID + 16 * ks + 8 * hi) / 4;
+        uint2 a0, a1, a2, b0, b1, b2;
+        nsvd_bf3_split(src[0], a0, a1, a2);
+        nsvd_bf3_split(src[1], b0, b1, b2);
+        uint4* dst = a.Ph + (((jl * 4 + w) * 8 + ks) * 3) * 64 + lane;
+        dst[0] = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        dst[64] = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        dst[128] = make_uint4(a2.x, a2.y, b2.x, b2.y);
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), ks = (int)((i >> 6) & 1), w = (int)((i >> 7) & 3);
+        const size_t lc = i >> 9;  // l * nch + c
+        const int c = (int)(lc % nch), l = (int)(lc / nch);
+        const int li = lane & 31, hi = lane >> 5;
+        const int k0 = ((c & 1) ? m : 0) + (c >> 1) * BK + 16 * ks + 8 * hi;
+        const float4* src = W + (((size_t)l * HID + 32 * w + li) * F + k0) / 4;
+        uint2 a0, a1, a2, b0, b1, b2;
+        nsvd_bf3_split(src[0], a0, a1, a2);
+        nsvd_bf3_split(src[1], b0, b1, b2);
+        uint4* dst = P + ((lc * 4 + w) * 3 * 2 + ks) * 64 + lane;
+        dst[0] = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        dst[2 * 64] = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        dst[4 * 64] = make_uint4(a2.x, a2.y, b2.x, b2.y);
     }
 }
 
-// No code: ties a register quad to this point of the instruction stream. Computations that depend only on registers
-// otherwise float freely - hipcc hoists the next step's conversion arithmetic above the barrier to right behind the
-// loads that feed it, and then waits there for them.
-__device__ __forceinline__ void nsvd_pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// No code: ties a value to this point of the instruction stream as ONE 128-bit register tuple. Computations that depend
+// only on registers otherwise float freely - hipcc hoists the next step's conversion arithmetic above the barrier to
+// right behind the loads that feed it, and then waits there for them. And the tuple matters: with four scalar
+// constraints the allocator scatters the components of a 16-byte load's destination, loads into a temporary tuple
+// and copies - and the copies wait for the load right behind its issue (seen: vmcnt(0) at the loop's back edge).
+typedef float nsvd_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nsvd_pin(nsvd_f32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ float4 nsvd_f4(const nsvd_f32x4 v) { return __builtin_bit_cast(float4, v); }
 
+// diagnostic builds only (scripts/dev/build_stamps.sh EXTRA=-DNSVD_BF3_EXP=mask): leave parts of the K loop out to
+// price them - 1: the generation of the next chunk's sample planes (VALU + LDS stores), 2: the global requests,
+// 4: the barrier, 8: the sample fragment reads. Results are then wrong; only the stamps are read.
+// Measured (cycles per 32-wide chunk, cfg2, 1920 of them MFMA issue): everything in 2740; without 1: 2290; without 2:
+// 2500; without 4: 2460; without 8: 2650; MFMAs alone: 1920.
+#ifndef NSVD_BF3_EXP
+#define NSVD_BF3_EXP 0
+#endif
 template <int E, int JET>
 __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[E], char* lds, int l, int b0) {
     constexpr int NC = E * BS;
     constexpr int DD = JET ? E - 2 : (E - 1) / 2;
-    constexpr int A_BUF = 3 * HID * B3_ROW, B_BUF = 3 * NC * B3_ROW;  // bytes per buffer
-    char* As = lds;                 // [2][3][128][80 B]
-    char* Bs = lds + 2 * A_BUF;     // [2][3][NC][80 B]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, hi = lane >> 5;
+    constexpr int B_BUF = 3 * NC * B3_ROW;  // bytes per buffer
+    char* Bs = lds;                 // [2][3][NC][80 B]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s_row = tid >> 3, s_c4 = tid & 7;
-    const float* b_src = a.phiT + (size_t)(b0 + s_row) * a.F + 4 * s_c4;
-    const float* t_src = a.sctab + 4 * s_c4;
+    // every request of the loop: uniform base + one 32-bit byte offset per thread, fixed for the whole loop
+    const char* b_u = reinterpret_cast<const char*>(a.phiT + (size_t)b0 * a.F);
+    const char* t_u = reinterpret_cast<const char*>(a.sctab);
+    const unsigned offB = (unsigned)(s_row * a.F + 4 * s_c4) * 4u, offT = (unsigned)(4 * s_c4) * 4u;
     const int mm = a.m, nch = a.F / BK;
-    float4 rs, rc, cd[3], sd[3];
-    uint4 rw0, rw1, rw2, rw3, rw4, rw5;  // W_0 planes of the chunk: 3 planes x 2 pieces of 16 B (8 bf16) per thread
-    rw0 = rw1 = rw2 = rw3 = rw4 = rw5 = make_uint4(0u, 0u, 0u, 0u);
-    rs = rc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // this wave's A fragments: 6 x 1 KB per chunk, contiguous; chunk stride 4 waves x 6 KB
+    const char* wf_u = reinterpret_cast<const char*>(a.w0p) + ((size_t)l * nch * 4 + w) * (6 * 64 * 16);
+    const unsigned offW = (unsigned)lane * 16u;
+    constexpr size_t WCH = 4 * 6 * 64 * 16;  // bytes per chunk
+    uint4 fa[4][6];                           // [register set][2 p + ks]
+    nsvd_f32x4 rs[2], rc[2], cd[2][3], sd[2][3];  // centre features + stencil constants of a PAIR of chunks, two sets
 #pragma unroll
-    for (int d = 0; d < 3; ++d) cd[d] = sd[d] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // W tile of a chunk, per plane 128 rows x 64 B, contiguous in the chunk-major plane layout: piece q (16 B) of row r
-    // for thread index r * 4 + q (2 per thread: rows r and r + 64)
-    const int w_row = tid >> 2, w_q = tid & 3;
-    const unsigned short* w_src = a.w0p + (size_t)l * HID * a.F + 8 * tid;
-    const size_t w_half = (size_t)64 * BK;  // second piece: row + 64
+    for (int s = 0; s < 2; ++s) {
+        rs[s] = rc[s] = nsvd_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) cd[s][d] = sd[s][d] = nsvd_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    auto load = [&](int c, auto half) {  // chunk c = pair (c >> 1), half (c & 1)
-        constexpr int HALF = decltype(half)::value;
-        const int kp = (c >> 1) * BK;
-        const unsigned short* pw = w_src + (size_t)c * (HID * BK);
-        rw0 = *reinterpret_cast<const uint4*>(pw);
-        rw1 = *reinterpret_cast<const uint4*>(pw + w_half);
-        rw2 = *reinterpret_cast<const uint4*>(pw + a.w0_plane);
-        rw3 = *reinterpret_cast<const uint4*>(pw + a.w0_plane + w_half);
-        rw4 = *reinterpret_cast<const uint4*>(pw + 2 * a.w0_plane);
-        rw5 = *reinterpret_cast<const uint4*>(pw + 2 * a.w0_plane + w_half);
-        if (!HALF) {
-            rs = *reinterpret_cast<const float4*>(b_src + kp);
-            rc = *reinterpret_cast<const float4*>(b_src + mm + kp);
+    auto load_w = [&](auto set, int c) {  // fragments of chunk c (clamped: the tail requests an in-range chunk again)
+        constexpr int S = decltype(set)::value;
+        const char* p = wf_u + (size_t)(c < nch ? c : nch - 1) * WCH;
 #pragma unroll
-            for (int d = 0; d < DD; ++d) {
-                cd[d] = *reinterpret_cast<const float4*>(t_src + (2 * d) * mm + kp);
-                sd[d] = *reinterpret_cast<const float4*>(t_src + (2 * d + 1) * mm + kp);
-            }
+        for (int i = 0; i < 6; ++i) fa[S][i] = *reinterpret_cast<const uint4*>(p + i * 1024 + offW);
+    };
+    auto load_f = [&](auto set, int pair) {  // centre features and stencil constants of pair `pair` of chunks
+        constexpr int S = decltype(set)::value;
+        const int kp = (pair < nch / 2 ? pair : nch / 2 - 1) * BK;
+        rs[S] = *reinterpret_cast<const nsvd_f32x4*>(b_u + (size_t)kp * 4 + offB);
+        rc[S] = *reinterpret_cast<const nsvd_f32x4*>(b_u + (size_t)(mm + kp) * 4 + offB);
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+            cd[S][d] = *reinterpret_cast<const nsvd_f32x4*>(t_u + (size_t)((2 * d) * mm + kp) * 4 + offT);
+            sd[S][d] = *reinterpret_cast<const nsvd_f32x4*>(t_u + (size_t)((2 * d + 1) * mm + kp) * 4 + offT);
         }
     };
-    auto store_w = [&](int buf, int i) {  // piece i (plane i / 2, row half i % 2) of the W tile in registers
-        char* Ab = As + buf * A_BUF + ((i >> 1) * HID + w_row + 64 * (i & 1)) * B3_ROW + 16 * w_q;
-        *reinterpret_cast<uint4*>(Ab) = i == 0 ? rw0 : i == 1 ? rw1 : i == 2 ? rw2 : i == 3 ? rw3 : i == 4 ? rw4 : rw5;
-    };
-    auto store = [&](int buf, auto half) {  // split into planes and write the chunk held in registers (prologue)
-        constexpr int HALF = decltype(half)::value;
-        char* Bb = Bs + buf * B_BUF + s_row * B3_ROW + 8 * s_c4;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) store_w(buf, i);
-        float4 rb[E];
-        nsvd_rows_from_centre<E, JET, HALF>(rs, rc, cd, sd, rb);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            uint2 p0, p1, p2;
-            nsvd_bf3_split(rb[e], p0, p1, p2);
-            *reinterpret_cast<uint2*>(Bb + (0 * NC + 32 * e) * B3_ROW) = p0;
-            *reinterpret_cast<uint2*>(Bb + (1 * NC + 32 * e) * B3_ROW) = p1;
-            *reinterpret_cast<uint2*>(Bb + (2 * NC + 32 * e) * B3_ROW) = p2;
-        }
-    };
-    // operand fragments of the two 16-wide k steps of a chunk; those of k step 0 are fetched one chunk ahead
-    nsvd_bf16x8 fa[2][3], fb[2][E][3];
+    // sample-column fragments of the two 16-wide k steps of a chunk; those of k step 0 are fetched one chunk ahead
+    nsvd_bf16x8 fb[2][E][3];
     auto frags = [&](int ks, int buf) {
-        const char* Ap = As + buf * A_BUF + (32 * w + li) * B3_ROW + 16 * hi;
         const char* Bp = Bs + buf * B_BUF + li * B3_ROW + 16 * hi;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            fa[ks][p] = *reinterpret_cast<const nsvd_bf16x8*>(Ap + p * HID * B3_ROW + 32 * ks);
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 fb[ks][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + (p * NC + 32 * e) * B3_ROW + 32 * ks);
     };
-    // One chunk: the 12 groups of E MFMAs (2 k-steps x 6 partial products) of buffer `buf`, and behind them the NEXT
-    // chunk (held in registers) on its way into buffer `buf ^ 1`: behind group g < E the stencil row g (generated from
-    // the centre features, split into three planes, three 8-byte LDS stores), behind group g < 6 one ready-made 16-byte
-    // piece of the W_0 planes; behind group 6 the global loads of the chunk after next, behind group 7 the barrier,
-    // behind group 8 the first fragments of the next chunk. The fences pin that placement (left alone hipcc issues
-    // all MFMAs first and the conversion instructions after them).
-    auto step = [&](int buf, auto half, auto do_store, auto do_load, int cload) {
-        constexpr int HALF = decltype(half)::value;      // which half of its pair the NEXT chunk is
+    // One chunk j = c + J (c a multiple of 4: register sets are named at compile time): the 12 groups of E MFMAs
+    // (2 k-steps x 6 partial products) on fragment set J and sample buffer J & 1, and in their shadow
+    //   groups 0 .. E-1: sample row g of chunk j + 1 (generated from the centre features of its pair, split into three
+    //                    planes, three 8-byte LDS stores) into the other buffer;
+    //   group 1:         the k-step-1 sample fragments of this chunk;
+    //   group 6:         the requests for the A fragments of chunk j + 3 and (even j) the centre features of the pair
+    //                    whose first chunk is j + 4 - two and a half chunks before their first use;
+    //   group 7:         the chunk's only barrier (every wave has read this buffer and written the next);
+    //   groups 8 .. 11:  the k-step-0 sample fragments of chunk j + 1.
+    // The fences pin that placement (left alone hipcc issues all MFMAs first and the conversion instructions after).
+    auto step = [&](auto jj, auto do_store, int c) {
+        constexpr int J = decltype(jj)::value;
         constexpr bool ST = decltype(do_store)::value;
-        constexpr bool LD = decltype(do_load)::value;    // fetch chunk cload (the one after next) once the registers are free
+        constexpr int buf = J & 1;
+        constexpr int HALF = (J + 1) & 1;          // which half of its pair chunk j + 1 is
+        constexpr int FS = ((J + 1) >> 1) & 1;     // the feature set holding that pair
         char* Bb = Bs + (buf ^ 1) * B_BUF + s_row * B3_ROW + 8 * s_c4;
         float4 rb[E];
         if (ST) {
-            nsvd_pin(rs);
-            nsvd_pin(rc);
+            nsvd_pin(rs[FS]);
+            nsvd_pin(rc[FS]);
 #pragma unroll
             for (int d = 0; d < DD; ++d) {
-                nsvd_pin(cd[d]);
-                nsvd_pin(sd[d]);
+                nsvd_pin(cd[FS][d]);
+                nsvd_pin(sd[FS][d]);
             }
         }
         constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // (A plane, B plane), smallest first
@@ -201,19 +240,17 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
             const int ks = g / 6, t = g % 6;
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][TA[t]], fb[ks][e][TB[t]], acc[e], 0, 0, 0);
-            if (g == 1) frags(1, buf);
-            // The chunk's only barrier sits behind group 7: by then every wave has issued all its reads of this buffer
-            // (k step 1 was fetched behind group 1) and has written its share of the next chunk (groups 0..5), so the
-            // first fragments of the NEXT chunk are fetched here, under the last four groups. (With the barrier at the
-            // chunk boundary all four waves start each chunk waiting on the same 18 fragment reads per wave, ~600
-            // cycles of LDS bandwidth with the matrix pipe empty.)
-            if (g == 7) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (ST && g == 8) frags(0, buf ^ 1);
-            if (ST) {
-                // behind group g: the sample row g of the next chunk (generated, split, three 8-byte stores) for
-                // g < E, then one ready-made 16-byte piece of its W planes per group
-                if (g == 0) nsvd_rows_from_centre<E, JET, HALF>(rs, rc, cd, sd, rb);
+                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nsvd_bf16x8, fa[J][2 * TA[t] + ks]),
+                                                                 fb[ks][e][TB[t]], acc[e], 0, 0, 0);
+            if (g == 1 && !(NSVD_BF3_EXP & 8)) frags(1, buf);
+            if (g == 7 && !(NSVD_BF3_EXP & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ST && g == 8 && !(NSVD_BF3_EXP & 8)) frags(0, buf ^ 1);
+            if (ST && !(NSVD_BF3_EXP & 1)) {
+                if (g == 0) {
+                    const float4 cdf[3] = {nsvd_f4(cd[FS][0]), nsvd_f4(cd[FS][1]), nsvd_f4(cd[FS][2])};
+                    const float4 sdf[3] = {nsvd_f4(sd[FS][0]), nsvd_f4(sd[FS][1]), nsvd_f4(sd[FS][2])};
+                    nsvd_rows_from_centre<E, JET, HALF>(nsvd_f4(rs[FS]), nsvd_f4(rc[FS]), cdf, sdf, rb);
+                }
                 if (g < E) {
                     uint2 p0, p1, p2;
                     nsvd_bf3_split(rb[g < E ? g : 0], p0, p1, p2);
@@ -221,22 +258,21 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
                     *reinterpret_cast<uint2*>(Bb + (1 * NC + 32 * g) * B3_ROW) = p1;
                     *reinterpret_cast<uint2*>(Bb + (2 * NC + 32 * g) * B3_ROW) = p2;
                 }
-                if (g < 6) store_w(buf ^ 1, g);
             }
-            // the registers are free from here: the chunk after next is requested half a chunk (~1000 cycles) before
-            // the next step starts to convert it (requested at the top of that step, the wave - which issues in order -
-            // sits out the whole load latency at its first conversion instruction with the matrix pipe drained)
-            if (LD && g == 6) {
-                if constexpr (HALF) load(cload, std::integral_constant<int, 0>{});
-                else load(cload, std::integral_constant<int, 1>{});
+            if (g == 6 && !(NSVD_BF3_EXP & 2)) {
+                load_w(std::integral_constant<int, (J + 3) & 3>{}, c + J + 3);
+                // (set 0 was last read by this step's own groups 0 .. E-1 when J = 0, set 1 when J = 2)
+                if constexpr (J == 0) load_f(std::integral_constant<int, 0>{}, (c + 4) >> 1);
+                if constexpr (J == 2) load_f(std::integral_constant<int, 1>{}, (c + 6) >> 1);
             }
             // inside the group: every MFMA followed by its share of the group's other work (a wave issues in order:
             // VALU placed behind all E MFMAs would start only when the last one has issued)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g == 1 || (ST && g == 8)) __builtin_amdgcn_sched_group_barrier(0x100, (3 + 3 * E + E - 1) / E, 0);
+                if (g == 1 || (ST && g == 8)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 if (ST && g < E) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (g == 6) __builtin_amdgcn_sched_group_barrier(0x020, (J & 1) ? 2 : 3, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // keep the groups apart (no code: the accumulators are tied to one statement, so that the E chains advance
@@ -247,21 +283,46 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
                 asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]));
         }
     };
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>;
+    using J3 = std::integral_constant<int, 3>;
     using T1 = std::integral_constant<bool, true>;
     using T0 = std::integral_constant<bool, false>;
-    load(0, H0{});
-    store(0, H0{});
-    __syncthreads();
-    load(1, H1{});
-    frags(0, 0);
-    int c = 0;
-    for (; c + 2 < nch; c += 2) {  // nch is even: pairs (sin chunk, cos chunk); branch-free steady state
-        step(0, H1{}, T1{}, T1{}, c + 2);  // chunk c; converts chunk c + 1 (registers) into buffer 1, fetches c + 2
-        step(1, H0{}, T1{}, T1{}, c + 3);  // chunk c + 1; converts chunk c + 2 into buffer 0, fetches c + 3
+    // prologue: fragments of chunks 0..2, features of pairs 0 and 1, the sample planes of chunk 0
+    load_f(J0{}, 0);
+    load_w(J0{}, 0);
+    load_f(J1{}, 1);
+    load_w(J1{}, 1);
+    load_w(J2{}, 2);
+    {
+        char* Bb = Bs + s_row * B3_ROW + 8 * s_c4;
+        float4 rb[E];
+        const float4 cdf[3] = {nsvd_f4(cd[0][0]), nsvd_f4(cd[0][1]), nsvd_f4(cd[0][2])};
+        const float4 sdf[3] = {nsvd_f4(sd[0][0]), nsvd_f4(sd[0][1]), nsvd_f4(sd[0][2])};
+        nsvd_rows_from_centre<E, JET, 0>(nsvd_f4(rs[0]), nsvd_f4(rc[0]), cdf, sdf, rb);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            uint2 p0, p1, p2;
+            nsvd_bf3_split(rb[e], p0, p1, p2);
+            *reinterpret_cast<uint2*>(Bb + (0 * NC + 32 * e) * B3_ROW) = p0;
+            *reinterpret_cast<uint2*>(Bb + (1 * NC + 32 * e) * B3_ROW) = p1;
+            *reinterpret_cast<uint2*>(Bb + (2 * NC + 32 * e) * B3_ROW) = p2;
+        }
     }
-    step(0, H1{}, T1{}, T0{}, 0);
-    step(1, H0{}, T0{}, T0{}, 0);
+    __syncthreads();
+    frags(0, 0);
+    NSVD_STAMP(1)
+    int c = 0;
+    for (; c + 4 < nch; c += 4) {  // nch is a multiple of 4 (F of 128); branch-free steady state
+        step(J0{}, T1{}, c);
+        step(J1{}, T1{}, c);
+        step(J2{}, T1{}, c);
+        step(J3{}, T1{}, c);
+    }
+    step(J0{}, T1{}, c);
+    step(J1{}, T1{}, c);
+    step(J2{}, T1{}, c);
+    step(J3{}, T0{}, c);
     __syncthreads();
 }
