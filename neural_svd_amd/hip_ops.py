@@ -17,6 +17,59 @@ from ._lib import (MASK_CUSTOM, MASK_JOINT, MASK_SEQUENTIAL, PATH_AUTO, PATH_FUS
                    POT_HARMONIC, POT_HYDROGEN, ModelDesc, NsvdError, Params, Problem, check)
 
 
+# ---- which binding carries the hot-path calls: ctypes (default) or the tensor-level torch extension -----------------
+_TB = None
+_TB_SHAPES: dict = {}
+
+
+def torch_binding():
+    """The tensor-level binding neural_svd_amd/_nsvd_torch.so (csrc/torch_binding.cpp: tensors checked in C++, current
+    HIP stream taken in C++, the same C ABI underneath) when NSVD_BINDING=torch, else None. Like the ctypes binding it
+    fails loudly when its shared object is missing."""
+    global _TB
+    import os
+    if os.environ.get("NSVD_BINDING", "ctypes") != "torch":
+        return None
+    if _TB is None:
+        import importlib.util
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nsvd_torch.so")
+        if not os.path.exists(path):
+            raise NsvdError(f"{path} not found: NSVD_BINDING=torch needs the torch binding built "
+                            f"(`make -C neural_svd_amd/csrc`, or __graft_entry__.build())")
+        _lib.load()  # libnsvd_hip.so first: the extension links against it
+        spec = importlib.util.spec_from_file_location("_nsvd_torch", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.abi_version() != _lib.ABI_VERSION:
+            raise NsvdError("torch binding built against another ABI version; rebuild the extension")
+        _TB = mod
+    return _TB
+
+
+def _tb_shape(shape: "ModelShape"):
+    sh = _TB_SHAPES.get(shape)
+    if sh is None:
+        sh = _TB_SHAPES[shape] = _TB.Shape(shape.L, shape.D, shape.m, list(shape.dims), bool(shape.has_exp_mask))
+    return sh
+
+
+def _tb_params(shape: "ModelShape", params: Params):
+    """the extension's ParamSet twin of a packed parameter set (built once, from the tensors pack_params pinned)"""
+    ps = getattr(params, "_tb", None)
+    if ps is None:
+        ws, bs, fB, sc = params._keepalive
+        ps = params._tb = _TB.ParamSet(_tb_shape(shape), list(ws), list(bs), fB, sc)
+    return ps
+
+
+def _tb_problem(prob: Problem):
+    q = getattr(prob, "_tb", None)
+    if q is None:
+        q = prob._tb = _TB.Problem(prob.potential, prob.charge_or_k, prob.eps, prob.op_scale, prob.op_shift, prob.sigma,
+                                   prob.scale_kinetic, prob.hard_mul_const, bool(prob.use_importance))
+    return q
+
+
 def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
     if t is None:
         return None
@@ -210,6 +263,10 @@ def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.
         Tf = torch.empty_like(f)
     else:
         f, Tf = out
+    if torch_binding() is not None:
+        _TB.operator_forward(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob), x, f, Tf, ws,
+                             int(save_for_backward) | (_lib.FEATURES_READY if features_ready else 0), int(path))
+        return f, Tf
     d = shape.desc()
     rc = _lib.load().nsvd_operator_forward(C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"),
                                            _ptr(Tf, "Tf"), ws.data_ptr(), ws.numel(),
@@ -233,6 +290,11 @@ def operator_sample_features(shape: ModelShape, params: Params, prob: Problem, s
                              path: int = PATH_AUTO) -> None:
     """x <- sigma * N(0, 1) (counter-based, keyed by seed / offset) and its features into ws, one launch."""
     B = x.shape[0]
+    if torch_binding() is not None:
+        _TB.operator_sample_features(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob),
+                                     int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), None, x, ws,
+                                     bool(save_for_backward), int(path))
+        return
     d = shape.desc()
     rc = _lib.load().nsvd_operator_sample_features(C.byref(d), C.byref(params), C.byref(prob),
                                                    int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
@@ -246,6 +308,11 @@ def operator_sample_features_dev(shape: ModelShape, params: Params, prob: Proble
                                  save_for_backward: bool = True, path: int = PATH_AUTO) -> None:
     """operator_sample_features whose batch counter is offset_base + state.step, read on the device."""
     B = x.shape[0]
+    if torch_binding() is not None:
+        _TB.operator_sample_features(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob),
+                                     int(seed) & (2 ** 64 - 1), int(offset_base) & (2 ** 64 - 1), state.buf, x, ws,
+                                     bool(save_for_backward), int(path))
+        return
     d = shape.desc()
     rc = _lib.load().nsvd_operator_sample_features_dev(C.byref(d), C.byref(params), C.byref(prob),
                                                        int(seed) & (2 ** 64 - 1), int(offset_base) & (2 ** 64 - 1),
@@ -259,6 +326,10 @@ def operator_backward(shape: ModelShape, params: Params, prob: Problem, x: torch
     B = x.shape[0]
     if tuple(df.shape) != (B, shape.L):
         raise NsvdError(f"df must be {(B, shape.L)}")
+    if torch_binding() is not None:
+        _TB.operator_backward(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob), x, df,
+                              _tb_params(shape, grads), ws, int(path))
+        return
     d = shape.desc()
     rc = _lib.load().nsvd_operator_backward(C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B,
                                             _ptr(df, "df"), C.byref(grads), ws.data_ptr(), ws.numel(), int(path),
@@ -299,6 +370,9 @@ def evd_moments(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[t
         moments = torch.empty(2 * L * L + 1, dtype=torch.float32, device=f.device)
     if scratch is None:
         scratch = evd_scratch(B, L, f.device)
+    if torch_binding() is not None:
+        _TB.evd_moments(f, Tf, int(mask_kind), v, moments, scratch)
+        return moments
     rc = _lib.load().nsvd_evd_moments(_ptr(f, "f"), _ptr(Tf, "Tf"), B, L, int(mask_kind), _ptr(v, "v"),
                                       _ptr(moments, "moments"), scratch.data_ptr(), _stream())
     check(rc, "nsvd_evd_moments")
@@ -314,6 +388,9 @@ def evd_loss_grad(f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional
         loss = torch.empty(3, dtype=torch.float32, device=f.device)
     if want_grad and df is None:
         df = torch.empty_like(f)
+    if torch_binding() is not None:
+        _TB.evd_loss_grad(f, Tf, int(mask_kind), v, M, moments, float(grad_scale), loss, df if want_grad else None)
+        return loss, (df if want_grad else None)
     rc = _lib.load().nsvd_evd_loss_grad(_ptr(f, "f"), _ptr(Tf, "Tf"), B, L, int(mask_kind), _ptr(v, "v"),
                                         _ptr(M, "M"), _ptr(moments, "moments"), float(grad_scale),
                                         _ptr(loss, "loss"), _ptr(df, "df") if want_grad else None, _stream())
@@ -449,6 +526,12 @@ def rmsprop_state(sq: Params, ema: Optional[Params], lr: float, alpha: float, ep
     return o
 
 
+def _tb_rmsprop(shape: ModelShape, opt: "_lib.Rmsprop"):
+    sq, ema, state = opt._keepalive
+    return _TB.Rmsprop(_tb_params(shape, sq), _tb_params(shape, ema) if ema is not None else None, opt.lr, opt.alpha,
+                       opt.eps, opt.ema_decay, state.buf if state is not None else None)
+
+
 def operator_backward_evd_step(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, f: torch.Tensor,
                                Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
                                M: Optional[torch.Tensor], moments: torch.Tensor, moments_reduced: bool,
@@ -461,6 +544,12 @@ def operator_backward_evd_step(shape: ModelShape, params: Params, prob: Problem,
     if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or \
             (moments is not None and moments.numel() != 2 * L_total * L_total + 1):
         raise NsvdError("operator_backward_evd_step: f/Tf must be (B, L_total), moments 2*L_total^2+1")
+    if torch_binding() is not None:
+        _TB.operator_backward_evd_step(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob), x, f, Tf,
+                                       int(mask_kind), v, M, moments, bool(moments_reduced), evd_scratch, int(l_offset),
+                                       float(grad_scale), loss, _tb_params(shape, grads) if grads is not None else None,
+                                       _tb_rmsprop(shape, opt), ws, int(path), None, None, 0, 0)
+        return
     d = shape.desc()
     rc = _lib.load().nsvd_operator_backward_evd_step(
         C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
@@ -484,6 +573,13 @@ def operator_backward_evd_step_next(shape: ModelShape, params: Params, prob: Pro
     if tuple(Tf.shape) != (B, L_total) or L_total < shape.L or tuple(x_next.shape) != tuple(x.shape) or \
             (moments is not None and moments.numel() != 2 * L_total * L_total + 1):
         raise NsvdError("operator_backward_evd_step_next: f/Tf (B, L_total), moments 2*L_total^2+1, x_next like x")
+    if torch_binding() is not None:
+        _TB.operator_backward_evd_step(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob), x, f, Tf,
+                                       int(mask_kind), v, M, moments, bool(moments_reduced), evd_scratch, int(l_offset),
+                                       float(grad_scale), loss, _tb_params(shape, grads) if grads is not None else None,
+                                       _tb_rmsprop(shape, opt), ws, int(path), x_next, ws_next,
+                                       int(next_seed) & (2 ** 64 - 1), int(next_offset) & (2 ** 64 - 1))
+        return
     d = shape.desc()
     rc = _lib.load().nsvd_operator_backward_evd_step_next(
         C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
@@ -589,6 +685,9 @@ def rmsprop_ema_step(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, ema:
     n = p.numel()
     if grad.numel() != n or sq.numel() != n or (ema is not None and ema.numel() != n):
         raise NsvdError("rmsprop_ema_step: size mismatch")
+    if torch_binding() is not None:
+        _TB.rmsprop_ema_step(p, grad, sq, ema, float(lr), float(alpha), float(eps), float(ema_decay), float(grad_scale))
+        return
     rc = _lib.load().nsvd_rmsprop_ema_step(_ptr(p, "p"), _ptr(grad, "grad"), _ptr(sq, "sq"), _ptr(ema, "ema"), n,
                                            float(lr), float(alpha), float(eps), float(ema_decay), float(grad_scale),
                                            _stream())
@@ -611,6 +710,9 @@ def spectrum_accumulate(f: torch.Tensor, Tf: torch.Tensor, x: torch.Tensor, sigm
                         lim: float, cov: torch.Tensor, quad: torch.Tensor) -> None:
     B, L = f.shape
     D = x.shape[1]
+    if torch_binding() is not None:
+        _TB.spectrum_accumulate(f, Tf, x, float(sigma), bool(use_importance), float(lim), cov, quad)
+        return
     rc = _lib.load().nsvd_spectrum_accumulate(_ptr(f, "f"), _ptr(Tf, "Tf"), _ptr(x, "x"), B, L, D, float(sigma),
                                               int(bool(use_importance)), float(lim), _ptr(cov, "cov"),
                                               _ptr(quad, "quad"), _stream())

@@ -71,6 +71,42 @@ def test_struct_layout_matches_header():
                                      _lib.StepState.ema_decay.offset]
 
 
+def _torch_ext():
+    import importlib.util
+    from neural_svd_amd import _lib
+    path = os.path.join(ROOT, "neural_svd_amd", "_nsvd_torch.so")
+    if not os.path.exists(path) or not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    _lib.load()
+    spec = importlib.util.spec_from_file_location("_nsvd_torch", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_torch_binding_agrees_with_the_header():
+    """the tensor-level binding (csrc/torch_binding.cpp, NSVD_BINDING=torch): built, loadable, on the same ABI version,
+    its compiler's view of the structs == ctypes' == the header's, and every entry point it binds is one the header
+    declares"""
+    from neural_svd_amd import _lib
+    tb = _torch_ext()
+    assert tb.abi_version() == _lib.ABI_VERSION
+    assert tb.struct_layout() == [ctypes.sizeof(_lib.ModelDesc), ctypes.sizeof(_lib.Params), ctypes.sizeof(_lib.Problem),
+                                  ctypes.sizeof(_lib.Rmsprop), _lib.Rmsprop.state.offset, ctypes.sizeof(_lib.StepState),
+                                  _lib.StepState.cur.offset]
+    bound = tb.bound_entry_points()
+    assert set(bound) <= set(_declared()) and "nsvd_operator_forward" in bound and len(bound) >= 12
+    # host-side queries work without a GPU, tensors are refused in C++
+    import torch
+    sh = tb.Shape(16, 2, 1024, [128, 128, 128, 1], False)
+    from neural_svd_amd import hip_ops as H
+    assert tb.workspace_bytes(sh, 512) == H.workspace_bytes(H.ModelShape(L=16, D=2, m=1024, hidden=(128, 128, 128)), 512)
+    assert tb.path_name(sh, None, 512, 0) == "fused_mfma"
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        tb.evd_moments(torch.zeros(4, 2), torch.zeros(4, 2), 1, None, torch.zeros(9), torch.zeros(16))
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from neural_svd_amd import hip_ops as H

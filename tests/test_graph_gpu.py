@@ -189,3 +189,35 @@ def test_loss_value_of_every_step_comes_from_the_step_s_own_kernels():
         assert abs(float(got[0]) - float(l64)) < 2e-5 * scale
         assert torch.equal(tr.moments, mom)  # on demand, and the reported loss stays the step's own
         assert torch.equal(tr.loss, got)
+
+
+def test_torch_binding_runs_the_same_step_bit_for_bit():
+    """NSVD_BINDING=torch: the hot-path calls go through the tensor-level torch extension (csrc/torch_binding.cpp:
+    tensors checked and the current stream taken in C++) instead of ctypes - the same C ABI underneath, so the same bits:
+    five trainer steps, the stand-alone loss pieces, the optimiser, and the refusal of a non-contiguous tensor."""
+    import os
+    from neural_svd_amd import hip_ops as H
+    old = os.environ.get("NSVD_BINDING")
+    try:
+        res = {}
+        for binding in ("ctypes", "torch"):
+            os.environ["NSVD_BINDING"] = binding
+            assert (H.torch_binding() is not None) == (binding == "torch")
+            tr = _trainer(4, 64, 64, False)
+            for _ in range(5):
+                tr.step()
+            mom = H.evd_moments(tr.f, tr.Tf, tr.mask_kind, None)
+            loss, df = H.evd_loss_grad(tr.f, tr.Tf, tr.mask_kind, None, None, mom)
+            torch.cuda.synchronize()
+            res[binding] = (tr.P.flat.clone(), tr.P.ema.clone(), tr.f.clone(), tr.Tf.clone(), mom, loss, df)
+        for a, b in zip(res["ctypes"], res["torch"]):
+            assert torch.equal(a, b)
+        os.environ["NSVD_BINDING"] = "torch"
+        f = torch.zeros(8, 4, device=DEV)
+        with pytest.raises(RuntimeError, match="contiguous"):
+            H.evd_moments(f.t(), f.t(), H.MASK_SEQUENTIAL, None, torch.zeros(33, device=DEV))
+    finally:
+        if old is None:
+            os.environ.pop("NSVD_BINDING", None)
+        else:
+            os.environ["NSVD_BINDING"] = old
