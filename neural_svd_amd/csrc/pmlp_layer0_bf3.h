@@ -146,19 +146,24 @@ __device__ __forceinline__ void nsvd_pin(nsvd_f32x4& v) { asm volatile("" : "+v"
 __device__ __forceinline__ float4 nsvd_f4(const nsvd_f32x4 v) { return __builtin_bit_cast(float4, v); }
 
 // diagnostic builds only (scripts/dev/build_stamps.sh EXTRA=-DNSVD_BF3_EXP=mask): leave parts of the K loop out to
-// price them - 1: the generation of the next chunk's sample planes (VALU + LDS stores), 2: the global requests,
+// price them - 1: the generation of the next pair's sample planes (VALU + LDS stores), 2: the global requests,
 // 4: the barrier, 8: the sample fragment reads. Results are then wrong; only the stamps are read.
-// Measured (cycles per 32-wide chunk, cfg2, 1920 of them MFMA issue): everything in 2740; without 1: 2290; without 2:
-// 2500; without 4: 2460; without 8: 2650; MFMAs alone: 1920.
+// Measured on the one-barrier-per-chunk form (cycles per 32-wide chunk, cfg2, 1920 of them MFMA issue): everything in
+// 2740; without 1: 2290; without 2: 2500; without 4: 2460; without 8: 2650; MFMAs alone: 1920.
 #ifndef NSVD_BF3_EXP
 #define NSVD_BF3_EXP 0
 #endif
+// The K loop walks PAIRS of chunks - the 32 sin features k in [32 q, 32 q + 32) and their 32 cos partners - with ONE
+// barrier per pair (the barrier costs ~280 cycles: the four waves re-align on it).
+// LDS: the sample-column planes of a pair, [buffer 2][half 2][plane 3][NC rows][64 B], unpadded: the 16-byte slot of row
+// r holds k-octet slot ^ ((r >> 2) & 3) (applied on the 8-byte stores and on the fragment reads), which makes the
+// ds_read_b128 of 16 consecutive rows hit 16 distinct 4-bank groups. 120 KB at E = 5.
 template <int E, int JET>
 __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[E], char* lds, int l, int b0) {
     constexpr int NC = E * BS;
     constexpr int DD = JET ? E - 2 : (E - 1) / 2;
-    constexpr int B_BUF = 3 * NC * B3_ROW;  // bytes per buffer
-    char* Bs = lds;                 // [2][3][NC][80 B]
+    constexpr int PLANE = NC * 64, HALFB = 3 * PLANE, B_BUF = 2 * HALFB;  // bytes
+    char* Bs = lds;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s_row = tid >> 3, s_c4 = tid & 7;
@@ -166,29 +171,28 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
     const char* b_u = reinterpret_cast<const char*>(a.phiT + (size_t)b0 * a.F);
     const char* t_u = reinterpret_cast<const char*>(a.sctab);
     const unsigned offB = (unsigned)(s_row * a.F + 4 * s_c4) * 4u, offT = (unsigned)(4 * s_c4) * 4u;
-    const int mm = a.m, nch = a.F / BK;
+    const int mm = a.m, nch = a.F / BK, npair = nch / 2;
     // this wave's A fragments: 6 x 1 KB per chunk, contiguous; chunk stride 4 waves x 6 KB
     const char* wf_u = reinterpret_cast<const char*>(a.w0p) + ((size_t)l * nch * 4 + w) * (6 * 64 * 16);
     const unsigned offW = (unsigned)lane * 16u;
     constexpr size_t WCH = 4 * 6 * 64 * 16;  // bytes per chunk
-    uint4 fa[4][6];                           // [register set][2 p + ks]
-    nsvd_f32x4 rs[2], rc[2], cd[2][3], sd[2][3];  // centre features + stencil constants of a PAIR of chunks, two sets
+    uint4 fa[4][6];                           // [register set = chunk & 3][2 p + ks]
+    nsvd_f32x4 rs[2], rc[2], cd[2][3], sd[2][3];  // centre features + stencil constants of a pair, set = pair & 1
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         rs[s] = rc[s] = nsvd_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < 3; ++d) cd[s][d] = sd[s][d] = nsvd_f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
     auto load_w = [&](auto set, int c) {  // fragments of chunk c (clamped: the tail requests an in-range chunk again)
         constexpr int S = decltype(set)::value;
         const char* p = wf_u + (size_t)(c < nch ? c : nch - 1) * WCH;
 #pragma unroll
         for (int i = 0; i < 6; ++i) fa[S][i] = *reinterpret_cast<const uint4*>(p + i * 1024 + offW);
     };
-    auto load_f = [&](auto set, int pair) {  // centre features and stencil constants of pair `pair` of chunks
+    auto load_f = [&](auto set, int pair) {  // centre features and stencil constants of pair `pair`
         constexpr int S = decltype(set)::value;
-        const int kp = (pair < nch / 2 ? pair : nch / 2 - 1) * BK;
+        const int kp = (pair < npair ? pair : npair - 1) * BK;
         rs[S] = *reinterpret_cast<const nsvd_f32x4*>(b_u + (size_t)kp * 4 + offB);
         rc[S] = *reinterpret_cast<const nsvd_f32x4*>(b_u + (size_t)(mm + kp) * 4 + offB);
 #pragma unroll
@@ -197,33 +201,42 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
             sd[S][d] = *reinterpret_cast<const nsvd_f32x4*>(t_u + (size_t)((2 * d + 1) * mm + kp) * 4 + offT);
         }
     };
-    // sample-column fragments of the two 16-wide k steps of a chunk; those of k step 0 are fetched one chunk ahead
+    // sample-column fragments of one 16-wide k step (k-step s = 2 half + ks of a pair), two register sets
     nsvd_bf16x8 fb[2][E][3];
-    auto frags = [&](int ks, int buf) {
-        const char* Bp = Bs + buf * B_BUF + li * B3_ROW + 16 * hi;
+    const int rsw = (li >> 2) & 3;  // the swizzle of this lane's rows (32 e does not touch bits 2..3)
+    auto frags = [&](auto set, int buf, int s) {
+        constexpr int S = decltype(set)::value;
+        const char* Bp = Bs + buf * B_BUF + (s >> 1) * HALFB + li * 64 + ((((2 * (s & 1) + hi) ^ rsw)) << 4);
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                fb[ks][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + (p * NC + 32 * e) * B3_ROW + 32 * ks);
+                fb[S][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + p * PLANE + e * (32 * 64));
     };
-    // One chunk j = c + J (c a multiple of 4: register sets are named at compile time): the 12 groups of E MFMAs
-    // (2 k-steps x 6 partial products) on fragment set J and sample buffer J & 1, and in their shadow
-    //   groups 0 .. E-1: sample row g of chunk j + 1 (generated from the centre features of its pair, split into three
-    //                    planes, three 8-byte LDS stores) into the other buffer;
-    //   group 1:         the k-step-1 sample fragments of this chunk;
-    //   group 6:         the requests for the A fragments of chunk j + 3 and (even j) the centre features of the pair
-    //                    whose first chunk is j + 4 - two and a half chunks before their first use;
-    //   group 7:         the chunk's only barrier (every wave has read this buffer and written the next);
-    //   groups 8 .. 11:  the k-step-0 sample fragments of chunk j + 1.
-    // The fences pin that placement (left alone hipcc issues all MFMAs first and the conversion instructions after).
-    auto step = [&](auto jj, auto do_store, int c) {
-        constexpr int J = decltype(jj)::value;
+    // store address of this thread's 4 k of row s_row (+ 32 e): slot (s_c4 >> 1) swizzled by the row, 8-byte half
+    const int wofs = s_row * 64 + ((((s_c4 >> 1) ^ ((s_row >> 2) & 3))) << 4) + 8 * (s_c4 & 1);
+    auto put_row = [&](char* Bh, int e, const float4 v) {  // Bh: the (buffer, half) image
+        uint2 p0, p1, p2;
+        nsvd_bf3_split(v, p0, p1, p2);
+        char* q = Bh + wofs + e * (32 * 64);
+        *reinterpret_cast<uint2*>(q) = p0;
+        *reinterpret_cast<uint2*>(q + PLANE) = p1;
+        *reinterpret_cast<uint2*>(q + 2 * PLANE) = p2;
+    };
+    // One PAIR q (chunks 2 q, 2 q + 1), PQ = q & 1 named at compile time: 24 groups of E MFMAs (2 halves x 2 k-steps x
+    // 6 partial products) on fragment sets 2 PQ, 2 PQ + 1 and sample buffer PQ, and in their shadow
+    //   groups 0 .. 2E-1: sample row g of pair q + 1 (half g / E, row g % E) into the other buffer;
+    //   groups 1, 7, 13:  the sample fragments of k-steps 1, 2, 3 of this pair;
+    //   group 10:         the request for the centre features of pair q + 3 (their set was consumed in groups 0 .. 2E-1);
+    //   groups 12, 23:    the requests for the A fragments of chunks 2 q + 4, 2 q + 5 (their sets just went idle) -
+    //                     three chunks before their first use;
+    //   group 19:         the pair's only barrier (every wave has read this buffer and written the next);
+    //   groups 20 .. 23:  the k-step-0 sample fragments of pair q + 1.
+    auto pstep = [&](auto pq, auto do_store, int q) {
+        constexpr int PQ = decltype(pq)::value;
         constexpr bool ST = decltype(do_store)::value;
-        constexpr int buf = J & 1;
-        constexpr int HALF = (J + 1) & 1;          // which half of its pair chunk j + 1 is
-        constexpr int FS = ((J + 1) >> 1) & 1;     // the feature set holding that pair
-        char* Bb = Bs + (buf ^ 1) * B_BUF + s_row * B3_ROW + 8 * s_c4;
+        constexpr int FS = PQ ^ 1;                 // feature set of pair q + 1
+        char* Bn = Bs + (PQ ^ 1) * B_BUF;          // where pair q + 1 is written
         float4 rb[E];
         if (ST) {
             nsvd_pin(rs[FS]);
@@ -236,43 +249,39 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
         }
         constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // (A plane, B plane), smallest first
 #pragma unroll
-        for (int g = 0; g < 12; ++g) {
-            const int ks = g / 6, t = g % 6;
+        for (int g = 0; g < 24; ++g) {
+            const int h = g / 12, ks = (g % 12) / 6, t = g % 6, s = 2 * h + ks;
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nsvd_bf16x8, fa[J][2 * TA[t] + ks]),
-                                                                 fb[ks][e][TB[t]], acc[e], 0, 0, 0);
-            if (g == 1 && !(NSVD_BF3_EXP & 8)) frags(1, buf);
-            if (g == 7 && !(NSVD_BF3_EXP & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (ST && g == 8 && !(NSVD_BF3_EXP & 8)) frags(0, buf ^ 1);
-            if (ST && !(NSVD_BF3_EXP & 1)) {
-                if (g == 0) {
-                    const float4 cdf[3] = {nsvd_f4(cd[FS][0]), nsvd_f4(cd[FS][1]), nsvd_f4(cd[FS][2])};
-                    const float4 sdf[3] = {nsvd_f4(sd[FS][0]), nsvd_f4(sd[FS][1]), nsvd_f4(sd[FS][2])};
-                    nsvd_rows_from_centre<E, JET, HALF>(nsvd_f4(rs[FS]), nsvd_f4(rc[FS]), cdf, sdf, rb);
-                }
-                if (g < E) {
-                    uint2 p0, p1, p2;
-                    nsvd_bf3_split(rb[g < E ? g : 0], p0, p1, p2);
-                    *reinterpret_cast<uint2*>(Bb + (0 * NC + 32 * g) * B3_ROW) = p0;
-                    *reinterpret_cast<uint2*>(Bb + (1 * NC + 32 * g) * B3_ROW) = p1;
-                    *reinterpret_cast<uint2*>(Bb + (2 * NC + 32 * g) * B3_ROW) = p2;
-                }
+                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(nsvd_bf16x8, fa[2 * PQ + h][2 * TA[t] + ks]), fb[s & 1][e][TB[t]], acc[e], 0, 0, 0);
+            const bool rd = !(NSVD_BF3_EXP & 8);
+            if (g == 1 && rd) frags(std::integral_constant<int, 1>{}, PQ, 1);
+            if (g == 7 && rd) frags(std::integral_constant<int, 0>{}, PQ, 2);
+            if (g == 13 && rd) frags(std::integral_constant<int, 1>{}, PQ, 3);
+            if (g == 19 && !(NSVD_BF3_EXP & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ST && g == 20 && rd) frags(std::integral_constant<int, 0>{}, PQ ^ 1, 0);
+            if (ST && !(NSVD_BF3_EXP & 1) && g < 2 * E) {
+                const float4 cdf[3] = {nsvd_f4(cd[FS][0]), nsvd_f4(cd[FS][1]), nsvd_f4(cd[FS][2])};
+                const float4 sdf[3] = {nsvd_f4(sd[FS][0]), nsvd_f4(sd[FS][1]), nsvd_f4(sd[FS][2])};
+                if (g == 0) nsvd_rows_from_centre<E, JET, 0>(nsvd_f4(rs[FS]), nsvd_f4(rc[FS]), cdf, sdf, rb);
+                if (g == E) nsvd_rows_from_centre<E, JET, 1>(nsvd_f4(rs[FS]), nsvd_f4(rc[FS]), cdf, sdf, rb);
+                put_row(Bn + (g / E) * HALFB, g % E, rb[g % E]);
             }
-            if (g == 6 && !(NSVD_BF3_EXP & 2)) {
-                load_w(std::integral_constant<int, (J + 3) & 3>{}, c + J + 3);
-                // (set 0 was last read by this step's own groups 0 .. E-1 when J = 0, set 1 when J = 2)
-                if constexpr (J == 0) load_f(std::integral_constant<int, 0>{}, (c + 4) >> 1);
-                if constexpr (J == 2) load_f(std::integral_constant<int, 1>{}, (c + 6) >> 1);
+            if (!(NSVD_BF3_EXP & 2)) {
+                // (the feature set of pair q + 1 is free once its rows are generated: pair q + 3 goes there)
+                if (g == 2 * E) load_f(std::integral_constant<int, FS>{}, q + 3);
+                if (g == 12) load_w(std::integral_constant<int, 2 * PQ>{}, 2 * q + 4);
+                if (g == 23) load_w(std::integral_constant<int, 2 * PQ + 1>{}, 2 * q + 5);
             }
             // inside the group: every MFMA followed by its share of the group's other work (a wave issues in order:
             // VALU placed behind all E MFMAs would start only when the last one has issued)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g == 1 || (ST && g == 8)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                if (ST && g < E) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                if (g == 6) __builtin_amdgcn_sched_group_barrier(0x020, (J & 1) ? 2 : 3, 0);
+                if (g == 1 || g == 7 || g == 13 || (ST && g == 20)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                if (ST && g < 2 * E) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (g == 2 * E || g == 12 || g == 23) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // keep the groups apart (no code: the accumulators are tied to one statement, so that the E chains advance
@@ -283,46 +292,40 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
                 asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]));
         }
     };
-    using J0 = std::integral_constant<int, 0>;
-    using J1 = std::integral_constant<int, 1>;
-    using J2 = std::integral_constant<int, 2>;
-    using J3 = std::integral_constant<int, 3>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
     using T1 = std::integral_constant<bool, true>;
     using T0 = std::integral_constant<bool, false>;
-    // prologue: fragments of chunks 0..2, features of pairs 0 and 1, the sample planes of chunk 0
-    load_f(J0{}, 0);
-    load_w(J0{}, 0);
-    load_f(J1{}, 1);
-    load_w(J1{}, 1);
-    load_w(J2{}, 2);
+    // prologue: fragments of chunks 0..3, features of pairs 0, 1 (and 2, once pair 0's are consumed), planes of pair 0
+    load_f(P0{}, 0);
+    load_w(P0{}, 0);
+    load_w(P1{}, 1);
+    load_f(P1{}, 1);
+    load_w(S2{}, 2);
+    load_w(S3{}, 3);
     {
-        char* Bb = Bs + s_row * B3_ROW + 8 * s_c4;
         float4 rb[E];
         const float4 cdf[3] = {nsvd_f4(cd[0][0]), nsvd_f4(cd[0][1]), nsvd_f4(cd[0][2])};
         const float4 sdf[3] = {nsvd_f4(sd[0][0]), nsvd_f4(sd[0][1]), nsvd_f4(sd[0][2])};
         nsvd_rows_from_centre<E, JET, 0>(nsvd_f4(rs[0]), nsvd_f4(rc[0]), cdf, sdf, rb);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            uint2 p0, p1, p2;
-            nsvd_bf3_split(rb[e], p0, p1, p2);
-            *reinterpret_cast<uint2*>(Bb + (0 * NC + 32 * e) * B3_ROW) = p0;
-            *reinterpret_cast<uint2*>(Bb + (1 * NC + 32 * e) * B3_ROW) = p1;
-            *reinterpret_cast<uint2*>(Bb + (2 * NC + 32 * e) * B3_ROW) = p2;
-        }
+        for (int e = 0; e < E; ++e) put_row(Bs, e, rb[e]);
+        nsvd_rows_from_centre<E, JET, 1>(nsvd_f4(rs[0]), nsvd_f4(rc[0]), cdf, sdf, rb);
+#pragma unroll
+        for (int e = 0; e < E; ++e) put_row(Bs + HALFB, e, rb[e]);
     }
+    load_f(P0{}, 2);
     __syncthreads();
-    frags(0, 0);
+    frags(P0{}, 0, 0);
     NSVD_STAMP(1)
-    int c = 0;
-    for (; c + 4 < nch; c += 4) {  // nch is a multiple of 4 (F of 128); branch-free steady state
-        step(J0{}, T1{}, c);
-        step(J1{}, T1{}, c);
-        step(J2{}, T1{}, c);
-        step(J3{}, T1{}, c);
+    int q = 0;
+    for (; q + 2 < npair; q += 2) {  // npair is even (F a multiple of 128); branch-free steady state
+        pstep(P0{}, T1{}, q);
+        pstep(P1{}, T1{}, q + 1);
     }
-    step(J0{}, T1{}, c);
-    step(J1{}, T1{}, c);
-    step(J2{}, T1{}, c);
-    step(J3{}, T0{}, c);
+    pstep(P0{}, T1{}, q);
+    pstep(P1{}, T0{}, q + 1);
     __syncthreads();
 }
