@@ -215,7 +215,7 @@ def test_torch_binding_runs_the_same_step_bit_for_bit():
         os.environ["NSVD_BINDING"] = "torch"
         f = torch.zeros(8, 4, device=DEV)
         with pytest.raises(RuntimeError, match="contiguous"):
-            H.evd_moments(f.t(), f.t(), H.MASK_SEQUENTIAL, None, torch.zeros(33, device=DEV))
+            H.evd_moments(f.t(), f.t(), H.MASK_SEQUENTIAL, None, torch.zeros(2 * 8 * 8 + 1, device=DEV))
     finally:
         if old is None:
             os.environ.pop("NSVD_BINDING", None)
