@@ -230,10 +230,37 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         if (a.loss_part && b0 == 0 && tid == 0 && !(a.evd.moments || a.evd.part))
             a.loss_part[(size_t)a.L * nsb + l] = (red_mt[0] + red_mt[1]) + (red_mt[2] + red_mt[3]);
         const bool first = b < B1;
-        const float* cp = col + (first ? Lg : 0);  // the OTHER half's moments
         const float* fr = a.evd.f + (size_t)b * Lg;
-        float acc = 0.f;
-        for (int lp = 0; lp < Lg; ++lp) acc = fmaf(fr[lp], cp[lp], acc);
+        // sum_l' f[b][l'] (M lam_other)[l'][l] for the workgroup's 32 rows, cooperatively: thread t takes row t & 31 and
+        // the t >> 5-th eighth of it (16-byte loads), the eight partial sums of a row meet in LDS and are added in a
+        // fixed order. (Every thread walking its own whole row - 8 x redundant, Lg 4-byte loads each from 64 different
+        // lines per instruction - cost the address unit more than the chain's MFMAs at L = 64.)
+        float acc;
+        {
+            float* dfp = DZ + 1536;  // [8][32]  (col: DZ[0, 256), red: [256, 1280), red_mt: [1280, 1284))
+            const int srow = tid & 31, sg = tid >> 5;
+            const int bb = b0 + srow;
+            const float* cps = col + (bb < B1 ? Lg : 0);  // the OTHER half's moments
+            const float* frs = a.evd.f + (size_t)bb * Lg;
+            const int seg = ((Lg + 31) >> 5) << 2;  // floats per eighth, a multiple of 4
+            const int lp0 = sg * seg, lp1 = min(Lg, lp0 + seg);
+            float part = 0.f;
+            if ((Lg & 3) == 0) {
+                for (int lp = lp0; lp < lp1; lp += 4) {
+                    const float4 fv = *reinterpret_cast<const float4*>(frs + lp);
+                    part = fmaf(fv.x, cps[lp], part);
+                    part = fmaf(fv.y, cps[lp + 1], part);
+                    part = fmaf(fv.z, cps[lp + 2], part);
+                    part = fmaf(fv.w, cps[lp + 3], part);
+                }
+            } else {
+                for (int lp = lp0; lp < lp1; ++lp) part = fmaf(frs[lp], cps[lp], part);
+            }
+            dfp[sg * 32 + srow] = part;
+            __syncthreads();
+            const float* dq = dfp + li;
+            acc = ((dq[0] + dq[32]) + (dq[64] + dq[96])) + ((dq[128] + dq[160]) + (dq[192] + dq[224]));
+        }
         const float tfv = a.evd.Tf[(size_t)b * Lg + lg];
         dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * tfv +
                                   (2.f / (float)(first ? B1 : B2)) * acc);
