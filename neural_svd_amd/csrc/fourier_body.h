@@ -43,7 +43,7 @@ struct StencilArgs {
     const float* fB;     // (D, m)
     float* phi;          // (B, 2m)
     float* phiTc;        // (2m, B) or null
-    float* sctab;        // (D, 2, m)
+    float* sctab;        // (D, 2, m) + (D, m)
     int B, m, D;
     float eps;
     NsvdSampler smp;
@@ -86,6 +86,11 @@ __device__ __forceinline__ void stencil_tile(const StencilArgs& a, int bx, int b
             for (int d = 0; d < D; ++d) {
                 sctab[(size_t)(2 * d) * m + j] = cd[d];
                 sctab[(size_t)(2 * d + 1) * m + j] = sd[d];
+                // cos(eps B_dj) - 1 = -2 sin^2(eps B_dj / 2), without the cancellation of cd - 1 (the bf16x3 forward
+                // builds the stencil rows as centre + perturbation: pmlp_layer0_bf3.h)
+                float sh, ch;
+                sincos_d2f(0.5 * (double)eps * (double)bj[d], &sh, &ch);
+                sctab[(size_t)(2 * D + d) * m + j] = -2.f * sh * sh;
             }
         } else {          // exact-Laplacian jets: B_dj in the even slots, |B_j|^2 in slot 1
             float q = 0.f;

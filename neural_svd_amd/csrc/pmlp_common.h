@@ -98,7 +98,7 @@ __device__ __forceinline__ void xcd_block_map(int block, int HX, int L, int nsb,
 
 struct FusedWs {
     float* phi;                       // (B, F) sample-major Fourier features of the centre rows
-    float* sctab;                     // (D, 2, m) cos / sin of eps * fourier_B (stencil rows by angle addition)
+    float* sctab;                     // (D, 2, m) cos / sin of eps * fourier_B (stencil rows by angle addition) + (D, m) cos - 1
     float* phiTc;                     // (F, B) feature-major copy of the centre rows (weight gradient)
     float* zsave[NSVD_MAX_LAYERS];    // (L, 128, B) per hidden layer
     float* jac;                       // (B, L)
@@ -180,7 +180,7 @@ inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
         return q;
     };
     w.phi = take(F * B);
-    w.sctab = take((size_t)2 * d.D * d.m);
+    w.sctab = take((size_t)3 * d.D * d.m);  // (D, 2, m) cos / sin of eps B_dj, then (D, m) cos - 1 (bf16x3 forward)
     w.phiTc = take(F * B);
     for (int i = 0; i < d.nlayers - 1; ++i) w.zsave[i] = take((size_t)d.L * HID * B);
     w.jac = take((size_t)B * d.L);

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     float* Hs = smem;                       // [NC][H_LD]       activations, k contiguous (aliases the stage buffers)
     constexpr int STAGE = 2 * HID * A_LD + 2 * NC * A_LD;
     constexpr int HSZ = NC * H_LD;
-    constexpr int STAGE3 = (2 * 2 * 3 * NC * 64) / 4;  // floats: the sample-column planes of two PAIRS of chunks
+    constexpr int STAGE3 = (2 * 2 * 3 * NC * 64) / 4;  // floats: the sample-column planes of two PAIRS of chunks (upper bound)
     constexpr int WL_OFF = BF3 ? HSZ : (STAGE > HSZ ? STAGE : HSZ);
     float* Wl = smem + WL_OFF;   // [4 waves][32][128]  next layer's W rows of each wave (XOR-swizzled chunks)
     constexpr int RED_OFF = BF3 ? (STAGE3 > HSZ + HID * HID ? STAGE3 : HSZ + HID * HID) : WL_OFF + HID * HID;

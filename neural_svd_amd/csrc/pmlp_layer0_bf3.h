@@ -82,6 +82,44 @@ __device__ __forceinline__ void nsvd_rows_from_centre(const float4 rs, const flo
     }
 }
 
+// Stencil mode only: the 2 DD shifted rows as PERTURBATIONS of the centre row,
+//     phi(x +- eps e_d) - phi(x):   sin: s (cd - 1) +- c sd,   cos: c (cd - 1) -+ s sd        (cm = cd - 1 from the table)
+// |perturbation| ~ eps |B_dj| |phi| ~ 2^-7 |phi|. Layer 0 is linear, so W phi(x +- eps e_d) = W phi(x) + W (perturbation):
+// the centre product is computed ONCE (column tile 0, all six partial products) and shared - bit for bit - by every
+// stencil column, and the perturbation, being 2^-7 of the size, needs two bf16 planes and three partial products
+// (hi hi + hi mid + mid hi; dropped: lo hi, hi lo', mid mid <= 2^-18 of a term that is 2^-7 of the centre's: below
+// the float32 rounding of the sum) for the same absolute accuracy: 12 + 4 x 6 = 36 MFMAs per chunk and wave instead
+// of 60, 11 fragment reads per k-step instead of 15, and the common part of the five columns - what the
+// finite-difference stencil subtracts - carries no independent rounding noise at all.
+template <int E, int HALF>
+__device__ __forceinline__ void nsvd_rows_delta(const float4 rs, const float4 rc, const float4 (&cm)[3],
+                                                const float4 (&sd)[3], float4 (&rb)[E]) {
+    constexpr int DD = (E - 1) / 2;
+    const float4 u = HALF ? rc : rs, v = HALF ? rs : rc;  // this half's feature and its partner
+    rb[0] = u;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+        const float4 pl = make_float4(fmaf(u.x, cm[d].x, v.x * sd[d].x), fmaf(u.y, cm[d].y, v.y * sd[d].y),
+                                      fmaf(u.z, cm[d].z, v.z * sd[d].z), fmaf(u.w, cm[d].w, v.w * sd[d].w));
+        const float4 mi = make_float4(fmaf(u.x, cm[d].x, -(v.x * sd[d].x)), fmaf(u.y, cm[d].y, -(v.y * sd[d].y)),
+                                      fmaf(u.z, cm[d].z, -(v.z * sd[d].z)), fmaf(u.w, cm[d].w, -(v.w * sd[d].w)));
+        rb[1 + 2 * d] = HALF ? mi : pl;
+        rb[2 + 2 * d] = HALF ? pl : mi;
+    }
+}
+// two planes of 4 consecutive-k floats (the perturbation rows)
+__device__ __forceinline__ void nsvd_bf2_split(const float4 x, uint2& p0, uint2& p1) {
+    p0.x = nsvd_cvt_pk_bf16(x.x, x.y);
+    p0.y = nsvd_cvt_pk_bf16(x.z, x.w);
+    float4 r;
+    r.x = x.x - __uint_as_float(p0.x << 16);
+    r.y = x.y - __uint_as_float(p0.x & 0xffff0000u);
+    r.z = x.z - __uint_as_float(p0.y << 16);
+    r.w = x.w - __uint_as_float(p0.y & 0xffff0000u);
+    p1.x = nsvd_cvt_pk_bf16(r.x, r.y);
+    p1.y = nsvd_cvt_pk_bf16(r.z, r.w);
+}
+
 // W_0 (L, 128, F) float32 -> three bf16 planes, FRAGMENT-MAJOR: for head l, chunk c (the order the K loop visits them:
 // pair j of 32-wide sin / cos chunks, k = 32 j .. and m + 32 j ..), wave w (hidden rows 32 w ..), plane p, k-step ks,
 // lane (li, hi): the 16 bytes the lane feeds v_mfma_f32_32x32x16_bf16 as its A fragment,
@@ -148,21 +186,27 @@ __device__ __forceinline__ float4 nsvd_f4(const nsvd_f32x4 v) { return __builtin
 // diagnostic builds only (scripts/dev/build_stamps.sh EXTRA=-DNSVD_BF3_EXP=mask): leave parts of the K loop out to
 // price them - 1: the generation of the next pair's sample planes (VALU + LDS stores), 2: the global requests,
 // 4: the barrier, 8: the sample fragment reads. Results are then wrong; only the stamps are read.
-// Measured on the one-barrier-per-chunk form (cycles per 32-wide chunk, cfg2, 1920 of them MFMA issue): everything in
-// 2740; without 1: 2290; without 2: 2500; without 4: 2460; without 8: 2650; MFMAs alone: 1920.
+// Measured on the one-barrier-per-chunk, six-products-everywhere form (cycles per 32-wide chunk, cfg2, 1920 of them
+// MFMA issue): everything in 2740; without 1: 2290; without 2: 2500; without 4: 2460; without 8: 2650; MFMAs alone: 1920.
 #ifndef NSVD_BF3_EXP
 #define NSVD_BF3_EXP 0
 #endif
 // The K loop walks PAIRS of chunks - the 32 sin features k in [32 q, 32 q + 32) and their 32 cos partners - with ONE
-// barrier per pair (the barrier costs ~280 cycles: the four waves re-align on it).
-// LDS: the sample-column planes of a pair, [buffer 2][half 2][plane 3][NC rows][64 B], unpadded: the 16-byte slot of row
-// r holds k-octet slot ^ ((r >> 2) & 3) (applied on the 8-byte stores and on the fragment reads), which makes the
-// ds_read_b128 of 16 consecutive rows hit 16 distinct 4-bank groups. 120 KB at E = 5.
+// barrier per pair.
+// Column tiles: tile 0 = the centre rows (three planes, six partial products); tiles 1 .. E-1 = in stencil mode the
+// perturbation rows (two planes, three partial products: nsvd_rows_delta above; the centre product is added to them once,
+// after the loop), in jet mode the derivative streams (three planes, six products, as tile 0).
+// LDS: the sample-column planes of a pair, [buffer 2][half 2][plane][rows][64 B], unpadded: the 16-byte slot of row r
+// holds k-octet slot ^ ((r >> 2) & 3) (applied on the 8-byte stores and on the fragment reads), which makes the
+// ds_read_b128 of 16 consecutive rows hit 16 distinct 4-bank groups. Plane 0 and 1: NC rows, plane 2: the tiles that
+// have one (32 rows in stencil mode, NC in jet mode).
 template <int E, int JET>
 __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[E], char* lds, int l, int b0) {
     constexpr int NC = E * BS;
+    constexpr bool DELTA = !JET;               // stencil columns as centre + perturbation
     constexpr int DD = JET ? E - 2 : (E - 1) / 2;
-    constexpr int PLANE = NC * 64, HALFB = 3 * PLANE, B_BUF = 2 * HALFB;  // bytes
+    constexpr int P2ROWS = DELTA ? BS : NC;    // rows of plane 2
+    constexpr int PLANE = NC * 64, HALFB = 2 * PLANE + P2ROWS * 64, B_BUF = 2 * HALFB;  // bytes
     char* Bs = lds;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,7 +221,9 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
     const unsigned offW = (unsigned)lane * 16u;
     constexpr size_t WCH = 4 * 6 * 64 * 16;  // bytes per chunk
     uint4 fa[4][6];                           // [register set = chunk & 3][2 p + ks]
-    nsvd_f32x4 rs[2], rc[2], cd[2][3], sd[2][3];  // centre features + stencil constants of a pair, set = pair & 1
+    // centre features + stencil constants of a pair, set = pair & 1; cd: cos(eps B) in jet mode... the table's first
+    // slot: B_dj (jets), cos(eps B_dj) - 1 (stencil, DELTA)
+    nsvd_f32x4 rs[2], rc[2], cd[2][3], sd[2][3];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         rs[s] = rc[s] = nsvd_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -197,11 +243,14 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
         rc[S] = *reinterpret_cast<const nsvd_f32x4*>(b_u + (size_t)(mm + kp) * 4 + offB);
 #pragma unroll
         for (int d = 0; d < DD; ++d) {
-            cd[S][d] = *reinterpret_cast<const nsvd_f32x4*>(t_u + (size_t)((2 * d) * mm + kp) * 4 + offT);
+            // stencil mode: cos - 1 from the table's third block (D, m) behind the (D, 2, m) cos / sin pairs
+            const size_t c_at = DELTA ? (size_t)((2 * DD + d) * mm + kp) : (size_t)((2 * d) * mm + kp);
+            cd[S][d] = *reinterpret_cast<const nsvd_f32x4*>(t_u + c_at * 4 + offT);
             sd[S][d] = *reinterpret_cast<const nsvd_f32x4*>(t_u + (size_t)((2 * d + 1) * mm + kp) * 4 + offT);
         }
     };
-    // sample-column fragments of one 16-wide k step (k-step s = 2 half + ks of a pair), two register sets
+    // sample-column fragments of one 16-wide k step (k-step s = 2 half + ks of a pair), two register sets; plane 2 of
+    // the perturbation tiles does not exist (never read)
     nsvd_bf16x8 fb[2][E][3];
     const int rsw = (li >> 2) & 3;  // the swizzle of this lane's rows (32 e does not touch bits 2..3)
     auto frags = [&](auto set, int buf, int s) {
@@ -211,32 +260,88 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
         for (int e = 0; e < E; ++e)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                fb[S][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + p * PLANE + e * (32 * 64));
+                if (p < 2 || !DELTA || e == 0)
+                    fb[S][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + p * PLANE + e * (32 * 64));
     };
+    constexpr int NFR = DELTA ? 3 + 2 * (E - 1) : 3 * E;  // fragment reads per k-step
     // store address of this thread's 4 k of row s_row (+ 32 e): slot (s_c4 >> 1) swizzled by the row, 8-byte half
     const int wofs = s_row * 64 + ((((s_c4 >> 1) ^ ((s_row >> 2) & 3))) << 4) + 8 * (s_c4 & 1);
     auto put_row = [&](char* Bh, int e, const float4 v) {  // Bh: the (buffer, half) image
-        uint2 p0, p1, p2;
-        nsvd_bf3_split(v, p0, p1, p2);
         char* q = Bh + wofs + e * (32 * 64);
-        *reinterpret_cast<uint2*>(q) = p0;
-        *reinterpret_cast<uint2*>(q + PLANE) = p1;
-        *reinterpret_cast<uint2*>(q + 2 * PLANE) = p2;
+        if (DELTA && e > 0) {
+            uint2 p0, p1;
+            nsvd_bf2_split(v, p0, p1);
+            *reinterpret_cast<uint2*>(q) = p0;
+            *reinterpret_cast<uint2*>(q + PLANE) = p1;
+        } else {
+            uint2 p0, p1, p2;
+            nsvd_bf3_split(v, p0, p1, p2);
+            *reinterpret_cast<uint2*>(q) = p0;
+            *reinterpret_cast<uint2*>(q + PLANE) = p1;
+            *reinterpret_cast<uint2*>(q + 2 * PLANE) = p2;
+        }
     };
-    // One PAIR q (chunks 2 q, 2 q + 1), PQ = q & 1 named at compile time: 24 groups of E MFMAs (2 halves x 2 k-steps x
-    // 6 partial products) on fragment sets 2 PQ, 2 PQ + 1 and sample buffer PQ, and in their shadow
-    //   groups 0 .. 2E-1: sample row g of pair q + 1 (half g / E, row g % E) into the other buffer;
-    //   groups 1, 7, 13:  the sample fragments of k-steps 1, 2, 3 of this pair;
-    //   group 10:         the request for the centre features of pair q + 3 (their set was consumed in groups 0 .. 2E-1);
-    //   groups 12, 23:    the requests for the A fragments of chunks 2 q + 4, 2 q + 5 (their sets just went idle) -
-    //                     three chunks before their first use;
-    //   group 19:         the pair's only barrier (every wave has read this buffer and written the next);
-    //   groups 20 .. 23:  the k-step-0 sample fragments of pair q + 1.
+    auto gen_rows = [&](auto half, int FSi, float4 (&rb)[E]) {
+        constexpr int HALF = decltype(half)::value;
+        const float4 cdf[3] = {nsvd_f4(cd[FSi][0]), nsvd_f4(cd[FSi][1]), nsvd_f4(cd[FSi][2])};
+        const float4 sdf[3] = {nsvd_f4(sd[FSi][0]), nsvd_f4(sd[FSi][1]), nsvd_f4(sd[FSi][2])};
+        if constexpr (DELTA) nsvd_rows_delta<E, HALF>(nsvd_f4(rs[FSi]), nsvd_f4(rc[FSi]), cdf, sdf, rb);
+        else nsvd_rows_from_centre<E, JET, HALF>(nsvd_f4(rs[FSi]), nsvd_f4(rc[FSi]), cdf, sdf, rb);
+    };
+    // stencil mode: the centre tile's six products alternate between TWO accumulators (consecutive MFMAs on one
+    // accumulator wait for each other); tiles 1 .. E-1 start from zero and receive the centre product after the loop
+    f32x16 accb;
+    if constexpr (DELTA) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accb[r] = 0.f;
+#pragma unroll
+            for (int e = 1; e < E; ++e) acc[e][r] = 0.f;
+        }
+    }
+    // MFMA groups of one k-step. Jets: six groups of E (one partial product each, smallest first). Stencil: four groups -
+    // {centre lo hi, perturbations mid hi'} {centre hi lo, perturbations hi mid'} {centre mid mid, perturbations hi hi'}
+    // {centre mid hi, hi mid, hi hi} - 18 MFMAs.
+    constexpr int NG = DELTA ? 4 : 6;          // groups per k-step
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // (A plane, B plane), smallest first
+    constexpr int DA[3] = {1, 0, 0}, DB[3] = {0, 1, 0};                    // the perturbation tiles' three products
+    auto mma_group = [&](auto set, auto fset, int ks, int gk) {  // group gk of k-step (fragment set fset, A set `set`)
+        constexpr int S = decltype(set)::value;
+        constexpr int FB = decltype(fset)::value;
+        auto A = [&](int p) { return __builtin_bit_cast(nsvd_bf16x8, fa[S][2 * p + ks]); };
+        if constexpr (DELTA) {
+            if (gk < 3) {
+                if (gk & 1) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[gk]), fb[FB][0][TB[gk]], accb, 0, 0, 0);
+                else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[gk]), fb[FB][0][TB[gk]], acc[0], 0, 0, 0);
+#pragma unroll
+                for (int e = 1; e < E; ++e)
+                    acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(DA[gk]), fb[FB][e][DB[gk]], acc[e], 0, 0, 0);
+            } else {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[3]), fb[FB][0][TB[3]], accb, 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[4]), fb[FB][0][TB[4]], acc[0], 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[5]), fb[FB][0][TB[5]], accb, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[gk]), fb[FB][e][TB[gk]], acc[e], 0, 0, 0);
+        }
+    };
+    // One PAIR q (chunks 2 q, 2 q + 1), PQ = q & 1 named at compile time: 4 k-steps (2 halves x 2) of NG MFMA groups
+    // on fragment sets 2 PQ, 2 PQ + 1 and sample buffer PQ, and in their shadow (g = global group index, 0 .. 4 NG - 1)
+    //   groups 0 .. 2E-1:      sample row g of pair q + 1 (half g / E, row g % E) into the other buffer;
+    //   group 2E:              the request for the centre features of pair q + 3 (their set was just consumed);
+    //   first group of k-step s (s = 0, 1, 2): the sample fragments of k-step s + 1 of this pair;
+    //   first group of k-step 2, last group: the requests for the A fragments of chunks 2 q + 4, 2 q + 5 (their sets
+    //                          just went idle) - three chunks before their first use;
+    //   first group of k-step 3: the pair's only barrier (every wave has read this buffer and written the next), then
+    //                          the k-step-0 sample fragments of pair q + 1.
     auto pstep = [&](auto pq, auto do_store, int q) {
         constexpr int PQ = decltype(pq)::value;
         constexpr bool ST = decltype(do_store)::value;
         constexpr int FS = PQ ^ 1;                 // feature set of pair q + 1
         char* Bn = Bs + (PQ ^ 1) * B_BUF;          // where pair q + 1 is written
+        f32x16& accb_l = accb;                     // (named here: an asm operand alone does not capture it)
         float4 rb[E];
         if (ST) {
             nsvd_pin(rs[FS]);
@@ -247,49 +352,64 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
                 nsvd_pin(sd[FS][d]);
             }
         }
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // (A plane, B plane), smallest first
+        static_assert(2 * E + 1 <= 4 * NG - 1, "the pair's groups must hold the generation of the next pair");
 #pragma unroll
-        for (int g = 0; g < 24; ++g) {
-            const int h = g / 12, ks = (g % 12) / 6, t = g % 6, s = 2 * h + ks;
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(nsvd_bf16x8, fa[2 * PQ + h][2 * TA[t] + ks]), fb[s & 1][e][TB[t]], acc[e], 0, 0, 0);
+        for (int g = 0; g < 4 * NG; ++g) {
+            const int s = g / NG, gk = g % NG, h = s >> 1, ks = s & 1;
             const bool rd = !(NSVD_BF3_EXP & 8);
-            if (g == 1 && rd) frags(std::integral_constant<int, 1>{}, PQ, 1);
-            if (g == 7 && rd) frags(std::integral_constant<int, 0>{}, PQ, 2);
-            if (g == 13 && rd) frags(std::integral_constant<int, 1>{}, PQ, 3);
-            if (g == 19 && !(NSVD_BF3_EXP & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (ST && g == 20 && rd) frags(std::integral_constant<int, 0>{}, PQ ^ 1, 0);
-            if (ST && !(NSVD_BF3_EXP & 1) && g < 2 * E) {
-                const float4 cdf[3] = {nsvd_f4(cd[FS][0]), nsvd_f4(cd[FS][1]), nsvd_f4(cd[FS][2])};
-                const float4 sdf[3] = {nsvd_f4(sd[FS][0]), nsvd_f4(sd[FS][1]), nsvd_f4(sd[FS][2])};
-                if (g == 0) nsvd_rows_from_centre<E, JET, 0>(nsvd_f4(rs[FS]), nsvd_f4(rc[FS]), cdf, sdf, rb);
-                if (g == E) nsvd_rows_from_centre<E, JET, 1>(nsvd_f4(rs[FS]), nsvd_f4(rc[FS]), cdf, sdf, rb);
+            if (s == 3 && gk == 0 && !(NSVD_BF3_EXP & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // fragment set: k-step s reads set s & 1; A fragments: register set 2 PQ + h
+            if (s & 1) {
+                if (h) mma_group(std::integral_constant<int, 2 * PQ + 1>{}, std::integral_constant<int, 1>{}, ks, gk);
+                else mma_group(std::integral_constant<int, 2 * PQ>{}, std::integral_constant<int, 1>{}, ks, gk);
+            } else {
+                if (h) mma_group(std::integral_constant<int, 2 * PQ + 1>{}, std::integral_constant<int, 0>{}, ks, gk);
+                else mma_group(std::integral_constant<int, 2 * PQ>{}, std::integral_constant<int, 0>{}, ks, gk);
+            }
+            bool did_frags = false;
+            if (gk == 0 && rd) {
+                if (s == 0) { frags(std::integral_constant<int, 1>{}, PQ, 1); did_frags = true; }
+                if (s == 1) { frags(std::integral_constant<int, 0>{}, PQ, 2); did_frags = true; }
+                if (s == 2) { frags(std::integral_constant<int, 1>{}, PQ, 3); did_frags = true; }
+                if (s == 3 && ST) { frags(std::integral_constant<int, 0>{}, PQ ^ 1, 0); did_frags = true; }
+            }
+            const bool gen = ST && !(NSVD_BF3_EXP & 1) && g < 2 * E;
+            if (gen) {
+                if (g == 0) gen_rows(std::integral_constant<int, 0>{}, FS, rb);
+                if (g == E) gen_rows(std::integral_constant<int, 1>{}, FS, rb);
                 put_row(Bn + (g / E) * HALFB, g % E, rb[g % E]);
             }
+            bool did_loads = false;
             if (!(NSVD_BF3_EXP & 2)) {
                 // (the feature set of pair q + 1 is free once its rows are generated: pair q + 3 goes there)
-                if (g == 2 * E) load_f(std::integral_constant<int, FS>{}, q + 3);
-                if (g == 12) load_w(std::integral_constant<int, 2 * PQ>{}, 2 * q + 4);
-                if (g == 23) load_w(std::integral_constant<int, 2 * PQ + 1>{}, 2 * q + 5);
+                if (g == 2 * E) { load_f(std::integral_constant<int, FS>{}, q + 3); did_loads = true; }
+                if (s == 2 && gk == 1) { load_w(std::integral_constant<int, 2 * PQ>{}, 2 * q + 4); did_loads = true; }
+                if (g == 4 * NG - 1) { load_w(std::integral_constant<int, 2 * PQ + 1>{}, 2 * q + 5); did_loads = true; }
             }
             // inside the group: every MFMA followed by its share of the group's other work (a wave issues in order:
-            // VALU placed behind all E MFMAs would start only when the last one has issued)
+            // VALU placed behind all the MFMAs would start only when the last one has issued)
+            const int nm = DELTA ? (gk < 3 ? E : 3) : E;  // MFMAs of this group
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
+            for (int e = 0; e < nm; ++e) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g == 1 || g == 7 || g == 13 || (ST && g == 20)) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                if (ST && g < 2 * E) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                if (g == 2 * E || g == 12 || g == 23) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (did_frags) {
+                    if (nm == E) __builtin_amdgcn_sched_group_barrier(0x100, (NFR + E - 1) / E, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, (NFR + 2) / 3, 0);
+                }
+                if (gen) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (did_loads) {
+                    if (nm == E) __builtin_amdgcn_sched_group_barrier(0x020, (6 + E - 1) / E, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // keep the groups apart (no code: the accumulators are tied to one statement, so that the E chains advance
-            // together; left alone the compiler runs three dependent MFMAs of one chain back to back at the chunk start)
+            // keep the groups apart (no code: the accumulators are tied to one statement, so that the chains advance
+            // together; left alone the compiler runs dependent MFMAs of one chain back to back)
             if constexpr (E == 3) asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]));
             if constexpr (E == 4) asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
             if constexpr (E == 5)
                 asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]));
+            if constexpr (DELTA) asm volatile("" : "+a"(accb_l));
         }
     };
     using P0 = std::integral_constant<int, 0>;
@@ -307,12 +427,10 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
     load_w(S3{}, 3);
     {
         float4 rb[E];
-        const float4 cdf[3] = {nsvd_f4(cd[0][0]), nsvd_f4(cd[0][1]), nsvd_f4(cd[0][2])};
-        const float4 sdf[3] = {nsvd_f4(sd[0][0]), nsvd_f4(sd[0][1]), nsvd_f4(sd[0][2])};
-        nsvd_rows_from_centre<E, JET, 0>(nsvd_f4(rs[0]), nsvd_f4(rc[0]), cdf, sdf, rb);
+        gen_rows(std::integral_constant<int, 0>{}, 0, rb);
 #pragma unroll
         for (int e = 0; e < E; ++e) put_row(Bs, e, rb[e]);
-        nsvd_rows_from_centre<E, JET, 1>(nsvd_f4(rs[0]), nsvd_f4(rc[0]), cdf, sdf, rb);
+        gen_rows(std::integral_constant<int, 1>{}, 0, rb);
 #pragma unroll
         for (int e = 0; e < E; ++e) put_row(Bs + HALFB, e, rb[e]);
     }
@@ -327,5 +445,14 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
     }
     pstep(P0{}, T1{}, q);
     pstep(P1{}, T0{}, q + 1);
+    if constexpr (DELTA) {
+        // the centre product joins every stencil column: z(x +- eps e_d) = [b + W phi(x)] + W (perturbation)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[0][r] += accb[r];
+#pragma unroll
+            for (int e = 1; e < E; ++e) acc[e][r] += acc[0][r];
+        }
+    }
     __syncthreads();
 }
