@@ -434,10 +434,16 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         }
         NSVD_STAMP(4 + 4 * i)
         if constexpr (BF3) {
-            // activations -> three bf16 planes in LDS, [plane][column][128 k + 16 B pad] (272-B rows: the ds_read_b128
+            // activations -> bf16 planes in LDS, [plane][column][128 k + 16 B pad] (272-B rows: the ds_read_b128
             // fragment reads of 16 consecutive columns hit 16 distinct 4-bank groups); registers 4g .. 4g+3 of a lane
-            // are 4 consecutive k = 32 w + 8 g + 4 hi + (0..3): one 8-byte store per plane
-            constexpr int HB_ROW = 2 * HID + 16, HB_PL = NC * HB_ROW;  // bytes
+            // are 4 consecutive k = 32 w + 8 g + 4 hi + (0..3): one 8-byte store per plane.
+            // Stencil mode (as in layer 0, pmlp_layer0_bf3.h): the shifted columns enter the next layer as
+            // centre + perturbation, W a(x +- eps e_d) = W a(x) + W [a(x +- eps e_d) - a(x)]. The difference of the two
+            // float32 activations is exact (they agree to ~7 bits), 2^-7 of the centre's size, and takes two planes and
+            // three partial products; the centre product (six, on two alternating accumulators) is shared by all columns.
+            constexpr bool DELTA = !JET;
+            constexpr int HB_ROW = 2 * HID + 16, HB_PL = NC * HB_ROW;  // bytes (plane 2: the centre tile's 32 rows only
+                                                                       // in stencil mode - the same stride is kept)
             char* Hb = reinterpret_cast<char*>(smem);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // previous LDS contents are dead
 #pragma unroll
@@ -445,21 +451,33 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 char* hcol = Hb + (e * BS + li) * HB_ROW + 2 * (32 * w + 4 * hi);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    uint2 p0, p1, p2;
-                    nsvd_bf3_split(make_float4(acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]),
-                                   p0, p1, p2);
-                    *reinterpret_cast<uint2*>(hcol + 16 * g) = p0;
-                    *reinterpret_cast<uint2*>(hcol + 16 * g + HB_PL) = p1;
-                    *reinterpret_cast<uint2*>(hcol + 16 * g + 2 * HB_PL) = p2;
+                    if (DELTA && e > 0) {
+                        uint2 p0, p1;
+                        nsvd_bf2_split(make_float4(acc[e][4 * g] - acc[0][4 * g], acc[e][4 * g + 1] - acc[0][4 * g + 1],
+                                                   acc[e][4 * g + 2] - acc[0][4 * g + 2],
+                                                   acc[e][4 * g + 3] - acc[0][4 * g + 3]), p0, p1);
+                        *reinterpret_cast<uint2*>(hcol + 16 * g) = p0;
+                        *reinterpret_cast<uint2*>(hcol + 16 * g + HB_PL) = p1;
+                    } else {
+                        uint2 p0, p1, p2;
+                        nsvd_bf3_split(make_float4(acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]),
+                                       p0, p1, p2);
+                        *reinterpret_cast<uint2*>(hcol + 16 * g) = p0;
+                        *reinterpret_cast<uint2*>(hcol + 16 * g + HB_PL) = p1;
+                        *reinterpret_cast<uint2*>(hcol + 16 * g + 2 * HB_PL) = p2;
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             NSVD_STAMP(5 + 4 * i)
+            f32x16 accb;  // stencil mode: the centre tile's second accumulator
 #pragma unroll
-            for (int e = 0; e < E; ++e)
+            for (int r = 0; r < 16; ++r) {
+                accb[r] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[e][r] = (JET && e > 0) ? 0.f : nb[r];
-            // K = 128 in 8 k-steps of 16: fragments of k-step ks + 1 are read under the 6 E MFMAs of k-step ks
+                for (int e = 0; e < E; ++e) acc[e][r] = e > 0 ? 0.f : nb[r];  // (jets: the bias joins the value stream only)
+            }
+            // K = 128 in 8 k-steps of 16: fragments of k-step ks + 1 are read under the MFMAs of k-step ks
             const char* Bp = Hb + li * HB_ROW + 16 * hi;
             nsvd_bf16x8 hb[2][E][3];
             auto hfrags = [&](int buf, int ks) {
@@ -467,29 +485,55 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 for (int e = 0; e < E; ++e)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        hb[buf][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + p * HB_PL + e * BS * HB_ROW + 32 * ks);
+                        if (p < 2 || !DELTA || e == 0)
+                            hb[buf][e][p] = *reinterpret_cast<const nsvd_bf16x8*>(Bp + p * HB_PL + e * BS * HB_ROW + 32 * ks);
             };
             hfrags(0, 0);
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // (A plane, B plane), smallest first
+            constexpr int DA[3] = {1, 0, 0}, DB[3] = {0, 1, 0};                    // the perturbation tiles' three products
+            constexpr int NFRH = DELTA ? 3 + 2 * (E - 1) : 3 * E, NMMH = DELTA ? 6 + 3 * (E - 1) : 6 * E;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 if (ks + 1 < 8) hfrags((ks + 1) & 1, ks + 1);
+                auto A = [&](int p) { return __builtin_bit_cast(nsvd_bf16x8, wa[ks][p]); };
+                if constexpr (DELTA) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                    for (int t = 0; t < 3; ++t) {
+                        if (t & 1) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[t]), hb[ks & 1][0][TB[t]], accb, 0, 0, 0);
+                        else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[t]), hb[ks & 1][0][TB[t]], acc[0], 0, 0, 0);
 #pragma unroll
-                    for (int e = 0; e < E; ++e)
-                        acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nsvd_bf16x8, wa[ks][TA[t]]),
-                                                                         hb[ks & 1][e][TB[t]], acc[e], 0, 0, 0);
+                        for (int e = 1; e < E; ++e)
+                            acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(DA[t]), hb[ks & 1][e][DB[t]], acc[e], 0, 0, 0);
+                    }
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[3]), hb[ks & 1][0][TB[3]], accb, 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[4]), hb[ks & 1][0][TB[4]], acc[0], 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[5]), hb[ks & 1][0][TB[5]], accb, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A(TA[t]), hb[ks & 1][e][TB[t]], acc[e], 0, 0, 0);
+                    }
                 }
-                // one fragment read per two MFMAs (3 E reads under 6 E MFMAs)
+                // the next k-step's fragment reads spread under this k-step's MFMAs
                 if (ks + 1 < 8) {
 #pragma unroll
-                    for (int q = 0; q < 3 * E; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    for (int q = 0; q < NFRH; ++q) {
+                        if (q < NMMH - NFRH) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
                 NSVD_FENCE();
+            }
+            if constexpr (DELTA) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[0][r] += accb[r];
+#pragma unroll
+                    for (int e = 1; e < E; ++e) acc[e][r] += acc[0][r];
+                }
             }
             NSVD_STAMP(6 + 4 * i)
             continue;
