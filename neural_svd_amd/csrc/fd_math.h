@@ -64,6 +64,53 @@ __device__ __forceinline__ NsvdFdOut nsvd_fd_combine(const float* g, float sp0, 
     return o;
 }
 
+// The same central difference with the stencil points given in EVEN / ODD form (the bf16x3 forward propagates
+// perturbations, pmlp_layer0_bf3.h): along direction d the head's raw output is base(x +- eps e_d) = base0 + bE[d] +- bO[d],
+// and the weight w(x) = sqrt p(x) mask_l(x) at the shifted point is w0 (1 + rho_+-), rho = expm1(log w(x_+-) - log w(x0))
+// with |x_+-|^2 - |x0|^2 = eps (+-2 x_d + eps) formed exactly:
+//     g_+ + g_- - 2 g_0 = c w0 [ (rho_+ + rho_-)(base0 + bE) + 2 bE + (rho_+ - rho_-) bO ]
+// - every term small, none the difference of two large numbers: the float32 result carries the Laplacian to ~1e-6 where
+// the point-wise form (nsvd_fd_combine, the reference's own float32 arithmetic) carries it to a few per cent.
+__device__ __forceinline__ NsvdFdOut nsvd_fd_evenodd(float base0, const float* bE, const float* bO, const float* xc,
+                                                     int D, bool has_mask, float s_l, const nsvd_problem& prob,
+                                                     float log_norm) {
+    float r2 = 0.f;
+    for (int d = 0; d < D; ++d) r2 = fmaf(xc[d], xc[d], r2);
+    const float r0 = sqrtf(r2);
+    const float c = prob.hard_mul_const;
+    const float sp0 = prob.use_importance ? nsvd_sqrt_gauss_pdf(xc, D, prob.sigma, log_norm) : 1.f;
+    const float mk0 = has_mask ? expf(-r0 / s_l) : 1.f;
+    const float eps = prob.eps;
+    const float qs = prob.use_importance ? -1.f / (4.f * prob.sigma * prob.sigma) : 0.f;  // d log sqrt p / d |x|^2
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float dp = eps * (2.f * xc[d] + eps), dm = eps * (eps - 2.f * xc[d]);  // |x_+-|^2 - |x0|^2
+        float ap = qs * dp, am = qs * dm;
+        if (has_mask) {
+            const float rp = sqrtf(fmaxf(r2 + dp, 0.f)), rm = sqrtf(fmaxf(r2 + dm, 0.f));
+            ap -= (dp / (rp + r0)) / s_l;  // |x_+| - |x0| = (|x_+|^2 - |x0|^2) / (|x_+| + |x0|)
+            am -= (dm / (rm + r0)) / s_l;
+        }
+        const float rhop = expm1f(ap), rhom = expm1f(am);
+        acc += (rhop + rhom) * (base0 + bE[d]) + 2.f * bE[d] + (rhop - rhom) * bO[d];
+    }
+    const float eps2 = (float)((double)prob.eps * (double)prob.eps);
+    const float spc = prob.use_importance ? fmaxf(sp0, NSVD_SQRT_P_CLAMP) : 1.f;
+    const float lap = ((c * (sp0 * mk0)) * acc / eps2) / spc;
+    const float fs = (sp0 * (c * base0 * mk0)) / spc;
+    float V;
+    if (prob.potential == NSVD_POT_HYDROGEN) V = -(prob.charge_or_k / r0);
+    else V = prob.charge_or_k * (r0 * r0);
+    const float H = -prob.scale_kinetic * lap + V * fs;
+    NsvdFdOut o;
+    o.f = fs;
+    o.Tf = prob.op_scale * (-H) + prob.op_shift * fs;
+    const float w = (sp0 / spc) * c;
+    o.jac = w * mk0;
+    o.dsc = has_mask ? w * base0 * mk0 * r0 / (s_l * s_l) : 0.f;
+    return o;
+}
+
 __device__ __forceinline__ NsvdFdOut nsvd_fd_point(const float* bv, const float* xc, int D, bool has_mask, float s_l,
                                                    const nsvd_problem& prob, float log_norm) {
     const int E = 1 + 2 * D;

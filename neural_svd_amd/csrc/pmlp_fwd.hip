@@ -377,7 +377,37 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         // softplus in registers; the centre rows' ACTIVATIONS are saved for the backward (its kernels then need
         // no softplus: sigmoid(z) = 1 - exp(-softplus(z)), and the weight gradients contract activations)
         float* zs = (a.zsave[i] && grp == 0) ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
-        if (JET) {
+        if (BF3 && !JET) {
+            // stencil mode of the bf16x3 path: tile 0 holds z(x), tiles 1 + 2 d / 2 + 2 d the even / odd parts zE, zO of
+            // z(x +- eps e_d) - z(x) = zE +- zO. The softplus acts on the triple by its Taylor expansion around z
+            // (s = sigmoid z, q = 1 - s: c1 = s, c2 = s q / 2, c3 = s q (1 - 2 s) / 6, c4 = s q (1 - 6 s q) / 24):
+            //   even' = c1 zE + c2 (zE^2 + zO^2) + 3 c3 zE zO^2 + c4 zO^4,   odd' = zO (c1 + 2 c2 zE + c3 zO^2)
+            // - zO ~ 2^-7 .. 2^-4, zE ~ zO^2: the terms left out are below 1e-6 of even' and 1e-4 of odd' (odd enters
+            // the stencil only through its squares). No transcendental for the shifted tiles.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z0 = acc[0][r];
+                const float s1 = nsvd_sigmoid(z0);
+                const float sq = z0 > NSVD_SOFTPLUS_THRESHOLD ? 0.f : s1 * (1.f - s1);
+                const float c2 = 0.5f * sq;
+                const float c3 = sq * fmaf(-2.f, s1, 1.f) * (1.f / 6.f);
+                const float c4 = sq * fmaf(-6.f, sq, 1.f) * (1.f / 24.f);
+#pragma unroll
+                for (int d = 0; d < (E - 1) / 2; ++d) {
+                    const float zE = acc[1 + 2 * d][r], zO = acc[2 + 2 * d][r];
+                    const float o2 = zO * zO;
+                    float ev = fmaf(c4, o2, 3.f * c3 * zE);      // c4 zO^2 + 3 c3 zE      (x zO^2)
+                    ev = fmaf(ev, o2, c2 * fmaf(zE, zE, o2));    // + c2 (zE^2 + zO^2)
+                    acc[1 + 2 * d][r] = fmaf(s1, zE, ev);
+                    acc[2 + 2 * d][r] = zO * fmaf(c3, o2, fmaf(2.f * c2, zE, s1));
+                }
+                acc[0][r] = nsvd_softplus(z0);
+            }
+            if (zs) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zs[(size_t)acc_row(r, hi) * a.B] = acc[0][r];
+            }
+        } else if (JET) {
             // forward-mode jet through the softplus, all streams of a (row, sample) in this lane's registers
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -437,10 +467,9 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             // activations -> bf16 planes in LDS, [plane][column][128 k + 16 B pad] (272-B rows: the ds_read_b128
             // fragment reads of 16 consecutive columns hit 16 distinct 4-bank groups); registers 4g .. 4g+3 of a lane
             // are 4 consecutive k = 32 w + 8 g + 4 hi + (0..3): one 8-byte store per plane.
-            // Stencil mode (as in layer 0, pmlp_layer0_bf3.h): the shifted columns enter the next layer as
-            // centre + perturbation, W a(x +- eps e_d) = W a(x) + W [a(x +- eps e_d) - a(x)]. The difference of the two
-            // float32 activations is exact (they agree to ~7 bits), 2^-7 of the centre's size, and takes two planes and
-            // three partial products; the centre product (six, on two alternating accumulators) is shared by all columns.
+            // Stencil mode (as in layer 0, pmlp_layer0_bf3.h): tiles 1 .. E-1 hold the even / odd perturbations of the
+            // activations - small, so two planes and three partial products carry them; the centre tile takes all six
+            // (on two alternating accumulators).
             constexpr bool DELTA = !JET;
             constexpr int HB_ROW = 2 * HID + 16, HB_PL = NC * HB_ROW;  // bytes (plane 2: the centre tile's 32 rows only
                                                                        // in stencil mode - the same stride is kept)
@@ -453,9 +482,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 for (int g = 0; g < 4; ++g) {
                     if (DELTA && e > 0) {
                         uint2 p0, p1;
-                        nsvd_bf2_split(make_float4(acc[e][4 * g] - acc[0][4 * g], acc[e][4 * g + 1] - acc[0][4 * g + 1],
-                                                   acc[e][4 * g + 2] - acc[0][4 * g + 2],
-                                                   acc[e][4 * g + 3] - acc[0][4 * g + 3]), p0, p1);
+                        nsvd_bf2_split(make_float4(acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]),
+                                       p0, p1);
                         *reinterpret_cast<uint2*>(hcol + 16 * g) = p0;
                         *reinterpret_cast<uint2*>(hcol + 16 * g + HB_PL) = p1;
                     } else {
@@ -529,11 +557,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             }
             if constexpr (DELTA) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[0][r] += accb[r];
-#pragma unroll
-                    for (int e = 1; e < E; ++e) acc[e][r] += acc[0][r];
-                }
+                for (int r = 0; r < 16; ++r) acc[0][r] += accb[r];  // (the even / odd tiles stay apart)
             }
             NSVD_STAMP(6 + 4 * i)
             continue;
@@ -640,6 +664,30 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             const float s_l = a.scales ? a.scales[l] : 0.f;
             const NsvdFdOut o = nsvd_fd_exact(gs[tid], db, gs[(E - 1) * BS + tid], xc, a.D, a.scales != nullptr, s_l,
                                               a.prob, a.log_norm);
+            const size_t idx = (size_t)b * a.L + l;
+            a.f[idx] = o.f;
+            a.Tf[idx] = o.Tf;
+            if (a.jac) a.jac[idx] = o.jac;
+            if (a.dsc) a.dsc[idx] = o.dsc;
+        }
+        NSVD_STAMP(14)
+        return;
+    }
+    if (BF3) {
+        // stencil mode of the bf16x3 path: outputs of the 128 -> 1 layer in even / odd form (its bias joins the centre)
+        if (tid < NC)
+            gs[tid] = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + (tid < BS ? a.b[nh][l] : 0.f);
+        __syncthreads();
+        if (tid < BS) {
+            const int b = b0 + tid;
+            float xc[NSVD_FD_MAXD], bE[NSVD_FD_MAXD], bO[NSVD_FD_MAXD];
+            for (int d = 0; d < a.D; ++d) {
+                xc[d] = a.x[(size_t)b * a.D + d];
+                bE[d] = gs[(1 + 2 * d) * BS + tid];
+                bO[d] = gs[(2 + 2 * d) * BS + tid];
+            }
+            const float s_l = a.scales ? a.scales[l] : 0.f;
+            const NsvdFdOut o = nsvd_fd_evenodd(gs[tid], bE, bO, xc, a.D, a.scales != nullptr, s_l, a.prob, a.log_norm);
             const size_t idx = (size_t)b * a.L + l;
             a.f[idx] = o.f;
             a.Tf[idx] = o.Tf;

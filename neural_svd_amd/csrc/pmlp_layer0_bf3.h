@@ -82,29 +82,30 @@ __device__ __forceinline__ void nsvd_rows_from_centre(const float4 rs, const flo
     }
 }
 
-// Stencil mode only: the 2 DD shifted rows as PERTURBATIONS of the centre row,
-//     phi(x +- eps e_d) - phi(x):   sin: s (cd - 1) +- c sd,   cos: c (cd - 1) -+ s sd        (cm = cd - 1 from the table)
-// |perturbation| ~ eps |B_dj| |phi| ~ 2^-7 |phi|. Layer 0 is linear, so W phi(x +- eps e_d) = W phi(x) + W (perturbation):
-// the centre product is computed ONCE (column tile 0, all six partial products) and shared - bit for bit - by every
-// stencil column, and the perturbation, being 2^-7 of the size, needs two bf16 planes and three partial products
-// (hi hi + hi mid + mid hi; dropped: lo hi, hi lo', mid mid <= 2^-18 of a term that is 2^-7 of the centre's: below
-// the float32 rounding of the sum) for the same absolute accuracy: 12 + 4 x 6 = 36 MFMAs per chunk and wave instead
-// of 60, 11 fragment reads per k-step instead of 15, and the common part of the five columns - what the
-// finite-difference stencil subtracts - carries no independent rounding noise at all.
+// Stencil mode only: the 2 DD shifted rows in EVEN / ODD form. With d = eps B_dj,
+//     phi(x +- eps e_d) - phi(x):   sin: s (cos d - 1) +- c sin d,   cos: c (cos d - 1) -+ s sin d,
+// i.e. an even part u (cos d - 1) (~ d^2 / 2: 2^-14 of the centre at configs[1]) and an odd part +- v sin d (~ d: 2^-7);
+// `cm` = cos d - 1 comes from the table as -2 sin^2(d / 2), without the cancellation. Layer 0 is linear, so
+//     W phi(x +- eps e_d) = W phi(x) + W even_d +- W odd_d :
+// column tile 0 is the centre product (all six partial products), tiles 1 + 2 d / 2 + 2 d the even / odd products of
+// direction d - small, so two bf16 planes and three partial products (hi hi + hi mid + mid hi; what is dropped is <=
+// 2^-17 of the tile's OWN size) carry them: 12 + 4 x 6 = 36 MFMAs per chunk and wave instead of 60, 11 fragment reads
+// per k-step instead of 15. And the tiles stay apart through the whole network (pmlp_fwd.hip: the softplus acts on
+// (centre, even, odd) by its Taylor expansion around the centre), so that the quantity the finite-difference stencil
+// is after - sum_d [f(x + eps e_d) + f(x - eps e_d) - 2 f(x)] = 2 sum_d even_d - is never formed as the difference of
+// rounded large numbers: the float32 stencil noise (a per-point error of ~|f| at eps = 0.01, for the reference's own
+// arithmetic too) is gone, the Laplacian stream is accurate to ~1e-5 of itself.
 template <int E, int HALF>
 __device__ __forceinline__ void nsvd_rows_delta(const float4 rs, const float4 rc, const float4 (&cm)[3],
                                                 const float4 (&sd)[3], float4 (&rb)[E]) {
     constexpr int DD = (E - 1) / 2;
     const float4 u = HALF ? rc : rs, v = HALF ? rs : rc;  // this half's feature and its partner
+    const float sg = HALF ? -1.f : 1.f;                   // d sin = +cos, d cos = -sin
     rb[0] = u;
 #pragma unroll
     for (int d = 0; d < DD; ++d) {
-        const float4 pl = make_float4(fmaf(u.x, cm[d].x, v.x * sd[d].x), fmaf(u.y, cm[d].y, v.y * sd[d].y),
-                                      fmaf(u.z, cm[d].z, v.z * sd[d].z), fmaf(u.w, cm[d].w, v.w * sd[d].w));
-        const float4 mi = make_float4(fmaf(u.x, cm[d].x, -(v.x * sd[d].x)), fmaf(u.y, cm[d].y, -(v.y * sd[d].y)),
-                                      fmaf(u.z, cm[d].z, -(v.z * sd[d].z)), fmaf(u.w, cm[d].w, -(v.w * sd[d].w)));
-        rb[1 + 2 * d] = HALF ? mi : pl;
-        rb[2 + 2 * d] = HALF ? pl : mi;
+        rb[1 + 2 * d] = make_float4(u.x * cm[d].x, u.y * cm[d].y, u.z * cm[d].z, u.w * cm[d].w);
+        rb[2 + 2 * d] = make_float4(sg * (v.x * sd[d].x), sg * (v.y * sd[d].y), sg * (v.z * sd[d].z), sg * (v.w * sd[d].w));
     }
 }
 // two planes of 4 consecutive-k floats (the perturbation rows)
@@ -194,8 +195,8 @@ __device__ __forceinline__ float4 nsvd_f4(const nsvd_f32x4 v) { return __builtin
 // The K loop walks PAIRS of chunks - the 32 sin features k in [32 q, 32 q + 32) and their 32 cos partners - with ONE
 // barrier per pair.
 // Column tiles: tile 0 = the centre rows (three planes, six partial products); tiles 1 .. E-1 = in stencil mode the
-// perturbation rows (two planes, three partial products: nsvd_rows_delta above; the centre product is added to them once,
-// after the loop), in jet mode the derivative streams (three planes, six products, as tile 0).
+// even / odd perturbation rows (two planes, three partial products: nsvd_rows_delta above), in jet mode the
+// derivative streams (three planes, six products, as tile 0).
 // LDS: the sample-column planes of a pair, [buffer 2][half 2][plane][rows][64 B], unpadded: the 16-byte slot of row r
 // holds k-octet slot ^ ((r >> 2) & 3) (applied on the 8-byte stores and on the fragment reads), which makes the
 // ds_read_b128 of 16 consecutive rows hit 16 distinct 4-bank groups. Plane 0 and 1: NC rows, plane 2: the tiles that
@@ -446,13 +447,9 @@ __device__ __forceinline__ void nsvd_layer0_bf3(const FwdArgs& a, f32x16 (&acc)[
     pstep(P0{}, T1{}, q);
     pstep(P1{}, T0{}, q + 1);
     if constexpr (DELTA) {
-        // the centre product joins every stencil column: z(x +- eps e_d) = [b + W phi(x)] + W (perturbation)
+        // tile 0: b + W phi(x); tiles 1 + 2 d, 2 + 2 d: the even / odd perturbations of direction d, kept apart
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc[0][r] += accb[r];
-#pragma unroll
-            for (int e = 1; e < E; ++e) acc[e][r] += acc[0][r];
-        }
+        for (int r = 0; r < 16; ++r) acc[0][r] += accb[r];
     }
     __syncthreads();
 }
