@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(256) fd_epilogue_kernel(const float* __restric
                                                           const float* __restrict__ scales, nsvd_problem prob,
                                                           float log_norm, int B, int D, int L, float* __restrict__ f,
                                                           float* __restrict__ Tf, float* __restrict__ jac,
-                                                          float* __restrict__ dsc) {
+                                                          float* __restrict__ dsc, int evenodd) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * L) return;
     const int b = idx / L, l = idx - b * L;
@@ -26,7 +26,17 @@ __global__ void __launch_bounds__(256) fd_epilogue_kernel(const float* __restric
     float bv[2 * NSVD_FD_MAXD + 1];
     for (int e = 0; e < E; ++e) bv[e] = base[(size_t)l * ldr + (size_t)e * B + b];
     const float s_l = scales ? scales[l] : 0.f;
-    NsvdFdOut o = nsvd_fd_point(bv, xc, D, scales != nullptr, s_l, prob, log_norm);
+    NsvdFdOut o;
+    if (evenodd) {  // rows 1 + 2 d / 2 + 2 d hold the even / odd perturbations of direction d (fused split-stencil form)
+        float bE[NSVD_FD_MAXD], bO[NSVD_FD_MAXD];
+        for (int d = 0; d < D; ++d) {
+            bE[d] = bv[1 + 2 * d];
+            bO[d] = bv[2 + 2 * d];
+        }
+        o = nsvd_fd_evenodd(bv[0], bE, bO, xc, D, scales != nullptr, s_l, prob, log_norm);
+    } else {
+        o = nsvd_fd_point(bv, xc, D, scales != nullptr, s_l, prob, log_norm);
+    }
     f[idx] = o.f;
     Tf[idx] = o.Tf;
     if (jac) jac[idx] = o.jac;
@@ -86,11 +96,11 @@ int nsvd_model_out(const float* base, int ldr, const float* x, const float* scal
 }
 
 int nsvd_fd_epilogue(const float* base, int ldr, const float* x, const float* scales, const nsvd_problem& prob,
-                     int B, int D, int L, float* f, float* Tf, float* jac, float* dsc, hipStream_t s) {
+                     int B, int D, int L, float* f, float* Tf, float* jac, float* dsc, hipStream_t s, int evenodd) {
     if (D > NSVD_FD_MAXD) return NSVD_EUNSUPPORTED;
     const float log_norm = nsvd_gauss_log_norm(D, prob.sigma);
     hipLaunchKernelGGL(fd_epilogue_kernel, dim3(nsvd_cdiv(B * L, 256)), dim3(256), 0, s, base, ldr, x, scales, prob,
-                       log_norm, B, D, L, f, Tf, jac, dsc);
+                       log_norm, B, D, L, f, Tf, jac, dsc, evenodd);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

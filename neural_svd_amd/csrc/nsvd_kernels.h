@@ -43,8 +43,10 @@ int nsvd_rowsum(const float* in, float* out, int rows, int n, long ld, hipStream
 // ---- FD Hamiltonian epilogue + its backward head (fd_epilogue.hip) ------------------------------
 // base: (L, ldr) head outputs at the E*B stencil rows -> f, Tf (B, L); optionally jac, dsc (B, L):
 //   jac = d f / d base(centre), dsc = d f / d scales_l per row (ExponentialMask only).
+// evenodd != 0: rows 1 + 2 d / 2 + 2 d of `base` hold the EVEN / ODD perturbations of the head output along direction d
+// (base(x +- eps e_d) = base[0] + even_d +- odd_d: the fused kernels' split-stencil form) instead of the point values
 int nsvd_fd_epilogue(const float* base, int ldr, const float* x, const float* scales, const nsvd_problem& prob,
-                     int B, int D, int L, float* f, float* Tf, float* jac, float* dsc, hipStream_t s);
+                     int B, int D, int L, float* f, float* Tf, float* jac, float* dsc, hipStream_t s, int evenodd = 0);
 // dzT[l][b] = df[b][l] * jac[b][l]; dscales[l] = sum_b df[b][l] * dsc[b][l] (when dscales != null)
 int nsvd_head_backward(const float* df, const float* jac, const float* dsc, int B, int L, float* dzT,
                        float* dscales, hipStream_t s);

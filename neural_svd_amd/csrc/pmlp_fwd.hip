@@ -85,6 +85,15 @@ template <int E, int JET, int BF3 = 0, int PL = 0>
 __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     static_assert(!PL || (!JET && !BF3 && E <= 4), "plain tiles: native fp32 layer 0, at most four sample tiles");
     constexpr int NC = E * BS;
+    // Stencil mode (neither jets nor plain tiles), both the native and the bf16x3 kernel: the 2 D shifted evaluations
+    // travel through the network in EVEN / ODD form - tile 0 the centre x, tile 1 + 2 d the even part and tile 2 + 2 d the
+    // odd part of (value at x + eps e_d, value at x - eps e_d) minus the centre value: z(x +- eps e_d) = z + zE_d +- zO_d.
+    // Layer 0 is linear in the features (even rows u (cos d - 1), odd rows +- v sin d: pmlp_layer0_bf3.h), the softplus
+    // acts on the triple by its Taylor expansion around the centre, and the epilogue forms the central difference from
+    // the even parts (fd_math.h: nsvd_fd_evenodd). The finite-difference Laplacian - what the reference's float32
+    // arithmetic, and round 3's kernels, carry with a per-point error of ~|f| at eps = 0.01 - is then never the
+    // difference of rounded large numbers: Tf agrees with the float64 stencil to ~1e-5 instead of a few per cent.
+    constexpr bool EO = !JET && !PL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][128][A_LD]   W_0 tile, k contiguous
     float* Bs = smem + 2 * HID * A_LD;      // [2][NC][A_LD]    phi tile (rows = sample columns), k contiguous
@@ -124,7 +133,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         for (int r = 0; r < 16; ++r) {
             const float bv = bi0[acc_row(r, hi)];
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e][r] = (JET && e > 0) ? 0.f : bv;
+            for (int e = 0; e < E; ++e) acc[e][r] = ((JET || EO) && e > 0) ? 0.f : bv;  // (the bias joins tile 0 only)
         }
     }
 
@@ -158,6 +167,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const float* a_u = W0;
     const float* b_u = a.phiT + (size_t)b0 * a.F;               // centre features, (B, F) row-major
     const float* t_u = a.sctab + (size_t)grp * 2 * a.m;         // (D, 2, m): this group's direction first
+    const float* tc_u = a.sctab + (size_t)(2 * a.D + grp) * a.m;  // (D, m) behind it: cos(eps B_dj) - 1
     const size_t a_step = (size_t)32 * a.F;
     const int mm = a.m;
 #define NSVD_LDGU(ub, off) (*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ub) + (off)))
@@ -179,11 +189,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         } else if (!(HALF)) {                                                    \
             rs = NSVD_LDGU(b_u + kp_, offA);                                     \
             rc = NSVD_LDGU(b_u + mm + kp_, offA);                                \
-            if (DD > 0) cd0 = NSVD_LDGU(t_u + kp_, offT);                        \
+            /* stencil mode: the cd slots hold cos(eps B) - 1 (even / odd rows); jets: B_dj */ \
+            if (DD > 0) cd0 = NSVD_LDGU((EO ? tc_u : t_u) + kp_, offT);          \
             if (DD > 0) sd0 = NSVD_LDGU(t_u + mm + kp_, offT);                   \
-            if (DD > 1) cd1 = NSVD_LDGU(t_u + 2 * mm + kp_, offT);               \
+            if (DD > 1) cd1 = NSVD_LDGU((EO ? tc_u + mm : t_u + 2 * mm) + kp_, offT); \
             if (DD > 1) sd1 = NSVD_LDGU(t_u + 3 * mm + kp_, offT);               \
-            if (DD > 2) cd2 = NSVD_LDGU(t_u + 4 * mm + kp_, offT);               \
+            if (DD > 2) cd2 = NSVD_LDGU((EO ? tc_u + 2 * mm : t_u + 4 * mm) + kp_, offT); \
             if (DD > 2) sd2 = NSVD_LDGU(t_u + 5 * mm + kp_, offT);               \
         }                                                                        \
     }
@@ -233,16 +244,16 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 NSVD_NMUL4(gm_, rc, sd0);                                        \
                 NSVD_STS(Bb_ + (DD + 1) * 32 * A_LD, gm_);                       \
             }                                                                    \
-        } else if (!(HALF)) {  /* sin rows: x + eps e_d -> s cd + c sd, x - eps e_d -> s cd - c sd */ \
+        } else if (!(HALF)) {  /* sin rows, even / odd: s (cos d - 1), +c sin d  (sin(t +- d) - sin t) */ \
             NSVD_STS(Bb_, rs);                                                   \
-            if (DD > 0) { NSVD_PM(gp_, gm_, rs, rc, cd0, sd0) NSVD_STS(Bb_ + 32 * A_LD, gp_); NSVD_STS(Bb_ + 64 * A_LD, gm_); }   \
-            if (DD > 1) { NSVD_PM(gp_, gm_, rs, rc, cd1, sd1) NSVD_STS(Bb_ + 96 * A_LD, gp_); NSVD_STS(Bb_ + 128 * A_LD, gm_); }  \
-            if (DD > 2) { NSVD_PM(gp_, gm_, rs, rc, cd2, sd2) NSVD_STS(Bb_ + 160 * A_LD, gp_); NSVD_STS(Bb_ + 192 * A_LD, gm_); } \
-        } else {        /* cos rows: x + eps e_d -> c cd - s sd, x - eps e_d -> c cd + s sd */ \
+            if (DD > 0) { NSVD_MUL4(gp_, rs, cd0); NSVD_MUL4(gm_, rc, sd0); NSVD_STS(Bb_ + 32 * A_LD, gp_); NSVD_STS(Bb_ + 64 * A_LD, gm_); }   \
+            if (DD > 1) { NSVD_MUL4(gp_, rs, cd1); NSVD_MUL4(gm_, rc, sd1); NSVD_STS(Bb_ + 96 * A_LD, gp_); NSVD_STS(Bb_ + 128 * A_LD, gm_); }  \
+            if (DD > 2) { NSVD_MUL4(gp_, rs, cd2); NSVD_MUL4(gm_, rc, sd2); NSVD_STS(Bb_ + 160 * A_LD, gp_); NSVD_STS(Bb_ + 192 * A_LD, gm_); } \
+        } else {        /* cos rows, even / odd: c (cos d - 1), -s sin d  (cos(t +- d) - cos t) */ \
             NSVD_STS(Bb_, rc);                                                   \
-            if (DD > 0) { NSVD_PM(gp_, gm_, rc, rs, cd0, sd0) NSVD_STS(Bb_ + 32 * A_LD, gm_); NSVD_STS(Bb_ + 64 * A_LD, gp_); }   \
-            if (DD > 1) { NSVD_PM(gp_, gm_, rc, rs, cd1, sd1) NSVD_STS(Bb_ + 96 * A_LD, gm_); NSVD_STS(Bb_ + 128 * A_LD, gp_); }  \
-            if (DD > 2) { NSVD_PM(gp_, gm_, rc, rs, cd2, sd2) NSVD_STS(Bb_ + 160 * A_LD, gm_); NSVD_STS(Bb_ + 192 * A_LD, gp_); } \
+            if (DD > 0) { NSVD_MUL4(gp_, rc, cd0); NSVD_NMUL4(gm_, rs, sd0); NSVD_STS(Bb_ + 32 * A_LD, gp_); NSVD_STS(Bb_ + 64 * A_LD, gm_); }   \
+            if (DD > 1) { NSVD_MUL4(gp_, rc, cd1); NSVD_NMUL4(gm_, rs, sd1); NSVD_STS(Bb_ + 96 * A_LD, gp_); NSVD_STS(Bb_ + 128 * A_LD, gm_); }  \
+            if (DD > 2) { NSVD_MUL4(gp_, rc, cd2); NSVD_NMUL4(gm_, rs, sd2); NSVD_STS(Bb_ + 160 * A_LD, gp_); NSVD_STS(Bb_ + 192 * A_LD, gm_); } \
         }                                                                        \
     }
 
@@ -377,8 +388,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         // softplus in registers; the centre rows' ACTIVATIONS are saved for the backward (its kernels then need
         // no softplus: sigmoid(z) = 1 - exp(-softplus(z)), and the weight gradients contract activations)
         float* zs = (a.zsave[i] && grp == 0) ? a.zsave[i] + ((size_t)l * HID + 32 * w) * a.B + b0 + li : nullptr;
-        if (BF3 && !JET) {
-            // stencil mode of the bf16x3 path: tile 0 holds z(x), tiles 1 + 2 d / 2 + 2 d the even / odd parts zE, zO of
+        if (EO) {
+            // stencil mode: tile 0 holds z(x), tiles 1 + 2 d / 2 + 2 d the even / odd parts zE, zO of
             // z(x +- eps e_d) - z(x) = zE +- zO. The softplus acts on the triple by its Taylor expansion around z
             // (s = sigmoid z, q = 1 - s: c1 = s, c2 = s q / 2, c3 = s q (1 - 2 s) / 6, c4 = s q (1 - 6 s q) / 24):
             //   even' = c1 zE + c2 (zE^2 + zO^2) + 3 c3 zE zO^2 + c4 zO^4,   odd' = zO (c1 + 2 c2 zE + c3 zO^2)
@@ -582,7 +593,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[e][r] = (JET && e > 0) ? 0.f : nb[r];
+            for (int r = 0; r < 16; ++r) acc[e][r] = ((JET || EO) && e > 0) ? 0.f : nb[r];
         // K = 128 in 16 q-groups, fragments read one q-group ahead, one LDS read per MFMA gap
         const float* Ap = Wt + li * HID;        // + 4 * ((2q + hi) ^ (li & 15)): swizzled 16-B chunk
         const int sw = li & 15;
@@ -612,7 +623,10 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         if (tid < NC) {
             const int e_t = tid / BS, sidx = tid - e_t * BS;
             if (e_t > 0 || grp == 0) {
-                const float bve = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
+                // (even / odd form: rows 1 + 2 g, 2 + 2 g receive the even / odd perturbation of direction g; the bias
+                // of the 128 -> 1 layer joins the centre row only)
+                const float bve = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) +
+                                  (e_t == 0 ? a.b[nh][l] : 0.f);
                 const int eg = e_t == 0 ? 0 : 2 * grp + e_t;  // x + eps e_g at 1 + 2 g, x - eps e_g at 2 + 2 g
                 a.base_raw[(size_t)l * a.ldr + (size_t)eg * a.B + b0 + sidx] = bve;
             }
@@ -673,8 +687,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         NSVD_STAMP(14)
         return;
     }
-    if (BF3) {
-        // stencil mode of the bf16x3 path: outputs of the 128 -> 1 layer in even / odd form (its bias joins the centre)
+    {
+        // stencil mode: outputs of the 128 -> 1 layer in even / odd form (its bias joins the centre)
         if (tid < NC)
             gs[tid] = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + (tid < BS ? a.b[nh][l] : 0.f);
         __syncthreads();
@@ -697,44 +711,6 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         NSVD_STAMP(14)
         return;
     }
-    NsvdFdG og;
-    float bve = 0.f;
-    og.g = og.sp = og.mk = og.r = 0.f;
-    const int e_t = tid / BS, sidx = tid - e_t * BS;
-    if (tid < NC) {
-        bve = (red[tid] + red[NC + tid]) + (red[2 * NC + tid] + red[3 * NC + tid]) + a.b[nh][l];
-        float xc[NSVD_FD_MAXD];
-        for (int d = 0; d < a.D; ++d) xc[d] = a.x[(size_t)(b0 + sidx) * a.D + d];
-        const float s_l = a.scales ? a.scales[l] : 0.f;
-        og = nsvd_fd_g(e_t, bve, xc, a.D, a.scales != nullptr, s_l, a.prob, a.log_norm);
-    }
-    __syncthreads();          // every thread has consumed its red[] inputs before the centre values overwrite them
-    if (tid < NC) {
-        gs[tid] = og.g;
-        if (e_t == 0) {
-            cen[sidx] = og.sp;
-            cen[BS + sidx] = og.mk;
-            cen[2 * BS + sidx] = og.r;
-            cen[3 * BS + sidx] = bve;
-        }
-    }
-    __syncthreads();
-    NSVD_STAMP(13)
-    if (tid < BS) {
-        const int b = b0 + tid;
-        float g[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) g[e] = gs[e * BS + tid];
-        const float s_l = a.scales ? a.scales[l] : 0.f;
-        const NsvdFdOut o = nsvd_fd_combine(g, cen[tid], cen[BS + tid], cen[2 * BS + tid], cen[3 * BS + tid], a.D,
-                                            a.scales != nullptr, s_l, a.prob);
-        const size_t idx = (size_t)b * a.L + l;
-        a.f[idx] = o.f;
-        a.Tf[idx] = o.Tf;
-        if (a.jac) a.jac[idx] = o.jac;
-        if (a.dsc) a.dsc[idx] = o.dsc;
-    }
-    NSVD_STAMP(14)
 }
 
 template <int E, int BF3 = 0>
@@ -877,7 +853,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         rc = launch_fwd<3>(a, s);
         if (rc) return rc;
         return nsvd_fd_epilogue(w.base_raw, R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
-                                save ? w.jac : nullptr, (save && d.has_exp_mask) ? w.dsc : nullptr, s);
+                                save ? w.jac : nullptr, (save && d.has_exp_mask) ? w.dsc : nullptr, s, 1);
     }
     switch (E) {
         case 3: return launch_fwd<3>(a, s);
