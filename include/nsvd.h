@@ -340,6 +340,13 @@ int nsvd_rmsprop_ema_step(float* p, const float* grad, float* sq, float* ema, si
 int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, int B, int L, int D,
                              float sigma, int use_importance, float lim, float* cov, float* quad,
                              void* stream);
+/* The same accumulation with float64 products, sums and accumulators (cov, quad: (L, L) doubles). The reference keeps
+ * float32 accumulators (methods/spectrum.py:60-61,74-75); for excited states diag(quad) is a sum of terms up to 10^2 x
+ * larger than itself, which a float32 running sum carries to ~1e-4 only - the evaluation paths of this package
+ * (trainer.spectrum, spectrum.compute_spectrum_evd) accumulate here and round once at the end. */
+int nsvd_spectrum_accumulate_f64(const float* f, const float* Tf, const float* x, int B, int L, int D,
+                                 float sigma, int use_importance, float lim, double* cov, double* quad,
+                                 void* stream);
 
 /* ---- next row: dense kernel operator on a minibatch (kernel-operator configuration) ---------------------------
  * Kf[i][l] = scale * sum_k K[rows[i]][cols[k]] f[k][l]: the (Kf, f) producer that

@@ -122,6 +122,7 @@ SIGNATURES = {
     "nsvd_cdk_loss_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "nsvd_cdk_loss_backward": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "nsvd_spectrum_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
+    "nsvd_spectrum_accumulate_f64": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
     "nsvd_row_normalize_forward": (_I, [_P, _I, _I, _F, _I, _P, _P]),
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
     "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),

@@ -82,17 +82,32 @@ __device__ __forceinline__ NsvdFdOut nsvd_fd_evenodd(float base0, const float* b
     const float mk0 = has_mask ? expf(-r0 / s_l) : 1.f;
     const float eps = prob.eps;
     const float qs = prob.use_importance ? -1.f / (4.f * prob.sigma * prob.sigma) : 0.f;  // d log sqrt p / d |x|^2
+    const float e2 = eps * eps;
     float acc = 0.f;
     for (int d = 0; d < D; ++d) {
-        const float dp = eps * (2.f * xc[d] + eps), dm = eps * (eps - 2.f * xc[d]);  // |x_+-|^2 - |x0|^2
-        float ap = qs * dp, am = qs * dm;
+        // log w(x_+-) - log w(x0) = s +- a, split into its even part s = O(eps^2) and odd part a = O(eps) BEFORE any
+        // exponential: rho_+ + rho_- is O(eps^2) while each rho is O(eps), so expm1(s + a) + expm1(s - a) loses
+        // |x_d| / eps ~ 10^3 of its digits (measured: 7e-5 relative at the median of a [-50, 50] grid, i.e. the whole
+        // Laplacian term); with |x_+-|^2 - |x0|^2 = e2 +- b, b = 2 x_d eps:
+        //     rho_+ + rho_- = 2 [expm1(s) cosh a + (cosh a - 1)],  cosh a - 1 = 2 sinh^2(a / 2)
+        //     rho_+ - rho_- = 2 exp(s) sinh a
+        const float b = 2.f * xc[d] * eps;
+        float sv = qs * e2, av = qs * b;
         if (has_mask) {
-            const float rp = sqrtf(fmaxf(r2 + dp, 0.f)), rm = sqrtf(fmaxf(r2 + dm, 0.f));
-            ap -= (dp / (rp + r0)) / s_l;  // |x_+| - |x0| = (|x_+|^2 - |x0|^2) / (|x_+| + |x0|)
-            am -= (dm / (rm + r0)) / s_l;
+            // |x_+-| - |x0| = (e2 +- b) / (r_+- + r0) =: t_+-, with r_- - r_+ = -2 b / (r_+ + r_-):
+            //   t_+ + t_- = [e2 (S + 2 r0) - 2 b^2 / S] / den,  t_+ - t_- = b [(S + 2 r0) - 2 e2 / S] / den,
+            //   S = r_+ + r_-, den = (r_+ + r0)(r_- + r0)
+            const float rp = sqrtf(fmaxf(r2 + (e2 + b), 0.f)), rm = sqrtf(fmaxf(r2 + (e2 - b), 0.f));
+            const float S = rp + rm, den = (rp + r0) * (rm + r0);
+            const float tsum = (e2 * (S + 2.f * r0) - 2.f * b * b / S) / den;
+            const float tdif = b * ((S + 2.f * r0) - 2.f * e2 / S) / den;
+            sv -= 0.5f * tsum / s_l;
+            av -= 0.5f * tdif / s_l;
         }
-        const float rhop = expm1f(ap), rhom = expm1f(am);
-        acc += (rhop + rhom) * (base0 + bE[d]) + 2.f * bE[d] + (rhop - rhom) * bO[d];
+        const float sh = sinhf(0.5f * av), chm1 = 2.f * sh * sh, es1 = expm1f(sv);
+        const float ev = 2.f * (es1 * (1.f + chm1) + chm1);  // rho_+ + rho_-
+        const float od = 2.f * (1.f + es1) * sinhf(av);      // rho_+ - rho_-
+        acc += ev * (base0 + bE[d]) + 2.f * bE[d] + od * bO[d];
     }
     const float eps2 = (float)((double)prob.eps * (double)prob.eps);
     const float spc = prob.use_importance ? fmaxf(sp0, NSVD_SQRT_P_CLAMP) : 1.f;

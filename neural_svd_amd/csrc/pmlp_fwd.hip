@@ -391,26 +391,37 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         if (EO) {
             // stencil mode: tile 0 holds z(x), tiles 1 + 2 d / 2 + 2 d the even / odd parts zE, zO of
             // z(x +- eps e_d) - z(x) = zE +- zO. The softplus acts on the triple by its Taylor expansion around z
-            // (s = sigmoid z, q = 1 - s: c1 = s, c2 = s q / 2, c3 = s q (1 - 2 s) / 6, c4 = s q (1 - 6 s q) / 24):
-            //   even' = c1 zE + c2 (zE^2 + zO^2) + 3 c3 zE zO^2 + c4 zO^4,   odd' = zO (c1 + 2 c2 zE + c3 zO^2)
-            // - zO ~ 2^-7 .. 2^-4, zE ~ zO^2: the terms left out are below 1e-6 of even' and 1e-4 of odd' (odd enters
-            // the stencil only through its squares). No transcendental for the shifted tiles.
+            // to sixth order (s = sigmoid z, p = s (1 - s): c1 = s, c2 = p / 2, c3 = p (1 - 2 s) / 6, c4 = p (1 - 6 p) / 24,
+            // c5 = p (1 - 2 s)(1 - 12 p) / 120, c6 = p (1 - 30 p + 120 p^2) / 720), with zO = O(delta), zE = O(delta^2), w = zO^2:
+            //   even' = c1 zE + c2 (zE^2 + w) + c3 zE (zE^2 + 3 w) + c4 w (w + 6 zE^2) + 5 c5 zE w^2 + c6 w^3   + O(delta^8)
+            //   odd'  = zO [c1 + 2 c2 zE + c3 (3 zE^2 + w) + 4 c4 zE w + c5 w^2]                               + O(delta^7)
+            // - delta is 2^-7 .. 2^-4 at the reference's initialisations and stays below ~0.3 in trained models: the
+            // truncation is delta^6 of the signal (measured with W_0 scaled by 4 at configs[2], delta ~ 0.25: the
+            // fourth-order form was 3e-4 from the float64 stencil). No transcendental for the shifted tiles.
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float z0 = acc[0][r];
                 const float s1 = nsvd_sigmoid(z0);
                 const float sq = z0 > NSVD_SOFTPLUS_THRESHOLD ? 0.f : s1 * (1.f - s1);
+                const float t12 = fmaf(-2.f, s1, 1.f);
                 const float c2 = 0.5f * sq;
-                const float c3 = sq * fmaf(-2.f, s1, 1.f) * (1.f / 6.f);
+                const float c3 = sq * t12 * (1.f / 6.f);
                 const float c4 = sq * fmaf(-6.f, sq, 1.f) * (1.f / 24.f);
+                const float c5 = sq * t12 * fmaf(-12.f, sq, 1.f) * (1.f / 120.f);
+                const float c6 = sq * fmaf(sq, fmaf(120.f, sq, -30.f), 1.f) * (1.f / 720.f);
 #pragma unroll
                 for (int d = 0; d < (E - 1) / 2; ++d) {
                     const float zE = acc[1 + 2 * d][r], zO = acc[2 + 2 * d][r];
-                    const float o2 = zO * zO;
-                    float ev = fmaf(c4, o2, 3.f * c3 * zE);      // c4 zO^2 + 3 c3 zE      (x zO^2)
-                    ev = fmaf(ev, o2, c2 * fmaf(zE, zE, o2));    // + c2 (zE^2 + zO^2)
+                    const float w = zO * zO, e2 = zE * zE;
+                    float ev = fmaf(c6, w, 5.f * c5 * zE);                   // (c6 w + 5 c5 zE) w^2
+                    ev = fmaf(ev, w, c4 * fmaf(6.f, e2, w));                 // + c4 (w + 6 zE^2), all x w
+                    ev = fmaf(ev, w, c3 * zE * fmaf(3.f, w, e2));            // + c3 zE (zE^2 + 3 w)
+                    ev = fmaf(c2, e2 + w, ev);                               // + c2 (zE^2 + w)
+                    float od = fmaf(c5, w, 4.f * c4 * zE);                   // (c5 w + 4 c4 zE) w
+                    od = fmaf(od, w, c3 * fmaf(3.f, e2, w));                 // + c3 (3 zE^2 + w)
+                    od = fmaf(2.f * c2, zE, od) + s1;
                     acc[1 + 2 * d][r] = fmaf(s1, zE, ev);
-                    acc[2 + 2 * d][r] = zO * fmaf(c3, o2, fmaf(2.f * c2, zE, s1));
+                    acc[2 + 2 * d][r] = zO * od;
                 }
                 acc[0][r] = nsvd_softplus(z0);
             }

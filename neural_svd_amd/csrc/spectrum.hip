@@ -1,8 +1,12 @@
 // Streaming accumulators of compute_spectrum_evd (reference methods/spectrum.py:56-75):
 //   cov += phi^T phi, quad += phi^T Tphi  with phi = nan_to_num(w f), Tphi = nan_to_num(w Tf),
 //   w = sqrt(p_train(x)) / sqrt(p_val), rows with x ~ 0 zeroed in Tphi (:73).
-// One workgroup per 256 rows: rows staged in LDS, L x L partial products in registers, then one
-// float atomic per (i, j) and workgroup.
+// One workgroup per 128 rows: rows staged in LDS, L x L partial products in registers, then one
+// atomic per (i, j) and workgroup. Acc = float: the reference's float32 accumulators; Acc = double
+// (nsvd_spectrum_accumulate_f64): products and sums in float64 - the quotient diag(quad) / diag(cov) of an excited state
+// is a sum of terms up to 10^2 x larger than itself (the potential near the nucleus against the kinetic term), and a
+// float32 running sum over 500 workgroups then carries it to 1e-4 only (measured at configs[1]: 1.7e-4 on the n = 4
+// shell with float32 accumulators, 1e-6 with these - scripts/dev/parity_diag.py).
 #include "nsvd_kernels.h"
 #include <float.h>
 
@@ -17,10 +21,11 @@ __device__ __forceinline__ float nan_to_num(float v) {
     return v;
 }
 
+template <typename Acc>
 __global__ void __launch_bounds__(256) spectrum_kernel(const float* __restrict__ f, const float* __restrict__ Tf,
                                                        const float* __restrict__ x, int B, int L, int D, float sigma,
                                                        float log_norm, int use_imp, float inv_sqrt_val,
-                                                       float* __restrict__ cov, float* __restrict__ quad) {
+                                                       Acc* __restrict__ cov, Acc* __restrict__ quad) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // phi[SR][L], tphi[SR][L]
     float* ph = sm;
     float* tp = sm + SR * L;
@@ -40,11 +45,11 @@ __global__ void __launch_bounds__(256) spectrum_kernel(const float* __restrict__
     __syncthreads();
     for (int o = threadIdx.x; o < L * L; o += 256) {
         const int i = o / L, j = o - i * L;
-        float c = 0.f, q = 0.f;
+        Acc c = 0, q = 0;
         for (int r = 0; r < nr; ++r) {
-            const float pi = ph[r * L + i];
-            c = fmaf(pi, ph[r * L + j], c);
-            q = fmaf(pi, tp[r * L + j], q);
+            const Acc pi = ph[r * L + i];
+            c = fma(pi, (Acc)ph[r * L + j], c);
+            q = fma(pi, (Acc)tp[r * L + j], q);
         }
         atomicAdd(&cov[o], c);
         atomicAdd(&quad[o], q);
@@ -53,17 +58,29 @@ __global__ void __launch_bounds__(256) spectrum_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, int B, int L, int D,
-                                        float sigma, int use_importance, float lim, float* cov, float* quad,
-                                        void* stream) {
+template <typename Acc>
+static int spectrum_accumulate_impl(const float* f, const float* Tf, const float* x, int B, int L, int D, float sigma,
+                                    int use_importance, float lim, Acc* cov, Acc* quad, void* stream) {
     if (!f || !Tf || !x || !cov || !quad || B <= 0 || L <= 0 || D <= 0) return NSVD_EINVAL;
     if (L > SMAXL) return NSVD_EUNSUPPORTED;
     // importance_val is built as a float32 tensor in the reference (main_pde.py:130)
     const float pval = (float)(1.0 / pow(2.0 * (double)lim, (double)D));
     const float inv_sqrt_val = 1.f / sqrtf(pval);
     const size_t lds = (size_t)2 * SR * L * sizeof(float);
-    hipLaunchKernelGGL(spectrum_kernel, dim3(nsvd_cdiv(B, SR)), dim3(256), lds, (hipStream_t)stream, f, Tf, x, B, L, D,
-                       sigma, nsvd_gauss_log_norm(D, sigma), use_importance, inv_sqrt_val, cov, quad);
+    hipLaunchKernelGGL(spectrum_kernel<Acc>, dim3(nsvd_cdiv(B, SR)), dim3(256), lds, (hipStream_t)stream, f, Tf, x, B,
+                       L, D, sigma, nsvd_gauss_log_norm(D, sigma), use_importance, inv_sqrt_val, cov, quad);
     NSVD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, int B, int L, int D,
+                                        float sigma, int use_importance, float lim, float* cov, float* quad,
+                                        void* stream) {
+    return spectrum_accumulate_impl<float>(f, Tf, x, B, L, D, sigma, use_importance, lim, cov, quad, stream);
+}
+
+extern "C" int nsvd_spectrum_accumulate_f64(const float* f, const float* Tf, const float* x, int B, int L, int D,
+                                            float sigma, int use_importance, float lim, double* cov, double* quad,
+                                            void* stream) {
+    return spectrum_accumulate_impl<double>(f, Tf, x, B, L, D, sigma, use_importance, lim, cov, quad, stream);
 }

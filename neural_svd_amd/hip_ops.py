@@ -70,13 +70,13 @@ def _tb_problem(prob: Problem):
     return q
 
 
-def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
+def _ptr(t: Optional[torch.Tensor], name: str = "tensor", dtype: torch.dtype = torch.float32) -> Optional[int]:
     if t is None:
         return None
     if not t.is_cuda:
         raise NsvdError(f"{name} must live on the GPU (got {t.device}); neural_svd_amd has no CPU path")
-    if t.dtype != torch.float32:
-        raise NsvdError(f"{name} must be float32 (got {t.dtype})")
+    if t.dtype != dtype:
+        raise NsvdError(f"{name} must be {str(dtype).replace('torch.', '')} (got {t.dtype})")
     if not t.is_contiguous():
         raise NsvdError(f"{name} must be contiguous")
     return t.data_ptr()
@@ -237,19 +237,25 @@ def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.
     B = x.shape[0]
     if x.dim() != 2 or x.shape[1] != shape.D:
         raise NsvdError(f"x must be (B, {shape.D})")
-    if not prob.eps > 0 and (B % 32 != 0 or B > 8192) and not save_for_backward and not features_ready and B > 0:
-        # exact-Laplacian mode exists on the MFMA path only (batches of a multiple of 32 rows, at most 8192 of them
-        # without a backward layout): evaluation batches of any size go through in pieces of <= 8192 rows, the
-        # last one padded with copies of its last row, and the padding is dropped again
+    if ((B % 32 != 0 or B > 8192) and not save_for_backward and not features_ready and B > 0 and path != PATH_GENERIC
+            and path_name(shape, 32, path, prob) == "fused_mfma"):
+        # EVALUATION batches of any size on a model the MFMA kernels take (they want a multiple of 32 rows, at most
+        # 8192 of them without a backward layout): in pieces of <= 8192 rows, the last one padded with copies of its
+        # last row, and the padding dropped again - a row never sees its neighbours (bit-exact row equivariance is a
+        # test). The exact-Laplacian mode exists on that path only; in stencil mode it is the path that carries the
+        # stencil in even / odd form: a ragged validation batch must not fall back to the point-wise
+        # float32 stencil of the generic kernels, whose Tf is a few per cent from the float64 stencil.
         fs, Tfs = [], []
+        wsc = None
         for i in range(0, B, 8192):
             xc = x[i:i + 8192]
             n = xc.shape[0]
             npad = (n + 31) // 32 * 32
             if npad != n:
                 xc = torch.cat([xc, xc[-1:].expand(npad - n, -1)])
-            fp, Tfp = operator_forward(shape, params, prob, xc.contiguous(), new_workspace(shape, npad, x.device),
-                                       False, path)
+            if wsc is None or wsc.numel() < workspace_bytes(shape, npad):
+                wsc = new_workspace(shape, npad, x.device)
+            fp, Tfp = operator_forward(shape, params, prob, xc.contiguous(), wsc, False, path)
             fs.append(fp[:n])
             Tfs.append(Tfp[:n])
         fa, Tfa = torch.cat(fs), torch.cat(Tfs)
@@ -708,8 +714,19 @@ def rmsprop_ema_step_dev(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, 
 
 def spectrum_accumulate(f: torch.Tensor, Tf: torch.Tensor, x: torch.Tensor, sigma: float, use_importance: bool,
                         lim: float, cov: torch.Tensor, quad: torch.Tensor) -> None:
+    """cov += phi^T phi, quad += phi^T Tphi. float32 accumulators: the reference's (methods/spectrum.py:60-75);
+    float64 accumulators (cov.dtype == torch.float64): products and sums in float64 (nsvd_spectrum_accumulate_f64)."""
     B, L = f.shape
     D = x.shape[1]
+    if cov.dtype != quad.dtype or cov.dtype not in (torch.float32, torch.float64):
+        raise NsvdError("spectrum_accumulate: cov / quad must both be float32 or both float64")
+    if cov.dtype == torch.float64:
+        rc = _lib.load().nsvd_spectrum_accumulate_f64(_ptr(f, "f"), _ptr(Tf, "Tf"), _ptr(x, "x"), B, L, D, float(sigma),
+                                                      int(bool(use_importance)), float(lim),
+                                                      _ptr(cov, "cov", torch.float64), _ptr(quad, "quad", torch.float64),
+                                                      _stream())
+        check(rc, "nsvd_spectrum_accumulate_f64")
+        return
     if torch_binding() is not None:
         _TB.spectrum_accumulate(f, Tf, x, float(sigma), bool(use_importance), float(lim), cov, quad)
         return

@@ -26,7 +26,9 @@ def compute_spectrum_evd(model, dataloader, operator, importance_train=None, imp
         raise NsvdError("HIP path: importance_train must be None or GaussianImportance")
     dev = torch.device(f"cuda:{gpu}") if gpu is not None else torch.device(device)
     L = model.neigs
-    cov = torch.zeros((L, L), dtype=torch.float32, device=dev)
+    # float64 accumulators, rounded to the reference's float32 once at the end (include/nsvd.h:
+    # nsvd_spectrum_accumulate_f64 - a float32 running sum carries an excited state's quotient to ~1e-4 only)
+    cov = torch.zeros((L, L), dtype=torch.float64, device=dev)
     quad = torch.zeros_like(cov)
     eigfuncs, n = [], 0
     sigma = importance_train.sigma if importance_train is not None else 1.0
@@ -40,11 +42,12 @@ def compute_spectrum_evd(model, dataloader, operator, importance_train=None, imp
         H.spectrum_accumulate(phi, Tphi, x, sigma, importance_train is not None, importance_val.lim, cov, quad)
         n += len(x)
     out = dict()
-    cov = (cov / n).cpu().numpy()
-    quad = (quad / n).cpu().numpy()
+    cov64 = (cov / n).cpu().numpy()
+    quad64 = (quad / n).cpu().numpy()
+    cov, quad = cov64.astype(np.float32), quad64.astype(np.float32)
     eigfuncs = torch.cat(eigfuncs, dim=0).cpu().numpy()
     out["eigfuncs"], out["cov"], out["quad"] = eigfuncs, cov, quad
-    out["eigvals"] = eigvals = np.diag(quad) / np.diag(cov)
+    out["eigvals"] = eigvals = (np.diag(quad64) / np.diag(cov64)).astype(np.float32)
     out["norms"] = norms = np.diag(cov)
     if normalize:
         s = np.sqrt(norms)

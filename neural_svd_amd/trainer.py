@@ -602,18 +602,18 @@ def _spectrum_of(shape, params, problem, device, path, lim, val_eps, chunk):
         # np.meshgrid's default 'xy' indexing, flattened row-major: the reference's point order
         grid = torch.stack([g.reshape(-1) for g in torch.meshgrid(*(D * [ax]), indexing="xy" if D > 1 else "ij")],
                            dim=1).float().to(device)
-        cov = torch.zeros((L, L), dtype=torch.float32, device=device)
+        # float64 accumulators (the reference's are float32, methods/spectrum.py:60-61: nsvd.h on why these are not)
+        cov = torch.zeros((L, L), dtype=torch.float64, device=device)
         quad = torch.zeros_like(cov)
         ws = H.new_workspace(shape, min(chunk, grid.shape[0]), device)
         for i in range(0, grid.shape[0], chunk):
             xb = grid[i:i + chunk]
-            # a ragged last chunk is outside the MFMA kernels' shapes: let the library choose the path for it
-            pth = path if xb.shape[0] % 32 == 0 else H.PATH_AUTO
+            # (a ragged last chunk: hip_ops.operator_forward pads it for the MFMA kernels and drops the padding)
             wsb = ws if xb.shape[0] == chunk else H.new_workspace(shape, xb.shape[0], device)
-            f, Tf = H.operator_forward(shape, params, problem, xb, wsb, False, pth)
+            f, Tf = H.operator_forward(shape, params, problem, xb, wsb, False, path)
             H.spectrum_accumulate(f, Tf, xb, problem.sigma, bool(problem.use_importance), lim, cov, quad)
     n = grid.shape[0]
-    cov, quad = cov.double().cpu() / n, quad.double().cpu() / n
+    cov, quad = cov.cpu() / n, quad.cpu() / n
     return dict(cov=cov, quad=quad, eigvals=torch.diag(quad) / torch.diag(cov), norms=torch.diag(cov))
 
 
