@@ -946,9 +946,10 @@ def main():
         elif world == 1:
             side("opt_in_path_bf16x3", cfg, "dp", H.PATH_FUSED_BF16X3,
                  "same workload with NSVD_PATH_FUSED_BF16X3: every layer of the forward as three-way split bf16 "
-                 "products accumulated in float32 (the stencil columns as centre + perturbation: DESIGN.md 3.7) - "
-                 "measured MORE accurate against float64 than the native fp32 MFMA path (accuracy_vs_float64 below), "
-                 "same backward; not the headline value, which stays native float32 arithmetic")
+                 "products accumulated in float32 (the stencil columns as centre + even / odd perturbations: "
+                 "DESIGN.md 3.7, 3.9) - against float64 its f is closer than the native fp32 MFMA path's and its Tf "
+                 "within 1e-5 (the reference's own float32 arithmetic: 4e-2; accuracy_vs_float64 below), same "
+                 "backward; not the headline value, which stays native float32 arithmetic")
             try:  # f error and finite-difference noise of both paths against the float64 oracle (committed record of
                 # scripts/dev/bf3_check.py on the GPU box: the oracle is test infrastructure, not imported here)
                 bj = json.load(open(os.path.join(ROOT, "profiles", "latest_bf16x3_accuracy.json")))

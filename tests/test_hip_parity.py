@@ -7,6 +7,8 @@ Tolerances (float32 path, see DESIGN.md "Numerics"):
     everything downstream of it is compared against the float64 truth with the float32 reference's
     own error as yardstick: err <= max(3 * ref_err, floor).
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -762,6 +764,65 @@ def test_spectrum_matches_reference(case):
     ref_err = float(np.max(np.abs(e32 - e64) / np.abs(e64)))
     got_err = float(np.max(np.abs(eig.numpy() - e64) / np.abs(e64)))
     assert got_err < max(3 * ref_err, 1e-4), (got_err, ref_err)
+
+
+@pytest.mark.parametrize("fpath", FPATHS)
+def test_ragged_evaluation_batch_goes_through_the_mfma_kernels(fpath):
+    """An evaluation batch (no backward layout) of ANY size on a model the MFMA kernels take - the validation grids of
+    the reference's scripts are not multiples of 32 rows - is padded onto them and the padding dropped: the rows are
+    bit for bit the rows of the padded call, and Tf is the even / odd stencil's (1e-4 of the float64 stencil), not the
+    point-wise float32 stencil of the generic kernels (a few per cent). Also a batch beyond 8192 rows (pieces)."""
+    L, D, m, hidden = 4, 2, 64, (128, 128, 128)
+    p = O.init_params(L, D, m, hidden, 0.15, seed=3)
+    prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+    shape, prob = shape_of(p), hip_problem(prob_o)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    path = _path(fpath)
+    for B in (1060, 7, 8192 + 45):
+        x = (16.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(B))).to(DEV)
+        f, Tf = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV), False, path)
+        assert f.shape == (B, L) and Tf.shape == (B, L)
+        lo = (B - 1) // 8192 * 8192          # the last piece, padded by hand
+        xp = torch.cat([x[lo:], x[-1:].expand(-B % 32, -1)]).contiguous()
+        fp, Tfp = H.operator_forward(shape, params, prob, xp, H.new_workspace(shape, xp.shape[0], DEV), False, path)
+        assert torch.equal(f[lo:], fp[:B - lo]) and torch.equal(Tf[lo:], Tfp[:B - lo])
+        rows = torch.arange(0, B, max(1, B // 64))
+        ref = O.operator_forward(x[rows.to(DEV)].double().cpu(), p.to(torch.float64), prob_o)
+        assert rel(f[rows.to(DEV)], ref.f) < 2e-5
+        assert rel(Tf[rows.to(DEV)], ref.Tf) < 1e-4, (B, rel(Tf[rows.to(DEV)], ref.Tf))
+    # the generic kernels, asked for by name, still take the ragged batch as it is (point-wise stencil)
+    x = (16.0 * torch.randn(100, D, generator=torch.Generator().manual_seed(1))).to(DEV)
+    fg, Tfg = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, 100, DEV), False, H.PATH_GENERIC)
+    f, Tf = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, 100, DEV), False, path)
+    assert rel(fg, f.double().cpu()) < 1e-5 and rel(Tfg, Tf.double().cpu()) < 0.3
+
+
+def test_spectrum_accumulators_float64():
+    """nsvd_spectrum_accumulate_f64 (the evaluation paths' accumulators) against numpy float64 on the same float32
+    inputs, and the float32 accumulators (the reference's) beside it."""
+    g = torch.Generator().manual_seed(2)
+    B, L, D = 5000, 16, 2
+    f = torch.randn(B, L, generator=g).to(DEV)
+    Tf = (100.0 * torch.randn(B, L, generator=g)).to(DEV)
+    x = (10.0 * torch.randn(B, D, generator=g)).to(DEV)
+    x[17] = 0.0  # a row at the origin: its Tphi is zeroed (methods/spectrum.py:73)
+    c64 = torch.zeros(L, L, dtype=torch.float64, device=DEV)
+    q64 = torch.zeros_like(c64)
+    c32 = torch.zeros(L, L, device=DEV)
+    q32 = torch.zeros_like(c32)
+    for i in range(0, B, 1700):
+        H.spectrum_accumulate(f[i:i + 1700].contiguous(), Tf[i:i + 1700].contiguous(), x[i:i + 1700].contiguous(), 16.0, True, 50.0, c64, q64)
+        H.spectrum_accumulate(f[i:i + 1700].contiguous(), Tf[i:i + 1700].contiguous(), x[i:i + 1700].contiguous(), 16.0, True, 50.0, c32, q32)
+    xd = x.double().cpu()
+    sp = torch.exp(-(xd ** 2).sum(1) / (4 * 16.0 ** 2)) / math.sqrt(2 * math.pi * 16.0 ** 2)  # sqrt of the D = 2 Gaussian pdf
+    w = (sp * math.sqrt(100.0 ** 2)).unsqueeze(1)   # / sqrt(p_val), p_val = 1 / (2 lim)^D
+    ph, tp = w * f.double().cpu(), w * Tf.double().cpu()
+    tp[17] = 0.0
+    assert rel(c64, ph.T @ ph) < 1e-6 and rel(q64, ph.T @ tp) < 1e-6  # (the weights are float32: 1e-7 each)
+    assert rel(c32, ph.T @ ph) < 1e-5 and rel(q32, ph.T @ tp) < 1e-4
+    with pytest.raises(H.NsvdError):
+        H.spectrum_accumulate(f, Tf, x, 16.0, True, 50.0, c64, q32)
 
 
 # ------------------------------------------------------------------------------ full-size properties (cfg2)

@@ -1,10 +1,11 @@
 """Eigenvalue parity at the configs[1] MODEL SIZE (BASELINE.json's "(2a)": same weights, same grid): the HIP float32
 path against the float64 oracle, with the float32 oracle - the reference's own arithmetic - as the yardstick.
 
-  * laplacian_eps = 0.01 (the scripts' setting): a float32 central difference at eps = 0.01 carries a per-point error
-    of about |f|, so float32 eigenvalues are percent-level noisy on a 10^4-point grid WHATEVER
-    computes them. The bar: the HIP path is no further from float64 than 1.5 x what the float32 oracle is (mean over
-    the 16 eigenvalues) and 2.5 x on the worst eigenvalue.
+  * laplacian_eps = 0.01 (the scripts' setting): a float32 central difference at eps = 0.01 taken point-wise - the
+    reference's arithmetic, the float32 oracle here - carries a per-point error of about |f| and
+    its eigenvalues are percent-level noisy. The fused kernels carry the stencil in even / odd form and
+    are held to north_star's 1e-4 against the FLOAT64 stencil on every eigenvalue (measured 3e-6 worst on the 62 500-point
+    grid of scripts/parity_spectrum_cfg2.py), with the float32 oracle's own distance printed beside it.
   * laplacian_eps = 0 (exact Laplacian, reference diff_ops.py:54-61): nothing is differenced; the bar is 1e-5 relative
     on every eigenvalue (north_star asks for 1e-4).
 
@@ -48,7 +49,7 @@ def _rel(e, e64):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("path", ["auto", "bf16x3"])
-def test_eigenvalue_parity_stencil_against_float32_yardstick(path):
+def test_eigenvalue_parity_stencil_1e4_of_float64(path):
     from neural_svd_amd import hip_ops as H
     tr, p64, prob_o, grid = _setup(0.01)
     e64 = np.asarray(O.spectrum_evd(grid, p64, prob_o, 50.0)["eigvals"], dtype=np.float64)
@@ -57,11 +58,6 @@ def test_eigenvalue_parity_stencil_against_float32_yardstick(path):
     got = tr.spectrum(50.0, 1.0, use_ema=True)["eigvals"].numpy()
     r_hip, r_ref = _rel(got, e64), _rel(e32, e64)
     assert np.all(np.isfinite(got))
-    assert r_hip.mean() <= 1.5 * r_ref.mean() + 1e-4, (r_hip.mean(), r_ref.mean())
-    assert r_hip.max() <= 2.5 * r_ref.max() + 1e-4, (r_hip.max(), r_ref.max())
-    # the same statement as NUMBERS (north_star asks for 1e-4; in the scripts' default mode, eps = 0.01 in float32,
-    # neither this path nor the reference's own float32 arithmetic reaches it - the exact-Laplacian test below does):
-    # default mode, this grid: HIP float32 within 2e-2 of float64 on average, the float32 oracle likewise.
     # Measured values go to gpurun_out/ (bench.py quotes the 62 500-point run of scripts/parity_spectrum_cfg2.py).
     import json
     import os
@@ -71,7 +67,10 @@ def test_eigenvalue_parity_stencil_against_float32_yardstick(path):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(rec, open(os.path.join(out, f"parity_test_stencil_{path}.json"), "w"), indent=1)
-    assert r_hip.mean() < 2e-2 and r_hip.max() < 1e-1, rec
+    # north_star's tolerance, every eigenvalue, in the scripts' default mode (the reference's own float32 arithmetic is
+    # two to three orders of magnitude further from float64: rec)
+    assert r_hip.max() < 1e-4, rec
+    assert r_hip.max() < r_ref.max(), rec
 
 
 @pytest.mark.timeout(900)
