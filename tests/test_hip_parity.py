@@ -278,6 +278,11 @@ def test_operator_headline_shapes(case, path):
             ref_err = rel(z[pre32 + "gradsample_" + n], gs64)
             assert rel(got, gs64) < max(4 * ref_err, 4 * pooled, 2e-3), (n, rel(got, gs64), ref_err)
     assert (got_num / den) ** 0.5 < max(4 * pooled, 2e-3), ((got_num / den) ** 0.5, pooled)
+    if path != "generic":
+        # end to end in the scripts' default mode: with Tf at 1e-6 of the float64 stencil, d loss / d f and every sampled
+        # gradient element follow - the pooled error against the FLOAT64 reference is at north_star's 1e-4 (the
+        # float32 reference's own pooled error on these cases: `pooled`, 1e-3 .. 1e-2)
+        assert (got_num / den) ** 0.5 < 1e-4, ((got_num / den) ** 0.5, pooled)
 
 
 @pytest.mark.parametrize("path", PATHS)
