@@ -34,6 +34,32 @@ __global__ void __launch_bounds__(256) fourier_kernel(const float* __restrict__ 
     phiT[(size_t)(m + j) * ldr + r] = c;
 }
 
+// the same with the shifted rows in EVEN / ODD form: row block 1 + 2 d holds phi's even perturbation
+// along direction d, [s (cos t - 1), c (cos t - 1)] with t = eps B_dj, block 2 + 2 d the odd one, [c sin t, -s sin t]:
+// phi(x +- eps e_d) = phi + even +- odd exactly (angle addition), products in double
+__global__ void __launch_bounds__(256) fourier_evenodd_kernel(const float* __restrict__ x, const float* __restrict__ fB,
+                                                              float* __restrict__ phiT, int B, int D, int m, float eps,
+                                                              int ldr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (b >= B) return;
+    double proj = 0.0;
+    for (int d = 0; d < D; ++d) proj = fma((double)x[(size_t)b * D + d], (double)fB[(size_t)d * m + j], proj);
+    float s, c;
+    sincos_d2f(proj, &s, &c);
+    phiT[(size_t)j * ldr + b] = s;
+    phiT[(size_t)(m + j) * ldr + b] = c;
+    for (int d = 0; d < D; ++d) {
+        const double t = (double)eps * (double)fB[(size_t)d * m + j];
+        const double sh = sin(0.5 * t), cm = -2.0 * sh * sh, sd = sin(t);
+        const size_t re = (size_t)(1 + 2 * d) * B + b, ro = (size_t)(2 + 2 * d) * B + b;
+        phiT[(size_t)j * ldr + re] = (float)((double)s * cm);
+        phiT[(size_t)(m + j) * ldr + re] = (float)((double)c * cm);
+        phiT[(size_t)j * ldr + ro] = (float)((double)c * sd);
+        phiT[(size_t)(m + j) * ldr + ro] = (float)(-(double)s * sd);
+    }
+}
+
 constexpr int FT = 1024;
 template <int D>
 __global__ void __launch_bounds__(FT) fourier_stencil_kernel(nsvd_feat::StencilArgs a) {
@@ -52,6 +78,15 @@ extern "C" int nsvd_fourier_features(const float* x, const float* fourier_B, flo
     dim3 grid(nsvd_cdiv(R, 256), m);
     hipLaunchKernelGGL(fourier_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, fourier_B, phiT, B, D, m, eps,
                        nstencil, ldr);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+int nsvd_fourier_features_evenodd(const float* x, const float* fourier_B, float* phiT, int B, int D, int m, float eps,
+                                  int ldr, hipStream_t s) {
+    if (!x || !fourier_B || !phiT || B <= 0 || D <= 0 || m <= 0 || ldr < (1 + 2 * D) * B) return NSVD_EINVAL;
+    hipLaunchKernelGGL(fourier_evenodd_kernel, dim3(nsvd_cdiv(B, 256), m), dim3(256), 0, s, x, fourier_B, phiT, B, D, m,
+                       eps, ldr);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

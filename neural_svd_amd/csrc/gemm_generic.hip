@@ -41,7 +41,20 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(NsvdGemm g) {
             float v = 0.f;
             if (gn < g.N && gk < g.K) {
                 v = Bm[(size_t)gk * g.sBk + (size_t)gn * g.sBn];
-                if (g.softplus_b) v = nsvd_softplus(v);
+                if (g.softplus_b) {
+                    if (g.eo_cols > 0 && gn >= g.eo_cols) {
+                        const int e = gn / g.eo_cols, bcol = gn - e * g.eo_cols, dd = (e - 1) >> 1;
+                        const float* zr = Bm + (size_t)gk * g.sBk;
+                        const float z0 = zr[(size_t)bcol * g.sBn];
+                        const float zE = zr[(size_t)((1 + 2 * dd) * g.eo_cols + bcol) * g.sBn];
+                        const float zO = zr[(size_t)((2 + 2 * dd) * g.eo_cols + bcol) * g.sBn];
+                        float ev, od;
+                        nsvd_softplus_evenodd(z0, zE, zO, &ev, &od);
+                        v = ((e - 1) & 1) ? od : ev;
+                    } else {
+                        v = nsvd_softplus(v);
+                    }
+                }
             }
             Bs[kk][nn] = v;
         }
@@ -70,7 +83,7 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(NsvdGemm g) {
         for (int j = 0; j < 4; ++j) {
             const int gn = n0 + tx * 4 + j;
             if (gn >= g.N) continue;
-            float v = acc[i][j] + bi;
+            float v = acc[i][j] + ((g.eo_cols > 0 && gn >= g.eo_cols) ? 0.f : bi);
             if (g.sigmoid_mul) v *= nsvd_sigmoid(Z[(size_t)gm * g.sZm + gn]);
             C[(size_t)gm * g.sCm + gn] = v;
         }

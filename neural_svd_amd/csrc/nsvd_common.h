@@ -44,6 +44,33 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
     return z > NSVD_SOFTPLUS_THRESHOLD ? 1.0f : s;
 }
 
+// softplus on a stencil pair in EVEN / ODD form: z(x +- eps e_d) = z0 + zE +- zO with zO = O(delta),
+// zE = O(delta^2); returns the even and odd parts of softplus(z0 + zE +- zO) - softplus(z0) by the Taylor expansion
+// around z0 to sixth order in delta (s = sigmoid z0, p = s (1 - s), w = zO^2):
+//   even' = s zE + c2 (zE^2 + w) + c3 zE (zE^2 + 3 w) + c4 w (w + 6 zE^2) + 5 c5 zE w^2 + c6 w^3   + O(delta^8)
+//   odd'  = zO [s + 2 c2 zE + c3 (3 zE^2 + w) + 4 c4 zE w + c5 w^2]                                 + O(delta^7)
+// (the fused forward kernels carry the same expansion inline, sharing the coefficients between the directions)
+__device__ __forceinline__ void nsvd_softplus_evenodd(float z0, float zE, float zO, float* even, float* odd) {
+    const float s1 = nsvd_sigmoid(z0);
+    const float sq = z0 > NSVD_SOFTPLUS_THRESHOLD ? 0.f : s1 * (1.f - s1);
+    const float t12 = fmaf(-2.f, s1, 1.f);
+    const float c2 = 0.5f * sq;
+    const float c3 = sq * t12 * (1.f / 6.f);
+    const float c4 = sq * fmaf(-6.f, sq, 1.f) * (1.f / 24.f);
+    const float c5 = sq * t12 * fmaf(-12.f, sq, 1.f) * (1.f / 120.f);
+    const float c6 = sq * fmaf(sq, fmaf(120.f, sq, -30.f), 1.f) * (1.f / 720.f);
+    const float w = zO * zO, e2 = zE * zE;
+    float ev = fmaf(c6, w, 5.f * c5 * zE);
+    ev = fmaf(ev, w, c4 * fmaf(6.f, e2, w));
+    ev = fmaf(ev, w, c3 * zE * fmaf(3.f, w, e2));
+    ev = fmaf(c2, e2 + w, ev);
+    float od = fmaf(c5, w, 4.f * c4 * zE);
+    od = fmaf(od, w, c3 * fmaf(3.f, e2, w));
+    od = fmaf(2.f * c2, zE, od) + s1;
+    *even = fmaf(s1, zE, ev);
+    *odd = zO * od;
+}
+
 // The same derivative from the ACTIVATION a = softplus(z) >= 0 (what the fused forward saves for the backward, so
 // that no kernel of the backward recomputes a softplus): sigmoid(z) = 1 - e^{-a}. Below a = 1/16 the series of
 // -expm1(-a) to a^4 (no cancellation; truncation a^4/120 < 1.3e-7 relative), above it 1 - exp directly (the result

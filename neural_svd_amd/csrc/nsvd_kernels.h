@@ -12,6 +12,9 @@ void nsvd_prof_end(hipStream_t s);
 // sampler != null: the coordinates are drawn inside the kernel (N(0, sigma^2), counter-based) and stored to xout.
 int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, float* sctab, int B, int D,
                          int m, float eps, const NsvdSampler* sampler, float* xout, hipStream_t s);
+// generic path, stencil mode: feature-major phiT (2 m, ldr) with the 2 D shifted row blocks in even / odd form
+int nsvd_fourier_features_evenodd(const float* x, const float* fourier_B, float* phiT, int B, int D, int m, float eps,
+                                  int ldr, hipStream_t s);
 // centre features only, any input dimension D (plain model evaluation): phi (B, 2m), phiTc (2m, B) or null
 int nsvd_fourier_plain(const float* x, const float* fourier_B, float* phi, float* phiTc, int B, int D, int m,
                        hipStream_t s);
@@ -34,6 +37,11 @@ struct NsvdGemm {
     long sZm = 0, bZ = 0;
     int softplus_b = 0;
     int sigmoid_mul = 0;
+    // stencil columns in even / odd form (eo_cols = samples per stencil block, 0: off): column j belongs to block
+    // e = j / eo_cols (0 the centre, 1 + 2 d / 2 + 2 d the even / odd perturbation along d). The bias joins the centre
+    // block only; with softplus_b the B element of a perturbation column is the even / odd part of the softplus of the
+    // pair (nsvd_softplus_evenodd on the centre, even and odd pre-activations of the same sample: three loads)
+    int eo_cols = 0;
 };
 int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s);
 

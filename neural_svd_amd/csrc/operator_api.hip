@@ -98,7 +98,12 @@ int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, 
                 const GenericWs& w, hipStream_t s, bool features_ready = false) {
     const int R = w.R, F = 2 * d.m;
     int rc = 0;
-    if (!features_ready) rc = nsvd_fourier_features(x, p.fourier_B, w.phiT, B, d.D, d.m, eps, nst, R, s);
+    // all stencil rows: the shifted row blocks in EVEN / ODD form - features, pre-activations and head
+    // outputs of block 1 + 2 d / 2 + 2 d are the even / odd perturbations along d; centre rows only (nst = 1): plain
+    const bool eo = nst > 1;
+    if (!features_ready)
+        rc = eo ? nsvd_fourier_features_evenodd(x, p.fourier_B, w.phiT, B, d.D, d.m, eps, R, s)
+                : nsvd_fourier_features(x, p.fourier_B, w.phiT, B, d.D, d.m, eps, nst, R, s);
     if (rc) return rc;
     int kin = F;
     for (int i = 0; i < d.nlayers; ++i) {
@@ -110,6 +115,7 @@ int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, 
         g.C = w.z[i]; g.sCm = R; g.bC = (long)d.dims[i] * R;
         g.bias = p.b[i]; g.bBias = d.dims[i];
         g.softplus_b = (i > 0);
+        g.eo_cols = eo ? B : 0;
         if (i == 0 && nst > 1) nsvd_prof_begin(s);
         rc = nsvd_gemm_generic(g, s);
         if (i == 0 && nst > 1) nsvd_prof_end(s);
@@ -126,7 +132,7 @@ int generic_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_p
     int rc = generic_mlp(d, p, x, B, prob.eps, E, w, s, features_ready);
     if (rc) return rc;
     return nsvd_fd_epilogue(w.z[d.nlayers - 1], R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
-                            w.jac, w.dsc, s);
+                            w.jac, w.dsc, s, 1);
 }
 
 int generic_backward(const nsvd_model_desc& d, const nsvd_params& p, const float* x, int B, const float* df,
@@ -236,7 +242,8 @@ extern "C" int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_pa
     if (!(prob->eps > 0.f)) return NSVD_EUNSUPPORTED;
     const GenericWs w = carve(*desc, B, ws);
     const int E = 1 + 2 * desc->D;
-    return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
+    return nsvd_fourier_features_evenodd(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E * B,
+                                         (hipStream_t)stream);
 }
 
 namespace {
@@ -263,7 +270,8 @@ int sample_features_impl(const nsvd_model_desc* desc, const nsvd_params* params,
     if (rc) return rc;
     const GenericWs w = carve(*desc, B, ws);
     const int E = 1 + 2 * desc->D;
-    return nsvd_fourier_features(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E, E * B, stream);
+    return nsvd_fourier_features_evenodd(x, params->fourier_B, w.phiT, B, desc->D, desc->m, prob->eps, E * B,
+                                         (hipStream_t)stream);
 }
 }  // namespace
 

@@ -154,7 +154,6 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // with the same float32 expressions the feature kernel used to evaluate: phi(x +- eps e_d) is never stored.
     // (5x less feature traffic per tile; the feature kernel writes B x F instead of E x B x F.)
     constexpr int DD = PL ? 0 : (JET ? E - 2 : (E - 1) / 2);  // input dimensions
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     float4 ra0, ra1, ra2, ra3, rs, rc, cd0, sd0, cd1, sd1, cd2, sd2;
     ra0 = ra1 = ra2 = ra3 = rs = rc = cd0 = sd0 = cd1 = sd1 = cd2 = sd2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int s_row = tid >> 3, s_c4 = tid & 7;  // 32 rows x 8 float4 per slab
@@ -199,18 +198,9 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         }                                                                        \
     }
 #define NSVD_STS(p, v) (*reinterpret_cast<float4*>(p) = (v))
-// u cd + v sd and u cd - v sd, componentwise, as fmaf(u, cd, +-(v * sd)) (the feature kernel's expressions), written
-// on vector types: outside MFMA shadows hipcc emits v_pk_mul_f32 / v_pk_fma_f32 for them, inside it unpacks them again
-// (packed fp32 cannot co-issue with an MFMA on this part). Measured upper bound for this arithmetic: with it removed
-// altogether the cfg2 kernel runs 176.0 us instead of 178.9 - the loop's overhead over its MFMA issue is barrier skew
-// and LDS traffic, not the vector ALU.
-#define NSVD_PM(plus, minus, u, v, cd, sd)                                                         \
-    {                                                                                              \
-        const f32x4 u_ = __builtin_bit_cast(f32x4, u), c_ = __builtin_bit_cast(f32x4, cd);         \
-        const f32x4 t_ = __builtin_bit_cast(f32x4, v) * __builtin_bit_cast(f32x4, sd);             \
-        plus = __builtin_bit_cast(float4, __builtin_elementwise_fma(u_, c_, t_));                  \
-        minus = __builtin_bit_cast(float4, __builtin_elementwise_fma(u_, c_, -t_));                \
-    }
+// (rounds 1-3 generated the shifted rows by angle addition here, u cd +- v sd; measured upper bound for that arithmetic:
+// with it removed altogether the cfg2 kernel ran 176.0 us instead of 178.9 - the loop's overhead over its MFMA issue
+// is barrier skew and LDS traffic, not the vector ALU. The even / odd rows of round 4 are two multiplies per row.)
 // jet rows of a chunk: value u, derivative streams w * b_d (w = the partner feature, sign folded in), Laplacian -q u
 #define NSVD_MUL4(o, u, k) o = make_float4(u.x * k.x, u.y * k.y, u.z * k.z, u.w * k.w)
 #define NSVD_NMUL4(o, u, k) o = make_float4(-(u.x * k.x), -(u.y * k.y), -(u.z * k.z), -(u.w * k.w))
@@ -647,8 +637,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // ------------------------------------------------------------------ FD Hamiltonian epilogue
     // one thread per (stencil point, sample): output of the 128 -> 1 layer, then g_e = sqrt p(x_e) c base_e mask(x_e)
     // (the exp / sqrt heavy part, E x 32 threads wide instead of a 5-point loop on 32 threads)
-    float* gs = outs;         // [NC]   g_e
-    float* cen = red;         // [4][BS] centre: sqrt p, mask, |x|, base   (red is dead once read below)
+    float* gs = outs;         // [NC]   head outputs (stencil mode: centre, even / odd perturbations; jets: the streams)
     if (PL) {
         // model(x) = c * base * exp(-|x| / scales_l)   (reference pde/__init__.py:15-16), any input dimension
         if (tid < NC) {

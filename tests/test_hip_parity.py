@@ -216,7 +216,8 @@ def test_operator_forward_backward_small(case, path):
     pre64, pre32 = f"{case}_f64_step0_", f"{case}_f32_step0_"
     assert rel(r["f"], z[pre64 + "f"]) < 2e-5
     check_tf(r["Tf"], z, case, cfg)
-    # gradients given the SAME df (isolates the backward kernels from the FD noise in Tf)
+    assert rel(r["Tf"], z[pre64 + "Tf"]) < 1e-4, rel(r["Tf"], z[pre64 + "Tf"])  # even / odd stencil form: every path
+    # gradients given the SAME df (isolates the backward kernels)
     names = G.trainable_names(z, case)
     for n, g, gr in zip(names, r["grads"], ref["grads"]):
         assert torch.isfinite(g).all(), n
@@ -224,14 +225,15 @@ def test_operator_forward_backward_small(case, path):
     # loss given the path's own (f, Tf): tight
     l_given, *_ = O.evd_loss_forward(r["f"].double().cpu(), r["Tf"].double().cpu(), v.double(), M.double())
     assert abs(float(r["loss"][0]) - float(l_given)) < 1e-5 * abs(float(l_given))
-    # end to end (df from the HIP loss kernels, Tf noise included): sanity band only - tiny batches do
-    # not average the FD noise, the tight checks are the isolated ones above
+    # end to end (df from the HIP loss kernels): rounds 1-3 could only band this (a point-wise float32 stencil does not
+    # average its noise over 24-32 rows: the float32 reference's own gradients are ref_err = 1e-2 .. 1e-1 away); with the
+    # stencil in even / odd form it is north_star's 1e-4 against the reference's float64 loss and gradients
     r2 = run_hip(p, prob, x, v, M, _path(path))
-    assert abs(float(r2["loss"][0]) - float(z[pre64 + "loss"])) <= 0.1 * abs(float(z[pre64 + "loss"]))
+    assert abs(float(r2["loss"][0]) - float(z[pre64 + "loss"])) <= 1e-4 * abs(float(z[pre64 + "loss"]))
     for n, g in zip(names, r2["grads"]):
         g64 = z[pre64 + "grad_" + n]
-        ref_err = rel(z[pre32 + "grad_" + n], g64)
-        assert rel(g.view(-1), g64.reshape(-1)) < max(5 * ref_err, 5e-2), (n, ref_err)
+        assert rel(g.view(-1), g64.reshape(-1)) < 1e-4, (n, rel(g.view(-1), g64.reshape(-1)),
+                                                         rel(z[pre32 + "grad_" + n], g64))
 
 
 @pytest.mark.parametrize("path", PATHS + ["bf16x3"])
@@ -250,13 +252,11 @@ def test_operator_headline_shapes(case, path):
     check_tf(r["Tf"], z, case, cfg)
     l_given, *_ = O.evd_loss_forward(r["f"].double().cpu(), r["Tf"].double().cpu(), v.double(), M.double())
     assert abs(float(r["loss"][0]) - float(l_given)) < 1e-5 * abs(float(l_given))
-    if path != "generic":
-        # the fused kernels carry the stencil in even / odd form: Tf - and with it the loss - agrees with
-        # the FLOAT64 stencil to north_star's 1e-4, where the reference's own float32 arithmetic (and the generic path,
-        # which follows it operation by operation) is a few per cent away
-        assert r["path"].startswith("fused_mfma"), r["path"]
-        assert rel(r["Tf"], z[pre64 + "Tf"]) < 1e-4, rel(r["Tf"], z[pre64 + "Tf"])
-        assert abs(float(r["loss"][0]) - float(z[pre64 + "loss"])) < 1e-4 * abs(float(z[pre64 + "loss"]))
+    # every path carries the stencil in even / odd form: Tf - and with it the loss - agrees with the
+    # FLOAT64 stencil to north_star's 1e-4, where the reference's own float32 arithmetic is a few per cent away
+    assert r["path"] == ("generic" if path == "generic" else "fused_mfma"), r["path"]
+    assert rel(r["Tf"], z[pre64 + "Tf"]) < 1e-4, rel(r["Tf"], z[pre64 + "Tf"])
+    assert abs(float(r["loss"][0]) - float(z[pre64 + "loss"])) < 1e-4 * abs(float(z[pre64 + "loss"]))
     loss_ref_err = abs(float(z[pre32 + "loss"]) - float(z[pre64 + "loss"])) / abs(float(z[pre64 + "loss"]))
     assert abs(float(r["loss"][0]) - float(z[pre64 + "loss"])) <= max(4 * loss_ref_err, 2e-2) * abs(
         float(z[pre64 + "loss"]))
@@ -278,11 +278,10 @@ def test_operator_headline_shapes(case, path):
             ref_err = rel(z[pre32 + "gradsample_" + n], gs64)
             assert rel(got, gs64) < max(4 * ref_err, 4 * pooled, 2e-3), (n, rel(got, gs64), ref_err)
     assert (got_num / den) ** 0.5 < max(4 * pooled, 2e-3), ((got_num / den) ** 0.5, pooled)
-    if path != "generic":
-        # end to end in the scripts' default mode: with Tf at 1e-6 of the float64 stencil, d loss / d f and every sampled
-        # gradient element follow - the pooled error against the FLOAT64 reference is at north_star's 1e-4 (the
-        # float32 reference's own pooled error on these cases: `pooled`, 1e-3 .. 1e-2)
-        assert (got_num / den) ** 0.5 < 1e-4, ((got_num / den) ** 0.5, pooled)
+    # end to end in the scripts' default mode: with Tf at 1e-6 of the float64 stencil, d loss / d f and every sampled
+    # gradient element follow - the pooled error against the FLOAT64 reference is at north_star's 1e-4 (the float32
+    # reference's own pooled error on these cases: `pooled`, 1e-3 .. 1e-2)
+    assert (got_num / den) ** 0.5 < 1e-4, ((got_num / den) ** 0.5, pooled)
 
 
 @pytest.mark.parametrize("path", PATHS)
@@ -775,8 +774,8 @@ def test_spectrum_matches_reference(case):
 def test_ragged_evaluation_batch_goes_through_the_mfma_kernels(fpath):
     """An evaluation batch (no backward layout) of ANY size on a model the MFMA kernels take - the validation grids of
     the reference's scripts are not multiples of 32 rows - is padded onto them and the padding dropped: the rows are
-    bit for bit the rows of the padded call, and Tf is the even / odd stencil's (1e-4 of the float64 stencil), not the
-    point-wise float32 stencil of the generic kernels (a few per cent). Also a batch beyond 8192 rows (pieces)."""
+    bit for bit the rows of the padded call (and Tf within 1e-4 of the float64 stencil). Also a batch beyond 8192 rows
+    (pieces), and the generic kernels asked for by name."""
     L, D, m, hidden = 4, 2, 64, (128, 128, 128)
     p = O.init_params(L, D, m, hidden, 0.15, seed=3)
     prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
@@ -796,11 +795,11 @@ def test_ragged_evaluation_batch_goes_through_the_mfma_kernels(fpath):
         ref = O.operator_forward(x[rows.to(DEV)].double().cpu(), p.to(torch.float64), prob_o)
         assert rel(f[rows.to(DEV)], ref.f) < 2e-5
         assert rel(Tf[rows.to(DEV)], ref.Tf) < 1e-4, (B, rel(Tf[rows.to(DEV)], ref.Tf))
-    # the generic kernels, asked for by name, still take the ragged batch as it is (point-wise stencil)
+    # the generic kernels, asked for by name, take the ragged batch as it is (the same even / odd stencil, FMA GEMMs)
     x = (16.0 * torch.randn(100, D, generator=torch.Generator().manual_seed(1))).to(DEV)
     fg, Tfg = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, 100, DEV), False, H.PATH_GENERIC)
     f, Tf = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, 100, DEV), False, path)
-    assert rel(fg, f.double().cpu()) < 1e-5 and rel(Tfg, Tf.double().cpu()) < 0.3
+    assert rel(fg, f.double().cpu()) < 1e-5 and rel(Tfg, Tf.double().cpu()) < 1e-4
 
 
 def test_spectrum_accumulators_float64():
