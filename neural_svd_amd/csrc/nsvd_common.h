@@ -50,7 +50,14 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
 //   even' = s zE + c2 (zE^2 + w) + c3 zE (zE^2 + 3 w) + c4 w (w + 6 zE^2) + 5 c5 zE w^2 + c6 w^3   + O(delta^8)
 //   odd'  = zO [s + 2 c2 zE + c3 (3 zE^2 + w) + 4 c4 zE w + c5 w^2]                                 + O(delta^7)
 // (the fused forward kernels carry the same expansion inline, sharing the coefficients between the directions)
+#define NSVD_EO_TAYLOR_MAX 0.25f  // beyond it (truncation > ~1e-5): the plain differences, which are accurate there
 __device__ __forceinline__ void nsvd_softplus_evenodd(float z0, float zE, float zO, float* even, float* odd) {
+    if (fmaxf(fabsf(zO), fabsf(zE)) > NSVD_EO_TAYLOR_MAX) {
+        const float sp = nsvd_softplus((z0 + zE) + zO), sm = nsvd_softplus((z0 + zE) - zO), s0 = nsvd_softplus(z0);
+        *even = 0.5f * ((sp - s0) + (sm - s0));
+        *odd = 0.5f * (sp - sm);
+        return;
+    }
     const float s1 = nsvd_sigmoid(z0);
     const float sq = z0 > NSVD_SOFTPLUS_THRESHOLD ? 0.f : s1 * (1.f - s1);
     const float t12 = fmaf(-2.f, s1, 1.f);

@@ -802,6 +802,28 @@ def test_ragged_evaluation_batch_goes_through_the_mfma_kernels(fpath):
     assert rel(fg, f.double().cpu()) < 1e-5 and rel(Tfg, Tf.double().cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("path", ["generic", "auto", "bf16x3"])
+@pytest.mark.parametrize("eps,wscale", [(0.3, 1.0), (0.01, 30.0), (0.05, 4.0)])
+def test_wide_stencils_and_large_perturbations(eps, wscale, path):
+    """The even / odd form expands the softplus around the centre value - valid for small perturbations, which is what
+    eps = 0.01 gives; laplacian_eps is the caller's, though (and so are the weights): beyond |perturbation| = 0.25 the
+    kernels take the plain differences of softplus values, which are accurate THERE. Wide stencils and inflated first-
+    layer weights, every path, against the float64 stencil of the same eps."""
+    L, D, m, hidden = 4, 2, 64, (128, 128, 128)
+    p = O.init_params(L, D, m, hidden, 1.0, exp_mask_init=10.0, seed=11)
+    p.ws[0] = p.ws[0] * wscale
+    prob_o = O.Problem(potential=O.POT_HARMONIC, eps=eps, op_scale=1.0, op_shift=16.0, sigma=4.0)
+    shape, prob = shape_of(p), hip_problem(prob_o)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    B = 96
+    x = (4.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(12))).to(DEV)
+    f, Tf = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV), False, _path(path))
+    ref = O.operator_forward(x.double().cpu(), p.to(torch.float64), prob_o)
+    assert rel(f, ref.f) < 2e-5
+    assert rel(Tf, ref.Tf) < 1e-4, rel(Tf, ref.Tf)
+
+
 def test_spectrum_accumulators_float64():
     """nsvd_spectrum_accumulate_f64 (the evaluation paths' accumulators) against numpy float64 on the same float32
     inputs, and the float32 accumulators (the reference's) beside it."""
