@@ -139,6 +139,11 @@ int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_params* param
  * re-weighting, central-difference Laplacian, potential, scale/shift
  * (examples/__init__.py:7-9 -> schrodinger/__init__.py:16-22 -> diff_ops.py:9-52 ->
  *  pde/__init__.py:15-16 -> models/mlp.py:204-221).
+ * The stencil is the reference's - the same 1 + 2 D points, the same eps - but every path carries the shifted
+ * evaluations as EVEN / ODD perturbations of the centre one (z(x +- eps e_d) = z + zE_d +- zO_d through the Fourier map,
+ * every layer and the re-weighting), so the float32 result is the stencil's value to ~1e-6 instead of
+ * the few per cent a point-wise float32 difference at eps = 0.01 carries (the reference's own float32 Tf is 4e-2 from
+ * its float64 Tf: BASELINE.md). f is unaffected. Any eps > 0 (perturbations beyond 0.25 fall back to plain differences).
  * save_for_backward != 0 keeps the centre-row pre-activations in `ws` for nsvd_operator_backward. */
 int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_params* params,
                           const nsvd_problem* prob, const float* x, int B, float* f, float* Tf,
