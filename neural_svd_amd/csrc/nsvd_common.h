@@ -50,12 +50,29 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
 //   even' = s zE + c2 (zE^2 + w) + c3 zE (zE^2 + 3 w) + c4 w (w + 6 zE^2) + 5 c5 zE w^2 + c6 w^3   + O(delta^8)
 //   odd'  = zO [s + 2 c2 zE + c3 (3 zE^2 + w) + 4 c4 zE w + c5 w^2]                                 + O(delta^7)
 // (the fused forward kernels carry the same expansion inline, sharing the coefficients between the directions)
-#define NSVD_EO_TAYLOR_MAX 0.25f  // beyond it (truncation > ~1e-5): the plain differences, which are accurate there
+#define NSVD_EO_TAYLOR_MAX 0.25f  // beyond it (truncation > ~1e-5): nsvd_softplus_evenodd_large
+// softplus(z0 + d) - softplus(z0) = log1p(sigmoid(z0) expm1(d)): the difference itself to ~1e-7 RELATIVE whatever its
+// size (taking it from two softplus values costs their absolute rounding, 1e-7 x |z| - measured: 1e-4 on the ground
+// state's eigenvalue, whose cusp at the nucleus is where the large perturbations are).
+// (hardware exp2 / log2 with the rounding of 1 + u put back: a dozen instructions. Only pairs with a perturbation above
+// NSVD_EO_TAYLOR_MAX come here, so exp(d) - 1 is good to ~2e-7 of the pair's scale; the library's expm1f / log1pf inlined
+// into the fused forward's rare path cost the whole kernel 18 % of its speed, a series for small d 1.6 %)
+__device__ __forceinline__ float nsvd_softplus_diff(float s, float d) {
+    const float em = __builtin_amdgcn_exp2f(fminf(d, 80.f) * NSVD_LOG2E) - 1.f;  // (no overflow: e^80 is finite)
+    const float u = s * em;                                                     // > -1
+    const float w = 1.f + u;
+    return fmaf(__builtin_amdgcn_logf(w), NSVD_LN2, (u - (w - 1.f)) * __builtin_amdgcn_rcpf(w));  // log1p(u)
+}
+// the even / odd parts for a LARGE perturbation (the rare path of the kernels: wide stencils, very large weights)
+__device__ __forceinline__ void nsvd_softplus_evenodd_large(float z0, float zE, float zO, float* even, float* odd) {
+    const float s = nsvd_sigmoid(z0);
+    const float dp = nsvd_softplus_diff(s, zE + zO), dm = nsvd_softplus_diff(s, zE - zO);
+    *even = 0.5f * (dp + dm);
+    *odd = 0.5f * (dp - dm);
+}
 __device__ __forceinline__ void nsvd_softplus_evenodd(float z0, float zE, float zO, float* even, float* odd) {
     if (fmaxf(fabsf(zO), fabsf(zE)) > NSVD_EO_TAYLOR_MAX) {
-        const float sp = nsvd_softplus((z0 + zE) + zO), sm = nsvd_softplus((z0 + zE) - zO), s0 = nsvd_softplus(z0);
-        *even = 0.5f * ((sp - s0) + (sm - s0));
-        *odd = 0.5f * (sp - sm);
+        nsvd_softplus_evenodd_large(z0, zE, zO, even, odd);
         return;
     }
     const float s1 = nsvd_sigmoid(z0);

@@ -81,6 +81,9 @@ __device__ __forceinline__ void nsvd_glds16(const float* gsrc, float* lds_base) 
 //   the same code (one extra barrier after the K loop: the hidden layers' W tile DMA lands in the stage buffers).
 // PL = 1: plain model evaluation (nsvd_model_forward): the E column tiles of a workgroup are E consecutive 32-sample
 // tiles of the batch (no stencil, no jets), so that a head's weight tiles are fetched once per 32 E samples
+#ifdef NSVD_EO_COUNT
+__device__ unsigned long long g_eo_count[8];
+#endif
 template <int E, int JET, int BF3 = 0, int PL = 0>
 __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     static_assert(!PL || (!JET && !BF3 && E <= 4), "plain tiles: native fp32 layer 0, at most four sample tiles");
@@ -390,8 +393,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             // fourth-order form was 3e-4 from the float64 stencil). No transcendental for the shifted tiles.
             // The expansion wants small perturbations - what eps = 0.01 gives; laplacian_eps and the weights are the
             // caller's, though: a LANE (sample) with a perturbation beyond NSVD_EO_TAYLOR_MAX among the four accumulator
-            // registers of a group takes the plain differences of softplus values for that group instead, which are
-            // accurate there (they lose log2(1 / delta^2) bits). One v_max3 per pair of squares and one skipped branch
+            // registers of a group takes softplus(z0 + d) - softplus(z0) = log1p(s expm1(d)) for that group instead
+            // (nsvd_softplus_evenodd_large: the even part then loses log2(1 / delta) bits only). One v_max3 per pair of squares and one skipped branch
             // per group when no lane needs it (the scripts' settings: delta < 0.1, tails to ~0.3 at configs[2]); the
             // decision is the sample's own, so a sample still never sees its neighbours.
             constexpr int DDE = (E - 1) / 2;
@@ -435,14 +438,18 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                     s0v[jj] = nsvd_softplus(z0);
                 }
                 if (__builtin_expect(big > NSVD_EO_TAYLOR_MAX * NSVD_EO_TAYLOR_MAX, 0)) {
+#ifdef NSVD_EO_COUNT
+                    atomicAdd(&g_eo_count[i], 1ull);
+#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                         for (int d = 0; d < DDE; ++d) {
-                            const float zc = z0v[jj] + zEv[jj][d];
-                            const float sp = nsvd_softplus(zc + zOv[jj][d]), sm = nsvd_softplus(zc - zOv[jj][d]);
-                            evv[jj][d] = 0.5f * ((sp - s0v[jj]) + (sm - s0v[jj]));
-                            odv[jj][d] = 0.5f * (sp - sm);
+                            float evl, odl;
+                            nsvd_softplus_evenodd_large(z0v[jj], zEv[jj][d], zOv[jj][d], &evl, &odl);
+                            const bool lg = fmaxf(fabsf(zOv[jj][d]), fabsf(zEv[jj][d])) > NSVD_EO_TAYLOR_MAX;
+                            evv[jj][d] = lg ? evl : evv[jj][d];   // (a small pair of a flagged sample keeps its expansion)
+                            odv[jj][d] = lg ? odl : odv[jj][d];
                         }
                 }
 #pragma unroll
@@ -943,3 +950,13 @@ int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, con
     a.xcd_remap = pick_xcd_remap(d.L, B / BS, F);
     return launch_fwd<1, 0, 0, 1>(a, s);
 }
+
+#ifdef NSVD_EO_COUNT
+extern "C" void nsvd_debug_eo_count(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eo_count), 8 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_eo_count), z, sizeof(z));
+    }
+}
+#endif
