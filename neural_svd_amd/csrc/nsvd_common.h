@@ -57,16 +57,19 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
 // (hardware exp2 / log2 with the rounding of 1 + u put back: a dozen instructions. Only pairs with a perturbation above
 // NSVD_EO_TAYLOR_MAX come here, so exp(d) - 1 is good to ~2e-7 of the pair's scale; the library's expm1f / log1pf inlined
 // into the fused forward's rare path cost the whole kernel 18 % of its speed, a series for small d 1.6 %)
-__device__ __forceinline__ float nsvd_softplus_diff(float s, float d) {
-    const float em = __builtin_amdgcn_exp2f(fminf(d, 80.f) * NSVD_LOG2E) - 1.f;  // (no overflow: e^80 is finite)
-    const float u = s * em;                                                     // > -1
+__device__ __forceinline__ float nsvd_softplus_diff(float z0, float s, float d) {
+    const float dc = fminf(fmaxf(d, -16.f), 16.f);
+    const float em = __builtin_amdgcn_exp2f(dc * NSVD_LOG2E) - 1.f;
+    const float u = s * em;                                                     // >= -(1 - e^-16) > -1
     const float w = 1.f + u;
-    return fmaf(__builtin_amdgcn_logf(w), NSVD_LN2, (u - (w - 1.f)) * __builtin_amdgcn_rcpf(w));  // log1p(u)
+    const float v = fmaf(__builtin_amdgcn_logf(w), NSVD_LN2, (u - (w - 1.f)) * __builtin_amdgcn_rcpf(w));  // log1p(u)
+    // beyond |d| = 16 nothing cancels: the plain difference (a select, not a branch: this is the rare path already)
+    return fabsf(d) > 16.f ? nsvd_softplus(z0 + d) - nsvd_softplus(z0) : v;
 }
 // the even / odd parts for a LARGE perturbation (the rare path of the kernels: wide stencils, very large weights)
 __device__ __forceinline__ void nsvd_softplus_evenodd_large(float z0, float zE, float zO, float* even, float* odd) {
     const float s = nsvd_sigmoid(z0);
-    const float dp = nsvd_softplus_diff(s, zE + zO), dm = nsvd_softplus_diff(s, zE - zO);
+    const float dp = nsvd_softplus_diff(z0, s, zE + zO), dm = nsvd_softplus_diff(z0, s, zE - zO);
     *even = 0.5f * (dp + dm);
     *odd = 0.5f * (dp - dm);
 }

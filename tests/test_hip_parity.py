@@ -803,7 +803,7 @@ def test_ragged_evaluation_batch_goes_through_the_mfma_kernels(fpath):
 
 
 @pytest.mark.parametrize("path", ["generic", "auto", "bf16x3"])
-@pytest.mark.parametrize("eps,wscale", [(0.3, 1.0), (0.01, 30.0), (0.05, 4.0)])
+@pytest.mark.parametrize("eps,wscale", [(0.3, 1.0), (0.01, 30.0), (0.05, 4.0), (0.5, 20.0)])
 def test_wide_stencils_and_large_perturbations(eps, wscale, path):
     """The even / odd form expands the softplus around the centre value - valid for small perturbations, which is what
     eps = 0.01 gives; laplacian_eps is the caller's, though (and so are the weights): beyond |perturbation| = 0.25 the
