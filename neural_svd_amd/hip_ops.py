@@ -242,9 +242,9 @@ def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.
         # EVALUATION batches of any size on a model the MFMA kernels take (they want a multiple of 32 rows, at most
         # 8192 of them without a backward layout): in pieces of <= 8192 rows, the last one padded with copies of its
         # last row, and the padding dropped again - a row never sees its neighbours (bit-exact row equivariance is a
-        # test). The exact-Laplacian mode exists on that path only; in stencil mode it is the path that carries the
-        # stencil in even / odd form: a ragged validation batch must not fall back to the point-wise
-        # float32 stencil of the generic kernels, whose Tf is a few per cent from the float64 stencil.
+        # test). The exact-Laplacian mode exists on that path only; in stencil mode it keeps the reference's validation
+        # batches (not multiples of 32 rows) on the fast kernels (the generic ones compute the same even / odd stencil
+        # with FMA GEMMs, several times slower).
         fs, Tfs = [], []
         wsc = None
         for i in range(0, B, 8192):
