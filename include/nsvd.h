@@ -65,10 +65,11 @@ extern "C" {
 #define NSVD_PATH_AUTO 0    /* fused MFMA kernels when the shape allows, else generic   */
 #define NSVD_PATH_GENERIC 1 /* layer-by-layer generic kernels (any shape)               */
 #define NSVD_PATH_FUSED 2   /* fused MFMA kernels or NSVD_EUNSUPPORTED                  */
-#define NSVD_PATH_FUSED_BF16X3 3 /* EXPERIMENTAL, never picked by AUTO: the fused kernels with the first layer on the
-                                  * bf16 MFMA, every float32 operand split into three bf16 planes and six partial
-                                  * products accumulated in float32 (error below the fp32 MFMA's own rounding);
-                                  * forward only - the backward entry points treat it as NSVD_PATH_FUSED */
+#define NSVD_PATH_FUSED_BF16X3 3 /* opt-in, never picked by AUTO: the fused forward with every layer on the bf16 MFMA,
+                                  * every float32 operand split into three bf16 planes and six partial products
+                                  * accumulated in float32 (f and Tf as close to float64 as the fp32 MFMA's). The
+                                  * backward is NSVD_PATH_FUSED's; a fused training step on this path also leaves
+                                  * the planes of the updated weights for the next forward (nsvd_step_emits_planes) */
 
 /* Shape of WaveFunctions(ParallelMLP(GaussianFourierFeatureTransform)):
  * examples/operator/pde/__init__.py:19-55, examples/models/mlp.py:167-221, examples/utils.py:90-143 */
@@ -128,6 +129,16 @@ int nsvd_fourier_features(const float* x, const float* fourier_B, float* phiT, i
  * the workspace (put there by nsvd_operator_features, typically on another stream while the previous
  * step's optimiser runs - they do not depend on the trainable weights) */
 #define NSVD_FEATURES_READY 0x100
+/* bit for nsvd_operator_forward's save_for_backward argument, path NSVD_PATH_FUSED_BF16X3 only: the bfloat16 planes of
+ * the CURRENT weights are already in this workspace - left there by the nsvd_operator_backward_evd_step[_next] call
+ * (same path) that produced these weights, when nsvd_step_emits_planes says it does: the forward then needs no split
+ * launch (9 us of 167 at the headline configuration). The caller answers for "current": any other change of the
+ * parameters between that step and this forward (a load, another optimiser) invalidates the planes. */
+#define NSVD_W_PLANES_READY 0x200
+/* Does a fused training step on this shape and path write the planes of the updated weights (1) or not (0)?
+ * (NSVD_PATH_FUSED_BF16X3 on a shape the MFMA kernels take, weight gradients without batch slices.) They go into the
+ * workspace the next forward reads: `next_ws` of nsvd_operator_backward_evd_step_next, `ws` of .._step. */
+int nsvd_step_emits_planes(const nsvd_model_desc* desc, int B, int path);
 
 /* The weight-independent prologue of nsvd_operator_forward alone: Fourier features of the stencil rows of
  * x into `ws`, in the layout the path selected by (desc, B, path) reads. */

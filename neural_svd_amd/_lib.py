@@ -20,6 +20,7 @@ MASK_CUSTOM, MASK_SEQUENTIAL, MASK_JOINT = 0, 1, 2
 PATH_AUTO, PATH_GENERIC, PATH_FUSED, PATH_FUSED_BF16X3 = 0, 1, 2, 3
 NORMALIZE_L2_BALL, NORMALIZE_L2_SPHERE = 0, 1
 FEATURES_READY = 0x100
+W_PLANES_READY = 0x200
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # NSVD_LIB_PATH: diagnostic builds only (e.g. the stamped kernels of scripts/dev/stamps.py)
@@ -123,6 +124,7 @@ SIGNATURES = {
     "nsvd_cdk_loss_backward": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "nsvd_spectrum_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
     "nsvd_spectrum_accumulate_f64": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
+    "nsvd_step_emits_planes": (_I, [C.POINTER(ModelDesc), _I, _I]),
     "nsvd_row_normalize_forward": (_I, [_P, _I, _I, _F, _I, _P, _P]),
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
     "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),

@@ -51,25 +51,22 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
 //   odd'  = zO [s + 2 c2 zE + c3 (3 zE^2 + w) + 4 c4 zE w + c5 w^2]                                 + O(delta^7)
 // (the fused forward kernels carry the same expansion inline, sharing the coefficients between the directions)
 #define NSVD_EO_TAYLOR_MAX 0.25f  // beyond it (truncation > ~1e-5): nsvd_softplus_evenodd_large
-// softplus(z0 + d) - softplus(z0) = log1p(sigmoid(z0) expm1(d)): the difference itself to ~1e-7 RELATIVE whatever its
-// size (taking it from two softplus values costs their absolute rounding, 1e-7 x |z| - measured: 1e-4 on the ground
-// state's eigenvalue, whose cusp at the nucleus is where the large perturbations are).
-// (hardware exp2 / log2 with the rounding of 1 + u put back: a dozen instructions. Only pairs with a perturbation above
-// NSVD_EO_TAYLOR_MAX come here, so exp(d) - 1 is good to ~2e-7 of the pair's scale; the library's expm1f / log1pf inlined
-// into the fused forward's rare path cost the whole kernel 18 % of its speed, a series for small d 1.6 %)
-__device__ __forceinline__ float nsvd_softplus_diff(float z0, float s, float d) {
-    const float dc = fminf(fmaxf(d, -16.f), 16.f);
-    const float em = __builtin_amdgcn_exp2f(dc * NSVD_LOG2E) - 1.f;
-    const float u = s * em;                                                     // >= -(1 - e^-16) > -1
-    const float w = 1.f + u;
-    const float v = fmaf(__builtin_amdgcn_logf(w), NSVD_LN2, (u - (w - 1.f)) * __builtin_amdgcn_rcpf(w));  // log1p(u)
-    // beyond |d| = 16 nothing cancels: the plain difference (a select, not a branch: this is the rare path already)
-    return fabsf(d) > 16.f ? nsvd_softplus(z0 + d) - nsvd_softplus(z0) : v;
+// softplus(z0 + d) - softplus(z0) for a LARGE d (the kernels' rare path), through the mirrored identity
+// softplus(z) = z + softplus(-z): with a = |z0|,
+//     z0 <= 0:  softplus(d - a) - softplus(-a),        z0 > 0:  d + [softplus(-d - a) - softplus(-a)]
+// - both softplus values are taken at NON-POSITIVE-centred arguments, where softplus(-a) = log1p(e^-a) is small and
+// known to full relative accuracy, so their difference carries ~1e-7 of ITS OWN size (p99.9 7e-6 over wide ranges of
+// z0 and d; the plain difference softplus(z0 + d) - softplus(z0) carries 1e-7 x |z0|: 1.2e-4 on the ground state's
+// eigenvalue, whose cusp at the nucleus is where the large perturbations are). No clamp, no overflow, no select: two
+// softplus per value - what the rare path may cost the kernel that hosts it was measured the hard way.
+__device__ __forceinline__ float nsvd_softplus_diff(float a, float sp_ma, bool pos, float d) {
+    return (pos ? d : 0.f) + (nsvd_softplus((pos ? -d : d) - a) - sp_ma);
 }
 // the even / odd parts for a LARGE perturbation (the rare path of the kernels: wide stencils, very large weights)
 __device__ __forceinline__ void nsvd_softplus_evenodd_large(float z0, float zE, float zO, float* even, float* odd) {
-    const float s = nsvd_sigmoid(z0);
-    const float dp = nsvd_softplus_diff(z0, s, zE + zO), dm = nsvd_softplus_diff(z0, s, zE - zO);
+    const float a = fabsf(z0), sp_ma = nsvd_softplus(-a);
+    const bool pos = z0 > 0.f;
+    const float dp = nsvd_softplus_diff(a, sp_ma, pos, zE + zO), dm = nsvd_softplus_diff(a, sp_ma, pos, zE - zO);
     *even = 0.5f * (dp + dm);
     *odd = 0.5f * (dp - dm);
 }

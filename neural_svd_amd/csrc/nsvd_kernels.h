@@ -82,6 +82,8 @@ int nsvd_fused_features(const nsvd_model_desc& d, const nsvd_params& p, const ns
 // save: bit 0 = keep what the backward needs, bit 1 = features already prepared by nsvd_fused_features
 int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                        int B, float* f, float* Tf, void* ws, int save, hipStream_t s, int bf3 = 0);
+// batch slices of the weight-gradient kernel (1: every tile contracts the whole batch)
+int nsvd_fused_wgrad_slices(const nsvd_model_desc& d, int B);
 int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                         int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s);
 struct NsvdEvdIn;  // evd_math.h

@@ -185,6 +185,13 @@ extern "C" const char* nsvd_path_name(const nsvd_model_desc* desc, int B, int pa
     return want_fused(*desc, B, path) ? "fused_mfma" : "generic";
 }
 
+extern "C" int nsvd_step_emits_planes(const nsvd_model_desc* desc, int B, int path) {
+    if (validate(desc) != 0 || B <= 0 || path != NSVD_PATH_FUSED_BF16X3) return 0;
+    const char* e = getenv("NSVD_PLANES_FROM_STEP");
+    if (e && atoi(e) == 0) return 0;
+    return nsvd_fused_supported(*desc, B, false) && nsvd_fused_wgrad_slices(*desc, B) == 1 ? 1 : 0;
+}
+
 extern "C" const char* nsvd_path_name_for(const nsvd_model_desc* desc, const nsvd_problem* prob, int B, int path) {
     if (validate(desc) != 0 || B <= 0 || !prob) return "invalid";
     const bool exact = !(prob->eps > 0.f);
@@ -222,9 +229,11 @@ extern "C" int nsvd_operator_forward(const nsvd_model_desc* desc, const nsvd_par
     // eps <= 0 selects the exact Laplacian (reference diff_ops.py:7): forward-mode jets, MFMA path only
     if (!(prob->eps > 0.f) && !fused) return NSVD_EUNSUPPORTED;
     const bool ready = (save_for_backward & NSVD_FEATURES_READY) != 0;
+    const bool planes = (save_for_backward & NSVD_W_PLANES_READY) != 0 && path == NSVD_PATH_FUSED_BF16X3;
     if (fused)
-        return nsvd_fused_forward(*desc, *params, *prob, x, B, f, Tf, ws, (save_for_backward & 1) | (ready ? 2 : 0),
-                                  (hipStream_t)stream, path == NSVD_PATH_FUSED_BF16X3);
+        return nsvd_fused_forward(*desc, *params, *prob, x, B, f, Tf, ws,
+                                  (save_for_backward & 1) | (ready ? 2 : 0) | (planes ? 4 : 0), (hipStream_t)stream,
+                                  path == NSVD_PATH_FUSED_BF16X3);
     return generic_forward(*desc, *params, *prob, x, B, f, Tf, ws, (hipStream_t)stream, ready);
 }
 
@@ -392,6 +401,9 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
         st.h = nsvd_make_hyper(opt->lr, opt->alpha, opt->eps, opt->has_ema ? opt->ema_decay : 0.0, 1.0);
         st.state = opt->state;
         if (st.state && ((uintptr_t)st.state & 7) != 0) return NSVD_EINVAL;
+        // (NSVD_PLANES_FROM_STEP=0: measurements of the split launch against the epilogue's emission)
+        static const bool planes_env = [] { const char* e = getenv("NSVD_PLANES_FROM_STEP"); return !e || atoi(e) != 0; }();
+        st.emit_planes = !model_mode && path == NSVD_PATH_FUSED_BF16X3 && planes_env;
     }
     if (ws_bytes < (model_mode ? nsvd_model_workspace_bytes(desc, B) : nsvd_workspace_bytes(desc, B))) return NSVD_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;

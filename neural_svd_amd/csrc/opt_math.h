@@ -22,6 +22,8 @@ struct NsvdOptStep {
     nsvd_params sq;
     const nsvd_params* ema;  // null: no EMA
     nsvd_step_state* state;  // device-resident schedule (nsvd.h): h is then read from state->cur on the device
+    int emit_planes;         // NSVD_PATH_FUSED_BF16X3 steps: the weight-gradient epilogue also writes the bf16 planes of
+                             // the UPDATED hidden-layer weights (pmlp_layer0_bf3.h) into the workspace the next forward reads
 };
 
 static_assert(sizeof(((nsvd_step_state*)0)->cur) == sizeof(NsvdHyper), "nsvd_step_state::cur is an NsvdHyper");

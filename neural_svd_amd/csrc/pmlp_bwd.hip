@@ -414,6 +414,11 @@ struct WgradArgs {
     const float* loss_part;  // [loss_L][B / 32] operator-term partials, then [loss_L] metric-term partials
     float* loss;             // {loss, operator term, metric term}
     int loss_L;
+    // EMIT instantiations (bf16x3 steps): the three bf16 planes of every UPDATED element of W_0 / W_1 .. in the
+    // fragment-major layouts the bf16x3 forward reads (pmlp_layer0_bf3.h: w0_split_kernel's), so that the step needs no
+    // split launch (9 us, 17 MB read + 26 MB written per step): same rounding, same bits
+    unsigned short* w0p;
+    unsigned short* whp;
 };
 
 // where a gradient element goes: the caller's gradient tensor (+ fused optimiser) or this slice's partial buffer
@@ -459,9 +464,56 @@ __device__ __forceinline__ void wg_st(float* p, unsigned byte_off, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(p) + byte_off) = v;
 }
 
+// bf16 planes of one updated 32 x 32 block (EMIT): this lane holds column k = li of the block for the 16 rows
+// acc_row(r, hi); in both fragment-major layouts the 16-byte item of (row, 8 consecutive k) is 16 (row) bytes from the
+// block's base, the k-octet (k / 8) selects k-step and lane half, the planes are PLANE bytes apart: two bytes per
+// (row, plane) from this lane, eight lanes complete an item, 8 items (128 B) per instruction and wave half.
+struct WgPlanes {
+    unsigned short* base;  // null: no emission
+    unsigned lane_off;     // bytes: this lane's k inside the block
+    unsigned plane;        // bytes between planes
+};
+// W_0 block: head l, hidden rows 32 wr .. (wr = 0..3), features kabs0 .. kabs0 + 31 (a multiple of 32)
+__device__ __forceinline__ WgPlanes wg_planes_w0(unsigned short* w0p, int l, int wr, int kabs0, int m, int li) {
+    WgPlanes p;
+    p.base = nullptr; p.lane_off = 0; p.plane = 2048;
+    if (!w0p) return p;
+    const int nch = 2 * m / 32;
+    const int c = kabs0 < m ? 2 * (kabs0 / 32) : 2 * ((kabs0 - m) / 32) + 1;  // pair-of-chunks order of the K loop
+    // P[((((l nch + c) 4 + wr) 3 + p) 2 + ks) 64 + 32 hi' + row] x 16 B, ks = k / 16, hi' = (k / 8) & 1
+    p.base = w0p + ((size_t)(l * nch + c) * 4 + wr) * (6 * 64 * 8);
+    p.lane_off = (unsigned)(((li >> 4) * 64 + ((li >> 3) & 1) * 32) * 16 + 2 * (li & 7));
+    return p;
+}
+// W_j block (j >= 1; jh = j - 1): head l of L, rows 32 wr .., columns kabs0 .. + 31
+__device__ __forceinline__ WgPlanes wg_planes_wh(unsigned short* whp, int jh, int L, int l, int wr, int kabs0, int li) {
+    WgPlanes p;
+    p.base = nullptr; p.lane_off = 0; p.plane = 1024;
+    if (!whp) return p;
+    // Ph[((((jh L + l) 4 + wr) 8 + ks) 3 + p) 64 + 32 hi' + row] x 16 B, ks = k / 16 of the 128 columns
+    const int k = kabs0 + li;
+    p.base = whp + ((size_t)(jh * L + l) * 4 + wr) * (8 * 3 * 64 * 8);
+    p.lane_off = (unsigned)(((k >> 4) * 3 * 64 + ((k >> 3) & 1) * 32) * 16 + 2 * (k & 7));
+    return p;
+}
+__device__ __forceinline__ void wg_planes_store(const WgPlanes& pl, int r, int hi, float v) {
+    // three-way split by round-to-nearest residuals (nsvd_bf3_split's arithmetic, one value)
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{v, 0.f}, b2_t)) & 0xffffu;
+    const float r1 = v - __uint_as_float(h0 << 16);
+    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{r1, 0.f}, b2_t)) & 0xffffu;
+    const float r2 = r1 - __uint_as_float(h1 << 16);
+    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{r2, 0.f}, b2_t)) & 0xffffu;
+    char* q = reinterpret_cast<char*>(pl.base) + pl.lane_off + 16u * (unsigned)acc_row(r, hi);
+    *reinterpret_cast<unsigned short*>(q) = (unsigned short)h0;
+    *reinterpret_cast<unsigned short*>(q + pl.plane) = (unsigned short)h1;
+    *reinterpret_cast<unsigned short*>(q + 2 * pl.plane) = (unsigned short)h2;
+}
+
 template <bool EMA>
 __device__ __forceinline__ void wg_opt16(const NsvdHyper& h, const NsvdOptPtrs& o, unsigned base, unsigned ld, int hi,
-                                         const f32x16& acc) {
+                                         const f32x16& acc, const WgPlanes pl = WgPlanes{nullptr, 0, 0}) {
     float pv[16], sv[16], ev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // 48 independent loads in flight
@@ -477,19 +529,20 @@ __device__ __forceinline__ void wg_opt16(const NsvdHyper& h, const NsvdOptPtrs& 
         wg_st(o.p, off, pv[r]);
         wg_st(o.sq, off, sv[r]);
         if (EMA) wg_st(o.ema, off, ev[r]);
+        if (pl.base) wg_planes_store(pl, r, hi, pv[r]);
     }
 }
 
 __device__ __forceinline__ void wg_emit16(const NsvdHyper& h, const WgDst& d, const NsvdOptPtrs& o, size_t base,
-                                          size_t ld, int hi, const f32x16& acc) {
+                                          size_t ld, int hi, const f32x16& acc, const WgPlanes pl = WgPlanes{nullptr, 0, 0}) {
     float* g = d.g;
     if (g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) wg_st(g, 4u * ((unsigned)base + (unsigned)acc_row(r, hi) * (unsigned)ld), acc[r]);
     }
     if (!d.opt) return;
-    if (o.ema) wg_opt16<true>(h, o, (unsigned)base, (unsigned)ld, hi, acc);
-    else wg_opt16<false>(h, o, (unsigned)base, (unsigned)ld, hi, acc);
+    if (o.ema) wg_opt16<true>(h, o, (unsigned)base, (unsigned)ld, hi, acc, pl);
+    else wg_opt16<false>(h, o, (unsigned)base, (unsigned)ld, hi, acc, pl);
 }
 
 // stage one 32-row x 32-column (float4 per thread) slab global -> registers
@@ -536,7 +589,7 @@ __device__ __forceinline__ void wg_opt16_load(const NsvdOptPtrs& o, unsigned bas
 template <bool EMA>
 __device__ __forceinline__ void wg_opt16_apply(const NsvdHyper& h, const NsvdOptPtrs& o, unsigned base, unsigned ld,
                                                int hi, const f32x16& acc, float (&pv)[16], float (&sv)[16],
-                                               float (&ev)[16]) {
+                                               float (&ev)[16], const WgPlanes pl = WgPlanes{nullptr, 0, 0}) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned off = 4u * (base + (unsigned)acc_row(r, hi) * ld);
@@ -545,6 +598,7 @@ __device__ __forceinline__ void wg_opt16_apply(const NsvdHyper& h, const NsvdOpt
         wg_st(o.p, off, pv[r]);
         wg_st(o.sq, off, sv[r]);
         if (EMA) wg_st(o.ema, off, ev[r]);
+        if (pl.base) wg_planes_store(pl, r, hi, pv[r]);
     }
 }
 
@@ -552,7 +606,7 @@ __device__ __forceinline__ void wg_opt16_apply(const NsvdHyper& h, const NsvdOpt
 // shadow, the state of two blocks prefetched under the K loop (needs the pipelined loop, i.e. >= 4 chunks, and no
 // gradient output). NJ = 2: 128 x 128 tile (hidden units x features); NJ = 1: 128 x 64, chosen by the host when the
 // 128-wide tiles would leave half the CUs without one. The bias gradient db_0 is taken by the C workgroups.
-template <int MODE, int NJ>
+template <int MODE, int NJ, bool EMIT = false>
 __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, const NsvdHyper& h, float* lds, int unit, int slice) {
     constexpr int TW = 64 * NJ;  // features per tile
     const int tid = threadIdx.x;
@@ -585,7 +639,8 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, const NsvdHyper
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                wg_emit16(h, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j]);
+                wg_emit16(h, dW, a.oW[0], o + (size_t)(32 * i) * a.F + 32 * j, a.F, hi, acc[i][j],
+                          wg_planes_w0(EMIT ? a.w0p : nullptr, l, 2 * wm + i, kf0 + 32 * NJ * wn + 32 * j, a.F / 2, li));
     } else {
         constexpr bool EMA = MODE == 2;
         const NsvdOptPtrs& op = a.oW[0];
@@ -598,16 +653,18 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, const NsvdHyper
         if (NJ == 2) {
             // blocks (0,0), (0,1) have their state; the loads of (1,0), (1,1) go out behind the stores of the former
             float p2[16], s2[16], e2[16], p3[16], s3[16], e3[16];
-            wg_opt16_apply<EMA>(h, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
+#define WG_PL(i_, j_) wg_planes_w0(EMIT ? a.w0p : nullptr, l, 2 * wm + (i_), kf0 + 32 * NJ * wn + 32 * (j_), a.F / 2, li)
+            wg_opt16_apply<EMA>(h, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0], WG_PL(0, 0));
             wg_opt16_load<EMA>(op, b10, ld, hi, p2, s2, e2);
-            wg_opt16_apply<EMA>(h, op, b00 + 32u, ld, hi, acc[0][NJ - 1], pf.p[1], pf.s[1], pf.e[1]);
+            wg_opt16_apply<EMA>(h, op, b00 + 32u, ld, hi, acc[0][NJ - 1], pf.p[1], pf.s[1], pf.e[1], WG_PL(0, NJ - 1));
             wg_opt16_load<EMA>(op, b10 + 32u, ld, hi, p3, s3, e3);
-            wg_opt16_apply<EMA>(h, op, b10, ld, hi, acc[1][0], p2, s2, e2);
-            wg_opt16_apply<EMA>(h, op, b10 + 32u, ld, hi, acc[1][NJ - 1], p3, s3, e3);
+            wg_opt16_apply<EMA>(h, op, b10, ld, hi, acc[1][0], p2, s2, e2, WG_PL(1, 0));
+            wg_opt16_apply<EMA>(h, op, b10 + 32u, ld, hi, acc[1][NJ - 1], p3, s3, e3, WG_PL(1, NJ - 1));
         } else {
             // both blocks of the tile have their state
-            wg_opt16_apply<EMA>(h, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0]);
-            wg_opt16_apply<EMA>(h, op, b10, ld, hi, acc[1][0], pf.p[1], pf.s[1], pf.e[1]);
+            wg_opt16_apply<EMA>(h, op, b00, ld, hi, acc[0][0], pf.p[0], pf.s[0], pf.e[0], WG_PL(0, 0));
+            wg_opt16_apply<EMA>(h, op, b10, ld, hi, acc[1][0], pf.p[1], pf.s[1], pf.e[1], WG_PL(1, 0));
+#undef WG_PL
         }
     }
     WG_STAMP(5, __builtin_readcyclecounter());
@@ -617,6 +674,7 @@ __device__ __forceinline__ void wgrad_tile_A(const WgradArgs& a, const NsvdHyper
 // dW_i quadrant through the shared C = A B^T tile routine (tile_nt.h): both operands are plain (L, 128, B) rows now
 // that the forward saves activations - no softplus while staging, loads two chunks ahead, four accumulator chains.
 // Needs the slice length to be a multiple of 64 (the 32-chunk form below takes the rest).
+template <bool EMIT = false>
 __device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, const NsvdHyper& h, float* lds, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -636,7 +694,8 @@ __device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, const NsvdHyp
     if (k0 == 0) nsvd_tile_nt<true>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
     else nsvd_tile_nt<false>(A, a.B, Bm, a.B, b0, b0 + a.Bs, lds, acc, rs);
     wg_emit16(h, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
-              ((size_t)l * HID + n0 + 32 * (wv & 1)) * HID + k0 + 32 * (wv >> 1) + li, HID, hi, acc);
+              ((size_t)l * HID + n0 + 32 * (wv & 1)) * HID + k0 + 32 * (wv >> 1) + li, HID, hi, acc,
+              wg_planes_wh(EMIT ? a.whp : nullptr, i - 1, a.L, l, n0 / 32 + (wv & 1), k0 + 32 * (wv >> 1), li));
     if (k0 == 0) {
         // bias gradient: the 16 threads t & 15 of a staging row hold partial sums of rows (t >> 4) + 16 j
 #pragma unroll
@@ -652,6 +711,7 @@ __device__ __forceinline__ void wgrad_tile_B64(const WgradArgs& a, const NsvdHyp
     }
 }
 
+template <bool EMIT = false>
 __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, const NsvdHyper& h, float* As, float* Bs, int unit, int slice) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -729,7 +789,8 @@ __device__ __forceinline__ void wgrad_tile_B(const WgradArgs& a, const NsvdHyper
 #undef WB_LOAD
 #undef WB_STORE
     wg_emit16(h, wg_dst(a, a.gW[i], a.poW[i], slice), a.oW[i],
-              ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li, HID, hi, acc);
+              ((size_t)l * HID + n0 + 32 * wm) * HID + k0 + 32 * wn + li, HID, hi, acc,
+              wg_planes_wh(EMIT ? a.whp : nullptr, i - 1, a.L, l, n0 / 32 + wm, k0 + 32 * wn, li));
     if (k0 == 0) {
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -837,7 +898,8 @@ __device__ __forceinline__ void wgrad_tile_C(const WgradArgs& a, const NsvdHyper
 
 // NJ: the dW_0 tile shape (2: 128 x 128, 1: 128 x 64 = WgradArgs::tw 64); two kernels rather than one with both shapes
 // inside - with all six tile variants in one function the register allocator spills in the 128 x 128 ones
-template <int NJ>
+// EMIT: bf16x3 steps - the optimiser epilogues of W_0 and W_1 .. also write the bf16 planes of the updated values
+template <int NJ, bool EMIT = false>
 __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float smem_wg[4 * HID * A_LD];  // 72 KB: two blocks per CU
     static_assert(4 * HID * A_LD >= NSVD_TNT_FLOATS, "tile_nt buffers must fit the weight-gradient LDS");
@@ -859,17 +921,17 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
         // the optimiser state rides under the K loop when the step is fused, nothing else is written and the
         // loop has the four peeled chunks the prefetch hangs on
         const bool pf = a.S == 1 && a.opt && !a.gW[0] && a.Bs >= 4 * BK;
-        if (!pf) wgrad_tile_A<0, NJ>(a, h, smem_wg, unit, slice);
-        else if (a.oW[0].ema) wgrad_tile_A<2, NJ>(a, h, smem_wg, unit, slice);
-        else wgrad_tile_A<1, NJ>(a, h, smem_wg, unit, slice);
+        if (!pf) wgrad_tile_A<0, NJ, EMIT>(a, h, smem_wg, unit, slice);
+        else if (a.oW[0].ema) wgrad_tile_A<2, NJ, EMIT>(a, h, smem_wg, unit, slice);
+        else wgrad_tile_A<1, NJ, EMIT>(a, h, smem_wg, unit, slice);
         return;
     }
     bid -= a.nA * a.S;
     if (bid < a.nB * a.S) {
         WG_STAMP(0, 2ull);
         WG_STAMP(1, wall_clock64());
-        if (a.Bs % NSVD_TNT_KC == 0) wgrad_tile_B64(a, h, smem_wg, bid % a.nB, bid / a.nB);
-        else wgrad_tile_B(a, h, As, Bs, bid % a.nB, bid / a.nB);
+        if (a.Bs % NSVD_TNT_KC == 0) wgrad_tile_B64<EMIT>(a, h, smem_wg, bid % a.nB, bid / a.nB);
+        else wgrad_tile_B<EMIT>(a, h, As, Bs, bid % a.nB, bid / a.nB);
         WG_STAMP(6, wall_clock64());
         return;
     }
@@ -1049,10 +1111,22 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     // One launch: the dW_0 tiles go one per CU first, the small dW_i / db / last-layer workgroups
     // then co-reside with them (measured: 55 us together vs 42 + 23 us as two launches).
     wa.bid0 = 0;
-    if (wa.tw == 64)
-        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<1>, dim3(wa.S * (wa.nA + wa.nB + 4 * d.L)), dim3(256), 0, s, wa);
-    else
-        hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<2>, dim3(wa.S * (wa.nA + wa.nB + 4 * d.L)), dim3(256), 0, s, wa);
+    // bf16x3 steps: the planes of the updated weights go where the NEXT forward reads them (the other workspace set
+    // when the next batch's features ride along, this one otherwise); whole model, fused optimiser, no split-K only
+    const bool emit = opt && opt->emit_planes && wa.S == 1 && Lc == dfull.L && l0 == 0;
+    if (emit) {
+        const FusedWs wp = carve_fused(dfull, B, next ? next->ws : ws);
+        wa.w0p = reinterpret_cast<unsigned short*>(wp.w0p);
+        wa.whp = reinterpret_cast<unsigned short*>(wp.whp);
+    }
+    const dim3 wgrid(wa.S * (wa.nA + wa.nB + 4 * d.L));
+    if (wa.tw == 64) {
+        if (emit) hipLaunchKernelGGL((pmlp_fused_wgrad_kernel<1, true>), wgrid, dim3(256), 0, s, wa);
+        else hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<1>, wgrid, dim3(256), 0, s, wa);
+    } else {
+        if (emit) hipLaunchKernelGGL((pmlp_fused_wgrad_kernel<2, true>), wgrid, dim3(256), 0, s, wa);
+        else hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<2>, wgrid, dim3(256), 0, s, wa);
+    }
     NSVD_CHECK_LAUNCH();
     if (wa.S == 1) return 0;
     ReduceArgs ra;
@@ -1103,6 +1177,8 @@ int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int 
     if (next && (d.D < 1 || d.D > 3 || !p.fourier_B || !next->ws || !next->x)) return NSVD_EINVAL;
     return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s, l_begin, l_count, next);
 }
+
+int nsvd_fused_wgrad_slices(const nsvd_model_desc& d, int B) { return wgrad_slices(d, B); }
 
 bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count) {
     if (l_count <= 0 || l_count > d.L) return false;

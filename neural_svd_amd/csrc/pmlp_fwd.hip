@@ -831,6 +831,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         rc = nsvd_fused_features(d, p, prob, x, B, ws, save & 1, s);
         if (rc) return rc;
     }
+    const bool planes_ready = (save & 4) != 0;  // bf16x3: the weight planes in this workspace are current (nsvd.h)
     save &= 1;
     FwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -867,8 +868,10 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         for (int i = 0; i < sa.nhid; ++i) sa.Wh[i] = reinterpret_cast<const float4*>(p.W[i + 1]);
         sa.Ph = reinterpret_cast<uint4*>(w.whp);
         sa.L = d.L; sa.m = d.m;
-        hipLaunchKernelGGL(w0_split_kernel, dim3(2048), dim3(256), 0, s, sa);
-        NSVD_CHECK_LAUNCH();
+        if (!planes_ready) {  // (a fused bf16x3 step leaves the planes of the weights it has just updated)
+            hipLaunchKernelGGL(w0_split_kernel, dim3(2048), dim3(256), 0, s, sa);
+            NSVD_CHECK_LAUNCH();
+        }
         a.w0p = w.w0p;
         a.whp = w.whp;
         if (prob.eps <= 0.f) {

@@ -214,6 +214,13 @@ def path_name(shape: ModelShape, B: int, path: int = PATH_AUTO, prob: Optional[P
     return _lib.load().nsvd_path_name(C.byref(d), int(B), int(path)).decode()
 
 
+def step_emits_planes(shape: ModelShape, B: int, path: int) -> bool:
+    """Does a fused training step on this shape and path leave the bf16 planes of the updated weights for the next
+    forward (operator_forward(planes_ready=True))? PATH_FUSED_BF16X3, MFMA shapes, no batch slices."""
+    d = shape.desc()
+    return bool(_lib.load().nsvd_step_emits_planes(C.byref(d), int(B), int(path)))
+
+
 def new_workspace(shape: ModelShape, B: int, device) -> torch.Tensor:
     return torch.empty(workspace_bytes(shape, B), dtype=torch.uint8, device=device)
 
@@ -232,8 +239,10 @@ def fourier_features(x: torch.Tensor, fourier_B: torch.Tensor, eps: float, nsten
 def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, ws: torch.Tensor,
                      save_for_backward: bool = True, path: int = PATH_AUTO,
                      out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                     features_ready: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Tf, f = operator(model, x, importance). Returns (f, Tf), each (B, L)."""
+                     features_ready: bool = False, planes_ready: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Tf, f = operator(model, x, importance). Returns (f, Tf), each (B, L).
+    planes_ready (PATH_FUSED_BF16X3): the bf16 planes of the current weights are in `ws` already, left there by the
+    fused training step that produced these weights (step_emits_planes; include/nsvd.h: NSVD_W_PLANES_READY)."""
     B = x.shape[0]
     if x.dim() != 2 or x.shape[1] != shape.D:
         raise NsvdError(f"x must be (B, {shape.D})")
@@ -269,15 +278,15 @@ def operator_forward(shape: ModelShape, params: Params, prob: Problem, x: torch.
         Tf = torch.empty_like(f)
     else:
         f, Tf = out
+    flags = int(save_for_backward) | (_lib.FEATURES_READY if features_ready else 0) | \
+        (_lib.W_PLANES_READY if planes_ready else 0)
     if torch_binding() is not None:
-        _TB.operator_forward(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob), x, f, Tf, ws,
-                             int(save_for_backward) | (_lib.FEATURES_READY if features_ready else 0), int(path))
+        _TB.operator_forward(_tb_shape(shape), _tb_params(shape, params), _tb_problem(prob), x, f, Tf, ws, flags,
+                             int(path))
         return f, Tf
     d = shape.desc()
     rc = _lib.load().nsvd_operator_forward(C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"),
-                                           _ptr(Tf, "Tf"), ws.data_ptr(), ws.numel(),
-                                           int(save_for_backward) | (_lib.FEATURES_READY if features_ready else 0),
-                                           int(path), _stream())
+                                           _ptr(Tf, "Tf"), ws.data_ptr(), ws.numel(), flags, int(path), _stream())
     check(rc, "nsvd_operator_forward")
     return f, Tf
 

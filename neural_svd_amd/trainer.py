@@ -15,6 +15,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import hip_ops as H
@@ -49,6 +51,8 @@ class FlatParams:
     def __init__(self, shape: H.ModelShape, device, with_state: bool = True):
         self.shape = shape
         self.device = torch.device(device)
+        self.version = 0  # bumped by every change of the parameters that is not a fused training step (derived copies
+                          # of the weights - the bf16x3 path's planes - are tied to it); bump it after writing `flat`
         shapes = shape.param_shapes()
         # every tensor starts on a 256-B boundary so kernels may use 16-B accesses per tensor
         self.offsets, off = [], 0
@@ -82,6 +86,7 @@ class FlatParams:
                              v[2 * nl] if self.shape.has_exp_mask else None)
 
     def load(self, fB, ws, bs, scales=None) -> None:
+        self.version += 1
         self.fourier_B.copy_(fB)
         tensors = list(ws) + list(bs) + ([scales] if self.shape.has_exp_mask else [])
         for dst, src in zip(self.views(self.flat), tensors):
@@ -103,6 +108,7 @@ class FlatParams:
         """Weights (and frozen Fourier matrix) from a reference-layout state_dict. The EMA shadow is taken from
         ``ema_sd`` (same keys) or restarted from the loaded weights (what constructing torch_ema on them does); the
         RMSprop square averages restart from zero unless ``reset_optimizer`` is False."""
+        self.version += 1
         for n, t in zip(self.names, self.views(self.flat)):
             t.copy_(sd[n].reshape(t.shape))
         self.fourier_B.copy_(sd["model.base.feature_map._B"])
@@ -234,6 +240,7 @@ class FusedTrainer:
         self._partials_ready = False  # the scratch already holds the partial moments of the current f_g, Tf_g
         self._next_ready = False     # the other set already holds the next batch and its features
         self._features_ready = False  # the current set holds the features of the batch being stepped on
+        self._planes_ws, self._planes_version = None, -1  # bf16x3: which workspace holds the current weights' planes
         self._own_batch = False      # the batch being stepped on came from the internal device sampler
         # local (B, L_local) outputs of the forward, packed [f | Tf] so that one all-gather moves both
         self.fTf_loc = torch.empty((2, self.B, L), dtype=torch.float32, device=self.device)
@@ -338,8 +345,11 @@ class FusedTrainer:
     # -- compute-backend protocol of parallel.dp_step / parallel.hp_step ------------------------
     def forward(self, x: torch.Tensor) -> None:
         self._x_cur = x
+        # bf16x3: the planes of the current weights are in this workspace if the step that produced them put them there
+        planes = self._planes_ws is not None and self._planes_ws == self.ws.data_ptr() and \
+            self.path == H.PATH_FUSED_BF16X3 and self._planes_version == self.P.version
         H.operator_forward(self.shape, self._params, self.problem, x, self.ws, True, self.path, out=(self.f, self.Tf),
-                           features_ready=self._features_ready)
+                           features_ready=self._features_ready, planes_ready=planes)
 
     def local_moments(self) -> torch.Tensor:
         v, _ = self._masks()
@@ -378,11 +388,13 @@ class FusedTrainer:
                                                   self._x_other, self._ws_other, 1.0, self.path, l_offset=self.l_off)
                 self.batches_drawn += 1
                 self._next_ready = True
+                self._note_planes(self._ws_other)
                 return
             H.operator_backward_evd_step(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
                                          self.mask_kind, v, M, moments, reduced, scratch, loss,
                                          self._grads if self.keep_grads else None, opt, self.ws, 1.0, self.path,
                                          l_offset=self.l_off)
+            self._note_planes(self.ws)
             return
         H.operator_backward_evd(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g, self.mask_kind, v, M,
                                 moments, reduced, scratch, loss, self._grads, self.ws, 1.0, self.path,
@@ -390,6 +402,15 @@ class FusedTrainer:
         if take_step and (not self.multi or self.hp):  # no exchange between backward and optimiser
             self.begin_apply()
             self.apply(0, self.P.numel, 1.0)
+
+    def _note_planes(self, ws: torch.Tensor) -> None:
+        """a fused bf16x3 step has left the planes of the weights it updated in `ws` (include/nsvd.h:
+        nsvd_step_emits_planes); they stay valid until the parameters change by any other route (P.version)"""
+        if self.path == H.PATH_FUSED_BF16X3 and not self.multi and self.l_off == 0 and \
+                H.step_emits_planes(self.shape, self.B, self.path):
+            self._planes_ws, self._planes_version = ws.data_ptr(), self.P.version
+        else:
+            self._planes_ws = None
 
     def grad_buffer(self) -> torch.Tensor:
         return self.P.grad
@@ -466,6 +487,7 @@ class FusedTrainer:
         self._lr_now, self._decay_now = self._advance_schedule()
 
     def apply(self, lo: int, hi: int, grad_scale: float) -> None:
+        self.P.version += 1
         H.rmsprop_ema_step(self.P.flat[lo:hi], self.P.grad[lo:hi], self.P.sq[lo:hi], self.P.ema[lo:hi], self._lr_now,
                            self.alpha, self.eps, self._decay_now, grad_scale)
 

@@ -221,3 +221,45 @@ def test_torch_binding_runs_the_same_step_bit_for_bit():
             os.environ.pop("NSVD_BINDING", None)
         else:
             os.environ["NSVD_BINDING"] = old
+
+
+@pytest.mark.parametrize("L,m,B,potential,overlap", [(4, 64, 64, "hydrogen", True), (8, 128, 128, "oscillator", True),
+                                                     (4, 64, 96, "hydrogen", False), (16, 1024, 512, "hydrogen", True)])
+def test_bf16x3_step_leaves_the_planes_of_the_updated_weights(L, m, B, potential, overlap):
+    """NSVD_PATH_FUSED_BF16X3: the fused step's weight-gradient epilogue writes the three bf16 planes of every updated
+    element of W_0 / W_1 .. where the NEXT forward reads them (the other workspace set with guest features, the same one
+    without), and that forward skips its split launch (NSVD_W_PLANES_READY). Same rounding, same bits: 30 steps against a
+    trainer whose forwards always split (and against one whose parameters are reloaded half way: the planes are tied to
+    FlatParams.version), eager and replayed from a HIP graph; the last case is configs[1]'s shape."""
+    from neural_svd_amd import hip_ops as H
+    a = _trainer(L, m, B, False, potential=potential, overlap=overlap)
+    b = _trainer(L, m, B, False, potential=potential, overlap=overlap)
+    a.path = b.path = H.PATH_FUSED_BF16X3
+    assert H.step_emits_planes(a.shape, B, a.path) and not H.step_emits_planes(a.shape, B, H.PATH_AUTO)
+    b._note_planes = lambda ws: None  # never claims the planes: every forward of b splits the weights itself
+    used = 0
+    for t in range(30):
+        a.step()
+        b.step()
+        used += a._planes_ws is not None
+        if t == 14:  # a reload between two steps: the planes in the workspace are stale, the version says so
+            sd = a.P.state_dict()
+            a.P.load_state_dict(sd, reset_optimizer=False)
+            b.P.load_state_dict(sd, reset_optimizer=False)
+            assert a._planes_version != a.P.version
+    torch.cuda.synchronize()
+    assert used == 30 and b._planes_ws is None
+    _same(a, b)
+    # replayed from a graph (device schedule): the captured forwards carry the flag
+    g = _trainer(L, m, B, True, potential=potential, overlap=overlap)
+    e = _trainer(L, m, B, True, potential=potential, overlap=overlap)
+    g.path = e.path = H.PATH_FUSED_BF16X3
+    e._note_planes = lambda ws: None
+    if overlap:
+        gs = g.capture_graph(2)
+        pre = g.t
+        gs.replay(10)
+        for _ in range(pre + 20):
+            e.step()
+        torch.cuda.synchronize()
+        _same(e, g)
