@@ -8,7 +8,7 @@ void nsvd_prof_end(hipStream_t s);
 
 // Fused-path features (fourier.hip): phi (B, 2m) sample-major features of the CENTRE rows from one double-accurate
 // sincos per (sample, frequency); phiTc (2m, B) feature-major copy, or null; sctab (D, 2, m) = cos / sin of
-// eps * fourier_B, from which the forward kernel builds the shifted stencil rows by angle addition.
+// eps * fourier_B, from which the forward kernel builds the even / odd perturbation rows of the shifted stencil points.
 // sampler != null: the coordinates are drawn inside the kernel (N(0, sigma^2), counter-based) and stored to xout.
 int nsvd_fourier_stencil(const float* x, const float* fourier_B, float* phi, float* phiTc, float* sctab, int B, int D,
                          int m, float eps, const NsvdSampler* sampler, float* xout, hipStream_t s);

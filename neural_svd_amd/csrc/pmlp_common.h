@@ -98,7 +98,7 @@ __device__ __forceinline__ void xcd_block_map(int block, int HX, int L, int nsb,
 
 struct FusedWs {
     float* phi;                       // (B, F) sample-major Fourier features of the centre rows
-    float* sctab;                     // (D, 2, m) cos / sin of eps * fourier_B (stencil rows by angle addition) + (D, m) cos - 1
+    float* sctab;                     // (D, 2, m) cos / sin of eps * fourier_B + (D, m) cos - 1 (even / odd stencil rows)
     float* phiTc;                     // (F, B) feature-major copy of the centre rows (weight gradient)
     float* zsave[NSVD_MAX_LAYERS];    // (L, 128, B) per hidden layer
     float* jac;                       // (B, L)

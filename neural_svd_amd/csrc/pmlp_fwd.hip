@@ -29,7 +29,7 @@ namespace {
 struct FwdArgs {
     const float* phiT;   // (B, F) Fourier features of the CENTRE rows, sample-major: [sin(x.B) | cos(x.B)]
     const float* sctab;  // (D, 2, m): cos(eps B_dj), sin(eps B_dj) - the stencil rows are built from the centre
-                         // features by angle addition while the layer-0 tiles are staged
+                         // features (even / odd perturbation rows) while the layer-0 tiles are staged
     int m;
     int ldr;
     const float* W[NSVD_MAX_LAYERS];
@@ -152,9 +152,10 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int nch = a.F / BK;
     // K runs over PAIRS of chunks: 32 sin features k in [32 p, 32 p + 32) and their 32 cos partners m + k. The
     // pair is loaded once (centre row only: 2 float4 per thread + the per-frequency constants) and the E stencil
-    // rows of both chunks are generated in registers by angle addition,
-    //   sin(t +- d) = sin t cos d +- cos t sin d,  cos(t +- d) = cos t cos d -+ sin t sin d,   d = eps B_dj,
-    // with the same float32 expressions the feature kernel used to evaluate: phi(x +- eps e_d) is never stored.
+    // rows of both chunks are generated in registers (even rows u (cos d - 1), odd rows +- v sin d: the angle-addition
+    // identities with the centre value taken out),
+    //   sin(t +- d) - sin t = sin t (cos d - 1) +- cos t sin d,  cos(t +- d) - cos t = cos t (cos d - 1) -+ sin t sin d,
+    // d = eps B_dj (the table holds sin d, cos d and cos d - 1 = -2 sin^2(d / 2)): phi(x +- eps e_d) is never stored.
     // (5x less feature traffic per tile; the feature kernel writes B x F instead of E x B x F.)
     constexpr int DD = PL ? 0 : (JET ? E - 2 : (E - 1) / 2);  // input dimensions
     float4 ra0, ra1, ra2, ra3, rs, rc, cd0, sd0, cd1, sd1, cd2, sd2;
