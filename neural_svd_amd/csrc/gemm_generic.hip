@@ -1,5 +1,7 @@
 // Generic strided, batched fp32 GEMM for shapes the fused MFMA kernels do not cover
-// (hidden widths that are not 128, ragged batches). LDS-tiled 64x64x16, 4x4 register tiles.
+// (hidden widths that are not 128, ragged batches). LDS-tiled 64 x 64 x 16; the products on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: a wave owns one 32 x 32 quadrant of the tile, one MFMA and two 4-byte LDS reads per pair of
+// k) since round 4 - rounds 1-3 multiplied on the vector ALU (4 x 4 register tiles, 36 TFLOP/s).
 // Used for: ParallelMLP layers (reference mlp.py:204-221), their data gradients and weight
 // gradients (what autograd derives for those einsums).
 #include "nsvd_kernels.h"
@@ -17,8 +19,13 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(NsvdGemm g) {
     float* C = g.C + (size_t)bz * g.bC;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int t = threadIdx.x;
-    const int tx = t & 15, ty = t >> 4;
-    float acc[4][4] = {};
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;  // this wave's quadrant: rows 32 wm .., columns 32 wn ..
+    typedef float f32x16_t __attribute__((ext_vector_type(16)));
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool a_kfast = (g.sAk == 1);
     const bool b_nfast = (g.sBn == 1);
     for (int k0 = 0; k0 < g.K; k0 += TK) {
@@ -59,34 +66,24 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(NsvdGemm g) {
             Bs[kk][nn] = v;
         }
         __syncthreads();
+        // lane (li, hi) feeds row / column li of the quadrant at k = kk + hi: D[i][j] += sum_k A[i][k] B[k][j]
 #pragma unroll
-        for (int kk = 0; kk < TK; ++kk) {
-            const float4 a = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-            const float4 b = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-            const float bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-        }
+        for (int kk = 0; kk < TK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + hi][32 * wm + li], Bs[kk + hi][32 * wn + li], acc, 0, 0, 0);
         __syncthreads();
     }
     const float* bias = g.bias ? g.bias + (size_t)bz * g.bBias : nullptr;
     const float* Z = g.Z ? g.Z + (size_t)bz * g.bZ : nullptr;
+    // accumulator register r of lane (li, hi): row 8 (r / 4) + 4 hi + r % 4, column li of the quadrant
+    const int gn = n0 + 32 * wn + li;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + ty * 4 + i;
-        if (gm >= g.M) continue;
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (gm >= g.M || gn >= g.N) continue;
         const float bi = bias ? bias[gm] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + tx * 4 + j;
-            if (gn >= g.N) continue;
-            float v = acc[i][j] + ((g.eo_cols > 0 && gn >= g.eo_cols) ? 0.f : bi);
-            if (g.sigmoid_mul) v *= nsvd_sigmoid(Z[(size_t)gm * g.sZm + gn]);
-            C[(size_t)gm * g.sCm + gn] = v;
-        }
+        float v = acc[r] + ((g.eo_cols > 0 && gn >= g.eo_cols) ? 0.f : bi);
+        if (g.sigmoid_mul) v *= nsvd_sigmoid(Z[(size_t)gm * g.sZm + gn]);
+        C[(size_t)gm * g.sCm + gn] = v;
     }
 }
 
