@@ -241,6 +241,7 @@ class FusedTrainer:
         self._next_ready = False     # the other set already holds the next batch and its features
         self._features_ready = False  # the current set holds the features of the batch being stepped on
         self._planes_ws, self._planes_version = None, -1  # bf16x3: which workspace holds the current weights' planes
+        self._emits_planes_cached = None
         self._own_batch = False      # the batch being stepped on came from the internal device sampler
         # local (B, L_local) outputs of the forward, packed [f | Tf] so that one all-gather moves both
         self.fTf_loc = torch.empty((2, self.B, L), dtype=torch.float32, device=self.device)
@@ -406,11 +407,15 @@ class FusedTrainer:
     def _note_planes(self, ws: torch.Tensor) -> None:
         """a fused bf16x3 step has left the planes of the weights it updated in `ws` (include/nsvd.h:
         nsvd_step_emits_planes); they stay valid until the parameters change by any other route (P.version)"""
-        if self.path == H.PATH_FUSED_BF16X3 and not self.multi and self.l_off == 0 and \
-                H.step_emits_planes(self.shape, self.B, self.path):
+        if self.path == H.PATH_FUSED_BF16X3 and not self.multi and self.l_off == 0 and self._emits_planes():
             self._planes_ws, self._planes_version = ws.data_ptr(), self.P.version
         else:
             self._planes_ws = None
+
+    def _emits_planes(self) -> bool:
+        if self._emits_planes_cached is None:  # (one library call, not one per step)
+            self._emits_planes_cached = H.step_emits_planes(self.shape, self.B, H.PATH_FUSED_BF16X3)
+        return self._emits_planes_cached
 
     def grad_buffer(self) -> torch.Tensor:
         return self.P.grad
