@@ -23,8 +23,8 @@ torch.cuda.synchronize()
 nwg = (B // 32) * L
 st = wsb[off:off + nwg * 16 * 8].view(torch.int64).view(nwg, 16).cpu().numpy().astype(np.float64)
 names = {0: "start", 1: "prologue(chunk0 staged)", 2: "layer0 loop", 3: "softplus0", 4: "wf loads issued", 5: "exchange1 (2 barriers + Hs write)", 6: "layer1 MFMAs",
-         7: "softplus1", 8: "wf loads issued", 9: "exchange2", 10: "layer2 MFMAs", 11: "softplus2", 12: "-", 13: "last layer + reduce", 14: "FD epilogue"}
-order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14]
+         7: "softplus1", 8: "wf loads issued", 9: "exchange2", 10: "layer2 MFMAs", 11: "softplus2", 12: "-", 13: "last layer + reduce", 14: "last layer + reduce + FD epilogue"}
+order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 14]  # (stamp 13 left the kernel with the point-wise epilogue)
 tot = st[:, 14] - st[:, 0]
 print(f"per-WG total ticks median {np.median(tot):.0f} (s_memtime ticks; 100 MHz => {np.median(tot)/100:.1f} us)")
 prev = 0
