@@ -27,6 +27,49 @@ __device__ __forceinline__ void chunk_rows(const Chunking& c, int chunk, int& r0
     else { r0 = c.B1 + (chunk - c.n1) * CH; r1 = min(r0 + CH, c.B1 + c.B2); }
 }
 
+// part[i][j] = sum_r fs[r][i] fs[r][j] over the chunk's rows, 16 outputs per thread at a time: every output is still
+// summed over r in order (the same bits as one output at a time), but the 16 accumulator chains are independent - one
+// chain per thread was a dependent LDS-read + FMA sequence of 16 x nr steps (30 us at L = 64, B = 8192: 128 workgroups
+// of 64 rows), now the LDS reads of a row are in flight together
+// NQ outputs per thread and pass (4 covers L <= 32 in one pass without idle accumulators); JC: 256 is a multiple of L, so
+// a thread's column j = tid % L is the same for all of its outputs - one read of the row's element instead of NQ
+template <int NQ, bool JC>
+__device__ __forceinline__ void chunk_gram_t(const float* fs, int nr, int L, float* __restrict__ out) {
+    const int LL = L * L;
+    for (int base = 0; base < LL; base += 256 * NQ) {
+        float acc[NQ];
+        int ii[NQ], jj[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int o = min(base + (int)threadIdx.x + 256 * q, LL - 1);
+            ii[q] = o / L;
+            jj[q] = o - ii[q] * L;
+            acc[q] = 0.f;
+        }
+        for (int r = 0; r < nr; ++r) {
+            const float* row = fs + r * L;
+            const float rj = row[jj[0]];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = fmaf(row[ii[q]], JC ? rj : row[jj[q]], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int o = base + (int)threadIdx.x + 256 * q;
+            if (o < LL) out[o] = acc[q];
+        }
+    }
+}
+__device__ __forceinline__ void chunk_gram(const float* fs, int nr, int L, float* __restrict__ out) {
+    const bool jc = 256 % L == 0 && L * L >= 256;  // (every output of a thread then exists or is the clamped last one)
+    if (L * L <= 1024) {
+        if (jc) chunk_gram_t<4, true>(fs, nr, L, out);
+        else chunk_gram_t<4, false>(fs, nr, L, out);
+    } else {
+        if (jc) chunk_gram_t<16, true>(fs, nr, L, out);
+        else chunk_gram_t<16, false>(fs, nr, L, out);
+    }
+}
+
 __global__ void __launch_bounds__(256) evd_partial_kernel(const float* __restrict__ f, const float* __restrict__ Tf,
                                                           int B, int L, int kind, const float* __restrict__ v,
                                                           float* __restrict__ part, float* __restrict__ part_op) {
@@ -44,12 +87,7 @@ __global__ void __launch_bounds__(256) evd_partial_kernel(const float* __restric
         op = fmaf(mask_v(kind, v, l, L) * fv, Tf[(size_t)r0 * L + i], op);
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < L * L; o += 256) {
-        const int i = o / L, j = o - i * L;
-        float s = 0.f;
-        for (int r = 0; r < nr; ++r) s = fmaf(fs[r * L + i], fs[r * L + j], s);
-        part[(size_t)blockIdx.x * L * L + o] = s;
-    }
+    chunk_gram(fs, nr, L, part + (size_t)blockIdx.x * L * L);
     op = nsvd_wave_sum(op);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = op;
     __syncthreads();
@@ -86,12 +124,7 @@ __global__ void __launch_bounds__(256) evd_gather_heads_kernel(const float* __re
     }
     if (!part) return;
     __syncthreads();
-    for (int o = threadIdx.x; o < L * L; o += 256) {
-        const int i = o / L, j = o - i * L;
-        float s = 0.f;
-        for (int r = 0; r < nr; ++r) s = fmaf(fs[r * L + i], fs[r * L + j], s);
-        part[(size_t)blockIdx.x * L * L + o] = s;
-    }
+    chunk_gram(fs, nr, L, part + (size_t)blockIdx.x * L * L);
     op = nsvd_wave_sum(op);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = op;
     __syncthreads();
@@ -105,9 +138,24 @@ __global__ void __launch_bounds__(256) evd_reduce_kernel(const float* __restrict
     const int LL = L * L;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < LL) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < c.n1; ++k) s1 += part[(size_t)k * LL + i];
-        for (int k = 0; k < c.n2; ++k) s2 += part[(size_t)(c.n1 + k) * LL + i];
+        // chunk order, as everywhere these partials are summed (nsvd_evd_lam): the same bits; the loads of eight chunks
+        // are issued before the first is added (17 workgroups walk up to 128 chunks each: the kernel is one dependent
+        // load chain per thread otherwise - 36 us at L = 64, B = 8192)
+        auto sum_chunks = [&](const float* p0, int n) {
+            float s = 0.f;
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = p0[(size_t)(k + j) * LL];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += t[j];
+            }
+            for (; k < n; ++k) s += p0[(size_t)k * LL];
+            return s;
+        };
+        const float s1 = sum_chunks(part + i, c.n1);
+        const float s2 = sum_chunks(part + (size_t)c.n1 * LL + i, c.n2);
         moments[i] = s1 / (float)c.B1;
         moments[LL + i] = s2 / (float)c.B2;  // B2 == 0 (B == 1) gives nan, like the reference
     } else if (i == LL) {
