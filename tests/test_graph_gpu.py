@@ -232,8 +232,10 @@ def test_bf16x3_step_leaves_the_planes_of_the_updated_weights(L, m, B, potential
     trainer whose forwards always split (and against one whose parameters are reloaded half way: the planes are tied to
     FlatParams.version), eager and replayed from a HIP graph; the last case is configs[1]'s shape."""
     from neural_svd_amd import hip_ops as H
-    a = _trainer(L, m, B, False, potential=potential, overlap=overlap)
-    b = _trainer(L, m, B, False, potential=potential, overlap=overlap)
+    # (B = 96: also with the gradients stored beside the fused step - the weight-gradient kernel's plain epilogue)
+    kw = dict(keep_grads=True) if B == 96 else {}
+    a = _trainer(L, m, B, False, potential=potential, overlap=overlap, **kw)
+    b = _trainer(L, m, B, False, potential=potential, overlap=overlap, **kw)
     a.path = b.path = H.PATH_FUSED_BF16X3
     assert H.step_emits_planes(a.shape, B, a.path) and not H.step_emits_planes(a.shape, B, H.PATH_AUTO)
     b._note_planes = lambda ws: None  # never claims the planes: every forward of b splits the weights itself
