@@ -327,9 +327,24 @@ def _refresh_from_trainer(tr, method, ema, optimizer, scheduler):
 def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch_ftn_val, log_writer, log_file,
                    device, importance_train, importance_val, ground_truth_spectrum=None):
     if getattr(args, "use_amp", False):
-        # the reference wraps the step in autocast + GradScaler (examples/operator/__init__.py:37-38,62-72); the HIP
-        # path computes in float32 only and the PDE scripts never set the flag: refuse rather than ignore it
-        raise NotImplementedError("use_amp: the HIP path is float32 only (no autocast / GradScaler branch)")
+        # The reference's mixed-precision switch wraps the step in autocast + GradScaler (examples/operator/__init__.py:
+        # 37-38,62-72): half-precision matmuls, loss scaling against their underflow. Here it selects this package's
+        # mixed-precision forward, NSVD_PATH_FUSED_BF16X3 - every layer on the bf16 MFMA with operands split into three
+        # bfloat16 planes, float32 accumulation: the speed-up the flag asks for (2.2 x on the forward) with f and Tf as
+        # close to float64 as the float32 path's, so there is nothing for a GradScaler to do.
+        # DIFFERENT arithmetic from the reference's autocast, not bit-comparable to it (nor is the float32 path). Models
+        # the MFMA kernels do not take have no such forward: refuse rather than ignore the flag.
+        from . import hip_ops as H
+        from .models import WaveFunctions
+        from .nested_lowrank import NestedLoRA
+        from .operators import OperatorWrapper
+        model = getattr(method, "model", None)
+        ok = isinstance(method, NestedLoRA) and isinstance(model, WaveFunctions) and isinstance(operator, OperatorWrapper) \
+            and H.path_name(model.shape, max(32, (int(args.batch_size) + 31) // 32 * 32), H.PATH_FUSED_BF16X3) == "fused_mfma"
+        if not ok:
+            raise NotImplementedError("use_amp: the mixed-precision forward (NSVD_PATH_FUSED_BF16X3) exists for models "
+                                      "the MFMA kernels take only (128-wide hidden layers, D <= 3)")
+        method.path = H.PATH_FUSED_BF16X3
     optimizer = get_optimizer(args, method)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.num_iters)
     ema = ExponentialMovingAverage(method.parameters(), decay=args.ema_decay)
