@@ -541,7 +541,10 @@ def bench_widened(args):
                     f"constant mode, joint nesting, SGD lr 5e-3 momentum 0.9")
         metric = "training steps/sec, CDK two-tower step L=512 B=1024 (NestedLoRA CDK path)"
         if args.amp:
-            metric += " [mixed precision: bfloat16 operands in the tower contractions, float32 accumulation]"
+            metric += (" [mixed precision: bfloat16 operands in the tower contractions, float32 accumulation - this "
+                       "build's own mode, DIFFERENT arithmetic from the Sketchy script's float16 autocast + GradScaler "
+                       "(examples/cdk/sketchy/main_sketchy.py:161,182), pinned to the float64 oracle with the same "
+                       "operand rounding, not to a reference fixture]")
         note = ("one C call per step (nsvd_cdk_step): towers on csrc/tower.hip (five fp32-MFMA contractions + BatchNorm "
                 "strip kernels each, forward + backward), normalisation, CDK loss, global gradient-norm clip and SGD "
                 "momentum (scripts/exps/sketchy.sh: --optimizer sgd --momentum 0.9 --clip_grad_norm); no torch "
