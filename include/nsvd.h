@@ -363,6 +363,12 @@ int nsvd_spectrum_accumulate(const float* f, const float* Tf, const float* x, in
 int nsvd_spectrum_accumulate_f64(const float* f, const float* Tf, const float* x, int B, int L, int D,
                                  float sigma, int use_importance, float lim, double* cov, double* quad,
                                  void* stream);
+/* compute_spectrum_evd(set_first_mode_const=True) (methods/spectrum.py:68-70): the same float64 accumulation with a
+ * constant-one column padded in FRONT of the weighted phi and Tphi (after the weighting, before nan_to_num and the
+ * x ~ 0 zeroing of Tphi); cov, quad: (L + 1, L + 1) doubles. */
+int nsvd_spectrum_accumulate_const_f64(const float* f, const float* Tf, const float* x, int B, int L, int D,
+                                       float sigma, int use_importance, float lim, double* cov, double* quad,
+                                       void* stream);
 
 /* ---- next row: dense kernel operator on a minibatch (kernel-operator configuration) ---------------------------
  * Kf[i][l] = scale * sum_k K[rows[i]][cols[k]] f[k][l]: the (Kf, f) producer that

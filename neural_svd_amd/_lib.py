@@ -124,6 +124,7 @@ SIGNATURES = {
     "nsvd_cdk_loss_backward": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "nsvd_spectrum_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
     "nsvd_spectrum_accumulate_f64": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
+    "nsvd_spectrum_accumulate_const_f64": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
     "nsvd_step_emits_planes": (_I, [C.POINTER(ModelDesc), _I, _I]),
     "nsvd_row_normalize_forward": (_I, [_P, _I, _I, _F, _I, _P, _P]),
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),

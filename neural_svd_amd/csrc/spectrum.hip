@@ -24,22 +24,28 @@ __device__ __forceinline__ float nan_to_num(float v) {
 template <typename Acc>
 __global__ void __launch_bounds__(256) spectrum_kernel(const float* __restrict__ f, const float* __restrict__ Tf,
                                                        const float* __restrict__ x, int B, int L, int D, float sigma,
-                                                       float log_norm, int use_imp, float inv_sqrt_val,
+                                                       float log_norm, int use_imp, float inv_sqrt_val, int pad,
                                                        Acc* __restrict__ cov, Acc* __restrict__ quad) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // phi[SR][L], tphi[SR][L]
+    // pad = 1 (set_first_mode_const, methods/spectrum.py:68-70): a constant-one column in FRONT of the weighted phi and
+    // Tphi (ConstantPad1d((1, 0), 1) after the weighting); the accumulators are then (L + 1, L + 1)
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // phi[SR][L + pad], tphi[SR][L + pad]
+    const int Lin = L;
+    L += pad;
     float* ph = sm;
     float* tp = sm + SR * L;
     const int r0 = blockIdx.x * SR;
     const int nr = min(SR, B - r0);
     for (int i = threadIdx.x; i < nr * L; i += 256) {
-        const int r = i / L;
+        const int r = i / L, c = i - r * L;
         const float* xr = x + (size_t)(r0 + r) * D;
         const float sp = use_imp ? nsvd_sqrt_gauss_pdf(xr, D, sigma, log_norm) : 1.f;
         const float w = sp * inv_sqrt_val;
         bool zero = true;
         for (int d = 0; d < D; ++d) zero = zero && (fabsf(xr[d]) <= 1e-8f);  // torch.isclose(x, 0)
-        ph[i] = nan_to_num(w * f[(size_t)r0 * L + i]);
-        const float t = nan_to_num(w * Tf[(size_t)r0 * L + i]);
+        const bool one = pad && c == 0;
+        const size_t src = (size_t)(r0 + r) * Lin + (c - pad);
+        ph[i] = one ? 1.f : nan_to_num(w * f[src]);
+        const float t = one ? 1.f : nan_to_num(w * Tf[src]);
         tp[i] = zero ? 0.f : t;
     }
     __syncthreads();
@@ -60,15 +66,15 @@ __global__ void __launch_bounds__(256) spectrum_kernel(const float* __restrict__
 
 template <typename Acc>
 static int spectrum_accumulate_impl(const float* f, const float* Tf, const float* x, int B, int L, int D, float sigma,
-                                    int use_importance, float lim, Acc* cov, Acc* quad, void* stream) {
-    if (!f || !Tf || !x || !cov || !quad || B <= 0 || L <= 0 || D <= 0) return NSVD_EINVAL;
+                                    int use_importance, float lim, Acc* cov, Acc* quad, void* stream, int pad = 0) {
+    if (!f || !Tf || !x || !cov || !quad || B <= 0 || L <= 0 || D <= 0 || pad < 0 || pad > 1) return NSVD_EINVAL;
     if (L > SMAXL) return NSVD_EUNSUPPORTED;
     // importance_val is built as a float32 tensor in the reference (main_pde.py:130)
     const float pval = (float)(1.0 / pow(2.0 * (double)lim, (double)D));
     const float inv_sqrt_val = 1.f / sqrtf(pval);
-    const size_t lds = (size_t)2 * SR * L * sizeof(float);
+    const size_t lds = (size_t)2 * SR * (L + pad) * sizeof(float);
     hipLaunchKernelGGL(spectrum_kernel<Acc>, dim3(nsvd_cdiv(B, SR)), dim3(256), lds, (hipStream_t)stream, f, Tf, x, B,
-                       L, D, sigma, nsvd_gauss_log_norm(D, sigma), use_importance, inv_sqrt_val, cov, quad);
+                       L, D, sigma, nsvd_gauss_log_norm(D, sigma), use_importance, inv_sqrt_val, pad, cov, quad);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
@@ -83,4 +89,10 @@ extern "C" int nsvd_spectrum_accumulate_f64(const float* f, const float* Tf, con
                                             float sigma, int use_importance, float lim, double* cov, double* quad,
                                             void* stream) {
     return spectrum_accumulate_impl<double>(f, Tf, x, B, L, D, sigma, use_importance, lim, cov, quad, stream);
+}
+
+extern "C" int nsvd_spectrum_accumulate_const_f64(const float* f, const float* Tf, const float* x, int B, int L, int D,
+                                                  float sigma, int use_importance, float lim, double* cov,
+                                                  double* quad, void* stream) {
+    return spectrum_accumulate_impl<double>(f, Tf, x, B, L, D, sigma, use_importance, lim, cov, quad, stream, 1);
 }

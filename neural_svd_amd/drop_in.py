@@ -191,6 +191,10 @@ def _make_fused(FusedTrainer, args, method, model, operator, importance_train, s
                         exp_mask_init=1.0 if model.has_exp_mask else None)  # initial values: replaced by the caller
 
 
+class CaptureUnavailable(RuntimeError):
+    """CapturedPlainStep cannot take this step (and has changed nothing): run the eager plain loop instead."""
+
+
 class CapturedPlainStep:
     """The PLAIN loop body of the reference (examples/operator/__init__.py:55-74) - zero_grad, compute_loss_operator,
     loss.backward(), optimizer.step(), scheduler.step(), ema.update() - captured once into a HIP graph and replayed:
@@ -234,6 +238,10 @@ class CapturedPlainStep:
         loss, _aux = self.method.compute_loss_operator(self.operator, self.x, importance=self.importance)
         loss.backward()
         n = len(self.params)
+        if any(p.grad is None for p in self.params):
+            # a trainable parameter the loss does not reach (torch's RMSprop would skip it): nothing has been updated
+            # yet - the caller takes this and every later step with the eager plain loop
+            raise CaptureUnavailable("a trainable parameter received no gradient")
         for i, (p, sq, sh) in enumerate(zip(self.params, self.sq, self.ema.shadow_params)):
             H.rmsprop_ema_step_dev(p.data.view(-1), p.grad.view(-1), sq.view(-1), sh.view(-1), self.state, 1.0,
                                    advance=(i == n - 1))
@@ -253,11 +261,19 @@ class CapturedPlainStep:
                     torch.cuda.synchronize()
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
-                    self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.stream(side):
-                        with torch.cuda.graph(self.graph, stream=side):
-                            self.loss = self._body()
+                    graph = torch.cuda.CUDAGraph()
+                    try:
+                        with torch.cuda.stream(side):
+                            with torch.cuda.graph(graph, stream=side):
+                                self.loss = self._body()
+                    except CaptureUnavailable:
+                        raise
+                    except Exception as e:  # capture refused (an op that syncs, an allocation the pool cannot serve ..):
+                        # captured launches never ran, so the state is that of the last eager step
+                        torch.cuda.current_stream().wait_stream(side)
+                        raise CaptureUnavailable(f"HIP-graph capture of the plain loop body failed: {e!r}") from e
                     torch.cuda.current_stream().wait_stream(side)
+                    self.graph = graph
                 self.graph.replay()
         self.steps += 1
         return self.loss
@@ -339,12 +355,20 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
         from .nested_lowrank import NestedLoRA
         from .operators import OperatorWrapper
         model = getattr(method, "model", None)
+        # gated on the batch the training forward really runs (no padding applies there: rows must come in 32s)
         ok = isinstance(method, NestedLoRA) and isinstance(model, WaveFunctions) and isinstance(operator, OperatorWrapper) \
-            and H.path_name(model.shape, max(32, (int(args.batch_size) + 31) // 32 * 32), H.PATH_FUSED_BF16X3) == "fused_mfma"
+            and int(args.batch_size) % 32 == 0 \
+            and H.path_name(model.shape, int(args.batch_size), H.PATH_FUSED_BF16X3) == "fused_mfma"
         if not ok:
             raise NotImplementedError("use_amp: the mixed-precision forward (NSVD_PATH_FUSED_BF16X3) exists for models "
-                                      "the MFMA kernels take only (128-wide hidden layers, D <= 3)")
+                                      "the MFMA kernels take only (128-wide hidden layers, D <= 3) and batches that "
+                                      "are a multiple of 32 rows")
         method.path = H.PATH_FUSED_BF16X3
+        import warnings
+        warnings.warn("train_operator(use_amp=True): this package runs the forward as split-bfloat16 products with "
+                      "float32 accumulation (NSVD_PATH_FUSED_BF16X3) - NOT the reference's float16 autocast + GradScaler "
+                      "(examples/operator/__init__.py:37-38,62-72): no loss scaling, no skipped steps, different "
+                      "rounding; the evaluation forward (compute_spectrum_evd) runs on the same path", stacklevel=2)
     optimizer = get_optimizer(args, method)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.num_iters)
     ema = ExponentialMovingAverage(method.parameters(), decay=args.ema_decay)
@@ -368,10 +392,11 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     # the reference adds loss.item() to a host total on EVERY step (operator/__init__.py:74,99: a device sync per
     # step); here the running total lives on the device and is read at print time only. The fused loop's backward
     # kernels leave the loss scalars themselves on one GPU with batches of <= 1024 rows; otherwise (heads sharded, larger
-    # batches) the loss is evaluated (one extra launch) on every `loss_stride`-th step and at print time only, and the
-    # logged column is then called `avg_train_loss_sampled` (the mean over those sampled steps: a different quantity
-    # from the reference's every-step mean) - args.loss_every_step = True restores the every-step mean at one launch per
-    # step
+    # batches) the loss is evaluated (one extra launch) on every `loss_stride`-th step and at print time only: the
+    # `avg_train_loss` column (the reference's key: main_pde.py:195-198 builds a csv.DictWriter with exactly
+    # iter / train_loss / avg_train_loss / time, which raises on any other key) is then the mean over those sampled
+    # steps - said once on stdout and in the printed row's `avg_train_loss_over`, never in the CSV row -
+    # args.loss_every_step = True restores the every-step mean at one launch per step
     total_loss = torch.zeros((), dtype=torch.float64, device=device)
     n_loss = 0
     # (single GPU, batches of <= 1024 rows: the step's own kernels leave the loss value every step - no extra launch -
@@ -380,7 +405,10 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
     if every is None:
         every = fused is not None and fused._direct_loss
     loss_stride = 1 if every else max(1, int(args.print_freq) // 16)
-    loss_key = "avg_train_loss" if (loss_stride == 1 or fused is None) else "avg_train_loss_sampled"
+    sampled_mean = loss_stride > 1 and fused is not None
+    if sampled_mean and rank0:
+        print(f"train_operator: avg_train_loss is the mean over every {loss_stride}-th step's loss (and the printed "
+              f"steps'), not over every step: set args.loss_every_step = True for the reference's every-step mean")
     for it in range(args.num_iters):
         x = make_batch_ftn_train() if draws == 1 else torch.cat([make_batch_ftn_train() for _ in range(draws)])
         x = x.to(device)
@@ -406,11 +434,18 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
                 loss = fused.loss[0]  # evaluated on the device from this step's f, Tf (no sync)
                 total_loss += loss
                 n_loss += 1
-        elif captured is not None:
+        if fused is None and captured is not None:
             # the plain loop body replayed from a HIP graph (CapturedPlainStep): same launches, no host work per step
-            loss = captured.step(x.float().contiguous())
-            n_loss += 1
-        else:
+            try:
+                loss = captured.step(x.float().contiguous())
+                n_loss += 1
+            except CaptureUnavailable as e:
+                # nothing was updated by the refused step: the eager body below takes it, and every later one
+                print(f"train_operator: {e}; continuing with the eager plain loop")
+                captured.sync_counters()
+                total_loss = total_loss + captured.total
+                captured = None
+        if fused is None and captured is None:
             method.train()
             optimizer.zero_grad()
             loss, _aux = method.compute_loss_operator(operator, x, importance=importance_train)
@@ -425,13 +460,17 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
             # the only host sync, and only at print time (the reference syncs every step)
             if captured is not None:
                 total_loss = captured.total
-            row = {"iter": it + 1, "train_loss": float(loss), loss_key: float(total_loss) / n_loss,
+            assert n_loss > 0
+            row = {"iter": it + 1, "train_loss": float(loss), "avg_train_loss": float(total_loss) / n_loss,
                    "time": time.time() - start}
             if rank0:
-                print(row)
+                print(dict(row, avg_train_loss_over=f"every {loss_stride}-th step") if sampled_mean else row)
             if log_writer is not None and rank0:
-                log_writer.writerow(row)
-                log_file.flush()
+                # the reference's writer (examples/utils.py:40-45) takes exactly these four keys
+                names = getattr(log_writer, "fieldnames", None)
+                log_writer.writerow(row if names is None else {k: v for k, v in row.items() if k in names})
+                if log_file is not None:
+                    log_file.flush()
         if (it + 1) % args.eval_freq == 0:
             if fused is not None:
                 _refresh_from_trainer(fused, method, ema, optimizer, scheduler)

@@ -35,7 +35,7 @@ def torch_binding():
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nsvd_torch.so")
         if not os.path.exists(path):
             raise NsvdError(f"{path} not found: NSVD_BINDING=torch needs the torch binding built "
-                            f"(`make -C neural_svd_amd/csrc`, or __graft_entry__.build())")
+                            f"(`make -C neural_svd_amd/csrc torch_binding`, or __graft_entry__.build())")
         _lib.load()  # libnsvd_hip.so first: the extension links against it
         spec = importlib.util.spec_from_file_location("_nsvd_torch", path)
         mod = importlib.util.module_from_spec(spec)
@@ -722,19 +722,26 @@ def rmsprop_ema_step_dev(p: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, 
 
 
 def spectrum_accumulate(f: torch.Tensor, Tf: torch.Tensor, x: torch.Tensor, sigma: float, use_importance: bool,
-                        lim: float, cov: torch.Tensor, quad: torch.Tensor) -> None:
+                        lim: float, cov: torch.Tensor, quad: torch.Tensor, first_mode_const: bool = False) -> None:
     """cov += phi^T phi, quad += phi^T Tphi. float32 accumulators: the reference's (methods/spectrum.py:60-75);
-    float64 accumulators (cov.dtype == torch.float64): products and sums in float64 (nsvd_spectrum_accumulate_f64)."""
+    float64 accumulators (cov.dtype == torch.float64): products and sums in float64 (nsvd_spectrum_accumulate_f64).
+    first_mode_const (float64 accumulators of shape (L + 1, L + 1)): a constant-one column in front of phi and Tphi
+    (methods/spectrum.py:68-70)."""
     B, L = f.shape
     D = x.shape[1]
     if cov.dtype != quad.dtype or cov.dtype not in (torch.float32, torch.float64):
         raise NsvdError("spectrum_accumulate: cov / quad must both be float32 or both float64")
+    Lp = L + int(bool(first_mode_const))
+    if tuple(cov.shape) != (Lp, Lp) or tuple(quad.shape) != (Lp, Lp) or Tf.shape != f.shape:
+        raise NsvdError(f"spectrum_accumulate: cov / quad must be ({Lp}, {Lp}), Tf like f")
+    if first_mode_const and cov.dtype != torch.float64:
+        raise NsvdError("spectrum_accumulate(first_mode_const=True) takes float64 accumulators")
     if cov.dtype == torch.float64:
-        rc = _lib.load().nsvd_spectrum_accumulate_f64(_ptr(f, "f"), _ptr(Tf, "Tf"), _ptr(x, "x"), B, L, D, float(sigma),
-                                                      int(bool(use_importance)), float(lim),
-                                                      _ptr(cov, "cov", torch.float64), _ptr(quad, "quad", torch.float64),
-                                                      _stream())
-        check(rc, "nsvd_spectrum_accumulate_f64")
+        fn = "nsvd_spectrum_accumulate_const_f64" if first_mode_const else "nsvd_spectrum_accumulate_f64"
+        rc = getattr(_lib.load(), fn)(_ptr(f, "f"), _ptr(Tf, "Tf"), _ptr(x, "x"), B, L, D, float(sigma),
+                                      int(bool(use_importance)), float(lim),
+                                      _ptr(cov, "cov", torch.float64), _ptr(quad, "quad", torch.float64), _stream())
+        check(rc, fn)
         return
     if torch_binding() is not None:
         _TB.spectrum_accumulate(f, Tf, x, float(sigma), bool(use_importance), float(lim), cov, quad)

@@ -194,6 +194,9 @@ class _OperatorFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads.tensors)
 
 
+_FOREIGN_LOGGED = False
+
+
 class NestedLoRA(nn.Module):
     def __init__(self, model, neigs, step=1, sort=False, sequential=False, path: int = H.PATH_AUTO):
         self.name = "nestedlora"
@@ -257,8 +260,33 @@ class NestedLoRA(nn.Module):
         return loss, dict(f=f, Tf=Kf, eigvals=None)
 
     def apply_operator(self, operator, x, importance=None):
-        """Tf, f = operator(self, x, importance) on the HIP path."""
-        from .operators import fused_problem_of
+        """Tf, f = operator(self, x, importance).
+        This package's OperatorWrapper (finite-difference / exact Hamiltonian with Gaussian or no importance): ONE fused
+        forward on the HIP kernels (nsvd_operator_forward) and its backward.
+        Any other callable with the reference's contract `operator(model, x, importance=None) -> (Tf, f)`
+        (examples/__init__.py:7-9, methods/nestedlora.py:254-267; SURVEY 8(b): "otherwise fall back to python operator
+        + fused loss kernel"): it is CALLED, with this module as `model` - `self(x)` runs on nsvd_model_forward and is
+        differentiable through nsvd_model_backward - and its (Tf, f) go to the HIP loss kernels. Still no CPU path: the
+        model evaluations inside the foreign operator and the loss are the HIP kernels, only the operator's own
+        elementwise algebra is torch's."""
+        from .operators import OperatorWrapper, fused_problem_of
+        if not isinstance(operator, OperatorWrapper):
+            if not callable(operator):
+                raise NsvdError("compute_loss_operator: operator must be callable as operator(model, x, importance)")
+            global _FOREIGN_LOGGED
+            if not _FOREIGN_LOGGED:
+                _FOREIGN_LOGGED = True
+                print(f"neural_svd_amd: operator {type(operator).__name__} is not this package's OperatorWrapper: the "
+                      f"fused operator kernel is bypassed (it is called with the HIP model; the loss runs on the HIP "
+                      f"EVD kernels)")
+            Tf, f = operator(self, x, importance=importance) if importance is not None else operator(self, x)
+            if f.dim() != 2 or Tf.shape != f.shape:
+                raise NsvdError(f"operator returned Tf {tuple(Tf.shape)}, f {tuple(f.shape)}: expected two (B, L) tensors")
+            return Tf.float().contiguous(), f.float().contiguous()
+        if not operator.fused(importance):
+            # Laplace / uniform / any other density: the wrapper applies the stencil around HIP model evaluations
+            Tf, f = operator.apply_stencil(self, x, importance)
+            return Tf.contiguous(), f.contiguous()
         prob = fused_problem_of(operator, importance, self.model)
         x = x.reshape(x.shape[0], -1).float().contiguous()
         Tf, f = _OperatorFn.apply(x, self, operator, prob, *self.model.trainable_tensors())

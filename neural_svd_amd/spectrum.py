@@ -18,20 +18,20 @@ def compute_spectrum_evd(model, dataloader, operator, importance_train=None, imp
                          device=None):
     if (gpu is None) == (device is None):
         raise ValueError("exactly one of gpu / device")
-    if set_first_mode_const or post_align:
-        raise NotImplementedError("set_first_mode_const / post_align: not used by the PDE path")
     if not isinstance(importance_val, UniformBoxImportance):
         raise NsvdError("HIP path: importance_val must be UniformBoxImportance (the validation grid's density)")
-    if importance_train is not None and not isinstance(importance_train, GaussianImportance):
-        raise NsvdError("HIP path: importance_train must be None or GaussianImportance")
+    # Gaussian (or no) training density: the accumulation kernel evaluates sqrt(p_train) itself; any other callable
+    # density (Laplace / uniform samplers, main_pde.py:101-118): the rows are weighted here, the kernel divides by
+    # sqrt(p_val) only
+    in_kernel = importance_train is None or isinstance(importance_train, GaussianImportance)
     dev = torch.device(f"cuda:{gpu}") if gpu is not None else torch.device(device)
-    L = model.neigs
+    L = model.neigs + int(bool(set_first_mode_const))
     # float64 accumulators, rounded to the reference's float32 once at the end (include/nsvd.h:
     # nsvd_spectrum_accumulate_f64 - a float32 running sum carries an excited state's quotient to ~1e-4 only)
     cov = torch.zeros((L, L), dtype=torch.float64, device=dev)
     quad = torch.zeros_like(cov)
     eigfuncs, n = [], 0
-    sigma = importance_train.sigma if importance_train is not None else 1.0
+    sigma = importance_train.sigma if (importance_train is not None and in_kernel) else 1.0
     for (x, _) in dataloader:
         if isinstance(x, list):
             x = x[0]
@@ -39,7 +39,11 @@ def compute_spectrum_evd(model, dataloader, operator, importance_train=None, imp
         Tphi, phi = operator(model, x, importance=importance_train)
         sw = importance_train(x).sqrt() if importance_train is not None else 1.0
         eigfuncs.append(sw * phi)
-        H.spectrum_accumulate(phi, Tphi, x, sigma, importance_train is not None, importance_val.lim, cov, quad)
+        if not in_kernel:
+            phi, Tphi = sw * phi, sw * Tphi
+        H.spectrum_accumulate(phi.float().contiguous(), Tphi.float().contiguous(), x, sigma,
+                              importance_train is not None and in_kernel, importance_val.lim, cov, quad,
+                              first_mode_const=bool(set_first_mode_const))
         n += len(x)
     out = dict()
     cov64 = (cov / n).cpu().numpy()
@@ -60,4 +64,19 @@ def compute_spectrum_evd(model, dataloader, operator, importance_train=None, imp
         out["cov"] = out["cov"][:, idx][idx, :]
         out["quad"] = out["quad"][:, idx][idx, :]
         out["norms"] = out["norms"][idx]
+    if post_align:
+        out["eigfuncs_aligned"], out["eigvals_aligned"], out["cov_aligned"] = post_alignment(
+            out["eigfuncs"], out["cov"], out["quad"])
     return out
+
+
+def post_alignment(eigfuncs, cov, quad):
+    """methods/spectrum.py:161-169: whiten with cov^{-1/2}, diagonalise the whitened quad; the aligned functions
+    eigfuncs @ (V^T cov^{-1/2})^T, sqrt of the (descending) eigenvalues, and the identity as their Gram matrix."""
+    from scipy.linalg import eigh
+    ec, vc = eigh(cov)
+    whitening = vc @ np.diag(1 / np.sqrt(ec)) @ vc.T
+    ev, V = eigh(whitening @ quad @ whitening)
+    ev = np.sqrt(ev[::-1])
+    V = V[:, ::-1]
+    return eigfuncs @ (V.T @ whitening).T, ev, np.eye(quad.shape[0])

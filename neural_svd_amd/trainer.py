@@ -675,10 +675,24 @@ class GraphedSteps:
             torch.cuda.current_stream().wait_stream(side)
             # capture only recorded the launches: the host counters go back, replay() advances them
             tr.t, tr.num_updates, tr.batches_drawn = before
+        # host-side decisions frozen into the graph (whether the forward may read the bf16 planes of the weights, the
+        # device-resident schedule position): replay() re-validates them
+        self._version = tr.P.version
+        self._expect = (before[1] - before[0], before[2] - before[0])
 
     def replay(self, n: int = 1) -> None:
         """n replays = n * steps optimiser steps"""
         tr = self.tr
+        if tr.P.version != self._version:
+            # P.load / load_state_dict / apply changed the weights behind the graph's back: a captured bf16x3 forward
+            # would go on reading the planes of the OLD weights
+            raise H.NsvdError("GraphedSteps.replay: the parameters were changed from the host since the capture "
+                              "(P.version moved): capture the steps again")
+        if (tr.num_updates - tr.t, tr.batches_drawn - tr.t) != self._expect:
+            # the step counter itself lives on the device (nsvd_step_state, advanced by eager and replayed steps alike);
+            # what the graph froze are the OFFSETS of the EMA and sampler counters from it
+            raise H.NsvdError("GraphedSteps.replay: the trainer's counters (t / num_updates / batches_drawn) were "
+                              "changed from the host since the capture: capture the steps again")
         for _ in range(n):
             self.graph.replay()
         k = n * self.steps

@@ -92,13 +92,170 @@ def test_reference_style_pipeline(case):
     assert np.allclose(np.diag(out["cov"]), 1.0, atol=1e-5)
 
 
-def test_foreign_operator_is_refused():
-    from neural_svd_amd._lib import NsvdError
+class _PlainHarmonicOperator:
+    """A foreign operator with the reference's contract operator(model, x, importance=None) -> (Tf, f)
+    (examples/__init__.py:7-9): the harmonic-oscillator Hamiltonian with the point-wise central-difference stencil
+    and the Gaussian re-weighting (diff_ops.py:9-52, schrodinger/__init__.py:16-22), in plain torch around model(x)."""
+
+    def __init__(self, eps, scale, shift, k=1.0):
+        self.eps, self.scale, self.shift, self.k = eps, scale, shift, k
+
+    def __call__(self, model, x, importance=None):
+        x = x.reshape(x.shape[0], -1)
+        D = x.shape[1]
+        g = (lambda z: importance(z).sqrt() * model(z)) if importance is not None else model
+        gs = g(x)
+        lap = -2 * D * gs
+        for i in range(D):
+            e = torch.zeros((1, D), device=x.device)
+            e[0, i] = self.eps
+            lap = lap + g(x + e) + g(x - e)
+        lap = lap / self.eps ** 2
+        sw = torch.clamp(importance(x).sqrt(), min=1e-5) if importance is not None else 1.0
+        lap, fs = lap / sw, gs / sw
+        V = (self.k * x.norm(dim=1, p=2) ** 2).reshape(-1, 1)
+        Tf = -(-lap + V * fs)
+        return self.scale * Tf + self.shift * fs, fs
+
+
+def test_foreign_operator_falls_back():
+    """methods/nestedlora.py:254-267 takes ANY callable operator(model, x, importance): a plain-torch restatement of the
+    harmonic Hamiltonian goes through NestedLoRA.compute_loss_operator (model evaluations and the loss on the HIP
+    kernels, the operator's algebra in torch) and gives the fused path's loss and gradients. eps = 0.1 keeps the
+    point-wise float32 stencil's rounding noise (~ 1e-7 |g| (2D + 2) / eps^2) below the 1e-4 asserted."""
     z = G.load("model_small")
-    _, _, operator, _, method, loaders = build("hyd_small", z)
-    x = torch.randn(8, 2, device=DEV)
-    with pytest.raises(NsvdError):
-        method.compute_loss_operator(lambda m, xx, importance=None: (xx, xx), x, importance=loaders[3])
+    res = {}
+    for kind in ("fused", "foreign"):
+        cfg, args, operator, gt, method, loaders = build("osc_small", z)
+        operator.operator.laplacian_eps = 0.1
+        imp = loaders[3]
+        op = operator if kind == "fused" else _PlainHarmonicOperator(0.1, operator.scale, operator.shift)
+        x = torch.tensor(z["osc_small_x"][0]).to(DEV)
+        method.train()
+        loss, aux = method.compute_loss_operator(op, x, importance=imp)
+        loss.backward()
+        res[kind] = (float(loss.detach()), aux["f"].detach().clone(), aux["Tf"].detach().clone(),
+                     {n: p.grad.detach().clone() for n, p in method.named_parameters() if p.requires_grad})
+    assert rel(res["foreign"][1], res["fused"][1]) < 1e-6
+    assert rel(res["foreign"][2], res["fused"][2]) < 1e-4
+    assert abs(res["foreign"][0] - res["fused"][0]) < 1e-4 * abs(res["fused"][0])
+    for n, g in res["fused"][3].items():
+        assert rel(res["foreign"][3][n], g) < 1e-4, n
+    # evaluation takes the same callable (methods/spectrum.py:62)
+    from neural_svd_amd.spectrum import compute_spectrum_evd
+    cfg, args, operator, gt, method, (mb, val_data, batch_ftn_val, imp, imp_val) = build("osc_small", z)
+    operator.operator.laplacian_eps = 0.1
+    method.eval()
+    a = compute_spectrum_evd(method, dataloader=batch_ftn_val(), operator=operator, importance_train=imp,
+                             importance_val=imp_val, device=DEV)
+    b = compute_spectrum_evd(method, dataloader=batch_ftn_val(),
+                             operator=_PlainHarmonicOperator(0.1, operator.scale, operator.shift),
+                             importance_train=imp, importance_val=imp_val, device=DEV)
+    assert np.allclose(a["eigvals"], b["eigvals"], rtol=1e-4)
+    with pytest.raises(Exception):
+        method.compute_loss_operator(lambda m, xx, importance=None: (xx, xx), torch.randn(8, 2, device=DEV),
+                                     importance=imp)  # (B, D) is not (B, L): refused with a shape message
+
+
+@pytest.mark.parametrize("mode", ["laplacian", "uniform"])
+def test_laplace_and_uniform_samplers(mode):
+    """--sampling_mode laplacian / uniform (main_pde.py:101-118): the sampler, its importance density, and a step
+    through the reference's stencil around HIP model evaluations (OperatorWrapper.apply_stencil), against the float64
+    oracle model evaluated at the same stencil points with the same density."""
+    from neural_svd_amd.models import get_wavefunctions
+    from neural_svd_amd.nested_lowrank import get_evd_method
+    from neural_svd_amd.operators import get_dataloader, get_problem
+    z = G.load("model_small")
+    cfg = dict(G.cfg_of(z, "osc_small"), sampling_mode=mode, laplacian_eps=0.1, batch_size=64)
+    args = make_args(cfg)
+    torch.manual_seed(3)
+    operator, gt = get_problem(args, DEV)
+    method = get_evd_method(args, "neuralsvd", get_wavefunctions(args)).to(DEV)
+    make_batch, val_data, batch_ftn_val, imp, imp_val = get_dataloader(args, DEV)
+    x = make_batch()
+    assert x.shape == (64, 1, 2) and x.device.type == "cuda"
+    s = cfg["sampling_scale"]
+    x2 = x.reshape(64, 2).double().cpu()
+    if mode == "uniform":
+        assert float(x.abs().max()) <= s
+        p64 = torch.full((64, 1), 1.0 / (2 * s) ** 2, dtype=torch.float64)
+        dens = lambda q: torch.full((q.shape[0], 1), 1.0 / (2 * s) ** 2, dtype=torch.float64)  # noqa: E731
+    else:
+        dens = lambda q: torch.exp(-(q.abs() / s).sum(-1, keepdim=True)) / (2 * s) ** 2  # noqa: E731
+        p64 = dens(x2)
+    assert rel(imp(x), p64) < 1e-6
+    method.train()
+    loss, aux = method.compute_loss_operator(operator, x, importance=imp)
+    loss.backward()
+    # float64 restatement with the oracle's model
+    names = [n for n, _ in method.named_parameters()]
+    sd = {k: v.detach().double().cpu() for k, v in method.state_dict().items()}
+    nl = len([n for n in names if ".ws." in n])
+    p = O.Params(fourier_B=sd["model.base.feature_map._B"], ws=[sd[f"model.base.ws.{i}"] for i in range(nl)],
+                 bs=[sd[f"model.base.bs.{i}"] for i in range(nl)], scales=sd["model.boundary_mask.scales"])
+
+    def model64(q):
+        return O.mlp_forward(O.fourier_features(q, p.fourier_B), p) * O.boundary_mask(q, p)
+    g = lambda q: dens(q).sqrt() * model64(q)  # noqa: E731
+    gs = g(x2)
+    lap = -4 * gs
+    for i in range(2):
+        e = torch.zeros(1, 2, dtype=torch.float64)
+        e[0, i] = 0.1
+        lap = lap + g(x2 + e) + g(x2 - e)
+    sw = torch.clamp(dens(x2).sqrt(), min=1e-5)
+    lap, fs = lap / 0.01 / sw, gs / sw
+    Tf = -(-lap + (x2.norm(dim=1) ** 2).reshape(-1, 1) * fs)
+    Tf = cfg["operator_scale"] * Tf + cfg["operator_shift"] * fs
+    assert rel(aux["f"], fs) < 1e-5
+    assert rel(aux["Tf"], Tf) < 2e-4
+    v, M = O.joint_nesting_masks(cfg["neigs"], 1)
+    l64, *_ = O.evd_loss_forward(fs, Tf, v.double(), M.double())
+    assert abs(float(loss.detach()) - float(l64)) < 2e-4 * abs(float(l64))
+    for n, q in method.named_parameters():
+        assert (q.grad is not None) == q.requires_grad
+    # the evaluation path weights the rows itself for these densities
+    from neural_svd_amd.spectrum import compute_spectrum_evd
+    method.eval()
+    out = compute_spectrum_evd(method, dataloader=batch_ftn_val(), operator=operator, importance_train=imp,
+                               importance_val=imp_val, device=DEV)
+    assert out["eigvals"].shape == (cfg["neigs"],) and np.isfinite(out["eigvals"]).all()
+
+
+def test_spectrum_first_mode_const_and_post_align():
+    """compute_spectrum_evd(set_first_mode_const=True, post_align=True) (methods/spectrum.py:68-70,98-101,161-169): the
+    constant-one column in front of the weighted phi / Tphi and the whitened re-diagonalisation, against numpy on the
+    HIP path's own f, Tf."""
+    from neural_svd_amd.spectrum import compute_spectrum_evd
+    z = G.load("model_small")
+    cfg, args, operator, gt, method, (mb, val_data, batch_ftn_val, imp, imp_val) = build("osc_small", z)
+    method.eval()
+    L = cfg["neigs"]
+    out = compute_spectrum_evd(method, dataloader=batch_ftn_val(), operator=operator, importance_train=imp,
+                               importance_val=imp_val, set_first_mode_const=True, device=DEV)
+    plain = compute_spectrum_evd(method, dataloader=batch_ftn_val(), operator=operator, importance_train=imp,
+                                 importance_val=imp_val, post_align=True, device=DEV)
+    assert out["cov"].shape == (L + 1, L + 1) and np.allclose(out["cov"][1:, 1:], plain["cov"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(out["quad"][1:, 1:], plain["quad"], rtol=1e-6, atol=1e-9)
+    # the padded column by hand
+    with torch.no_grad():
+        Tphi, phi = operator(method, val_data, importance=imp)
+    w = (imp(val_data).sqrt() / imp_val(val_data).sqrt()).double().cpu().numpy()
+    ph = np.nan_to_num(w * phi.double().cpu().numpy())
+    tp = np.nan_to_num(w * Tphi.double().cpu().numpy())
+    nz = ~np.all(np.isclose(val_data.cpu().numpy(), 0.0), axis=1)
+    n = len(val_data)
+    assert np.isclose(out["cov"][0, 0], 1.0) and np.isclose(out["quad"][0, 0], nz.sum() / n)
+    assert np.allclose(out["cov"][0, 1:], ph.sum(0) / n, rtol=1e-5, atol=1e-8)
+    assert np.allclose(out["quad"][0, 1:], (tp * nz[:, None]).sum(0) / n, rtol=1e-5, atol=1e-7)
+    assert np.allclose(out["quad"][1:, 0], (ph * nz[:, None]).sum(0) / n, rtol=1e-5, atol=1e-8)
+    # post_align: orthonormal aligned functions under the grid measure, eigenvalues = sqrt of the whitened quad's
+    ef, ev, I = plain["eigfuncs_aligned"], plain["eigvals_aligned"], plain["cov_aligned"]
+    assert ef.shape == plain["eigfuncs"].shape and ev.shape == (L,) and np.array_equal(I, np.eye(L))
+    from scipy.linalg import eigh
+    ec, vc = eigh(plain["cov"].astype(np.float64))
+    wh = vc @ np.diag(ec ** -0.5) @ vc.T
+    assert np.allclose(np.sort(ev ** 2), np.sort(eigh(wh @ plain["quad"].astype(np.float64) @ wh)[0]), rtol=1e-4)
 
 
 @pytest.mark.parametrize("iters,lr,tol", [(1, 1e-3, 2e-6), (12, 1e-5, 2e-3)])
@@ -239,6 +396,32 @@ def test_train_operator_smoke():
         assert torch.isfinite(p).all()
         if p.requires_grad:
             assert not torch.equal(p, before[n]), n
+
+
+@pytest.mark.parametrize("batch", [None, 2048])
+def test_train_operator_writes_the_reference_csv_columns(batch, tmp_path):
+    """main_pde.py:195-198 / examples/utils.py:40-45 hand train_operator a csv.DictWriter with exactly the fields iter,
+    train_loss, avg_train_loss, time (extrasaction='raise'): every printed row must carry those keys and no other -
+    also where the loss is only sampled (batches above 1024 rows, several ranks: loss_stride > 1)."""
+    import csv
+    from neural_svd_amd.drop_in import train_operator
+    z = G.load("model_headline")
+    cfg, args, operator, gt, method, (make_batch, val_data, batch_ftn_val, imp_train, imp_val) = build("hyd_med", z)
+    if batch is not None:
+        from neural_svd_amd.operators import get_dataloader
+        args.batch_size = batch
+        make_batch, val_data, batch_ftn_val, imp_train, imp_val = get_dataloader(args, DEV)
+    args.num_iters, args.print_freq = 64, 32
+    path = tmp_path / "log.csv"
+    with open(path, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=["iter", "train_loss", "avg_train_loss", "time"])
+        w.writeheader()
+        train_operator(args, method, operator, make_batch, val_data, batch_ftn_val, w, fh, DEV, imp_train, imp_val, gt)
+    rows = list(csv.DictReader(open(path)))
+    assert [int(r["iter"]) for r in rows] == [32, 64]
+    for r in rows:
+        assert set(r) == {"iter", "train_loss", "avg_train_loss", "time"}
+        assert np.isfinite(float(r["train_loss"])) and np.isfinite(float(r["avg_train_loss"]))
 
 
 def test_train_operator_use_amp_selects_the_split_bf16_forward():

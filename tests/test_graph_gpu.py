@@ -265,3 +265,25 @@ def test_bf16x3_step_leaves_the_planes_of_the_updated_weights(L, m, B, potential
             e.step()
         torch.cuda.synchronize()
         _same(e, g)
+
+
+def test_graph_replay_refuses_weights_changed_behind_its_back():
+    """A captured step froze host-side decisions (bf16x3: whether the forward may read the planes of the weights): after
+    P.load / load_state_dict (P.version moves) or a host-side edit of the counters, replay() must refuse, not run on."""
+    from neural_svd_amd import hip_ops as H
+    g = _trainer(4, 64, 64, True)
+    gs = g.capture_graph(2)
+    gs.replay(2)
+    sd = g.P.state_dict()
+    g.P.load_state_dict(sd, reset_optimizer=False)
+    with pytest.raises(H.NsvdError, match="capture the steps again"):
+        gs.replay()
+    g2 = _trainer(4, 64, 64, True)
+    gs2 = g2.capture_graph(2)
+    gs2.replay()
+    g2.num_updates = 0
+    with pytest.raises(H.NsvdError, match="counters"):
+        gs2.replay()
+    gs3 = g2.capture_graph(2)  # a fresh capture takes the new offsets
+    gs3.replay()
+    torch.cuda.synchronize()
