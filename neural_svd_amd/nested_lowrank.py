@@ -280,8 +280,9 @@ class NestedLoRA(nn.Module):
                       f"fused operator kernel is bypassed (it is called with the HIP model; the loss runs on the HIP "
                       f"EVD kernels)")
             Tf, f = operator(self, x, importance=importance) if importance is not None else operator(self, x)
-            if f.dim() != 2 or Tf.shape != f.shape:
-                raise NsvdError(f"operator returned Tf {tuple(Tf.shape)}, f {tuple(f.shape)}: expected two (B, L) tensors")
+            if f.dim() != 2 or Tf.shape != f.shape or f.shape[1] != self.neigs:
+                raise NsvdError(f"operator returned Tf {tuple(Tf.shape)}, f {tuple(f.shape)}: expected two "
+                                f"(B, {self.neigs}) tensors")
             return Tf.float().contiguous(), f.float().contiguous()
         if not operator.fused(importance):
             # Laplace / uniform / any other density: the wrapper applies the stencil around HIP model evaluations

