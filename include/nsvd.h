@@ -436,12 +436,19 @@ typedef struct nsvd_tower_params {
     float *W2, *b2, *g2, *be2, *rm2, *rv2;
 } nsvd_tower_params;
 size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2);
-/*   gemm_bf16 != 0: MIXED PRECISION - the operands of the five contractions are rounded to bfloat16 (round to
- *   nearest even) and multiplied on the bf16 MFMA with float32 accumulation; BatchNorm, activation, gradients,
- *   statistics and every stored tensor stay float32. The role of the reference's autocast branch
- *   (examples/cdk/sketchy/main_sketchy.py:161,182, on by default there) without its float16 / GradScaler dynamics:
- *   not bit-comparable with it, pinned to the float64 oracle of the same rounding instead. The backward must be called
- *   with the flag of its forward (the workspace then holds bfloat16 activations where it otherwise holds float32). */
+/*   gemm_bf16 != 0: MIXED PRECISION, the role of the reference's autocast branch (examples/cdk/sketchy/
+ *   main_sketchy.py:161,182, on by default there: Linear and BatchNorm / activation outputs are half tensors, statistics
+ *   and master weights float32) with bfloat16 as the half type and no GradScaler: X, W1, W2 are rounded to bfloat16
+ *   (round to nearest even), the wide activations Y1 = X W1^T + b1, A1 = lrelu(BN1(Y1)) and the gradients dY2, dA1, dY1
+ *   are STORED as bfloat16, the five contractions run on the bf16 MFMA with float32 accumulation (csrc/gemm16.h, no
+ *   transposed copies), BatchNorm statistics, the narrow end (Y2, Z) and every parameter gradient stay float32.
+ *   Not bit-comparable with float16 autocast; pinned to the float64 oracle with the same roundings. Shapes:
+ *   nsvd_tower_mixed_supported (B, d1, d2 multiples of 256, d0 of 128, B <= 1024), NSVD_EUNSUPPORTED otherwise. The
+ *   backward must be called with the flag of its forward (the workspace holds bfloat16 activations).
+ *   Bit 1 (value 2) of the flag, forward only: the bfloat16 copies of W1 / W2 inside `ws` are current - set by callers
+ *   that know the weights have not changed since the copies were written (nsvd_cdk_step's optimiser kernel refreshes
+ *   them while it updates the float32 masters); clear, the forward casts the masters first. */
+int nsvd_tower_mixed_supported(int B, int d0, int d1, int d2);
 int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, int d0, int d1, int d2, float slope,
                        float eps, float momentum, int update_running, int gemm_bf16, float* z, void* ws,
                        size_t ws_bytes, void* stream);
@@ -518,12 +525,29 @@ typedef struct nsvd_cdk_step_desc {
     int32_t set_first_mode_const;
     double lr, momentum, max_grad_norm;
     int32_t first_step;
-    int32_t gemm_bf16;            /* != 0: the towers' contractions in mixed precision (nsvd_tower_forward) */
+    int32_t gemm_bf16;            /* != 0: the towers in mixed precision (nsvd_tower_forward; bit 1: this workspace's
+                                   * bfloat16 weight copies are those the previous nsvd_cdk_step call left) */
 } nsvd_cdk_step_desc;
 size_t nsvd_cdk_step_workspace_bytes(const nsvd_cdk_step_desc* desc);
 int nsvd_cdk_step(const nsvd_cdk_step_desc* desc, const float* x, const float* y, const nsvd_tower_params* towers,
                   const nsvd_tower_params* momentum_bufs, const float* v, const float* M, float* loss,
                   float* rs_joint, float* rs_indep, void* ws, size_t ws_bytes, void* stream);
+
+/* C = A B^T on the bf16 MFMA, float32 accumulation: the contraction of the mixed-precision towers (csrc/gemm16.h) as an
+ * entry point of its own - what torch.matmul on bfloat16 tensors is to the reference's autocast branch
+ * (examples/cdk/sketchy/main_sketchy.py:182; the reference's half type is float16). A, B hold bfloat16 values.
+ *   a_kstrided == 0: A is (M, lda), row m = the K contraction values of output row m (contiguous)
+ *   a_kstrided != 0: A is (K, lda), row k = the M values of contraction index k (A^T as stored: no transposed copy)
+ *   likewise B / b_kstrided with N columns of C. (A strided with B contiguous is not built.)
+ * C (M, ldc): float32, or bfloat16 when out_bf16; bias (N) is added per column when not NULL. slices > 1: split-K,
+ * slice s contracts k in [s K / slices, (s + 1) K / slices) into C + s * slice_stride (elements; bias goes to every
+ * slice: pass NULL). sumsq: NULL, or (M / 256) (N / 128) slices floats - per tile, the sum of squares of what was stored.
+ * M % 256 == 0, N % 128 == 0, K % (64 slices) == 0, lda, ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned pointers. */
+int nsvd_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
+                   long ldc, int a_kstrided, int b_kstrided, int out_bf16, int slices, long slice_stride, float* sumsq,
+                   void* stream);
+/* out[i] = bfloat16(in[i]) (round to nearest even), n % 8 == 0, 16-byte aligned pointers */
+int nsvd_to_bf16(const float* in, void* out, size_t n, void* stream);
 
 /* Measurement aid (bench.py): record the two hipEvent_t handles immediately before / after the
  * DOMINANT kernel of the next nsvd_operator_forward call made by this host thread (the fused MFMA

@@ -126,9 +126,12 @@ SIGNATURES = {
     "nsvd_spectrum_accumulate_f64": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
     "nsvd_spectrum_accumulate_const_f64": (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _P, _P]),
     "nsvd_step_emits_planes": (_I, [C.POINTER(ModelDesc), _I, _I]),
+    "nsvd_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, C.c_long, C.c_long, C.c_long, _I, _I, _I, _I, C.c_long, _P, _P]),
+    "nsvd_to_bf16": (_I, [_P, _P, _Z, _P]),
     "nsvd_row_normalize_forward": (_I, [_P, _I, _I, _F, _I, _P, _P]),
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
     "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "nsvd_tower_mixed_supported": (_I, [_I, _I, _I, _I]),
     "nsvd_tower_forward": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _P, _P, _Z, _P]),
     "nsvd_tower_forward_phase": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _P, _P, _Z, _P]),
     "nsvd_tower_y2_offset": (_Z, [_I, _I, _I, _I]),

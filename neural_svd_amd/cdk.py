@@ -207,9 +207,10 @@ class _TowerFn(torch.autograd.Function):
     """Linear -> BatchNorm1d -> LeakyReLU -> Linear -> BatchNorm1d in training mode on the HIP tower kernels
     (csrc/tower.hip: five fp32-MFMA contractions and four BatchNorm strip kernels for forward + backward).
     Under ``torch.autocast`` (the reference's Sketchy loop wraps ``method(x, y)`` in it unless --disable_amp,
-    main_sketchy.py:182) the contractions run in this library's mixed-precision mode - bfloat16-rounded operands,
-    float32 accumulation, float32 everything else (nsvd.h: gemm_bf16) - and the output stays float32; a GradScaler
-    around it is harmless (float32 gradients neither overflow nor underflow under its scale)."""
+    main_sketchy.py:182) the tower runs in this library's mixed-precision mode - bfloat16 operands and wide
+    activations, float32 accumulation, statistics and parameter gradients (nsvd.h: gemm_bf16; shapes:
+    nsvd_tower_mixed_supported, float32 kernels otherwise) - and the output stays float32; a GradScaler around it is
+    harmless (bfloat16 has float32's exponent range: its scale neither rescues nor overflows anything)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, seq):
@@ -220,7 +221,9 @@ class _TowerFn(torch.autograd.Function):
                  rm2=bn2.running_mean, rv2=bn2.running_var)
         ws = H.tower_workspace(xd.shape[0], W1.shape[1], W1.shape[0], W2.shape[0], xd.device)
         track = bn1.track_running_stats and bn1.running_mean is not None
-        mixed = bool(torch.is_autocast_enabled())
+        # (autocast on a shape the mixed-precision kernels do not take: the float32 kernels - more precise, never less)
+        mixed = bool(torch.is_autocast_enabled()) and H.tower_mixed_supported(xd.shape[0], W1.shape[1], W1.shape[0],
+                                                                              W2.shape[0])
         z = H.tower_forward(xd, t, seq.slope, bn1.eps, bn1.momentum, track, ws, gemm_bf16=mixed)
         if track:
             bn1.num_batches_tracked += 1
@@ -326,16 +329,18 @@ class FusedCdkStep:
     batch the tower kernels take; ``supported(method, batch_size)`` says whether it is.
 
     use_amp: the script runs its step under ``torch.cuda.amp.autocast`` + ``GradScaler`` unless ``--disable_amp``
-    (main_sketchy.py:161,182). True selects this library's MIXED-PRECISION mode, the counterpart of that branch: the ten
-    tower contractions of a step multiply bfloat16-rounded operands on the bf16 MFMA with float32 accumulation;
-    BatchNorm, activations, loss, gradients, clipping and the update stay float32, so there is no loss scaling and no
-    skipped step. It is NOT bit-comparable with float16 autocast (different 16-bit format, different set of
-    reduced-precision ops); it is pinned to the float64 oracle with the same operand rounding. False (default): float32
+    (main_sketchy.py:161,182). True selects this library's MIXED-PRECISION mode, the counterpart of that branch with
+    bfloat16 as the half type: operands, the wide activations and their gradients are bfloat16, the ten contractions of
+    a step run on the bf16 MFMA with float32 accumulation (both towers through every launch together, no transposed or
+    re-cast copies: the optimiser kernel leaves the bfloat16 weights of the next step), BatchNorm statistics, the loss,
+    parameter gradients, clipping and the update stay float32 - no loss scaling, no skipped step. NOT bit-comparable with
+    float16 autocast; pinned to the float64 oracle with the same roundings. Batch and the towers' two output widths must
+    be multiples of 256. False (default): float32
     throughout - the script's --disable_amp."""
 
     def __init__(self, method: "NestedLoRAForCDK", lr: float, momentum: float = 0.9, max_grad_norm: float = 1.0,
                  t_max: int = 0, batch_size: int = 1024, use_amp: bool = False):
-        ok, why = self.supported(method, batch_size)
+        ok, why = self.supported(method, batch_size, use_amp)
         if not ok:
             raise H.NsvdError(f"FusedCdkStep: {why}")
         model = method.model
@@ -343,6 +348,7 @@ class FusedCdkStep:
         self.lr0, self.momentum, self.max_grad_norm, self.t_max = float(lr), float(momentum), float(max_grad_norm or 0.0), int(t_max)
         self.t = 0
         self._pending = 0
+        self._weight_versions = None
         self.use_amp = bool(use_amp)
         tx = model.backbones["x"]
         self.B, self.d0, self.d1, self.d2 = int(batch_size), tx[0].in_features, tx[0].out_features, tx[3].out_features
@@ -365,7 +371,7 @@ class FusedCdkStep:
         self.ws = H.cdk_step_workspace(self._desc(self.lr0, True), dev)
 
     @staticmethod
-    def supported(method, batch_size: int):
+    def supported(method, batch_size: int, use_amp: bool = False):
         model = getattr(method, "model", None)
         if not isinstance(method, NestedLoRAForCDK) or not isinstance(model, HeteroNetwork):
             return False, "needs NestedLoRAForCDK over a HeteroNetwork"
@@ -386,12 +392,28 @@ class FusedCdkStep:
             return False, "neigs must equal the towers' output width"
         if not H.tower_supported(batch_size, d0, d1, d2):
             return False, f"tower shape {(batch_size, d0, d1, d2)} outside the tower kernels (multiples of 128, B <= 1024)"
+        if use_amp and not H.tower_mixed_supported(batch_size, d0, d1, d2):
+            return False, (f"tower shape {(batch_size, d0, d1, d2)} outside the mixed-precision kernels (batch and the "
+                           f"two output widths multiples of 256)")
         return True, ""
 
-    def _desc(self, lr, first):
+    def _weights(self):
+        """the four weight Parameters whose bfloat16 copies the mixed-precision step keeps in its workspace"""
+        return [self.model.backbones[side][i].weight for side in HeteroNetwork.SIDES for i in (0, 3)]
+
+    def weights_changed(self) -> None:
+        """Mixed precision: tell the step that W1 / W2 were modified from outside (the next step casts them again).
+        In-place operations on the Parameters themselves (optimizer steps, load_state_dict, copy_) are noticed without
+        this call - they move the Parameters' version counters; writes through ``.data`` or raw pointers are not."""
+        self._weight_versions = None
+
+    def _desc(self, lr, first, weights_ready=False):
+        # gemm_bf16 bit 1: the bfloat16 copies of W1 / W2 inside the workspace are the ones the previous step's
+        # optimiser kernel wrote, and nothing has touched the float32 masters since (their torch version counters:
+        # the C call updates them through raw pointers, which bumps nothing)
         return H.cdk_step_desc(self.B, self.d0, self.d1, self.d2, self.slope, self.bn_eps, self.bn_momentum,
                                self.model.mu, self.mode, self.first_const, lr, self.momentum, self.max_grad_norm, first,
-                               gemm_bf16=self.use_amp)
+                               gemm_bf16=(3 if weights_ready else 1) if self.use_amp else 0)
 
     def current_lr(self) -> float:
         """CosineAnnealingLR(optimizer, t_max) after self.t scheduler steps (t_max = 0: constant)"""
@@ -405,8 +427,11 @@ class FusedCdkStep:
         gradient norm before clipping) - no synchronisation"""
         if not self.model.training:
             raise H.NsvdError("FusedCdkStep.step: the model must be in training mode")
-        H.cdk_step(self._desc(self.current_lr(), self.t == 0), x.float().contiguous(), y.float().contiguous(),
+        vers = [(w.data_ptr(), w._version) for w in self._weights()]
+        ready = self.use_amp and self.t > 0 and vers == self._weight_versions
+        H.cdk_step(self._desc(self.current_lr(), self.t == 0, ready), x.float().contiguous(), y.float().contiguous(),
                    self.towers, self.bufs, self.v, self.M, self.loss, self.ws, rs_joint, rs_indep)
+        self._weight_versions = vers
         self.t += 1
         self._pending += 1
         if self._pending >= 256:
@@ -446,15 +471,16 @@ class ShardedCdkStep:
 
     def __init__(self, method: "NestedLoRAForCDK", comm, lr: float, momentum: float = 0.9, max_grad_norm: float = 1.0,
                  t_max: int = 0, batch_size: int = 1024, use_amp: bool = False):
-        ok, why = FusedCdkStep.supported(method, batch_size)
+        ok, why = FusedCdkStep.supported(method, batch_size, use_amp)
         if not ok:
             raise H.NsvdError(f"ShardedCdkStep: {why}")
         self.method, self.model, self.comm = method, method.model, comm
         W, r = comm.world, comm.rank
         tx = self.model.backbones["x"]
         self.B, self.d0, d1, self.d2 = int(batch_size), tx[0].in_features, tx[0].out_features, tx[3].out_features
-        if d1 % (128 * W) != 0:
-            raise H.NsvdError(f"ShardedCdkStep: hidden width {d1} must split into multiples of 128 over {W} ranks")
+        q = 256 if use_amp else 128
+        if d1 % (q * W) != 0:
+            raise H.NsvdError(f"ShardedCdkStep: hidden width {d1} must split into multiples of {q} over {W} ranks")
         self.d1_full, self.d1 = d1, d1 // W
         self.lo, self.hi = r * self.d1, (r + 1) * self.d1
         self.lr0, self.momentum, self.max_grad_norm, self.t_max = float(lr), float(momentum), float(max_grad_norm or 0.0), int(t_max)

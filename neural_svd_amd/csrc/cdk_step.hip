@@ -20,6 +20,8 @@ constexpr int SUMSQ_BLOCKS = 64;    // blocks of the small-tensor pass
 struct TensorTable {
     float* p[2 * NT];
     float* buf[2 * NT];
+    unsigned short* h[2 * NT];  // null, or where the updated parameter is ALSO written as bfloat16 (mixed precision: the
+                                // operand copies of W1 / W2 the next step's contractions read - no cast pass per step)
     const float* g[2 * NT];
     size_t n[2 * NT];
     size_t start[2 * NT + 1];  // prefix sums in float4 groups (every tensor padded to a multiple of 4 in the tables)
@@ -93,6 +95,13 @@ __global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float
             pv.z = fmaf(-lr, bv.z, pv.z); pv.w = fmaf(-lr, bv.w, pv.w);
             *reinterpret_cast<float4*>(b) = bv;
             *reinterpret_cast<float4*>(p) = pv;
+            if (t.h[k]) {
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<uint2*>(t.h[k] + e) =
+                    make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.x, pv.y}, bf2)),
+                               __builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.z, pv.w}, bf2)));
+            }
         } else {
             for (size_t c = 0; c < left; ++c) {
                 const float gc = g[c] * coef;
@@ -146,7 +155,7 @@ StepWs carve_step(const nsvd_cdk_step_desc& d, void* base) {
         g += (n[k] + 63) / 64 * 64;
     }
     for (int s = 0; s < 2; ++s) w.grad[s] = (float*)take(g * sizeof(float));
-    w.npartial = SUMSQ_BLOCKS + 2 * nsvd_tower_sumsq_count(d.d0, d.d1, d.d2);
+    w.npartial = SUMSQ_BLOCKS + 2 * nsvd_tower_sumsq_count(d.d0, d.d1, d.d2, d.gemm_bf16 != 0);
     w.partial = (float*)take((size_t)w.npartial * sizeof(float));
     w.scal = (float*)take(256);
     w.bytes = off;
@@ -156,6 +165,7 @@ StepWs carve_step(const nsvd_cdk_step_desc& d, void* base) {
 bool desc_ok(const nsvd_cdk_step_desc* d) {
     if (!d) return false;
     if (nsvd_tower_workspace_bytes(d->B, d->d0, d->d1, d->d2) == 0) return false;
+    if (d->gemm_bf16 != 0 && !nsvd_tower_mixed_supported(d->B, d->d0, d->d1, d->d2)) return false;
     if (d->normalize_mode != NSVD_NORMALIZE_L2_BALL && d->normalize_mode != NSVD_NORMALIZE_L2_SPHERE) return false;
     if (!(d->mu > 0.f)) return false;
     return true;
@@ -188,10 +198,19 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     const float* in[2] = {x, y};
     int rc = 0;
     // forward: towers (BatchNorm running statistics updated, as a training-mode module does), normalisation
-    for (int t = 0; t < 2; ++t) {
-        rc = nsvd_tower_forward(in[t], &towers[t], B, d->d0, d->d1, d->d2, d->slope, d->bn_eps, d->bn_momentum, 1,
-                                d->gemm_bf16, w.z[t], w.tower[t], w.tower_bytes, stream);
+    const bool mixed = d->gemm_bf16 != 0;
+    const nsvd_tower_params* tp[2] = {&towers[0], &towers[1]};
+    if (mixed) {  // both towers through every launch together (tower.hip, mixed-precision section)
+        rc = nsvd_tower16_forward_pair(in, tp, B, d->d0, d->d1, d->d2, d->slope, d->bn_eps, d->bn_momentum, 1,
+                                       d->gemm_bf16, w.z, w.tower, w.tower_bytes, s);
         if (rc) return rc;
+    }
+    for (int t = 0; t < 2; ++t) {
+        if (!mixed) {
+            rc = nsvd_tower_forward(in[t], &towers[t], B, d->d0, d->d1, d->d2, d->slope, d->bn_eps, d->bn_momentum, 1,
+                                    0, w.z[t], w.tower[t], w.tower_bytes, stream);
+            if (rc) return rc;
+        }
         rc = nsvd_row_normalize_forward(w.z[t], B, L, r_up, d->normalize_mode, w.e[t], stream);
         if (rc) return rc;
     }
@@ -205,27 +224,42 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     TensorTable tab;
     memset(&tab, 0, sizeof(tab));
     size_t q4 = 0;
+    nsvd_tower_params gr[2];
+    float* gp[2][NT];
+    const int nsq = nsvd_tower_sumsq_count(d->d0, d->d1, d->d2, mixed);
+    float* sq[2] = {w.partial + SUMSQ_BLOCKS, w.partial + SUMSQ_BLOCKS + nsq};
     for (int t = 0; t < 2; ++t) {
         rc = nsvd_row_normalize_backward(w.z[t], w.ge[t], B, L, r_up, d->normalize_mode, w.dz[t], stream);
         if (rc) return rc;
-        nsvd_tower_params g;
+        nsvd_tower_params& g = gr[t];
         memset(&g, 0, sizeof(g));
-        float* gp[NT];
-        for (int k = 0; k < NT; ++k) gp[k] = w.grad[t] + w.goff[k];
-        g.W1 = gp[0]; g.b1 = gp[1]; g.g1 = gp[2]; g.be1 = gp[3]; g.W2 = gp[4]; g.b2 = gp[5]; g.g2 = gp[6]; g.be2 = gp[7];
-        rc = nsvd_tower_backward_sumsq(in[t], &towers[t], w.dz[t], B, d->d0, d->d1, d->d2, d->slope, d->gemm_bf16, &g,
-                                       w.tower[t], w.tower_bytes,
-                                       w.partial + SUMSQ_BLOCKS + t * nsvd_tower_sumsq_count(d->d0, d->d1, d->d2),
-                                       stream);
+        for (int k = 0; k < NT; ++k) gp[t][k] = w.grad[t] + w.goff[k];
+        g.W1 = gp[t][0]; g.b1 = gp[t][1]; g.g1 = gp[t][2]; g.be1 = gp[t][3];
+        g.W2 = gp[t][4]; g.b2 = gp[t][5]; g.g2 = gp[t][6]; g.be2 = gp[t][7];
+        if (!mixed) {
+            rc = nsvd_tower_backward_sumsq(in[t], &towers[t], w.dz[t], B, d->d0, d->d1, d->d2, d->slope, 0, &g,
+                                           w.tower[t], w.tower_bytes, sq[t], stream);
+            if (rc) return rc;
+        }
+    }
+    if (mixed) {
+        const nsvd_tower_params* gq[2] = {&gr[0], &gr[1]};
+        const float* dzs[2] = {w.dz[0], w.dz[1]};
+        rc = nsvd_tower16_backward_pair(in, tp, dzs, B, d->d0, d->d1, d->d2, d->slope, gq, w.tower, w.tower_bytes, sq, s);
         if (rc) return rc;
+    }
+    for (int t = 0; t < 2; ++t) {
         float *pp[NT], *bb[NT];
         tower_fields(towers[t], pp);
         tower_fields(momentum_bufs[t], bb);
+        void *w1h = nullptr, *w2h = nullptr;
+        if (mixed) nsvd_tower16_weight_copies(B, d->d0, d->d1, d->d2, w.tower[t], &w1h, &w2h);
         for (int k = 0; k < NT; ++k) {
             const int i = t * NT + k;
             if (!pp[k] || !bb[k]) return NSVD_EINVAL;
             if ((((uintptr_t)pp[k] | (uintptr_t)bb[k]) & 15) != 0) return NSVD_EINVAL;
-            tab.p[i] = pp[k]; tab.buf[i] = bb[k]; tab.g[i] = gp[k]; tab.n[i] = w.gn[k];
+            tab.p[i] = pp[k]; tab.buf[i] = bb[k]; tab.g[i] = gp[t][k]; tab.n[i] = w.gn[k];
+            tab.h[i] = k == 0 ? (unsigned short*)w1h : (k == 4 ? (unsigned short*)w2h : nullptr);
             tab.start[i] = q4;
             q4 += (w.gn[k] + 3) / 4;
         }

@@ -1,0 +1,321 @@
+// C = A B^T-style contractions on the bf16 MFMA for the mixed-precision CDK towers (tower16.hip) and
+// nsvd_gemm_bf16 (include/nsvd.h): 256 x 128 output tile per workgroup, K in steps of 64, 8 waves (2 per SIMD, 4 x 2,
+// 64 x 64 per wave = 4 x 4 blocks of v_mfma_f32_16x16x32_bf16), operands global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) into a ring of three stages, one workgroup barrier per K step, the DMA of step t + 2 in
+// flight under the MFMAs of steps t and t + 1. Up to two independent problems of one shape per launch (the two towers).
+// Reference arithmetic this replaces: the five matmuls per tower and step of examples/models/mlp.py:129-164 under
+// torch.cuda.amp.autocast (examples/cdk/sketchy/main_sketchy.py:182) and their autograd backward.
+//
+// Operand forms. Each operand is either k-contiguous ("T": row r of the tile is a row of the matrix, K values
+// contiguous - X, W in the forward) or k-strided ("S": the matrix is stored (K, rows), rows contiguous - the batch-
+// contracted weight gradients dW = dY^T A read dY and A as they are, and dA = dY W reads W as it is): no transposed
+// copies exist anywhere in the mixed-precision tower.
+//   T image  [rows][64 k] bf16, 128-byte rows; the 16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7): the
+//            ds_read_b128 fragment reads of 16 consecutive rows x one chunk pair hit 16 distinct slots of the 256-byte
+//            bank row (MI355X_MICROARCH.md, LDS: lane groups of ds_read_b128).
+//   S image  [64 k][128 rows] bf16 per 128-row block, 256-byte rows; chunk c of k-row q sits in slot
+//            c ^ (((q & 3) << 2) | ((q >> 2) & 3)); fragments by ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane
+//            group, delivered column-major: cdna_hip_programming.md T10, image (b)) - two reads per fragment.
+//   The swizzles are applied on the DMA's per-lane SOURCE address (the LDS destination of an LDS-DMA is lane-linear)
+//   and again on the fragment reads.
+// MFMA orientation: D = mfma(B fragment, A fragment) - the accumulator's lane index is the tile ROW (of A), its four
+// registers four consecutive COLUMNS: one 16-byte (float32) / 8-byte (bfloat16) store per block and lane.
+#pragma once
+#include <stdlib.h>
+#include "nsvd_common.h"
+
+namespace nsvd_g16 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
+constexpr int A_BYTES = BM * BK * 2;         // 32 KB
+constexpr int B_BYTES = BN * BK * 2;         // 16 KB
+constexpr int ST_BYTES = A_BYTES + B_BYTES;  // 48 KB
+constexpr int LDS_BYTES = NST * ST_BYTES;    // 144 KB
+constexpr int NDMA = (A_BYTES + B_BYTES) / 1024 / 8;  // LDS-DMA instructions per wave and stage: 6
+
+struct Prob {
+    const void* A;      // bf16: T form (M, lda), S form (K, lda)
+    const void* B;      // bf16: T form (N, ldb), S form (K, ldb)
+    void* C;            // (M, ldc) float32 or bfloat16; split-K slice s at C + s * slice_stride elements
+    const float* bias;  // per column of C (N) or null
+    float* sumsq;       // null, or one float per workgroup of THIS problem: the sum of squares of its tile of C
+};
+
+struct Args {
+    Prob p[2];
+    int nprob, M, N, K, S;      // S split-K slices of K / S each
+    long lda, ldb, ldc;         // in elements
+    long slice_stride;          // elements of C between split-K slices
+    int tiles_m, tiles_n;
+    int dbg;  // diagnostic builds only (NSVD_G16_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+
+// 16 B per lane global -> LDS: source = sbase (wave-uniform) + voff (per lane, bytes), destination = m0 (wave-uniform LDS
+// byte address) + lane * 16. M0 is written here behind the compiler's back (check_m0.py: nothing else in the
+// translation unit may use it).
+__device__ __forceinline__ void dma16(const char* sbase, unsigned voff, unsigned m0) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0), "v"(voff), "s"(sbase) : "memory");
+}
+
+template <bool AS, bool BS, bool O16>
+__global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+
+    // ---- which tile: XCD-aware order (workgroups b, b + 8, .. share an XCD and its L2: they get a contiguous run of the
+    // tile order, whose fast index runs over the dimension with fewer tiles)
+    const int per = a.tiles_m * a.tiles_n;
+    const int nwg = per * a.S * a.nprob;
+    int id = blockIdx.x;
+    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+    const int prob = id / (per * a.S);
+    id -= prob * per * a.S;
+    const int slice = id / per;
+    id -= slice * per;
+    int tm, tn;
+    if (a.tiles_m <= a.tiles_n) {
+        tn = id / a.tiles_m;
+        tm = id - tn * a.tiles_m;
+    } else {
+        tm = id / a.tiles_n;
+        tn = id - tm * a.tiles_n;
+    }
+    const Prob& P = a.p[prob];
+    const int Ks = a.K / a.S;
+    const int nk = Ks / BK;
+    const long k0 = (long)slice * Ks;
+
+    // ---- DMA sources: wave w moves pieces 4 w .. 4 w + 3 of A and 2 w, 2 w + 1 of B (1 KB each)
+    const char* sa = reinterpret_cast<const char*>(P.A) + 2 * (AS ? (k0 * a.lda + (long)BM * tm) : ((long)BM * tm * a.lda + k0));
+    const char* sb = reinterpret_cast<const char*>(P.B) + 2 * (BS ? (k0 * a.ldb + (long)BN * tn) : ((long)BN * tn * a.ldb + k0));
+    const long sa_step = AS ? 2L * BK * a.lda : 2L * BK;
+    const long sb_step = BS ? 2L * BK * a.ldb : 2L * BK;
+    unsigned va[4], vb[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = 4 * w + j;
+        if (AS) {
+            const int krow = 4 * (p & 15) + (lane >> 4), slot = lane & 15;
+            const int chunk = slot ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
+            va[j] = 2u * ((unsigned)krow * (unsigned)a.lda + 128u * (unsigned)(p >> 4) + 8u * (unsigned)chunk);
+        } else {
+            const int row = 8 * p + (lane >> 3), slot = lane & 7;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            va[j] = 2u * ((unsigned)row * (unsigned)a.lda + 8u * (unsigned)chunk);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = 2 * w + j;
+        if (BS) {
+            const int krow = 4 * p + (lane >> 4), slot = lane & 15;
+            const int chunk = slot ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
+            vb[j] = 2u * ((unsigned)krow * (unsigned)a.ldb + 8u * (unsigned)chunk);
+        } else {
+            const int row = 8 * p + (lane >> 3), slot = lane & 7;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            vb[j] = 2u * ((unsigned)row * (unsigned)a.ldb + 8u * (unsigned)chunk);
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned m0a = lds0 + 4096u * (unsigned)w, m0b = lds0 + A_BYTES + 2048u * (unsigned)w;
+#define G16_ISSUE(stage)                                               \
+    {                                                                  \
+        const unsigned so = (unsigned)(stage) * (unsigned)ST_BYTES;    \
+        dma16(sa, va[0], m0a + so);                                    \
+        dma16(sa, va[1], m0a + so + 1024u);                            \
+        dma16(sa, va[2], m0a + so + 2048u);                            \
+        dma16(sa, va[3], m0a + so + 3072u);                            \
+        dma16(sb, vb[0], m0b + so);                                    \
+        dma16(sb, vb[1], m0b + so + 1024u);                            \
+        sa += sa_step;                                                 \
+        sb += sb_step;                                                 \
+    }
+#define G16_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
+
+    // ---- fragment addresses (byte offsets inside a stage)
+    // T image: block i (16 rows), k32 step s: row r0 + 16 i + (lane & 15), chunk 4 s + (lane >> 4)
+    // S image: block i, k32 step s, half h2: k-row 32 s + 8 (lane >> 4) + 4 h2 + q, q = (lane & 15) >> 2;
+    //          columns mo + 4 (lane & 3) .. + 3 of the 128-row block
+    const int l15 = lane & 15, g4 = lane >> 4;
+    int fa[2] = {0, 0}, fb[2] = {0, 0};  // T images: [k32 step s], blocks at + 2048 i (the S addresses: in the loop)
+    if (!AS) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            fa[s] = (64 * wm + l15) * 128 + (((4 * s + g4) ^ ((l15 >> 1) & 7)) << 4);
+    }
+    if (!BS) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            fb[s] = A_BYTES + (64 * wn + l15) * 128 + (((4 * s + g4) ^ ((l15 >> 1) & 7)) << 4);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // S-image fragment of block i, k32 step s: two transposed reads (k-rows 8 g4 + q and + 4, q = (lane & 15) >> 2; the
+    // lane supplies the address of columns 4 (lane & 3) .. + 3 of the block's 16). The k32 step is + 8192 bytes; the
+    // block enters through its chunk index inside the swizzle
+#define G16_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr))
+
+    G16_ISSUE(0);
+    if (nk > 1) G16_ISSUE(1);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk && !(a.dbg & 1)) G16_WAIT_BARRIER(NDMA);
+        else G16_WAIT_BARRIER(0);
+        if (t + 2 < nk && !(a.dbg & 1)) G16_ISSUE((t + 2) % NST);
+        if (a.dbg & 2) continue;
+        const char* st = lds + (t % NST) * ST_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (AS) {
+                    // block i: chunk index + 2 i inside the swizzle
+                    const int q = l15 >> 2, pp = l15 & 3;
+                    s16x4 lo, hi;
+                    {
+                        const int krow = 8 * g4 + q;
+                        const int chunk = ((64 * (wm & 1) + 16 * i) >> 3) + (pp >> 1);
+                        const int sw0 = ((krow & 3) << 2) | (((krow + 32 * s) >> 2) & 3);
+                        const int sw1 = (((krow + 4) & 3) << 2) | (((krow + 4 + 32 * s) >> 2) & 3);
+                        const char* base = st + 16384 * (wm >> 1) + 8192 * s + 8 * (pp & 1);
+                        lo = G16_TR(base + 256 * krow + 16 * (chunk ^ sw0));
+                        hi = G16_TR(base + 256 * (krow + 4) + 16 * (chunk ^ sw1));
+                    }
+                    af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                } else {
+                    af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa[s] + 2048 * i));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (BS) {
+                    const int q = l15 >> 2, pp = l15 & 3;
+                    s16x4 lo, hi;
+                    {
+                        const int krow = 8 * g4 + q;
+                        const int chunk = ((64 * wn + 16 * j) >> 3) + (pp >> 1);
+                        const int sw0 = ((krow & 3) << 2) | (((krow + 32 * s) >> 2) & 3);
+                        const int sw1 = (((krow + 4) & 3) << 2) | (((krow + 4 + 32 * s) >> 2) & 3);
+                        const char* base = st + A_BYTES + 8192 * s + 8 * (pp & 1);
+                        lo = G16_TR(base + 256 * krow + 16 * (chunk ^ sw0));
+                        hi = G16_TR(base + 256 * (krow + 4) + 16 * (chunk ^ sw1));
+                    }
+                    bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                } else {
+                    bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fb[s] + 2048 * j));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef G16_ISSUE
+#undef G16_WAIT_BARRIER
+#undef G16_TR
+
+    // ---- epilogue: lane = tile row 64 wm + 16 i + (lane & 15); registers = columns 64 wn + 16 j + 4 (lane >> 4) ..+3
+    const long row0 = (long)BM * tm + 64 * wm + l15;
+    const int col0 = BN * tn + 64 * wn + 4 * g4;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.bias) bv = *reinterpret_cast<const float4*>(P.bias + col0 + 16 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float c0 = acc[i][j][0] + bv.x, c1 = acc[i][j][1] + bv.y, c2 = acc[i][j][2] + bv.z,
+                        c3 = acc[i][j][3] + bv.w;
+            ss = fmaf(c0, c0, ss); ss = fmaf(c1, c1, ss); ss = fmaf(c2, c2, ss); ss = fmaf(c3, c3, ss);
+            const long off = (long)slice * a.slice_stride + (row0 + 16 * i) * a.ldc + col0 + 16 * j;
+            if (a.dbg & 4) {
+                asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));
+            } else if (O16) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(P.C) + off) =
+                    make_uint2(pack_bf16(c0, c1), pack_bf16(c2, c3));
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.C) + off) = make_float4(c0, c1, c2, c3);
+            }
+        }
+    }
+    if (P.sumsq) {  // fixed order: lanes of a wave (butterfly), then the eight waves
+        ss = nsvd_wave_sum(ss);
+        __syncthreads();  // every wave is done reading the last stage
+        float* red = reinterpret_cast<float*>(lds);
+        if (lane == 0) red[w] = ss;
+        __syncthreads();
+        if (tid == 0)
+            P.sumsq[slice * per + tm * a.tiles_n + tn] =
+                ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    }
+}
+
+// host side: validate and launch. out_bf16: C holds bfloat16. Returns 0 or NSVD_E*.
+inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16, hipStream_t s) {
+    Args a = a0;
+    if (a.nprob < 1 || a.nprob > 2 || a.S < 1 || a.M <= 0 || a.N <= 0 || a.K <= 0) return NSVD_EINVAL;
+    if (a.M % BM || a.N % BN || a.K % (BK * a.S)) return NSVD_EINVAL;
+    if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 4)) return NSVD_EINVAL;  // 16-byte DMA sources, 8 / 16-byte stores
+    for (int i = 0; i < a.nprob; ++i) {
+        if (!a.p[i].A || !a.p[i].B || !a.p[i].C) return NSVD_EINVAL;
+        if (((uintptr_t)a.p[i].A | (uintptr_t)a.p[i].B | (uintptr_t)a.p[i].C | (uintptr_t)a.p[i].bias) & 15) return NSVD_EINVAL;
+    }
+    // per-lane source offsets are 32-bit: a tile's rows must lie within 4 GB of its origin
+    const long span_a = 2L * (a_strided ? (long)BK * a.lda + BM : (long)BM * a.lda + BK);
+    const long span_b = 2L * (b_strided ? (long)BK * a.ldb + BN : (long)BN * a.ldb + BK);
+    if (span_a >= (1L << 32) || span_b >= (1L << 32)) return NSVD_EINVAL;
+    a.tiles_m = a.M / BM;
+    a.tiles_n = a.N / BN;
+    {
+        static const char* e = getenv("NSVD_G16_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
+    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.S * a.nprob));
+#define G16_LAUNCH(AS_, BS_, O_)                                                                                   \
+    {                                                                                                              \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm16_kernel<AS_, BS_, O_>,                           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);             \
+            if (e != hipSuccess) return -(int)e;                                                                   \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((gemm16_kernel<AS_, BS_, O_>), grid, dim3(512), LDS_BYTES, s, a);                       \
+    }
+    if (!a_strided && !b_strided) {
+        if (out_bf16) G16_LAUNCH(false, false, true) else G16_LAUNCH(false, false, false)
+    } else if (!a_strided && b_strided) {
+        if (out_bf16) G16_LAUNCH(false, true, true) else G16_LAUNCH(false, true, false)
+    } else if (a_strided && b_strided) {
+        if (out_bf16) G16_LAUNCH(true, true, true) else G16_LAUNCH(true, true, false)
+    } else {
+        return NSVD_EUNSUPPORTED;  // (A k-strided, B k-contiguous): no contraction of the towers has this form
+    }
+#undef G16_LAUNCH
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace nsvd_g16

@@ -111,7 +111,15 @@ int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size
 
 // ---- CDK towers (tower.hip): the backward with per-workgroup sums of squares of the two weight-gradient contractions
 // (cdk_step.hip clips the global gradient norm without another pass over them)
-int nsvd_tower_sumsq_count(int d0, int d1, int d2);
+int nsvd_tower_sumsq_count(int d0, int d1, int d2, int gemm_bf16 = 0);
 int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1,
                               int d2, float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws,
                               size_t ws_bytes, float* sumsq, void* stream);
+// mixed precision: both towers of a step through every launch together (tower.hip); sumsq[t]: that tower's partials
+int nsvd_tower16_forward_pair(const float* const* x, const nsvd_tower_params* const* p, int B, int d0, int d1, int d2,
+                              float slope, float eps, float momentum, int update_running, int flags, float* const* z,
+                              void* const* ws, size_t ws_bytes, hipStream_t s);
+int nsvd_tower16_backward_pair(const float* const* x, const nsvd_tower_params* const* p, const float* const* dz, int B,
+                               int d0, int d1, int d2, float slope, const nsvd_tower_params* const* grads,
+                               void* const* ws, size_t ws_bytes, float* const* sumsq, hipStream_t s);
+void nsvd_tower16_weight_copies(int B, int d0, int d1, int d2, void* ws, void** W1h, void** W2h);

@@ -22,6 +22,7 @@
 // Shapes: B, d0, d1, d2 multiples of 128, B <= 1024 (a BatchNorm strip's rows live in the registers of one workgroup).
 #include "nsvd_kernels.h"
 #include "tile128_dma.h"
+#include "gemm16.h"
 
 using namespace nsvd_pmlp;
 
@@ -39,9 +40,6 @@ struct GemmNT {
     int M, N, K, S;   // S split-K slices of K / S columns each
 };
 
-// BF: A and B hold bfloat16 values (K of them per row; lda / ldb in bf16 elements): the mixed-precision mode of the
-// towers - operands rounded to bfloat16, float32 accumulation, C float32 as ever
-template <bool BF>
 __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) float smem[T128D_LDS_FLOATS];  // 64 KB: two blocks per CU
     const int tid = threadIdx.x;
@@ -54,8 +52,7 @@ __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
     bid -= slice * tm * tn;
     // tiles that share their A rows (same tile row) are neighbours in block order: blocks b, b + 8, .. share an XCD
     const int trow = bid / tn, tcol = bid - trow * tn;
-    constexpr int EL = BF ? 2 : 1;  // operand elements per float
-    const int Ks = g.K / g.S / EL;  // floats per row and slice
+    const int Ks = g.K / g.S;  // floats per row and slice
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -63,9 +60,9 @@ __global__ void __launch_bounds__(256, 2) tower_gemm_nt_kernel(GemmNT g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float* a_base = g.A + (size_t)128 * trow * (g.lda / EL) + (size_t)slice * Ks;
-    const float* b_base = g.B + (size_t)128 * tcol * (g.ldb / EL) + (size_t)slice * Ks;
-    nsvd_tile128_dma<2, BF>(a_base, b_base, (unsigned)(g.lda / EL), (unsigned)(g.ldb / EL), Ks / BK, smem, acc);
+    const float* a_base = g.A + (size_t)128 * trow * g.lda + (size_t)slice * Ks;
+    const float* b_base = g.B + (size_t)128 * tcol * g.ldb + (size_t)slice * Ks;
+    nsvd_tile128_dma<2>(a_base, b_base, (unsigned)g.lda, (unsigned)g.ldb, Ks / BK, smem, acc);
     float* C = g.C + (size_t)slice * g.slice_stride + ((size_t)128 * trow + 64 * wm) * g.ldc + 128 * tcol + 64 * wn + li;
     float ss = 0.f;
 #pragma unroll
@@ -100,9 +97,7 @@ __device__ __forceinline__ unsigned bf16_pack2(float a, float b) {
 __device__ __forceinline__ uint2 bf16_pack4(const float4& v) { return make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w)); }
 __device__ __forceinline__ unsigned short bf16_one(float a) { return (unsigned short)(bf16_pack2(a, 0.f) & 0xffffu); }
 
-// BF: the transposed copy is written as bfloat16 (an operand of a mixed-precision contraction)
-template <bool BF>
-__global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __restrict__ in, void* __restrict__ outv,
+__global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               int R, int Cc) {
     __shared__ float t[32][33];
     const int tiles_c = Cc / 32;
@@ -113,9 +108,7 @@ __global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __res
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const size_t o = (size_t)(32 * tc + y + 8 * k) * R + 32 * tr + x;
-        if (BF) reinterpret_cast<unsigned short*>(outv)[o] = bf16_one(t[x][y + 8 * k]);
-        else reinterpret_cast<float*>(outv)[o] = t[x][y + 8 * k];
+        out[(size_t)(32 * tc + y + 8 * k) * R + 32 * tr + x] = t[x][y + 8 * k];
     }
 }
 
@@ -425,66 +418,31 @@ inline int launch_bn_backward(const BnBwd& b, hipStream_t s) {
     return 0;
 }
 
-// float32 -> bfloat16 (round to nearest even: v_cvt_pk_bf16_f32), 8 values per thread and pass
-__global__ void __launch_bounds__(256) tower_to_bf16_kernel(const float4* __restrict__ in, uint4* __restrict__ out,
-                                                            size_t n8) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-        const float4 a = in[2 * i], b = in[2 * i + 1];
-        uint4 o;
-        o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a.x, a.y}, bf2));
-        o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a.z, a.w}, bf2));
-        o.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){b.x, b.y}, bf2));
-        o.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){b.z, b.w}, bf2));
-        out[i] = o;
-    }
-}
-
-// Mixed precision (Mixed::on): the operands are bfloat16. An operand some kernel has already written as bfloat16
-// (BatchNorm strips, transposes) is `ready`; a float32 one (inputs, master weights) is rounded into the scratch copy
-// hA / hB (M K and N K values) by a cast launch first. prof: bracket the contraction for bench.py.
-struct Mixed {
-    bool on = false, a_ready = false, b_ready = false;
-    void *hA = nullptr, *hB = nullptr;
-    size_t capA = 0, capB = 0;  // capacity of hA / hB in bfloat16 values
-};
-inline int launch_gemm(const GemmNT& g0, hipStream_t s, const Mixed& mx = Mixed(), bool prof = false) {
-    GemmNT g = g0;
-    if (g.M % 128 || g.N % 128 || g.S < 1 || g.K % ((mx.on ? 64 : 32) * g.S)) return NSVD_EINVAL;
+// prof: bracket the contraction for bench.py
+inline int launch_gemm(const GemmNT& g, hipStream_t s, bool prof = false) {
+    if (g.M % 128 || g.N % 128 || g.S < 1 || g.K % (32 * g.S)) return NSVD_EINVAL;
     const dim3 grid((g.M / 128) * (g.N / 128) * g.S);
-    if (mx.on) {
-        if (g.lda != (size_t)g.K || g.ldb != (size_t)g.K) return NSVD_EINVAL;  // the copies are dense
-        const size_t na = (size_t)g.M * g.K / 8, nb = (size_t)g.N * g.K / 8;
-        if ((!mx.a_ready && 8 * na > mx.capA) || (!mx.b_ready && 8 * nb > mx.capB)) return NSVD_EINVAL;
-        if (!mx.a_ready) {
-            hipLaunchKernelGGL(tower_to_bf16_kernel, dim3((unsigned)((na + 255) / 256 > 4096 ? 4096 : (na + 255) / 256)),
-                               dim3(256), 0, s, (const float4*)g.A, (uint4*)mx.hA, na);
-            NSVD_CHECK_LAUNCH();
-            g.A = (const float*)mx.hA;
-        }
-        if (!mx.b_ready) {
-            hipLaunchKernelGGL(tower_to_bf16_kernel, dim3((unsigned)((nb + 255) / 256 > 4096 ? 4096 : (nb + 255) / 256)),
-                               dim3(256), 0, s, (const float4*)g.B, (uint4*)mx.hB, nb);
-            NSVD_CHECK_LAUNCH();
-            g.B = (const float*)mx.hB;
-        }
-    }
     if (prof) nsvd_prof_begin(s);
-    if (mx.on) hipLaunchKernelGGL(tower_gemm_nt_kernel<true>, grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(tower_gemm_nt_kernel<false>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(tower_gemm_nt_kernel, grid, dim3(256), 0, s, g);
     if (prof) nsvd_prof_end(s);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
 
 // split-K of the second forward GEMM: as many slices as it takes to give every CU a tile (K / S a multiple of 32)
-// (bf16 operands: a chunk is 64 values, so slices are at least twice as long - never more slices than float32 takes,
-// which is what the workspace is carved for)
-inline int fwd2_slices(int B, int d1, int d2, bool bf16 = false) {
+inline int fwd2_slices(int B, int d1, int d2) {
     const int tiles = (B / 128) * (d2 / 128);
     int S = 1;
-    while (S < 16 && tiles * S < 256 && d1 % ((bf16 ? 128 : 64) * S) == 0) S *= 2;
+    while (S < 16 && tiles * S < 256 && d1 % (64 * S) == 0) S *= 2;
+    return S;
+}
+
+// the same for the mixed-precision contraction (256 x 128 tiles, gemm16.h; nt towers per launch): slices until the launch
+// has 256 workgroups
+inline int fwd2_slices16(int nt, int B, int d1, int d2) {
+    const int tiles = nt * (B / 256) * (d2 / 128);
+    int S = 1;
+    while (S < 16 && tiles > 0 && tiles * S < 256 && d1 % (128 * S) == 0) S *= 2;
     return S;
 }
 
@@ -506,7 +464,8 @@ inline TowerWs carve_tower(int B, int d0, int d1, int d2, void* base) {
         off += nsvd_align(nfloats * sizeof(float));
         return q;
     };
-    const int S = fwd2_slices(B, d1, d2);
+    int S = fwd2_slices(B, d1, d2);  // (the larger of the two modes' slice counts: one layout for both)
+    if (B % 256 == 0 && fwd2_slices16(1, B, d1, d2) > S) S = fwd2_slices16(1, B, d1, d2);
     w.Y1 = take((size_t)B * d1);
     w.A1 = take((size_t)B * d1);
     w.A1T = take((size_t)B * d1);
@@ -536,6 +495,441 @@ inline TowerWs carve_tower(int B, int d0, int d1, int d2, void* base) {
 inline bool tower_shape_ok(int B, int d0, int d1, int d2) {
     return B > 0 && B <= 1024 && B % 128 == 0 && d0 > 0 && d0 % 128 == 0 && d1 > 0 && d1 % 128 == 0 && d2 > 0 &&
            d2 % 128 == 0;
+}
+
+
+// =====================================================================================================================
+// MIXED PRECISION (gemm_bf16 != 0): the counterpart of the reference's autocast branch
+// (examples/cdk/sketchy/main_sketchy.py:161,182: Linear outputs and BatchNorm / activation outputs are HALF tensors
+// there, statistics and master weights float32). Here the half type is bfloat16:
+//   stored as bfloat16: X, W1, W2 (copies of the float32 masters), Y1 = X W1^T + b1, A1 = lrelu(BN1(Y1)),
+//                       dY2 = BN2'(dZ), dA1 = dY2 W2, dY1 = BN1'(lrelu'(dA1))
+//   float32:            every accumulation, BatchNorm statistics, Y2 / Z / dZ (the narrow end), all parameter gradients
+// The five contractions run on gemm16.h (bf16 MFMA, 256 x 128 tiles) in the operand forms that need NO transposed copy
+// of anything; both towers of a step go through every launch together (nt = 2: twice the workgroups per launch).
+//   forward   Y1h = Xh W1h^T + b1                 T T   (B, d1) bf16
+//             A1h = lrelu(BN1(Y1h))               strip kernel over 64 columns (one 128-byte line of bf16 per row)
+//             Y2  = A1h W2h^T (+ b2)              T T   split-K slices (float32), summed by tower_sum_slices_kernel
+//             Z   = BN2(Y2)                       float32 strip kernel
+//   backward  dY2h = BN2'(dZ)                     float32 strip kernel, bfloat16 output
+//             dW2 = dY2h^T A1h                    S S   (contraction over the batch: both operands as stored)
+//             dA1h = dY2h W2h                     T S   (W2 as stored)
+//             dY1h = BN1'(lrelu'(dA1h))           strip kernel
+//             dW1 = dY1h^T Xh                     S S
+// Shapes: B, d1, d2 multiples of 256, d0 a multiple of 128, B <= 1024 (nsvd_tower_mixed_supported).
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+    v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y);
+    v[4] = bf16_lo(u.z); v[5] = bf16_hi(u.z); v[6] = bf16_lo(u.w); v[7] = bf16_hi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    return make_uint4(bf16_pack2(v[0], v[1]), bf16_pack2(v[2], v[3]), bf16_pack2(v[4], v[5]), bf16_pack2(v[6], v[7]));
+}
+
+// several float32 -> bfloat16 casts in one launch (blockIdx.y = segment)
+struct CastList {
+    const float4* in[6];
+    uint4* out[6];
+    size_t n8[6];
+};
+__global__ void __launch_bounds__(256) tower_cast_list_kernel(CastList c) {
+    const int k = blockIdx.y;
+    const float4* in = c.in[k];
+    uint4* out = c.out[k];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < c.n8[k]; i += (size_t)gridDim.x * 256) {
+        const float4 a = in[2 * i], b = in[2 * i + 1];
+        out[i] = make_uint4(bf16_pack2(a.x, a.y), bf16_pack2(a.z, a.w), bf16_pack2(b.x, b.y), bf16_pack2(b.z, b.w));
+    }
+}
+
+// BatchNorm strips on bfloat16 activations: one workgroup (512 threads) = 64 columns (one 128-byte line per row) x all
+// B rows in registers; thread t owns columns 8 (t & 7) .. + 7 of rows (t >> 3) + 64 k, k < B / 64 <= 16.
+// Column totals in a fixed order: 64 row groups per column through LDS, added in order by one thread per column.
+constexpr int BN16_STRIP = 64, BN16_NT = 512, BN16_RG = 64, BN16_MAXR = 16;
+
+__device__ __forceinline__ void bn16_reduce(float* red, const float (&part)[8], float* total, int tid) {
+    const int c0 = 8 * (tid & 7), rg = tid >> 3;
+    float* p = red + rg * BN16_STRIP + c0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = part[j];
+    __syncthreads();
+    if (tid < BN16_STRIP) {
+        float t = 0.f;
+        for (int k = 0; k < BN16_RG; ++k) t += red[k * BN16_STRIP + tid];
+        total[tid] = t;
+    }
+    __syncthreads();
+}
+
+struct Bn16Fwd {
+    const bf16_t* Y[2];   // (B, N) bfloat16 pre-normalisation output (bias included)
+    const float* gamma[2];
+    const float* beta[2];
+    float* running_mean[2];  // updated in place (null: no running statistics)
+    float* running_var[2];
+    float* mean[2];       // (N) saved for the backward
+    float* invstd[2];
+    bf16_t* out[2];       // (B, N) bfloat16  lrelu(BN(Y))
+    int B, N;
+    float eps, momentum, slope;
+};
+
+__global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) {
+    __shared__ float red[BN16_RG * BN16_STRIP];
+    __shared__ float csum[BN16_STRIP], cmean[BN16_STRIP], cinv[BN16_STRIP];
+    const int tid = threadIdx.x, t = blockIdx.y;
+    const int c0 = 8 * (tid & 7), rg = tid >> 3;
+    const int n0 = blockIdx.x * BN16_STRIP;
+    const int nr = a.B / BN16_RG;
+    const bf16_t* Y = a.Y[t];
+    uint4 raw[BN16_MAXR];
+#pragma unroll
+    for (int k = 0; k < BN16_MAXR; ++k)
+        if (k < nr) raw[k] = *reinterpret_cast<const uint4*>(Y + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0);
+    float s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN16_MAXR; ++k)
+        if (k < nr) {
+            float v[8];
+            unpack8(raw[k], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1[j] += v[j];
+        }
+    bn16_reduce(red, s1, csum, tid);
+    if (tid < BN16_STRIP) cmean[tid] = csum[tid] / (float)a.B;
+    __syncthreads();
+    float mu[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = cmean[c0 + j];
+        s2[j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < BN16_MAXR; ++k)  // two-pass variance: mean first, then the squared deviations
+        if (k < nr) {
+            float v[8];
+            unpack8(raw[k], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[j] - mu[j];
+                s2[j] = fmaf(d, d, s2[j]);
+            }
+        }
+    bn16_reduce(red, s2, csum, tid);
+    if (tid < BN16_STRIP) {
+        const float var = csum[tid];
+        const float inv = 1.0f / sqrtf(var / (float)a.B + a.eps);
+        cinv[tid] = inv;
+        a.mean[t][n0 + tid] = cmean[tid];
+        a.invstd[t][n0 + tid] = inv;
+        if (a.running_mean[t]) {
+            const float unb = var / (float)(a.B - 1);
+            a.running_mean[t][n0 + tid] = (1.f - a.momentum) * a.running_mean[t][n0 + tid] + a.momentum * cmean[tid];
+            a.running_var[t][n0 + tid] = (1.f - a.momentum) * a.running_var[t][n0 + tid] + a.momentum * unb;
+        }
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = cinv[c0 + j];
+        sh[j] = a.gamma[t][n0 + c0 + j];
+    }
+    float be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) be[j] = a.beta[t][n0 + c0 + j];
+    bf16_t* out = a.out[t];
+#pragma unroll
+    for (int k = 0; k < BN16_MAXR; ++k)
+        if (k < nr) {
+            float v[8];
+            unpack8(raw[k], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float o = fmaf((v[j] - mu[j]) * sc[j], sh[j], be[j]);
+                v[j] = o > 0.f ? o : a.slope * o;
+            }
+            *reinterpret_cast<uint4*>(out + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0) = pack8(v);
+        }
+}
+
+struct Bn16Bwd {
+    const bf16_t* dout[2];  // (B, N) bfloat16 gradient w.r.t. the strip's output (behind the activation)
+    const bf16_t* Y[2];     // (B, N) bfloat16 pre-normalisation output
+    const float* mean[2];
+    const float* invstd[2];
+    const float* gamma[2];
+    const float* beta[2];
+    bf16_t* dY[2];          // (B, N) bfloat16
+    float* dgamma[2];
+    float* dbeta[2];
+    float* dbias[2];        // column sums of the (unrounded) dY
+    int B, N;
+    float slope;
+};
+
+__global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a) {
+    __shared__ float red[BN16_RG * BN16_STRIP];
+    __shared__ float c1[BN16_STRIP], c2[BN16_STRIP], c3[BN16_STRIP];
+    const int tid = threadIdx.x, t = blockIdx.y;
+    const int c0 = 8 * (tid & 7), rg = tid >> 3;
+    const int n0 = blockIdx.x * BN16_STRIP;
+    const int nr = a.B / BN16_RG;
+    float mu[8], inv[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = a.mean[t][n0 + c0 + j];
+        inv[j] = a.invstd[t][n0 + c0 + j];
+        ga[j] = a.gamma[t][n0 + c0 + j];
+        be[j] = a.beta[t][n0 + c0 + j];
+    }
+    uint4 yr[BN16_MAXR], dr[BN16_MAXR];
+#pragma unroll
+    for (int k = 0; k < BN16_MAXR; ++k)
+        if (k < nr) {
+            const size_t off = (size_t)(rg + BN16_RG * k) * a.N + n0 + c0;
+            yr[k] = *reinterpret_cast<const uint4*>(a.Y[t] + off);
+            dr[k] = *reinterpret_cast<const uint4*>(a.dout[t] + off);
+        }
+    // dh = dout * act'(h); column sums of dh and dh * yhat
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN16_MAXR; ++k)
+        if (k < nr) {
+            float y[8], d[8];
+            unpack8(yr[k], y);
+            unpack8(dr[k], d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float yh = (y[j] - mu[j]) * inv[j];
+                const float dh = d[j] * (fmaf(yh, ga[j], be[j]) > 0.f ? 1.f : a.slope);
+                s1[j] += dh;
+                s2[j] = fmaf(dh, yh, s2[j]);
+            }
+        }
+    bn16_reduce(red, s1, c1, tid);
+    bn16_reduce(red, s2, c2, tid);
+    if (tid < BN16_STRIP) {
+        a.dbeta[t][n0 + tid] = c1[tid];
+        a.dgamma[t][n0 + tid] = c2[tid];
+    }
+    const float rB = 1.0f / (float)a.B;
+    float m1[8], m2[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m1[j] = c1[c0 + j] * rB;
+        m2[j] = c2[c0 + j] * rB;
+        sb[j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < BN16_MAXR; ++k)
+        if (k < nr) {
+            float y[8], d[8];
+            unpack8(yr[k], y);
+            unpack8(dr[k], d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float yh = (y[j] - mu[j]) * inv[j];
+                const float dh = d[j] * (fmaf(yh, ga[j], be[j]) > 0.f ? 1.f : a.slope);
+                const float dy = ga[j] * inv[j] * (dh - m1[j] - yh * m2[j]);
+                sb[j] += dy;
+                d[j] = dy;
+            }
+            *reinterpret_cast<uint4*>(a.dY[t] + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0) = pack8(d);
+        }
+    bn16_reduce(red, sb, c3, tid);
+    if (tid < BN16_STRIP) a.dbias[t][n0 + tid] = c3[tid];
+}
+
+inline bool tower16_shape_ok(int B, int d0, int d1, int d2) {
+    return tower_shape_ok(B, d0, d1, d2) && B % 256 == 0 && d1 % 256 == 0 && d2 % 256 == 0;
+}
+
+// the bfloat16 tensors of a mixed-precision tower, laid over the float32 layout's buffers (each at least twice as large)
+struct Tower16 {
+    bf16_t *Xh, *W1h, *W2h, *Y1h, *A1h, *dY2h, *dA1h, *dY1h;
+};
+inline Tower16 views16(const TowerWs& w) {
+    Tower16 v;
+    v.Xh = (bf16_t*)w.hA;      // capA = B d0 values
+    v.W1h = (bf16_t*)w.hB;     // capB >= d1 d0 values
+    v.W2h = (bf16_t*)w.W2T;    // d1 d2 floats
+    v.Y1h = (bf16_t*)w.Y1;
+    v.A1h = (bf16_t*)w.A1;
+    v.dY2h = (bf16_t*)w.dY2;
+    v.dA1h = (bf16_t*)w.dA1;
+    v.dY1h = (bf16_t*)w.dY1T;
+    return v;
+}
+
+// gemm_bf16 flag bits: 1 = mixed precision; 2 = the bfloat16 copies of W1 / W2 in the workspace are current (written by
+// the previous step's optimiser kernel, cdk_step.hip): the forward does not cast them again
+constexpr int MIXED_WEIGHTS_READY = 2;
+
+int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* const* p, int B, int d0, int d1, int d2,
+                    float slope, float eps, float momentum, int update_running, int flags, int phase, float* const* z,
+                    void* const* ws, hipStream_t s) {
+    if (!tower16_shape_ok(B, d0, d1, d2)) return NSVD_EUNSUPPORTED;
+    TowerWs w[2];
+    Tower16 v[2];
+    for (int t = 0; t < nt; ++t) {
+        w[t] = carve_tower(B, d0, d1, d2, ws[t]);
+        v[t] = views16(w[t]);
+    }
+    int rc = 0;
+    if (phase == 2) {
+        // second half of a hidden-width-sharded tower: Y2 holds the all-reduced partial products
+        for (int t = 0; t < nt; ++t) {
+            BnFwd f;
+            memset(&f, 0, sizeof(f));
+            f.Y = w[t].Y2; f.S = 1; f.bias = p[t]->b2; f.Ysum = w[t].Y2; f.gamma = p[t]->g2; f.beta = p[t]->be2;
+            f.running_mean = update_running ? p[t]->rm2 : nullptr; f.running_var = update_running ? p[t]->rv2 : nullptr;
+            f.mean = w[t].mean2; f.invstd = w[t].inv2; f.out = z[t]; f.outT = nullptr; f.B = B; f.N = d2;
+            f.eps = eps; f.momentum = momentum; f.slope = 1.0f;
+            rc = launch_bn_forward(f, s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    {   // casts: X always; the weights unless their copies are current
+        CastList c;
+        memset(&c, 0, sizeof(c));
+        int n = 0;
+        size_t maxn = 0;
+        for (int t = 0; t < nt; ++t) {
+            c.in[n] = (const float4*)x[t]; c.out[n] = (uint4*)v[t].Xh; c.n8[n] = (size_t)B * d0 / 8; ++n;
+            if (!(flags & MIXED_WEIGHTS_READY)) {
+                c.in[n] = (const float4*)p[t]->W1; c.out[n] = (uint4*)v[t].W1h; c.n8[n] = (size_t)d1 * d0 / 8; ++n;
+                c.in[n] = (const float4*)p[t]->W2; c.out[n] = (uint4*)v[t].W2h; c.n8[n] = (size_t)d2 * d1 / 8; ++n;
+            }
+        }
+        for (int k = 0; k < n; ++k) maxn = c.n8[k] > maxn ? c.n8[k] : maxn;
+        size_t blocks = (maxn + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(tower_cast_list_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, c);
+        NSVD_CHECK_LAUNCH();
+    }
+    nsvd_g16::Args g;
+    // Y1h = Xh W1h^T + b1
+    memset(&g, 0, sizeof(g));
+    for (int t = 0; t < nt; ++t) {
+        g.p[t].A = v[t].Xh; g.p[t].B = v[t].W1h; g.p[t].C = v[t].Y1h; g.p[t].bias = p[t]->b1;
+    }
+    g.nprob = nt; g.M = B; g.N = d1; g.K = d0; g.S = 1; g.lda = d0; g.ldb = d0; g.ldc = d1;
+    nsvd_prof_begin(s);  // bench.py --config cfg5 --amp brackets this contraction (nsvd_profile_next_forward)
+    rc = nsvd_g16::launch(g, false, false, true, s);
+    nsvd_prof_end(s);
+    if (rc) return rc;
+    {   // A1h = lrelu(BN1(Y1h))
+        Bn16Fwd f;
+        memset(&f, 0, sizeof(f));
+        for (int t = 0; t < nt; ++t) {
+            f.Y[t] = v[t].Y1h; f.gamma[t] = p[t]->g1; f.beta[t] = p[t]->be1;
+            f.running_mean[t] = update_running ? p[t]->rm1 : nullptr;
+            f.running_var[t] = update_running ? p[t]->rv1 : nullptr;
+            f.mean[t] = w[t].mean1; f.invstd[t] = w[t].inv1; f.out[t] = v[t].A1h;
+        }
+        f.B = B; f.N = d1; f.eps = eps; f.momentum = momentum; f.slope = slope;
+        hipLaunchKernelGGL(tower_bn16_forward_kernel, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, f);
+        NSVD_CHECK_LAUNCH();
+    }
+    // Y2 partial products, split-K
+    const int S = fwd2_slices16(nt, B, d1, d2);
+    memset(&g, 0, sizeof(g));
+    for (int t = 0; t < nt; ++t) {
+        g.p[t].A = v[t].A1h; g.p[t].B = v[t].W2h; g.p[t].C = w[t].Y2p;
+    }
+    g.nprob = nt; g.M = B; g.N = d2; g.K = d1; g.S = S; g.lda = d1; g.ldb = d1; g.ldc = d2;
+    g.slice_stride = (long)B * d2;
+    rc = nsvd_g16::launch(g, false, false, false, s);
+    if (rc) return rc;
+    for (int t = 0; t < nt; ++t) {
+        const size_t n4 = (size_t)B * d2 / 4;
+        hipLaunchKernelGGL(tower_sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w[t].Y2p,
+                           (size_t)B * d2, S, phase == 1 ? nullptr : p[t]->b2, w[t].Y2, d2, n4);
+        NSVD_CHECK_LAUNCH();
+    }
+    if (phase == 1) return 0;
+    for (int t = 0; t < nt; ++t) {
+        BnFwd f;
+        memset(&f, 0, sizeof(f));
+        f.Y = w[t].Y2; f.S = 1; f.gamma = p[t]->g2; f.beta = p[t]->be2;
+        f.running_mean = update_running ? p[t]->rm2 : nullptr; f.running_var = update_running ? p[t]->rv2 : nullptr;
+        f.mean = w[t].mean2; f.invstd = w[t].inv2; f.out = z[t]; f.outT = nullptr; f.B = B; f.N = d2;
+        f.eps = eps; f.momentum = momentum; f.slope = 1.0f;
+        rc = launch_bn_forward(f, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// tiles (= sum-of-squares partials) of the two weight-gradient contractions in mixed precision: dW2's, then dW1's
+inline int sumsq_count16(int d0, int d1, int d2) { return (d2 / 256) * (d1 / 128) + (d1 / 256) * (d0 / 128); }
+
+int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* const* p, const float* const* dz, int B,
+                     int d0, int d1, int d2, float slope, const nsvd_tower_params* const* grads, void* const* ws,
+                     float* const* sumsq, hipStream_t s) {
+    if (!tower16_shape_ok(B, d0, d1, d2)) return NSVD_EUNSUPPORTED;
+    TowerWs w[2];
+    Tower16 v[2];
+    for (int t = 0; t < nt; ++t) {
+        w[t] = carve_tower(B, d0, d1, d2, ws[t]);
+        v[t] = views16(w[t]);
+    }
+    int rc = 0;
+    for (int t = 0; t < nt; ++t) {  // dY2h = BN2'(dZ), db2
+        BnBwd b;
+        memset(&b, 0, sizeof(b));
+        b.dout = dz[t]; b.Y = w[t].Y2; b.mean = w[t].mean2; b.invstd = w[t].inv2; b.gamma = p[t]->g2; b.beta = p[t]->be2;
+        b.dY = (float*)v[t].dY2h; b.dYT = nullptr; b.dgamma = grads[t]->g2; b.dbeta = grads[t]->be2;
+        b.dbias = grads[t]->b2; b.B = B; b.N = d2; b.slope = 1.0f; b.bf16_out = 1;
+        rc = launch_bn_backward(b, s);
+        if (rc) return rc;
+    }
+    nsvd_g16::Args g;
+    // dW2 = dY2h^T A1h
+    memset(&g, 0, sizeof(g));
+    for (int t = 0; t < nt; ++t) {
+        g.p[t].A = v[t].dY2h; g.p[t].B = v[t].A1h; g.p[t].C = grads[t]->W2; g.p[t].sumsq = sumsq ? sumsq[t] : nullptr;
+    }
+    g.nprob = nt; g.M = d2; g.N = d1; g.K = B; g.S = 1; g.lda = d2; g.ldb = d1; g.ldc = d1;
+    rc = nsvd_g16::launch(g, true, true, false, s);
+    if (rc) return rc;
+    // dA1h = dY2h W2h
+    memset(&g, 0, sizeof(g));
+    for (int t = 0; t < nt; ++t) {
+        g.p[t].A = v[t].dY2h; g.p[t].B = v[t].W2h; g.p[t].C = v[t].dA1h;
+    }
+    g.nprob = nt; g.M = B; g.N = d1; g.K = d2; g.S = 1; g.lda = d2; g.ldb = d1; g.ldc = d1;
+    rc = nsvd_g16::launch(g, false, true, true, s);
+    if (rc) return rc;
+    {   // dY1h = BN1'(lrelu'(dA1h)), db1
+        Bn16Bwd b;
+        memset(&b, 0, sizeof(b));
+        for (int t = 0; t < nt; ++t) {
+            b.dout[t] = v[t].dA1h; b.Y[t] = v[t].Y1h; b.mean[t] = w[t].mean1; b.invstd[t] = w[t].inv1;
+            b.gamma[t] = p[t]->g1; b.beta[t] = p[t]->be1; b.dY[t] = v[t].dY1h; b.dgamma[t] = grads[t]->g1;
+            b.dbeta[t] = grads[t]->be1; b.dbias[t] = grads[t]->b1;
+        }
+        b.B = B; b.N = d1; b.slope = slope;
+        hipLaunchKernelGGL(tower_bn16_backward_kernel, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, b);
+        NSVD_CHECK_LAUNCH();
+    }
+    // dW1 = dY1h^T Xh
+    memset(&g, 0, sizeof(g));
+    for (int t = 0; t < nt; ++t) {
+        g.p[t].A = v[t].dY1h; g.p[t].B = v[t].Xh; g.p[t].C = grads[t]->W1;
+        g.p[t].sumsq = sumsq ? sumsq[t] + (d2 / 256) * (d1 / 128) : nullptr;
+    }
+    g.nprob = nt; g.M = d1; g.N = d0; g.K = B; g.S = 1; g.lda = d1; g.ldb = d0; g.ldc = d0;
+    return nsvd_g16::launch(g, true, true, false, s);
 }
 
 }  // namespace
@@ -570,10 +964,13 @@ int nsvd_tower_forward_phase(const float* x, const nsvd_tower_params* p, int B, 
     const TowerWs w = carve_tower(B, d0, d1, d2, ws);
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    // mixed precision: the contractions' operands rounded to bfloat16. X and the master weights are cast per call;
-    // the activations are WRITTEN as bfloat16 by the BatchNorm strips (into the float32 buffers' storage: A1, A1^T)
-    Mixed mx;
-    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB; mx.capA = w.capA; mx.capB = w.capB;
+    if (gemm_bf16 != 0) {  // mixed precision: the section above
+        const float* xs[1] = {x};
+        const nsvd_tower_params* ps[1] = {p};
+        float* zs[1] = {z};
+        void* wss[1] = {ws};
+        return tower16_forward(1, xs, ps, B, d0, d1, d2, slope, eps, momentum, update_running, gemm_bf16, phase, zs, wss, s);
+    }
     int rc = 0;
     GemmNT g;
     BnFwd f;
@@ -591,23 +988,22 @@ int nsvd_tower_forward_phase(const float* x, const nsvd_tower_params* p, int B, 
     memset(&g, 0, sizeof(g));
     g.A = x; g.lda = d0; g.B = p->W1; g.ldb = d0; g.C = w.Y1; g.ldc = d1; g.bias = p->b1;
     g.M = B; g.N = d1; g.K = d0; g.S = 1;
-    rc = launch_gemm(g, s, mx, true);  // bench.py --config cfg5 brackets this contraction (nsvd_profile_next_forward)
+    rc = launch_gemm(g, s, true);  // bench.py --config cfg5 brackets this contraction (nsvd_profile_next_forward)
     if (rc) return rc;
     // A1 = lrelu(BN1(Y1)), A1^T
     memset(&f, 0, sizeof(f));
     f.Y = w.Y1; f.S = 1; f.gamma = p->g1; f.beta = p->be1;
     f.running_mean = update_running ? p->rm1 : nullptr; f.running_var = update_running ? p->rv1 : nullptr;
     f.mean = w.mean1; f.invstd = w.inv1; f.out = w.A1; f.outT = w.A1T; f.B = B; f.N = d1;
-    f.eps = eps; f.momentum = momentum; f.slope = slope; f.bf16_out = mx.on;
+    f.eps = eps; f.momentum = momentum; f.slope = slope;
     rc = launch_bn_forward(f, s);
     if (rc) return rc;
     // Y2 = A1 W2^T (+ b2 in the strip kernel), split-K partials
-    const int S = fwd2_slices(B, d1, d2, gemm_bf16 != 0);
+    const int S = fwd2_slices(B, d1, d2);
     memset(&g, 0, sizeof(g));
     g.A = w.A1; g.lda = d1; g.B = p->W2; g.ldb = d1; g.C = w.Y2p; g.ldc = d2; g.slice_stride = (size_t)B * d2;
     g.M = B; g.N = d2; g.K = d1; g.S = S;
-    mx.a_ready = true;  // A1 as the strip kernel wrote it
-    rc = launch_gemm(g, s, mx);
+    rc = launch_gemm(g, s);
     if (rc) return rc;
     // Y2 = b2 + sum of the partials, then Z = BN2(Y2)
     {
@@ -635,7 +1031,44 @@ int nsvd_tower_backward(const float* x, const nsvd_tower_params* p, const float*
 
 // nsvd_tower_backward that also leaves, per workgroup of the two weight-gradient contractions, the sum of squares of
 // its tile: sumsq[0 .. nsvd_tower_sumsq_count) (dW2's tiles, then dW1's), or nothing when sumsq is null
-int nsvd_tower_sumsq_count(int d0, int d1, int d2) { return (d2 / 128) * (d1 / 128) + (d1 / 128) * (d0 / 128); }
+int nsvd_tower_sumsq_count(int d0, int d1, int d2, int gemm_bf16) {
+    if (gemm_bf16) return sumsq_count16(d0, d1, d2);
+    return (d2 / 128) * (d1 / 128) + (d1 / 128) * (d0 / 128);
+}
+
+extern "C" int nsvd_tower_mixed_supported(int B, int d0, int d1, int d2) { return tower16_shape_ok(B, d0, d1, d2) ? 1 : 0; }
+
+// both towers of a mixed-precision CDK step through every launch together (cdk_step.hip); flags: the gemm_bf16 bits
+int nsvd_tower16_forward_pair(const float* const* x, const nsvd_tower_params* const* p, int B, int d0, int d1, int d2,
+                              float slope, float eps, float momentum, int update_running, int flags, float* const* z,
+                              void* const* ws, size_t ws_bytes, hipStream_t s) {
+    if (!tower16_shape_ok(B, d0, d1, d2)) return NSVD_EUNSUPPORTED;
+    for (int t = 0; t < 2; ++t) {
+        if (!x[t] || !p[t] || !z[t] || !ws[t] || ((uintptr_t)ws[t] & 255) != 0) return NSVD_EINVAL;
+        if (!p[t]->W1 || !p[t]->b1 || !p[t]->g1 || !p[t]->be1 || !p[t]->W2 || !p[t]->b2 || !p[t]->g2 || !p[t]->be2)
+            return NSVD_EINVAL;
+        if (update_running && (!p[t]->rm1 || !p[t]->rv1 || !p[t]->rm2 || !p[t]->rv2)) return NSVD_EINVAL;
+    }
+    if (ws_bytes < carve_tower(B, d0, d1, d2, nullptr).bytes) return NSVD_EINVAL;
+    return tower16_forward(2, x, p, B, d0, d1, d2, slope, eps, momentum, update_running, flags, 0, z, ws, s);
+}
+
+int nsvd_tower16_backward_pair(const float* const* x, const nsvd_tower_params* const* p, const float* const* dz, int B,
+                               int d0, int d1, int d2, float slope, const nsvd_tower_params* const* grads,
+                               void* const* ws, size_t ws_bytes, float* const* sumsq, hipStream_t s) {
+    if (!tower16_shape_ok(B, d0, d1, d2)) return NSVD_EUNSUPPORTED;
+    for (int t = 0; t < 2; ++t)
+        if (!x[t] || !p[t] || !dz[t] || !grads[t] || !ws[t] || ((uintptr_t)ws[t] & 255) != 0) return NSVD_EINVAL;
+    if (ws_bytes < carve_tower(B, d0, d1, d2, nullptr).bytes) return NSVD_EINVAL;
+    return tower16_backward(2, x, p, dz, B, d0, d1, d2, slope, grads, ws, sumsq, s);
+}
+
+// where the bfloat16 copies of W1 / W2 live inside a tower workspace (the optimiser kernel of the fused step refreshes them)
+void nsvd_tower16_weight_copies(int B, int d0, int d1, int d2, void* ws, void** W1h, void** W2h) {
+    const Tower16 v = views16(carve_tower(B, d0, d1, d2, ws));
+    *W1h = v.W1h;
+    *W2h = v.W2h;
+}
 
 int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const float* dz, int B, int d0, int d1,
                               int d2, float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws,
@@ -646,15 +1079,22 @@ int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const 
     const TowerWs w = carve_tower(B, d0, d1, d2, ws);
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    Mixed mx;
-    mx.on = gemm_bf16 != 0; mx.hA = w.hA; mx.hB = w.hB; mx.capA = w.capA; mx.capB = w.capB;
+    if (gemm_bf16 != 0) {
+        const float* xs[1] = {x};
+        const nsvd_tower_params* ps[1] = {p};
+        const float* dzs[1] = {dz};
+        const nsvd_tower_params* gs[1] = {grads};
+        void* wss[1] = {ws};
+        float* sq[1] = {sumsq};
+        return tower16_backward(1, xs, ps, dzs, B, d0, d1, d2, slope, gs, wss, sumsq ? sq : nullptr, s);
+    }
     int rc = 0;
     // dY2 = BN2'(dZ), dY2^T, db2 = column sums of dY2
     BnBwd b;
     memset(&b, 0, sizeof(b));
     b.dout = dz; b.Y = w.Y2; b.mean = w.mean2; b.invstd = w.inv2; b.gamma = p->g2; b.beta = p->be2;
     b.dY = w.dY2; b.dYT = w.dY2T; b.dgamma = grads->g2; b.dbeta = grads->be2; b.dbias = grads->b2;
-    b.B = B; b.N = d2; b.slope = 1.0f; b.bf16_out = mx.on;
+    b.B = B; b.N = d2; b.slope = 1.0f;
     rc = launch_bn_backward(b, s);
     if (rc) return rc;
     // dW2 = dY2^T A1  (A = dY2^T (d2, B), B = A1^T (d1, B), K = B)
@@ -663,32 +1103,29 @@ int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const 
     g.A = w.dY2T; g.lda = B; g.B = w.A1T; g.ldb = B; g.C = grads->W2; g.ldc = d1;
     g.M = d2; g.N = d1; g.K = B; g.S = 1;
     g.sumsq = sumsq;
-    mx.a_ready = mx.b_ready = true;  // dY2^T and A1^T as the strip kernels wrote them
-    rc = launch_gemm(g, s, mx);
+    rc = launch_gemm(g, s);
     if (rc) return rc;
     // W2^T (d1, d2), then dA1 = dY2 W2  (A = dY2 (B, d2), B = W2^T (d1, d2), K = d2)
-    if (mx.on) hipLaunchKernelGGL(tower_transpose_kernel<true>, dim3((d2 / 32) * (d1 / 32)), dim3(256), 0, s, p->W2, (void*)w.W2T, d2, d1);
-    else hipLaunchKernelGGL(tower_transpose_kernel<false>, dim3((d2 / 32) * (d1 / 32)), dim3(256), 0, s, p->W2, (void*)w.W2T, d2, d1);
+    hipLaunchKernelGGL(tower_transpose_kernel, dim3((d2 / 32) * (d1 / 32)), dim3(256), 0, s, p->W2, w.W2T, d2, d1);
     NSVD_CHECK_LAUNCH();
     memset(&g, 0, sizeof(g));
     g.A = w.dY2; g.lda = d2; g.B = w.W2T; g.ldb = d2; g.C = w.dA1; g.ldc = d1;
     g.M = B; g.N = d1; g.K = d2; g.S = 1;
-    rc = launch_gemm(g, s, mx);
+    rc = launch_gemm(g, s);
     if (rc) return rc;
     // dY1^T = (BN1'(lrelu'(dA1)))^T, db1
     memset(&b, 0, sizeof(b));
     b.dout = w.dA1; b.Y = w.Y1; b.mean = w.mean1; b.invstd = w.inv1; b.gamma = p->g1; b.beta = p->be1;
     b.dY = nullptr; b.dYT = w.dY1T; b.dgamma = grads->g1; b.dbeta = grads->be1; b.dbias = grads->b1;
-    b.B = B; b.N = d1; b.slope = slope; b.bf16_out = mx.on;
+    b.B = B; b.N = d1; b.slope = slope;
     rc = launch_bn_backward(b, s);
     if (rc) return rc;
     // X^T (d0, B), then dW1 = dY1^T X  (A = dY1^T (d1, B), B = X^T (d0, B), K = B)
-    if (mx.on) hipLaunchKernelGGL(tower_transpose_kernel<true>, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, (void*)w.XT, B, d0);
-    else hipLaunchKernelGGL(tower_transpose_kernel<false>, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, (void*)w.XT, B, d0);
+    hipLaunchKernelGGL(tower_transpose_kernel, dim3((B / 32) * (d0 / 32)), dim3(256), 0, s, x, w.XT, B, d0);
     NSVD_CHECK_LAUNCH();
     memset(&g, 0, sizeof(g));
     g.A = w.dY1T; g.lda = B; g.B = w.XT; g.ldb = B; g.C = grads->W1; g.ldc = d0;
     g.M = d1; g.N = d0; g.K = B; g.S = 1;
     g.sumsq = sumsq ? sumsq + (d2 / 128) * (d1 / 128) : nullptr;
-    return launch_gemm(g, s, mx);
+    return launch_gemm(g, s);
 }

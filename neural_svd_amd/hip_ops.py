@@ -791,6 +791,11 @@ def tower_supported(B: int, d0: int, d1: int, d2: int) -> bool:
     return int(_lib.load().nsvd_tower_workspace_bytes(int(B), int(d0), int(d1), int(d2))) > 0
 
 
+def tower_mixed_supported(B: int, d0: int, d1: int, d2: int) -> bool:
+    """does the mixed-precision mode (gemm_bf16) take this shape? (B, d1, d2 multiples of 256, d0 of 128, B <= 1024)"""
+    return bool(_lib.load().nsvd_tower_mixed_supported(int(B), int(d0), int(d1), int(d2)))
+
+
 def tower_workspace(B: int, d0: int, d1: int, d2: int, device) -> torch.Tensor:
     n = int(_lib.load().nsvd_tower_workspace_bytes(int(B), int(d0), int(d1), int(d2)))
     if n == 0:
@@ -821,7 +826,8 @@ def tower_y2(ws: torch.Tensor, B: int, d0: int, d1: int, d2: int) -> torch.Tenso
 def tower_forward(x: torch.Tensor, params: dict, slope: float, eps: float, momentum: float, update_running: bool,
                   ws: torch.Tensor, gemm_bf16: bool = False, phase: int = 0) -> Optional[torch.Tensor]:
     """z = BN2(Linear2(lrelu(BN1(Linear1(x))))) in training mode; params: dict over TOWER_KEYS (torch layouts).
-    gemm_bf16: mixed precision - the contractions' operands rounded to bfloat16, float32 accumulation (nsvd.h).
+    gemm_bf16: mixed precision - bfloat16 operands and wide activations, float32 accumulation and statistics (nsvd.h;
+    shapes: tower_mixed_supported). The value 3 (bit 1) says the bfloat16 weight copies inside ws are current.
     phase (hidden width sharded over processes, params = this rank's slices): 1 = up to the partial product in
     tower_y2(ws, ...) (returns None), 2 = bias + second BatchNorm from the all-reduced tower_y2; 0 = the whole tower."""
     B, d0 = x.shape
@@ -834,7 +840,7 @@ def tower_forward(x: torch.Tensor, params: dict, slope: float, eps: float, momen
     z = torch.empty((B, d2), dtype=torch.float32, device=x.device) if phase != 1 else None
     p = _tower_struct(params, bool(update_running))
     rc = _lib.load().nsvd_tower_forward_phase(_ptr(x, "x"), C.byref(p), B, d0, d1, d2, float(slope), float(eps),
-                                              float(momentum), int(bool(update_running)), int(bool(gemm_bf16)),
+                                              float(momentum), int(bool(update_running)), int(gemm_bf16),
                                               int(phase), _ptr(z, "z"), ws.data_ptr(), ws.numel(), _stream())
     check(rc, "nsvd_tower_forward")
     return z
@@ -855,16 +861,50 @@ def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float
     return grads
 
 
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """bfloat16(x), round to nearest even (nsvd_to_bf16) - the cast the mixed-precision towers' operands go through"""
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() % 8:
+        raise NsvdError("to_bf16: contiguous float32 tensor with a multiple of 8 elements")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().nsvd_to_bf16(_ptr(x, "x"), out.data_ptr(), x.numel(), _stream()), "nsvd_to_bf16")
+    return out
+
+
+def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, a_kstrided: bool = False,
+              b_kstrided: bool = False, out_bf16: bool = False, slices: int = 1, want_sumsq: bool = False):
+    """C = A B^T on the bf16 MFMA with float32 accumulation (nsvd_gemm_bf16). A, B: bfloat16, 2-D, contiguous.
+    a_kstrided: A is (K, M) - the contraction index first (A^T as stored), else (M, K); likewise B with N.
+    slices > 1: C has a leading slice dimension (split-K partial products). Returns C, or (C, sumsq per tile)."""
+    for t, n in ((A, "A"), (B, "B")):
+        if t.dtype != torch.bfloat16 or t.dim() != 2 or not t.is_contiguous() or not t.is_cuda:
+            raise NsvdError(f"gemm_bf16: {n} must be a contiguous 2-D bfloat16 GPU tensor")
+    K, M = (A.shape if a_kstrided else A.shape[::-1])
+    Kb, N = (B.shape if b_kstrided else B.shape[::-1])
+    if K != Kb:
+        raise NsvdError("gemm_bf16: contraction lengths differ")
+    shape = (M, N) if slices == 1 else (slices, M, N)
+    Cm = torch.empty(shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=A.device)
+    ss = torch.zeros((M // 256) * (N // 128) * slices, dtype=torch.float32, device=A.device) if want_sumsq else None
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_cuda):
+        raise NsvdError("gemm_bf16: bias must be N float32 values on the GPU")
+    rc = _lib.load().nsvd_gemm_bf16(A.data_ptr(), B.data_ptr(), Cm.data_ptr(),
+                                    bias.data_ptr() if bias is not None else None, M, N, K, A.shape[1], B.shape[1], N,
+                                    int(bool(a_kstrided)), int(bool(b_kstrided)), int(bool(out_bf16)), int(slices),
+                                    M * N, ss.data_ptr() if ss is not None else None, _stream())
+    check(rc, "nsvd_gemm_bf16")
+    return (Cm, ss) if want_sumsq else Cm
+
+
 def cdk_step_desc(B: int, d0: int, d1: int, d2: int, slope: float, bn_eps: float, bn_momentum: float, mu: float,
                   normalize_mode: int, set_first_mode_const: bool, lr: float, momentum: float, max_grad_norm: float,
-                  first_step: bool, gemm_bf16: bool = False) -> "_lib.CdkStepDesc":
+                  first_step: bool, gemm_bf16: int = 0) -> "_lib.CdkStepDesc":
     d = _lib.CdkStepDesc()
     d.B, d.d0, d.d1, d.d2 = int(B), int(d0), int(d1), int(d2)
     d.slope, d.bn_eps, d.bn_momentum, d.mu = float(slope), float(bn_eps), float(bn_momentum), float(mu)
     d.normalize_mode, d.set_first_mode_const = int(normalize_mode), int(bool(set_first_mode_const))
     d.lr, d.momentum, d.max_grad_norm = float(lr), float(momentum), float(max_grad_norm or 0.0)
     d.first_step = int(bool(first_step))
-    d.gemm_bf16 = int(bool(gemm_bf16))
+    d.gemm_bf16 = int(gemm_bf16)
     return d
 
 
@@ -900,6 +940,6 @@ for _name in ("fourier_features", "operator_forward", "operator_features", "oper
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
               "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "operator_backward_evd_step_next", "model_backward_evd_step", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
-              "row_normalize_backward", "tower_forward", "tower_backward", "cdk_step"):
+              "row_normalize_backward", "tower_forward", "tower_backward", "cdk_step", "to_bf16", "gemm_bf16"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

@@ -517,8 +517,10 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
     (d2, d1), b2, g2, be2 (d2) in torch's layouts. Pinned by tests/golden/tower.npz.
     Returns z, dict of gradients, and the batch statistics (mean, biased var, unbiased var) of both BatchNorms.
     gemm_bf16: the build's mixed-precision mode (no reference counterpart to pin it to: the reference's autocast is
-    float16 and covers more ops) - both operands of each of the five contractions rounded to bfloat16, products and
-    sums exact in this dtype; everything else unchanged."""
+    float16, has a GradScaler and covers more ops): the values the HIP path STORES as bfloat16 are rounded to bfloat16
+    here - X, W1, W2; Y1 = X W1^T + b1; A1 = lrelu(BN1(Y1)); dY2, dA1, dY1 - products, sums, BatchNorm statistics, the
+    narrow end (Y2, Z) and every parameter gradient exact in this dtype; the bias gradients are column sums of the
+    unrounded dY (include/nsvd.h, nsvd_tower_forward)."""
     B = x.shape[0]
     r = _bf16_round if gemm_bf16 else (lambda t: t)
 
@@ -532,16 +534,17 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
     def bn_back(dh, yh, inv, g):
         return g * inv * (dh - dh.mean(0) - yh * (dh * yh).mean(0)), (dh * yh).sum(0), dh.sum(0)
 
-    y1 = r(x) @ r(P["W1"]).T + P["b1"]
+    xh, W1h, W2h = r(x), r(P["W1"]), r(P["W2"])
+    y1 = r(xh @ W1h.T + P["b1"])
     h1, yh1, inv1, st1 = bn(y1, P["g1"], P["be1"])
-    a1 = torch.where(h1 > 0, h1, slope * h1)
-    y2 = r(a1) @ r(P["W2"]).T + P["b2"]
+    a1 = r(torch.where(h1 > 0, h1, slope * h1))
+    y2 = a1 @ W2h.T + P["b2"]
     z, yh2, inv2, st2 = bn(y2, P["g2"], P["be2"])
     dy2, dg2, dbe2 = bn_back(dz, yh2, inv2, P["g2"])
-    da1 = r(dy2) @ r(P["W2"])
+    da1 = r(r(dy2) @ W2h)
     dh1 = da1 * torch.where(h1 > 0, torch.ones_like(h1), torch.full_like(h1, slope))
     dy1, dg1, dbe1 = bn_back(dh1, yh1, inv1, P["g1"])
-    grads = dict(W1=r(dy1).T @ r(x), b1=dy1.sum(0), g1=dg1, be1=dbe1, W2=r(dy2).T @ r(a1), b2=dy2.sum(0), g2=dg2,
+    grads = dict(W1=r(dy1).T @ xh, b1=dy1.sum(0), g1=dg1, be1=dbe1, W2=r(dy2).T @ a1, b2=dy2.sum(0), g2=dg2,
                  be2=dbe2)
     return z, grads, (st1, st2)
 

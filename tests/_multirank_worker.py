@@ -81,19 +81,20 @@ def dropin_blocks():
     return [4.0 * torch.randn(32, 2, generator=g) for _ in range(16)]
 
 
-def cdk_case(dev):
-    """the Sketchy-style CDK objects (two towers 128 -> 512 -> 128, l2_ball, NestedLoRAForCDK) and three (x, y) batches"""
+def cdk_case(dev, amp=False):
+    """the Sketchy-style CDK objects (two towers 128 -> 512 -> 128, l2_ball, NestedLoRAForCDK) and three (x, y) batches
+    of 128 rows; amp: 128 -> 512 -> 256 and 256 rows (the mixed-precision kernels take multiples of 256)"""
     import torch.nn as nn
     from neural_svd_amd.cdk import HeteroNetwork, NestedLoRAForCDK, get_mlp
     torch.manual_seed(17)
-    sizes = [128, 512, 128]
+    sizes, B = ([128, 512, 256], 256) if amp else ([128, 512, 128], 128)
     model = HeteroNetwork([get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True),
                            get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True)],
                           [nn.Identity(), nn.Identity()], mu=16.0, regularize_mode="l2_ball").to(dev).train()
     method = NestedLoRAForCDK(model, neigs=sizes[-1], step=1, sequential=False, set_first_mode_const=True).to(dev)
     g = torch.Generator().manual_seed(18)
-    xs = [torch.randn(128, 128, generator=g).to(dev) for _ in range(3)]
-    ys = [torch.randn(128, 128, generator=g).to(dev) for _ in range(3)]
+    xs = [torch.randn(B, 128, generator=g).to(dev) for _ in range(3)]
+    ys = [torch.randn(B, 128, generator=g).to(dev) for _ in range(3)]
     return model, method, xs, ys
 
 
@@ -190,9 +191,10 @@ def main():
     elif mode in ("cdk_tp", "cdk_tp_amp"):
         # the CDK training step with the towers' hidden width sharded over the ranks (cdk.ShardedCdkStep)
         from neural_svd_amd.cdk import ShardedCdkStep
-        model, method, xs, ys = cdk_case(dev)
-        st = ShardedCdkStep(method, comm, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=0, batch_size=128,
-                            use_amp=mode.endswith("amp"))
+        amp = mode.endswith("amp")
+        model, method, xs, ys = cdk_case(dev, amp)
+        st = ShardedCdkStep(method, comm, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=0, batch_size=xs[0].shape[0],
+                            use_amp=amp)
         res["losses"] = [st.step(xs[t], ys[t]).clone().cpu() for t in range(3)]
         st.gather_into_model()
         res["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}

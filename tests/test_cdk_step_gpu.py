@@ -131,12 +131,14 @@ def test_cdk_step_refuses_what_it_does_not_implement():
 
 
 def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding():
-    """FusedCdkStep(use_amp=True): three training steps with the towers' contractions on bfloat16-rounded operands,
-    against oracle.cdk_train_step(gemm_bf16=True) in float64 from the same initial weights and batches - losses, total
-    gradient norms, parameters and momentum buffers - and the float32 mode beside it (close, not equal)."""
+    """FusedCdkStep(use_amp=True): three training steps in the mixed-precision mode (bfloat16 operands and wide
+    activations, both towers through every launch together, the bfloat16 weight copies of steps 2 and 3 written by the
+    previous step's optimiser kernel), against oracle.cdk_train_step(gemm_bf16=True) in float64 with the same roundings
+    from the same initial weights and batches - losses, total gradient norms, parameters and momentum buffers - and the
+    float32 mode beside it (close, not equal)."""
     from oracle import nsvd_oracle as O
     from neural_svd_amd.cdk import FusedCdkStep
-    sizes, B, mu, lr, mom, max_norm, slope = [128, 256, 128], 128, 16.0, 5e-3, 0.9, 1.0, 0.2
+    sizes, B, mu, lr, mom, max_norm, slope = [128, 256, 256], 256, 16.0, 5e-3, 0.9, 1.0, 0.2
     g = torch.Generator().manual_seed(77)
     xs = torch.randn(3, B, sizes[0], generator=g)
     ys = torch.randn(3, B, sizes[0], generator=g)

@@ -330,9 +330,9 @@ def test_cdk_step_with_the_hidden_width_sharded_matches_single_process(tmp_path,
     import _multirank_worker as W
     from neural_svd_amd.cdk import FusedCdkStep
     dev = torch.device("cuda:0")
-    model, method, xs, ys = W.cdk_case(dev)
+    model, method, xs, ys = W.cdk_case(dev, amp)
     init = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    fs = FusedCdkStep(method, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=0, batch_size=128, use_amp=amp)
+    fs = FusedCdkStep(method, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=0, batch_size=xs[0].shape[0], use_amp=amp)
     losses = [fs.step(xs[t], ys[t]).clone().cpu() for t in range(3)]
     fs.flush_counters()
     ref = {k: v.detach().cpu() for k, v in model.state_dict().items()}

@@ -130,16 +130,16 @@ def test_tower_behind_a_trainable_module_passes_the_gradient_upstream():
     assert type(head) is torch.nn.Sequential and len(head) == 3 and head[0] is m[0]
 
 
-@pytest.mark.parametrize("B,d0,d1,d2", [(128, 128, 256, 128), (1024, 512, 8192, 512),
-                                        # bottleneck towers (d1 < d0): the per-call bfloat16 copy of X is the largest
-                                        # cast operand there (round 3's scratch was sized by d1 only and overran)
-                                        (512, 512, 128, 128), (256, 1024, 128, 256)])
+@pytest.mark.parametrize("B,d0,d1,d2", [(256, 128, 256, 256), (1024, 512, 8192, 512),
+                                        # bottleneck towers (d1 < d0): the bfloat16 copy of X is the largest cast
+                                        # operand there (round 3's scratch was sized by d1 only and overran)
+                                        (512, 512, 256, 256), (256, 1024, 256, 512)])
 def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, d1, d2):
-    """gemm_bf16 (the counterpart of the reference's autocast branch, main_sketchy.py:161,182): both operands of each of
-    the five contractions rounded to bfloat16, float32 accumulation, everything else float32. Against the float64 oracle
-    that rounds the same operands (its own intermediates differ from the float32 ones by 1e-7, which moves a few
-    values in 10^5 across a bfloat16 rounding boundary: the tolerances below, not float32 noise level) - and against the
-    float32 mode, from which it must differ by about the bfloat16 rounding (2^-9 per operand), no more."""
+    """gemm_bf16 (the counterpart of the reference's autocast branch, main_sketchy.py:161,182): operands and the wide
+    activations / gradients stored as bfloat16, float32 accumulation and statistics (include/nsvd.h). Against the
+    float64 oracle that rounds the same tensors (its own intermediates differ from the float32 ones by 1e-7, which moves
+    a few values in 10^4 across a bfloat16 rounding boundary: the tolerances below, not float32 noise level) - and
+    against the float32 mode, from which it must differ by about the bfloat16 rounding (2^-9 per stored value), no more."""
     from neural_svd_amd import hip_ops as H
     g = torch.Generator().manual_seed(B + d1)
     P = dict(W1=torch.randn(d1, d0, generator=g) / d0 ** 0.5, b1=0.1 * torch.randn(d1, generator=g),
@@ -185,15 +185,15 @@ def test_tower_module_under_autocast_runs_the_mixed_precision_mode():
     from neural_svd_amd import hip_ops as H
     from neural_svd_amd.cdk import get_mlp
     torch.manual_seed(3)
-    m = get_mlp([128, 256, 128], bias=True, nonlinearity="lrelu0.2", use_bn=True).to(DEV).train()
+    m = get_mlp([128, 256, 256], bias=True, nonlinearity="lrelu0.2", use_bn=True).to(DEV).train()
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(128, 128, generator=g).to(DEV)
-    dz = torch.randn(128, 128, generator=g).to(DEV)
+    x = torch.randn(256, 128, generator=g).to(DEV)
+    dz = torch.randn(256, 256, generator=g).to(DEV)
     P = {k: dict(m.named_parameters())[n].detach().clone() for k, n in NAMES.items()}
     for k, mod, attr in (("rm1", m[1], "running_mean"), ("rv1", m[1], "running_var"), ("rm2", m[4], "running_mean"),
                          ("rv2", m[4], "running_var")):
         P[k] = getattr(mod, attr).detach().clone()
-    ws = H.tower_workspace(128, 128, 256, 128, DEV)
+    ws = H.tower_workspace(256, 128, 256, 256, DEV)
     want = H.tower_forward(x, P, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=True)
     gwant = H.tower_backward(x, P, dz, 0.2, ws, gemm_bf16=True)
     with torch.autocast("cuda", dtype=torch.float16):
@@ -205,3 +205,26 @@ def test_tower_module_under_autocast_runs_the_mixed_precision_mode():
     m.zero_grad()
     out32 = m(x)  # outside autocast: float32 contractions
     assert not torch.equal(out32, out) and rel(out32.detach(), out.detach()) < 2e-2
+
+
+def test_tower_mixed_precision_shapes_and_fallback():
+    """shapes the mixed-precision kernels do not take (a width that is not a multiple of 256): the C call refuses with
+    NSVD_EUNSUPPORTED, and the module under autocast runs the float32 kernels instead (never less precise)."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.cdk import get_mlp
+    assert H.tower_mixed_supported(1024, 512, 8192, 512) and H.tower_mixed_supported(256, 128, 256, 256)
+    assert not H.tower_mixed_supported(128, 128, 256, 256) and not H.tower_mixed_supported(256, 128, 256, 128)
+    assert H.tower_supported(128, 128, 256, 128)
+    torch.manual_seed(5)
+    m = get_mlp([128, 256, 128], bias=True, nonlinearity="lrelu0.2", use_bn=True).to(DEV).train()
+    x = torch.randn(128, 128, generator=torch.Generator().manual_seed(6)).to(DEV)
+    P = {k: dict(m.named_parameters())[n].detach().clone() for k, n in NAMES.items()}
+    for k, n in (("rm1", 256), ("rv1", 256), ("rm2", 128), ("rv2", 128)):
+        P[k] = torch.zeros(n, device=DEV) if k.startswith("rm") else torch.ones(n, device=DEV)
+    ws = H.tower_workspace(128, 128, 256, 128, DEV)
+    with pytest.raises(H.NsvdError):
+        H.tower_forward(x, P, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=True)
+    want = H.tower_forward(x, P, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=False)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = m(x)
+    assert torch.equal(out, want)
