@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
         sa += sa_step;                                                 \
         sb += sb_step;                                                 \
     }
-#define G16_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
+#define G16_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
 
     // ---- fragment addresses (byte offsets inside a stage)
     // T image: block i (16 rows), k32 step s: row r0 + 16 i + (lane & 15), chunk 4 s + (lane >> 4)
@@ -170,99 +170,130 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // S-image fragment of block i, k32 step s: two transposed reads (k-rows 8 g4 + q and + 4, q = (lane & 15) >> 2; the
-    // lane supplies the address of columns 4 (lane & 3) .. + 3 of the block's 16). The k32 step is + 8192 bytes; the
-    // block enters through its chunk index inside the swizzle
+    // ---- fragment loads. T image: block i at + 2048 i from fa[s] / fb[s]. S image: per block and k-row half one
+    // address (the block enters through its chunk index INSIDE the swizzle), the k32 step at + 8192.
 #define G16_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr))
+    int sa_off[4][2], sb_off[4][2];  // S images: [block][k-row half]
+    if (AS || BS) {
+        const int q = l15 >> 2, pp = l15 & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int krow = 8 * g4 + 4 * h2 + q;
+                const int sw = ((krow & 3) << 2) | ((krow >> 2) & 3);
+                const int ca = ((64 * (wm & 1) + 16 * i) >> 3) + (pp >> 1);
+                const int cb = ((64 * wn + 16 * i) >> 3) + (pp >> 1);
+                sa_off[i][h2] = 16384 * (wm >> 1) + 256 * krow + 16 * (ca ^ sw) + 8 * (pp & 1);
+                sb_off[i][h2] = A_BYTES + 256 * krow + 16 * (cb ^ sw) + 8 * (pp & 1);
+            }
+    }
+    struct Frags {
+        bf16x8 a[4], b[4];
+    };
+    auto load_frags = [&](Frags& f, const char* st, int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (AS) {
+                const s16x4 lo = G16_TR(st + sa_off[i][0] + 8192 * s), hi = G16_TR(st + sa_off[i][1] + 8192 * s);
+                f.a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            } else {
+                f.a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa[s] + 2048 * i));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (BS) {
+                const s16x4 lo = G16_TR(st + sb_off[j][0] + 8192 * s), hi = G16_TR(st + sb_off[j][1] + 8192 * s);
+                f.b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            } else {
+                f.b[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fb[s] + 2048 * j));
+            }
+        }
+    };
+    auto mma = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
+    };
 
+    // ---- the K loop, software-pipelined across the K steps: ONE workgroup barrier per step, in its MIDDLE.
+    //   first half of step t : MFMAs on the fragments of (t, k32 step 0) | reads of (t, k32 step 1)
+    //   barrier t            : "stage t + 1 has landed" (counted vmcnt: the DMA of t + 2 stays in flight) - and every
+    //                          wave has read all of stage t (its reads waited for: lgkmcnt(0))
+    //   DMA of step t + 3 into stage t % 3 (just freed)
+    //   second half          : MFMAs on (t, 1) | reads of (t + 1, 0)
+    // Every MFMA block runs on fragments read half a step earlier; a DMA has two steps to land.
     G16_ISSUE(0);
     if (nk > 1) G16_ISSUE(1);
+    if (nk > 2) G16_ISSUE(2);
+    if (nk > 2) G16_WAIT_BARRIER(2 * NDMA);
+    else if (nk > 1) G16_WAIT_BARRIER(NDMA);
+    else G16_WAIT_BARRIER(0);
+    Frags f0, f1;
+    if (!(a.dbg & 2)) load_frags(f0, lds, 0);
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk && !(a.dbg & 1)) G16_WAIT_BARRIER(NDMA);
-        else G16_WAIT_BARRIER(0);
-        if (t + 2 < nk && !(a.dbg & 1)) G16_ISSUE((t + 2) % NST);
-        if (a.dbg & 2) continue;
         const char* st = lds + (t % NST) * ST_BYTES;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (AS) {
-                    // block i: chunk index + 2 i inside the swizzle
-                    const int q = l15 >> 2, pp = l15 & 3;
-                    s16x4 lo, hi;
-                    {
-                        const int krow = 8 * g4 + q;
-                        const int chunk = ((64 * (wm & 1) + 16 * i) >> 3) + (pp >> 1);
-                        const int sw0 = ((krow & 3) << 2) | (((krow + 32 * s) >> 2) & 3);
-                        const int sw1 = (((krow + 4) & 3) << 2) | (((krow + 4 + 32 * s) >> 2) & 3);
-                        const char* base = st + 16384 * (wm >> 1) + 8192 * s + 8 * (pp & 1);
-                        lo = G16_TR(base + 256 * krow + 16 * (chunk ^ sw0));
-                        hi = G16_TR(base + 256 * (krow + 4) + 16 * (chunk ^ sw1));
-                    }
-                    af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                } else {
-                    af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa[s] + 2048 * i));
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (BS) {
-                    const int q = l15 >> 2, pp = l15 & 3;
-                    s16x4 lo, hi;
-                    {
-                        const int krow = 8 * g4 + q;
-                        const int chunk = ((64 * wn + 16 * j) >> 3) + (pp >> 1);
-                        const int sw0 = ((krow & 3) << 2) | (((krow + 32 * s) >> 2) & 3);
-                        const int sw1 = (((krow + 4) & 3) << 2) | (((krow + 4 + 32 * s) >> 2) & 3);
-                        const char* base = st + A_BYTES + 8192 * s + 8 * (pp & 1);
-                        lo = G16_TR(base + 256 * krow + 16 * (chunk ^ sw0));
-                        hi = G16_TR(base + 256 * (krow + 4) + 16 * (chunk ^ sw1));
-                    }
-                    bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                } else {
-                    bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fb[s] + 2048 * j));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        const char* sn = lds + ((t + 1) % NST) * ST_BYTES;
+        if (!(a.dbg & 2)) {
+            load_frags(f1, st, 1);
+            mma(f0);
+        }
+        if (t + 2 < nk && !(a.dbg & 1)) G16_WAIT_BARRIER(NDMA);
+        else G16_WAIT_BARRIER(0);
+        if (t + 3 < nk && !(a.dbg & 1)) G16_ISSUE(t % NST);
+        if (!(a.dbg & 2)) {
+            if (t + 1 < nk) load_frags(f0, sn, 0);
+            mma(f1);
         }
     }
 #undef G16_ISSUE
 #undef G16_WAIT_BARRIER
 #undef G16_TR
 
-    // ---- epilogue: lane = tile row 64 wm + 16 i + (lane & 15); registers = columns 64 wn + 16 j + 4 (lane >> 4) ..+3
-    const long row0 = (long)BM * tm + 64 * wm + l15;
-    const int col0 = BN * tn + 64 * wn + 4 * g4;
+    // ---- epilogue: lane = tile row 64 wm + 16 i + (lane & 15); registers = columns 64 wn + 16 j + 4 (lane >> 4) ..+3.
+    // Straight from the registers a store instruction would write 16 rows x 64 (32) bytes - a quarter of a cache line
+    // per row, 5.5 us for the 16 MB of a (1024, 8192) bfloat16 output. The tile goes through LDS instead (the ring is
+    // free now) and leaves as whole rows: 512 (256) contiguous bytes per row, 16-byte stores.
+    constexpr int RS = O16 ? 272 : 528;  // staged row stride in bytes (padded: the column writes spread over the banks)
     float ss = 0.f;
+    __syncthreads();  // every wave is done reading the last stage
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.bias) bv = *reinterpret_cast<const float4*>(P.bias + col0 + 16 * j);
+        if (P.bias) bv = *reinterpret_cast<const float4*>(P.bias + BN * tn + 64 * wn + 4 * g4 + 16 * j);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float c0 = acc[i][j][0] + bv.x, c1 = acc[i][j][1] + bv.y, c2 = acc[i][j][2] + bv.z,
                         c3 = acc[i][j][3] + bv.w;
             ss = fmaf(c0, c0, ss); ss = fmaf(c1, c1, ss); ss = fmaf(c2, c2, ss); ss = fmaf(c3, c3, ss);
-            const long off = (long)slice * a.slice_stride + (row0 + 16 * i) * a.ldc + col0 + 16 * j;
+            char* dst = lds + (64 * wm + 16 * i + l15) * RS + (64 * wn + 16 * j + 4 * g4) * (O16 ? 2 : 4);
             if (a.dbg & 4) {
                 asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));
             } else if (O16) {
-                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(P.C) + off) =
-                    make_uint2(pack_bf16(c0, c1), pack_bf16(c2, c3));
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(c0, c1), pack_bf16(c2, c3));
             } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.C) + off) = make_float4(c0, c1, c2, c3);
+                *reinterpret_cast<float4*>(dst) = make_float4(c0, c1, c2, c3);
             }
+        }
+    }
+    __syncthreads();
+    if (!(a.dbg & 4)) {
+        constexpr int LPR = O16 ? 16 : 32;        // lanes per row (16 bytes each)
+        constexpr int RPP = 512 / LPR;            // rows per pass of the workgroup
+        const int rr = tid / LPR, cc = tid % LPR;
+        char* cbase = reinterpret_cast<char*>(P.C) + ((long)slice * a.slice_stride + (long)BM * tm * a.ldc + BN * tn) * (O16 ? 2 : 4);
+#pragma unroll 4
+        for (int r = rr; r < BM; r += RPP) {
+            const uint4 v = *reinterpret_cast<const uint4*>(lds + r * RS + 16 * cc);
+            *reinterpret_cast<uint4*>(cbase + (long)r * a.ldc * (O16 ? 2 : 4) + 16 * cc) = v;
         }
     }
     if (P.sumsq) {  // fixed order: lanes of a wave (butterfly), then the eight waves
         ss = nsvd_wave_sum(ss);
-        __syncthreads();  // every wave is done reading the last stage
+        __syncthreads();  // the staged tile has been read out
         float* red = reinterpret_cast<float*>(lds);
         if (lane == 0) red[w] = ss;
         __syncthreads();
@@ -277,7 +308,7 @@ inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16,
     Args a = a0;
     if (a.nprob < 1 || a.nprob > 2 || a.S < 1 || a.M <= 0 || a.N <= 0 || a.K <= 0) return NSVD_EINVAL;
     if (a.M % BM || a.N % BN || a.K % (BK * a.S)) return NSVD_EINVAL;
-    if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 4)) return NSVD_EINVAL;  // 16-byte DMA sources, 8 / 16-byte stores
+    if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % (out_bf16 ? 8 : 4))) return NSVD_EINVAL;  // 16-byte DMA sources and stores
     for (int i = 0; i < a.nprob; ++i) {
         if (!a.p[i].A || !a.p[i].B || !a.p[i].C) return NSVD_EINVAL;
         if (((uintptr_t)a.p[i].A | (uintptr_t)a.p[i].B | (uintptr_t)a.p[i].C | (uintptr_t)a.p[i].bias) & 15) return NSVD_EINVAL;

@@ -521,6 +521,15 @@ typedef unsigned short bf16_t;
 
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// (opaque: the compiler may not keep the eight floats of a row alive from one phase of a strip kernel to the next - the
+// strip lives in registers PACKED, 4 registers per row, and is unpacked again where it is used)
+__device__ __forceinline__ void unpack8_fresh(uint4 u, float (&v)[8]) {
+    asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w));
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
 __device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
     v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y);
     v[4] = bf16_lo(u.z); v[5] = bf16_hi(u.z); v[6] = bf16_lo(u.w); v[7] = bf16_hi(u.w);
@@ -596,7 +605,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) 
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float v[8];
-            unpack8(raw[k], v);
+            unpack8_fresh(raw[k], v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s1[j] += v[j];
         }
@@ -613,7 +622,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) 
     for (int k = 0; k < BN16_MAXR; ++k)  // two-pass variance: mean first, then the squared deviations
         if (k < nr) {
             float v[8];
-            unpack8(raw[k], v);
+            unpack8_fresh(raw[k], v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = v[j] - mu[j];
@@ -648,7 +657,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) 
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float v[8];
-            unpack8(raw[k], v);
+            unpack8_fresh(raw[k], v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float o = fmaf((v[j] - mu[j]) * sc[j], sh[j], be[j]);
@@ -704,8 +713,8 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a)
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float y[8], d[8];
-            unpack8(yr[k], y);
-            unpack8(dr[k], d);
+            unpack8_fresh(yr[k], y);
+            unpack8_fresh(dr[k], d);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float yh = (y[j] - mu[j]) * inv[j];
@@ -732,8 +741,8 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a)
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float y[8], d[8];
-            unpack8(yr[k], y);
-            unpack8(dr[k], d);
+            unpack8_fresh(yr[k], y);
+            unpack8_fresh(dr[k], d);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float yh = (y[j] - mu[j]) * inv[j];
