@@ -121,6 +121,7 @@ struct StepWs {
     float* partial;  // [small tensors: SUMSQ_BLOCKS | tower x: per GEMM tile | tower y: per GEMM tile]
     int npartial;
     float* scal;
+    float* narrow;   // scratch of the fused narrow end (cdk_narrow.hip), mixed precision
     size_t tower_bytes, cdk_bytes, bytes;
     size_t goff[NT], gn[NT];
 };
@@ -158,6 +159,7 @@ StepWs carve_step(const nsvd_cdk_step_desc& d, void* base) {
     w.npartial = SUMSQ_BLOCKS + 2 * nsvd_tower_sumsq_count(d.d0, d.d1, d.d2, d.gemm_bf16 != 0);
     w.partial = (float*)take((size_t)w.npartial * sizeof(float));
     w.scal = (float*)take(256);
+    w.narrow = (float*)take(nsvd_narrow_scratch_floats(2, d.B, d.d2) * sizeof(float));
     w.bytes = off;
     return w;
 }
@@ -200,12 +202,32 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     // forward: towers (BatchNorm running statistics updated, as a training-mode module does), normalisation
     const bool mixed = d->gemm_bf16 != 0;
     const nsvd_tower_params* tp[2] = {&towers[0], &towers[1]};
-    if (mixed) {  // both towers through every launch together (tower.hip, mixed-precision section)
+    // mixed precision: both towers through every launch together (tower.hip, mixed-precision section), and the narrow
+    // end - split-K sum, second BatchNorm, normalisation - as three launches for both (cdk_narrow.hip)
+    const bool narrow = mixed && nsvd_narrow_supported(2, B, L);
+    NsvdTowerNarrowViews nv[2];
+    if (mixed) {
         rc = nsvd_tower16_forward_pair(in, tp, B, d->d0, d->d1, d->d2, d->slope, d->bn_eps, d->bn_momentum, 1,
-                                       d->gemm_bf16, w.z, w.tower, w.tower_bytes, s);
+                                       d->gemm_bf16 | (narrow ? NSVD_TOWER16_WIDE_ONLY : 0), w.z, w.tower,
+                                       w.tower_bytes, s);
         if (rc) return rc;
     }
-    for (int t = 0; t < 2; ++t) {
+    if (narrow) {
+        NsvdNarrowFwd f;
+        memset(&f, 0, sizeof(f));
+        for (int t = 0; t < 2; ++t) {
+            nv[t] = nsvd_tower16_narrow_views(2, B, d->d0, d->d1, d->d2, w.tower[t]);
+            f.Y2p[t] = nv[t].Y2p; f.bias[t] = towers[t].b2; f.gamma[t] = towers[t].g2; f.beta[t] = towers[t].be2;
+            f.running_mean[t] = towers[t].rm2; f.running_var[t] = towers[t].rv2;
+            f.mean[t] = nv[t].mean2; f.invstd[t] = nv[t].inv2; f.Y2[t] = nv[t].Y2; f.z[t] = w.z[t]; f.e[t] = w.e[t];
+        }
+        f.nt = 2; f.B = B; f.N = L; f.S = nv[0].S; f.slice_stride = nv[0].slice_stride; f.part = w.narrow;
+        f.eps = d->bn_eps; f.momentum = d->bn_momentum; f.r_up = r_up;
+        f.sphere = d->normalize_mode == NSVD_NORMALIZE_L2_SPHERE;
+        rc = nsvd_narrow_forward(f, s);
+        if (rc) return rc;
+    }
+    for (int t = 0; t < 2 && !narrow; ++t) {
         if (!mixed) {
             rc = nsvd_tower_forward(in[t], &towers[t], B, d->d0, d->d1, d->d2, d->slope, d->bn_eps, d->bn_momentum, 1,
                                     0, w.z[t], w.tower[t], w.tower_bytes, stream);
@@ -229,8 +251,10 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     const int nsq = nsvd_tower_sumsq_count(d->d0, d->d1, d->d2, mixed);
     float* sq[2] = {w.partial + SUMSQ_BLOCKS, w.partial + SUMSQ_BLOCKS + nsq};
     for (int t = 0; t < 2; ++t) {
-        rc = nsvd_row_normalize_backward(w.z[t], w.ge[t], B, L, r_up, d->normalize_mode, w.dz[t], stream);
-        if (rc) return rc;
+        if (!narrow) {
+            rc = nsvd_row_normalize_backward(w.z[t], w.ge[t], B, L, r_up, d->normalize_mode, w.dz[t], stream);
+            if (rc) return rc;
+        }
         nsvd_tower_params& g = gr[t];
         memset(&g, 0, sizeof(g));
         for (int k = 0; k < NT; ++k) gp[t][k] = w.grad[t] + w.goff[k];
@@ -242,10 +266,24 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
             if (rc) return rc;
         }
     }
+    if (narrow) {  // normalisation backward, second BatchNorm backward -> bfloat16 dY2 in the towers' workspaces
+        NsvdNarrowBwd b;
+        memset(&b, 0, sizeof(b));
+        for (int t = 0; t < 2; ++t) {
+            b.z[t] = w.z[t]; b.ge[t] = w.ge[t]; b.Y2[t] = nv[t].Y2; b.mean[t] = nv[t].mean2; b.invstd[t] = nv[t].inv2;
+            b.gamma[t] = towers[t].g2; b.dz[t] = w.dz[t]; b.dY[t] = nv[t].dY2h;
+            b.dgamma[t] = gr[t].g2; b.dbeta[t] = gr[t].be2; b.dbias[t] = gr[t].b2;
+        }
+        b.nt = 2; b.B = B; b.N = L; b.dy_bf16 = 1; b.part = w.narrow; b.r_up = r_up;
+        b.sphere = d->normalize_mode == NSVD_NORMALIZE_L2_SPHERE;
+        rc = nsvd_narrow_backward(b, s);
+        if (rc) return rc;
+    }
     if (mixed) {
         const nsvd_tower_params* gq[2] = {&gr[0], &gr[1]};
         const float* dzs[2] = {w.dz[0], w.dz[1]};
-        rc = nsvd_tower16_backward_pair(in, tp, dzs, B, d->d0, d->d1, d->d2, d->slope, gq, w.tower, w.tower_bytes, sq, s);
+        rc = nsvd_tower16_backward_pair(in, tp, dzs, B, d->d0, d->d1, d->d2, d->slope, gq, w.tower, w.tower_bytes, sq, s,
+                                        narrow ? NSVD_TOWER16_WIDE_ONLY : 0);
         if (rc) return rc;
     }
     for (int t = 0; t < 2; ++t) {

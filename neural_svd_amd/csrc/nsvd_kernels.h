@@ -116,10 +116,67 @@ int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const 
                               int d2, float slope, int gemm_bf16, const nsvd_tower_params* grads, void* ws,
                               size_t ws_bytes, float* sumsq, void* stream);
 // mixed precision: both towers of a step through every launch together (tower.hip); sumsq[t]: that tower's partials
+// flags: the gemm_bf16 bits, plus NSVD_TOWER16_WIDE_ONLY: stop behind the split-K partial products of Y2 (forward; z
+// unused) / start behind dY2 (backward: the caller has written the bfloat16 dY2 into the workspace, dz unused) - the
+// narrow end is then the caller's (cdk_narrow.hip)
+constexpr int NSVD_TOWER16_WIDE_ONLY = 4;
 int nsvd_tower16_forward_pair(const float* const* x, const nsvd_tower_params* const* p, int B, int d0, int d1, int d2,
                               float slope, float eps, float momentum, int update_running, int flags, float* const* z,
                               void* const* ws, size_t ws_bytes, hipStream_t s);
 int nsvd_tower16_backward_pair(const float* const* x, const nsvd_tower_params* const* p, const float* const* dz, int B,
                                int d0, int d1, int d2, float slope, const nsvd_tower_params* const* grads,
-                               void* const* ws, size_t ws_bytes, float* const* sumsq, hipStream_t s);
+                               void* const* ws, size_t ws_bytes, float* const* sumsq, hipStream_t s, int flags = 0);
 void nsvd_tower16_weight_copies(int B, int d0, int d1, int d2, void* ws, void** W1h, void** W2h);
+
+// ---- the narrow end of a CDK step for both towers at once (cdk_narrow.hip): split-K sum + bias, BatchNorm2 (training),
+// normalize; and the backward of the three. Per tower t < nt.
+struct NsvdNarrowFwd {
+    int nt, B, N, S;
+    size_t slice_stride;         // floats between the split-K slices of Y2p
+    const float* Y2p[2];         // (S, B, N) partial products (no bias)
+    const float* bias[2];        // b2 (N) or null
+    const float* gamma[2];
+    const float* beta[2];
+    float* running_mean[2];      // updated in place, or null
+    float* running_var[2];
+    float* mean[2];              // (N) saved for the backward
+    float* invstd[2];
+    float* Y2[2];                // (B, N) the summed pre-normalisation output (kept for the backward)
+    float* z[2];                 // (B, N) BatchNorm output
+    float* e[2];                 // (B, N) normalize(z)
+    float* part;                 // scratch: nsvd_narrow_scratch_floats
+    float eps, momentum, r_up;
+    int sphere;                  // 0: l2_ball, 1: l2_sphere
+};
+struct NsvdNarrowBwd {
+    int nt, B, N;
+    const float* z[2];           // (B, N) the forward's BatchNorm output
+    const float* ge[2];          // (B, N) gradient w.r.t. normalize(z)
+    const float* Y2[2];
+    const float* mean[2];
+    const float* invstd[2];
+    const float* gamma[2];
+    float* dz[2];                // (B, N) scratch: gradient w.r.t. z
+    void* dY[2];                 // (B, N) gradient w.r.t. Y2: bfloat16 when dy_bf16, else float32
+    int dy_bf16;
+    float* dgamma[2];
+    float* dbeta[2];
+    float* dbias[2];             // gradient of b2
+    float* part;                 // scratch: nsvd_narrow_scratch_floats
+    float* m1[2];                // (set by nsvd_narrow_backward: inside `part`)
+    float* m2[2];
+    float r_up;
+    int sphere;
+};
+size_t nsvd_narrow_scratch_floats(int nt, int B, int N);
+bool nsvd_narrow_supported(int nt, int B, int N);
+int nsvd_narrow_forward(const NsvdNarrowFwd& a, hipStream_t s);
+int nsvd_narrow_backward(const NsvdNarrowBwd& a, hipStream_t s);
+// a mixed-precision tower's narrow-end buffers inside its workspace, and the split-K slice count of a launch of nt towers
+struct NsvdTowerNarrowViews {
+    float *Y2p, *Y2, *mean2, *inv2;
+    void* dY2h;
+    int S;
+    size_t slice_stride;
+};
+NsvdTowerNarrowViews nsvd_tower16_narrow_views(int nt, int B, int d0, int d1, int d2, void* ws);

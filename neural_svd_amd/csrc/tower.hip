@@ -859,6 +859,7 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
     g.slice_stride = (long)B * d2;
     rc = nsvd_g16::launch(g, false, false, false, s);
     if (rc) return rc;
+    if (flags & NSVD_TOWER16_WIDE_ONLY) return 0;  // the narrow end is the caller's (cdk_narrow.hip)
     for (int t = 0; t < nt; ++t) {
         const size_t n4 = (size_t)B * d2 / 4;
         hipLaunchKernelGGL(tower_sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w[t].Y2p,
@@ -884,7 +885,7 @@ inline int sumsq_count16(int d0, int d1, int d2) { return (d2 / 256) * (d1 / 128
 
 int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* const* p, const float* const* dz, int B,
                      int d0, int d1, int d2, float slope, const nsvd_tower_params* const* grads, void* const* ws,
-                     float* const* sumsq, hipStream_t s) {
+                     float* const* sumsq, hipStream_t s, int flags = 0) {
     if (!tower16_shape_ok(B, d0, d1, d2)) return NSVD_EUNSUPPORTED;
     TowerWs w[2];
     Tower16 v[2];
@@ -893,7 +894,7 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
         v[t] = views16(w[t]);
     }
     int rc = 0;
-    for (int t = 0; t < nt; ++t) {  // dY2h = BN2'(dZ), db2
+    for (int t = 0; t < nt && !(flags & NSVD_TOWER16_WIDE_ONLY); ++t) {  // dY2h = BN2'(dZ), db2
         BnBwd b;
         memset(&b, 0, sizeof(b));
         b.dout = dz[t]; b.Y = w[t].Y2; b.mean = w[t].mean2; b.invstd = w[t].inv2; b.gamma = p[t]->g2; b.beta = p[t]->be2;
@@ -1053,7 +1054,8 @@ int nsvd_tower16_forward_pair(const float* const* x, const nsvd_tower_params* co
                               void* const* ws, size_t ws_bytes, hipStream_t s) {
     if (!tower16_shape_ok(B, d0, d1, d2)) return NSVD_EUNSUPPORTED;
     for (int t = 0; t < 2; ++t) {
-        if (!x[t] || !p[t] || !z[t] || !ws[t] || ((uintptr_t)ws[t] & 255) != 0) return NSVD_EINVAL;
+        if (!x[t] || !p[t] || (!z[t] && !(flags & NSVD_TOWER16_WIDE_ONLY)) || !ws[t] || ((uintptr_t)ws[t] & 255) != 0)
+            return NSVD_EINVAL;
         if (!p[t]->W1 || !p[t]->b1 || !p[t]->g1 || !p[t]->be1 || !p[t]->W2 || !p[t]->b2 || !p[t]->g2 || !p[t]->be2)
             return NSVD_EINVAL;
         if (update_running && (!p[t]->rm1 || !p[t]->rv1 || !p[t]->rm2 || !p[t]->rv2)) return NSVD_EINVAL;
@@ -1064,12 +1066,23 @@ int nsvd_tower16_forward_pair(const float* const* x, const nsvd_tower_params* co
 
 int nsvd_tower16_backward_pair(const float* const* x, const nsvd_tower_params* const* p, const float* const* dz, int B,
                                int d0, int d1, int d2, float slope, const nsvd_tower_params* const* grads,
-                               void* const* ws, size_t ws_bytes, float* const* sumsq, hipStream_t s) {
+                               void* const* ws, size_t ws_bytes, float* const* sumsq, hipStream_t s, int flags) {
     if (!tower16_shape_ok(B, d0, d1, d2)) return NSVD_EUNSUPPORTED;
     for (int t = 0; t < 2; ++t)
-        if (!x[t] || !p[t] || !dz[t] || !grads[t] || !ws[t] || ((uintptr_t)ws[t] & 255) != 0) return NSVD_EINVAL;
+        if (!x[t] || !p[t] || (!dz[t] && !(flags & NSVD_TOWER16_WIDE_ONLY)) || !grads[t] || !ws[t] ||
+            ((uintptr_t)ws[t] & 255) != 0)
+            return NSVD_EINVAL;
     if (ws_bytes < carve_tower(B, d0, d1, d2, nullptr).bytes) return NSVD_EINVAL;
-    return tower16_backward(2, x, p, dz, B, d0, d1, d2, slope, grads, ws, sumsq, s);
+    return tower16_backward(2, x, p, dz, B, d0, d1, d2, slope, grads, ws, sumsq, s, flags);
+}
+
+NsvdTowerNarrowViews nsvd_tower16_narrow_views(int nt, int B, int d0, int d1, int d2, void* ws) {
+    const TowerWs w = carve_tower(B, d0, d1, d2, ws);
+    NsvdTowerNarrowViews v;
+    v.Y2p = w.Y2p; v.Y2 = w.Y2; v.mean2 = w.mean2; v.inv2 = w.inv2; v.dY2h = views16(w).dY2h;
+    v.S = fwd2_slices16(nt, B, d1, d2);
+    v.slice_stride = (size_t)B * d2;
+    return v;
 }
 
 // where the bfloat16 copies of W1 / W2 live inside a tower workspace (the optimiser kernel of the fused step refreshes them)
