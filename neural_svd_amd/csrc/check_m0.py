@@ -7,7 +7,7 @@ no M0 use of its own in those kernels (movrel register-array indexing, the LDS-D
 an M0 payload ...). This script disassembles the code object of the build's architecture (NSVD_ARCH, default gfx950) inside each given .o and fails the build unless
 
   * every instruction that mentions m0 is `s_mov_b32 m0, <sgpr>`, and
-  * each of them is followed by `s_nop 0` and then `global_load_lds_dwordx4`, and
+  * each of them is followed by `s_nop 0` and then `global_load_lds_dwordx4` (or `_dword`: gemm16.h's bias pieces), and
   * every `global_load_lds_*` is preceded by exactly that pair.
 
 Usage: check_m0.py build/pmlp_bwd.o build/tower.o
@@ -53,7 +53,7 @@ def check(obj):
     for i, t in enumerate(ins):
         if re.search(r"\bm0\b", t):
             ok = bool(mov.match(t)) and i + 2 < len(ins) and ins[i + 1].startswith("s_nop 0") and \
-                ins[i + 2].startswith("global_load_lds_dwordx4")
+                re.match(r"^global_load_lds_dword(x4)?\b", ins[i + 2]) is not None
             pairs += ok
             if not ok:
                 bad.append((i, t, ins[i + 1:i + 3]))

@@ -288,7 +288,13 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
 #pragma unroll 4
         for (int r = rr; r < BM; r += RPP) {
             const uint4 v = *reinterpret_cast<const uint4*>(lds + r * RS + 16 * cc);
-            *reinterpret_cast<uint4*>(cbase + (long)r * a.ldc * (O16 ? 2 : 4) + 16 * cc) = v;
+            char* dstp = cbase + (long)r * a.ldc * (O16 ? 2 : 4) + 16 * cc;
+            // write-through (sc1): the rows leave for memory as they are stored instead of sitting dirty in this XCD's L2
+            // until the kernel-end write-back (MI355X_MICROARCH.md, stores of each flavour / row `boundary`): 0.9 us of
+            // the 15.8 at (1024, 8192, 512) bfloat16 out, 1.5 of 23.5 at (512, 8192, 1024) float32 out
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 vv = {v.x, v.y, v.z, v.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
         }
     }
     if (P.sumsq) {  // fixed order: lanes of a wave (butterfly), then the eight waves
