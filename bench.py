@@ -534,20 +534,27 @@ def bench_widened(args):
 
         def step():
             last["loss"] = fused.step(x, y)[0]
-        kflops = 2.0 * B * d0 * (d1 // world)
-        kname = "tower_gemm_nt_kernel"
+        # the bracketed launch (nsvd_profile_next_forward): the first contraction Y1 = X W1^T + b1 - float32: one tower's
+        # (tower_gemm_nt_kernel, fp32 MFMA); mixed precision: BOTH towers' in one launch (gemm16_kernel, bf16 MFMA)
+        kflops = 2.0 * B * d0 * (d1 // world) * (2 if (args.amp and comm is None) else 1)
+        kname = "nsvd_g16::gemm16_kernel<false, false, true>" if args.amp else "tower_gemm_nt_kernel"
+        # algorithmic bytes of that launch: X and W1 read once, Y1 written once (bfloat16 / float32)
+        kbytes = ((B * d0 + d0 * (d1 // world)) * (2 if args.amp else 4) + B * (d1 // world) * (2 if args.amp else 4)) * \
+            (2 if (args.amp and comm is None) else 1)
         workload = (f"configs[4]: CDK step on synthetic features x, y ~ randn({B}, {d0}): two towers {d0} -> {d1} -> "
                     f"{d2} (Linear-BatchNorm-lrelu0.2-Linear-BatchNorm), l2_ball mu = 16, NestedLoRAForCDK L = {L} + "
                     f"constant mode, joint nesting, SGD lr 5e-3 momentum 0.9")
         metric = "training steps/sec, CDK two-tower step L=512 B=1024 (NestedLoRA CDK path)"
         if args.amp:
-            metric += (" [mixed precision: bfloat16 operands in the tower contractions, float32 accumulation - this "
-                       "build's own mode, DIFFERENT arithmetic from the Sketchy script's float16 autocast + GradScaler "
+            metric += (" [mixed precision: bfloat16 operands, wide activations and their gradients, bf16 MFMA with "
+                       "float32 accumulation, float32 statistics / loss / parameter gradients / update - this build's own "
+                       "mode, DIFFERENT arithmetic from the Sketchy script's float16 autocast + GradScaler "
                        "(examples/cdk/sketchy/main_sketchy.py:161,182), pinned to the float64 oracle with the same "
-                       "operand rounding, not to a reference fixture]")
-        note = ("one C call per step (nsvd_cdk_step): towers on csrc/tower.hip (five fp32-MFMA contractions + BatchNorm "
-                "strip kernels each, forward + backward), normalisation, CDK loss, global gradient-norm clip and SGD "
-                "momentum (scripts/exps/sketchy.sh: --optimizer sgd --momentum 0.9 --clip_grad_norm); no torch "
+                       "roundings, not to a reference fixture]")
+        note = ("one C call per step (nsvd_cdk_step): towers on csrc/tower.hip (five contractions + BatchNorm strip "
+                "kernels each way; mixed precision: csrc/gemm16.h, both towers per launch, no transposed or re-cast "
+                "copies, the narrow end on csrc/cdk_narrow.hip), normalisation, CDK loss, global gradient-norm clip and "
+                "SGD momentum (scripts/exps/sketchy.sh: --optimizer sgd --momentum 0.9 --clip_grad_norm); no torch "
                 "autograd, no torch.optim")
     use_ev = not args.no_kernel_events
     blocks, kms, n_pre = _timed_blocks(step, steps, warmup, repeats, args.prewarm_seconds,
@@ -584,6 +591,12 @@ def bench_widened(args):
                     frac=round(ach / peak, 4), traffic=None, kernel=kname,
                     kernel_avg_us=round(kavg * 1e3, 2), kernel_med_us=round(kms[len(kms) // 2] * 1e3, 2),
                     kernel_launches_timed=len(kms), kernel_flops=kflops)
+        if args.config == "cfg5":
+            # this contraction's arithmetic intensity sits next to the ridge of the bf16 roofline (2500 TFLOP/s over
+            # 8 TB/s = 312 FLOP/B): both bounds are reported
+            roof.update(algorithmic_bytes=int(kbytes), flops_per_byte=round(kflops / kbytes, 1),
+                        hbm_GBps=round(kbytes / (kavg * 1e-3) / 1e9, 1),
+                        hbm_frac=round(kbytes / (kavg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
     out = {"metric": metric, "value": summ["value"], "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
            "vs_baseline": None,

@@ -44,36 +44,42 @@ __global__ void __launch_bounds__(256) cdk_sumsq_kernel(TensorTable t, float* __
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// scal[0] = total gradient norm, scal[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (torch's clip_grad_norm_)
-__global__ void __launch_bounds__(256) cdk_norm_finish_kernel(const float* __restrict__ partial, int nblocks,
-                                                              float max_norm, float* __restrict__ scal,
-                                                              float* __restrict__ loss_out) {
+// g' = coef g; buf = first ? g' : momentum buf + g'; p -= lr buf   (torch.optim.SGD, no dampening / nesterov / decay)
+// coef = torch's clip_grad_norm_ coefficient min(1, max_norm / (norm + 1e-6)), norm = sqrt of the sum of the partial
+// sums of squares - added by EVERY workgroup for itself, in one fixed order (256 threads stride the partials, then a
+// halving tree, in double): every workgroup gets the same bits, and the one-workgroup launch that used to sit between
+// the gradient kernels and this one is gone. Workgroup 0 leaves norm and coefficient in scal / loss_out[3].
+__global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float* __restrict__ partial, int npartial,
+                                                      float max_norm, float* __restrict__ scal,
+                                                      float* __restrict__ loss_out, float lr, float momentum, int first) {
     __shared__ double red[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __shared__ float coef_s;
+    {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < npartial; i += 256) s += (double)partial[i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float norm = (float)sqrt(red[0]);
+            float coef = 1.f;
+            if (max_norm > 0.f) {
+                coef = max_norm / (norm + 1e-6f);
+                coef = coef > 1.f ? 1.f : coef;  // (a NaN norm gives a NaN coefficient, as in torch)
+            }
+            coef_s = coef;
+            if (blockIdx.x == 0) {
+                scal[0] = norm;
+                scal[1] = coef;
+                if (loss_out) loss_out[3] = norm;
+            }
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const float norm = (float)sqrt(red[0]);
-        float coef = 1.f;
-        if (max_norm > 0.f) {
-            coef = max_norm / (norm + 1e-6f);
-            coef = coef > 1.f ? 1.f : coef;  // (a NaN norm gives a NaN coefficient, as in torch)
-        }
-        scal[0] = norm;
-        scal[1] = coef;
-        if (loss_out) loss_out[3] = norm;
-    }
-}
-
-// g' = coef g; buf = first ? g' : momentum buf + g'; p -= lr buf   (torch.optim.SGD, no dampening / nesterov / decay)
-__global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float* __restrict__ scal, float lr,
-                                                      float momentum, int first) {
-    const float coef = scal[1];
+    const float coef = coef_s;
     const size_t total4 = t.start[2 * NT];
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (size_t)gridDim.x * 256) {
         int k = 0;
@@ -306,13 +312,10 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     // clip_grad_norm_ + SGD momentum over all 16 tensors
     hipLaunchKernelGGL(cdk_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, tab, w.partial);
     NSVD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cdk_norm_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)w.partial, w.npartial,
-                       (float)d->max_grad_norm, w.scal, loss);
-    NSVD_CHECK_LAUNCH();
     size_t blocks = (q4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, (const float*)w.scal,
-                       (float)d->lr, (float)d->momentum, d->first_step);
+    if (blocks > 2048) blocks = 2048;  // (each workgroup first adds the partials for itself: not too many of them)
+    hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, (const float*)w.partial, w.npartial,
+                       (float)d->max_grad_norm, w.scal, loss, (float)d->lr, (float)d->momentum, d->first_step);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
