@@ -15,6 +15,13 @@ from tests import _golden as G
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
 KEYS = {"W1": "0.weight", "b1": "0.bias", "g1": "1.weight", "be1": "1.bias", "W2": "3.weight", "b2": "3.bias",
         "g2": "4.weight", "be2": "4.bias"}
 
@@ -175,3 +182,51 @@ def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding():
     # float32 mode: the same trajectory up to the bfloat16 operand rounding
     l_amp, l_32 = float(runs[True][0][2][0]), float(runs[False][0][2][0])
     assert l_amp != l_32 and abs(l_amp - l_32) < 2e-2 * max(1.0, abs(l_32)), (l_amp, l_32)
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_cdk_step_at_headline_size_against_the_oracle(amp):
+    """BASELINE.json configs[4] at its own size (B = 1024, towers 512 -> 8192 -> 512, L = 512 + constant mode): ONE fused
+    nsvd_cdk_step against oracle.cdk_train_step (reference main_sketchy.py:180-212; float64; amp: the same roundings) from
+    the same weights and batch: loss terms, total gradient norm, and the update of every parameter tensor on sampled
+    rows / columns (the oracle's 16.8 M-parameter step runs once, in float64, on the CPU: about half a minute)."""
+    from oracle import nsvd_oracle as O
+    from neural_svd_amd.cdk import FusedCdkStep
+    sizes, B, mu, lr, mom, max_norm, slope = [512, 8192, 512], 1024, 16.0, 5e-3, 0.9, 1.0, 0.2
+    g = torch.Generator().manual_seed(123)
+    x, y = torch.randn(B, sizes[0], generator=g), torch.randn(B, sizes[0], generator=g)
+    model, method = _build(sizes, mu, 5)
+    sd0 = {k: v.detach().double().cpu().clone() for k, v in model.state_dict().items()}
+    fs = FusedCdkStep(method, lr=lr, momentum=mom, max_grad_norm=max_norm, t_max=0, batch_size=B, use_amp=amp)
+    out = fs.step(x.to(DEV), y.to(DEV)).cpu().double().clone()
+    fs.flush_counters()
+    sd = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    towers = [{k: sd0[f"backbones.{s}.{n}"].clone() for k, n in KEYS.items()} for s in "xy"]
+    bufs = [{k: torch.zeros_like(v) for k, v in t.items()} for t in towers]
+    running = [dict(rm1=sd0[f"backbones.{s}.1.running_mean"].clone(), rv1=sd0[f"backbones.{s}.1.running_var"].clone(),
+                    rm2=sd0[f"backbones.{s}.4.running_mean"].clone(), rv2=sd0[f"backbones.{s}.4.running_var"].clone())
+               for s in "xy"]
+    v, M = method.vector_mask.double().cpu(), method.matrix_mask.double().cpu()
+    (loss, lop, lmet), total = O.cdk_train_step(x.double(), y.double(), towers, bufs, running, v, M, mu, lr, mom,
+                                                max_norm, slope, True, gemm_bf16=amp)
+    tl = 5e-4 if amp else 2e-5
+    assert abs(float(out[0]) - float(loss)) < tl * max(1.0, abs(float(loss))), (float(out[0]), float(loss))
+    assert abs(float(out[1]) - float(lop)) < tl * max(1.0, abs(float(lop)))
+    assert abs(float(out[2]) - float(lmet)) < tl * max(1.0, abs(float(lmet)))
+    assert abs(float(out[3]) - float(total)) < (5e-3 if amp else 1e-4) * float(total), (float(out[3]), float(total))
+    rows = torch.tensor([0, 1, 127, 128, 255, 256, 300, 511])
+    for si, s in enumerate("xy"):
+        for k, n in KEYS.items():
+            got, want, start = sd[f"backbones.{s}.{n}"], towers[si][k], sd0[f"backbones.{s}.{n}"]
+            if got.dim() == 2:  # sampled rows and a stride of columns of the weight matrices
+                r = rows[rows < got.shape[0]]
+                got, want, start = got[r][:, ::7], want[r][:, ::7], start[r][:, ::7]
+            move = float((want - start).norm())
+            d = float((got - want).norm())
+            # the UPDATE (lr x clipped gradient) against the oracle's; float32 storage of the parameter itself: 6e-8 |p|
+            assert d < (2e-2 if amp else 2e-4) * move + 2e-7 * float(want.norm()), (s, k, d, move)
+        for tag in ("1", "4"):
+            for stat in ("running_mean", "running_var"):
+                got = sd[f"backbones.{s}.{tag}.{stat}"]
+                want = running[si][("rm" if stat == "running_mean" else "rv") + ("1" if tag == "1" else "2")]
+                assert rel(got, want) < (2e-3 if amp else 1e-5), (s, tag, stat, rel(got, want))

@@ -228,3 +228,77 @@ def test_fused_kernel_trainer_matches_the_module_loop():
         # biases start at zero: after three sign-like RMSprop steps they are ~3e-3 and float32 noise in a gradient of
         # the same magnitude on both sides shows at 1e-5..1e-4 of that
         assert d < (2e-4 if ".bs." in n else 2e-5), (n, d)
+
+
+def test_configs3_full_size_fused_step():
+    """BASELINE.json configs[3] at its OWN size - dense PSD kernel operator on N = 10 000 points, L = 64, B = 8192
+    indices, joint nesting - the COMPOSITE step FusedKernelTrainer takes there (reduced moments from 128 chunk partials,
+    split weight-gradient tiles, the optimiser in the weight-gradient epilogue), against the float64 oracle of
+    NestedLoRA.compute_loss_kernel (reference methods/nestedlora.py:230-252; the operator itself has no reference
+    implementation: K f in float64 from the same K):
+      * f = model(z[idx]) (all 64 heads) and Kf = K[idx][:, idx] f / B against float64;
+      * moments, loss against the float64 formulas on the float64 (f, Kf) - end to end;
+      * every gradient of two sampled heads (first and last) against the float64 backward with the float64 d loss / d f;
+      * the step itself: its loss is that loss, its parameters are RMSprop(those gradients) bit for bit."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.kernel_ops import FusedKernelTrainer, synthetic_psd_kernel
+    from oracle import nsvd_oracle as O
+    N, D, L, B, m = 10000, 16, 64, 8192, 64
+    op = synthetic_psd_kernel(N, 256, D, 0, DEV)
+    lr, alpha, eps = 1e-4, 0.99, 1e-8
+    fk = FusedKernelTrainer(op, L=L, m=m, hidden=(128, 128), batch_size=B, sequential=False, lr=lr, rmsprop_decay=alpha,
+                            rmsprop_eps=eps, fourier_scale=0.05, seed=0)
+    assert fk.mask_kind == H.MASK_JOINT
+    idx = op.sample_indices(B, torch.Generator(device=DEV).manual_seed(3))
+    x = op.points.index_select(0, idx)
+    # the trainer's own call sequence with the gradients written instead of consumed
+    H.model_forward(fk.shape, fk._params, x, 1.0, fk.ws, save_for_backward=True, out=fk.f_loc)
+    H.kernel_apply(op.K, op.N, idx, idx, fk.f_loc, 1.0 / B, ws=fk.ka_ws, out=fk.Kf_loc)
+    H.evd_moments(fk.f, fk.Kf, fk.mask_kind, None, fk.moments, fk.scratch)
+    fk.P.grad.fill_(float("nan"))
+    loss = torch.zeros(3, device=DEV)
+    H.model_backward_evd_step(fk.shape, fk._params, x, fk.f, fk.Kf, fk.mask_kind, None, None, fk.moments, True, None,
+                              loss, fk.P.pack(fk.P.grad, False), None, fk.ws)
+    torch.cuda.synchronize()
+    f_hip, Kf_hip, mom = fk.f.clone(), fk.Kf.clone(), fk.moments.clone()
+    grads = [g.clone() for g in fk.P.views(fk.P.grad)]
+    assert all(bool(torch.isfinite(g).all()) for g in grads)
+    # ---- float64 oracle
+    sd = {k: v.double().cpu() for k, v in fk.P.state_dict().items()}
+    nl = 3
+    p64 = O.Params([sd[f"model.base.ws.{i}"] for i in range(nl)], [sd[f"model.base.bs.{i}"] for i in range(nl)],
+                   sd["model.base.feature_map._B"])
+    x64 = x.double().cpu()
+    phi = O.fourier_features(x64, p64.fourier_B)
+    f64 = torch.cat([O.mlp_forward(phi, O.Params([w[l0:l0 + 8] for w in p64.ws], [b[l0:l0 + 8] for b in p64.bs],
+                                                 p64.fourier_B)) for l0 in range(0, L, 8)], dim=1)
+    assert rel(f_hip, f64) < 2e-5
+    ic = idx.cpu().numpy()
+    Ksub = op.K.cpu().numpy()[ic][:, ic].astype(np.float64)
+    Kf64 = torch.from_numpy(Ksub @ f64.numpy() / B)
+    assert rel(Kf_hip, Kf64) < 2e-5
+    v, M = O.joint_nesting_masks(L, 1)
+    l64, lam1, lam2 = O.evd_loss_forward(f64, Kf64, v.double(), M.double())[:3]
+    assert rel(mom[:L * L], lam1.reshape(-1)) < 2e-5 and rel(mom[L * L:2 * L * L], lam2.reshape(-1)) < 2e-5
+    assert abs(float(loss[0]) - float(l64)) < 1e-4 * max(abs(float(loss[1])), abs(float(loss[2])))
+    df64 = O.evd_loss_backward(f64, Kf64, v.double(), M.double(), lam1, lam2)
+    plain = O.Problem(potential=O.POT_HARMONIC, eps=0.01, use_importance=False, hard_mul_const=1.0)
+    one = torch.ones(B, 1, dtype=torch.float64)
+    for l in (0, L - 1):
+        ph = O.Params([w[l:l + 1] for w in p64.ws], [b[l:l + 1] for b in p64.bs], p64.fourier_B)
+        out, zs = O.mlp_forward(phi, ph, keep=True)
+        c = O.OperatorCache(x64, phi, zs, out, None, one, one, out, None)
+        gref = O.operator_backward(c, ph, plain, df64[:, l:l + 1])
+        for i in range(nl):
+            assert rel(grads[i][l], gref[i][0]) < 5e-5, (l, i, rel(grads[i][l], gref[i][0]))
+            assert rel(grads[nl + i][l], gref[nl + i][0]) < 5e-5, (l, i, rel(grads[nl + i][l], gref[nl + i][0]))
+    # ---- the fused step on the same batch: same loss, RMSprop of exactly those gradients
+    p0 = fk.P.flat.clone()
+    want = p0.clone()
+    H.rmsprop_ema_step(want, fk.P.grad.clone(), torch.zeros_like(p0), None, lr, alpha, eps, 0.0)
+    got_loss = fk.step(idx).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got_loss, loss)
+    for a, b in zip(fk.P.views(fk.P.flat), fk.P.views(want)):
+        assert torch.equal(a, b)
+    assert not torch.equal(fk.P.flat, p0)
