@@ -32,6 +32,26 @@ def test_launcher_propagates_a_failing_rank():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_launcher_worst_case_wall_time_is_inside_the_drivers_window():
+    """`python bench.py --gpus N` from the argument DEFAULTS: the launcher's ladder (auto-tuned run, then the plain
+    all-reduce, then heads sharded over gloo) is bounded by --launch-timeout in total, whatever the tuner
+    (--tune-seconds) or a hung collective (--collective-timeout) do inside an attempt - under 1500 s, inside the
+    driver's 1800 s; and the tuner's own cap leaves room for the headline run behind it."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    src = open(BENCH).read()
+    lt = float(re.search(r'"--launch-timeout", type=float, default=([0-9.]+)', src).group(1))
+    tune = float(re.search(r'"--tune-seconds", type=float, default=([0-9.]+)', src).group(1))
+    coll = float(re.search(r'"--collective-timeout", type=float, default=([0-9.]+)', src).group(1))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for n_attempts in (1, 2, 3):
+        assert mod.launcher_worst_case_seconds(lt, n_attempts) < 1500.0
+    # inside the first attempt (60 % of the window at worst): both shardings tuned to their cap + one hung collective
+    assert 2 * tune + coll < 0.6 * lt
+
+
 def test_launcher_refuses_more_ranks_than_gpus():
     import torch
     n = torch.cuda.device_count() + 1
@@ -91,6 +111,13 @@ def test_bench_two_ranks_exactly_as_the_driver_calls_it():
     for k in (f"sharding_{other}", "cfg3_dp", "cfg3_hp"):
         assert k in d and "error" not in d[k] and d[k]["value"] > 0 and d[k]["params_finite"], (k, d.get(k))
     assert d["cfg3_dp"]["global_batch"] == 1024
+    # `metric` itself says what the N > 1 value is; BASELINE configs[2] at its stated GLOBAL batch rides on every N > 1 line
+    assert "weak scaling: value = n_gpus x optimiser steps/s of the global batch of 1024 rows" in d["metric"]
+    ss = d["strong_scaling_configs2"]
+    assert ss["global_batch"] == 4096 and ss["n_gpus"] == 2 and ss["scaling"] == "strong"
+    assert ss["dp"]["optimizer_steps_per_s"] > 0 and ss["hp"]["optimizer_steps_per_s"] > 0 and ss["dp"]["params_finite"]
+    assert ss["optimizer_steps_per_s"] == max(ss["dp"]["optimizer_steps_per_s"], ss["hp"]["optimizer_steps_per_s"])
+    assert "not_measured_in_this_run" not in json.dumps(d)
 
 
 @pytest.mark.gpu

@@ -120,6 +120,8 @@ def slice_heads(p, lo, hi):
 def _setup():
     # 3 * (12*10 + 10 + 10*8 + 8 + 8 + 1) + 3 = 684 gradient elements: divisible by 2, 3, 4 and 6
     L, D, m, hidden, Bg = 3, 2, 6, (10, 8), 16
+    # (the eight-rank topology test: 32 heads, 64 rows - through the environment, which the spawned ranks inherit)
+    L, Bg = int(os.environ.get("NSVD_TEST_L", L)), int(os.environ.get("NSVD_TEST_B", Bg))
     p = O.init_params(L, D, m, hidden, 0.1, exp_mask_init=10.0, seed=3).to(torch.float64)
     prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=4.0)
     v, M = O.joint_nesting_masks(L, 2)
@@ -314,3 +316,52 @@ def test_hp_three_ranks_equals_single_process(tmp_path):
         assert torch.allclose(o["f"], ref["f"], rtol=1e-13, atol=1e-15)
         want = torch.cat([(g[r:r + 1]).reshape(-1) for g in ref["grads"]])
         assert float((o["grad"] - want).norm() / want.norm()) < 1e-12
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("exchange", ["allreduce", "rs_ag", "a2a", "hp"])
+def test_world_of_eight_at_the_target_topology(tmp_path, exchange):
+    """BASELINE.json configs[2]'s topology - EIGHT ranks, L = 32 heads (4 per rank when heads are sharded; 7296 gradient
+    elements in 3 buckets of 8 equal slices), a global batch of 64 rows (8 per rank: the exchange logic, not the
+    arithmetic, is under test) - for every gradient exchange of dp_step and for hp_step: every rank ends with the
+    single-process result."""
+    world = 8
+    os.environ["NSVD_TEST_L"], os.environ["NSVD_TEST_B"] = "32", "64"
+    try:
+        if exchange == "hp":
+            mp.spawn(_worker_hp, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+        else:
+            mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
+        p, prob, v, M, x = _setup()
+    finally:
+        del os.environ["NSVD_TEST_L"], os.environ["NSVD_TEST_B"]
+    L = p.ws[0].shape[0]
+    assert L == 32 and x.shape[0] == 64
+    ref = O.loss_and_grads(x, p, prob, v, M)
+    gref = torch.cat([g.reshape(-1) for g in ref["grads"]])
+    if exchange == "hp":
+        Ll = L // world
+        for r in range(world):
+            o = torch.load(os.path.join(str(tmp_path), f"h{r}.pt"))
+            assert abs(float(o["loss"]) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
+            assert torch.allclose(o["f"], ref["f"], rtol=1e-13, atol=1e-15)
+            want = torch.cat([(g[r * Ll:(r + 1) * Ll]).reshape(-1) for g in ref["grads"]])
+            assert float((o["grad"] - want).norm() / want.norm()) < 1e-12
+        return
+    outs = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(world)]
+    covered = torch.zeros(gref.numel(), dtype=torch.bool)
+    for o in outs:
+        assert abs(float(o["loss"]) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
+        assert torch.allclose(o["mom"][:L * L].view(L, L), ref["lam1"], rtol=1e-13, atol=1e-15)
+        if exchange == "allreduce":
+            assert float((o["grad"] - gref).norm() / gref.norm()) < 1e-12
+            assert torch.equal(o["grad"], outs[0]["grad"])
+        else:
+            own = o["own"]
+            assert float((o["grad"][own] - gref[own]).norm() / gref[own].norm()) < 1e-12
+            assert not bool((covered & own).any())
+            covered |= own
+            assert torch.equal(o["params"], outs[0]["params"])
+            want = o["params0"] - 0.5 * gref
+            assert float((o["params"] - want).norm() / want.norm()) < 1e-12
+    assert exchange == "allreduce" or bool(covered.all())
