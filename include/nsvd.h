@@ -467,6 +467,29 @@ int nsvd_tower_forward_phase(const float* x, const nsvd_tower_params* params, in
                              float slope, float eps, float momentum, int update_running, int gemm_bf16, int phase,
                              float* z, void* ws, size_t ws_bytes, void* stream);
 
+/* nsvd_operator_backward_evd_step for the heads [l_begin, l_begin + l_count) only: ONE fused step taken as several head
+ * windows (the heads of ParallelMLP share nothing but the input, examples/models/mlp.py:187-189), each window its own
+ * pair of launches, possibly on its own stream - a two-window step lets the latency-bound chain of window 1 and the
+ * HBM-bound optimiser epilogue of window 0 sit under the other window's MFMA loops (trainer.FusedTrainer
+ * (backward_windows=2)). Every window of a step gets the same arguments except l_begin / l_count, last_window and
+ * ev_after_chain; the windows must cover every head exactly once; last_window != 0 on exactly one of them, the one whose
+ * launches are ordered behind the CHAIN launches of all others: it advances the device-resident schedule (opt->state)
+ * and adds up the loss scalars. ev_after_chain: NULL, or a hipEvent_t this call records between its two launches (what
+ * the next window's stream waits for). x_next != NULL (one window of the step only): the next batch is drawn and its
+ * features written by guest workgroups of this window's first launch, as nsvd_operator_backward_evd_step_next does.
+ * Fused MFMA path, windows whose weight-gradient contraction needs no batch slices
+ * (nsvd_backward_head_window_ok), direct or reduced moments: NSVD_EUNSUPPORTED otherwise. Results are bit-identical to
+ * the one-call step. */
+int nsvd_operator_backward_evd_step_window(const nsvd_model_desc* desc, const nsvd_params* params,
+                                           const nsvd_problem* prob, const float* x, int B, const float* f,
+                                           const float* Tf, int mask_kind, const float* v, const float* M,
+                                           float* moments, int moments_reduced, const void* evd_scratch, int L_total,
+                                           int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
+                                           const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, int l_begin,
+                                           int l_count, int last_window, void* ev_after_chain,
+                                           unsigned long long next_seed, unsigned long long next_offset, float* x_next,
+                                           void* ws_next, size_t ws_next_bytes, void* stream);
+
 /* nsvd_operator_backward_evd_step that ALSO draws the next batch and writes its Fourier features - what
  * nsvd_operator_sample_features(next_seed, next_offset, x_next, ws_next) does as a launch of its own - as guest
  * workgroups of the backward's first kernel: sampling and features (main_pde.py:92-93, examples/utils.py:139-140)

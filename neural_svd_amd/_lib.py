@@ -104,6 +104,10 @@ SIGNATURES = {
     "nsvd_operator_backward_evd_step": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,
                                              _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params),
                                              C.POINTER(Rmsprop), _P, _Z, _I, _P]),
+    "nsvd_operator_backward_evd_step_window": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I,
+                                                    _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params),
+                                                    C.POINTER(Rmsprop), _P, _Z, _I, _I, _I, _I, _P, C.c_ulonglong,
+                                                    C.c_ulonglong, _P, _P, _Z, _P]),
     "nsvd_operator_backward_evd_step_next": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I,
                                                   _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params),
                                                   C.POINTER(Rmsprop), _P, _Z, _I, C.c_uint64, C.c_uint64, _P, _P, _Z,

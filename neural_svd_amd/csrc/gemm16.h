@@ -285,7 +285,6 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
         constexpr int RPP = 512 / LPR;            // rows per pass of the workgroup
         const int rr = tid / LPR, cc = tid % LPR;
         char* cbase = reinterpret_cast<char*>(P.C) + ((long)slice * a.slice_stride + (long)BM * tm * a.ldc + BN * tn) * (O16 ? 2 : 4);
-#pragma unroll 4
         for (int r = rr; r < BM; r += RPP) {
             const uint4 v = *reinterpret_cast<const uint4*>(lds + r * RS + 16 * cc);
             char* dstp = cbase + (long)r * a.ldc * (O16 ? 2 : 4) + 16 * cc;

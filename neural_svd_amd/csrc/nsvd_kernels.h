@@ -101,9 +101,12 @@ struct NsvdNextBatch {
     void* ws;     // the other workspace set (same size as the step's)
     float eps;    // the problem's finite-difference eps (<= 0: exact-Laplacian constants)
 };
+// window_of_step: this call is one of several head windows of ONE fused step; not_last: it neither advances the device-
+// resident schedule nor adds up the step's loss; ev_after_chain (hipEvent_t or null): recorded between its two launches
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
                             const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s, int l_begin = 0,
-                            int l_count = 0, const NsvdNextBatch* next = nullptr);
+                            int l_count = 0, const NsvdNextBatch* next = nullptr, int window_of_step = 0,
+                            int not_last = 0, void* ev_after_chain = nullptr);
 bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count);
 // stand-alone optimiser launch over n contiguous floats (optimizer.hip)
 int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,

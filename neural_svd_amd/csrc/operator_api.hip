@@ -369,7 +369,8 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
                       const float* M, float* moments, int moments_reduced, const void* evd_scratch, int L_total,
                       int l_offset, float grad_scale, float* loss, const nsvd_params* grads,
                       const nsvd_rmsprop* opt, void* ws, size_t ws_bytes, int path, void* stream, int l_begin = 0,
-                      int l_count = 0, const NsvdNextBatch* next = nullptr, bool model_mode = false) {
+                      int l_count = 0, const NsvdNextBatch* next = nullptr, bool model_mode = false,
+                      int window_of_step = 0, int not_last = 0, void* ev_after_chain = nullptr) {
     // model_mode: the forward was nsvd_model_forward (plain model evaluation, any input dimension up to 64, no
     // Hamiltonian): Tf is whatever operator output the caller computed from f (the kernel-operator path)
     int rc = validate(desc, model_mode ? MODEL_MAX_D : 4);
@@ -435,8 +436,9 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
         }
         if (l_count < 0 || l_begin < 0 || l_begin + l_count > desc->L) return NSVD_EINVAL;
         return nsvd_fused_backward_evd(*desc, *params, B, in, grads, opt ? &st : nullptr, ws, s, l_begin, l_count,
-                                       next);
+                                       next, window_of_step, not_last, ev_after_chain);
     }
+    if (window_of_step) return NSVD_EUNSUPPORTED;  // windows of a fused step exist on the fused kernels only
     if (next) return NSVD_EUNSUPPORTED;  // guest feature workgroups exist on the fused kernels only
     if (opt && opt->state) return NSVD_EUNSUPPORTED;  // the device-resident schedule is read by the fused kernels only
     if (l_count > 0 && l_count != desc->L) return NSVD_EUNSUPPORTED;  // head windows need the fused kernels
@@ -515,6 +517,37 @@ extern "C" int nsvd_operator_backward_evd_step(const nsvd_model_desc* desc, cons
     return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
                              evd_scratch, L_total, l_offset, grad_scale, loss, grads, opt, ws, ws_bytes, path,
                              stream);
+}
+
+extern "C" int nsvd_operator_backward_evd_step_window(const nsvd_model_desc* desc, const nsvd_params* params,
+                                                      const nsvd_problem* prob, const float* x, int B, const float* f,
+                                                      const float* Tf, int mask_kind, const float* v, const float* M,
+                                                      float* moments, int moments_reduced, const void* evd_scratch,
+                                                      int L_total, int l_offset, float grad_scale, float* loss,
+                                                      const nsvd_params* grads, const nsvd_rmsprop* opt, void* ws,
+                                                      size_t ws_bytes, int path, int l_begin, int l_count,
+                                                      int last_window, void* ev_after_chain,
+                                                      unsigned long long next_seed, unsigned long long next_offset,
+                                                      float* x_next, void* ws_next, size_t ws_next_bytes,
+                                                      void* stream) {
+    if (!opt || !prob || l_count <= 0) return NSVD_EINVAL;
+    NsvdNextBatch nb;
+    if (x_next) {  // the next batch rides in THIS window's chain launch (pass it to one window of the step only)
+        if (!ws_next || ws_next == ws) return NSVD_EINVAL;
+        if (ws_next_bytes < nsvd_workspace_bytes(desc, B) || ((uintptr_t)ws_next & 255) != 0) return NSVD_EINVAL;
+        memset(&nb, 0, sizeof(nb));
+        nb.smp.seed = next_seed;
+        nb.smp.offset = next_offset;
+        nb.smp.sigma = prob->sigma;
+        nb.smp.on = 1;
+        nb.x = x_next;
+        nb.ws = ws_next;
+        nb.eps = prob->eps;
+    }
+    return backward_evd_impl(desc, params, prob, x, B, f, Tf, mask_kind, v, M, moments, moments_reduced,
+                             evd_scratch, L_total, l_offset, grad_scale, loss, grads, opt, ws, ws_bytes, path,
+                             stream, l_begin, l_count, x_next ? &nb : nullptr, false, 1, last_window ? 0 : 1,
+                             ev_after_chain);
 }
 
 extern "C" int nsvd_operator_backward_evd_step_next(const nsvd_model_desc* desc, const nsvd_params* params,

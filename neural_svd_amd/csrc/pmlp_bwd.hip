@@ -48,8 +48,11 @@ struct ChainArgs {
     nsvd_step_state* state;
     // direct mode only, or null: partial sums of the loss, added by the weight-gradient kernel in a fixed order:
     // [L][B / 32] operator term v_l sum_b f Tf over the workgroup's 32 rows, then [L] metric term
-    // sum_l' M lam_f1 lam_f2 of column l (left by each head's first workgroup)
+    // sum_l' M lam_f1 lam_f2 of column l (left by each head's first workgroup). The layout runs over ALL loss_L heads of
+    // the model; this launch's heads start at l0 (head windows of one step: each window's chain fills its heads, the
+    // LAST window's weight-gradient kernel adds them all)
     float* loss_part;
+    int loss_L;
 };
 
 // PRE: the whole chain's weights and sigmoid inputs are fetched at kernel start (two or three hidden layers; ~290
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         }
         __syncthreads();
         if (a.loss_part && b0 == 0 && tid == 0 && !(a.evd.moments || a.evd.part))
-            a.loss_part[(size_t)a.L * nsb + l] = (red_mt[0] + red_mt[1]) + (red_mt[2] + red_mt[3]);
+            a.loss_part[(size_t)a.loss_L * nsb + a.l0 + l] = (red_mt[0] + red_mt[1]) + (red_mt[2] + red_mt[3]);
         const bool first = b < B1;
         const float* fr = a.evd.f + (size_t)b * Lg;
         // sum_l' f[b][l'] (M lam_other)[l'][l] for the workgroup's 32 rows, cooperatively: thread t takes row t & 31 and
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         if (a.loss_part && w == 0) {
             // the operator term of the loss over this workgroup's 32 rows: v_l sum_b f[b][l] Tf[b][l]
             const float part = nsvd_wave_sum(hi == 0 ? fr[lg] * tfv : 0.f);
-            if (lane == 0) a.loss_part[(size_t)l * nsb + (b0 / BS)] = nsvd_evd_mask_v(a.evd, lg, Lg) * part;
+            if (lane == 0) a.loss_part[(size_t)(a.l0 + l) * nsb + (b0 / BS)] = nsvd_evd_mask_v(a.evd, lg, Lg) * part;
         }
         __syncthreads();  // col[] is dead before DZ is reused
     }
@@ -408,8 +411,10 @@ struct WgradArgs {
     size_t part_stride;                                        // floats per slice
     size_t poW[NSVD_MAX_LAYERS], pob[NSVD_MAX_LAYERS], poscales;  // tensor offsets inside a slice
     // device-resident schedule (or null): `h` is read from state->cur (written by the chain kernel's schedule block)
-    // and ONE thread of the last kernel of the step increments state->step
+    // and ONE thread of the last kernel of the step increments state->step (state; null in a window of a step that is
+    // not the step's last: hstate is then where the optimiser scalars are read)
     nsvd_step_state* state;
+    nsvd_step_state* hstate;
     // the step's loss from the chain kernel's per-head partials (direct mode), or null
     const float* loss_part;  // [loss_L][B / 32] operator-term partials, then [loss_L] metric-term partials
     float* loss;             // {loss, operator term, metric term}
@@ -908,7 +913,7 @@ __global__ void __launch_bounds__(256, 2) pmlp_fused_wgrad_kernel(WgradArgs a) {
     float* Bs = smem_wg + 2 * HID * A_LD;
     // the step's optimiser scalars: launch arguments, or read from the device-resident schedule (uniform loads)
     NsvdHyper h = a.h;
-    if (a.state) h = *nsvd_state_hyper(a.state);
+    if (a.hstate) h = *nsvd_state_hyper(a.hstate);
     // grid = S x (nA | nB | 4 L) blocks, kind-major so that the long dW_0 tiles are dispatched first
     int bid = blockIdx.x + a.bid0;
     if (bid < a.nA * a.S) {
@@ -997,9 +1002,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
 // Head window [l0, l0 + Lc) of the model's d.L heads: the heads of ParallelMLP share nothing but the input, so the
 // backward of a window is the same two launches on pointers that start at head l0 (sample-sharded runs cut the
 // backward into windows to start exchanging the first window's gradients while the next one is computed).
+// win: one of SEVERAL head windows of ONE fused step (nsvd_operator_backward_evd_step_window). not_last: this window
+// neither advances the device-resident schedule nor adds up the loss; ev_after_chain: recorded between the two launches
+// (the next window's chain, on another stream, waits for it: two chains side by side only slow each other).
+struct NsvdStepWindow {
+    int not_last;
+    hipEvent_t ev_after_chain;
+};
 static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& p, int B, const float* df,
                                const NsvdEvdIn* evd, const nsvd_params* gp, const NsvdOptStep* opt, void* ws,
-                               hipStream_t s, int l0 = 0, int Lc = 0, const NsvdNextBatch* next = nullptr) {
+                               hipStream_t s, int l0 = 0, int Lc = 0, const NsvdNextBatch* next = nullptr,
+                               const NsvdStepWindow* win = nullptr) {
     if (Lc <= 0) Lc = dfull.L;
     if (l0 < 0 || l0 + Lc > dfull.L) return NSVD_EINVAL;
     nsvd_params g;
@@ -1038,8 +1051,10 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     a.state = state;
     // the loss of the step in direct mode (no moment kernel): only when this launch sees every head of the loss
     const bool direct = evd && !evd->moments && !evd->part;
-    const bool step_loss = direct && evd->loss && B / BS <= 32 && Lc == dfull.L && evd->l_off == 0 && evd->Lg == dfull.L && !df;
+    const bool step_loss = direct && evd->loss && B / BS <= 32 && (Lc == dfull.L || win) && evd->l_off == 0 &&
+                           evd->Lg == dfull.L && !df;
     a.loss_part = step_loss ? w.loss_part : nullptr;
+    a.loss_L = dfull.L;
     if (next) {  // the next batch's sampling + features as guest workgroups (same arguments as nsvd_fused_features)
         const FusedWs wn = carve_fused(dfull, B, next->ws);
         memset(&a.feat, 0, sizeof(a.feat));
@@ -1058,6 +1073,10 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     else
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<false>, dim3(chain_grid), dim3(256), 0, s, a);
     NSVD_CHECK_LAUNCH();
+    if (win && win->ev_after_chain) {
+        hipError_t e = hipEventRecord(win->ev_after_chain, s);
+        if (e != hipSuccess) return -(int)e;
+    }
 
     WgradArgs wa;
     memset(&wa, 0, sizeof(wa));
@@ -1082,8 +1101,9 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
         if (d.has_exp_mask)
             wa.oscales = NsvdOptPtrs{p.scales + l0, opt->sq.scales + l0, opt->ema ? opt->ema->scales + l0 : nullptr};
     }
-    wa.state = state;
-    if (step_loss) {
+    wa.state = (win && win->not_last) ? nullptr : state;  // (the optimiser reads the schedule through wa.hstate)
+    wa.hstate = state;
+    if (step_loss && !(win && win->not_last)) {
         wa.loss_part = w.loss_part;
         wa.loss = evd->loss;
         wa.loss_L = dfull.L;
@@ -1172,10 +1192,15 @@ int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const ns
 
 int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int B, const NsvdEvdIn& evd,
                             const nsvd_params* g, const NsvdOptStep* opt, void* ws, hipStream_t s, int l_begin,
-                            int l_count, const NsvdNextBatch* next) {
+                            int l_count, const NsvdNextBatch* next, int window_of_step, int not_last,
+                            void* ev_after_chain) {
     if (!g && !opt) return NSVD_EINVAL;
     if (next && (d.D < 1 || d.D > 3 || !p.fourier_B || !next->ws || !next->x)) return NSVD_EINVAL;
-    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s, l_begin, l_count, next);
+    NsvdStepWindow win;
+    win.not_last = not_last;
+    win.ev_after_chain = (hipEvent_t)ev_after_chain;
+    return fused_backward_impl(d, p, B, nullptr, &evd, g, opt, ws, s, l_begin, l_count, next,
+                               window_of_step ? &win : nullptr);
 }
 
 int nsvd_fused_wgrad_slices(const nsvd_model_desc& d, int B) { return wgrad_slices(d, B); }

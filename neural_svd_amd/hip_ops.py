@@ -575,6 +575,37 @@ def operator_backward_evd_step(shape: ModelShape, params: Params, prob: Problem,
     check(rc, "nsvd_operator_backward_evd_step")
 
 
+def operator_backward_evd_step_window(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor,
+                                      f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
+                                      M: Optional[torch.Tensor], moments: Optional[torch.Tensor], moments_reduced: bool,
+                                      evd_scratch: Optional[torch.Tensor], loss: torch.Tensor, opt: "_lib.Rmsprop",
+                                      ws: torch.Tensor, l_begin: int, l_count: int, last_window: bool,
+                                      ev_after_chain: Optional["torch.cuda.Event"] = None, next_seed: int = 0,
+                                      next_offset: int = 0, x_next: Optional[torch.Tensor] = None,
+                                      ws_next: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
+                                      path: int = PATH_AUTO, l_offset: int = 0) -> None:
+    """operator_backward_evd_step for the heads [l_begin, l_begin + l_count) of ONE fused step taken as several head
+    windows (nsvd_operator_backward_evd_step_window: include/nsvd.h). Launches on the CURRENT stream; ev_after_chain is
+    recorded between the window's two launches."""
+    B = x.shape[0]
+    L_total = f.shape[1]
+    ev = None
+    if ev_after_chain is not None:
+        if ev_after_chain.cuda_event == 0:  # torch creates the hipEvent lazily, at the first record
+            ev_after_chain.record()
+        ev = ev_after_chain.cuda_event
+    d = shape.desc()
+    rc = _lib.load().nsvd_operator_backward_evd_step_window(
+        C.byref(d), C.byref(params), C.byref(prob), _ptr(x, "x"), B, _ptr(f, "f"), _ptr(Tf, "Tf"), int(mask_kind),
+        _ptr(v, "v"), _ptr(M, "M"), _ptr(moments, "moments"), int(bool(moments_reduced)),
+        evd_scratch.data_ptr() if evd_scratch is not None else None, int(L_total), int(l_offset),
+        float(grad_scale), _ptr(loss, "loss"), None, C.byref(opt), ws.data_ptr(), ws.numel(), int(path),
+        int(l_begin), int(l_count), int(bool(last_window)), ev, int(next_seed) & (2 ** 64 - 1),
+        int(next_offset) & (2 ** 64 - 1), _ptr(x_next, "x_next"), ws_next.data_ptr() if ws_next is not None else None,
+        ws_next.numel() if ws_next is not None else 0, _stream())
+    check(rc, "nsvd_operator_backward_evd_step_window")
+
+
 def operator_backward_evd_step_next(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor,
                                     f: torch.Tensor, Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor],
                                     M: Optional[torch.Tensor], moments: torch.Tensor, moments_reduced: bool,
@@ -938,7 +969,7 @@ def cdk_step(desc: "_lib.CdkStepDesc", x: torch.Tensor, y: torch.Tensor, towers:
 for _name in ("fourier_features", "operator_forward", "operator_features", "operator_sample_features",
               "operator_sample_features_dev", "rmsprop_ema_step_dev",
               "operator_backward", "model_forward", "model_backward", "evd_moments", "evd_loss_grad", "evd_loss_fused",
-              "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "operator_backward_evd_step_next", "model_backward_evd_step", "kernel_apply", "cdk_loss_forward",
+              "evd_partial", "operator_backward_evd", "operator_backward_evd_heads", "operator_backward_evd_step", "operator_backward_evd_step_next", "operator_backward_evd_step_window", "model_backward_evd_step", "kernel_apply", "cdk_loss_forward",
               "cdk_loss_backward", "rmsprop_ema_step", "spectrum_accumulate", "row_normalize",
               "row_normalize_backward", "tower_forward", "tower_backward", "cdk_step", "to_bf16", "gemm_bf16"):
     globals()[_name] = _on_tensor_device(globals()[_name])

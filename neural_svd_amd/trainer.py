@@ -134,7 +134,7 @@ class FusedTrainer:
                  parallelism: str = "dp", fused_step: bool = True, keep_grads: bool = False,
                  device_sampler: bool = True, overlap: bool = True, grad_buckets: int = 4,
                  dp_exchange: str = "allreduce", grad_windows: Optional[int] = None, sync_collectives: bool = False,
-                 device_schedule: bool = False):
+                 device_schedule: bool = False, backward_windows: int = 1):
         """batch_size is the per-GPU batch. parallelism (only with comm.world > 1): "dp" = every rank draws its
         own batch_size rows (moments + gradient all-reduce); "hp" = every rank owns L/world heads and evaluates
         them on the same global batch of batch_size * world rows (one all-gather of f, Tf; see parallel.py).
@@ -191,6 +191,11 @@ class FusedTrainer:
         self.ema_decay, self.num_iters, self.use_sched = ema_decay, num_iters, use_lr_scheduler
         self.sigma = sampling_scale
         self.device_schedule = bool(device_schedule)
+        # backward_windows = 2 (single process, fused step on the MFMA kernels): the backward of a step as two head
+        # windows on two streams (nsvd_operator_backward_evd_step_window): window 1's latency-bound chain and window 0's
+        # HBM-bound optimiser epilogue sit under the other window's MFMA loops. Bit-identical to one window.
+        self.backward_windows = int(backward_windows)
+        self._side_stream = None
         with torch.cuda.device(self.device):
             self._build(shape, problem, fourier_scale, exp_mask_init, seed, sample_seed, sequential, step, fused_step,
                         keep_grads, device_sampler, overlap, grad_buckets, world, rank, dp_exchange, grad_windows)
@@ -378,6 +383,15 @@ class FusedTrainer:
             lr, decay = self._advance_schedule()
             # (device schedule: lr / decay are read on the device, the host values only keep the counters in step)
             opt = H.rmsprop_state(self._sq_params, self._ema_params, lr, self.alpha, self.eps, decay, self.state)
+            if self._two_windows():
+                ride = self.guest_features and self._own_batch and not self._next_ready
+                self._backward_two_windows(x, v, M, moments, reduced, scratch, loss, opt, ride,
+                                           self.batches_drawn - (t_before if self.state is not None else 0))
+                if ride:
+                    self.batches_drawn += 1
+                    self._next_ready = True
+                self._note_planes(None)
+                return
             if self.guest_features and self._own_batch and not self._next_ready and \
                     (not self.multi or not self.overlap):
                 # the next batch rides in this backward's first launch (hp with overlap prepares it under its
@@ -403,6 +417,39 @@ class FusedTrainer:
         if take_step and (not self.multi or self.hp):  # no exchange between backward and optimiser
             self.begin_apply()
             self.apply(0, self.P.numel, 1.0)
+
+    def _two_windows(self) -> bool:
+        if self.backward_windows != 2 or self.multi or self.keep_grads or self.shape.L % 2:
+            return False
+        if self._side_stream is None:
+            ok = H.path_name(self.shape, self.B, self.path, self.problem) == "fused_mfma" and \
+                self.path != H.PATH_FUSED_BF16X3 and \
+                H.backward_head_window_ok(self.shape, self.problem, self.B, self.path, self.shape.L // 2)
+            if not ok:
+                self.backward_windows = 1
+                return False
+            self._side_stream = torch.cuda.Stream(device=self.device)
+            self._ev_chain0 = torch.cuda.Event()
+            self._ev_done1 = torch.cuda.Event()
+        return True
+
+    def _backward_two_windows(self, x, v, M, moments, reduced, scratch, loss, opt, ride, next_offset) -> None:
+        half = self.shape.L // 2
+        cur = torch.cuda.current_stream(self.device)
+        kw = dict(grad_scale=1.0, path=self.path, l_offset=self.l_off)
+        # window 0 on the current stream (the next batch rides in its chain launch); the event sits between its launches
+        H.operator_backward_evd_step_window(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
+                                            self.mask_kind, v, M, moments, reduced, scratch, loss, opt, self.ws, 0, half,
+                                            False, self._ev_chain0, self.sample_key, next_offset,
+                                            self._x_other if ride else None, self._ws_other if ride else None, **kw)
+        # window 1 (the LAST: schedule advance, loss) on the side stream, behind window 0's chain
+        self._side_stream.wait_event(self._ev_chain0)
+        with torch.cuda.stream(self._side_stream):
+            H.operator_backward_evd_step_window(self.shape, self._params, self.problem, x, self.f_g, self.Tf_g,
+                                                self.mask_kind, v, M, moments, reduced, scratch, loss, opt, self.ws,
+                                                half, self.shape.L - half, True, None, **kw)
+            self._ev_done1.record(self._side_stream)
+        cur.wait_event(self._ev_done1)
 
     def _note_planes(self, ws: torch.Tensor) -> None:
         """a fused bf16x3 step has left the planes of the weights it updated in `ws` (include/nsvd.h:
