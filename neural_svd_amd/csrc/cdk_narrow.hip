@@ -294,7 +294,12 @@ __global__ void __launch_bounds__(NTH) narrow_bwd_finish_kernel(NsvdNarrowBwd a,
     const float rB = 1.0f / (float)a.B;
     a.m1[t][c] = s0 * rB;
     a.m2[t][c] = s1 * rB;
-    a.dbias[t][c] = a.gamma[t][c] * a.invstd[t][c] * ((s0 - (float)a.B * (s0 * rB)) - (s1 * rB) * s2);
+    const float db = a.gamma[t][c] * a.invstd[t][c] * ((s0 - (float)a.B * (s0 * rB)) - (s1 * rB) * s2);
+    a.dbias[t][c] = db;
+    if (a.sumsq[t]) {  // group 0 is one wave = this workgroup's 64 columns (columns beyond N: masked out above -> N % 64 == 0)
+        const float q = nsvd_wave_sum(fmaf(s0, s0, fmaf(s1, s1, db * db)));
+        if (cl == 0) a.sumsq[t][blockIdx.x] = q;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- backward (3)
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(NTH) narrow_bwd_apply_kernel(NsvdNarrowBwd a) 
 }
 
 bool narrow_ok(int nt, int B, int N) {
-    return nt >= 1 && nt <= 2 && B > 0 && B % RB == 0 && N > 0 && N % 4 == 0 && N <= 1024 && NTH % (N / 4) == 0 &&
+    return nt >= 1 && nt <= 2 && B > 0 && B % RB == 0 && N > 0 && N % 64 == 0 && N <= 1024 && NTH % (N / 4) == 0 &&
            RB % (NTH / (N / 4)) == 0;
 }
 

@@ -124,8 +124,8 @@ struct StepWs {
     void* cdk;
     float *z[2], *e[2], *ge[2], *dz[2];
     float* grad[2];  // per tower: [W1 | b1 | g1 | be1 | W2 | b2 | g2 | be2], each padded to 64 floats
-    float* partial;  // [small tensors: SUMSQ_BLOCKS | tower x: per GEMM tile | tower y: per GEMM tile]
-    int npartial;
+    float* partial;  // [small tensors: SUMSQ_BLOCKS | tower x: per GEMM tile (+ per strip) | tower y: likewise]
+    int npartial, nsmall;
     float* scal;
     float* narrow;   // scratch of the fused narrow end (cdk_narrow.hip), mixed precision
     size_t tower_bytes, cdk_bytes, bytes;
@@ -162,7 +162,10 @@ StepWs carve_step(const nsvd_cdk_step_desc& d, void* base) {
         g += (n[k] + 63) / 64 * 64;
     }
     for (int s = 0; s < 2; ++s) w.grad[s] = (float*)take(g * sizeof(float));
-    w.npartial = SUMSQ_BLOCKS + 2 * nsvd_tower_sumsq_count(d.d0, d.d1, d.d2, d.gemm_bf16 != 0);
+    // mixed precision with the fused narrow end: the small tensors' squares come from the kernels that write those
+    // gradients (one float per 64-column strip: d1 / 64 + d2 / 64 per tower), and the SUMSQ_BLOCKS slots hold zeros
+    w.nsmall = (d.gemm_bf16 != 0 && nsvd_narrow_supported(2, d.B, d.d2)) ? (d.d1 / 64 + d.d2 / 64) : 0;
+    w.npartial = SUMSQ_BLOCKS + 2 * (nsvd_tower_sumsq_count(d.d0, d.d1, d.d2, d.gemm_bf16 != 0) + w.nsmall);
     w.partial = (float*)take((size_t)w.npartial * sizeof(float));
     w.scal = (float*)take(256);
     w.narrow = (float*)take(nsvd_narrow_scratch_floats(2, d.B, d.d2) * sizeof(float));
@@ -255,7 +258,8 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     nsvd_tower_params gr[2];
     float* gp[2][NT];
     const int nsq = nsvd_tower_sumsq_count(d->d0, d->d1, d->d2, mixed);
-    float* sq[2] = {w.partial + SUMSQ_BLOCKS, w.partial + SUMSQ_BLOCKS + nsq};
+    float* sq[2] = {w.partial + SUMSQ_BLOCKS, w.partial + SUMSQ_BLOCKS + nsq + w.nsmall};
+    const bool small_fused = narrow && w.nsmall > 0;
     for (int t = 0; t < 2; ++t) {
         if (!narrow) {
             rc = nsvd_row_normalize_backward(w.z[t], w.ge[t], B, L, r_up, d->normalize_mode, w.dz[t], stream);
@@ -279,6 +283,7 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
             b.z[t] = w.z[t]; b.ge[t] = w.ge[t]; b.Y2[t] = nv[t].Y2; b.mean[t] = nv[t].mean2; b.invstd[t] = nv[t].inv2;
             b.gamma[t] = towers[t].g2; b.dz[t] = w.dz[t]; b.dY[t] = nv[t].dY2h;
             b.dgamma[t] = gr[t].g2; b.dbeta[t] = gr[t].be2; b.dbias[t] = gr[t].b2;
+            b.sumsq[t] = small_fused ? sq[t] + nsq + d->d1 / 64 : nullptr;
         }
         b.nt = 2; b.B = B; b.N = L; b.dy_bf16 = 1; b.part = w.narrow; b.r_up = r_up;
         b.sphere = d->normalize_mode == NSVD_NORMALIZE_L2_SPHERE;
@@ -289,7 +294,7 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
         const nsvd_tower_params* gq[2] = {&gr[0], &gr[1]};
         const float* dzs[2] = {w.dz[0], w.dz[1]};
         rc = nsvd_tower16_backward_pair(in, tp, dzs, B, d->d0, d->d1, d->d2, d->slope, gq, w.tower, w.tower_bytes, sq, s,
-                                        narrow ? NSVD_TOWER16_WIDE_ONLY : 0);
+                                        (narrow ? NSVD_TOWER16_WIDE_ONLY : 0) | (small_fused ? NSVD_TOWER16_SMALL_SUMSQ : 0));
         if (rc) return rc;
     }
     for (int t = 0; t < 2; ++t) {
@@ -310,11 +315,16 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     }
     tab.start[2 * NT] = q4;
     // clip_grad_norm_ + SGD momentum over all 16 tensors
-    hipLaunchKernelGGL(cdk_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, tab, w.partial);
-    NSVD_CHECK_LAUNCH();
+    if (!small_fused) {
+        hipLaunchKernelGGL(cdk_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, tab, w.partial);
+        NSVD_CHECK_LAUNCH();
+    }
+    // (small_fused: the SUMSQ_BLOCKS slots are unused - the partials the optimiser adds start behind them)
+    const float* part0 = small_fused ? w.partial + SUMSQ_BLOCKS : w.partial;
+    const int npart = small_fused ? w.npartial - SUMSQ_BLOCKS : w.npartial;
     size_t blocks = (q4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;  // (each workgroup first adds the partials for itself: not too many of them)
-    hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, (const float*)w.partial, w.npartial,
+    hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, part0, npart,
                        (float)d->max_grad_norm, w.scal, loss, (float)d->lr, (float)d->momentum, d->first_step);
     NSVD_CHECK_LAUNCH();
     return 0;

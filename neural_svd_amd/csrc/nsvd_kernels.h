@@ -123,6 +123,9 @@ int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const 
 // unused) / start behind dY2 (backward: the caller has written the bfloat16 dY2 into the workspace, dz unused) - the
 // narrow end is then the caller's (cdk_narrow.hip)
 constexpr int NSVD_TOWER16_WIDE_ONLY = 4;
+// backward: sumsq[t] continues behind the contractions' partials with one float per 64-column strip of the first
+// BatchNorm's backward (d1 / 64): the squares of the b1 / g1 / be1 gradients that strip wrote
+constexpr int NSVD_TOWER16_SMALL_SUMSQ = 8;
 int nsvd_tower16_forward_pair(const float* const* x, const nsvd_tower_params* const* p, int B, int d0, int d1, int d2,
                               float slope, float eps, float momentum, int update_running, int flags, float* const* z,
                               void* const* ws, size_t ws_bytes, hipStream_t s);
@@ -165,6 +168,7 @@ struct NsvdNarrowBwd {
     float* dgamma[2];
     float* dbeta[2];
     float* dbias[2];             // gradient of b2
+    float* sumsq[2];             // null, or N / 64 floats per tower: squares of the b2 / g2 / be2 gradients, per 64 columns
     float* part;                 // scratch: nsvd_narrow_scratch_floats
     float* m1[2];                // (set by nsvd_narrow_backward: inside `part`)
     float* m2[2];

@@ -678,6 +678,8 @@ struct Bn16Bwd {
     float* dgamma[2];
     float* dbeta[2];
     float* dbias[2];        // column sums of the (unrounded) dY
+    float* sumsq[2];        // null, or one float per workgroup (N / 64 per tower): the sum of the squares of the 3 x 64
+                            // bias / BatchNorm-weight gradients it wrote (clip_grad_norm_ without a pass over them)
     int B, N;
     float slope;
 };
@@ -755,6 +757,11 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a)
         }
     bn16_reduce(red, sb, c3, tid);
     if (tid < BN16_STRIP) a.dbias[t][n0 + tid] = c3[tid];
+    if (a.sumsq[t] && tid < 64) {  // (BN16_STRIP == 64: one wave holds the strip's columns; butterfly = fixed order)
+        float q = fmaf(c1[tid], c1[tid], fmaf(c2[tid], c2[tid], c3[tid] * c3[tid]));
+        q = nsvd_wave_sum(q);
+        if (tid == 0) a.sumsq[t][blockIdx.x] = q;
+    }
 }
 
 inline bool tower16_shape_ok(int B, int d0, int d1, int d2) {
@@ -927,6 +934,7 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
             b.dout[t] = v[t].dA1h; b.Y[t] = v[t].Y1h; b.mean[t] = w[t].mean1; b.invstd[t] = w[t].inv1;
             b.gamma[t] = p[t]->g1; b.beta[t] = p[t]->be1; b.dY[t] = v[t].dY1h; b.dgamma[t] = grads[t]->g1;
             b.dbeta[t] = grads[t]->be1; b.dbias[t] = grads[t]->b1;
+            b.sumsq[t] = (sumsq && (flags & NSVD_TOWER16_SMALL_SUMSQ)) ? sumsq[t] + sumsq_count16(d0, d1, d2) : nullptr;
         }
         b.B = B; b.N = d1; b.slope = slope;
         hipLaunchKernelGGL(tower_bn16_backward_kernel, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, b);
