@@ -15,8 +15,10 @@
 namespace {
 
 constexpr int RB = 8;         // rows per workgroup of the row-block kernels (B / 8 workgroups per tower: 256 at B = 1024, nt = 2)
-constexpr int FG = 4;         // block groups of the finish kernels (64 columns x 4 groups per workgroup)
+constexpr int FG = 16;        // block groups of the finish kernels (16 columns x 16 groups per workgroup: at B = 1024 a
+                              // thread has 8 blocks to merge - ONE batch of loads, one memory latency)
 constexpr int NTH = 256;
+constexpr int FC = NTH / FG;  // columns per workgroup of the finish kernels
 constexpr float NRM_EPS = 1e-12f;  // torch.nn.functional.normalize's default eps
 
 __device__ __forceinline__ float wsum(float v) {
@@ -96,14 +98,14 @@ __global__ void __launch_bounds__(NTH) narrow_sum_stats_kernel(NsvdNarrowFwd a) 
 }
 
 // ---------------------------------------------------------------------------------------------------- forward (2)
-// per column: merge the blocks' (mean, M2) (Chan et al.) in a fixed order - four groups of consecutive blocks, each merged
+// per column: merge the blocks' (mean, M2) (Chan et al.) in a fixed order - FG groups of consecutive blocks, each merged
 // in block order by its own thread (the group's partials are loaded before any is used: one memory latency, not one per
 // block), then the four groups in order - then mean / invstd / running statistics. Workgroup = 64 columns x 4 groups.
 __global__ void __launch_bounds__(NTH) narrow_stats_finish_kernel(NsvdNarrowFwd a, int nblocks) {
-    __shared__ float gm[FG][64], gq[FG][64], gn[FG][64];
+    __shared__ float gm[FG][FC], gq[FG][FC], gn[FG][FC];
     const int t = blockIdx.y;
-    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x % FC, grp = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + cl;
     const int per = (nblocks + FG - 1) / FG;
     const int b0 = grp * per, b1 = min(nblocks, b0 + per);
     float mean = 0.f, m2 = 0.f, n = 0.f;
@@ -259,14 +261,15 @@ __global__ void __launch_bounds__(NTH) narrow_bwd_rows_kernel(NsvdNarrowBwd a) {
 // column sum of dY = gamma invstd (dz - mean(dz) - yhat mean(dz yhat)) = gamma invstd (- mean(dz yhat) sum(yhat)):
 // rounding noise around zero, as torch's own (sum(yhat) = 0 in exact arithmetic)
 __global__ void __launch_bounds__(NTH) narrow_bwd_finish_kernel(NsvdNarrowBwd a, int nblocks) {
-    __shared__ float gs[FG][3][64];
+    __shared__ float gs[FG][3][FC];
+    __shared__ float sqp[FC];
     const int t = blockIdx.y;
-    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x % FC, grp = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + cl;
     const int per = (nblocks + FG - 1) / FG;
     const int b0 = grp * per, b1 = min(nblocks, b0 + per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (c < a.N) {  // (four groups of consecutive blocks, each summed in block order; the groups then in order)
+    if (c < a.N) {  // (FG groups of consecutive blocks, each summed in block order; the groups then in order)
         const float* p = a.part + (size_t)t * nblocks * 3 * a.N + c;
         for (int bb = b0; bb < b1; bb += 16) {
             float u0[16], u1[16], u2[16];
@@ -296,9 +299,14 @@ __global__ void __launch_bounds__(NTH) narrow_bwd_finish_kernel(NsvdNarrowBwd a,
     a.m2[t][c] = s1 * rB;
     const float db = a.gamma[t][c] * a.invstd[t][c] * ((s0 - (float)a.B * (s0 * rB)) - (s1 * rB) * s2);
     a.dbias[t][c] = db;
-    if (a.sumsq[t]) {  // group 0 is one wave = this workgroup's 64 columns (columns beyond N: masked out above -> N % 64 == 0)
-        const float q = nsvd_wave_sum(fmaf(s0, s0, fmaf(s1, s1, db * db)));
-        if (cl == 0) a.sumsq[t][blockIdx.x] = q;
+    if (a.sumsq[t]) {  // this workgroup's FC columns (threads 0 .. FC - 1: group 0), added in column order
+        sqp[cl] = fmaf(s0, s0, fmaf(s1, s1, db * db));
+        __builtin_amdgcn_wave_barrier();  // (FC <= 64: one wave wrote sqp)
+        if (cl == 0) {
+            float q = 0.f;
+            for (int i = 0; i < FC; ++i) q += sqp[i];
+            a.sumsq[t][blockIdx.x] = q;
+        }
     }
 }
 
@@ -342,12 +350,14 @@ size_t nsvd_narrow_scratch_floats(int nt, int B, int N) { return (size_t)nt * (B
 
 bool nsvd_narrow_supported(int nt, int B, int N) { return narrow_ok(nt, B, N); }
 
+int nsvd_narrow_sumsq_count(int N) { return nsvd_cdiv(N, FC); }
+
 int nsvd_narrow_forward(const NsvdNarrowFwd& a, hipStream_t s) {
     if (!narrow_ok(a.nt, a.B, a.N) || a.S < 1 || !a.part) return NSVD_EINVAL;
     const int nblocks = a.B / RB;
     hipLaunchKernelGGL(narrow_sum_stats_kernel, dim3(nblocks, a.nt), dim3(NTH), 0, s, a);
     NSVD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(narrow_stats_finish_kernel, dim3(nsvd_cdiv(a.N, 64), a.nt), dim3(NTH), 0, s, a, nblocks);
+    hipLaunchKernelGGL(narrow_stats_finish_kernel, dim3(nsvd_cdiv(a.N, FC), a.nt), dim3(NTH), 0, s, a, nblocks);
     NSVD_CHECK_LAUNCH();
     hipLaunchKernelGGL(narrow_bn_normalize_kernel, dim3(nsvd_cdiv(a.B, 4), a.nt), dim3(NTH), 0, s, a);
     NSVD_CHECK_LAUNCH();
@@ -364,7 +374,7 @@ int nsvd_narrow_backward(const NsvdNarrowBwd& a0, hipStream_t s) {
     }
     hipLaunchKernelGGL(narrow_bwd_rows_kernel, dim3(nblocks, a.nt), dim3(NTH), 0, s, a);
     NSVD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(narrow_bwd_finish_kernel, dim3(nsvd_cdiv(a.N, 64), a.nt), dim3(NTH), 0, s, a, nblocks);
+    hipLaunchKernelGGL(narrow_bwd_finish_kernel, dim3(nsvd_cdiv(a.N, FC), a.nt), dim3(NTH), 0, s, a, nblocks);
     NSVD_CHECK_LAUNCH();
     const size_t n4 = (size_t)a.B * a.N / 4;
     hipLaunchKernelGGL(narrow_bwd_apply_kernel, dim3((unsigned)((n4 + NTH - 1) / NTH), a.nt), dim3(NTH), 0, s, a);

@@ -163,8 +163,8 @@ StepWs carve_step(const nsvd_cdk_step_desc& d, void* base) {
     }
     for (int s = 0; s < 2; ++s) w.grad[s] = (float*)take(g * sizeof(float));
     // mixed precision with the fused narrow end: the small tensors' squares come from the kernels that write those
-    // gradients (one float per 64-column strip: d1 / 64 + d2 / 64 per tower), and the SUMSQ_BLOCKS slots hold zeros
-    w.nsmall = (d.gemm_bf16 != 0 && nsvd_narrow_supported(2, d.B, d.d2)) ? (d.d1 / 64 + d.d2 / 64) : 0;
+    // gradients (one float per strip of columns: d1 / 64 + nsvd_narrow_sumsq_count(d2) per tower)
+    w.nsmall = (d.gemm_bf16 != 0 && nsvd_narrow_supported(2, d.B, d.d2)) ? (d.d1 / 64 + nsvd_narrow_sumsq_count(d.d2)) : 0;
     w.npartial = SUMSQ_BLOCKS + 2 * (nsvd_tower_sumsq_count(d.d0, d.d1, d.d2, d.gemm_bf16 != 0) + w.nsmall);
     w.partial = (float*)take((size_t)w.npartial * sizeof(float));
     w.scal = (float*)take(256);

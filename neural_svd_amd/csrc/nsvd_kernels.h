@@ -168,7 +168,8 @@ struct NsvdNarrowBwd {
     float* dgamma[2];
     float* dbeta[2];
     float* dbias[2];             // gradient of b2
-    float* sumsq[2];             // null, or N / 64 floats per tower: squares of the b2 / g2 / be2 gradients, per 64 columns
+    float* sumsq[2];             // null, or nsvd_narrow_sumsq_count(N) floats per tower: squares of the b2 / g2 / be2
+                                 // gradients, per group of columns
     float* part;                 // scratch: nsvd_narrow_scratch_floats
     float* m1[2];                // (set by nsvd_narrow_backward: inside `part`)
     float* m2[2];
@@ -176,6 +177,7 @@ struct NsvdNarrowBwd {
     int sphere;
 };
 size_t nsvd_narrow_scratch_floats(int nt, int B, int N);
+int nsvd_narrow_sumsq_count(int N);
 bool nsvd_narrow_supported(int nt, int B, int N);
 int nsvd_narrow_forward(const NsvdNarrowFwd& a, hipStream_t s);
 int nsvd_narrow_backward(const NsvdNarrowBwd& a, hipStream_t s);

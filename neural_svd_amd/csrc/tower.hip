@@ -538,6 +538,15 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     return make_uint4(bf16_pack2(v[0], v[1]), bf16_pack2(v[2], v[3]), bf16_pack2(v[4], v[5]), bf16_pack2(v[6], v[7]));
 }
 
+// 16-byte write-through store (sc1): a strip's 32 MB of output leaves for memory while the kernel runs instead of sitting
+// dirty in the XCDs' L2s until the kernel-end write-back (MI355X_MICROARCH.md, stores of each flavour; gemm16.h's
+// epilogue does the same)
+__device__ __forceinline__ void store16_wt(void* dst, const uint4& v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 vv = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+}
+
 // several float32 -> bfloat16 casts in one launch (blockIdx.y = segment)
 struct CastList {
     const float4* in[6];
@@ -663,7 +672,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) 
                 float o = fmaf((v[j] - mu[j]) * sc[j], sh[j], be[j]);
                 v[j] = o > 0.f ? o : a.slope * o;
             }
-            *reinterpret_cast<uint4*>(out + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0) = pack8(v);
+            store16_wt(out + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0, pack8(v));
         }
 }
 
@@ -753,7 +762,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a)
                 sb[j] += dy;
                 d[j] = dy;
             }
-            *reinterpret_cast<uint4*>(a.dY[t] + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0) = pack8(d);
+            store16_wt(a.dY[t] + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0, pack8(d));
         }
     bn16_reduce(red, sb, c3, tid);
     if (tid < BN16_STRIP) a.dbias[t][n0 + tid] = c3[tid];
