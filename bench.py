@@ -1082,7 +1082,7 @@ def main():
             side("opt_in_path_bf16x3", cfg, "dp", H.PATH_FUSED_BF16X3,
                  "same workload with NSVD_PATH_FUSED_BF16X3: every layer of the forward as three-way split bf16 "
                  "products accumulated in float32 (the stencil columns as centre + even / odd perturbations: "
-                 "DESIGN.md 3.7, 3.9) - against float64 its f is closer than the native fp32 MFMA path's and its Tf "
+                 "DESIGN.md 3.5, 3.2) - against float64 its f is closer than the native fp32 MFMA path's and its Tf "
                  "within 1e-5 (the reference's own float32 arithmetic: 4e-2; accuracy_vs_float64 below), same "
                  "backward; not the headline value, which stays native float32 arithmetic")
             try:

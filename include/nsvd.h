@@ -152,7 +152,7 @@ int nsvd_operator_features(const nsvd_model_desc* desc, const nsvd_params* param
  *  pde/__init__.py:15-16 -> models/mlp.py:204-221).
  * The stencil is the reference's - the same 1 + 2 D points, the same eps - but every path carries the shifted
  * evaluations as EVEN / ODD perturbations of the centre one (z(x +- eps e_d) = z + zE_d +- zO_d through the Fourier map,
- * every layer and the re-weighting; DESIGN.md 3.9), so the float32 result is the stencil's value to ~1e-6 instead of
+ * every layer and the re-weighting; DESIGN.md 3.2), so the float32 result is the stencil's value to ~1e-6 instead of
  * the few per cent a point-wise float32 difference at eps = 0.01 carries (the reference's own float32 Tf is 4e-2 from
  * its float64 Tf: BASELINE.md). f is unaffected. Any eps > 0 (perturbations beyond 0.25 fall back to plain differences).
  * save_for_backward != 0 keeps the centre-row pre-activations in `ws` for nsvd_operator_backward. */

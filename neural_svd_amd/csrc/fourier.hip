@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) fourier_kernel(const float* __restrict__ 
     phiT[(size_t)(m + j) * ldr + r] = c;
 }
 
-// the same with the shifted rows in EVEN / ODD form (DESIGN.md 3.9): row block 1 + 2 d holds phi's even perturbation
+// the same with the shifted rows in EVEN / ODD form (DESIGN.md 3.2): row block 1 + 2 d holds phi's even perturbation
 // along direction d, [s (cos t - 1), c (cos t - 1)] with t = eps B_dj, block 2 + 2 d the odd one, [c sin t, -s sin t]:
 // phi(x +- eps e_d) = phi + even +- odd exactly (angle addition), products in double
 __global__ void __launch_bounds__(256) fourier_evenodd_kernel(const float* __restrict__ x, const float* __restrict__ fB,

@@ -44,7 +44,7 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
     return z > NSVD_SOFTPLUS_THRESHOLD ? 1.0f : s;
 }
 
-// softplus on a stencil pair in EVEN / ODD form (DESIGN.md 3.9): z(x +- eps e_d) = z0 + zE +- zO with zO = O(delta),
+// softplus on a stencil pair in EVEN / ODD form (DESIGN.md 3.2): z(x +- eps e_d) = z0 + zE +- zO with zO = O(delta),
 // zE = O(delta^2); returns the even and odd parts of softplus(z0 + zE +- zO) - softplus(z0) by the Taylor expansion
 // around z0 to sixth order in delta (s = sigmoid z0, p = s (1 - s), w = zO^2):
 //   even' = s zE + c2 (zE^2 + w) + c3 zE (zE^2 + 3 w) + c4 w (w + 6 zE^2) + 5 c5 zE w^2 + c6 w^3   + O(delta^8)
@@ -58,7 +58,7 @@ __device__ __forceinline__ float nsvd_sigmoid(float z) {
 // known to full relative accuracy, so their difference carries ~1e-7 of ITS OWN size (p99.9 7e-6 over wide ranges of
 // z0 and d; the plain difference softplus(z0 + d) - softplus(z0) carries 1e-7 x |z0|: 1.2e-4 on the ground state's
 // eigenvalue, whose cusp at the nucleus is where the large perturbations are). No clamp, no overflow, no select: two
-// softplus per value - what the rare path may cost the kernel that hosts it was measured the hard way (DESIGN.md 3.9).
+// softplus per value - what the rare path may cost the kernel that hosts it was measured the hard way (DESIGN.md 3.2).
 __device__ __forceinline__ float nsvd_softplus_diff(float a, float sp_ma, bool pos, float d) {
     return (pos ? d : 0.f) + (nsvd_softplus((pos ? -d : d) - a) - sp_ma);
 }

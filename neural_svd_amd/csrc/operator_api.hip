@@ -98,7 +98,7 @@ int generic_mlp(const nsvd_model_desc& d, const nsvd_params& p, const float* x, 
                 const GenericWs& w, hipStream_t s, bool features_ready = false) {
     const int R = w.R, F = 2 * d.m;
     int rc = 0;
-    // all stencil rows: the shifted row blocks in EVEN / ODD form (DESIGN.md 3.9) - features, pre-activations and head
+    // all stencil rows: the shifted row blocks in EVEN / ODD form (DESIGN.md 3.2) - features, pre-activations and head
     // outputs of block 1 + 2 d / 2 + 2 d are the even / odd perturbations along d; centre rows only (nst = 1): plain
     const bool eo = nst > 1;
     if (!features_ready)

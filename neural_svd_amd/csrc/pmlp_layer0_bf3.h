@@ -1,4 +1,4 @@
-// Layer 0 of the fused forward on the bf16 MFMA (NSVD_PATH_FUSED_BF16X3, DESIGN.md 3.7). Included by pmlp_fwd.hip
+// Layer 0 of the fused forward on the bf16 MFMA (NSVD_PATH_FUSED_BF16X3, DESIGN.md 3.5). Included by pmlp_fwd.hip
 // inside its unnamed namespace, after FwdArgs.
 // ================================================================================================
 // Layer 0 on the bf16 MFMA with float32-equivalent accuracy (opt-in path NSVD_PATH_FUSED_BF16X3).
@@ -8,7 +8,7 @@
 //     hi hi + hi mid + mid hi + hi lo + lo hi + mid mid          (dropped: mid lo + lo mid + lo lo <= 2^-25 |a b|)
 // accumulated in float32 by v_mfma_f32_32x32x16_bf16, smallest terms first. Each partial product of two 8-bit
 // significands is exact in the MFMA, so the only errors are the dropped terms and the float32 accumulation - no
-// larger than the native fp32 MFMA's own rounding (DESIGN.md 3.7 for the measured parity), at 16/6 of its rate.
+// larger than the native fp32 MFMA's own rounding (DESIGN.md 3.5 for the measured parity), at 16/6 of its rate.
 //
 // Round 4 form. What bounded the round-1 loop (3200 cycles per 32-wide chunk against 1920 of MFMA issue) was the refill
 // of its double-buffered LDS stage: 54 KB per chunk through registers and ds_write with one chunk of lead, less than

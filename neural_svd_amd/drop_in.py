@@ -347,7 +347,7 @@ def train_operator(args, method, operator, make_batch_ftn_train, val_data, batch
         # 37-38,62-72): half-precision matmuls, loss scaling against their underflow. Here it selects this package's
         # mixed-precision forward, NSVD_PATH_FUSED_BF16X3 - every layer on the bf16 MFMA with operands split into three
         # bfloat16 planes, float32 accumulation: the speed-up the flag asks for (2.2 x on the forward) with f and Tf as
-        # close to float64 as the float32 path's (DESIGN.md 3.7, 3.9), so there is nothing for a GradScaler to do.
+        # close to float64 as the float32 path's (DESIGN.md 3.5, 3.2), so there is nothing for a GradScaler to do.
         # DIFFERENT arithmetic from the reference's autocast, not bit-comparable to it (nor is the float32 path). Models
         # the MFMA kernels do not take have no such forward: refuse rather than ignore the flag.
         from . import hip_ops as H

@@ -16,7 +16,7 @@ workload = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 SHORT = [("pmlp_fused_fwd_kernel<5, 0, 0", "pmlp_fused_fwd"),  # the headline forward (stencil, native fp32 MFMA)
-         ("pmlp_fused_fwd_kernel<5, 0, 1", "pmlp_fused_fwd_bf16x3"),  # bench.py's side measurement (DESIGN 3.7)
+         ("pmlp_fused_fwd_kernel<5, 0, 1", "pmlp_fused_fwd_bf16x3"),  # bench.py's side measurement (DESIGN 3.5)
          ("w0_split", "w0_split_bf16x3"), ("pmlp_fused_wgrad", "pmlp_fused_wgrad"),
          ("pmlp_fused_bwd_chain", "pmlp_fused_bwd_chain"), ("fourier_stencil", "fourier_stencil"),
          ("evd_partial", "evd_partial"), ("rmsprop_ema", "rmsprop_ema"), ("distribution_elementwise", "torch_randn"),

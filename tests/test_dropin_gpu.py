@@ -70,7 +70,7 @@ def test_reference_style_pipeline(case):
     pre64, pre32 = f"{case}_f64_step0_", f"{case}_f32_step0_"
     assert rel(aux["f"], z[pre64 + "f"]) < 2e-5
     # end to end through the reference's API, against the reference's FLOAT64 loss and gradients at north_star's 1e-4 (the
-    # stencil in even / odd form, DESIGN.md 3.9; its own float32 run is ref_err = 1e-2 .. 1e-1 away on these 24-32 rows)
+    # stencil in even / odd form, DESIGN.md 3.2; its own float32 run is ref_err = 1e-2 .. 1e-1 away on these 24-32 rows)
     assert abs(float(loss.detach()) - float(z[pre64 + "loss"])) < 1e-4 * abs(float(z[pre64 + "loss"]))
     for n, p in method.named_parameters():
         if not p.requires_grad:

@@ -1,4 +1,4 @@
-"""The stencil in EVEN / ODD form (DESIGN.md 3.9) restated in float64 on the CPU, against the oracle's point-wise stencil
+"""The stencil in EVEN / ODD form (DESIGN.md 3.2) restated in float64 on the CPU, against the oracle's point-wise stencil
 (= the reference's algorithm, diff_ops.py:36-48): the two are the SAME central difference - the kernels' representation
 changes what float32 rounding does to it, not what is computed. Float64 on both sides, so what remains is the softplus
 expansion's truncation (sixth order; pairs above |perturbation| 0.25 take the mirrored differences) - far below 1e-9 at

@@ -1,11 +1,11 @@
 """GPU parity tests: every C-ABI entry point vs the CPU oracle / the reference's golden vectors.
 
-Tolerances (float32 path, see DESIGN.md "Numerics"):
+Tolerances (float32 path):
   * f, moments, loss-given-(f,Tf), gradients-given-df, optimiser: <= 2e-5 relative (L2) vs float64;
-  * Tf: two correct float32 evaluations of the eps=0.01 central difference differ at the percent
-    level (the reference's own float32 Tf is 1e-3..4e-2 away from its float64 Tf), so Tf and
-    everything downstream of it is compared against the float64 truth with the float32 reference's
-    own error as yardstick: err <= max(3 * ref_err, floor).
+  * Tf (eps = 0.01 stencil, carried in even / odd form by every path), the end-to-end loss and every
+    gradient: <= 1e-4 relative of the FLOAT64 stencil / the reference's float64 values (measured
+    2e-7 .. 7e-6). The float32 reference's own error (1e-3 .. 4e-2 on Tf) is still evaluated by
+    `check_tf` as a yardstick, but it is no longer the bar.
 """
 import math
 
@@ -252,7 +252,7 @@ def test_operator_headline_shapes(case, path):
     check_tf(r["Tf"], z, case, cfg)
     l_given, *_ = O.evd_loss_forward(r["f"].double().cpu(), r["Tf"].double().cpu(), v.double(), M.double())
     assert abs(float(r["loss"][0]) - float(l_given)) < 1e-5 * abs(float(l_given))
-    # every path carries the stencil in even / odd form (DESIGN.md 3.9): Tf - and with it the loss - agrees with the
+    # every path carries the stencil in even / odd form (DESIGN.md 3.2): Tf - and with it the loss - agrees with the
     # FLOAT64 stencil to north_star's 1e-4, where the reference's own float32 arithmetic is a few per cent away
     assert r["path"] == ("generic" if path == "generic" else "fused_mfma"), r["path"]
     assert rel(r["Tf"], z[pre64 + "Tf"]) < 1e-4, rel(r["Tf"], z[pre64 + "Tf"])

@@ -3,7 +3,7 @@ path against the float64 oracle, with the float32 oracle - the reference's own a
 
   * laplacian_eps = 0.01 (the scripts' setting): a float32 central difference at eps = 0.01 taken point-wise - the
     reference's arithmetic, the float32 oracle here - carries a per-point error of about |f| and
-    its eigenvalues are percent-level noisy. The fused kernels carry the stencil in even / odd form (DESIGN.md 3.9) and
+    its eigenvalues are percent-level noisy. The fused kernels carry the stencil in even / odd form (DESIGN.md 3.2) and
     are held to north_star's 1e-4 against the FLOAT64 stencil on every eigenvalue (measured 3e-6 worst on the 62 500-point
     grid of scripts/parity_spectrum_cfg2.py), with the float32 oracle's own distance printed beside it.
   * laplacian_eps = 0 (exact Laplacian, reference diff_ops.py:54-61): nothing is differenced; the bar is 1e-5 relative
