@@ -619,7 +619,7 @@ def bench_widened(args, as_dict=False):
         out["comm"] = comm_block
     if as_dict:
         return out
-    print(json.dumps(out))
+    _emit(out)
     if comm is not None:
         comm.close()
 
@@ -1260,9 +1260,27 @@ def main():
         out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    _emit(out)
     if comm is not None:
         comm.close()
+
+
+
+def _emit(line):
+    """the ONE JSON line, as the LAST line of stdout: native libraries write there too through C stdio (RCCL's version
+    banner sits in that buffer until the process exits - behind the JSON line in a pipe or a file), so their buffers
+    are flushed first, and once the line is out file descriptor 1 goes to /dev/null for the teardown"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+    try:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    except OSError:
+        pass
 
 
 def launcher_worst_case_seconds(launch_timeout, n_attempts=3):
@@ -1281,7 +1299,6 @@ if __name__ == "__main__":
             _PROVISIONAL["degraded"] = (f"the run died after its first measured split ({type(e).__name__}: {e}); this is "
                                         f"north_star's literal split (samples sharded, one moments all-reduce + one "
                                         f"gradient all-reduce per step, blocking), measured before that")
-            print(json.dumps(_PROVISIONAL))
-            sys.stdout.flush()
+            _emit(_PROVISIONAL)
             os._exit(0)  # (no teardown of a process group whose collectives are failing)
         raise

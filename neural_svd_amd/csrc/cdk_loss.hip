@@ -22,7 +22,8 @@
 // Launches:  cdk_stage (pad + transpose + operator-term partials)
 //            cdk_forward_gemm (border rows, gram tiles, lam_f / lam_g tiles in one grid)
 //            cdk_finish (M * lam, transposed for the backward; metric-term partials)
-//            cdk_loss_reduce (one block: loss[3] from the partials)
+//            cdk_loss_reduce (one block: loss[3] from the partials; the fused training step lets its optimiser kernel
+//                             do this sum instead: nsvd_cdk_loss_forward_parts)
 //            cdk_backward_gemm (both gradients in one grid)
 #include "nsvd_kernels.h"
 #include "tile_nt.h"
@@ -321,20 +322,9 @@ __global__ void __launch_bounds__(256) cdk_finish_kernel(CdkWs w, const float* _
 // loss[0..2] from the per-block partials, added in index order. A separate one-block launch: the
 // "last block reduces" idiom needs a device-scope release per block, which on this multi-XCD part is an L2
 // writeback per block (measured: 17 us for the finish kernel with it, 5 without).
-__global__ void __launch_bounds__(256) cdk_loss_reduce_kernel(CdkWs w, int B, float* __restrict__ loss) {
-    __shared__ float red[4];
-    float so = 0.f, sm = 0.f;
-    for (int i = threadIdx.x; i < w.nstage; i += 256) so += w.part_op[i];
-    for (int i = threadIdx.x; i < w.nfin; i += 256) sm += w.part_met[i];
-    so = block_sum_256(so, red);
-    __syncthreads();
-    sm = block_sum_256(sm, red);
-    if (threadIdx.x == 0) {
-        const float lop = -2.0f * so / (float)B;
-        loss[0] = lop + sm;
-        loss[1] = lop;
-        loss[2] = sm;
-    }
+__global__ void __launch_bounds__(256) cdk_loss_reduce_kernel(NsvdCdkLossParts lp, float* __restrict__ loss) {
+    __shared__ float red[8];
+    nsvd_cdk_loss_sum(lp, red, loss);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -390,14 +380,13 @@ extern "C" size_t nsvd_cdk_workspace_bytes(int B, int L, int set_first_mode_cons
     return carve(nullptr, B, L, set_first_mode_const).bytes;
 }
 
-extern "C" int nsvd_cdk_loss_forward(const float* f, const float* g, const float* batch_weights, const float* v,
-                                     const float* M, int B, int L, int set_first_mode_const, float* loss,
-                                     float* rs_joint, float* rs_indep, void* ws, size_t ws_bytes, void* stream) {
-    if (!f || !g || !v || !M || !loss || !ws || B <= 0 || L <= 0) return NSVD_EINVAL;
+int nsvd_cdk_loss_forward_parts(const float* f, const float* g, const float* batch_weights, const float* v,
+                                const float* M, int B, int L, int set_first_mode_const, float* rs_joint,
+                                float* rs_indep, void* ws, size_t ws_bytes, NsvdCdkLossParts* parts, hipStream_t s) {
+    if (!f || !g || !v || !M || !ws || !parts || B <= 0 || L <= 0) return NSVD_EINVAL;
     if (rs_indep && B < 2) return NSVD_EINVAL;
     const CdkWs w = carve(ws, B, L, set_first_mode_const);
     if (ws_bytes < w.bytes) return NSVD_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
     const int nr = w.R / T, nb = w.Bp / T;
     cdk_stage_kernel<<<dim3(w.Bp / TS, w.LD / TS), 256, 0, s>>>(f, g, batch_weights, v, B, L, w);
     NSVD_CHECK_LAUNCH();
@@ -409,7 +398,21 @@ extern "C" int nsvd_cdk_loss_forward(const float* f, const float* g, const float
     NSVD_CHECK_LAUNCH();
     cdk_finish_kernel<<<w.nfin, 256, 0, s>>>(w, M, B);
     NSVD_CHECK_LAUNCH();
-    cdk_loss_reduce_kernel<<<1, 256, 0, s>>>(w, B, loss);
+    parts->part_op = w.part_op; parts->part_met = w.part_met;
+    parts->nstage = w.nstage; parts->nfin = w.nfin; parts->B = B;
+    return 0;
+}
+
+extern "C" int nsvd_cdk_loss_forward(const float* f, const float* g, const float* batch_weights, const float* v,
+                                     const float* M, int B, int L, int set_first_mode_const, float* loss,
+                                     float* rs_joint, float* rs_indep, void* ws, size_t ws_bytes, void* stream) {
+    if (!loss) return NSVD_EINVAL;
+    NsvdCdkLossParts lp;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = nsvd_cdk_loss_forward_parts(f, g, batch_weights, v, M, B, L, set_first_mode_const, rs_joint, rs_indep,
+                                               ws, ws_bytes, &lp, s);
+    if (rc) return rc;
+    cdk_loss_reduce_kernel<<<1, 256, 0, s>>>(lp, loss);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

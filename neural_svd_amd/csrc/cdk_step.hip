@@ -51,9 +51,13 @@ __global__ void __launch_bounds__(256) cdk_sumsq_kernel(TensorTable t, float* __
 // the gradient kernels and this one is gone. Workgroup 0 leaves norm and coefficient in scal / loss_out[3].
 __global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float* __restrict__ partial, int npartial,
                                                       float max_norm, float* __restrict__ scal,
-                                                      float* __restrict__ loss_out, float lr, float momentum, int first) {
+                                                      float* __restrict__ loss_out, float lr, float momentum, int first,
+                                                      NsvdCdkLossParts lp) {
     __shared__ double red[256];
     __shared__ float coef_s;
+    // the step's loss value: the loss kernels left per-block partials (no reduction launch of their own)
+    if (blockIdx.x == 0 && loss_out && lp.part_op) nsvd_cdk_loss_sum(lp, reinterpret_cast<float*>(red), loss_out);
+    __syncthreads();
     {
         double s = 0.0;
         for (int i = threadIdx.x; i < npartial; i += 256) s += (double)partial[i];
@@ -246,8 +250,9 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
         if (rc) return rc;
     }
     // loss and its gradient w.r.t. the two embeddings
-    rc = nsvd_cdk_loss_forward(w.e[0], w.e[1], nullptr, v, M, B, L, d->set_first_mode_const, loss, rs_joint, rs_indep,
-                               w.cdk, w.cdk_bytes, stream);
+    NsvdCdkLossParts lparts;
+    rc = nsvd_cdk_loss_forward_parts(w.e[0], w.e[1], nullptr, v, M, B, L, d->set_first_mode_const, rs_joint, rs_indep,
+                                     w.cdk, w.cdk_bytes, &lparts, s);
     if (rc) return rc;
     rc = nsvd_cdk_loss_backward(v, B, L, d->set_first_mode_const, nullptr, w.ge[0], w.ge[1], w.cdk, w.cdk_bytes, stream);
     if (rc) return rc;
@@ -325,7 +330,7 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     size_t blocks = (q4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;  // (each workgroup first adds the partials for itself: not too many of them)
     hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, part0, npart,
-                       (float)d->max_grad_norm, w.scal, loss, (float)d->lr, (float)d->momentum, d->first_step);
+                       (float)d->max_grad_norm, w.scal, loss, (float)d->lr, (float)d->momentum, d->first_step, lparts);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

@@ -2,7 +2,8 @@
 // nsvd_gemm_bf16 (include/nsvd.h): 256 x 128 output tile per workgroup, K in steps of 64, 8 waves (2 per SIMD, 4 x 2,
 // 64 x 64 per wave = 4 x 4 blocks of v_mfma_f32_16x16x32_bf16), operands global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4) into a ring of three stages, one workgroup barrier per K step, the DMA of step t + 2 in
-// flight under the MFMAs of steps t and t + 1. Up to two independent problems of one shape per launch (the two towers).
+// flight under the MFMAs of steps t and t + 1. Up to four independent problems per launch (the two towers; both weight-
+// gradient contractions of both towers: one kernel boundary instead of two), each with its own output shape.
 // Reference arithmetic this replaces: the five matmuls per tower and step of examples/models/mlp.py:129-164 under
 // torch.cuda.amp.autocast (examples/cdk/sketchy/main_sketchy.py:182) and their autograd backward.
 //
@@ -46,16 +47,27 @@ struct Prob {
     void* C;            // (M, ldc) float32 or bfloat16; split-K slice s at C + s * slice_stride elements
     const float* bias;  // per column of C (N) or null
     float* sumsq;       // null, or one float per workgroup of THIS problem: the sum of squares of its tile of C
+    int M, N;           // this problem's output shape (the problems of a launch share K, S and the operand forms)
+    long lda, ldb, ldc; // in elements
+    int tiles_m, tiles_n, wg0;  // filled by launch(): tile counts; this problem's first workgroup in the launch's order
 };
 
+constexpr int MAXPROB = 4;
+
 struct Args {
-    Prob p[2];
-    int nprob, M, N, K, S;      // S split-K slices of K / S each
-    long lda, ldb, ldc;         // in elements
+    Prob p[MAXPROB];
+    int nprob, K, S;            // S split-K slices of K / S each
     long slice_stride;          // elements of C between split-K slices
-    int tiles_m, tiles_n;
+    int nwg;
     int dbg;  // diagnostic builds only (NSVD_G16_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs
 };
+
+// the problems of a launch with one shape (the two towers): shape and strides of all nprob entries
+inline void set_uniform(Args& a, int M, int N, long lda, long ldb, long ldc) {
+    for (int i = 0; i < a.nprob; ++i) {
+        a.p[i].M = M; a.p[i].N = N; a.p[i].lda = lda; a.p[i].ldb = ldb; a.p[i].ldc = ldc;
+    }
+}
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
@@ -77,33 +89,36 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
     const int wm = w >> 1, wn = w & 1;
 
     // ---- which tile: XCD-aware order (workgroups b, b + 8, .. share an XCD and its L2: they get a contiguous run of the
-    // tile order, whose fast index runs over the dimension with fewer tiles)
-    const int per = a.tiles_m * a.tiles_n;
-    const int nwg = per * a.S * a.nprob;
+    // launch's order - problem, split-K slice, then the tiles with the fast index over the dimension with fewer tiles)
     int id = blockIdx.x;
-    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
-    const int prob = id / (per * a.S);
-    id -= prob * per * a.S;
+    if ((a.nwg & 7) == 0) id = (id & 7) * (a.nwg >> 3) + (id >> 3);
+    int prob = 0;
+#pragma unroll
+    for (int i = 1; i < MAXPROB; ++i)
+        if (i < a.nprob && id >= a.p[i].wg0) prob = i;
+    const Prob& P = a.p[prob];
+    id -= P.wg0;
+    const int per = P.tiles_m * P.tiles_n;
     const int slice = id / per;
     id -= slice * per;
     int tm, tn;
-    if (a.tiles_m <= a.tiles_n) {
-        tn = id / a.tiles_m;
-        tm = id - tn * a.tiles_m;
+    if (P.tiles_m <= P.tiles_n) {
+        tn = id / P.tiles_m;
+        tm = id - tn * P.tiles_m;
     } else {
-        tm = id / a.tiles_n;
-        tn = id - tm * a.tiles_n;
+        tm = id / P.tiles_n;
+        tn = id - tm * P.tiles_n;
     }
-    const Prob& P = a.p[prob];
     const int Ks = a.K / a.S;
     const int nk = Ks / BK;
     const long k0 = (long)slice * Ks;
+    const unsigned lda = (unsigned)P.lda, ldb = (unsigned)P.ldb;
 
     // ---- DMA sources: wave w moves pieces 4 w .. 4 w + 3 of A and 2 w, 2 w + 1 of B (1 KB each)
-    const char* sa = reinterpret_cast<const char*>(P.A) + 2 * (AS ? (k0 * a.lda + (long)BM * tm) : ((long)BM * tm * a.lda + k0));
-    const char* sb = reinterpret_cast<const char*>(P.B) + 2 * (BS ? (k0 * a.ldb + (long)BN * tn) : ((long)BN * tn * a.ldb + k0));
-    const long sa_step = AS ? 2L * BK * a.lda : 2L * BK;
-    const long sb_step = BS ? 2L * BK * a.ldb : 2L * BK;
+    const char* sa = reinterpret_cast<const char*>(P.A) + 2 * (AS ? (k0 * P.lda + (long)BM * tm) : ((long)BM * tm * P.lda + k0));
+    const char* sb = reinterpret_cast<const char*>(P.B) + 2 * (BS ? (k0 * P.ldb + (long)BN * tn) : ((long)BN * tn * P.ldb + k0));
+    const long sa_step = AS ? 2L * BK * P.lda : 2L * BK;
+    const long sb_step = BS ? 2L * BK * P.ldb : 2L * BK;
     unsigned va[4], vb[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -111,11 +126,11 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
         if (AS) {
             const int krow = 4 * (p & 15) + (lane >> 4), slot = lane & 15;
             const int chunk = slot ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
-            va[j] = 2u * ((unsigned)krow * (unsigned)a.lda + 128u * (unsigned)(p >> 4) + 8u * (unsigned)chunk);
+            va[j] = 2u * ((unsigned)krow * lda + 128u * (unsigned)(p >> 4) + 8u * (unsigned)chunk);
         } else {
             const int row = 8 * p + (lane >> 3), slot = lane & 7;
             const int chunk = slot ^ ((row >> 1) & 7);
-            va[j] = 2u * ((unsigned)row * (unsigned)a.lda + 8u * (unsigned)chunk);
+            va[j] = 2u * ((unsigned)row * lda + 8u * (unsigned)chunk);
         }
     }
 #pragma unroll
@@ -124,11 +139,11 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
         if (BS) {
             const int krow = 4 * p + (lane >> 4), slot = lane & 15;
             const int chunk = slot ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
-            vb[j] = 2u * ((unsigned)krow * (unsigned)a.ldb + 8u * (unsigned)chunk);
+            vb[j] = 2u * ((unsigned)krow * ldb + 8u * (unsigned)chunk);
         } else {
             const int row = 8 * p + (lane >> 3), slot = lane & 7;
             const int chunk = slot ^ ((row >> 1) & 7);
-            vb[j] = 2u * ((unsigned)row * (unsigned)a.ldb + 8u * (unsigned)chunk);
+            vb[j] = 2u * ((unsigned)row * ldb + 8u * (unsigned)chunk);
         }
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -284,10 +299,10 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
         constexpr int LPR = O16 ? 16 : 32;        // lanes per row (16 bytes each)
         constexpr int RPP = 512 / LPR;            // rows per pass of the workgroup
         const int rr = tid / LPR, cc = tid % LPR;
-        char* cbase = reinterpret_cast<char*>(P.C) + ((long)slice * a.slice_stride + (long)BM * tm * a.ldc + BN * tn) * (O16 ? 2 : 4);
+        char* cbase = reinterpret_cast<char*>(P.C) + ((long)slice * a.slice_stride + (long)BM * tm * P.ldc + BN * tn) * (O16 ? 2 : 4);
         for (int r = rr; r < BM; r += RPP) {
             const uint4 v = *reinterpret_cast<const uint4*>(lds + r * RS + 16 * cc);
-            char* dstp = cbase + (long)r * a.ldc * (O16 ? 2 : 4) + 16 * cc;
+            char* dstp = cbase + (long)r * P.ldc * (O16 ? 2 : 4) + 16 * cc;
             // write-through (sc1): the rows leave for memory as they are stored instead of sitting dirty in this XCD's L2
             // until the kernel-end write-back (MI355X_MICROARCH.md, stores of each flavour / row `boundary`): 0.9 us of
             // the 15.8 at (1024, 8192, 512) bfloat16 out, 1.5 of 23.5 at (512, 8192, 1024) float32 out
@@ -303,7 +318,7 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
         if (lane == 0) red[w] = ss;
         __syncthreads();
         if (tid == 0)
-            P.sumsq[slice * per + tm * a.tiles_n + tn] =
+            P.sumsq[slice * per + tm * P.tiles_n + tn] =
                 ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
     }
 }
@@ -311,24 +326,29 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
 // host side: validate and launch. out_bf16: C holds bfloat16. Returns 0 or NSVD_E*.
 inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16, hipStream_t s) {
     Args a = a0;
-    if (a.nprob < 1 || a.nprob > 2 || a.S < 1 || a.M <= 0 || a.N <= 0 || a.K <= 0) return NSVD_EINVAL;
-    if (a.M % BM || a.N % BN || a.K % (BK * a.S)) return NSVD_EINVAL;
-    if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % (out_bf16 ? 8 : 4))) return NSVD_EINVAL;  // 16-byte DMA sources and stores
+    if (a.nprob < 1 || a.nprob > MAXPROB || a.S < 1 || a.K <= 0 || a.K % (BK * a.S)) return NSVD_EINVAL;
+    int nwg = 0;
     for (int i = 0; i < a.nprob; ++i) {
-        if (!a.p[i].A || !a.p[i].B || !a.p[i].C) return NSVD_EINVAL;
-        if (((uintptr_t)a.p[i].A | (uintptr_t)a.p[i].B | (uintptr_t)a.p[i].C | (uintptr_t)a.p[i].bias) & 15) return NSVD_EINVAL;
+        Prob& P = a.p[i];
+        if (P.M <= 0 || P.N <= 0 || P.M % BM || P.N % BN) return NSVD_EINVAL;
+        if ((P.lda % 8) || (P.ldb % 8) || (P.ldc % (out_bf16 ? 8 : 4))) return NSVD_EINVAL;  // 16-byte DMA sources and stores
+        if (!P.A || !P.B || !P.C) return NSVD_EINVAL;
+        if (((uintptr_t)P.A | (uintptr_t)P.B | (uintptr_t)P.C | (uintptr_t)P.bias) & 15) return NSVD_EINVAL;
+        // per-lane source offsets are 32-bit: a tile's rows must lie within 4 GB of its origin
+        const long span_a = 2L * (a_strided ? (long)BK * P.lda + BM : (long)BM * P.lda + BK);
+        const long span_b = 2L * (b_strided ? (long)BK * P.ldb + BN : (long)BN * P.ldb + BK);
+        if (span_a >= (1L << 32) || span_b >= (1L << 32)) return NSVD_EINVAL;
+        P.tiles_m = P.M / BM;
+        P.tiles_n = P.N / BN;
+        P.wg0 = nwg;
+        nwg += P.tiles_m * P.tiles_n * a.S;
     }
-    // per-lane source offsets are 32-bit: a tile's rows must lie within 4 GB of its origin
-    const long span_a = 2L * (a_strided ? (long)BK * a.lda + BM : (long)BM * a.lda + BK);
-    const long span_b = 2L * (b_strided ? (long)BK * a.ldb + BN : (long)BN * a.ldb + BK);
-    if (span_a >= (1L << 32) || span_b >= (1L << 32)) return NSVD_EINVAL;
-    a.tiles_m = a.M / BM;
-    a.tiles_n = a.N / BN;
+    a.nwg = nwg;
     {
         static const char* e = getenv("NSVD_G16_DBG");
         a.dbg = e ? atoi(e) : 0;
     }
-    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.S * a.nprob));
+    const dim3 grid((unsigned)nwg);
 #define G16_LAUNCH(AS_, BS_, O_)                                                                                   \
     {                                                                                                              \
         static bool attr_set = false;                                                                              \

@@ -42,7 +42,7 @@ extern "C" int nsvd_gemm_bf16(const void* A, const void* B, void* C, const float
     nsvd_g16::Args a;
     memset(&a, 0, sizeof(a));
     a.p[0].A = A; a.p[0].B = B; a.p[0].C = C; a.p[0].bias = bias; a.p[0].sumsq = sumsq;
-    a.nprob = 1; a.M = M; a.N = N; a.K = K; a.S = slices;
-    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.slice_stride = slice_stride;
+    a.nprob = 1; a.K = K; a.S = slices; a.slice_stride = slice_stride;
+    nsvd_g16::set_uniform(a, M, N, lda, ldb, ldc);
     return nsvd_g16::launch(a, a_kstrided != 0, b_kstrided != 0, out_bf16 != 0, (hipStream_t)stream);
 }

@@ -176,6 +176,37 @@ struct NsvdNarrowBwd {
     float r_up;
     int sphere;
 };
+// the CDK loss forward without its one-block reduction launch: the per-block partials of the two loss terms, for a later
+// kernel of the same stream to add (nsvd_cdk_loss_sum: the reduction's own order) - cdk_step.hip's optimiser kernel
+struct NsvdCdkLossParts {
+    const float *part_op, *part_met;
+    int nstage, nfin, B;
+};
+int nsvd_cdk_loss_forward_parts(const float* f, const float* g, const float* batch_weights, const float* v,
+                                const float* M, int B, int L, int set_first_mode_const, float* rs_joint,
+                                float* rs_indep, void* ws, size_t ws_bytes, NsvdCdkLossParts* parts, hipStream_t s);
+// loss[0..2] = {loss, operator term, metric term} from the partials, added in index order by one workgroup of 256
+// threads (red: 4 floats of LDS); every thread of the workgroup must call it
+__device__ __forceinline__ void nsvd_cdk_loss_sum(const NsvdCdkLossParts& lp, float* red, float* __restrict__ loss) {
+    float so = 0.f, sm = 0.f;
+    for (int i = threadIdx.x; i < lp.nstage; i += 256) so += lp.part_op[i];
+    for (int i = threadIdx.x; i < lp.nfin; i += 256) sm += lp.part_met[i];
+    so = nsvd_wave_sum(so);
+    sm = nsvd_wave_sum(sm);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = so;
+        red[4 + (threadIdx.x >> 6)] = sm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lop = -2.0f * (red[0] + red[1] + red[2] + red[3]) / (float)lp.B;
+        const float met = red[4] + red[5] + red[6] + red[7];
+        loss[0] = lop + met;
+        loss[1] = lop;
+        loss[2] = met;
+    }
+}
 size_t nsvd_narrow_scratch_floats(int nt, int B, int N);
 int nsvd_narrow_sumsq_count(int N);
 bool nsvd_narrow_supported(int nt, int B, int N);

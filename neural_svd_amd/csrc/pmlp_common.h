@@ -111,6 +111,7 @@ struct FusedWs {
     unsigned short* whp;              // (nlayers - 2, 3, L, 128, 128) bf16 planes of W_1 .. (the same path)
     float* base_raw;                  // (L, (1 + 2D) B) head outputs per stencil point (split-stencil forward only)
     float* loss_part;                 // (L, 32 + 1) partial sums of the loss (direct-moment backward, B <= 1024)
+    float* kpart;                     // K-split forward only (fwd_kslices() > 1): the slices' partial layer-0 pre-activations
     size_t bytes;
 };
 
@@ -168,6 +169,21 @@ inline PartLayout part_layout(const nsvd_model_desc& d) {
     return p;
 }
 
+// K-split of the forward's layer 0 (pmlp_fwd.hip, template parameter KS): the D = 2 stencil in split form (one
+// direction per workgroup) on a batch that still leaves half of the CUs idle - configs[0]: 2 x 64 workgroups - cuts the
+// layer-0 contraction (nine tenths of the kernel) into this many K slices, one workgroup each, which leave their
+// partial pre-activations in the workspace; a second launch adds them and runs the rest of the network
+inline int fwd_kslices(const nsvd_model_desc& d, int B) {
+    if (d.D != 2 || B % BS != 0) return 1;
+    if ((B / BS) * d.L > 64) return 1;        // 2 x that many split-form workgroups, x 2 slices <= 256 CUs
+    if (d.m % 64 != 0 || d.m < 128) return 1;  // a slice is an even number (>= 4) of 32-wide chunks
+    return 2;
+}
+inline size_t fwd_kpart_floats(const nsvd_model_desc& d, int B) {
+    const int ks = fwd_kslices(d, B);
+    return ks > 1 ? (size_t)ks * 2 * (B / BS) * d.L * 3 * HID * BS : 0;  // slices x workgroups x (3 tiles of 128 x 32)
+}
+
 inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     FusedWs w;
     memset(&w, 0, sizeof(w));
@@ -194,6 +210,7 @@ inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     w.whp = (unsigned short*)take(((size_t)(d.nlayers > 2 ? d.nlayers - 2 : 0) * 3 * d.L * HID * HID + 1) / 2);
     w.base_raw = take((size_t)d.L * (1 + 2 * (size_t)d.D) * B);
     w.loss_part = take(33 * (size_t)d.L);
+    w.kpart = fwd_kpart_floats(d, B) ? take(fwd_kpart_floats(d, B)) : nullptr;
     w.bytes = off;
     return w;
 }

@@ -57,6 +57,12 @@ struct FwdArgs {
     // times) the workgroups for batches that leave CUs idle, and the only way 7 stencil columns (D = 3) fit at all.
     int split;
     float* base_raw;
+    // K-split of layer 0 (KS = 1 / 2 instances, split-stencil form only; pmlp_common.h: fwd_kslices): the KS = 1 launch
+    // holds `ks` x the split form's workgroups, slice k of a workgroup contracts features [k m / ks, (k + 1) m / ks) of the
+    // sin block and their cos partners and leaves its accumulators in kpart [slice][workgroup][tile][wave][register][lane];
+    // the KS = 2 launch (the split form's own grid) adds the slices in order and runs the rest of the network
+    int ks;
+    float* kpart;
     unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
 
@@ -84,9 +90,10 @@ __device__ __forceinline__ void nsvd_glds16(const float* gsrc, float* lds_base) 
 #ifdef NSVD_EO_COUNT
 __device__ unsigned long long g_eo_count[8];
 #endif
-template <int E, int JET, int BF3 = 0, int PL = 0>
+template <int E, int JET, int BF3 = 0, int PL = 0, int KS = 0>
 __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     static_assert(!PL || (!JET && !BF3 && E <= 4), "plain tiles: native fp32 layer 0, at most four sample tiles");
+    static_assert(!KS || (E == 3 && !JET && !BF3 && !PL), "K-split: the split-stencil form only");
     constexpr int NC = E * BS;
     // Stencil mode (neither jets nor plain tiles), both the native and the bf16x3 kernel: the 2 D shifted evaluations
     // travel through the network in EVEN / ODD form - tile 0 the centre x, tile 1 + 2 d the even part and tile 2 + 2 d the
@@ -115,6 +122,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int li = lane & 31, hi = lane >> 5;
     const int nsb = a.B / (PL ? NC : BS);
     int l, sb, grp = 0, bid = blockIdx.x;
+    int kslice = 0;
+    if (KS == 1) {  // K-split, first launch: which slice of layer 0's contraction
+        const int per = nsb * a.L * a.split;
+        kslice = __builtin_amdgcn_readfirstlane(bid / per);
+        bid -= kslice * per;
+    }
     if (E == 3 && !JET && !BF3 && a.split) {  // split-stencil form: which direction's points this workgroup evaluates
         grp = bid / (nsb * a.L);
         bid -= grp * nsb * a.L;
@@ -139,17 +152,39 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
             for (int e = 0; e < E; ++e) acc[e][r] = ((JET || EO) && e > 0) ? 0.f : bv;  // (the bias joins tile 0 only)
         }
     }
+    // K-split: this workgroup's block of partial accumulators, [tile][wave][register][lane] floats per (slice, workgroup)
+    float* kp = nullptr;
+    if (KS) {
+        const size_t unit = ((size_t)grp * a.L + l) * nsb + sb;
+        kp = a.kpart + (((size_t)kslice * a.split * a.L * nsb + unit) * E * 4 + w) * 16 * 64 + lane;
+        if (KS == 1 && kslice > 0) {  // (the bias joins slice 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+        }
+    }
 
     if constexpr (BF3) {
         nsvd_layer0_bf3<E, JET>(a, acc, reinterpret_cast<char*>(smem), l, b0);
         __syncthreads();  // the W-tile DMA below lands in the tail of the stage buffers
+    } else if constexpr (KS == 2) {
+        // K-split, second launch: the slices' partial pre-activations, added in slice order
+        const size_t sstride = (size_t)a.split * a.L * nsb * E * 4 * 16 * 64;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = kp[(size_t)(e * 4 * 16 + r) * 64];
+                for (int k = 1; k < a.ks; ++k) v += kp[(size_t)k * sstride + (size_t)(e * 4 * 16 + r) * 64];
+                acc[e][r] = v;
+            }
     } else {
     // ------------------------------------------------------------------ layer 0: K = F in chunks of BK
     // Both operands are k-contiguous rows (W_0[l][n][:] and phi[r][:]): each thread moves one float4 of a
     // 32-row slab per step, global -> registers -> LDS; chunk c+1 is in flight while chunk c is multiplied.
     // Named registers, no arrays: hipcc leaves a conditionally written float4 array in scratch.
     const float* W0 = a.W[0] + (size_t)l * HID * a.F;
-    const int nch = a.F / BK;
+    const int nch = KS == 1 ? a.F / BK / a.ks : a.F / BK;
+    const int kf0 = KS == 1 ? kslice * (a.m / a.ks) : 0;  // first sin feature of this K slice
     // K runs over PAIRS of chunks: 32 sin features k in [32 p, 32 p + 32) and their 32 cos partners m + k. The
     // pair is loaded once (centre row only: 2 float4 per thread + the per-frequency constants) and the E stencil
     // rows of both chunks are generated in registers (even rows u (cos d - 1), odd rows +- v sin d: the angle-addition
@@ -167,10 +202,10 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     // this loop costs matrix-pipe time, see the header).
     const unsigned offA = (unsigned)(s_row * a.F + 4 * s_c4) * 4u;
     const unsigned offT = (unsigned)(4 * s_c4) * 4u;
-    const float* a_u = W0;
-    const float* b_u = a.phiT + (size_t)b0 * a.F;               // centre features, (B, F) row-major
-    const float* t_u = a.sctab + (size_t)grp * 2 * a.m;         // (D, 2, m): this group's direction first
-    const float* tc_u = a.sctab + (size_t)(2 * a.D + grp) * a.m;  // (D, m) behind it: cos(eps B_dj) - 1
+    const float* a_u = W0 + kf0;
+    const float* b_u = a.phiT + (size_t)b0 * a.F + kf0;               // centre features, (B, F) row-major
+    const float* t_u = a.sctab + (size_t)grp * 2 * a.m + kf0;         // (D, 2, m): this group's direction first
+    const float* tc_u = a.sctab + (size_t)(2 * a.D + grp) * a.m + kf0;  // (D, m) behind it: cos(eps B_dj) - 1
     const size_t a_step = (size_t)32 * a.F;
     const int mm = a.m;
 #define NSVD_LDGU(ub, off) (*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ub) + (off)))
@@ -335,6 +370,13 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
 
     }
     NSVD_STAMP(2)
+    if constexpr (KS == 1) {  // K-split, first launch: leave this slice's accumulators (256-byte rows per register)
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kp[(size_t)(e * 4 * 16 + r) * 64] = acc[e][r];
+        return;
+    }
     // ------------------------------------------------------------------ hidden layers 1 .. nh-1
     const int nh = a.nlayers - 1;
     for (int i = 0; i < nh; ++i) {
@@ -773,20 +815,20 @@ size_t fwd_lds_bytes() {
     return (RED_OFF + 5 * NC) * sizeof(float);
 }
 
-template <int E, int JET = 0, int BF3 = 0, int PL = 0>
-int launch_fwd(const FwdArgs& a, hipStream_t s) {
+template <int E, int JET = 0, int BF3 = 0, int PL = 0, int KS = 0>
+int launch_fwd(const FwdArgs& a, hipStream_t s, int prof = 3) {  // prof: bit 0 / 1 = this launch opens / closes the bracket
     const size_t lds = fwd_lds_bytes<E, BF3>();
     static bool attr_done = false;  // idempotent, racing threads set the same value
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)pmlp_fused_fwd_kernel<E, JET, BF3, PL>,
+        hipError_t e = hipFuncSetAttribute((const void*)pmlp_fused_fwd_kernel<E, JET, BF3, PL, KS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
-    const int grid = (a.B / (PL ? E * BS : BS)) * a.L * (a.split > 0 ? a.split : 1);
-    nsvd_prof_begin(s);
-    hipLaunchKernelGGL((pmlp_fused_fwd_kernel<E, JET, BF3, PL>), dim3(grid), dim3(256), lds, s, a);
-    nsvd_prof_end(s);
+    const int grid = (a.B / (PL ? E * BS : BS)) * a.L * (a.split > 0 ? a.split : 1) * (KS == 1 ? a.ks : 1);
+    if (prof & 1) nsvd_prof_begin(s);
+    hipLaunchKernelGGL((pmlp_fused_fwd_kernel<E, JET, BF3, PL, KS>), dim3(grid), dim3(256), lds, s, a);
+    if (prof & 2) nsvd_prof_end(s);
     NSVD_CHECK_LAUNCH();
     return 0;
 }
@@ -902,7 +944,15 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     if (d.D == 3 || (d.D == 2 && (B / BS) * d.L <= 128)) {
         a.split = d.D;
         a.base_raw = w.base_raw;
-        rc = launch_fwd<3>(a, s);
+        a.ks = fwd_kslices(d, B);
+        if (a.ks > 1) {  // configs[0]: 2 x 128 workgroups for layer 0, then 128 for the rest of the network
+            a.kpart = w.kpart;
+            rc = launch_fwd<3, 0, 0, 0, 1>(a, s, 1);  // (the in-run bracket of bench.py spans both launches)
+            if (rc) return rc;
+            rc = launch_fwd<3, 0, 0, 0, 2>(a, s, 2);
+        } else {
+            rc = launch_fwd<3>(a, s);
+        }
         if (rc) return rc;
         return nsvd_fd_epilogue(w.base_raw, R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
                                 save ? w.jac : nullptr, (save && d.has_exp_mask) ? w.dsc : nullptr, s, 1);

@@ -847,7 +847,8 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
     for (int t = 0; t < nt; ++t) {
         g.p[t].A = v[t].Xh; g.p[t].B = v[t].W1h; g.p[t].C = v[t].Y1h; g.p[t].bias = p[t]->b1;
     }
-    g.nprob = nt; g.M = B; g.N = d1; g.K = d0; g.S = 1; g.lda = d0; g.ldb = d0; g.ldc = d1;
+    g.nprob = nt; g.K = d0; g.S = 1;
+    nsvd_g16::set_uniform(g, B, d1, d0, d0, d1);
     nsvd_prof_begin(s);  // bench.py --config cfg5 --amp brackets this contraction (nsvd_profile_next_forward)
     rc = nsvd_g16::launch(g, false, false, true, s);
     nsvd_prof_end(s);
@@ -871,7 +872,8 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
     for (int t = 0; t < nt; ++t) {
         g.p[t].A = v[t].A1h; g.p[t].B = v[t].W2h; g.p[t].C = w[t].Y2p;
     }
-    g.nprob = nt; g.M = B; g.N = d2; g.K = d1; g.S = S; g.lda = d1; g.ldb = d1; g.ldc = d2;
+    g.nprob = nt; g.K = d1; g.S = S;
+    nsvd_g16::set_uniform(g, B, d2, d1, d1, d2);
     g.slice_stride = (long)B * d2;
     rc = nsvd_g16::launch(g, false, false, false, s);
     if (rc) return rc;
@@ -920,20 +922,13 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
         if (rc) return rc;
     }
     nsvd_g16::Args g;
-    // dW2 = dY2h^T A1h
-    memset(&g, 0, sizeof(g));
-    for (int t = 0; t < nt; ++t) {
-        g.p[t].A = v[t].dY2h; g.p[t].B = v[t].A1h; g.p[t].C = grads[t]->W2; g.p[t].sumsq = sumsq ? sumsq[t] : nullptr;
-    }
-    g.nprob = nt; g.M = d2; g.N = d1; g.K = B; g.S = 1; g.lda = d2; g.ldb = d1; g.ldc = d1;
-    rc = nsvd_g16::launch(g, true, true, false, s);
-    if (rc) return rc;
     // dA1h = dY2h W2h
     memset(&g, 0, sizeof(g));
     for (int t = 0; t < nt; ++t) {
         g.p[t].A = v[t].dY2h; g.p[t].B = v[t].W2h; g.p[t].C = v[t].dA1h;
     }
-    g.nprob = nt; g.M = B; g.N = d1; g.K = d2; g.S = 1; g.lda = d2; g.ldb = d1; g.ldc = d1;
+    g.nprob = nt; g.K = d2; g.S = 1;
+    nsvd_g16::set_uniform(g, B, d1, d2, d1, d1);
     rc = nsvd_g16::launch(g, false, true, true, s);
     if (rc) return rc;
     {   // dY1h = BN1'(lrelu'(dA1h)), db1
@@ -949,13 +944,19 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
         hipLaunchKernelGGL(tower_bn16_backward_kernel, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, b);
         NSVD_CHECK_LAUNCH();
     }
-    // dW1 = dY1h^T Xh
+    // dW2 = dY2h^T A1h and dW1 = dY1h^T Xh of every tower in ONE launch (same operand forms, same contraction length B,
+    // different output shapes): a kernel boundary of these launches costs as much as a third of their MFMA work
     memset(&g, 0, sizeof(g));
     for (int t = 0; t < nt; ++t) {
-        g.p[t].A = v[t].dY1h; g.p[t].B = v[t].Xh; g.p[t].C = grads[t]->W1;
-        g.p[t].sumsq = sumsq ? sumsq[t] + (d2 / 256) * (d1 / 128) : nullptr;
+        nsvd_g16::Prob& q2 = g.p[t];
+        q2.A = v[t].dY2h; q2.B = v[t].A1h; q2.C = grads[t]->W2; q2.sumsq = sumsq ? sumsq[t] : nullptr;
+        q2.M = d2; q2.N = d1; q2.lda = d2; q2.ldb = d1; q2.ldc = d1;
+        nsvd_g16::Prob& q1 = g.p[nt + t];
+        q1.A = v[t].dY1h; q1.B = v[t].Xh; q1.C = grads[t]->W1;
+        q1.sumsq = sumsq ? sumsq[t] + (d2 / 256) * (d1 / 128) : nullptr;
+        q1.M = d1; q1.N = d0; q1.lda = d1; q1.ldb = d0; q1.ldc = d0;
     }
-    g.nprob = nt; g.M = d1; g.N = d0; g.K = B; g.S = 1; g.lda = d1; g.ldb = d0; g.ldc = d0;
+    g.nprob = 2 * nt; g.K = B; g.S = 1;
     return nsvd_g16::launch(g, true, true, false, s);
 }
 

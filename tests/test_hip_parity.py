@@ -630,14 +630,16 @@ def test_exact_mode_three_dimensional(fpath):
     assert rel(r2["f"], ref["f"]) < 2e-5
 
 
-@pytest.mark.parametrize("D,L,B", [(3, 3, 96), (2, 16, 128)])
-def test_split_stencil_form(D, L, B):
+@pytest.mark.parametrize("D,L,B,m", [(3, 3, 96, 64), (2, 16, 128, 64), (2, 16, 128, 256), (2, 4, 64, 128)])
+def test_split_stencil_form(D, L, B, m):
     """The split-stencil form of the fused forward (one direction's two shifted points + the centre per workgroup, raw
     head outputs combined by the generic FD epilogue): the only way the 7 stencil columns of a 3-D problem fit the
     MFMA kernels, and what small batches (configs[0]: 64 workgroups of the plain form on 256 CUs) take to fill the chip.
     f, the FD-noise yardstick on Tf, and every gradient against the float64 oracle; f and the saved state bit-identical
-    to ... nothing else computes them, so: the generic kernels as a second witness at float32 level."""
-    m, hidden = 64, (128, 128, 128)
+    to ... nothing else computes them, so: the generic kernels as a second witness at float32 level.
+    The last two cases (m >= 128, at most 64 plain workgroups: configs[0]'s situation) also cut layer 0 into two K slices
+    of one workgroup each, added by a second launch that runs the rest of the network (pmlp_common.h: fwd_kslices)."""
+    hidden = (128, 128, 128)
     p = O.init_params(L, D, m, hidden, 0.2, exp_mask_init=4.0, seed=44)
     prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=3.0)
     v, M = O.sequential_nesting_masks(L)
