@@ -1,5 +1,6 @@
 // Fused MFMA path, backward half: the data-gradient chain kernel, the weight-gradient kernel with the optimiser in
 // its epilogue, and the split-K reduction (forward half and the overall design: pmlp_fwd.hip).
+#include <stdlib.h>
 #include "pmlp_common.h"
 #include "evd_math.h"
 #include "opt_math.h"
@@ -355,6 +356,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];
     }
 }
+
+#include "pmlp_stream_bwd.h"
 
 // ================================================================================================
 // BACKWARD, part 2 (pmlp_fused_wgrad_kernel): every parameter gradient, one launch, no atomics.
@@ -1068,7 +1071,41 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
         chain_grid += a.feat_blocks;
     }
     if (state) chain_grid += 1;  // the schedule block
-    if ((nh == 2 || nh == 3) && chain_only <= 128)
+    // the streaming form (pmlp_stream_bwd.h) where the shape allows: no dz_i through HBM, the slices' partial gradients
+    // through the split-K second pass below
+    int SS = 0;
+    if (nh == 2 && F == HID && !next && !win && !state && Lc == dfull.L && l0 == 0 && w.gpart &&
+        (df || (evd && (evd->moments || evd->part) && evd->Lg % 4 == 0 && evd->Lg <= 128))) {
+        static const char* e = getenv("NSVD_STREAM_BWD");
+        if (!(e && e[0] == '0')) SS = stream_bwd_slices(d, B);
+    }
+    const PartLayout pl = part_layout(d);
+    if (SS) {
+        StreamArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.df = df; sa.jac = a.jac; sa.dsc = a.dsc;
+        sa.W1 = a.W[1]; sa.Wl = a.W[2]; sa.a0 = a.zsave[0]; sa.a1 = a.zsave[1]; sa.phiTc = w.phiTc;
+        sa.B = B; sa.L = d.L; sa.ldl = a.ldl; sa.l0 = a.l0; sa.S = SS; sa.Bs = B / SS;
+        sa.evd = a.evd;
+        sa.part = w.gpart; sa.part_stride = pl.stride;
+        for (int i = 0; i < 3; ++i) {
+            sa.poW[i] = pl.oW[i];
+            sa.pob[i] = pl.ob[i];
+        }
+        sa.poscales = pl.oscales;
+        {
+            static const char* e2 = getenv("NSVD_STREAM_DBG");
+            sa.dbg = e2 ? atoi(e2) : 0;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)pmlp_stream_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)SB_LDS_BYTES);
+            if (e != hipSuccess) return -(int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(pmlp_stream_bwd_kernel, dim3(d.L * SS), dim3(256), SB_LDS_BYTES, s, sa);
+    } else if ((nh == 2 || nh == 3) && chain_only <= 128)
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<true>, dim3(chain_grid), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<false>, dim3(chain_grid), dim3(256), 0, s, a);
@@ -1112,7 +1149,7 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     wa.S = wgrad_slices(d, B);
     wa.Bs = B / wa.S;
     wa.nB = 4 * (nh - 1) * d.L;
-    const PartLayout pl = part_layout(d);
+    if (SS) wa.S = SS;
     if (wa.S > 1) {
         wa.part = w.gpart;
         wa.part_stride = pl.stride;
@@ -1140,7 +1177,9 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
         wa.whp = reinterpret_cast<unsigned short*>(wp.whp);
     }
     const dim3 wgrid(wa.S * (wa.nA + wa.nB + 4 * d.L));
-    if (wa.tw == 64) {
+    if (SS) {
+        // (the streaming kernel has written every slice)
+    } else if (wa.tw == 64) {
         if (emit) hipLaunchKernelGGL((pmlp_fused_wgrad_kernel<1, true>), wgrid, dim3(256), 0, s, wa);
         else hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<1>, wgrid, dim3(256), 0, s, wa);
     } else {
@@ -1148,7 +1187,7 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
         else hipLaunchKernelGGL(pmlp_fused_wgrad_kernel<2>, wgrid, dim3(256), 0, s, wa);
     }
     NSVD_CHECK_LAUNCH();
-    if (wa.S == 1) return 0;
+    if (wa.S == 1 && !SS) return 0;
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.part = w.gpart;
@@ -1175,6 +1214,11 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ra);
     NSVD_CHECK_LAUNCH();
     return 0;
+}
+
+// developer diagnostic (not in include/nsvd.h): the streaming backward's per-region cycle counts (NSVD_STREAM_DBG = 4)
+extern "C" int nsvd_debug_stream_stamps(unsigned long long* host) {
+    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sb_stamps), 8 * sizeof(unsigned long long));
 }
 
 #ifdef NSVD_WG_STAMPS

@@ -145,6 +145,19 @@ inline int wgrad_slices(const nsvd_model_desc& d, int B) {
     return S;
 }
 
+// The streaming backward (pmlp_stream_bwd.h: one workgroup = head x batch slice, no dz through HBM): plain-model shapes
+// with F = 128 features and two hidden layers, enough (head, 32-sample chunk) pairs to keep a slice long. Returns the
+// number of batch slices (heads x slices >= 256 workgroups where the batch allows), 0 = the two-launch form.
+inline int stream_bwd_slices(const nsvd_model_desc& d, int B) {
+    if (d.nlayers != 3 || 2 * d.m != HID || d.dims[0] != HID || d.dims[1] != HID) return 0;
+    if (B % BS != 0 || (B / BS) * d.L < 2048) return 0;
+    int S = 1;
+    while (d.L * S < 256 && S < 16) S *= 2;
+    while (S > 1 && (B % (BS * S) != 0 || B / S < 256)) S /= 2;
+    if (B / S < 256) return 0;
+    return S;
+}
+
 // per-slice layout of the partial gradients: [W_0 | .. | W_n | b_0 | .. | b_n | scales], each padded to 4 floats
 struct PartLayout {
     size_t oW[NSVD_MAX_LAYERS], ob[NSVD_MAX_LAYERS], oscales, nW[NSVD_MAX_LAYERS], nb[NSVD_MAX_LAYERS], nscales;
@@ -204,8 +217,8 @@ inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     for (int i = 0; i < d.nlayers - 1; ++i) w.dz[i] = take((size_t)d.L * HID * B);
     w.dbase = take((size_t)B * d.L);
     w.dfsc = take((size_t)B * d.L);
-    const int S = wgrad_slices(d, B);
-    w.gpart = S > 1 ? take((size_t)S * part_layout(d).stride) : nullptr;
+    const int S = wgrad_slices(d, B), SS = stream_bwd_slices(d, B);
+    w.gpart = (S > 1 || SS > 0) ? take((size_t)(S > SS ? S : SS) * part_layout(d).stride) : nullptr;
     w.w0p = (unsigned short*)take(((size_t)3 * d.L * HID * F + 1) / 2);
     w.whp = (unsigned short*)take(((size_t)(d.nlayers > 2 ? d.nlayers - 2 : 0) * 3 * d.L * HID * HID + 1) / 2);
     w.base_raw = take((size_t)d.L * (1 + 2 * (size_t)d.D) * B);
