@@ -18,6 +18,7 @@
 // workgroups of one head share an XCD (its 1 MB W_0 stays in that XCD's L2).
 // Reference arithmetic being replaced: examples/models/mlp.py:204-221 x (1+2D) evaluations
 // (diff_ops.py:36-45) + diff_ops.py:9-23 + schrodinger/__init__.py:16-22 + examples/__init__.py:7-9.
+#include <stdlib.h>
 #include <type_traits>
 #include "pmlp_common.h"
 #include "fd_math.h"
@@ -804,6 +805,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     }
 }
 
+#include "pmlp_plain_fwd.h"
+
 template <int E, int BF3 = 0>
 size_t fwd_lds_bytes() {
     constexpr int NC = E * BS;
@@ -994,6 +997,34 @@ int nsvd_fused_model_forward(const nsvd_model_desc& d, const nsvd_params& p, con
     a.f = out;
     a.jac = save ? w.jac : nullptr;
     a.dsc = (save && d.has_exp_mask) ? w.dsc : nullptr;
+    // the model shape of the kernel-operator row on enough tiles: the streaming form (pmlp_plain_fwd.h) - weights in
+    // registers, two workgroups per CU
+    {
+        static const char* e = getenv("NSVD_PLAIN_STREAM");
+        const int tpw = (e && e[0] == '0') ? 0 : plain_stream_tpw(d, B);
+        if (tpw > 0) {
+            PlainFwdArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.phi = w.phi;
+            pa.W0 = p.W[0]; pa.b0 = p.b[0]; pa.W1 = p.W[1]; pa.b1 = p.b[1]; pa.Wl = p.W[2]; pa.bl = p.b[2];
+            pa.x = x; pa.scales = a.scales; pa.D = d.D; pa.c = c;
+            pa.out = out; pa.jac = a.jac; pa.dsc = a.dsc;
+            pa.z0 = a.zsave[0]; pa.z1 = a.zsave[1];
+            pa.B = B; pa.L = d.L; pa.tpw = tpw;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t er = hipFuncSetAttribute((const void*)pmlp_plain_stream_fwd_kernel,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS_BYTES);
+                if (er != hipSuccess) return -(int)er;
+                attr_set = true;
+            }
+            nsvd_prof_begin(s);
+            hipLaunchKernelGGL(pmlp_plain_stream_fwd_kernel, dim3((B / BS / tpw) * d.L), dim3(256), PF_LDS_BYTES, s, pa);
+            nsvd_prof_end(s);
+            NSVD_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     // four sample tiles per workgroup (a head's W_0 / W_i tiles fetched once per 128 samples, the fixed costs of a
     // workgroup - first-chunk latency, weight DMA, epilogue - paid once per 128) whenever that still leaves every CU
     // two workgroups; one tile otherwise
