@@ -34,9 +34,9 @@ __device__ __forceinline__ void chunk_rows(const Chunking& c, int chunk, int& r0
 // NQ outputs per thread and pass (4 covers L <= 32 in one pass without idle accumulators); JC: 256 is a multiple of L, so
 // a thread's column j = tid % L is the same for all of its outputs - one read of the row's element instead of NQ
 template <int NQ, bool JC>
-__device__ __forceinline__ void chunk_gram_t(const float* fs, int nr, int L, float* __restrict__ out) {
+__device__ __forceinline__ void chunk_gram_t(const float* fs, int nr, int L, float* __restrict__ out, int o0, int o1) {
     const int LL = L * L;
-    for (int base = 0; base < LL; base += 256 * NQ) {
+    for (int base = o0; base < o1; base += 256 * NQ) {
         float acc[NQ];
         int ii[NQ], jj[NQ];
 #pragma unroll
@@ -55,19 +55,32 @@ __device__ __forceinline__ void chunk_gram_t(const float* fs, int nr, int L, flo
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int o = base + (int)threadIdx.x + 256 * q;
-            if (o < LL) out[o] = acc[q];
+            if (o < o1) out[o] = acc[q];
         }
     }
 }
-__device__ __forceinline__ void chunk_gram(const float* fs, int nr, int L, float* __restrict__ out) {
+// outputs [o0, o1) of the chunk's L x L block (o0 a multiple of 256; the whole block: 0, L * L)
+__device__ __forceinline__ void chunk_gram(const float* fs, int nr, int L, float* __restrict__ out, int o0, int o1) {
     const bool jc = 256 % L == 0 && L * L >= 256;  // (every output of a thread then exists or is the clamped last one)
-    if (L * L <= 1024) {
-        if (jc) chunk_gram_t<4, true>(fs, nr, L, out);
-        else chunk_gram_t<4, false>(fs, nr, L, out);
+    if (o1 - o0 <= 512) {
+        if (jc) chunk_gram_t<2, true>(fs, nr, L, out, o0, o1);
+        else chunk_gram_t<2, false>(fs, nr, L, out, o0, o1);
+    } else if (o1 - o0 <= 1024) {
+        if (jc) chunk_gram_t<4, true>(fs, nr, L, out, o0, o1);
+        else chunk_gram_t<4, false>(fs, nr, L, out, o0, o1);
     } else {
-        if (jc) chunk_gram_t<16, true>(fs, nr, L, out);
-        else chunk_gram_t<16, false>(fs, nr, L, out);
+        if (jc) chunk_gram_t<16, true>(fs, nr, L, out, o0, o1);
+        else chunk_gram_t<16, false>(fs, nr, L, out, o0, o1);
     }
+}
+// a chunk's block is cut over this many workgroups (gridDim.y): 64-row chunks give B / 64 workgroups - 128 at
+// configs[3] - each walking L^2 / 256 outputs per thread through LDS reads; cut four ways the kernel is 4 x as parallel (24.9 -> 17.0 us; eight ways: the same - what is left is the staging)
+// (every output is summed by one thread over the same rows in the same order: the same bits)
+inline int evd_partial_cuts(int B, int L) {
+    const int nch = chunking(B).n1 + chunking(B).n2;
+    int cuts = 1;
+    while (cuts < 8 && nch * cuts < 512 && (L * L) % (256 * 2 * cuts) == 0 && (L * L) / (2 * cuts) >= 1024) cuts *= 2;
+    return cuts;
 }
 
 __global__ void __launch_bounds__(256) evd_partial_kernel(const float* __restrict__ f, const float* __restrict__ Tf,
@@ -87,7 +100,12 @@ __global__ void __launch_bounds__(256) evd_partial_kernel(const float* __restric
         op = fmaf(mask_v(kind, v, l, L) * fv, Tf[(size_t)r0 * L + i], op);
     }
     __syncthreads();
-    chunk_gram(fs, nr, L, part + (size_t)blockIdx.x * L * L);
+    {
+        const int per = L * L / (int)gridDim.y;  // (gridDim.y > 1: a multiple of 256, evd_partial_cuts)
+        const int o0 = per * (int)blockIdx.y;
+        chunk_gram(fs, nr, L, part + (size_t)blockIdx.x * L * L, o0, blockIdx.y + 1 == gridDim.y ? L * L : o0 + per);
+    }
+    if (blockIdx.y != 0) return;
     op = nsvd_wave_sum(op);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = op;
     __syncthreads();
@@ -124,7 +142,12 @@ __global__ void __launch_bounds__(256) evd_gather_heads_kernel(const float* __re
     }
     if (!part) return;
     __syncthreads();
-    chunk_gram(fs, nr, L, part + (size_t)blockIdx.x * L * L);
+    {
+        const int per = L * L / (int)gridDim.y;  // (gridDim.y > 1: a multiple of 256, evd_partial_cuts)
+        const int o0 = per * (int)blockIdx.y;
+        chunk_gram(fs, nr, L, part + (size_t)blockIdx.x * L * L, o0, blockIdx.y + 1 == gridDim.y ? L * L : o0 + per);
+    }
+    if (blockIdx.y != 0) return;
     op = nsvd_wave_sum(op);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = op;
     __syncthreads();
@@ -383,7 +406,7 @@ extern "C" int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, i
     const int nch = c.n1 + c.n2;
     float* part = (float*)scratch;
     float* part_op = part + (size_t)nch * L * L;
-    hipLaunchKernelGGL(evd_partial_kernel, dim3(nch), dim3(256), (size_t)CH * L * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(evd_partial_kernel, dim3(nch, evd_partial_cuts(B, L)), dim3(256), (size_t)CH * L * sizeof(float), (hipStream_t)stream,
                        f, Tf, B, L, mask_kind, v, part, part_op);
     NSVD_CHECK_LAUNCH();
     return 0;
@@ -420,7 +443,7 @@ extern "C" int nsvd_evd_moments(const float* f, const float* Tf, int B, int L, i
     float* part = (float*)scratch;
     float* part_op = part + (size_t)nch * L * L;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(evd_partial_kernel, dim3(nch), dim3(256), (size_t)CH * L * sizeof(float), s, f, Tf, B, L,
+    hipLaunchKernelGGL(evd_partial_kernel, dim3(nch, evd_partial_cuts(B, L)), dim3(256), (size_t)CH * L * sizeof(float), s, f, Tf, B, L,
                        mask_kind, v, part, part_op);
     NSVD_CHECK_LAUNCH();
     hipLaunchKernelGGL(evd_reduce_kernel, dim3(nsvd_cdiv(L * L + 1, 256)), dim3(256), 0, s, part, part_op, B, L,
