@@ -497,7 +497,7 @@ def bench_widened(args, as_dict=False):
         # dominant kernel (rocprofv3: 560 us of the 1.6 ms, the gathered-row contraction ka_gemm_kernel 99 us):
         # 2 B L M flops, M = MACs per sample and head of the 128 -> 128 -> 128 -> 1 network behind 2 x 64 features
         kflops = 2.0 * B * (L // world) * (128 * 128 + 128 * 128 + 128)
-        kname = "pmlp_fused_fwd_kernel<4, 0, 0, 1>"
+        kname = "pmlp_plain_stream_fwd_kernel"  # (pmlp_plain_fwd.h; up to round 4: pmlp_fused_fwd_kernel<4, 0, 0, 1>)
         workload = (f"configs[3]: dense PSD kernel operator K = A A^T / 256 + 1e-3 I on N = {N} points in R^16, "
                     f"L = {L}, batch {B} indices with replacement, NestedLoRA.compute_loss_kernel(split_batch=False) "
                     f"on a 2 x 128 softplus ParallelMLP, RMSprop")

@@ -60,6 +60,7 @@ struct Args {
     long slice_stride;          // elements of C between split-K slices
     int nwg;
     int dbg;  // diagnostic builds only (NSVD_G16_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs
+    unsigned long long* stamps;  // diagnostic, or null: cycles of block 0 / wave 0 - prologue, K loop (first half | barrier | second half), epilogue
 };
 
 // the problems of a launch with one shape (the two towers): shape and strides of all nprob entries
@@ -241,6 +242,9 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
     //   DMA of step t + 3 into stage t % 3 (just freed)
     //   second half          : MFMAs on (t, 1) | reads of (t + 1, 0)
     // Every MFMA block runs on fragments read half a step earlier; a DMA has two steps to land.
+    const bool stamp = a.stamps && blockIdx.x == 0 && tid == 0;
+    const unsigned long long ts0 = a.stamps ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long th1 = 0, thb = 0, th2 = 0;
     G16_ISSUE(0);
     if (nk > 1) G16_ISSUE(1);
     if (nk > 2) G16_ISSUE(2);
@@ -249,21 +253,28 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
     else G16_WAIT_BARRIER(0);
     Frags f0, f1;
     if (!(a.dbg & 2)) load_frags(f0, lds, 0);
+    const unsigned long long ts1 = a.stamps ? __builtin_readcyclecounter() : 0ull;
     for (int t = 0; t < nk; ++t) {
         const char* st = lds + (t % NST) * ST_BYTES;
         const char* sn = lds + ((t + 1) % NST) * ST_BYTES;
+        const unsigned long long u0 = a.stamps ? __builtin_readcyclecounter() : 0ull;
         if (!(a.dbg & 2)) {
             load_frags(f1, st, 1);
             mma(f0);
         }
+        const unsigned long long u1 = a.stamps ? __builtin_readcyclecounter() : 0ull;
         if (t + 2 < nk && !(a.dbg & 1)) G16_WAIT_BARRIER(NDMA);
         else G16_WAIT_BARRIER(0);
+        const unsigned long long u2 = a.stamps ? __builtin_readcyclecounter() : 0ull;
         if (t + 3 < nk && !(a.dbg & 1)) G16_ISSUE(t % NST);
         if (!(a.dbg & 2)) {
             if (t + 1 < nk) load_frags(f0, sn, 0);
             mma(f1);
         }
+        const unsigned long long u3 = a.stamps ? __builtin_readcyclecounter() : 0ull;
+        th1 += u1 - u0; thb += u2 - u1; th2 += u3 - u2;
     }
+    const unsigned long long ts2 = a.stamps ? __builtin_readcyclecounter() : 0ull;
 #undef G16_ISSUE
 #undef G16_WAIT_BARRIER
 #undef G16_TR
@@ -310,6 +321,10 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
             const u32x4 vv = {v.x, v.y, v.z, v.w};
             asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
         }
+    }
+    if (stamp) {
+        a.stamps[0] = ts1 - ts0; a.stamps[1] = th1 / nk; a.stamps[2] = thb / nk; a.stamps[3] = th2 / nk;
+        a.stamps[4] = __builtin_readcyclecounter() - ts2; a.stamps[5] = (unsigned long long)nk;
     }
     if (P.sumsq) {  // fixed order: lanes of a wave (butterfly), then the eight waves
         ss = nsvd_wave_sum(ss);

@@ -36,6 +36,8 @@ extern "C" int nsvd_to_bf16(const float* in, void* out, size_t n, void* stream) 
     return nsvd_to_bf16_launch(in, out, n, (hipStream_t)stream);
 }
 
+static unsigned long long* g_dbg_stamps = nullptr;
+
 extern "C" int nsvd_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                               long ldb, long ldc, int a_kstrided, int b_kstrided, int out_bf16, int slices,
                               long slice_stride, float* sumsq, void* stream) {
@@ -44,5 +46,18 @@ extern "C" int nsvd_gemm_bf16(const void* A, const void* B, void* C, const float
     a.p[0].A = A; a.p[0].B = B; a.p[0].C = C; a.p[0].bias = bias; a.p[0].sumsq = sumsq;
     a.nprob = 1; a.K = K; a.S = slices; a.slice_stride = slice_stride;
     nsvd_g16::set_uniform(a, M, N, lda, ldb, ldc);
+    a.stamps = g_dbg_stamps;  // (null unless nsvd_debug_g16_stamps armed it)
     return nsvd_g16::launch(a, a_kstrided != 0, b_kstrided != 0, out_bf16 != 0, (hipStream_t)stream);
 }
+
+// developer diagnostic (not in include/nsvd.h): the first call arms the stamps of nsvd_gemm_bf16's launches (cycles of
+// block 0 / wave 0: prologue, K-loop halves and barrier per step, epilogue, K steps), later calls read the last launch's
+extern "C" int nsvd_debug_g16_stamps(unsigned long long* host) {
+    if (!g_dbg_stamps) {
+        hipError_t e = hipMalloc((void**)&g_dbg_stamps, 8 * sizeof(unsigned long long));
+        if (e != hipSuccess) return -(int)e;
+        return -(int)hipMemset(g_dbg_stamps, 0, 8 * sizeof(unsigned long long));
+    }
+    return -(int)hipMemcpy(host, g_dbg_stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
