@@ -182,19 +182,24 @@ inline PartLayout part_layout(const nsvd_model_desc& d) {
     return p;
 }
 
-// K-split of the forward's layer 0 (pmlp_fwd.hip, template parameter KS): the D = 2 stencil in split form (one
-// direction per workgroup) on a batch that still leaves half of the CUs idle - configs[0]: 2 x 64 workgroups - cuts the
-// layer-0 contraction (nine tenths of the kernel) into this many K slices, one workgroup each, which leave their
-// partial pre-activations in the workspace; a second launch adds them and runs the rest of the network
+// K-split of the forward's layer 0 (pmlp_fwd.hip, template parameter KS): a D = 2 stencil batch that leaves most CUs
+// idle (configs[0]: 64 workgroups of the plain form) cuts the layer-0 contraction - nine tenths of the kernel - into K
+// slices of one workgroup each, which leave their partial pre-activations in the workspace; a second launch adds them in
+// slice order and runs the rest of the network. Returns the slice count: 4 = plain form (all five stencil tiles per
+// workgroup, 4 x 64 = 256 workgroups, no fd_epilogue launch), 2 = on top of the split-stencil form (one direction per
+// workgroup, 2 x 2 x 64: narrower feature blocks), 1 = no K-split.
 inline int fwd_kslices(const nsvd_model_desc& d, int B) {
     if (d.D != 2 || B % BS != 0) return 1;
-    if ((B / BS) * d.L > 64) return 1;        // 2 x that many split-form workgroups, x 2 slices <= 256 CUs
-    if (d.m % 64 != 0 || d.m < 128) return 1;  // a slice is an even number (>= 4) of 32-wide chunks
-    return 2;
+    if ((B / BS) * d.L > 64) return 1;
+    if (d.m % 128 == 0 && d.m >= 256) return 4;  // a slice is an even number (>= 4) of 32-wide chunks
+    if (d.m % 64 == 0 && d.m >= 128) return 2;
+    return 1;
 }
 inline size_t fwd_kpart_floats(const nsvd_model_desc& d, int B) {
     const int ks = fwd_kslices(d, B);
-    return ks > 1 ? (size_t)ks * 2 * (B / BS) * d.L * 3 * HID * BS : 0;  // slices x workgroups x (3 tiles of 128 x 32)
+    if (ks == 4) return (size_t)4 * (B / BS) * d.L * 5 * HID * BS;      // slices x workgroups x (5 tiles of 128 x 32)
+    if (ks == 2) return (size_t)2 * 2 * (B / BS) * d.L * 3 * HID * BS;  // slices x (2 directions x workgroups) x 3 tiles
+    return 0;
 }
 
 inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
