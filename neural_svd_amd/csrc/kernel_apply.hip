@@ -12,6 +12,7 @@
 #include <string.h>
 #include "nsvd_kernels.h"
 #include "tile_nt.h"
+#include "tile128_dma.h"
 
 namespace {
 
@@ -21,6 +22,7 @@ struct KaWs {
     float* ST;      // (Lp, Np) scattered batch, zero padded
     float* part;    // (S, B1p, Lp) split-K partial tiles
     int Np, Lp, B1p, S;
+    int dma;        // 1: 128-row tiles on the LDS-DMA ring (ka_gemm_dma_kernel), 0: 64-row tiles (ka_gemm_kernel)
     int all_rows;   // 1: the contraction runs over ALL N rows of K once and the output rows are gathered from it
     size_t bytes;
 };
@@ -34,9 +36,17 @@ KaWs carve(void* base, int N, int B1, int L) {
     // every row of K once (N rows) and gather the B1 output rows from the product
     w.all_rows = B1 > N ? 1 : 0;
     w.B1p = nsvd_cdiv(w.all_rows ? N : B1, T) * T;
-    const int tiles = (w.B1p / T) * (w.Lp / T), chunks = w.Np / KC;
+    // 128 gathered rows per tile through the LDS-DMA ring of tile128_dma.h where the row count allows (the gathered rows
+    // of K are what this kernel streams from HBM: 328 MB at configs[3]; the ring keeps two chunks of every row in flight)
+    w.dma = (w.B1p % 128 == 0 && w.B1p >= 1024) ? 1 : 0;
     int S = 1;
-    while (tiles * S < 512 && chunks / (2 * S) >= 8) S *= 2;  // enough blocks for two per CU, >= 8 chunks per slice
+    if (w.dma) {
+        const int tiles = (w.B1p / 128) * (w.Lp / T), chunks32 = w.Np / 32;
+        while (tiles * S < 512 && chunks32 / (2 * S) >= 16) S *= 2;
+    } else {
+        const int tiles = (w.B1p / T) * (w.Lp / T), chunks = w.Np / KC;
+        while (tiles * S < 512 && chunks / (2 * S) >= 8) S *= 2;  // enough blocks for two per CU, >= 8 chunks per slice
+    }
     w.S = S;
     char* p = (char*)base;
     size_t off = 0;
@@ -93,6 +103,45 @@ __global__ void __launch_bounds__(256, 2) ka_gemm_kernel(const float* __restrict
     }
 }
 
+// the same contraction on 128 x 64 tiles with both operands by LDS-DMA (tile128_dma.h, gathered A rows): no staging
+// registers, four half chunks of every row in flight
+__global__ void __launch_bounds__(256, 2) ka_gemm_dma_kernel(const float* __restrict__ K, long ldk, int N,
+                                                             const long long* __restrict__ rows, int B1, KaWs w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using namespace nsvd_pmlp;
+    const int tb = blockIdx.x, tl = blockIdx.y, slice = blockIdx.z;
+    const int chunks = w.Np / 32;
+    const int c0 = (int)((long)chunks * slice / w.S), c1 = (int)((long)chunks * (slice + 1) / w.S);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    unsigned ga[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = tb * 128 + 32 * wv + (lane >> 2) + 16 * i;
+        long long g = r < B1 ? (rows ? rows[r] : (long long)r) : 0;  // (padding rows read row 0; never used)
+        if (g < 0 || g >= N) g = 0;
+        ga[i] = (unsigned)((size_t)g * (size_t)ldk * sizeof(float));
+    }
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    Tile128NoHook none;
+    nsvd_tile128_dma<Tile128NoHook, 1, false, true>(K + (size_t)c0 * 32, w.ST + (size_t)tl * T * w.Np + (size_t)c0 * 32, 0u,
+                                                    (unsigned)w.Np, c1 - c0, lds, acc, none, ga[0], ga[1]);
+    // wave (wm, wn): rows 64 wm + 32 i of the tile, columns 32 wn of the 64
+    const int li = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
+    float* out = w.part + (size_t)slice * w.B1p * w.Lp;
+    const int col = tl * T + 32 * wn + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tb * 128 + 64 * wm + 32 * i + acc_row(r, hi);
+            out[(size_t)row * w.Lp + col] = acc[i][0][r];
+        }
+}
+
 __global__ void __launch_bounds__(256) ka_reduce_kernel(KaWs w, const long long* __restrict__ rows, int N, int B1, int L,
                                                         float scale, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -140,9 +189,20 @@ extern "C" int nsvd_kernel_apply(const float* K, size_t ldk, int N, const long l
     ka_scatter_kernel<<<nsvd_cdiv(B2 * L, 256), 256, 0, s>>>(f, cols, B2, L, N, w.ST, w.Np);
     NSVD_CHECK_LAUNCH();
     nsvd_prof_begin(s);  // bench.py --config cfg4 brackets the contraction (nsvd_profile_next_forward)
-    ka_gemm_kernel<<<dim3(w.B1p / T, w.Lp / T, w.S), 256, ka_lds_bytes(), s>>>(K, (long)ldk, N,
-                                                                                w.all_rows ? nullptr : rows,
-                                                                                w.all_rows ? N : B1, w);
+    if (w.dma && (size_t)N * ldk * sizeof(float) < ((size_t)1 << 32)) {  // (32-bit row offsets)
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)ka_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(nsvd_pmlp::T128D_LDS_FLOATS * sizeof(float)));
+            attr_set = true;
+        }
+        ka_gemm_dma_kernel<<<dim3(w.B1p / 128, w.Lp / T, w.S), 256, nsvd_pmlp::T128D_LDS_FLOATS * sizeof(float), s>>>(
+            K, (long)ldk, N, w.all_rows ? nullptr : rows, w.all_rows ? N : B1, w);
+    } else {
+        ka_gemm_kernel<<<dim3(w.B1p / T, w.Lp / T, w.S), 256, ka_lds_bytes(), s>>>(K, (long)ldk, N,
+                                                                                    w.all_rows ? nullptr : rows,
+                                                                                    w.all_rows ? N : B1, w);
+    }
     nsvd_prof_end(s);
     NSVD_CHECK_LAUNCH();
     ka_reduce_kernel<<<nsvd_cdiv(B1 * L, 256), 256, 0, s>>>(w, rows, N, B1, L, scale, out);

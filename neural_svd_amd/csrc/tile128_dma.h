@@ -62,9 +62,12 @@ __device__ __forceinline__ void t128d_dma(const float* sbase, unsigned voff, uns
 // contraction indices) feeds ONE v_mfma_f32_32x32x16_bf16 where four float32 fragments' components fed four
 // v_mfma_f32_32x32x2_f32: the loop turns from MFMA-bound into staging-bound (mixed-precision tower GEMMs, tower.hip).
 typedef __bf16 nsvd_bf16x8 __attribute__((ext_vector_type(8)));
-template <class Hook, int NJ, bool BF = false>
+// GA = true: the rows of A are GATHERED - ga0 / ga1 = byte offsets from a_base of this lane's two rows (tile rows
+// 32 w + lane / 4 and + 16; w = wave), a_ld unused (the dense kernel operator's K[rows, :], kernel_apply.hip).
+template <class Hook, int NJ, bool BF = false, bool GA = false>
 __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const float* b_base, unsigned a_ld, unsigned b_ld,
-                                                 int nch, float* lds, f32x16 (&acc)[2][NJ], Hook& hook) {
+                                                 int nch, float* lds, f32x16 (&acc)[2][NJ], Hook& hook,
+                                                 unsigned ga0 = 0, unsigned ga1 = 0) {
     static_assert(NJ == 1 || NJ == 2, "B operand: 64 or 128 rows");
     const int tid = threadIdx.x & 255;  // four waves; a larger workgroup may run the routine in one of its wave groups
     const int lane = tid & 63;
@@ -73,7 +76,8 @@ __device__ __forceinline__ bool nsvd_tile128_dma(const float* a_base, const floa
     const int wm = w >> 1, wn = w & 1;
     // DMA: this wave moves rows 32 w .. 32 w + 31 of A and 16 NJ w .. + 16 NJ - 1 of B, 16 rows per instruction
     const unsigned dq = 4u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3));  // source column (floats) of this lane's slot
-    const unsigned va0 = 4u * ((unsigned)(32 * w + (lane >> 2)) * a_ld + dq), va1 = va0 + 64u * a_ld;
+    const unsigned va0 = GA ? ga0 + 4u * dq : 4u * ((unsigned)(32 * w + (lane >> 2)) * a_ld + dq);
+    const unsigned va1 = GA ? ga1 + 4u * dq : va0 + 64u * a_ld;
     const unsigned vb0 = 4u * ((unsigned)(16 * NJ * w + (lane >> 2)) * b_ld + dq), vb1 = vb0 + 64u * b_ld;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
     const unsigned m0a = lds0 + 2048u * (unsigned)w, m0b = lds0 + 8192u + 1024u * NJ * (unsigned)w;
