@@ -788,6 +788,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the launcher (nothing has touched the GPU yet) and never computes
         return self_launch(args, sys.argv[1:])
+    _claim_stdout()
     if args.config in ("cfg4", "cfg5"):
         return bench_widened(args)
 
@@ -1266,21 +1267,28 @@ def main():
 
 
 
+_JSON_FD = None
+
+
+def _claim_stdout():
+    """a process that computes keeps stdout for the ONE JSON line: file descriptor 1 is pointed at stderr for everything
+    else - native libraries write to it through C stdio (RCCL prints a five-line version banner there) - and the line
+    goes out through a private duplicate of the original descriptor (_emit)"""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 def _emit(line):
-    """the ONE JSON line, as the LAST line of stdout: native libraries write there too through C stdio (RCCL's version
-    banner sits in that buffer until the process exits - behind the JSON line in a pipe or a file), so their buffers
-    are flushed first, and once the line is out file descriptor 1 goes to /dev/null for the teardown"""
-    import ctypes
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:  # noqa: BLE001
-        pass
-    sys.stdout.write(json.dumps(line) + "\n")
-    sys.stdout.flush()
-    try:
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
-    except OSError:
-        pass
+    """the ONE JSON line, the only thing on the process's original stdout (_claim_stdout)"""
+    data = (json.dumps(line) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
 
 
 def launcher_worst_case_seconds(launch_timeout, n_attempts=3):
