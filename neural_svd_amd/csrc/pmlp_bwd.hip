@@ -286,15 +286,16 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
     // one step down the chain: store dz_i, exchange it through LDS, dz_{i-1} = (W_i^T dz_i) * sigmoid(z_{i-1}); the
     // W_i fragments (WF: 64 floats, W_i[n = 8 q + 4 hi + j][k = 32 w + li] at 4 q + j) and the sigmoid inputs (ZIN)
     // are in registers already
+#define CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define CHAIN_STEP(i, WF, ZIN)                                                                          \
     {                                                                                                   \
         float* o = a.dz[i] + row0;                                                                      \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) o[(size_t)acc_row(r, hi) * a.B] = dz[r];         \
-        __syncthreads(); /* previous round's LDS reads are done */                                      \
+        CHAIN_BARRIER(); /* previous round's LDS reads are done (raw: the dz stores above stay in flight) */ \
         _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                   \
             *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =                      \
                 make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);                    \
-        __syncthreads();                                                                                \
+        CHAIN_BARRIER();                                                                                \
         f32x16 acc1[1];                                                                                 \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;                                \
         const float* Bp = DZ + li * H_LD + 4 * hi;                                                      \
@@ -326,12 +327,12 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zin[r] = zp[(size_t)acc_row(r, hi) * a.B];
             }
-            __syncthreads();  // previous round's LDS reads are done
+            CHAIN_BARRIER();  // previous round's LDS reads are done
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =
                     make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);
-            __syncthreads();
+            CHAIN_BARRIER();
             f32x16 acc1[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
@@ -350,6 +351,7 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_bwd_chain_kernel(ChainArgs 
         }
     }
 #undef CHAIN_STEP
+#undef CHAIN_BARRIER
     {
         float* o = a.dz[0] + row0;
 #pragma unroll

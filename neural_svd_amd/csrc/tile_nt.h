@@ -73,6 +73,9 @@ __device__ __forceinline__ float nsvd_tnt_sum4(float4 v) { return (v.x + v.y) + 
             bv = bn;                                                                          \
         }                                                                                     \
     }
+// workgroup barrier that leaves the global loads in flight (__syncthreads() waits for vmcnt(0): the chunk requested at
+// the top of the step would have to land by its end - one step of lead instead of the two the register sets are for)
+#define NSVD_TNT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // one pipeline step: prefetch chunk c+2 into set S, compute chunk c, stage chunk c+1 (set SN) into LDS
 #define NSVD_TNT_STEP(S, SN, c)                                                               \
     NSVD_TNT_LOAD(S, min((c) + 2, nc - 1) * NSVD_TNT_KC)                                      \
@@ -86,7 +89,7 @@ __device__ __forceinline__ float nsvd_tnt_sum4(float4 v) { return (v.x + v.y) + 
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                        \
     NSVD_TNT_PUT(SN, SN)                                                                      \
     if (ROWSUM && (c) + 1 < nc) NSVD_TNT_SUM(SN)                                              \
-    __syncthreads();
+    NSVD_TNT_BARRIER();
 
 // core: the four A rows this thread stages (tile rows (t >> 4) + 16 i) are given as pointers, already offset to
 // its 4 columns of the first chunk - the rows of A may therefore be GATHERED (kernel_apply.hip); bp likewise.
@@ -130,3 +133,4 @@ __device__ __forceinline__ void nsvd_tile_nt(const float* __restrict__ A, long l
 #undef NSVD_TNT_SUM
 #undef NSVD_TNT_COMPUTE
 #undef NSVD_TNT_STEP
+#undef NSVD_TNT_BARRIER
