@@ -156,9 +156,25 @@ def test_bench_as_a_rank_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[-2000:]  # nothing else on stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] in ("dp2", "hp2") and d["value"] > 0 and d["params_finite"]
     assert d["rccl_ranks"] == 2 and "launcher_retry" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_stdout_carries_the_json_line_only_with_rccl_loaded():
+    """RCCL prints a version banner to stdout through C stdio when its first communicator comes up (seen on the GPU
+    box: five lines, behind the JSON line in a pipe). A computing bench.py process points file descriptor 1 at stderr and
+    writes its line through a private duplicate of the original stdout: a driver that parses stdout finds one line."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-exchange", "--steps", "20", "--warmup", "2",
+                        "--accuracy", "off", "--no-extras", "--no-cpu-baseline"],
+                       env=_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1 and out[0].startswith("{"), r.stdout[-2000:]
+    assert json.loads(out[0])["n_gpus"] == 1
 
 
 @pytest.mark.gpu
