@@ -656,6 +656,25 @@ def test_split_stencil_form(D, L, B, m):
         assert rel(a.view(-1), b.reshape(-1)) < 3e-5, i
 
 
+def test_k_split_forward_agrees_with_the_unsplit_kernel():
+    """configs[0]'s K-split (layer 0 of a 128-row batch cut into four K slices, pmlp_common.h: fwd_kslices) against the
+    plain kernel: the same 128 rows evaluated as the head of a 512-row batch (256 plain workgroups: no K-split). The
+    rows never see their neighbours, so f and Tf agree up to the summation order of layer 0."""
+    D, L, m, hidden = 2, 16, 1024, (128, 128, 128)
+    p = O.init_params(L, D, m, hidden, 0.1, exp_mask_init=None, seed=5)
+    prob = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    hp = hip_problem(prob)
+    x = (16.0 * torch.randn(512, D, generator=torch.Generator().manual_seed(2))).float().to(DEV)
+    f_big, Tf_big = H.operator_forward(shape, params, hp, x, H.new_workspace(shape, 512, DEV), path=H.PATH_FUSED)
+    xs = x[:128].contiguous()
+    f_ks, Tf_ks = H.operator_forward(shape, params, hp, xs, H.new_workspace(shape, 128, DEV), path=H.PATH_FUSED)
+    assert rel(f_ks, f_big[:128]) < 2e-6
+    assert rel(Tf_ks, Tf_big[:128]) < 2e-5  # (the stencil amplifies the last bits of layer 0 by 1 / eps^2 x eps-sized terms)
+
+
 @pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True), (16, 64, 1024, False),
                                         (5, 32, 2048, True)])
 def test_model_forward_backward_mfma(D, L, B, mask):
