@@ -1106,7 +1106,22 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
             if (e != hipSuccess) return -(int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL(pmlp_stream_bwd_kernel, dim3(d.L * SS), dim3(256), SB_LDS_BYTES, s, sa);
+        static const char* e3 = getenv("NSVD_STREAM_BWD");
+        if (e3 && e3[0] == '1') {  // the one-group form (pmlp_stream_bwd.h), kept for A/B measurements
+            hipLaunchKernelGGL(pmlp_stream_bwd_kernel, dim3(d.L * SS), dim3(256), SB_LDS_BYTES, s, sa);
+        } else {
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                hipError_t er = hipFuncSetAttribute((const void*)pmlp_stream_bwd2_kernel,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB2_LDS_BYTES);
+                if (er != hipSuccess) return -(int)er;
+                attr2_set = true;
+            }
+            if (!df) {  // the loss scalars from the moments (block 0 of the one-group kernel does this itself)
+                hipLaunchKernelGGL(stream_evd_finish_kernel, dim3(1), dim3(256), 0, s, sa.evd, B);
+            }
+            hipLaunchKernelGGL(pmlp_stream_bwd2_kernel, dim3(d.L * SS), dim3(512), SB2_LDS_BYTES, s, sa);
+        }
     } else if ((nh == 2 || nh == 3) && chain_only <= 128)
         hipLaunchKernelGGL(pmlp_fused_bwd_chain_kernel<true>, dim3(chain_grid), dim3(256), 0, s, a);
     else

@@ -332,3 +332,298 @@ __global__ void __launch_bounds__(256, 1) pmlp_stream_bwd_kernel(StreamArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same backward with the work of a chunk split over TWO wave groups per workgroup (8 waves, two per SIMD):
+//   group A (waves 0-3)  the element-wise chain of chunk c: d loss / d f, dz_1, the chain step's 64 MFMAs, dz_0, the
+//                        per-lane sums; W_1 in registers. Leaves dz_1 / dz_0 of its 32 rows in LDS (double buffered).
+//   group B (waves 4-7)  the weight-gradient products of chunk c - 1: 128 MFMAs per wave on dW_1 / dW_0 (128 accumulator
+//                        registers), and the staging of the a_0 / phi^T tiles they contract with.
+// A single wave's vector-ALU work does not hide under its own MFMAs (the one-group kernel above: 20 K cycles per chunk
+// for 12.3 K of MFMA issue); here B's MFMAs fill the matrix pipe while A's waves do theirs. s_barrier is workgroup-wide:
+// both groups execute the same three barriers per iteration, and B's MFMAs are spread over the three segments.
+constexpr int SB2_LDS_FLOATS = 6 * SB_TILE + SB_DZ + SB_MISC;  // a_0, phi^T tiles | DT1 x 2, DT0 x 2 | DZ | misc: 130 KB
+constexpr size_t SB2_LDS_BYTES = (size_t)SB2_LDS_FLOATS * sizeof(float);
+
+// the loss scalars of a step whose moments / partial moments are given (what block 0 of the kernels above does)
+__global__ void __launch_bounds__(256) stream_evd_finish_kernel(NsvdEvdIn evd, int B) {
+    __shared__ float red[8];
+    nsvd_evd_finish(evd, B, evd.Lg, red);
+}
+
+__global__ void __launch_bounds__(512, 1) pmlp_stream_bwd2_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sb_smem[];
+    float* A0s = sb_smem;                 // [128 k][36]   a_0 tile of chunk c - 1 (group B)
+    float* PHs = A0s + SB_TILE;           // [128 kf][36]  phi^T tile of chunk c - 1
+    float* DT1 = PHs + SB_TILE;           // [2][128 n][36]  dz_1 (written by A for chunk c, read by B one iteration later)
+    float* DT0 = DT1 + 2 * SB_TILE;       // [2][128 n][36]  dz_0
+    float* DZ = DT0 + 2 * SB_TILE;        // [32 c][132]   dz_1, rows contiguous (A's chain step)
+    float* col = DZ + SB_DZ;              // [2][Lg]
+    float* dfp = col + 256;               // [8][32]
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int tid = threadIdx.x & 255;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    int l, slice;
+    {
+        const int bid = blockIdx.x;
+        if (a.S <= 8 && 8 % a.S == 0 && a.L % (8 / a.S) == 0) {
+            const int x = bid & 7, hpg = 8 / a.S;
+            slice = x % a.S;
+            l = (bid >> 3) * hpg + x / a.S;
+        } else {
+            l = bid / a.S;
+            slice = bid - l * a.S;
+        }
+    }
+    const int nch = a.Bs / BS;
+    const int bbase = slice * a.Bs;
+    float* P = a.part + (size_t)slice * a.part_stride;
+#define SB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    if (grp == 0) {
+        // =============================================================================================== group A
+        const int Lg = a.df ? 0 : a.evd.Lg, lg = a.df ? 0 : a.evd.l_off + l;
+        const int B1 = (a.B + 1) / 2, B2 = a.B - B1;
+        float WF[64], wlv[16];
+        {
+            const float* Wi = a.W1 + (size_t)l * HID * HID + 32 * w + li;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float* wp = Wi + (size_t)(8 * q + 4 * hi) * HID;
+                WF[4 * q] = wp[0];
+                WF[4 * q + 1] = wp[HID];
+                WF[4 * q + 2] = wp[2 * HID];
+                WF[4 * q + 3] = wp[3 * HID];
+            }
+            const float* wl = a.Wl + (size_t)l * HID + 32 * w;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wlv[r] = wl[acc_row(r, hi)];
+        }
+        if (!a.df) {
+            for (int t = tid; t < 2 * Lg; t += 256) {
+                const int h = t / Lg, lp = t - h * Lg;
+                col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * nsvd_evd_lam(a.evd, h, lp * Lg + lg, a.B, Lg);
+            }
+        }
+        float dwl[16];  // (db_1 / db_0 are row sums of what group B reads anyway: taken there)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dwl[r] = 0.f;
+        float dbl = 0.f, dscl = 0.f;
+        const int srow = tid & 31, sg = tid >> 5;
+        const int seg = ((Lg + 31) >> 5) << 2;
+        const float* a1p = a.a1 + ((size_t)l * HID + 32 * w) * a.B + bbase + li;
+        const float* a0p = a.a0 + ((size_t)l * HID + 32 * w) * a.B + bbase + li;
+        float4 pf[4];
+        float zn[16], a0n[16], tfn = 0.f, jacn = 0.f, dscn = 0.f, dfn = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto request = [&](int c) {
+            const int o = c * BS;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                zn[r] = a1p[(size_t)acc_row(r, hi) * a.B + o];
+                a0n[r] = a0p[(size_t)acc_row(r, hi) * a.B + o];
+            }
+            const int b = bbase + o + li;
+            jacn = a.jac[(size_t)b * a.ldl + a.l0 + l];
+            if (a.dsc) dscn = a.dsc[(size_t)b * a.ldl + a.l0 + l];
+            if (a.df) {
+                dfn = a.df[(size_t)b * a.ldl + a.l0 + l];
+            } else {
+                tfn = a.evd.Tf[(size_t)b * Lg + lg];
+                const float* fr = a.evd.f + (size_t)(bbase + o + srow) * Lg + sg * seg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * k < seg && sg * seg + 4 * k < Lg) pf[k] = *reinterpret_cast<const float4*>(fr + 4 * k);
+            }
+        };
+        request(0);
+        SB_BARRIER();  // X0: the moment columns are in place (group B executes the same barrier)
+        for (int c = 0; c <= nch; ++c) {
+            const bool act = c < nch;
+            // ---- segment 1: the moment dot of this chunk's rows
+            if (act && !a.df) {
+                const float* cps = col + ((bbase + c * BS + srow) < B1 ? Lg : 0) + sg * seg;
+                float part = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * k < seg && sg * seg + 4 * k < Lg) {
+                        part = fmaf(pf[k].x, cps[4 * k], part);
+                        part = fmaf(pf[k].y, cps[4 * k + 1], part);
+                        part = fmaf(pf[k].z, cps[4 * k + 2], part);
+                        part = fmaf(pf[k].w, cps[4 * k + 3], part);
+                    }
+                dfp[sg * 32 + srow] = part;
+            }
+            SB_BARRIER();  // X1
+            // ---- segment 2: dz_1
+            float dz[16], s0[16];  // dz_1; sigmoid'(a_0) for the step after the chain (a_0's registers are then free)
+            if (act) {
+                float dfv = dfn;
+                if (!a.df) {
+                    const float* dq = dfp + li;
+                    const float acc = ((dq[0] + dq[32]) + (dq[64] + dq[96])) + ((dq[128] + dq[160]) + (dq[192] + dq[224]));
+                    const bool first = (bbase + c * BS + li) < B1;
+                    dfv = a.evd.grad_scale * ((-4.f / (float)a.B) * nsvd_evd_mask_v(a.evd, lg, Lg) * tfn +
+                                              (2.f / (float)(first ? B1 : B2)) * acc);
+                }
+                const float dbase = dfv * jacn;
+                if (w == 0 && hi == 0) {
+                    dbl += dbase;
+                    dscl = fmaf(dfv, dscn, dscl);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s0[r] = nsvd_sigmoid_from_softplus(a0n[r]);
+                    dz[r] = wlv[r] * dbase * nsvd_sigmoid_from_softplus(zn[r]);
+                    dwl[r] = fmaf(dbase, zn[r], dwl[r]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(&DZ[li * H_LD + 32 * w + 8 * g + 4 * hi]) =
+                        make_float4(dz[4 * g], dz[4 * g + 1], dz[4 * g + 2], dz[4 * g + 3]);
+                float* D1 = DT1 + (c & 1) * SB_TILE;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D1[(32 * w + acc_row(r, hi)) * A_LD + li] = dz[r];
+            }
+            SB_BARRIER();  // X2
+            // ---- segment 3: the next chunk's operands requested; chain step; dz_0
+            if (act) {
+                if (c + 1 < nch) request(c + 1);
+                f32x16 acc1[1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+                const float* Bq = DZ + li * H_LD + 4 * hi;
+                Frag<1> g0, g1;
+                g0.b[0] = *reinterpret_cast<const float4*>(Bq);
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    g1.b[0] = *reinterpret_cast<const float4*>(Bq + 8 * (q + 1));
+                    g0.a = make_float4(WF[4 * q], WF[4 * q + 1], WF[4 * q + 2], WF[4 * q + 3]);
+                    mma_frag<1>(acc1, g0);
+                    if (q + 2 < 16) g0.b[0] = *reinterpret_cast<const float4*>(Bq + 8 * (q + 2));
+                    g1.a = make_float4(WF[4 * q + 4], WF[4 * q + 5], WF[4 * q + 6], WF[4 * q + 7]);
+                    mma_frag<1>(acc1, g1);
+                }
+                float* D0 = DT0 + (c & 1) * SB_TILE;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D0[(32 * w + acc_row(r, hi)) * A_LD + li] = acc1[0][r] * s0[r];
+            }
+            SB_BARRIER();  // X3
+        }
+        // ---- row sums over the samples, in a fixed order
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) dwl[r] += __shfl_xor(dwl[r], off, 64);
+        }
+        if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[a.poW[2] + (size_t)l * HID + 32 * w + acc_row(r, hi)] = dwl[r];
+        }
+        if (w == 0) {
+            dbl = nsvd_wave_sum(dbl);
+            dscl = nsvd_wave_sum(dscl);
+            if (lane == 0) {
+                P[a.pob[2] + l] = dbl;
+                if (a.dsc) P[a.poscales + l] = dscl;
+            }
+        }
+    } else {
+        // =============================================================================================== group B
+        f32x16 aW1[4], aW0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aW1[j][r] = aW0[j][r] = 0.f;
+        const int s_row = tid >> 3, s_c4 = tid & 7;
+        const float* a0p = a.a0 + ((size_t)l * HID + s_row) * a.B + bbase + 4 * s_c4;
+        const float* php = a.phiTc + (size_t)s_row * a.B + bbase + 4 * s_c4;
+        const size_t slab = (size_t)32 * a.B;
+        float4 pa[4], pp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pa[k] = pp[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // db_1 / db_0: row sums of dz_1 / dz_0 over the samples - this lane's A fragments are row 32 w + li, four samples each
+        float rs1 = 0.f, rs0 = 0.f;
+#define SB2_RS(acc_, f_) acc_ += ((f_).a.x + (f_).a.y) + ((f_).a.z + (f_).a.w)
+        SB_BARRIER();  // X0
+        for (int c = 0; c <= nch; ++c) {
+            const bool act = c >= 1;  // this iteration multiplies chunk c - 1
+            // ---- segment 1: the tiles of chunk c - 1 (requested an iteration ago) go to LDS - every wave of the group
+            // has finished reading the previous ones (barrier X3)
+            if (act) {
+                float* A_ = A0s + s_row * A_LD + 4 * s_c4;
+                float* P_ = PHs + s_row * A_LD + 4 * s_c4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    *reinterpret_cast<float4*>(A_ + k * 32 * A_LD) = pa[k];
+                    *reinterpret_cast<float4*>(P_ + k * 32 * A_LD) = pp[k];
+                }
+            }
+            SB_BARRIER();  // X1
+            const float* D1 = DT1 + ((c + 1) & 1) * SB_TILE + (32 * w + li) * A_LD + 4 * hi;
+            const float* D0 = DT0 + ((c + 1) & 1) * SB_TILE + (32 * w + li) * A_LD + 4 * hi;
+            const float* Ba = A0s + li * A_LD + 4 * hi;
+            const float* Bp = PHs + li * A_LD + 4 * hi;
+            Frag<4> f0, f1;
+            // ---- segment 2: the first half of dW_1
+            if (act) {
+                load_frag<4>(f0, D1, Ba, A_LD);
+                load_frag<4>(f1, D1 + 8, Ba + 8, A_LD);
+                mma_frag<4>(aW1, f0);
+                SB2_RS(rs1, f0);
+                mma_frag<4>(aW1, f1);
+                SB2_RS(rs1, f1);
+            }
+            SB_BARRIER();  // X2
+            // ---- segment 3: the tiles of chunk c requested; the rest of dW_1, dW_0
+            if (c < nch) {
+                const int o = c * BS;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pa[k] = *reinterpret_cast<const float4*>(a0p + k * slab + o);
+                    pp[k] = *reinterpret_cast<const float4*>(php + k * slab + o);
+                }
+            }
+            if (act) {
+                load_frag<4>(f0, D1 + 16, Ba + 16, A_LD);
+                load_frag<4>(f1, D1 + 24, Ba + 24, A_LD);
+                mma_frag<4>(aW1, f0);
+                SB2_RS(rs1, f0);
+                load_frag<4>(f0, D0, Bp, A_LD);
+                mma_frag<4>(aW1, f1);
+                SB2_RS(rs1, f1);
+                load_frag<4>(f1, D0 + 8, Bp + 8, A_LD);
+                mma_frag<4>(aW0, f0);
+                SB2_RS(rs0, f0);
+                load_frag<4>(f0, D0 + 16, Bp + 16, A_LD);
+                mma_frag<4>(aW0, f1);
+                SB2_RS(rs0, f1);
+                load_frag<4>(f1, D0 + 24, Bp + 24, A_LD);
+                mma_frag<4>(aW0, f0);
+                SB2_RS(rs0, f0);
+                mma_frag<4>(aW0, f1);
+                SB2_RS(rs0, f1);
+            }
+            SB_BARRIER();  // X3
+        }
+#undef SB2_RS
+        float* g1 = P + a.poW[1] + ((size_t)l * HID + 32 * w) * HID + li;
+        float* g0 = P + a.poW[0] + ((size_t)l * HID + 32 * w) * HID + li;  // (F = 128)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g1[(size_t)acc_row(r, hi) * HID + 32 * j] = aW1[j][r];
+                g0[(size_t)acc_row(r, hi) * HID + 32 * j] = aW0[j][r];
+            }
+        rs1 += __shfl_xor(rs1, 32, 64);  // the two lane halves hold the two halves of every q-group's samples
+        rs0 += __shfl_xor(rs0, 32, 64);
+        if (hi == 0) {
+            P[a.pob[1] + (size_t)l * HID + 32 * w + li] = rs1;
+            P[a.pob[0] + (size_t)l * HID + 32 * w + li] = rs0;
+        }
+    }
+#undef SB_BARRIER
+}
