@@ -1117,9 +1117,6 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
                 if (er != hipSuccess) return -(int)er;
                 attr2_set = true;
             }
-            if (!df) {  // the loss scalars from the moments (block 0 of the one-group kernel does this itself)
-                hipLaunchKernelGGL(stream_evd_finish_kernel, dim3(1), dim3(256), 0, s, sa.evd, B);
-            }
             hipLaunchKernelGGL(pmlp_stream_bwd2_kernel, dim3(d.L * SS), dim3(512), SB2_LDS_BYTES, s, sa);
         }
     } else if ((nh == 2 || nh == 3) && chain_only <= 128)

@@ -345,12 +345,6 @@ __global__ void __launch_bounds__(256, 1) pmlp_stream_bwd_kernel(StreamArgs a) {
 constexpr int SB2_LDS_FLOATS = 6 * SB_TILE + SB_DZ + SB_MISC;  // a_0, phi^T tiles | DT1 x 2, DT0 x 2 | DZ | misc: 130 KB
 constexpr size_t SB2_LDS_BYTES = (size_t)SB2_LDS_FLOATS * sizeof(float);
 
-// the loss scalars of a step whose moments / partial moments are given (what block 0 of the kernels above does)
-__global__ void __launch_bounds__(256) stream_evd_finish_kernel(NsvdEvdIn evd, int B) {
-    __shared__ float red[8];
-    nsvd_evd_finish(evd, B, evd.Lg, red);
-}
-
 __global__ void __launch_bounds__(512, 1) pmlp_stream_bwd2_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sb_smem[];
     float* A0s = sb_smem;                 // [128 k][36]   a_0 tile of chunk c - 1 (group B)
@@ -405,6 +399,9 @@ __global__ void __launch_bounds__(512, 1) pmlp_stream_bwd2_kernel(StreamArgs a) 
                 const int h = t / Lg, lp = t - h * Lg;
                 col[t] = nsvd_evd_mask_M(a.evd, lp, lg, Lg) * nsvd_evd_lam(a.evd, h, lp * Lg + lg, a.B, Lg);
             }
+            // block 0: the loss scalars of the step (this group's 256 threads are the routine's; its one workgroup
+            // barrier is matched by group B below)
+            if (blockIdx.x == 0) nsvd_evd_finish(a.evd, a.B, Lg, dfp);
         }
         float dwl[16];  // (db_1 / db_0 are row sums of what group B reads anyway: taken there)
 #pragma unroll
@@ -547,6 +544,7 @@ __global__ void __launch_bounds__(512, 1) pmlp_stream_bwd2_kernel(StreamArgs a) 
         // db_1 / db_0: row sums of dz_1 / dz_0 over the samples - this lane's A fragments are row 32 w + li, four samples each
         float rs1 = 0.f, rs0 = 0.f;
 #define SB2_RS(acc_, f_) acc_ += ((f_).a.x + (f_).a.y) + ((f_).a.z + (f_).a.w)
+        if (blockIdx.x == 0 && !a.df) SB_BARRIER();  // (the barrier inside group A's nsvd_evd_finish)
         SB_BARRIER();  // X0
         for (int c = 0; c <= nch; ++c) {
             const bool act = c >= 1;  // this iteration multiplies chunk c - 1
