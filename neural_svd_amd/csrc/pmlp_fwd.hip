@@ -64,6 +64,8 @@ struct FwdArgs {
     // the KS = 2 launch (the split form's own grid) adds the slices in order and runs the rest of the network
     int ks;
     float* kpart;
+    int kplain;  // KS = 2, E = 3 only: the partials were left by PLAIN-form workgroups (five tiles per (head, sample block):
+                 // centre, even_0, odd_0, even_1, odd_1) - direction g's workgroup adds tiles 0, 1 + 2 g, 2 + 2 g
     unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
 
@@ -159,6 +161,8 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         const size_t unit = ((size_t)grp * a.L + l) * nsb + sb;
         // [slice][workgroup][tile][wave][lane][16 registers]: a lane's accumulator tile is 64 contiguous bytes
         kp = a.kpart + ((((size_t)kslice * (a.split > 0 ? a.split : 1) * a.L * nsb + unit) * E * 4 + w) * 64 + lane) * 16;
+        if (KS == 2 && E == 3 && a.kplain)
+            kp = a.kpart + ((((size_t)l * nsb + sb) * 5 * 4 + w) * 64 + lane) * 16;
         if (KS == 1 && kslice > 0) {  // (the bias joins slice 0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
@@ -170,15 +174,18 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
         __syncthreads();  // the W-tile DMA below lands in the tail of the stage buffers
     } else if constexpr (KS == 2) {
         // K-split, second launch: the slices' partial pre-activations, added in slice order
-        const size_t sstride = (size_t)(a.split > 0 ? a.split : 1) * a.L * nsb * E * 4 * 16 * 64;
+        const bool kpl = E == 3 && a.kplain;
+        const size_t sstride = kpl ? (size_t)a.L * nsb * 5 * 4 * 16 * 64
+                                   : (size_t)(a.split > 0 ? a.split : 1) * a.L * nsb * E * 4 * 16 * 64;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
+            const int et = (kpl && e > 0) ? 2 * grp + e : e;  // tile index inside the producer's block
             float4 v[4][4];  // [slice][quarter]: every load of a tile requested before the first is used
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    v[k][g] = k < a.ks ? *reinterpret_cast<const float4*>(kp + (size_t)k * sstride + (size_t)e * 4 * 64 * 16 + 4 * g)
+                    v[k][g] = k < a.ks ? *reinterpret_cast<const float4*>(kp + (size_t)k * sstride + (size_t)et * 4 * 64 * 16 + 4 * g)
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -961,7 +968,15 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         a.kpart = w.kpart;
         rc = launch_fwd<5, 0, 0, 0, 1>(a, s, 1);  // (the in-run bracket of bench.py spans both launches)
         if (rc) return rc;
-        return launch_fwd<5, 0, 0, 0, 2>(a, s, 2);
+        // the rest of the network in SPLIT form - 2 x 64 workgroups of three tiles read the plain-form partials - then
+        // the finite-difference epilogue kernel: 128 CUs busy for the latency-bound hidden layers instead of 64
+        a.split = d.D;
+        a.base_raw = w.base_raw;
+        a.kplain = 1;
+        rc = launch_fwd<3, 0, 0, 0, 2>(a, s, 2);
+        if (rc) return rc;
+        return nsvd_fd_epilogue(w.base_raw, R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
+                                save ? w.jac : nullptr, (save && d.has_exp_mask) ? w.dsc : nullptr, s, 1);
     }
     // split-stencil form: D = 3 (7 stencil columns do not fit one workgroup's LDS image), and D = 2 when the plain grid
     // would leave at least half of the CUs without a workgroup (cfg1: 64 -> 128 workgroups of three column tiles)
