@@ -7,8 +7,8 @@
 // Form used: scatter the batch into the index space, S^T[l][j] = sum_{k: cols_k = j} f[k][l], then
 //     Kf = K[rows, :] S    -  a (B1 x N) . (N x L) contraction with GATHERED rows of K, both operands K-contiguous,
 // on the fp32-input MFMA through the shared tile routine (tile_nt.h), split over N so that the grid fills the chip,
-// partial tiles reduced in slice order (bit-reproducible when cols has no duplicates; duplicates are summed with
-// float atomics in the scatter).
+// partial tiles reduced in slice order; the scatter adds duplicates in batch order (ka_scatter_blocks_kernel: no
+// atomics), so the result is bit-reproducible whatever the indices.
 #include <string.h>
 #include "nsvd_kernels.h"
 #include "tile_nt.h"
@@ -70,6 +70,94 @@ __global__ void __launch_bounds__(256) ka_scatter_kernel(const float* __restrict
     const long long j = cols[k];
     if (j < 0 || j >= N) return;  // out-of-range indices contribute nothing
     atomicAdd(ST + (size_t)l * Np + j, f[i]);
+}
+
+// The same scatter WITHOUT atomics and without the zeroing pass: one workgroup owns 32 consecutive points and a block of
+// 64 heads, scans the batch's column indices for hits (8 consecutive k per thread, hits listed in k order through a
+// prefix sum over the workgroup) and adds the hit rows of f in that order: S^T is bit-reproducible whatever the
+// duplicates, every element is written exactly once (zeros included), and 0.5 M float atomics (28 us at configs[3])
+// become a 64 KB scan per workgroup.
+constexpr int KS_PB = 32;      // points per workgroup
+constexpr int KS_RK = 8192;    // batch entries per round (the hit list can hold them all)
+constexpr int KS_PT = KS_RK / 256;  // consecutive entries per thread
+__global__ void __launch_bounds__(256) ka_scatter_blocks_kernel(const float* __restrict__ f, const long long* __restrict__ cols,
+                                                                int B2, int L, int N, float* __restrict__ ST, int Np) {
+    __shared__ int hit_k[KS_RK];
+    __shared__ unsigned char hit_j[KS_RK];
+    __shared__ int wsum[4], total;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int j0 = blockIdx.x * KS_PB, l0 = blockIdx.y * 64;
+    const int jj = t & 31, lq = t >> 5;  // this thread accumulates point j0 + jj, heads l0 + 8 lq .. + 7
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < B2; k0 += KS_RK) {
+        // hits of this round, in k order (bit i of `mask`: entry k0 + KS_PT t + i hits point j0 + pj[i])
+        unsigned mask = 0;
+        unsigned char pj[KS_PT];
+#pragma unroll
+        for (int i = 0; i < KS_PT; ++i) {
+            const int k = k0 + KS_PT * t + i;
+            const long long c = k < B2 ? cols[k] : -1;
+            const bool hit = c >= j0 && c < j0 + KS_PB && c < N;
+            pj[i] = hit ? (unsigned char)(c - j0) : 0;
+            mask |= hit ? (1u << i) : 0u;
+        }
+        const int cnt = __builtin_popcount(mask);
+        int incl = cnt;  // inclusive prefix over the wave, then over the four waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int base = incl - cnt;
+        for (int q = 0; q < wv; ++q) base += wsum[q];
+        if (t == 255) total = base + cnt;
+#pragma unroll
+        for (int i = 0; i < KS_PT; ++i)
+            if (mask & (1u << i)) {
+                hit_k[base] = k0 + KS_PT * t + i;
+                hit_j[base] = pj[i];
+                ++base;
+            }
+        __syncthreads();
+        // this thread's point: its hits are collected first (up to four at a time), their rows of f requested together -
+        // one memory latency per pass instead of one per hit - and added in k order
+        const int nh = total;
+        int e = 0;
+        while (e < nh) {
+            int ks[4], n = 0;
+            for (; e < nh && n < 4; ++e)
+                if (hit_j[e] == jj) ks[n++] = hit_k[e];
+            float4 v[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i][0] = v[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n) {
+                    const float* fr = f + (size_t)ks[i] * L + l0 + 8 * lq;
+                    if (l0 + 8 * lq + 8 <= L && (L & 3) == 0) {
+                        v[i][0] = *reinterpret_cast<const float4*>(fr);
+                        v[i][1] = *reinterpret_cast<const float4*>(fr + 4);
+                    } else {
+                        float tmp[8];
+                        for (int q = 0; q < 8; ++q) tmp[q] = l0 + 8 * lq + q < L ? fr[q] : 0.f;
+                        v[i][0] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                        v[i][1] = make_float4(tmp[4], tmp[5], tmp[6], tmp[7]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0] += v[i][0].x; acc[1] += v[i][0].y; acc[2] += v[i][0].z; acc[3] += v[i][0].w;
+                acc[4] += v[i][1].x; acc[5] += v[i][1].y; acc[6] += v[i][1].z; acc[7] += v[i][1].w;
+            }
+        }
+        __syncthreads();  // the list is rewritten in the next round
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ST[(size_t)(l0 + 8 * lq + i) * Np + j0 + jj] = acc[i];
 }
 
 // tile (tb, tl) x slice: rows of K gathered by `rows`, contraction range [c0, c1) chunks of the point index
@@ -183,11 +271,16 @@ extern "C" int nsvd_kernel_apply(const float* K, size_t ldk, int N, const long l
     if (ldk < (size_t)w.Np || (ldk & 3) != 0 || ((uintptr_t)K & 15) != 0) return NSVD_EINVAL;
     if (ws_bytes < w.bytes || ((uintptr_t)ws & 255) != 0) return NSVD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const size_t n4 = (size_t)w.Lp * w.Np / 4;
-    ka_zero_kernel<<<(unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256), 256, 0, s>>>((float4*)w.ST, n4);
-    NSVD_CHECK_LAUNCH();
-    ka_scatter_kernel<<<nsvd_cdiv(B2 * L, 256), 256, 0, s>>>(f, cols, B2, L, N, w.ST, w.Np);
-    NSVD_CHECK_LAUNCH();
+    if (w.Np % KS_PB == 0 && w.Lp % 64 == 0) {  // (always: Np is a multiple of 64, Lp of 64)
+        ka_scatter_blocks_kernel<<<dim3(w.Np / KS_PB, w.Lp / 64), 256, 0, s>>>(f, cols, B2, L, N, w.ST, w.Np);
+        NSVD_CHECK_LAUNCH();
+    } else {
+        const size_t n4 = (size_t)w.Lp * w.Np / 4;
+        ka_zero_kernel<<<(unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256), 256, 0, s>>>((float4*)w.ST, n4);
+        NSVD_CHECK_LAUNCH();
+        ka_scatter_kernel<<<nsvd_cdiv(B2 * L, 256), 256, 0, s>>>(f, cols, B2, L, N, w.ST, w.Np);
+        NSVD_CHECK_LAUNCH();
+    }
     nsvd_prof_begin(s);  // bench.py --config cfg4 brackets the contraction (nsvd_profile_next_forward)
     if (w.dma && (size_t)N * ldk * sizeof(float) < ((size_t)1 << 32)) {  // (32-bit row offsets)
         static bool attr_set = false;
