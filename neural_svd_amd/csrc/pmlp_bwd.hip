@@ -983,7 +983,24 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
             gsum.x += v.x; gsum.y += v.y; gsum.z += v.z; gsum.w += v.w;
         }
         const int cnt = a.n[t] - e < 4 ? (int)(a.n[t] - e) : 4;
-        const float gv[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+        float gv[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+        if (cnt == 4 && !a.g[t] && a.opt) {
+            // the common case as 16-byte accesses (one group of four per thread: 4-byte accesses 16 bytes apart use a
+            // quarter of every line per instruction)
+            const NsvdOptPtrs& o = a.o[t];
+            if ((((uintptr_t)(o.p + e) | (uintptr_t)(o.sq + e) | (uintptr_t)(o.ema ? o.ema + e : o.p + e)) & 15) == 0) {
+                float4 pv = *reinterpret_cast<const float4*>(o.p + e), sv = *reinterpret_cast<const float4*>(o.sq + e);
+                float4 ev = o.ema ? *reinterpret_cast<const float4*>(o.ema + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                nsvd_rmsprop_upd(pv.x, gv[0], sv.x, ev.x, o.ema != nullptr, h);
+                nsvd_rmsprop_upd(pv.y, gv[1], sv.y, ev.y, o.ema != nullptr, h);
+                nsvd_rmsprop_upd(pv.z, gv[2], sv.z, ev.z, o.ema != nullptr, h);
+                nsvd_rmsprop_upd(pv.w, gv[3], sv.w, ev.w, o.ema != nullptr, h);
+                *reinterpret_cast<float4*>(o.p + e) = pv;
+                *reinterpret_cast<float4*>(o.sq + e) = sv;
+                if (o.ema) *reinterpret_cast<float4*>(o.ema + e) = ev;
+                continue;
+            }
+        }
         for (int c = 0; c < cnt; ++c) {
             if (a.g[t]) a.g[t][e + c] = gv[c];
             if (a.opt) {
