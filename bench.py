@@ -537,7 +537,7 @@ def bench_widened(args, as_dict=False):
         # the bracketed launch (nsvd_profile_next_forward): the first contraction Y1 = X W1^T + b1 - float32: one tower's
         # (tower_gemm_nt_kernel, fp32 MFMA); mixed precision: BOTH towers' in one launch (gemm16_kernel, bf16 MFMA)
         kflops = 2.0 * B * d0 * (d1 // world) * (2 if (args.amp and comm is None) else 1)
-        kname = "nsvd_g16::gemm16_kernel<false, false, true>" if args.amp else "tower_gemm_nt_kernel"
+        kname = "nsvd_g16::gemm16b_kernel<false, false, true>" if args.amp else "tower_gemm_nt_kernel"
         # algorithmic bytes of that launch: X and W1 read once, Y1 written once (bfloat16 / float32)
         kbytes = ((B * d0 + d0 * (d1 // world)) * (2 if args.amp else 4) + B * (d1 // world) * (2 if args.amp else 4)) * \
             (2 if (args.amp and comm is None) else 1)

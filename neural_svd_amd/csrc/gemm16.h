@@ -341,6 +341,10 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
     }
 }
 
+// the two-workgroups-per-CU form of the kernel (gemm16b.h, included at the end of this header)
+template <bool AS_, bool BS_, bool O_>
+inline int launch_b_inst(const Args& a, hipStream_t s);
+
 // host side: validate and launch. out_bf16: C holds bfloat16. Returns 0 or NSVD_E*.
 inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16, hipStream_t s) {
     Args a = a0;
@@ -367,8 +371,15 @@ inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16,
         a.dbg = e ? atoi(e) : 0;
     }
     const dim3 grid((unsigned)nwg);
+    static const char* form_env = getenv("NSVD_G16_FORM");  // "a": the one-workgroup-per-CU kernel above (A/B measurements)
+    // two workgroups per CU (gemm16b.h) where the launch has at least two per CU to give; one per CU otherwise (this kernel:
+    // deeper K steps, fragments double-buffered - better alone on its CU)
+    const bool form_b = !(form_env && form_env[0] == 'a') && !a.stamps && nwg >= 512;
 #define G16_LAUNCH(AS_, BS_, O_)                                                                                   \
-    {                                                                                                              \
+    if (form_b) {                                                                                                  \
+        const int rcb = launch_b_inst<AS_, BS_, O_>(a, s);                                                         \
+        if (rcb) return rcb;                                                                                       \
+    } else {                                                                                                       \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
             hipError_t e = hipFuncSetAttribute((const void*)gemm16_kernel<AS_, BS_, O_>,                           \
@@ -393,3 +404,5 @@ inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16,
 }
 
 }  // namespace nsvd_g16
+
+#include "gemm16b.h"
