@@ -1,4 +1,4 @@
-"""GPU parity of nsvd_gemm_bf16 (csrc/gemm16.h) - the bf16-MFMA contraction of the mixed-precision CDK towers - against
+"""GPU parity of nsvd_gemm_bf16 (csrc/gemm16.h, gemm16b.h) - the bf16-MFMA contraction of the mixed-precision CDK towers - against
 float64 products of the SAME bfloat16 operand values (oracle arithmetic: numpy / torch float64 on the CPU), in every
 operand form the towers use, at the towers' five shapes (BASELINE configs[4]: B = 1024, 512 -> 8192 -> 512)."""
 import numpy as np
@@ -53,6 +53,13 @@ def _check(M, N, K, a_s, b_s, out16, slices=1, bias=False, seed=0, rows=64):
     (512, 8192, 1024, True, True, False, 1, False),    # dW2 = dY2^T A1
     (1024, 8192, 512, False, True, True, 1, False),    # dA1 = dY2 W2
     (8192, 512, 1024, True, True, False, 1, False),    # dW1 = dY1^T X
+    # 512 tiles and more: the two-workgroups-per-CU form of the kernel (gemm16b.h: K steps of 32, three-stage ring)
+    (2048, 8192, 64, False, False, True, 1, True),     # two K steps of 32
+    (2048, 8192, 320, False, False, True, 1, True),    # ten: the ring wraps
+    (2048, 8192, 320, False, True, True, 1, False),
+    (2048, 8192, 320, True, True, False, 1, False),    # float32 tile out in two passes
+    (2048, 8192, 192, False, False, False, 1, False),
+    (2048, 4096, 384, True, True, True, 2, False),     # split-K slices in this form
 ])
 def test_gemm_bf16_forms(M, N, K, a_s, b_s, out16, slices, bias):
     _check(M, N, K, a_s, b_s, out16, slices, bias)
