@@ -162,6 +162,18 @@ def test_bench_as_a_rank_under_torch_distributed_run():
     assert d["rccl_ranks"] == 2 and "launcher_retry" not in d
 
 
+def test_claimed_stdout_carries_only_the_emitted_line():
+    """bench._claim_stdout / _emit on the CPU: after the claim, whatever anything writes to file descriptor 1 - C stdio
+    of a native library included - lands on stderr; the emitted JSON line is the whole of stdout."""
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; "
+            "bench._claim_stdout(); os.write(1, b'banner of a native library\\n'); print('python chatter'); "
+            "bench._emit({'metric': 'x', 'value': 1})") % os.path.dirname(BENCH)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == json.dumps({"metric": "x", "value": 1}) + "\n", r.stdout
+    assert "banner of a native library" in r.stderr and "python chatter" in r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_stdout_carries_the_json_line_only_with_rccl_loaded():
