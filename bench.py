@@ -32,6 +32,8 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
 PEAK_HBM_GBS = 8000.0
+_KILL_GRACE_S = 10.0  # _launch_ranks: what the other ranks get to exit by themselves after the first one failed
+DEGRADED_RC = 3  # exit code of a run that printed a line marked `degraded` (run_main, self_launch)
 _PROVISIONAL = {}  # rank 0, N > 1: the line to print if the run dies after its first measured split (main())
 
 CFG = dict(L=16, D=2, m=1024, hidden=(128, 128, 128), B=512, sequential=False, eps=0.01, op_scale=100.0, op_shift=0.0,
@@ -347,12 +349,20 @@ def _launch_ranks(n, argv, timeout, extra_env=None):
         if pending and err is None:
             time.sleep(0.2)
     if err is not None:
+        # a short grace for the surviving ranks: the rank that holds the provisional line prints it as it dies
+        # (run_main), usually within a moment of the first casualty
+        grace = time.time() + _KILL_GRACE_S
+        while time.time() < grace and any(q.poll() is None for q in procs):
+            time.sleep(0.1)
         for q in procs:  # exactly the processes started above
             if q.poll() is None:
                 q.kill()
         for q in procs:
             q.wait()
-        return rc, "", err
+        # rank 0's drained stdout is kept: a rank that died after its first measured split has printed a line marked
+        # `degraded` (run_main) which self_launch relays once its ladder is exhausted
+        reader.join(timeout=30)
+        return rc, "".join(chunks), err
     reader.join(timeout=30)
     out = "".join(chunks)
     if not [ln for ln in out.splitlines() if ln.startswith("{")]:
@@ -398,7 +408,7 @@ def self_launch(args, argv):
             hp_gloo = ["--parallelism", "hp", "--sync", "--no-extras"]
             ladder.append((" ".join(hp_gloo) + "  [NSVD_DIST_BACKEND=gloo]", hp_gloo, {"NSVD_DIST_BACKEND": "gloo"}))
     shares = {1: [1.0], 2: [0.6, 0.4], 3: [0.5, 0.25, 0.25]}[len(ladder)]
-    failures = []
+    failures, degraded = [], None
     for (label, extra, env), share in zip(ladder, shares):
         if failures:
             sys.stderr.write(f"bench.py: {failures[-1]['failed_with']}; starting the ranks again: {label}\n")
@@ -412,7 +422,19 @@ def self_launch(args, argv):
             print(line)
             return
         failures.append({"attempt": label, "failed_with": err})
-    sys.stderr.write(f"bench.py: {failures[-1]['failed_with']}\n" + (out[-2000:] if out else ""))
+        if degraded is None:
+            for ln in out.splitlines():
+                if ln.startswith("{") and '"degraded"' in ln:
+                    degraded = (label, ln)
+    sys.stderr.write(f"bench.py: {failures[-1]['failed_with']}\n" + (out[-2000:] if out and degraded is None else ""))
+    if degraded is not None:
+        # every attempt failed, but one got as far as a measured split before it died: that line (it says `degraded`)
+        # beats no line - and the exit code still says the run failed
+        d = json.loads(degraded[1])
+        d["launcher_retry"] = {"failed_attempts": failures, "this_line": degraded[0] + "  [degraded: died after this split]"}
+        print(json.dumps(d))
+        sys.stdout.flush()
+        raise SystemExit(DEGRADED_RC)
     raise SystemExit(rc or 1)
 
 
@@ -1296,10 +1318,12 @@ def launcher_worst_case_seconds(launch_timeout, n_attempts=3):
     (self_launch: 1 / 0.6 + 0.4 / 0.5 + 0.25 + 0.25 of it), each attempt is killed at its share; + the poll interval
     and process start / teardown of every attempt"""
     shares = {1: [1.0], 2: [0.6, 0.4], 3: [0.5, 0.25, 0.25]}[n_attempts]
-    return sum(launch_timeout * sh for sh in shares) + n_attempts * (0.2 + 15.0)
+    return sum(launch_timeout * sh for sh in shares) + n_attempts * (0.2 + _KILL_GRACE_S + 15.0)
 
 
-if __name__ == "__main__":
+def run_main():
+    """main(); a multi-rank run that dies after its first measured split still prints that split's line, marked
+    `degraded`, and exits with DEGRADED_RC: the line is a measurement, the exit code says the run failed"""
     try:
         main()
     except Exception as e:  # noqa: BLE001
@@ -1308,5 +1332,9 @@ if __name__ == "__main__":
                                         f"north_star's literal split (samples sharded, one moments all-reduce + one "
                                         f"gradient all-reduce per step, blocking), measured before that")
             _emit(_PROVISIONAL)
-            os._exit(0)  # (no teardown of a process group whose collectives are failing)
+            os._exit(DEGRADED_RC)  # (no teardown of a process group whose collectives are failing)
         raise
+
+
+if __name__ == "__main__":
+    run_main()

@@ -564,7 +564,8 @@ int nsvd_cdk_step(const nsvd_cdk_step_desc* desc, const float* x, const float* y
  *   likewise B / b_kstrided with N columns of C. (A strided with B contiguous is not built.)
  * C (M, ldc): float32, or bfloat16 when out_bf16; bias (N) is added per column when not NULL. slices > 1: split-K,
  * slice s contracts k in [s K / slices, (s + 1) K / slices) into C + s * slice_stride (elements; bias goes to every
- * slice: pass NULL). sumsq: NULL, or (M / 256) (N / 128) slices floats - per tile, the sum of squares of what was stored.
+ * slice: pass NULL). sumsq: NULL, or (M / 256) (N / 128) slices floats - per tile, the sum of squares of the
+ * float32 values BEFORE any bfloat16 rounding of the store (the gradient norm is taken of the float32 gradient).
  * M % 256 == 0, N % 128 == 0, K % (64 slices) == 0, lda, ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned pointers. */
 int nsvd_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
                    long ldc, int a_kstrided, int b_kstrided, int out_bf16, int slices, long slice_stride, float* sumsq,

@@ -84,6 +84,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
                        int B, float* f, float* Tf, void* ws, int save, hipStream_t s, int bf3 = 0);
 // batch slices of the weight-gradient kernel (1: every tile contracts the whole batch)
 int nsvd_fused_wgrad_slices(const nsvd_model_desc& d, int B);
+int nsvd_fused_stream_bwd_slices(const nsvd_model_desc& d, int B);  // > 0: the streaming backward may take the step
 int nsvd_fused_backward(const nsvd_model_desc& d, const nsvd_params& p, const nsvd_problem& prob, const float* x,
                         int B, const float* df, const nsvd_params& g, void* ws, hipStream_t s);
 struct NsvdEvdIn;  // evd_math.h
@@ -186,7 +187,7 @@ int nsvd_cdk_loss_forward_parts(const float* f, const float* g, const float* bat
                                 const float* M, int B, int L, int set_first_mode_const, float* rs_joint,
                                 float* rs_indep, void* ws, size_t ws_bytes, NsvdCdkLossParts* parts, hipStream_t s);
 // loss[0..2] = {loss, operator term, metric term} from the partials, added in index order by one workgroup of 256
-// threads (red: 4 floats of LDS); every thread of the workgroup must call it
+// threads (red: 8 floats of LDS - red[0..7] are written); every thread of the workgroup must call it
 __device__ __forceinline__ void nsvd_cdk_loss_sum(const NsvdCdkLossParts& lp, float* red, float* __restrict__ loss) {
     float so = 0.f, sm = 0.f;
     for (int i = threadIdx.x; i < lp.nstage; i += 256) so += lp.part_op[i];

@@ -189,7 +189,9 @@ extern "C" int nsvd_step_emits_planes(const nsvd_model_desc* desc, int B, int pa
     if (validate(desc) != 0 || B <= 0 || path != NSVD_PATH_FUSED_BF16X3) return 0;
     const char* e = getenv("NSVD_PLANES_FROM_STEP");
     if (e && atoi(e) == 0) return 0;
-    return nsvd_fused_supported(*desc, B, false) && nsvd_fused_wgrad_slices(*desc, B) == 1 ? 1 : 0;
+    // (the streaming backward never runs the kernel that writes the planes)
+    return nsvd_fused_supported(*desc, B, false) && nsvd_fused_wgrad_slices(*desc, B) == 1 &&
+                   nsvd_fused_stream_bwd_slices(*desc, B) == 0 ? 1 : 0;
 }
 
 extern "C" const char* nsvd_path_name_for(const nsvd_model_desc* desc, const nsvd_problem* prob, int B, int path) {

@@ -1201,7 +1201,8 @@ static int fused_backward_impl(const nsvd_model_desc& dfull, const nsvd_params& 
     wa.bid0 = 0;
     // bf16x3 steps: the planes of the updated weights go where the NEXT forward reads them (the other workspace set
     // when the next batch's features ride along, this one otherwise); whole model, fused optimiser, no split-K only
-    const bool emit = opt && opt->emit_planes && wa.S == 1 && Lc == dfull.L && l0 == 0;
+    // (never with the streaming form: it skips the kernel that writes the planes)
+    const bool emit = opt && opt->emit_planes && !SS && wa.S == 1 && Lc == dfull.L && l0 == 0;
     if (emit) {
         const FusedWs wp = carve_fused(dfull, B, next ? next->ws : ws);
         wa.w0p = reinterpret_cast<unsigned short*>(wp.w0p);
@@ -1279,6 +1280,7 @@ int nsvd_fused_backward_evd(const nsvd_model_desc& d, const nsvd_params& p, int 
 }
 
 int nsvd_fused_wgrad_slices(const nsvd_model_desc& d, int B) { return wgrad_slices(d, B); }
+int nsvd_fused_stream_bwd_slices(const nsvd_model_desc& d, int B) { return stream_bwd_slices(d, B); }
 
 bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count) {
     if (l_count <= 0 || l_count > d.L) return false;

@@ -32,6 +32,36 @@ def test_launcher_propagates_a_failing_rank():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_degraded_run_keeps_its_line_and_exits_non_zero():
+    """every attempt of the launcher's ladder dies after its first measured split (tests/_bench_degraded_rank.py): the
+    rank that holds the provisional line prints it marked `degraded` and exits with bench.DEGRADED_RC; the launcher
+    tries its whole ladder, then relays that ONE line (of the first attempt, with the failed attempts listed) and
+    exits with the same non-zero code - a failed run never reports rc 0, and its measurement is not thrown away"""
+    wrapped = os.path.join(ROOT, "tests", "_bench_degraded_rank.py")
+    # as a rank under a launcher (torchrun's view): the line, then exit code 3
+    r = subprocess.run([sys.executable, wrapped, "--gpus", "2"], env=_env(RANK="0", WORLD_SIZE="2"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    d = json.loads(r.stdout.strip())
+    assert d["value"] == 123.0 and "died after its first measured split" in d["degraded"]
+    r = subprocess.run([sys.executable, wrapped, "--gpus", "2"], env=_env(RANK="1", WORLD_SIZE="2"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode not in (0, 3) and not r.stdout.strip()  # no provisional line on this rank: the plain traceback
+    # as the driver calls it: python bench.py --gpus 2
+    r = subprocess.run([sys.executable, wrapped, "--gpus", "2", "--steps", "3"],
+                       env=_env(NSVD_FORCE_DEVICE="0", NSVD_DIST_BACKEND="nccl"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] == 123.0 and "degraded" in d
+    lr = d["launcher_retry"]
+    assert len(lr["failed_attempts"]) == 3 and lr["this_line"].startswith("as given")
+    assert "--dp-exchange" not in d["argv"]  # the first attempt's line, not a retry's
+    assert all("exited with code" in a["failed_with"] for a in lr["failed_attempts"])
+
+
 def test_launcher_worst_case_wall_time_is_inside_the_drivers_window():
     """`python bench.py --gpus N` from the argument DEFAULTS: the launcher's ladder (auto-tuned run, then the plain
     all-reduce, then heads sharded over gloo) is bounded by --launch-timeout in total, whatever the tuner
