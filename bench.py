@@ -853,8 +853,8 @@ def main():
     path = {"auto": H.PATH_AUTO, "generic": H.PATH_GENERIC, "fused": H.PATH_FUSED,
             "bf16x3": H.PATH_FUSED_BF16X3}[args.path]
     repeats = args.repeats or max(3, min(25, round(6000 / max(args.steps, 1))))
-    if args.parallelism == "hp" and cfg["L"] % world != 0:
-        raise SystemExit(f"hp needs L ({cfg['L']}) divisible by the world size ({world})")
+    if args.parallelism == "hp" and cfg["L"] < world:
+        raise SystemExit(f"hp needs at least one head per rank: L = {cfg['L']} < world size {world}")
 
     # N > 1: which sharding, which exchange? Every candidate is timed with the same protocol (fewer blocks) and the
     # fastest takes the headline run - the first hardware contact of this code decides, not a guess. What an RCCL
@@ -952,7 +952,7 @@ def main():
             north_star = {"error": f"{type(e).__name__}: {e}"}
     if multi:
         pars = [args.parallelism] if args.parallelism != "auto" else \
-            (["dp", "hp"] if cfg["L"] % world == 0 else ["dp"])
+            (["dp", "hp"] if cfg["L"] >= world else ["dp"])  # (any L >= world: parallel.head_range)
         tuned = {p_: tune(p_) for p_ in pars}
         par = max(pars, key=lambda p_: tuned[p_][0] or 0.0) if len(pars) > 1 else pars[0]
         _, tr_kw, cand_report = tuned[par]
@@ -1114,7 +1114,7 @@ def main():
                 extras["opt_in_path_bf16x3"]["agreement_of_the_hip_paths"] = {"error": f"{type(e).__name__}: {e}"}
         else:
             other = "hp" if par == "dp" else "dp"
-            if other == "dp" or cfg["L"] % world == 0:
+            if other == "dp" or cfg["L"] >= world:
                 side(f"sharding_{other}", cfg, other, path,
                      "same workload and global batch, heads sharded instead of samples: one all-gather of f, Tf per "
                      "step, no gradient traffic (DESIGN.md 6)" if other == "hp" else
@@ -1126,7 +1126,7 @@ def main():
             if 4096 % world == 0 and (4096 // world) % 32 == 0:
                 c3s = dict(ALT["cfg3"], B=4096 // world)
                 side("_strong_dp", c3s, "dp", path, "samples sharded")
-                if c3s["L"] % world == 0:
+                if c3s["L"] >= world:
                     side("_strong_hp", c3s, "hp", path, "heads sharded")
                 block = {"workload": "configs[2]: 2D harmonic oscillator, L=32, sequential nesting, GLOBAL batch 4096 "
                                      f"({4096 // world} rows per GPU)", "global_batch": 4096, "n_gpus": world,
@@ -1151,7 +1151,7 @@ def main():
             side("cfg3_dp", c3, "dp", path,
                  "configs[2]: 2D harmonic oscillator, L=32, sequential nesting, 512 rows per GPU (global batch 4096 at "
                  "8 GPUs), samples sharded")
-            if c3["L"] % world == 0:
+            if c3["L"] >= world:
                 side("cfg3_hp", c3, "hp", path, "configs[2], heads sharded")
 
     if rank != 0:

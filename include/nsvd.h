@@ -231,6 +231,14 @@ int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, int mask_kin
 int nsvd_evd_gather_heads(const float* gathered, int world, int B, int L_local, int mask_kind, const float* v,
                           float* f, float* Tf, void* scratch, void* stream);
 
+/* The same for ANY head count L >= world (the reference scripts run --neigs 36 / 55, scripts/exps/pde/hydrogen.sh:28,
+ * oscillator.sh:27): rank w owns n_w = L / world + (w < L % world) consecutive heads starting at
+ * w (L / world) + min(w, L % world) - the first L % world ranks one head more. `gathered` holds `world` blocks of
+ * 2 B ceil(L / world) floats (all-gather blocks are equally long); block w begins with f (B, n_w) then Tf (B, n_w),
+ * packed, the rest of a short block is never read. With L % world == 0 this IS nsvd_evd_gather_heads. */
+int nsvd_evd_gather_head_blocks(const float* gathered, int world, int B, int L, int mask_kind, const float* v,
+                                float* f, float* Tf, void* scratch, void* stream);
+
 /* nsvd_evd_loss_grad + nsvd_operator_backward in ONE call: d loss / d f (methods/nestedlora.py:98-111) is
  * evaluated per sample inside the backward kernels and never stored. `moments` (2L^2+1 floats) is
  *   - an INPUT when moments_reduced != 0 (e.g. after the data-parallel all-reduce of nsvd_evd_moments), or

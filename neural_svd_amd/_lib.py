@@ -95,6 +95,7 @@ SIGNATURES = {
     "nsvd_evd_loss_grad": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P]),
     "nsvd_evd_partial": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "nsvd_evd_gather_heads": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "nsvd_evd_gather_head_blocks": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "nsvd_operator_backward_evd": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P, _P,
                                         _I, _P, _P, _P, _I, _P, _I, _I, _F, _P, C.POINTER(Params), _P, _Z, _I, _P]),
     "nsvd_operator_backward_evd_heads": (_I, [C.POINTER(ModelDesc), C.POINTER(Params), C.POINTER(Problem), _P, _I, _P,

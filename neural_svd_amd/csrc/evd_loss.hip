@@ -112,16 +112,19 @@ __global__ void __launch_bounds__(256) evd_partial_kernel(const float* __restric
     if (threadIdx.x == 0) part_op[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// Head-sharded runs: the ranks' packed [f | Tf] blocks as the all-gather leaves them, gath (W, 2, B, Ll), -> the
-// (B, W Ll) arrays every consumer reads, and (part != null) the per-chunk partial moments of evd_partial_kernel in the
-// same pass - the same loop, the same accumulation order: bit-identical to a permuting copy followed by that kernel.
-__global__ void __launch_bounds__(256) evd_gather_heads_kernel(const float* __restrict__ gath, int W, int B, int Ll,
-                                                               int kind, const float* __restrict__ v,
+// Head-sharded runs: the ranks' packed [f | Tf] blocks as the all-gather leaves them -> the (B, L) arrays every
+// consumer reads, and (part != null) the per-chunk partial moments of evd_partial_kernel in the same pass - the same
+// loop, the same accumulation order: bit-identical to a permuting copy followed by that kernel.
+// Rank w owns n_w = L / W + (w < L % W) consecutive heads (the first L % W ranks one more: include/nsvd.h); its block
+// starts at gath + w * 2 B Lb (Lb = ceil(L / W): all-gather blocks are equally long) and holds f (B, n_w) then
+// Tf (B, n_w), packed - with L % W == 0 that is the plain (W, 2, B, L / W) array.
+__global__ void __launch_bounds__(256) evd_gather_heads_kernel(const float* __restrict__ gath, int W, int B, int L,
+                                                               int Lb, int kind, const float* __restrict__ v,
                                                                float* __restrict__ f, float* __restrict__ Tf,
                                                                float* __restrict__ part, float* __restrict__ part_op) {
     extern __shared__ __attribute__((aligned(16))) float fs[];  // [CH][L]
     __shared__ float red[4];
-    const int L = W * Ll;
+    const int base = L / W, rem = L - base * W, big = rem * (base + 1);
     const Chunking c = chunking(B);
     int r0, r1;
     chunk_rows(c, blockIdx.x, r0, r1);
@@ -129,10 +132,15 @@ __global__ void __launch_bounds__(256) evd_gather_heads_kernel(const float* __re
     float op = 0.f;
     for (int i = threadIdx.x; i < nr * L; i += 256) {
         const int r = i / L, l = i - r * L;
-        const int w = l / Ll, ll = l - w * Ll;
-        const size_t src = ((size_t)(2 * w) * B + (size_t)(r0 + r)) * Ll + ll;
+        int w, ll, n;
+        if (l < big) {
+            n = base + 1; w = l / n; ll = l - w * n;
+        } else {
+            n = base; w = rem + (l - big) / n; ll = (l - big) - (w - rem) * n;
+        }
+        const size_t src = (size_t)w * 2 * B * Lb + (size_t)(r0 + r) * n + ll;
         const float fv = gath[src];
-        const float tv = gath[src + (size_t)B * Ll];
+        const float tv = gath[src + (size_t)B * n];
         f[(size_t)r0 * L + i] = fv;
         Tf[(size_t)r0 * L + i] = tv;
         if (part) {
@@ -414,8 +422,14 @@ extern "C" int nsvd_evd_partial(const float* f, const float* Tf, int B, int L, i
 
 extern "C" int nsvd_evd_gather_heads(const float* gathered, int world, int B, int L_local, int mask_kind,
                                      const float* v, float* f, float* Tf, void* scratch, void* stream) {
-    if (!gathered || !f || !Tf || world <= 0 || B <= 0 || L_local <= 0) return NSVD_EINVAL;
-    const int L = world * L_local;
+    if (world <= 0 || L_local <= 0) return NSVD_EINVAL;
+    return nsvd_evd_gather_head_blocks(gathered, world, B, world * L_local, mask_kind, v, f, Tf, scratch, stream);
+}
+
+extern "C" int nsvd_evd_gather_head_blocks(const float* gathered, int world, int B, int L, int mask_kind,
+                                           const float* v, float* f, float* Tf, void* scratch, void* stream) {
+    if (!gathered || !f || !Tf || world <= 0 || B <= 0 || L < world) return NSVD_EINVAL;
+    const int L_block = (L + world - 1) / world;
     if (L > MAXL) return NSVD_EUNSUPPORTED;
     if (scratch && mask_kind == NSVD_MASK_CUSTOM && !v) return NSVD_EINVAL;
     if (mask_kind < 0 || mask_kind > NSVD_MASK_JOINT) return NSVD_EINVAL;
@@ -424,7 +438,7 @@ extern "C" int nsvd_evd_gather_heads(const float* gathered, int world, int B, in
     float* part = (float*)scratch;
     float* part_op = part ? part + (size_t)nch * L * L : nullptr;
     hipLaunchKernelGGL(evd_gather_heads_kernel, dim3(nch), dim3(256), (size_t)CH * L * sizeof(float),
-                       (hipStream_t)stream, gathered, world, B, L_local, mask_kind, v, f, Tf, part, part_op);
+                       (hipStream_t)stream, gathered, world, B, L, L_block, mask_kind, v, f, Tf, part, part_op);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

@@ -159,9 +159,10 @@ def _fused_loop_trainer(args, method, operator, importance_train, device, comm=N
     # the trainer's constructor draws (and here discards) initial weights: keep the caller's random streams untouched
     par = "dp"
     if comm is not None:
-        # several ranks: heads sharded when they divide (no gradient traffic, one all-gather of f, Tf per step:
-        # parallel.py), samples sharded otherwise; args.parallelism overrides
-        par = getattr(args, "parallelism", None) or ("hp" if model.shape.L % comm.world == 0 else "dp")
+        # several ranks: heads sharded (no gradient traffic, one all-gather of f, Tf per step: parallel.py) for any
+        # head count with at least one head per rank - the scripts' --neigs 36 / 55 on 8 GPUs give ranks of 5 / 4 and
+        # 7 / 6 heads (parallel.head_range) -, samples sharded otherwise; args.parallelism overrides
+        par = getattr(args, "parallelism", None) or ("hp" if model.shape.L >= comm.world else "dp")
     with torch.random.fork_rng(devices=[dev.index if dev.index is not None else torch.cuda.current_device()]):
         tr = _make_fused(FusedTrainer, args, method, model, operator, importance_train, step, device,
                          fused_problem_of, comm, par)
@@ -316,13 +317,7 @@ def _refresh_from_trainer(tr, method, ema, optimizer, scheduler):
     shadow = {id(p): s for p, s in zip(ema.params, ema.shadow_params)}
     tr.gather_optimizer_state()  # (samples sharded with a sharded optimiser: make the state whole first)
 
-    def whole(v):
-        """heads sharded: every rank's (L / world, ...) slice of a tensor -> the (L, ...) tensor, on every rank"""
-        if not tr.hp:
-            return v
-        out = torch.empty((tr.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
-        tr.comm.all_gather(out, v.contiguous())
-        return out.view((tr.world * v.shape[0],) + tuple(v.shape[1:]))
+    whole = tr.gather_heads_tensor  # heads sharded: every rank's slice of a tensor -> the (L, ...) tensor, on every rank
 
     for n, w, e, q in zip(tr.P.names, tr.P.views(tr.P.flat), tr.P.views(tr.P.ema), tr.P.views(tr.P.sq)):
         w, e, q = whole(w), whole(e), whole(q)

@@ -445,6 +445,21 @@ def evd_gather_heads(gathered: torch.Tensor, f: torch.Tensor, Tf: torch.Tensor, 
     check(rc, "nsvd_evd_gather_heads")
 
 
+def evd_gather_head_blocks(gathered: torch.Tensor, L: int, f: torch.Tensor, Tf: torch.Tensor, mask_kind: int,
+                           v: Optional[torch.Tensor], scratch: Optional[torch.Tensor] = None) -> None:
+    """gathered (world, 2 * B * ceil(L / world)): rank w's block begins with its packed f (B, n_w) | Tf (B, n_w),
+    n_w = L // world + (w < L % world) -> f, Tf (B, L) (+ the partial moments with scratch): any L >= world."""
+    W = gathered.shape[0]
+    B = f.shape[0]
+    Lb = -(-int(L) // W)
+    if gathered.dim() != 2 or gathered.shape[1] != 2 * B * Lb or tuple(f.shape) != (B, L) or tuple(Tf.shape) != (B, L):
+        raise NsvdError("evd_gather_head_blocks: gathered (world, 2 B ceil(L / world)), f / Tf (B, L)")
+    rc = _lib.load().nsvd_evd_gather_head_blocks(_ptr(gathered, "gathered"), int(W), int(B), int(L), int(mask_kind),
+                                                 _ptr(v, "v"), _ptr(f, "f"), _ptr(Tf, "Tf"),
+                                                 scratch.data_ptr() if scratch is not None else None, _stream())
+    check(rc, "nsvd_evd_gather_head_blocks")
+
+
 def operator_backward_evd(shape: ModelShape, params: Params, prob: Problem, x: torch.Tensor, f: torch.Tensor,
                           Tf: torch.Tensor, mask_kind: int, v: Optional[torch.Tensor], M: Optional[torch.Tensor],
                           moments: torch.Tensor, moments_reduced: bool, evd_scratch: Optional[torch.Tensor],

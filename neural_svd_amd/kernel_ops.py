@@ -94,7 +94,7 @@ class FusedKernelTrainer:
     the heads [r L / W, (r + 1) L / W) - weights, gradients, optimiser state: nothing replicated, no gradient traffic.
     Every rank draws the same index batch (equal generator seeds), evaluates its heads on it, and applies K to ITS
     columns of f only (Kf[:, l] = K[x][:, x] f[:, l] / B needs no other head): the MFMA work of the step is split W
-    ways. One all-gather of the packed (2, B, L / W) block [f | Kf] per step (2 B L floats in total: 4 MB at cfg4) is
+    ways. One all-gather of the packed (2, B, L / W) block [f | Kf] per step (any L >= W: the first L % W ranks own one head more) (2 B L floats in total: 4 MB at cfg4) is
     the only exchange; moments, loss gradient and backward of the local heads are then local."""
 
     def __init__(self, op: DenseKernelOperator, L: int, m: int, hidden=(128, 128), batch_size: int = 8192,
@@ -110,10 +110,11 @@ class FusedKernelTrainer:
         self.comm = comm if comm is not None and comm.multi else None
         world = self.comm.world if self.comm is not None else 1
         rank = self.comm.rank if self.comm is not None else 0
-        if L % world != 0:
-            raise ValueError(f"head sharding needs L ({L}) divisible by the world size ({world})")
-        self.world, self.Lg, Ll = world, L, L // world
-        self.l_off = rank * Ll
+        # any L >= world: L // world heads each, the first L % world ranks one more (parallel.head_range)
+        from .parallel import head_block, head_range
+        self.world, self.Lg = world, L
+        self.l_off, Ll = head_range(L, rank, world)
+        Lb = head_block(L, world)
         self.full_shape = H.ModelShape(L=L, D=D, m=m, hidden=tuple(hidden), has_exp_mask=False)
         self.shape = H.ModelShape(L=Ll, D=D, m=m, hidden=tuple(hidden), has_exp_mask=False)
         self.B = int(batch_size)
@@ -139,10 +140,12 @@ class FusedKernelTrainer:
         self.ka_ws = torch.empty(H._lib.load().nsvd_kernel_apply_workspace_bytes(int(op.N), self.B, Ll),
                                  dtype=torch.uint8, device=dev)
         # this rank's outputs packed [f | Kf] so that one all-gather moves both
-        self.fKf_loc = torch.empty((2, self.B, Ll), dtype=torch.float32, device=dev)
+        # (the all-gather block, as long as the largest rank's, begins with it: nsvd_evd_gather_head_blocks)
+        self._blk = torch.zeros(2 * self.B * Lb, dtype=torch.float32, device=dev)
+        self.fKf_loc = self._blk[:2 * self.B * Ll].view(2, self.B, Ll)
         self.f_loc, self.Kf_loc = self.fKf_loc[0], self.fKf_loc[1]
         if self.comm is not None:
-            self.gath = torch.empty((world, 2, self.B, Ll), dtype=torch.float32, device=dev)
+            self.gath = torch.empty((world, 2 * self.B * Lb), dtype=torch.float32, device=dev)
             self.fKf = torch.empty((2, self.B, L), dtype=torch.float32, device=dev)
             self.f, self.Kf = self.fKf[0], self.fKf[1]
         else:
@@ -167,10 +170,10 @@ class FusedKernelTrainer:
         if self.comm is not None:
             if self.probe is not None:
                 with self.probe.span("f_Kf_all_gather_wait"):
-                    self.comm.all_gather(self.gath, self.fKf_loc)  # blocking: on the compute stream (parallel.dp_step)
+                    self.comm.all_gather(self.gath, self._blk)  # blocking: on the compute stream (parallel.dp_step)
             else:
-                self.comm.all_gather(self.gath, self.fKf_loc)
-            H.evd_gather_heads(self.gath, self.f, self.Kf, self.mask_kind, self.v)
+                self.comm.all_gather(self.gath, self._blk)
+            H.evd_gather_head_blocks(self.gath, self.Lg, self.f, self.Kf, self.mask_kind, self.v)
         # the reduced moment vector (partials + one reduction launch): at B = 8192 every workgroup of the backward
         # summing the 128 per-chunk partials of its 2 L moments itself would cost 3 x the reduction
         H.evd_moments(self.f, self.Kf, self.mask_kind, self.v, self.moments, self.scratch)

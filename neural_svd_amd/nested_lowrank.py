@@ -7,8 +7,11 @@ backed by the HIP C ABI.  Same names, argument meaning and return values as the 
     get_sequential_nesting_masks / get_joint_nesting_masks       methods/nestedlora.py:40-54
 
 ``compute_loss_operator(operator, x, importance)`` takes the fused HIP path when ``operator`` is
-this package's OperatorWrapper(NegativeHamiltonian) and ``self.model`` its WaveFunctions; anything
-else is refused loudly (there is no eager fallback).
+this package's OperatorWrapper(NegativeHamiltonian) and ``self.model`` its WaveFunctions. Any other
+callable with the reference's contract ``operator(model, x, importance) -> (Tf, f)`` is CALLED (its
+model evaluations and the loss still run on the HIP kernels, ``apply_operator``). The loss Function
+takes ``f1, f2`` that are chunks of ``f`` (one fused call) or independent tensors of any row counts
+(the reference's lower seam, :84 "f1 and f2 must be independent"). There is no CPU / eager fallback.
 """
 from __future__ import annotations
 
@@ -102,31 +105,72 @@ def _mask_kind_uncached(vector_mask: torch.Tensor, matrix_mask: torch.Tensor) ->
 
 class NestedLoRALossFunctionEVD(torch.autograd.Function):
     """loss = -2 mean_b sum_l v_l f_bl Tf_bl + sum(M * lam_f1 * lam_f2); gradients to f, f1, f2 only
-    (Tf gets none: the operator is assumed self-adjoint, reference :108-111)."""
+    (Tf gets none: the operator is assumed self-adjoint, reference :108-111).
+
+    f1, f2 = torch.chunk(f, 2) (what compute_loss_operator passes, reference :263): one moment call + one loss call on
+    f, the three gradients summed in d loss / d f. INDEPENDENT f1, f2 (reference :84; what
+    compute_loss_kernel(split_batch=True) passes, :239-244 - any row counts B, B1, B2): the operator term and its
+    gradient -(4 / B) v Tf come from the kernels on (f, Tf) with a zero matrix mask; the metric term from the kernels
+    on X = [f1; f2] with TX = 0, the shorter of the two padded with zero rows to the longer's B' rows - that scales
+    its lam by B_short / B', so the metric term and BOTH its gradients (2 / B1) f1 (M lam_f2), (2 / B2) f2 (M lam_f1)
+    come out of the kernels times B_short / B' and are multiplied back. Gradients return separately to f, f1, f2
+    (autograd adds them when the caller passed one tensor twice)."""
 
     @staticmethod
     def forward(ctx, f, Tf, f1, f2, vector_mask, matrix_mask):
-        if not _is_chunk_of(f, f1, f2):
-            raise NsvdError("NestedLoRALossFunctionEVD (HIP): f1, f2 must be torch.chunk(f, 2) of a contiguous "
-                            "(B, L) f; independent f1/f2 (compute_loss_kernel split_batch) is not on this path")
         kind = _mask_kind(vector_mask, matrix_mask)
         dev = f.device
         v = vector_mask.to(dev).float().contiguous() if kind == H.MASK_CUSTOM else None
         M = matrix_mask.to(dev).float().contiguous() if kind == H.MASK_CUSTOM else None
-        fd, Tfd = f.detach(), Tf.detach().contiguous()
-        moments = H.evd_moments(fd, Tfd, kind, v)
-        loss, _ = H.evd_loss_grad(fd, Tfd, kind, v, M, moments, want_grad=False)
         ctx.kind, ctx.v, ctx.M = kind, v, M
-        ctx.save_for_backward(fd, Tfd, moments)
-        return loss[0].clone()
+        ctx.chunked = _is_chunk_of(f, f1, f2)
+        if ctx.chunked:
+            fd, Tfd = f.detach(), Tf.detach().contiguous()
+            moments = H.evd_moments(fd, Tfd, kind, v)
+            loss, _ = H.evd_loss_grad(fd, Tfd, kind, v, M, moments, want_grad=False)
+            ctx.save_for_backward(fd, Tfd, moments)
+            return loss[0].clone()
+        if f.dim() != 2 or Tf.shape != f.shape or f1.dim() != 2 or f2.dim() != 2 or \
+                f1.shape[1] != f.shape[1] or f2.shape[1] != f.shape[1] or min(f1.shape[0], f2.shape[0]) < 1:
+            raise NsvdError(f"NestedLoRALossFunctionEVD (HIP): f, Tf (B, L) and f1 (B1, L), f2 (B2, L) expected, got "
+                            f"{tuple(f.shape)}, {tuple(Tf.shape)}, {tuple(f1.shape)}, {tuple(f2.shape)} (the (B, L, O) "
+                            f"form of the reference is not on this path)")
+        L = f.shape[1]
+        B1, B2 = f1.shape[0], f2.shape[0]
+        fd, Tfd = f.detach().float().contiguous(), Tf.detach().float().contiguous()
+        # operator term: the caller's vector mask, a zero matrix mask
+        vv = vector_mask.to(dev).float().contiguous()
+        Z = torch.zeros(L, L, dtype=torch.float32, device=dev)
+        mom_op = H.evd_moments(fd, Tfd, H.MASK_CUSTOM, vv)
+        loss_op, _ = H.evd_loss_grad(fd, Tfd, H.MASK_CUSTOM, vv, Z, mom_op, want_grad=False)
+        # metric term on [f1; f2] (zero rows up to equal halves), no operator term
+        Bm = max(B1, B2)
+        X = torch.zeros(2 * Bm, L, dtype=torch.float32, device=dev)
+        X[:B1] = f1.detach()
+        X[Bm:Bm + B2] = f2.detach()
+        TX = torch.zeros_like(X)
+        mom = H.evd_moments(X, TX, kind, v)
+        loss_m, _ = H.evd_loss_grad(X, TX, kind, v, M, mom, want_grad=False)
+        ctx.rows = (B1, B2, Bm)
+        ctx.metric_scale = float(Bm) / float(min(B1, B2))
+        ctx.vv, ctx.Z = vv, Z
+        ctx.save_for_backward(fd, Tfd, mom_op, X, TX, mom)
+        return (loss_op[1] + ctx.metric_scale * loss_m[2]).to(f.dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
-        fd, Tfd, moments = ctx.saved_tensors
-        _, df = H.evd_loss_grad(fd, Tfd, ctx.kind, ctx.v, ctx.M, moments, 1.0, True)
-        df = df * grad_output
-        # the f1 / f2 contributions are already summed into df (they are views of f)
-        return df, None, None, None, None, None
+        if ctx.chunked:
+            fd, Tfd, moments = ctx.saved_tensors
+            _, df = H.evd_loss_grad(fd, Tfd, ctx.kind, ctx.v, ctx.M, moments, 1.0, True)
+            df = df * grad_output
+            # the f1 / f2 contributions are already summed into df (they are views of f)
+            return df, None, None, None, None, None
+        fd, Tfd, mom_op, X, TX, mom = ctx.saved_tensors
+        B1, B2, Bm = ctx.rows
+        _, df = H.evd_loss_grad(fd, Tfd, H.MASK_CUSTOM, ctx.vv, ctx.Z, mom_op, 1.0, True)
+        _, dX = H.evd_loss_grad(X, TX, ctx.kind, ctx.v, ctx.M, mom, 1.0, True)
+        dX = dX * (grad_output * ctx.metric_scale)
+        return df * grad_output, None, dX[:B1], dX[Bm:Bm + B2], None, None
 
 
 class NestedLoRALossFunctionSVD(torch.autograd.Function):

@@ -26,11 +26,13 @@ device - so the exchange sequence the product runs is the one the tests execute.
                     straight to every rank. Whatever RCCL's reduce-scatter / all-gather do internally, this one IS
                     the direct algorithm.
   "hp"  heads sharded (SURVEY 8(e) "alternative worth measuring"): the L heads of ParallelMLP share nothing but
-     the input, so rank r owns heads [r L/W, (r+1) L/W) - weights, gradients and optimiser state are not
-     replicated and there is NO gradient traffic; every rank evaluates its heads on the whole global batch and
-     the only exchange is one all-gather of 2 B L floats (f and Tf), under which the next batch's features are
-     produced. On xGMI the 18.9 MB gradient exchange of "dp" costs about as much as the whole compute step; the
-     all-gather is ~0.5 MB.
+     the input, so rank r owns the consecutive heads `head_range(L, r, W)` (L // W each, the first L % W ranks one
+     more: ANY L >= W, e.g. the reference scripts' --neigs 36 / 55 on 8 GPUs) - weights, gradients and optimiser
+     state are not replicated and there is NO gradient traffic; every rank evaluates its heads on the whole global
+     batch and the only exchange is one all-gather of the ranks' packed [f | Tf] blocks (2 B ceil(L / W) floats per
+     rank: equally long blocks, a short rank's tail unused), under which the next batch's features are produced. On
+     xGMI the 18.9 MB gradient exchange of "dp" costs about as much as the whole compute step; the all-gather is
+     ~0.5 MB.
 The reference itself has no live distributed code (tools/generic.py:65-180 is never imported).
 
 Backend protocol (all methods enqueue work and return immediately on the HIP backend):
@@ -49,7 +51,8 @@ Backend protocol (all methods enqueue work and return immediately on the HIP bac
   a2a_buffers(lo, hi) -> (r, s)    dp a2a: two (world, (hi - lo) / world) staging buffers of a bucket (received gradient
                                    slices; the updated slice replicated once per destination)
   sum_slices(recv, out)            dp a2a: out = recv[0] + recv[1] + ... (rank order)
-  gather_buffers() -> (out, inp)   hp: out (world, *inp.shape) receives every rank's packed [f | Tf] block
+  gather_buffers() -> (out, inp)   hp: inp = this rank's block of 2 B head_block(L, world) floats beginning with its
+                                   packed f (B, n_r) | Tf (B, n_r); out (world, inp.numel()) receives every rank's
   after_gather()                   hp: gathered blocks -> the (B, L) arrays the backward reads
   prefetch()                       work for the NEXT step that depends on no weight (issued under a collective)
 
@@ -240,6 +243,20 @@ def _world(comm: Optional[Communicator]) -> int:
 
 def _multi(comm: Optional[Communicator]) -> bool:
     return comm is not None and comm.multi
+
+
+def head_range(L: int, rank: int, world: int):
+    """heads sharded: (first head, number of heads) of `rank` - L // world each, the first L % world ranks one more
+    (the layout nsvd_evd_gather_head_blocks unpacks, include/nsvd.h)"""
+    if L < world:
+        raise ValueError(f"head-parallel needs at least one head per rank: L = {L} < world size {world}")
+    base, rem = divmod(L, world)
+    return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+
+
+def head_block(L: int, world: int) -> int:
+    """heads per all-gather block = the largest rank's head count (blocks are equally long)"""
+    return -(-L // world)
 
 
 def shard_range(lo: int, hi: int, rank: int, world: int):

@@ -180,10 +180,9 @@ class FusedTrainer:
         self.full_shape = shape
         self.Lg, self.l_off = shape.L, 0
         if self.hp:
-            if shape.L % world != 0:
-                raise ValueError(f"head-parallel needs L ({shape.L}) divisible by the world size ({world})")
-            Ll = shape.L // world
-            self.l_off = rank * Ll
+            # any L >= world: L // world heads each, the first L % world ranks one more (parallel.head_range)
+            from .parallel import head_range
+            self.l_off, Ll = head_range(shape.L, rank, world)
             shape = H.ModelShape(L=Ll, D=shape.D, m=shape.m, hidden=shape.hidden, has_exp_mask=shape.has_exp_mask)
             batch_size = int(batch_size) * world
         self.shape, self.problem, self.B = shape, problem, int(batch_size)
@@ -249,10 +248,16 @@ class FusedTrainer:
         self._emits_planes_cached = None
         self._own_batch = False      # the batch being stepped on came from the internal device sampler
         # local (B, L_local) outputs of the forward, packed [f | Tf] so that one all-gather moves both
-        self.fTf_loc = torch.empty((2, self.B, L), dtype=torch.float32, device=self.device)
+        # (heads sharded: the all-gather block - as long as the largest rank's, parallel.head_block - begins with it)
+        from .parallel import head_block
+        self._Lb = head_block(Lg, world) if self.hp else L
+        self._fTf_blk = torch.empty(2 * self.B * self._Lb, dtype=torch.float32, device=self.device)
+        self.fTf_loc = self._fTf_blk[:2 * self.B * L].view(2, self.B, L)
         self.f, self.Tf = self.fTf_loc[0], self.fTf_loc[1]
         if self.hp:
-            self.gath = torch.empty((world, 2, self.B, L), dtype=torch.float32, device=self.device)
+            if self._Lb != L:
+                self._fTf_blk[2 * self.B * L:].zero_()  # (never read; keeps what goes on the wire defined)
+            self.gath = torch.empty((world, 2 * self.B * self._Lb), dtype=torch.float32, device=self.device)
             self.fTf_g = torch.empty((2, self.B, Lg), dtype=torch.float32, device=self.device)
             self.f_g, self.Tf_g = self.fTf_g[0], self.fTf_g[1]
         else:
@@ -529,11 +534,26 @@ class FusedTrainer:
         if not self.hp or not gather:
             return sd
         for n in self.P.names:
-            v = sd[n].contiguous()
-            out = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
-            self.comm.all_gather(out, v)
-            sd[n] = out.view((self.world * v.shape[0],) + tuple(v.shape[1:]))
+            sd[n] = self.gather_heads_tensor(sd[n])
         return sd
+
+    def gather_heads_tensor(self, v: torch.Tensor) -> torch.Tensor:
+        """heads sharded: every rank's (n_r, ...) slice of a per-head tensor -> the (L, ...) tensor, on every rank (a
+        collective: call on every rank). Ranks own L // world or L // world + 1 heads (parallel.head_range): the
+        all-gather moves equally long blocks, a rank with fewer heads pads its block."""
+        if not self.hp:
+            return v
+        from .parallel import head_range
+        v = v.contiguous()
+        blk = v
+        if v.shape[0] != self._Lb:
+            blk = torch.zeros((self._Lb,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            blk[:v.shape[0]] = v
+        out = torch.empty((self.world,) + tuple(blk.shape), dtype=v.dtype, device=v.device)
+        self.comm.all_gather(out, blk)
+        if self.Lg % self.world == 0:
+            return out.view((self.Lg,) + tuple(v.shape[1:]))
+        return torch.cat([out[r, :head_range(self.Lg, r, self.world)[1]] for r in range(self.world)])
 
     def begin_apply(self) -> None:
         self._lr_now, self._decay_now = self._advance_schedule()
@@ -544,14 +564,15 @@ class FusedTrainer:
                            self.alpha, self.eps, self._decay_now, grad_scale)
 
     def gather_buffers(self):
-        return self.gath, self.fTf_loc
+        return self.gath, self._fTf_blk
 
     def after_gather(self) -> None:
         """the ranks' gathered [f | Tf] blocks -> the (B, L) arrays the backward reads; beyond 1024 rows (where the
-        backward wants per-chunk partial moments) those leave the same launch (nsvd_evd_gather_heads)"""
+        backward wants per-chunk partial moments) those leave the same launch (nsvd_evd_gather_head_blocks)"""
         v, _ = self._masks()
         want_partials = not self.direct_moments
-        H.evd_gather_heads(self.gath, self.f_g, self.Tf_g, self.mask_kind, v, self.scratch if want_partials else None)
+        H.evd_gather_head_blocks(self.gath, self.Lg, self.f_g, self.Tf_g, self.mask_kind, v,
+                                 self.scratch if want_partials else None)
         self._partials_ready = want_partials
 
     def prefetch(self) -> None:

@@ -98,6 +98,20 @@ def evd_loss_backward(f, Tf, v, M, lam1, lam2, grad_output=1.0):
 
 
 # ----------------------------------------------------------------------------- dense kernel operator
+def evd_loss_independent(f, Tf, f1, f2, v, M, grad_output=1.0):
+    """NestedLoRALossFunctionEVD with f1, f2 that are NOT chunks of f (reference methods/nestedlora.py:70-111; :84 "f1
+    and f2 must be independent"; the call of compute_loss_kernel(split_batch=True), :239-244). f, Tf (B, L), f1 (B1,
+    L), f2 (B2, L). Returns loss, grad_f, grad_f1, grad_f2 - the three gradients SEPARATE (when the caller passes one
+    tensor as f and f1, autograd adds them). Pinned by tests/golden/evd_loss_indep.npz."""
+    lam1 = f1.T @ f1 / f1.shape[0]                                     # compute_lambda, :10-11
+    lam2 = f2.T @ f2 / f2.shape[0]
+    loss = -2.0 * ((f * Tf) @ v).mean() + (M * lam1 * lam2).sum()      # :88-93
+    g = -(4.0 / f.shape[0]) * Tf * v.unsqueeze(0)                      # :108
+    g1 = (2.0 / f1.shape[0]) * (f1 @ (M * lam2))                       # :109  'lm,lm,bl->bm'
+    g2 = (2.0 / f2.shape[0]) * (f2 @ (M * lam1))                       # :110
+    return loss, grad_output * g, grad_output * g1, grad_output * g2
+
+
 def kernel_apply(K, rows, cols, f, scale=None):
     """Kf = scale * K[rows][:, cols] @ f (default scale 1 / len(cols)). PARITY UNPINNED: the reference has no kernel
     operator (only the consumer contract methods/nestedlora.py:230-252); this restates the build's own definition

@@ -100,6 +100,9 @@ def cdk_case(dev, amp=False):
 
 def main():
     mode, out_dir = sys.argv[1], sys.argv[2]
+    if "_L" in mode:  # hp_L5: another head count (heads that do not divide over the ranks)
+        mode, l = mode.rsplit("_L", 1)
+        CASE["L"] = int(l)
     if mode.endswith("_big"):  # batches beyond 1024 rows: the backward takes partial moment sums instead of f itself
         CASE["B_local"] = 640
         mode = mode[:-4]

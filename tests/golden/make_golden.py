@@ -157,6 +157,51 @@ def golden_loss(out):
         out[p + "cfg"] = np.array([B, L, int(c["seq"]), c["step"]])
 
 
+def golden_loss_indep(out):
+    """NestedLoRALossFunctionEVD.apply with f1, f2 that are NOT chunks of f (the lower seam of
+    methods/nestedlora.py:70-111; what compute_loss_kernel(split_batch=True) passes, :239-244): gradients to f, f1
+    and f2 separately"""
+    g = torch.Generator().manual_seed(4321)
+    cases = dict(
+        a=dict(B=12, B1=12, B2=12, L=5, seq=True, step=1, f1_is_f=True),    # split_batch: f1 IS f, f2 another batch
+        b=dict(B=16, B1=8, B2=8, L=6, seq=False, step=1, f1_is_f=False),    # three independent tensors
+        c=dict(B=9, B1=7, B2=4, L=5, seq=False, step=2, f1_is_f=False),     # unequal halves, B1 > B2
+        d=dict(B=20, B1=6, B2=11, L=7, seq=True, step=1, f1_is_f=False),    # B1 < B2
+        e=dict(B=64, B1=64, B2=64, L=16, seq=False, step=1, f1_is_f=True),
+        f=dict(B=3, B1=1, B2=2, L=1, seq=True, step=1, f1_is_f=False),
+    )
+    for name, c in cases.items():
+        B, B1, B2, L = c["B"], c["B1"], c["B2"], c["L"]
+        f64 = torch.randn(B, L, generator=g, dtype=torch.float64)
+        Tf64 = torch.randn(B, L, generator=g, dtype=torch.float64) * 3.0
+        f1_64 = f64 if c["f1_is_f"] else torch.randn(B1, L, generator=g, dtype=torch.float64)
+        f2_64 = torch.randn(B2, L, generator=g, dtype=torch.float64)
+        m = NestedLoRA(model=None, neigs=L, step=c["step"], sequential=c["seq"])
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            f = f64.to(dt).clone().requires_grad_(True)
+            Tf = Tf64.to(dt).clone().requires_grad_(True)
+            f1 = f if c["f1_is_f"] else f1_64.to(dt).clone().requires_grad_(True)
+            f2 = f2_64.to(dt).clone().requires_grad_(True)
+            loss = NestedLoRALossFunctionEVD.apply(f, Tf, f1, f2, m.vector_mask.to(dt), m.matrix_mask.to(dt))
+            (loss * 1.5).backward()  # (a grad_output that is not 1)
+            p = f"indep_{name}_{tag}_"
+            out[p + "loss"] = np64(loss)
+            out[p + "grad_f"] = np64(f.grad)  # f1 is f: the operator and the metric gradients summed by autograd
+            if not c["f1_is_f"]:
+                out[p + "grad_f1"] = np64(f1.grad)
+            out[p + "grad_f2"] = np64(f2.grad)
+            assert Tf.grad is None
+        p = f"indep_{name}_"
+        out[p + "f"] = f64.numpy()
+        out[p + "Tf"] = Tf64.numpy()
+        if not c["f1_is_f"]:
+            out[p + "f1"] = f1_64.numpy()
+        out[p + "f2"] = f2_64.numpy()
+        out[p + "v"] = m.vector_mask.numpy()
+        out[p + "M"] = m.matrix_mask.numpy()
+        out[p + "cfg"] = np.array([B, B1, B2, L, int(c["seq"]), c["step"], int(c["f1_is_f"])])
+
+
 # --------------------------------------------------------------------------- full model
 def build(args, dtype):
     torch.manual_seed(args.seed)
@@ -563,6 +608,12 @@ def main():
         np.savez_compressed(os.path.join(HERE, "kernel_loss.npz"), **o)
         print("kernel_loss", os.path.getsize(os.path.join(HERE, "kernel_loss.npz")) // 1024, "KiB")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "loss_indep":
+        o = {}
+        golden_loss_indep(o)
+        np.savez_compressed(os.path.join(HERE, "evd_loss_indep.npz"), **o)
+        print("evd_loss_indep", os.path.getsize(os.path.join(HERE, "evd_loss_indep.npz")) // 1024, "KiB")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "svd":  # only the fixture added last (the others stay byte-identical)
         o = {}
         golden_svd(o)
@@ -591,6 +642,10 @@ def main():
     o = {}
     golden_loss(o)
     np.savez_compressed(os.path.join(HERE, "evd_loss.npz"), **o)
+
+    o = {}
+    golden_loss_indep(o)
+    np.savez_compressed(os.path.join(HERE, "evd_loss_indep.npz"), **o)
 
     o = {}
     golden_ground_truth(o)
@@ -643,7 +698,7 @@ def main():
                  fourier_scale=1.0, sampling_scale=4.0, batch_size=7, operator_scale=1.0, operator_shift=16.0,
                  apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=0, seed=9)
     np.savez_compressed(os.path.join(HERE, "model_exact.npz"), **o)
-    for fn in ("tower", "kernel_loss", "masks", "evd_loss", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
+    for fn in ("tower", "kernel_loss", "masks", "evd_loss", "evd_loss_indep", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

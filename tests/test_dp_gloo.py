@@ -99,14 +99,27 @@ class OracleBackend:
         self.applied[lo:hi] = self.grad[lo:hi] * scale
 
     def gather_buffers(self):
+        """the protocol's block layout (parallel.py): 2 B head_block(L, world) values per rank, beginning with this
+        rank's packed f (B, n_r) | Tf (B, n_r)"""
+        from neural_svd_amd.parallel import head_block
         B, Ll = self.f_loc.shape
-        self.gath = torch.empty((self.world, 2, B, Ll), dtype=self.f_loc.dtype)
-        return self.gath, torch.stack([self.f_loc, self.Tf_loc]).contiguous()
+        n = 2 * B * head_block(self.v.numel(), self.world)
+        self.gath = torch.empty((self.world, n), dtype=self.f_loc.dtype)
+        blk = torch.full((n,), float("nan"), dtype=self.f_loc.dtype)  # (a short rank's tail must never be read)
+        blk[:2 * B * Ll] = torch.stack([self.f_loc, self.Tf_loc]).reshape(-1)
+        return self.gath, blk
 
     def after_gather(self):
-        W, _, B, Ll = self.gath.shape
-        both = self.gath.permute(1, 2, 0, 3).reshape(2, B, W * Ll).contiguous()  # head = rank * Ll + local head
-        self.f, self.Tf = both[0], both[1]
+        """what nsvd_evd_gather_head_blocks does on the device: rank w's n_w = head_range(L, w, world) columns"""
+        from neural_svd_amd.parallel import head_range
+        L, B = self.v.numel(), self.f_loc.shape[0]
+        f, Tf = [], []
+        for w in range(self.world):
+            _, n = head_range(L, w, self.world)
+            f.append(self.gath[w, :B * n].view(B, n))
+            Tf.append(self.gath[w, B * n:2 * B * n].view(B, n))
+        self.f, self.Tf = torch.cat(f, dim=1).contiguous(), torch.cat(Tf, dim=1).contiguous()
+        assert self.f.shape == (B, L) and bool(torch.isfinite(self.f).all())
 
     def prefetch(self):
         self.calls.append("prefetch")
@@ -191,8 +204,8 @@ def _worker_hp(rank, world, port, tmp):
     comm = parallel.Communicator.from_env(device=None, backend="gloo")
     p, prob, v, M, x = _setup()
     L = p.ws[0].shape[0]
-    Ll = L // world
-    be = OracleBackend(slice_heads(p, rank * Ll, (rank + 1) * Ll), prob, v, M, l_off=rank * Ll, world=world)
+    l_off, Ll = parallel.head_range(L, rank, world)  # any L >= world: the first L % world ranks own one head more
+    be = OracleBackend(slice_heads(p, l_off, l_off + Ll), prob, v, M, l_off=l_off, world=world)
     parallel.hp_step(be, comm, x)
     assert be.calls[:3] == ["forward", "prefetch", "backward(reduced=False, take_step=True)"], be.calls
     assert comm.count_ranks() == world
@@ -316,6 +329,48 @@ def test_hp_three_ranks_equals_single_process(tmp_path):
         assert torch.allclose(o["f"], ref["f"], rtol=1e-13, atol=1e-15)
         want = torch.cat([(g[r:r + 1]).reshape(-1) for g in ref["grads"]])
         assert float((o["grad"] - want).norm() / want.norm()) < 1e-12
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("L,world", [(36, 8), (55, 8), (5, 3), (7, 4)])
+def test_hp_uneven_head_counts(tmp_path, L, world):
+    """heads sharded with L not a multiple of the world size - the reference scripts' own head counts (--neigs 36:
+    scripts/exps/pde/hydrogen.sh:28, --neigs 55: oscillator.sh:27) on EIGHT ranks (4 x 5 + 4 x 4 heads; 7 x 7 + 6), and
+    two small worlds: L // W heads per rank, the first L % W ranks one more (parallel.head_range), equally long
+    all-gather blocks whose tails are never read. Every rank ends with the single-process loss, the whole (B, L) f,
+    and its own heads' slices of the single-process gradient."""
+    from neural_svd_amd.parallel import head_range
+    os.environ["NSVD_TEST_L"], os.environ["NSVD_TEST_B"] = str(L), "16"
+    try:
+        mp.spawn(_worker_hp, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+        p, prob, v, M, x = _setup()
+    finally:
+        del os.environ["NSVD_TEST_L"], os.environ["NSVD_TEST_B"]
+    assert p.ws[0].shape[0] == L
+    ref = O.loss_and_grads(x, p, prob, v, M)
+    seen = 0
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), f"h{r}.pt"))
+        lo, n = head_range(L, r, world)
+        assert lo == seen and n in (L // world, L // world + 1)
+        seen += n
+        assert abs(float(o["loss"]) - float(ref["loss"])) < 1e-12 * abs(float(ref["loss"]))
+        assert torch.allclose(o["f"], ref["f"], rtol=1e-13, atol=1e-15)
+        want = torch.cat([(g[lo:lo + n]).reshape(-1) for g in ref["grads"]])
+        assert o["grad"].numel() == want.numel()
+        assert float((o["grad"] - want).norm() / want.norm()) < 1e-12
+    assert seen == L
+
+
+def test_head_range_partitions_the_heads():
+    from neural_svd_amd.parallel import head_block, head_range
+    for L, W in [(36, 8), (55, 8), (16, 8), (32, 8), (8, 8), (9, 8), (64, 3), (5, 5)]:
+        rs = [head_range(L, r, W) for r in range(W)]
+        assert rs[0][0] == 0 and all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(W - 1))
+        assert rs[-1][0] + rs[-1][1] == L and max(n for _, n in rs) == head_block(L, W)
+        assert max(n for _, n in rs) - min(n for _, n in rs) <= 1
+    with pytest.raises(ValueError):
+        head_range(7, 0, 8)
 
 
 @pytest.mark.timeout(600)

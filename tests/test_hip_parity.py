@@ -179,6 +179,39 @@ def test_evd_loss_golden(case):
     assert rel(df3 * 4, z[p + "grad_f"]) < 2e-6
 
 
+@pytest.mark.parametrize("case", list("abcdef"))
+def test_evd_loss_function_with_independent_f1_f2(case):
+    """the lower seam (reference methods/nestedlora.py:70-111, :84 "f1 and f2 must be independent", the call at
+    :239-244): NestedLoRALossFunctionEVD.apply DIRECTLY with f1, f2 from other batches (any row counts; cases a, e pass
+    f itself as f1) against the reference's own run of the same call (tests/golden/evd_loss_indep.npz, grad_output
+    1.5): the loss and separate gradients to f, f1, f2"""
+    from neural_svd_amd.nested_lowrank import NestedLoRALossFunctionEVD
+    z = G.load("evd_loss_indep")
+    B, B1, B2, L, seq, step, f1_is_f = [int(t) for t in z[f"indep_{case}_cfg"]]
+    f = torch.tensor(z[f"indep_{case}_f"]).float().to(DEV).requires_grad_(True)
+    Tf = torch.tensor(z[f"indep_{case}_Tf"]).float().to(DEV).requires_grad_(True)
+    f1 = f if f1_is_f else torch.tensor(z[f"indep_{case}_f1"]).float().to(DEV).requires_grad_(True)
+    f2 = torch.tensor(z[f"indep_{case}_f2"]).float().to(DEV).requires_grad_(True)
+    v = torch.tensor(z[f"indep_{case}_v"]).float()   # (host tensors, as NestedLoRA holds them)
+    M = torch.tensor(z[f"indep_{case}_M"]).float()
+    loss = NestedLoRALossFunctionEVD.apply(f, Tf, f1, f2, v, M)
+    (loss * 1.5).backward()
+    torch.cuda.synchronize()
+    p = f"indep_{case}_f64_"
+    assert abs(float(loss) - float(z[p + "loss"])) < 2e-5 * max(1.0, abs(float(z[p + "loss"])))
+    assert Tf.grad is None
+    assert rel(f.grad, z[p + "grad_f"]) < 2e-6
+    if not f1_is_f:
+        assert rel(f1.grad, z[p + "grad_f1"]) < 2e-6
+    assert rel(f2.grad, z[p + "grad_f2"]) < 2e-6
+    # and the oracle's restatement says the same
+    lo, g, g1, g2 = O.evd_loss_independent(f.detach().double().cpu(), Tf.detach().double().cpu(),
+                                           f1.detach().double().cpu(), f2.detach().double().cpu(), v.double(),
+                                           M.double(), 1.5)
+    assert abs(float(loss) - float(lo)) < 2e-5 * max(1.0, abs(float(lo)))
+    assert rel(f2.grad, g2) < 2e-6
+
+
 def test_evd_loss_large_L_and_B():
     g = torch.Generator().manual_seed(5)
     B, L = 8192, 64
@@ -1059,6 +1092,45 @@ def test_head_sharded_backward_at_the_multi_gpu_rank_shape(world, rank):
     assert rel(loss_loc, loss_full) < 1e-6
     for i, (a, b) in enumerate(zip(g_loc, g_full)):
         assert torch.isfinite(a).all() and rel(a, b[sl]) < 5e-6, (i, rel(a, b[sl]))
+
+
+@pytest.mark.parametrize("W,B,L,kind", [(8, 512, 36, "joint"), (8, 4096, 55, "seq"), (3, 96, 5, "custom"), (4, 1280, 7, "seq"),
+                                        (8, 64, 8, "joint"), (2, 64, 8, "seq")])
+def test_gather_head_blocks_with_uneven_head_counts(W, B, L, kind):
+    """nsvd_evd_gather_head_blocks: rank w's block of 2 B ceil(L / W) floats begins with its packed f (B, n_w) | Tf (B,
+    n_w), n_w = L // W + (w < L % W) (the scripts' --neigs 36 / 55 on 8 ranks: 5 / 4 and 7 / 6 heads); the tail of a
+    short block is poisoned with NaN and must never be read. f, Tf bit for bit the concatenation, the partial
+    moments bit for bit those of nsvd_evd_partial on them."""
+    from neural_svd_amd.parallel import head_block, head_range
+    g = torch.Generator().manual_seed(W * B + L)
+    Lb = head_block(L, W)
+    gath = torch.full((W, 2 * B * Lb), float("nan"))
+    fs, Ts = [], []
+    for w in range(W):
+        _, n = head_range(L, w, W)
+        fw, tw = torch.randn(B, n, generator=g), torch.randn(B, n, generator=g)
+        gath[w, :B * n], gath[w, B * n:2 * B * n] = fw.reshape(-1), tw.reshape(-1)
+        fs.append(fw), Ts.append(tw)
+    gath = gath.to(DEV)
+    want_f, want_T = torch.cat(fs, 1).contiguous().to(DEV), torch.cat(Ts, 1).contiguous().to(DEV)
+    v, M = (O.sequential_nesting_masks(L) if kind != "joint" else O.joint_nesting_masks(L, 1))
+    mk = {"seq": H.MASK_SEQUENTIAL, "joint": H.MASK_JOINT, "custom": H.MASK_CUSTOM}[kind]
+    vd = v.float().to(DEV) if kind == "custom" else None
+    f, Tf = torch.empty(B, L, device=DEV), torch.empty(B, L, device=DEV)
+    s1, s2 = H.evd_scratch(B, L, DEV), H.evd_scratch(B, L, DEV)
+    s1.zero_(); s2.zero_()
+    H.evd_gather_head_blocks(gath, L, f, Tf, mk, vd, s1)
+    H.evd_partial(want_f, want_T, mk, vd, s2)
+    torch.cuda.synchronize()
+    assert torch.equal(f, want_f) and torch.equal(Tf, want_T)
+    assert torch.equal(s1, s2)
+    f2, Tf2 = torch.zeros(B, L, device=DEV), torch.zeros(B, L, device=DEV)
+    H.evd_gather_head_blocks(gath, L, f2, Tf2, mk, vd, None)  # copy only
+    assert torch.equal(f2, want_f) and torch.equal(Tf2, want_T)
+    if L % W == 0:  # the even layout IS the (W, 2, B, L / W) array of nsvd_evd_gather_heads
+        f3, Tf3 = torch.zeros(B, L, device=DEV), torch.zeros(B, L, device=DEV)
+        H.evd_gather_heads(gath.view(W, 2, B, L // W), f3, Tf3, mk, vd, None)
+        assert torch.equal(f3, want_f) and torch.equal(Tf3, want_T)
 
 
 @pytest.mark.parametrize("W,B,Ll,kind", [(4, 96, 3, "seq"), (8, 4096, 2, "joint"), (2, 1280, 5, "custom"), (1, 64, 4, "seq")])

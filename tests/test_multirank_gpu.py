@@ -53,11 +53,12 @@ def run_ranks(mode, world, out_dir, backend="gloo"):
     return [torch.load(os.path.join(str(out_dir), f"{mode}_r{r}.pt"), weights_only=False) for r in range(world)]
 
 
-def single_process(world, b_local=None):
+def single_process(world, b_local=None, L=4):
     """the same steps by ONE trainer on the global batches (separate optimiser kernel so that the gradient is kept)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _multirank_worker as W
     W.CASE["B_local"] = b_local or 64  # (module state: set on every call)
+    W.CASE["L"] = L
     from neural_svd_amd.trainer import FusedTrainer
     dev = torch.device("cuda:0")
     tr = FusedTrainer(W.make_shape(), W.make_problem(), W.CASE["B_local"] * world, seed=5, device=dev,
@@ -174,6 +175,34 @@ def test_hp_ranks_match_single_process(tmp_path, world, big):
             want = torch.cat([t[rank * Ll:(rank + 1) * Ll].reshape(-1) for t in _views(ref[name], L)])
             got = torch.cat([t.reshape(-1) for t in _views(r[name], Ll)])
             assert rel(got, want) < tol, (name, rel(got, want))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,L", [(2, 5), (4, 7), (3, 4)])
+def test_hp_with_heads_that_do_not_divide_over_the_ranks(tmp_path, world, L):
+    """heads sharded for ANY L >= world (the reference scripts run --neigs 36 / 55: scripts/exps/pde/hydrogen.sh:28,
+    oscillator.sh:27): L // world heads per rank, the first L % world ranks one more (parallel.head_range) - 3 + 2,
+    2 + 2 + 2 + 1 and 2 + 1 + 1 heads here; equally long all-gather blocks unpacked by nsvd_evd_gather_head_blocks.
+    Every rank's tensors are its head slices of the single-process run's, and state_dict() is the whole model."""
+    from neural_svd_amd.parallel import head_range
+    rs = run_ranks(f"hp_L{L}", world, tmp_path)
+    ref = single_process(world, 64, L)
+    names = [n for n in rs[0]["sd"] if not n.endswith("_B")]
+    for k in rs[0]["sd"]:
+        assert all(torch.equal(r["sd"][k], rs[0]["sd"][k]) and torch.equal(r["sd_ema"][k], rs[0]["sd_ema"][k])
+                   for r in rs), k
+        if not k.endswith("_B"):
+            assert rs[0]["sd"][k].shape[0] == L
+    for rank, r in enumerate(rs):
+        lo, n = head_range(L, rank, world)
+        assert r["t"] == 3 and r["fused_step"] and r["l_off"] == lo
+        assert rel(r["loss0"], ref["loss0"]) < 2e-6 and rel(r["mom0"], ref["mom0"]) < 2e-6
+        for i, k in enumerate(names):
+            assert torch.equal(rs[0]["sd"][k][lo:lo + n], _views(r["flat"], n)[i]), k
+        for name, tol in (("grad0", 1e-5), ("sq", 1e-4), ("flat", 1e-5)):
+            want = torch.cat([t[lo:lo + n].reshape(-1) for t in _views(ref[name], L)])
+            got = torch.cat([t.reshape(-1) for t in _views(r[name], n)])
+            assert rel(got, want) < tol, (name, rank, rel(got, want))
 
 
 @pytest.mark.timeout(900)

@@ -44,6 +44,30 @@ def test_evd_loss(case, tag, dtype, tol):
     assert G.rel(g.numpy(), z[p + "grad_f"]) <= tol
 
 
+@pytest.mark.parametrize("case", list("abcdef"))
+@pytest.mark.parametrize("tag,dtype,tol", [("f64", torch.float64, 1e-13), ("f32", torch.float32, 2e-5)])
+def test_evd_loss_independent_f1_f2(case, tag, dtype, tol):
+    """the reference's loss Function called with f1, f2 that are not chunks of f (tests/golden/evd_loss_indep.npz:
+    grad_output = 1.5; cases a, e pass f itself as f1 - autograd then adds the two gradients)"""
+    z = G.load("evd_loss_indep")
+    B, B1, B2, L, seq, step, f1_is_f = [int(t) for t in z[f"indep_{case}_cfg"]]
+    f = torch.tensor(z[f"indep_{case}_f"]).to(dtype)
+    Tf = torch.tensor(z[f"indep_{case}_Tf"]).to(dtype)
+    f1 = f if f1_is_f else torch.tensor(z[f"indep_{case}_f1"]).to(dtype)
+    f2 = torch.tensor(z[f"indep_{case}_f2"]).to(dtype)
+    v = torch.tensor(z[f"indep_{case}_v"]).to(dtype)
+    M = torch.tensor(z[f"indep_{case}_M"]).to(dtype)
+    loss, g, g1, g2 = O.evd_loss_independent(f, Tf, f1, f2, v, M, grad_output=1.5)
+    p = f"indep_{case}_{tag}_"
+    assert abs(float(loss) - float(z[p + "loss"])) <= tol * max(1.0, abs(float(z[p + "loss"])))
+    if f1_is_f:
+        assert G.rel((g + g1).numpy(), z[p + "grad_f"]) <= tol
+    else:
+        assert G.rel(g.numpy(), z[p + "grad_f"]) <= tol
+        assert G.rel(g1.numpy(), z[p + "grad_f1"]) <= tol
+    assert G.rel(g2.numpy(), z[p + "grad_f2"]) <= tol
+
+
 # ------------------------------------------------------------------ full model, float64 truth
 SMALL = ["hyd_small", "osc_small", "hyd_ragged"]
 
