@@ -1051,6 +1051,77 @@ def test_configs2_at_its_global_batch_on_one_gpu():
         assert rel(gs[l], gref[2 * nl][0]) < 3e-5, (l, rel(gs[l], gref[2 * nl][0]))
 
 
+@pytest.mark.parametrize("case", ["hydrogen_L36", "oscillator_L55"])
+def test_reference_scripts_head_counts_at_full_size(case):
+    """The head counts the reference's own PDE scripts run (--neigs 36: scripts/exps/pde/hydrogen.sh:28, 128,128,128 /
+    m = 1024 / sigma 16 / operator_scale 100; --neigs 55: oscillator.sh:27, exponential mask, m = 256, sigma 4, shift
+    16) at B = 512 on the fused MFMA path - 576 and 880 workgroups on 256 CUs, odd head counts, head windows that do
+    not divide - against the float64 oracle:
+      * forward: bit reproducibility; 8 sampled rows x ALL heads of f and Tf;
+      * loss: moments, loss from (f, Tf) against the float64 formulas (methods/nestedlora.py:70-111), joint (hydrogen)
+        and sequential (oscillator) nesting;
+      * backward (the fused step's loss-gradient-inside-the-backward call): every gradient of the first, a middle and
+        the LAST head, all 512 rows, against the float64 oracle's backward."""
+    if case == "hydrogen_L36":
+        L, D, m, hidden, B = 36, 2, 1024, (128, 128, 128), 512
+        p = O.init_params(L, D, m, hidden, 0.1, seed=0)
+        prob_o = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+        v, M = O.joint_nesting_masks(L, 1)
+        kind = H.MASK_JOINT
+    else:
+        L, D, m, hidden, B = 55, 2, 256, (128, 128, 128), 512
+        p = O.init_params(L, D, m, hidden, 1.0, exp_mask_init=10.0, seed=0)
+        prob_o = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=4.0)
+        v, M = O.sequential_nesting_masks(L)
+        kind = H.MASK_SEQUENTIAL
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    prob = hip_problem(prob_o)
+    x = (prob_o.sigma * torch.randn(B, D, generator=torch.Generator().manual_seed(5))).to(DEV)
+    ws = H.new_workspace(shape, B, DEV)
+    assert H.path_name(shape, B, H.PATH_AUTO, prob) == "fused_mfma"
+    f, Tf = H.operator_forward(shape, params, prob, x, ws)
+    f2, Tf2 = H.operator_forward(shape, params, prob, x, H.new_workspace(shape, B, DEV))
+    assert torch.equal(f, f2) and torch.equal(Tf, Tf2)
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, 300, 511])
+    p64 = p.to(torch.float64)
+    ref = O.operator_forward(x[rows.to(DEV)].double().cpu(), p64, prob_o)
+    assert rel(f[rows.to(DEV)], ref.f) < 2e-5
+    assert rel(Tf[rows.to(DEV)], ref.Tf) < 1e-4, rel(Tf[rows.to(DEV)], ref.Tf)
+    # loss + backward: the direct form (moments from f inside the backward kernels, B <= 1024) the trainer takes
+    gw = [torch.full_like(w, float("nan")) for w in ws_t]
+    gb = [torch.full_like(b, float("nan")) for b in bs_t]
+    gs = torch.full_like(sc, float("nan")) if sc is not None else None
+    grads = H.pack_params(shape, gw, gb, None, gs)
+    loss = torch.zeros(3, device=DEV)
+    H.operator_backward_evd(shape, params, prob, x, f, Tf, kind, None, None, None, False, None, loss, grads, ws)
+    mom = H.evd_moments(f, Tf, kind, None)
+    loss2, _ = H.evd_loss_grad(f, Tf, kind, None, None, mom, want_grad=False)
+    torch.cuda.synchronize()
+    f64, Tf64 = f.double().cpu(), Tf.double().cpu()
+    l64, lam1, lam2 = O.evd_loss_forward(f64, Tf64, v.double(), M.double())[:3]
+    assert abs(float(loss2[0]) - float(l64)) < 2e-5 * max(abs(float(loss2[1])), abs(float(loss2[2])))
+    assert abs(float(loss[0]) - float(l64)) < 2e-5 * max(abs(float(loss2[1])), abs(float(loss2[2])))
+    assert rel(mom[:L * L], lam1.reshape(-1)) < 2e-6 and rel(mom[L * L:2 * L * L], lam2.reshape(-1)) < 2e-6
+    df64 = O.evd_loss_backward(f64, Tf64, v.double(), M.double(), lam1, lam2)
+    xc = x.double().cpu()
+    nl = len(p.ws)
+    for l in (0, L // 2, L - 1):
+        ph = O.Params([w[l:l + 1] for w in p.ws], [b[l:l + 1] for b in p.bs], p.fourier_B,
+                      None if p.scales is None else p.scales[l:l + 1]).to(torch.float64)
+        ch = O.operator_forward(xc, ph, prob_o)
+        assert rel(f[:, l], ch.f[:, 0]) < 2e-5 and rel(Tf[:, l], ch.Tf[:, 0]) < 1e-4
+        gref = O.operator_backward(ch, ph, prob_o, df64[:, l:l + 1])
+        for i in range(nl):
+            assert rel(gw[i][l], gref[i][0]) < 3e-5, (l, i, rel(gw[i][l], gref[i][0]))
+            assert rel(gb[i][l], gref[nl + i][0]) < 3e-5, (l, i, rel(gb[i][l], gref[nl + i][0]))
+        if gs is not None:
+            assert rel(gs[l], gref[2 * nl][0]) < 3e-5, (l, rel(gs[l], gref[2 * nl][0]))
+    for g in gw + gb:
+        assert bool(torch.isfinite(g).all())
+
+
 @pytest.mark.parametrize("world,rank", [(8, 7), (4, 1)])
 def test_head_sharded_backward_at_the_multi_gpu_rank_shape(world, rank):
     """What one rank of an N-GPU head-sharded run of configs[1] executes (L / N heads of 16 on the global batch of
