@@ -520,6 +520,9 @@ def bench_widened(args, as_dict=False):
         # 2 B L M flops, M = MACs per sample and head of the 128 -> 128 -> 128 -> 1 network behind 2 x 64 features
         kflops = 2.0 * B * (L // world) * (128 * 128 + 128 * 128 + 128)
         kname = "pmlp_plain_stream_fwd_kernel"  # (pmlp_plain_fwd.h; up to round 4: pmlp_fused_fwd_kernel<4, 0, 0, 1>)
+        # the step's algorithmic FLOPs: model evaluation + its backward (W_1^T dz_1, dW_1, dW_0: three 128 x 128
+        # products per sample and head) + the row's own B x B . B x L contraction
+        step_flops_cfg4 = kflops + 2.0 * B * (L // world) * 3 * 128 * 128 + 2.0 * B * B * (L // world)
         workload = (f"configs[3]: dense PSD kernel operator K = A A^T / 256 + 1e-3 I on N = {N} points in R^16, "
                     f"L = {L}, batch {B} indices with replacement, NestedLoRA.compute_loss_kernel(split_batch=False) "
                     f"on a 2 x 128 softplus ParallelMLP, RMSprop")
@@ -558,11 +561,33 @@ def bench_widened(args, as_dict=False):
             last["loss"] = fused.step(x, y)[0]
         # the bracketed launch (nsvd_profile_next_forward): the first contraction Y1 = X W1^T + b1 - float32: one tower's
         # (tower_gemm_nt_kernel, fp32 MFMA); mixed precision: BOTH towers' in one launch (gemm16_kernel, bf16 MFMA)
-        kflops = 2.0 * B * d0 * (d1 // world) * (2 if (args.amp and comm is None) else 1)
-        kname = "nsvd_g16::gemm16b_kernel<false, false, true>" if args.amp else "tower_gemm_nt_kernel"
-        # algorithmic bytes of that launch: X and W1 read once, Y1 written once (bfloat16 / float32)
-        kbytes = ((B * d0 + d0 * (d1 // world)) * (2 if args.amp else 4) + B * (d1 // world) * (2 if args.amp else 4)) * \
-            (2 if (args.amp and comm is None) else 1)
+        nt_l = 2 if (args.amp and comm is None) else 1  # towers per bracketed launch (mixed precision, one GPU: both)
+        kflops = 2.0 * B * d0 * (d1 // world) * nt_l
+        fused_col = bool(args.amp) and H.tower_mixed_fused(B, d0, d1 // world, d2, 0.2)
+        if not args.amp:
+            kname = "tower_gemm_nt_kernel"
+        elif fused_col:
+            # the wide layer with BatchNorm inside the contraction (csrc/tower_col.h): A1 = lrelu(BN1(X W1^T + b1)) in
+            # one launch, whole columns per workgroup
+            kname = f"nsvd_tcol::tower_col_kernel<false, {B // 128}, "
+        else:
+            # gemm16.h launch(): the two-workgroups-per-CU form takes launches of >= 512 tiles, gemm16_kernel the rest
+            tiles = nt_l * (B // 256) * ((d1 // world) // 128)
+            kname = ("nsvd_g16::gemm16b_kernel" if tiles >= 512 and os.environ.get("NSVD_G16_FORM", "")[:1] != "a"
+                     else "nsvd_g16::gemm16_kernel") + "<false, false, true>"
+        # algorithmic bytes of that launch: X and W1 read once, the (B, d1) output written once (bfloat16 / float32)
+        kbytes = ((B * d0 + d0 * (d1 // world)) * (2 if args.amp else 4) + B * (d1 // world) * (2 if args.amp else 4)) * nt_l
+        # the STEP against its roofs (one GPU): 2 towers x 5 contractions + the loss's; bytes of the wide tensors and
+        # the parameters, each counted once per kernel that must touch it (the narrow end, < 5 %, left out):
+        #   optimiser 22 B/param (p, momentum read + written, gradient read, bfloat16 copy written; float32: 20),
+        #   gradients written 4 B/param, bfloat16 weights read 3 x 2 B/param, A1 written + read by three consumers,
+        #   dY1 written + read, X cast and read twice (float32 mode: Y1, A1, dA1, dY1 and their transposes, 4 B each)
+        n_par = 2 * (d0 * d1 + d1 * d2)
+        step_flops = 2 * 5 * 2.0 * B * d0 * d1 + 2 * 2.0 * B * (d2 + 1) * (d2 + 1) * 3
+        if args.amp:
+            step_bytes = n_par * (22 + 4 + 6) + 2 * B * d1 * 2 * (4 + 2) + 2 * B * d0 * (4 + 2 + 2 * 2)
+        else:
+            step_bytes = n_par * (20 + 4 + 3 * 4) + 2 * B * d1 * 4 * (2 + 3 + 2 + 3) + 2 * B * d0 * 4 * 3
         workload = (f"configs[4]: CDK step on synthetic features x, y ~ randn({B}, {d0}): two towers {d0} -> {d1} -> "
                     f"{d2} (Linear-BatchNorm-lrelu0.2-Linear-BatchNorm), l2_ball mu = 16, NestedLoRAForCDK L = {L} + "
                     f"constant mode, joint nesting, SGD lr 5e-3 momentum 0.9")
@@ -614,11 +639,25 @@ def bench_widened(args, as_dict=False):
                     kernel_avg_us=round(kavg * 1e3, 2), kernel_med_us=round(kms[len(kms) // 2] * 1e3, 2),
                     kernel_launches_timed=len(kms), kernel_flops=kflops)
         if args.config == "cfg5":
-            # this contraction's arithmetic intensity sits next to the ridge of the bf16 roofline (2500 TFLOP/s over
-            # 8 TB/s = 312 FLOP/B): both bounds are reported
+            # this launch's arithmetic intensity sits next to the ridge of the bf16 roofline (2500 TFLOP/s over
+            # 8 TB/s = 312 FLOP/B): both bounds are reported, `bound` names the one whose floor is higher
+            hbm_frac = kbytes / (kavg * 1e-3) / 1e9 / PEAK_HBM_GBS
             roof.update(algorithmic_bytes=int(kbytes), flops_per_byte=round(kflops / kbytes, 1),
-                        hbm_GBps=round(kbytes / (kavg * 1e-3) / 1e9, 1),
-                        hbm_frac=round(kbytes / (kavg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+                        hbm_GBps=round(kbytes / (kavg * 1e-3) / 1e9, 1), hbm_frac=round(hbm_frac, 4),
+                        mfma_frac=roof["frac"])
+            if kbytes / (PEAK_HBM_GBS * 1e9) > kflops / (peak * 1e12):
+                roof.update(bound="hbm", achieved=roof["hbm_GBps"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(hbm_frac, 4))
+            if comm is None:
+                # the step: HBM-bound by a wide margin in mixed precision (its bytes at 8 TB/s take twice as long as its
+                # FLOPs at the bf16 MFMA peak), MFMA-bound in float32
+                st_s = summ["ms_per_step"] * 1e-3
+                t_hbm, t_mfma = step_bytes / (PEAK_HBM_GBS * 1e9), step_flops / (peak * 1e12)
+                roof["step"] = dict(bound="hbm" if t_hbm > t_mfma else "mfma", algorithmic_bytes=int(step_bytes),
+                                    flops=step_flops, hbm_GBps=round(step_bytes / st_s / 1e9, 1),
+                                    hbm_frac=round(t_hbm / st_s, 4), mfma_frac=round(t_mfma / st_s, 4))
+                roof["step_frac"] = roof["step"]["hbm_frac"] if t_hbm > t_mfma else roof["step"]["mfma_frac"]
+        elif comm is None:
+            roof["step_frac"] = round(step_flops_cfg4 / (summ["ms_per_step"] * 1e-3) / 1e12 / peak, 4)
     out = {"metric": metric, "value": summ["value"], "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
            "vs_baseline": None,
@@ -729,6 +768,19 @@ def measure_other_configs(args, dev):
           lambda: measure_pde_config(ALT["cfg3"], dev, H.PATH_AUTO, steps, warmup, 3, 0.3))
     guard("configs[2] oscillator L=32 sequential, B=4096 (its global batch on ONE GPU: the N = 1 end of the 1 -> 8 curve)",
           lambda: measure_pde_config(dict(ALT["cfg3"], B=4096), dev, H.PATH_AUTO, 60, 10, 3, 0.3))
+    # the reference scripts' OWN head counts (scripts/exps/pde/hydrogen.sh:28 --neigs 36, oscillator.sh:27 --neigs 55) at
+    # 512 rows: forward grids of 576 and 880 workgroups on 256 CUs (2.25 and 3.44 rounds: the tail round is partly empty)
+    def scripts_shape(cfg):
+        d = measure_pde_config(cfg, dev, H.PATH_AUTO, steps, warmup, 3, 0.3)
+        wgs = (cfg["B"] // 32) * cfg["L"]
+        rounds = -(-wgs // 256)
+        d["forward_workgroups"], d["cu_rounds"] = wgs, rounds
+        d["tail_quantisation_loss"] = round(1.0 - wgs / (256.0 * rounds), 4)  # share of the CU-rounds left empty
+        return d
+    guard("reference script shape: hydrogen L=36 B=512 joint (scripts/exps/pde/hydrogen.sh)",
+          lambda: scripts_shape(dict(ALT["cfg2"], L=36)))
+    guard("reference script shape: oscillator L=55 B=512 sequential (scripts/exps/pde/oscillator.sh)",
+          lambda: scripts_shape(dict(ALT["cfg3"], L=55)))
     for name, config, amp in (("configs[3] dense kernel operator L=64 B=8192 (cfg4)", "cfg4", False),
                               ("configs[4] CDK towers L=512 B=1024 (cfg5), float32", "cfg5", False),
                               ("configs[4] CDK towers L=512 B=1024 (cfg5), mixed precision", "cfg5", True)):

@@ -457,6 +457,13 @@ size_t nsvd_tower_workspace_bytes(int B, int d0, int d1, int d2);
  *   that know the weights have not changed since the copies were written (nsvd_cdk_step's optimiser kernel refreshes
  *   them while it updates the float32 masters); clear, the forward casts the masters first. */
 int nsvd_tower_mixed_supported(int B, int d0, int d1, int d2);
+/*   Which of the two mixed-precision forms a call with this shape and activation slope runs. 1: the wide layer with
+ *   BatchNorm INSIDE the contraction (csrc/tower_col.h, slope > 0): Y1 and dA1 stay float32 in the accumulators and are
+ *   never stored (statistics, normalisation and the activation on unrounded values); the backward recovers the normalised
+ *   value from the stored bfloat16 activation, h = A1 > 0 ? A1 : A1 / slope, yhat = (h - beta1) / gamma1 (needs
+ *   gamma1 != 0). 0: contraction + strip kernels, Y1 and dA1 stored as bfloat16 as described above (slope == 0: ReLU is
+ *   not invertible). The float64 oracle restates both (oracle.tower_forward_backward: gemm_bf16 = "fused" / True). */
+int nsvd_tower_mixed_fused(int B, int d0, int d1, int d2, float slope);
 int nsvd_tower_forward(const float* x, const nsvd_tower_params* params, int B, int d0, int d1, int d2, float slope,
                        float eps, float momentum, int update_running, int gemm_bf16, float* z, void* ws,
                        size_t ws_bytes, void* stream);

@@ -137,6 +137,7 @@ SIGNATURES = {
     "nsvd_row_normalize_backward": (_I, [_P, _P, _I, _I, _F, _I, _P, _P]),
     "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "nsvd_tower_mixed_supported": (_I, [_I, _I, _I, _I]),
+    "nsvd_tower_mixed_fused": (_I, [_I, _I, _I, _I, _F]),
     "nsvd_tower_forward": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _P, _P, _Z, _P]),
     "nsvd_tower_forward_phase": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _P, _P, _Z, _P]),
     "nsvd_tower_y2_offset": (_Z, [_I, _I, _I, _I]),

@@ -369,15 +369,30 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
         }
         __syncthreads();
         const float rslope = 1.0f / a.slope;
+        // per-lane partial sums of 4 columns -> this wave's row of `red` (set k: columns 64 k + ..): the 16 lanes of a
+        // row block by butterfly; few registers live at a time (the accumulators fill half the file)
+        auto put_partial = [&](int j, int set, const float (&v)[4]) {
+            const float t0 = row16_sum(v[0]), t1 = row16_sum(v[1]), t2 = row16_sum(v[2]), t3 = row16_sum(v[3]);
+            if (l15 == 0) *reinterpret_cast<float4*>(red + w * 128 + 64 * set + 16 * j + 4 * g4) = make_float4(t0, t1, t2, t3);
+        };
+        // the 8 waves' rows added in wave order by one thread per column -> crow[set]; two barriers
+        auto finish_totals = [&](int nsets) {
+            __syncthreads();
+            if (tid < 64 * nsets) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k * 128 + tid];
+                crow[tid] = t;
+            }
+            __syncthreads();
+        };
         // pass 1: dh = dA1 * lrelu'(h) (kept in the accumulators); column sums of dh and dh * yhat
-        float s1[4][4], s2[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 gv = *reinterpret_cast<const float4*>(P.gamma + n0 + 16 * j + 4 * g4);
             const float4 ev = *reinterpret_cast<const float4*>(P.beta + n0 + 16 * j + 4 * g4);
             const float rg[4] = {1.0f / gv.x, 1.0f / gv.y, 1.0f / gv.z, 1.0f / gv.w}, be[4] = {ev.x, ev.y, ev.z, ev.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s1[j][e] = s2[j][e] = 0.f;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const uint2 u = *reinterpret_cast<const uint2*>(img + 2048 * i + ia[j]);
@@ -389,38 +404,35 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
                     const float yh = (h - be[e]) * rg[e];
                     const float dh = acc[i][j][e] * (pos ? 1.f : a.slope);
                     acc[i][j][e] = dh;
-                    s1[j][e] += dh;
-                    s2[j][e] = fmaf(dh, yh, s2[j][e]);
+                    s1[e] += dh;
+                    s2[e] = fmaf(dh, yh, s2[e]);
                 }
             }
+            put_partial(j, 0, s1);
+            put_partial(j, 1, s2);
         }
-        col_totals(s1, s2);
+        finish_totals(2);
+        float qsum = 0.f;  // (sum of the squares of dbeta, dgamma: taken now, crow is overwritten by the next reduction)
         if (tid < 64) {
-            P.dbeta[n0 + tid] = crow[tid];
-            P.dgamma[n0 + tid] = crow[64 + tid];
+            const float c1 = crow[tid], c2 = crow[64 + tid];
+            P.dbeta[n0 + tid] = c1;
+            P.dgamma[n0 + tid] = c2;
+            qsum = fmaf(c1, c1, c2 * c2);
         }
-        float m1[4][4], m2[4][4];
-        read_row(crow, m1);
-        read_row(crow + 64, m2);
-        // (the sums of the squares of dbeta, dgamma: taken now, crow[0..1] is overwritten by the next reduction)
-        float qsum = 0.f;
-        if (tid < 64) qsum = fmaf(crow[tid], crow[tid], crow[64 + tid] * crow[64 + tid]);
         // pass 2: dy = gamma inv (dh - mean(dh) - yhat mean(dh yhat)); stored over the activation's image
-        float s3[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 gv = *reinterpret_cast<const float4*>(P.gamma + n0 + 16 * j + 4 * g4);
             const float4 ev = *reinterpret_cast<const float4*>(P.beta + n0 + 16 * j + 4 * g4);
             const float4 iv = *reinterpret_cast<const float4*>(P.invstd + n0 + 16 * j + 4 * g4);
-            const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, be[4] = {ev.x, ev.y, ev.z, ev.w};
-            const float in[4] = {iv.x, iv.y, iv.z, iv.w};
+            const float4 c1 = *reinterpret_cast<const float4*>(crow + 16 * j + 4 * g4);
+            const float4 c2 = *reinterpret_cast<const float4*>(crow + 64 + 16 * j + 4 * g4);
+            const float be[4] = {ev.x, ev.y, ev.z, ev.w};
+            const float gi[4] = {gv.x * iv.x, gv.y * iv.y, gv.z * iv.z, gv.w * iv.w};
             const float rg[4] = {1.0f / gv.x, 1.0f / gv.y, 1.0f / gv.z, 1.0f / gv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                m1[j][e] *= rM;
-                m2[j][e] *= rM;
-                s3[j][e] = 0.f;
-            }
+            const float m1[4] = {c1.x * rM, c1.y * rM, c1.z * rM, c1.w * rM};
+            const float m2[4] = {c2.x * rM, c2.y * rM, c2.z * rM, c2.w * rM};
+            float s3[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 char* cell = img + 2048 * i + ia[j];
@@ -431,13 +443,15 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
                 for (int e = 0; e < 4; ++e) {
                     const float h = av[e] > 0.f ? av[e] : av[e] * rslope;
                     const float yh = (h - be[e]) * rg[e];
-                    dy[e] = ga[e] * in[e] * (acc[i][j][e] - m1[j][e] - yh * m2[j][e]);
-                    s3[j][e] += dy[e];
+                    dy[e] = gi[e] * (acc[i][j][e] - m1[e] - yh * m2[e]);
+                    s3[e] += dy[e];
                 }
                 *reinterpret_cast<uint2*>(cell) = make_uint2(pack_bf16(dy[0], dy[1]), pack_bf16(dy[2], dy[3]));
             }
+            put_partial(j, 0, s3);
         }
-        col_totals(s3, nullptr);  // (its barriers also order the image writes before store_image's reads)
+        // (the readers of crow above are past their reads before anyone overwrites it: the first barrier below)
+        finish_totals(1);  // (its barriers also order the image writes before store_image's reads)
         if (tid < 64) {
             const float c3 = crow[tid];
             P.dbias[n0 + tid] = c3;

@@ -842,6 +842,13 @@ def tower_mixed_supported(B: int, d0: int, d1: int, d2: int) -> bool:
     return bool(_lib.load().nsvd_tower_mixed_supported(int(B), int(d0), int(d1), int(d2)))
 
 
+def tower_mixed_fused(B: int, d0: int, d1: int, d2: int, slope: float) -> bool:
+    """does the mixed-precision tower of this shape run the wide layer with BatchNorm inside the contraction
+    (csrc/tower_col.h; include/nsvd.h: nsvd_tower_mixed_fused)? The oracle mode that restates its roundings:
+    tower_forward_backward(gemm_bf16="fused") - otherwise gemm_bf16=True."""
+    return bool(_lib.load().nsvd_tower_mixed_fused(int(B), int(d0), int(d1), int(d2), float(slope)))
+
+
 def tower_workspace(B: int, d0: int, d1: int, d2: int, device) -> torch.Tensor:
     n = int(_lib.load().nsvd_tower_workspace_bytes(int(B), int(d0), int(d1), int(d2)))
     if n == 0:

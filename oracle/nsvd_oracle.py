@@ -534,9 +534,17 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
     float16, has a GradScaler and covers more ops): the values the HIP path STORES as bfloat16 are rounded to bfloat16
     here - X, W1, W2; Y1 = X W1^T + b1; A1 = lrelu(BN1(Y1)); dY2, dA1, dY1 - products, sums, BatchNorm statistics, the
     narrow end (Y2, Z) and every parameter gradient exact in this dtype; the bias gradients are column sums of the
-    unrounded dY (include/nsvd.h, nsvd_tower_forward)."""
+    unrounded dY (include/nsvd.h, nsvd_tower_forward).
+    gemm_bf16 == "fused": the mixed-precision form with BatchNorm-1 inside the wide contractions (csrc/tower_col.h;
+    include/nsvd.h, nsvd_tower_mixed_fused): Y1 and dA1 are NOT rounded (they never leave the accumulators), and the
+    backward of BatchNorm-1 recovers the normalised value from the ROUNDED activation it stored,
+    h = A1 > 0 ? A1 : A1 / slope, yhat = (h - beta1) / gamma1, lrelu' from the sign of A1 (slope > 0)."""
     B = x.shape[0]
+    fused = isinstance(gemm_bf16, str)
+    if fused and gemm_bf16 != "fused":
+        raise ValueError("gemm_bf16: False, True or 'fused'")
     r = _bf16_round if gemm_bf16 else (lambda t: t)
+    r1 = (lambda t: t) if fused else r  # the rounding of Y1 and dA1
 
     def bn(y, g, be):
         mu = y.mean(0)
@@ -549,13 +557,16 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
         return g * inv * (dh - dh.mean(0) - yh * (dh * yh).mean(0)), (dh * yh).sum(0), dh.sum(0)
 
     xh, W1h, W2h = r(x), r(P["W1"]), r(P["W2"])
-    y1 = r(xh @ W1h.T + P["b1"])
+    y1 = r1(xh @ W1h.T + P["b1"])
     h1, yh1, inv1, st1 = bn(y1, P["g1"], P["be1"])
     a1 = r(torch.where(h1 > 0, h1, slope * h1))
     y2 = a1 @ W2h.T + P["b2"]
     z, yh2, inv2, st2 = bn(y2, P["g2"], P["be2"])
     dy2, dg2, dbe2 = bn_back(dz, yh2, inv2, P["g2"])
-    da1 = r(r(dy2) @ W2h)
+    da1 = r1(r(dy2) @ W2h)
+    if fused:  # what the backward kernel sees is the stored activation, not Y1
+        h1 = torch.where(a1 > 0, a1, a1 / slope)
+        yh1 = (h1 - P["be1"]) / P["g1"]
     dh1 = da1 * torch.where(h1 > 0, torch.ones_like(h1), torch.full_like(h1, slope))
     dy1, dg1, dbe1 = bn_back(dh1, yh1, inv1, P["g1"])
     grads = dict(W1=r(dy1).T @ xh, b1=dy1.sum(0), g1=dg1, be1=dbe1, W2=r(dy2).T @ a1, b2=dy2.sum(0), g2=dg2,

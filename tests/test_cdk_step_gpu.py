@@ -137,8 +137,11 @@ def test_cdk_step_refuses_what_it_does_not_implement():
         fs.step(torch.zeros(128, 128, device=DEV), torch.zeros(128, 128, device=DEV))
 
 
-def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding():
-    """FusedCdkStep(use_amp=True): three training steps in the mixed-precision mode (bfloat16 operands and wide
+@pytest.mark.parametrize("form", ["fused", "strips"])
+def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding(form, monkeypatch):
+    """(form: the wide layer with BatchNorm inside the contraction - csrc/tower_col.h, the default - or the contraction +
+    strip kernels, NSVD_TOWER16_FUSED=0; each against the oracle mode that restates its roundings.)
+    FusedCdkStep(use_amp=True): three training steps in the mixed-precision mode (bfloat16 operands and wide
     activations, both towers through every launch together, the bfloat16 weight copies of steps 2 and 3 written by the
     previous step's optimiser kernel), against oracle.cdk_train_step(gemm_bf16=True) in float64 with the same roundings
     from the same initial weights and batches - losses, total gradient norms, parameters and momentum buffers - and the
@@ -146,6 +149,11 @@ def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding():
     from oracle import nsvd_oracle as O
     from neural_svd_amd.cdk import FusedCdkStep
     sizes, B, mu, lr, mom, max_norm, slope = [128, 256, 256], 256, 16.0, 5e-3, 0.9, 1.0, 0.2
+    from neural_svd_amd import hip_ops as H
+    if form == "strips":
+        monkeypatch.setenv("NSVD_TOWER16_FUSED", "0")
+    assert H.tower_mixed_fused(B, *sizes, slope) == (form == "fused")
+    omode = "fused" if form == "fused" else True
     g = torch.Generator().manual_seed(77)
     xs = torch.randn(3, B, sizes[0], generator=g)
     ys = torch.randn(3, B, sizes[0], generator=g)
@@ -169,7 +177,7 @@ def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding():
     v, M = method.vector_mask.double().cpu(), method.matrix_mask.double().cpu()
     for t in range(3):
         (loss, lop, lmet), total = O.cdk_train_step(xs[t].double(), ys[t].double(), towers, bufs, running, v, M, mu, lr,
-                                                    mom, max_norm, slope, t == 0, gemm_bf16=True)
+                                                    mom, max_norm, slope, t == 0, gemm_bf16=omode)
         got = runs[True][0][t]
         assert abs(float(got[0]) - float(loss)) < 2e-4 * max(1.0, abs(float(loss))), (t, float(got[0]), float(loss))
         assert abs(float(got[3]) - float(total)) < 2e-3 * float(total), (t, float(got[3]), float(total))
@@ -207,8 +215,10 @@ def test_cdk_step_at_headline_size_against_the_oracle(amp):
                     rm2=sd0[f"backbones.{s}.4.running_mean"].clone(), rv2=sd0[f"backbones.{s}.4.running_var"].clone())
                for s in "xy"]
     v, M = method.vector_mask.double().cpu(), method.matrix_mask.double().cpu()
+    from neural_svd_amd import hip_ops as H
+    omode = ("fused" if H.tower_mixed_fused(B, *sizes, slope) else True) if amp else False
     (loss, lop, lmet), total = O.cdk_train_step(x.double(), y.double(), towers, bufs, running, v, M, mu, lr, mom,
-                                                max_norm, slope, True, gemm_bf16=amp)
+                                                max_norm, slope, True, gemm_bf16=omode)
     tl = 5e-4 if amp else 2e-5
     assert abs(float(out[0]) - float(loss)) < tl * max(1.0, abs(float(loss))), (float(out[0]), float(loss))
     assert abs(float(out[1]) - float(lop)) < tl * max(1.0, abs(float(lop)))

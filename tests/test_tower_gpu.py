@@ -134,13 +134,20 @@ def test_tower_behind_a_trainable_module_passes_the_gradient_upstream():
                                         # bottleneck towers (d1 < d0): the bfloat16 copy of X is the largest cast
                                         # operand there (round 3's scratch was sized by d1 only and overran)
                                         (512, 512, 256, 256), (256, 1024, 256, 512)])
-def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, d1, d2):
-    """gemm_bf16 (the counterpart of the reference's autocast branch, main_sketchy.py:161,182): operands and the wide
+@pytest.mark.parametrize("form", ["fused", "strips"])
+def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, d1, d2, form, monkeypatch):
+    """form: "fused" = the wide layer with BatchNorm inside the contraction (csrc/tower_col.h: Y1 and dA1 never stored,
+    the backward recovers the normalised value from the stored activation; what slope > 0 runs); "strips" = the
+    contraction + strip kernels (NSVD_TOWER16_FUSED=0; what slope == 0 runs). Each against the float64 oracle that
+    restates ITS roundings (include/nsvd.h: nsvd_tower_mixed_fused), at the same tolerances.
+    gemm_bf16 (the counterpart of the reference's autocast branch, main_sketchy.py:161,182): operands and the wide
     activations / gradients stored as bfloat16, float32 accumulation and statistics (include/nsvd.h). Against the
     float64 oracle that rounds the same tensors (its own intermediates differ from the float32 ones by 1e-7, which moves
     a few values in 10^4 across a bfloat16 rounding boundary: the tolerances below, not float32 noise level) - and
     against the float32 mode, from which it must differ by about the bfloat16 rounding (2^-9 per stored value), no more."""
     from neural_svd_amd import hip_ops as H
+    if form == "strips":
+        monkeypatch.setenv("NSVD_TOWER16_FUSED", "0")
     g = torch.Generator().manual_seed(B + d1)
     P = dict(W1=torch.randn(d1, d0, generator=g) / d0 ** 0.5, b1=0.1 * torch.randn(d1, generator=g),
              g1=1.0 + 0.3 * torch.randn(d1, generator=g), be1=0.2 * torch.randn(d1, generator=g),
@@ -148,8 +155,10 @@ def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, 
              g2=1.0 + 0.3 * torch.randn(d2, generator=g), be2=0.2 * torch.randn(d2, generator=g))
     x = torch.randn(B, d0, generator=g)
     dz = torch.randn(B, d2, generator=g)
+    fused = H.tower_mixed_fused(B, d0, d1, d2, 0.2)
+    assert fused == (form == "fused")
     zo, go, _ = O.tower_forward_backward(x.double(), {k: v.double() for k, v in P.items()}, dz.double(), 0.2,
-                                         gemm_bf16=True)
+                                         gemm_bf16="fused" if fused else True)
     Pd = {k: v.to(DEV).contiguous() for k, v in P.items()}
     for k, n in (("rm1", d1), ("rv1", d1), ("rm2", d2), ("rv2", d2)):
         Pd[k] = torch.zeros(n, device=DEV) if k.startswith("rm") else torch.ones(n, device=DEV)
