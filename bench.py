@@ -548,7 +548,7 @@ def bench_widened(args, as_dict=False):
         # call (nsvd_cdk_step) on the modules' own parameters
         if comm is None:
             fused = FusedCdkStep(method, lr=5e-3, momentum=0.9, max_grad_norm=1.0, t_max=10 * 30, batch_size=B,
-                                 use_amp=args.amp)
+                                 use_amp=args.amp, amp_dtype=getattr(args, "amp_dtype", "bfloat16"))
         else:
             # several ranks: the towers' hidden width sharded (cdk.ShardedCdkStep): the SAME batch and the same
             # arithmetic, the work of a step split N ways - strong scaling; two collectives per step
@@ -592,7 +592,14 @@ def bench_widened(args, as_dict=False):
                     f"{d2} (Linear-BatchNorm-lrelu0.2-Linear-BatchNorm), l2_ball mu = 16, NestedLoRAForCDK L = {L} + "
                     f"constant mode, joint nesting, SGD lr 5e-3 momentum 0.9")
         metric = "training steps/sec, CDK two-tower step L=512 B=1024 (NestedLoRA CDK path)"
-        if args.amp:
+        if args.amp and getattr(args, "amp_dtype", "bfloat16") == "float16":
+            metric += (" [mixed precision: float16 operands, wide activations and their gradients (the reference's autocast "
+                       "dtype), f16 MFMA with float32 accumulation, float32 statistics / loss / parameter gradients / "
+                       "update, torch.cuda.amp.GradScaler's loss scaling, skipped steps and scheduler gate on the device "
+                       "(examples/cdk/sketchy/main_sketchy.py:161,182,194-208); pinned to the float64 oracle with the same "
+                       "roundings and scaler arithmetic - parity unpinned vs the reference, whose autocast cannot run "
+                       "without a CUDA device]")
+        elif args.amp:
             metric += (" [mixed precision: bfloat16 operands, wide activations and their gradients, bf16 MFMA with "
                        "float32 accumulation, float32 statistics / loss / parameter gradients / update - this build's own "
                        "mode, DIFFERENT arithmetic from the Sketchy script's float16 autocast + GradScaler "
@@ -661,13 +668,16 @@ def bench_widened(args, as_dict=False):
     out = {"metric": metric, "value": summ["value"], "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
            "vs_baseline": None,
-           "dtype": "bf16 operands / f32 accumulation (tower contractions), f32 elsewhere"
+           "dtype": (("f16" if getattr(args, "amp_dtype", "") == "float16" else "bf16") +
+                     " operands / f32 accumulation (tower contractions), f32 elsewhere")
                     if (args.config == "cfg5" and args.amp) else "f32", "data": "synthetic",
            "timing": {"blocks": summ["blocks"], "ms_per_step_min": summ["ms_per_step_min"],
                       "ms_per_step_max": summ["ms_per_step_max"], "prewarm_steps": n_pre},
            "config": {"workload": workload, "note": note, "developer_config": args.config,
                       "not_the_headline_workload": True},
            "final_loss": float(last["loss"]), "roofline": roof, "cpu_baseline": None}
+    if args.config == "cfg5" and comm is None and getattr(fused, "scaler", None) is not None:
+        out["grad_scaler"] = fused.scaler_state()  # scale, steps taken / skipped over the whole run
     if comm is not None and strong:
         out["config"].update(global_batch=B, parallelism=f"tp{world}",
                              sharding="hidden width of both towers: each GPU owns d1/N rows of Linear1 / BatchNorm1 and "
@@ -783,8 +793,12 @@ def measure_other_configs(args, dev):
           lambda: scripts_shape(dict(ALT["cfg3"], L=55)))
     for name, config, amp in (("configs[3] dense kernel operator L=64 B=8192 (cfg4)", "cfg4", False),
                               ("configs[4] CDK towers L=512 B=1024 (cfg5), float32", "cfg5", False),
-                              ("configs[4] CDK towers L=512 B=1024 (cfg5), mixed precision", "cfg5", True)):
+                              ("configs[4] CDK towers L=512 B=1024 (cfg5), mixed precision", "cfg5", True),
+                              ("configs[4] CDK towers L=512 B=1024 (cfg5), mixed precision float16 + GradScaler", "cfg5",
+                               "float16")):
         a = copy.copy(args)
+        a.amp_dtype = "float16" if amp == "float16" else "bfloat16"
+        amp = bool(amp)
         a.config, a.amp, a.gpus, a.steps, a.warmup, a.repeats, a.prewarm_seconds = config, amp, 1, 100, 10, 3, 0.3
         a.batch_size, a.no_kernel_events = None, False
 
@@ -837,6 +851,9 @@ def main():
                     help="--config cfg5: the mixed-precision mode (tower contractions on bfloat16-rounded operands, "
                          "float32 accumulation: FusedCdkStep(use_amp=True), the counterpart of the reference script's "
                          "default autocast branch); the line says so")
+    ap.add_argument("--amp-dtype", default="bfloat16", choices=["bfloat16", "float16"],
+                    help="--config cfg5 --amp: the half type. float16 = the reference's autocast dtype, run with its "
+                         "GradScaler on the device (loss scaling, skipped steps, scheduler gate: FusedCdkStep)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="developer option, --gpus 1 only: run the multi-GPU exchange sequences in an RCCL world of ONE "
                          "(every collective a real library call on the one GPU; the `comm` block then reads the "

@@ -51,7 +51,15 @@ class CdkStepDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("slope", C.c_float),
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("mu", C.c_float), ("normalize_mode", C.c_int32),
                 ("set_first_mode_const", C.c_int32), ("lr", C.c_double), ("momentum", C.c_double),
-                ("max_grad_norm", C.c_double), ("first_step", C.c_int32), ("gemm_bf16", C.c_int32)]
+                ("max_grad_norm", C.c_double), ("first_step", C.c_int32), ("gemm_bf16", C.c_int32),
+                ("sched_t_max", C.c_int32), ("grad_scaler", C.c_void_p)]
+
+
+class GradScalerState(C.Structure):
+    """host mirror of the DEVICE-resident nsvd_grad_scaler (include/nsvd.h)"""
+    _fields_ = [("scale", C.c_float), ("growth_factor", C.c_float), ("backoff_factor", C.c_float),
+                ("growth_interval", C.c_int32), ("growth_tracker", C.c_int32), ("steps_ok", C.c_int32),
+                ("steps_skipped", C.c_int32), ("last_found_inf", C.c_int32)]
 
 
 class Rmsprop(C.Structure):
@@ -138,6 +146,7 @@ SIGNATURES = {
     "nsvd_tower_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "nsvd_tower_mixed_supported": (_I, [_I, _I, _I, _I]),
     "nsvd_tower_mixed_fused": (_I, [_I, _I, _I, _I, _F]),
+    "nsvd_grad_scaler_init": (_I, [_P, _F, _F, _F, _I, _P]),
     "nsvd_tower_forward": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _P, _P, _Z, _P]),
     "nsvd_tower_forward_phase": (_I, [_P, C.POINTER(TowerParams), _I, _I, _I, _I, _F, _F, _F, _I, _I, _I, _P, _P, _Z, _P]),
     "nsvd_tower_y2_offset": (_Z, [_I, _I, _I, _I]),

@@ -207,10 +207,14 @@ class _TowerFn(torch.autograd.Function):
     """Linear -> BatchNorm1d -> LeakyReLU -> Linear -> BatchNorm1d in training mode on the HIP tower kernels
     (csrc/tower.hip: five fp32-MFMA contractions and four BatchNorm strip kernels for forward + backward).
     Under ``torch.autocast`` (the reference's Sketchy loop wraps ``method(x, y)`` in it unless --disable_amp,
-    main_sketchy.py:182) the tower runs in this library's mixed-precision mode - bfloat16 operands and wide
+    main_sketchy.py:182) the tower runs in this library's mixed-precision mode - 16-bit operands and wide
     activations, float32 accumulation, statistics and parameter gradients (nsvd.h: gemm_bf16; shapes:
-    nsvd_tower_mixed_supported, float32 kernels otherwise) - and the output stays float32; a GradScaler around it is
-    harmless (bfloat16 has float32's exponent range: its scale neither rescues nor overflows anything)."""
+    nsvd_tower_mixed_supported, float32 kernels otherwise) - with the AUTOCAST DTYPE as the half type: float16 under
+    the reference's ``torch.cuda.amp.autocast()`` (its default dtype), bfloat16 under autocast(dtype=torch.bfloat16).
+    The output stays float32. With float16 the script's GradScaler does what it is there for: the scaled gradients it
+    sends into this backward are stored as float16, an overflow comes back as inf / NaN parameter gradients, and
+    ``scaler.step`` skips the update (main_sketchy.py:194-208: torch's own GradScaler, unchanged). With bfloat16 a
+    GradScaler is harmless (float32's exponent range: its scale neither rescues nor overflows anything)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, seq):
@@ -224,6 +228,14 @@ class _TowerFn(torch.autograd.Function):
         # (autocast on a shape the mixed-precision kernels do not take: the float32 kernels - more precise, never less)
         mixed = bool(torch.is_autocast_enabled()) and H.tower_mixed_supported(xd.shape[0], W1.shape[1], W1.shape[0],
                                                                               W2.shape[0])
+        if mixed:
+            try:
+                f16 = torch.get_autocast_dtype("cuda") == torch.float16
+            except (AttributeError, TypeError):  # (older torch)
+                f16 = torch.get_autocast_gpu_dtype() == torch.float16
+            mixed = 1 | (H.TOWER16_F16 if f16 else 0)
+        else:
+            mixed = 0
         z = H.tower_forward(xd, t, seq.slope, bn1.eps, bn1.momentum, track, ws, gemm_bf16=mixed)
         if track:
             bn1.num_batches_tracked += 1
@@ -336,13 +348,31 @@ class FusedCdkStep:
     parameter gradients, clipping and the update stay float32 - no loss scaling, no skipped step. NOT bit-comparable with
     float16 autocast; pinned to the float64 oracle with the same roundings. Batch and the towers' two output widths must
     be multiples of 256. False (default): float32
-    throughout - the script's --disable_amp."""
+    throughout - the script's --disable_amp.
+
+    amp_dtype (with use_amp): "bfloat16" (default: the mode above) or "float16" - the reference's own half type. With
+    float16 the step runs the reference's GradScaler as well (grad_scaler=None -> on; a hip_ops.GradScaler to share or
+    pre-set one; False -> off): the loss gradient is multiplied by the scale where the backward starts, a step whose
+    (scaled) gradient norm is inf / NaN is SKIPPED as a whole - no parameter, momentum buffer or schedule position
+    changes, the scale halves - otherwise the gradients are unscaled before the clip and the scale doubles every
+    growth_interval clean steps (main_sketchy.py:194-208; torch defaults 65536 / 2 / 0.5 / 2000). All of it on the
+    device: ``scaler_state()`` reads it back. The learning-rate schedule then follows the count of steps TAKEN, as the
+    script's scheduler gate does. Same kernels as the bfloat16 mode with the float16 MFMA; pinned to the float64 oracle
+    with the same roundings and the same scaler arithmetic (oracle.cdk_train_step(half="f16", scaler=...))."""
 
     def __init__(self, method: "NestedLoRAForCDK", lr: float, momentum: float = 0.9, max_grad_norm: float = 1.0,
-                 t_max: int = 0, batch_size: int = 1024, use_amp: bool = False):
+                 t_max: int = 0, batch_size: int = 1024, use_amp: bool = False, amp_dtype: str = "bfloat16",
+                 grad_scaler=None, init_scale: float = 65536.0, growth_interval: int = 2000):
         ok, why = self.supported(method, batch_size, use_amp)
         if not ok:
             raise H.NsvdError(f"FusedCdkStep: {why}")
+        if amp_dtype not in ("bfloat16", "float16"):
+            raise H.NsvdError("FusedCdkStep: amp_dtype must be 'bfloat16' or 'float16'")
+        self.amp_f16 = bool(use_amp) and amp_dtype == "float16"
+        if grad_scaler is None:
+            grad_scaler = self.amp_f16
+        if grad_scaler and not use_amp:
+            raise H.NsvdError("FusedCdkStep: a GradScaler needs use_amp=True")
         model = method.model
         self.method, self.model = method, model
         self.lr0, self.momentum, self.max_grad_norm, self.t_max = float(lr), float(momentum), float(max_grad_norm or 0.0), int(t_max)
@@ -368,6 +398,10 @@ class FusedCdkStep:
         self.M = method.matrix_mask.detach().float().to(dev).contiguous()
         self.first_const = bool(method.set_first_mode_const)
         self.loss = torch.zeros(4, dtype=torch.float32, device=dev)  # loss, operator term, metric term, grad norm
+        self.scaler = None
+        if grad_scaler:
+            self.scaler = grad_scaler if isinstance(grad_scaler, H.GradScaler) else \
+                H.GradScaler(dev, init_scale=init_scale, growth_interval=growth_interval)
         self.ws = H.cdk_step_workspace(self._desc(self.lr0, True), dev)
 
     @staticmethod
@@ -411,13 +445,19 @@ class FusedCdkStep:
         # gemm_bf16 bit 1: the bfloat16 copies of W1 / W2 inside the workspace are the ones the previous step's
         # optimiser kernel wrote, and nothing has touched the float32 masters since (their torch version counters:
         # the C call updates them through raw pointers, which bumps nothing)
+        flags = ((3 if weights_ready else 1) | (H.TOWER16_F16 if self.amp_f16 else 0)) if self.use_amp else 0
         return H.cdk_step_desc(self.B, self.d0, self.d1, self.d2, self.slope, self.bn_eps, self.bn_momentum,
                                self.model.mu, self.mode, self.first_const, lr, self.momentum, self.max_grad_norm, first,
-                               gemm_bf16=(3 if weights_ready else 1) if self.use_amp else 0)
+                               gemm_bf16=flags, grad_scaler=self.scaler, sched_t_max=self.t_max if self.scaler else 0)
+
+    def scaler_state(self):
+        """the GradScaler's device state (synchronises), or None without one"""
+        return self.scaler.state() if self.scaler is not None else None
 
     def current_lr(self) -> float:
-        """CosineAnnealingLR(optimizer, t_max) after self.t scheduler steps (t_max = 0: constant)"""
-        if self.t_max <= 0:
+        """CosineAnnealingLR(optimizer, t_max) after self.t scheduler steps (t_max = 0: constant). With a GradScaler the
+        schedule lives on the device and follows the steps TAKEN: this returns the base rate it starts from."""
+        if self.t_max <= 0 or self.scaler is not None:
             return self.lr0
         return self.lr0 * (1.0 + math.cos(math.pi * self.t / self.t_max)) / 2.0
 

@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(NTH) narrow_bwd_rows_kernel(NsvdNarrowBwd a) {
     __shared__ float red[4][3][1024];  // [wave][sum kind][column]  (N <= 1024)
     const int t = blockIdx.y, rb = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int ncol = a.N;
+    const float lscale = a.loss_scale ? *a.loss_scale : 1.f;  // (a power of two: exact)
     float s0[4][4], s1[4][4], s2[4][4];  // [pass over the columns][component]: this lane's columns lane * 4 + 256 p
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -206,6 +207,7 @@ __global__ void __launch_bounds__(NTH) narrow_bwd_rows_kernel(NsvdNarrowBwd a) {
             if (i < ncol) {
                 zv[p] = *reinterpret_cast<const float4*>(z + i);
                 dv[p] = *reinterpret_cast<const float4*>(d + i);
+                dv[p].x *= lscale; dv[p].y *= lscale; dv[p].z *= lscale; dv[p].w *= lscale;
                 ss += (zv[p].x * zv[p].x + zv[p].y * zv[p].y) + (zv[p].z * zv[p].z + zv[p].w * zv[p].w);
                 zd += (zv[p].x * dv[p].x + zv[p].y * dv[p].y) + (zv[p].z * dv[p].z + zv[p].w * dv[p].w);
             }
@@ -330,7 +332,12 @@ __global__ void __launch_bounds__(NTH) narrow_bwd_apply_kernel(NsvdNarrowBwd a) 
     o.y = ga.y * iv.y * (g.y - m1.y - (y.y - mu.y) * iv.y * m2.y);
     o.z = ga.z * iv.z * (g.z - m1.z - (y.z - mu.z) * iv.z * m2.z);
     o.w = ga.w * iv.w * (g.w - m1.w - (y.w - mu.w) * iv.w * m2.w);
-    if (a.dy_bf16) {
+    if (a.dy_bf16 == 2) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        reinterpret_cast<uint2*>(a.dY[t])[q] =
+            make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f2){o.x, o.y}, h2)),
+                       __builtin_bit_cast(unsigned, __builtin_convertvector((f2){o.z, o.w}, h2)));
+    } else if (a.dy_bf16) {
         reinterpret_cast<uint2*>(a.dY[t])[q] =
             make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f2){o.x, o.y}, bf2)),
                        __builtin_bit_cast(unsigned, __builtin_convertvector((f2){o.z, o.w}, bf2)));

@@ -22,6 +22,7 @@ struct TensorTable {
     float* buf[2 * NT];
     unsigned short* h[2 * NT];  // null, or where the updated parameter is ALSO written as bfloat16 (mixed precision: the
                                 // operand copies of W1 / W2 the next step's contractions read - no cast pass per step)
+    int h_f16;                  // those copies are IEEE float16
     const float* g[2 * NT];
     size_t n[2 * NT];
     size_t start[2 * NT + 1];  // prefix sums in float4 groups (every tensor padded to a multiple of 4 in the tables)
@@ -52,9 +53,18 @@ __global__ void __launch_bounds__(256) cdk_sumsq_kernel(TensorTable t, float* __
 __global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float* __restrict__ partial, int npartial,
                                                       float max_norm, float* __restrict__ scal,
                                                       float* __restrict__ loss_out, float lr, float momentum, int first,
-                                                      NsvdCdkLossParts lp) {
+                                                      NsvdCdkLossParts lp, const nsvd_grad_scaler* gs, int t_max) {
     __shared__ double red[256];
     __shared__ float coef_s;
+    // loss scaling (include/nsvd.h: nsvd_grad_scaler): the gradients carry the factor `scale`; the schedule and the
+    // momentum buffers' first step follow the count of steps TAKEN. The state is only READ here (every workgroup the
+    // same values): cdk_scaler_update_kernel advances it behind this kernel.
+    float inv_scale = 1.f;
+    if (gs) {
+        inv_scale = 1.0f / gs->scale;
+        first = gs->steps_ok == 0;
+        if (t_max > 0) lr = 0.5f * lr * (1.f + cospif((float)gs->steps_ok / (float)t_max));
+    }
     // the step's loss value: the loss kernels left per-block partials (no reduction launch of their own)
     if (blockIdx.x == 0 && loss_out && lp.part_op) nsvd_cdk_loss_sum(lp, reinterpret_cast<float*>(red), loss_out);
     __syncthreads();
@@ -68,21 +78,25 @@ __global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            const float norm = (float)sqrt(red[0]);
+            const float norm_scaled = (float)sqrt(red[0]);
+            const bool found_inf = gs && !(fabsf(norm_scaled) <= 3.0e38f);  // inf or NaN
+            const float norm = norm_scaled * inv_scale;
             float coef = 1.f;
             if (max_norm > 0.f) {
                 coef = max_norm / (norm + 1e-6f);
                 coef = coef > 1.f ? 1.f : coef;  // (a NaN norm gives a NaN coefficient, as in torch)
             }
-            coef_s = coef;
+            coef_s = found_inf ? -1.f : coef;  // (a clip coefficient is never negative: -1 = skip the step)
             if (blockIdx.x == 0) {
                 scal[0] = norm;
                 scal[1] = coef;
+                scal[2] = found_inf ? 1.f : 0.f;
                 if (loss_out) loss_out[3] = norm;
             }
         }
         __syncthreads();
     }
+    if (coef_s < 0.f) return;  // GradScaler.step(): inf / NaN gradients - optimizer.step() is skipped as a whole
     const float coef = coef_s;
     const size_t total4 = t.start[2 * NT];
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (size_t)gridDim.x * 256) {
@@ -94,7 +108,10 @@ __global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float
         float* p = t.p[k] + e;
         float* b = t.buf[k] + e;
         if (left >= 4) {
-            const float4 gv = *reinterpret_cast<const float4*>(g);
+            float4 gv = *reinterpret_cast<const float4*>(g);
+            if (gs) {  // scaler.unscale_(): grad * (1 / scale), before the clip coefficient
+                gv.x *= inv_scale; gv.y *= inv_scale; gv.z *= inv_scale; gv.w *= inv_scale;
+            }
             float4 pv = *reinterpret_cast<float4*>(p);
             float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(b);
             bv.x = first ? gv.x * coef : fmaf(momentum, bv.x, gv.x * coef);
@@ -107,20 +124,48 @@ __global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float
             *reinterpret_cast<float4*>(p) = pv;
             if (t.h[k]) {
                 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 typedef float f2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<uint2*>(t.h[k] + e) =
-                    make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.x, pv.y}, bf2)),
-                               __builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.z, pv.w}, bf2)));
+                if (t.h_f16)
+                    *reinterpret_cast<uint2*>(t.h[k] + e) =
+                        make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.x, pv.y}, h2)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.z, pv.w}, h2)));
+                else
+                    *reinterpret_cast<uint2*>(t.h[k] + e) =
+                        make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.x, pv.y}, bf2)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector((f2){pv.z, pv.w}, bf2)));
             }
         } else {
             for (size_t c = 0; c < left; ++c) {
-                const float gc = g[c] * coef;
+                const float gc = (gs ? g[c] * inv_scale : g[c]) * coef;
                 const float bc = first ? gc : fmaf(momentum, b[c], gc);
                 b[c] = bc;
                 p[c] = fmaf(-lr, bc, p[c]);
             }
         }
     }
+}
+
+// GradScaler.update() (include/nsvd.h: nsvd_grad_scaler), one thread, behind the optimiser kernel that read the state
+__global__ void cdk_scaler_update_kernel(nsvd_grad_scaler* gs, const float* __restrict__ scal) {
+    const bool found_inf = scal[2] != 0.f;
+    gs->last_found_inf = found_inf ? 1 : 0;
+    if (found_inf) {
+        gs->scale *= gs->backoff_factor;
+        gs->growth_tracker = 0;
+        gs->steps_skipped += 1;
+    } else {
+        gs->steps_ok += 1;
+        if (++gs->growth_tracker == gs->growth_interval) {
+            gs->scale *= gs->growth_factor;
+            gs->growth_tracker = 0;
+        }
+    }
+}
+
+__global__ void cdk_scaler_init_kernel(nsvd_grad_scaler* gs, float scale, float growth, float backoff, int interval) {
+    gs->scale = scale; gs->growth_factor = growth; gs->backoff_factor = backoff; gs->growth_interval = interval;
+    gs->growth_tracker = 0; gs->steps_ok = 0; gs->steps_skipped = 0; gs->last_found_inf = 0;
 }
 
 struct StepWs {
@@ -179,6 +224,8 @@ StepWs carve_step(const nsvd_cdk_step_desc& d, void* base) {
 
 bool desc_ok(const nsvd_cdk_step_desc* d) {
     if (!d) return false;
+    if (d->grad_scaler && (d->gemm_bf16 == 0 || !nsvd_narrow_supported(2, d->B, d->d2))) return false;
+    if ((d->gemm_bf16 & NSVD_TOWER16_F16) && !(d->gemm_bf16 & 1)) return false;
     if (nsvd_tower_workspace_bytes(d->B, d->d0, d->d1, d->d2) == 0) return false;
     if (d->gemm_bf16 != 0 && !nsvd_tower_mixed_supported(d->B, d->d0, d->d1, d->d2)) return false;
     if (d->normalize_mode != NSVD_NORMALIZE_L2_BALL && d->normalize_mode != NSVD_NORMALIZE_L2_SPHERE) return false;
@@ -193,6 +240,17 @@ float* const* tower_fields(const nsvd_tower_params& t, float* out[NT]) {
 }
 
 }  // namespace
+
+extern "C" int nsvd_grad_scaler_init(void* state, float init_scale, float growth_factor, float backoff_factor,
+                                     int growth_interval, void* stream) {
+    if (!state || !(init_scale > 0.f) || !(growth_factor >= 1.f) || !(backoff_factor > 0.f && backoff_factor <= 1.f) ||
+        growth_interval < 1)
+        return NSVD_EINVAL;
+    hipLaunchKernelGGL(cdk_scaler_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (nsvd_grad_scaler*)state,
+                       init_scale, growth_factor, backoff_factor, growth_interval);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" size_t nsvd_cdk_step_workspace_bytes(const nsvd_cdk_step_desc* d) {
     if (!desc_ok(d)) return 0;
@@ -290,7 +348,8 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
             b.dgamma[t] = gr[t].g2; b.dbeta[t] = gr[t].be2; b.dbias[t] = gr[t].b2;
             b.sumsq[t] = small_fused ? sq[t] + nsq + d->d1 / 64 : nullptr;
         }
-        b.nt = 2; b.B = B; b.N = L; b.dy_bf16 = 1; b.part = w.narrow; b.r_up = r_up;
+        b.nt = 2; b.B = B; b.N = L; b.dy_bf16 = (d->gemm_bf16 & NSVD_TOWER16_F16) ? 2 : 1; b.part = w.narrow; b.r_up = r_up;
+        b.loss_scale = d->grad_scaler ? &((const nsvd_grad_scaler*)d->grad_scaler)->scale : nullptr;
         b.sphere = d->normalize_mode == NSVD_NORMALIZE_L2_SPHERE;
         rc = nsvd_narrow_backward(b, s);
         if (rc) return rc;
@@ -299,7 +358,8 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
         const nsvd_tower_params* gq[2] = {&gr[0], &gr[1]};
         const float* dzs[2] = {w.dz[0], w.dz[1]};
         rc = nsvd_tower16_backward_pair(in, tp, dzs, B, d->d0, d->d1, d->d2, d->slope, gq, w.tower, w.tower_bytes, sq, s,
-                                        (narrow ? NSVD_TOWER16_WIDE_ONLY : 0) | (small_fused ? NSVD_TOWER16_SMALL_SUMSQ : 0));
+                                        (narrow ? NSVD_TOWER16_WIDE_ONLY : 0) | (small_fused ? NSVD_TOWER16_SMALL_SUMSQ : 0) |
+                                            (d->gemm_bf16 & NSVD_TOWER16_F16));
         if (rc) return rc;
     }
     for (int t = 0; t < 2; ++t) {
@@ -319,6 +379,7 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
         }
     }
     tab.start[2 * NT] = q4;
+    tab.h_f16 = (d->gemm_bf16 & NSVD_TOWER16_F16) ? 1 : 0;
     // clip_grad_norm_ + SGD momentum over all 16 tensors
     if (!small_fused) {
         hipLaunchKernelGGL(cdk_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, tab, w.partial);
@@ -330,7 +391,12 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     size_t blocks = (q4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;  // (each workgroup first adds the partials for itself: not too many of them)
     hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, part0, npart,
-                       (float)d->max_grad_norm, w.scal, loss, (float)d->lr, (float)d->momentum, d->first_step, lparts);
+                       (float)d->max_grad_norm, w.scal, loss, (float)d->lr, (float)d->momentum, d->first_step, lparts,
+                       (const nsvd_grad_scaler*)d->grad_scaler, d->sched_t_max);
     NSVD_CHECK_LAUNCH();
+    if (d->grad_scaler) {
+        hipLaunchKernelGGL(cdk_scaler_update_kernel, dim3(1), dim3(1), 0, s, (nsvd_grad_scaler*)d->grad_scaler, w.scal);
+        NSVD_CHECK_LAUNCH();
+    }
     return 0;
 }

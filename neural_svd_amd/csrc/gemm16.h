@@ -28,6 +28,8 @@
 namespace nsvd_g16 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -59,6 +61,7 @@ struct Args {
     int nprob, K, S;            // S split-K slices of K / S each
     long slice_stride;          // elements of C between split-K slices
     int nwg;
+    int f16;  // the operands (and a 16-bit output) are IEEE float16 instead of bfloat16
     int dbg;  // diagnostic builds only (NSVD_G16_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs
     unsigned long long* stamps;  // diagnostic, or null: cycles of block 0 / wave 0 - prologue, K loop (first half | barrier | second half), epilogue
 };
@@ -73,6 +76,29 @@ inline void set_uniform(Args& a, int M, int N, long lda, long ldb, long ldc) {
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
 }
+// The HALF TYPE of a mixed-precision launch: bfloat16 (F16 = false), or IEEE float16 (F16 = true: the reference's
+// autocast dtype, examples/cdk/sketchy/main_sketchy.py:182 - used with the loss scaling of cdk_step.hip). Two 16-bit
+// values of either type from two floats (round to nearest even), and back; the MFMA on a pair of 8-value fragments.
+template <bool F16>
+__device__ __forceinline__ unsigned pack_h(float a, float b) {
+    if (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
+    return pack_bf16(a, b);
+}
+template <bool F16>
+__device__ __forceinline__ float h_lo(unsigned u) {
+    if (F16) return (float)__builtin_bit_cast(f16x2, u)[0];
+    return __uint_as_float(u << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float h_hi(unsigned u) {
+    if (F16) return (float)__builtin_bit_cast(f16x2, u)[1];
+    return __uint_as_float(u & 0xffff0000u);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& b, const bf16x8& a, const f32x4& c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+}
 
 // 16 B per lane global -> LDS: source = sbase (wave-uniform) + voff (per lane, bytes), destination = m0 (wave-uniform LDS
 // byte address) + lane * 16. M0 is written here behind the compiler's back (check_m0.py: nothing else in the
@@ -81,7 +107,7 @@ __device__ __forceinline__ void dma16(const char* sbase, unsigned voff, unsigned
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0), "v"(voff), "s"(sbase) : "memory");
 }
 
-template <bool AS, bool BS, bool O16>
+template <bool AS, bool BS, bool O16, bool F16 = false>
 __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x;
@@ -232,7 +258,7 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(f.b[j], f.a[i], acc[i][j]);
     };
 
     // ---- the K loop, software-pipelined across the K steps: ONE workgroup barrier per step, in its MIDDLE.
@@ -302,7 +328,7 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
             if (a.dbg & 4) {
                 asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));
             } else if (O16) {
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(c0, c1), pack_bf16(c2, c3));
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_h<F16>(c0, c1), pack_h<F16>(c2, c3));
             } else {
                 *reinterpret_cast<float4*>(dst) = make_float4(c0, c1, c2, c3);
             }
@@ -342,7 +368,7 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
 }
 
 // the two-workgroups-per-CU form of the kernel (gemm16b.h, included at the end of this header)
-template <bool AS_, bool BS_, bool O_>
+template <bool AS_, bool BS_, bool O_, bool F_>
 inline int launch_b_inst(const Args& a, hipStream_t s);
 
 // host side: validate and launch. out_bf16: C holds bfloat16. Returns 0 or NSVD_E*.
@@ -375,19 +401,23 @@ inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16,
     // two workgroups per CU (gemm16b.h) where the launch has at least two per CU to give; one per CU otherwise (this kernel:
     // deeper K steps, fragments double-buffered - better alone on its CU)
     const bool form_b = !(form_env && form_env[0] == 'a') && !a.stamps && nwg >= 512;
-#define G16_LAUNCH(AS_, BS_, O_)                                                                                   \
+#define G16_LAUNCH_T(AS_, BS_, O_, F_)                                                                             \
     if (form_b) {                                                                                                  \
-        const int rcb = launch_b_inst<AS_, BS_, O_>(a, s);                                                         \
+        const int rcb = launch_b_inst<AS_, BS_, O_, F_>(a, s);                                                     \
         if (rcb) return rcb;                                                                                       \
     } else {                                                                                                       \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm16_kernel<AS_, BS_, O_>,                           \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm16_kernel<AS_, BS_, O_, F_>,                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);             \
             if (e != hipSuccess) return -(int)e;                                                                   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((gemm16_kernel<AS_, BS_, O_>), grid, dim3(512), LDS_BYTES, s, a);                       \
+        hipLaunchKernelGGL((gemm16_kernel<AS_, BS_, O_, F_>), grid, dim3(512), LDS_BYTES, s, a);                   \
+    }
+#define G16_LAUNCH(AS_, BS_, O_)                                                                                   \
+    {                                                                                                              \
+        if (a.f16) { G16_LAUNCH_T(AS_, BS_, O_, true) } else { G16_LAUNCH_T(AS_, BS_, O_, false) }                 \
     }
     if (!a_strided && !b_strided) {
         if (out_bf16) G16_LAUNCH(false, false, true) else G16_LAUNCH(false, false, false)
@@ -398,6 +428,7 @@ inline int launch(const Args& a0, bool a_strided, bool b_strided, bool out_bf16,
     } else {
         return NSVD_EUNSUPPORTED;  // (A k-strided, B k-contiguous): no contraction of the towers has this form
     }
+#undef G16_LAUNCH_T
 #undef G16_LAUNCH
     NSVD_CHECK_LAUNCH();
     return 0;

@@ -21,7 +21,7 @@ constexpr int B_ST_BYTES = B_A_BYTES + B_B_BYTES;    // 24 KB
 constexpr int B_LDS_BYTES = B_NST * B_ST_BYTES;      // 72 KB
 constexpr int B_NDMA = 3;                            // LDS-DMA instructions per wave and stage (2 of A, 1 of B)
 
-template <bool AS, bool BS, bool O16>
+template <bool AS, bool BS, bool O16, bool F16 = false>
 __global__ void __launch_bounds__(512, 4) gemm16b_kernel(Args a) {  // (4 waves per SIMD: 128 registers, two workgroups per CU)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(512, 4) gemm16b_kernel(Args a) {  // (4 waves 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j], fa_[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(fb_[j], fa_[i], acc[i][j]);
     }
 #undef G16B_ISSUE
 #undef G16B_WAIT_BARRIER
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(512, 4) gemm16b_kernel(Args a) {  // (4 waves 
                                 c3 = acc[i][j][3] + bv.w;
                     ss = fmaf(c0, c0, ss); ss = fmaf(c1, c1, ss); ss = fmaf(c2, c2, ss); ss = fmaf(c3, c3, ss);
                     char* dst = lds + (64 * wm + 16 * i + l15 - ROWS * ps) * RS + (64 * wn + 16 * j + 4 * g4) * (O16 ? 2 : 4);
-                    if (O16) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(c0, c1), pack_bf16(c2, c3));
+                    if (O16) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_h<F16>(c0, c1), pack_h<F16>(c2, c3));
                     else *reinterpret_cast<float4*>(dst) = make_float4(c0, c1, c2, c3);
                 }
             }
@@ -214,16 +214,16 @@ __global__ void __launch_bounds__(512, 4) gemm16b_kernel(Args a) {  // (4 waves 
 }
 
 // launch the two-workgroups-per-CU form (arguments already validated and completed by launch(): tiles, wg0, nwg)
-template <bool AS_, bool BS_, bool O_>
+template <bool AS_, bool BS_, bool O_, bool F_>
 inline int launch_b_inst(const Args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm16b_kernel<AS_, BS_, O_>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm16b_kernel<AS_, BS_, O_, F_>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm16b_kernel<AS_, BS_, O_>), dim3((unsigned)a.nwg), dim3(512), B_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm16b_kernel<AS_, BS_, O_, F_>), dim3((unsigned)a.nwg), dim3(512), B_LDS_BYTES, s, a);
     return 0;
 }
 

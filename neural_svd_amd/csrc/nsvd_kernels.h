@@ -127,6 +127,8 @@ constexpr int NSVD_TOWER16_WIDE_ONLY = 4;
 // backward: sumsq[t] continues behind the contractions' partials with one float per 64-column strip of the first
 // BatchNorm's backward (d1 / 64): the squares of the b1 / g1 / be1 gradients that strip wrote
 constexpr int NSVD_TOWER16_SMALL_SUMSQ = 8;
+// the half type is IEEE float16 instead of bfloat16 (a gemm_bf16 bit of include/nsvd.h: forward and backward alike)
+constexpr int NSVD_TOWER16_F16 = 16;
 int nsvd_tower16_forward_pair(const float* const* x, const nsvd_tower_params* const* p, int B, int d0, int d1, int d2,
                               float slope, float eps, float momentum, int update_running, int flags, float* const* z,
                               void* const* ws, size_t ws_bytes, hipStream_t s);
@@ -164,8 +166,10 @@ struct NsvdNarrowBwd {
     const float* invstd[2];
     const float* gamma[2];
     float* dz[2];                // (B, N) scratch: gradient w.r.t. z
-    void* dY[2];                 // (B, N) gradient w.r.t. Y2: bfloat16 when dy_bf16, else float32
+    void* dY[2];                 // (B, N) gradient w.r.t. Y2: float32 (dy_bf16 0), bfloat16 (1) or float16 (2)
     int dy_bf16;
+    const float* loss_scale;     // null, or a DEVICE scalar the incoming gradient ge is multiplied by as it is read (the
+                                 // GradScaler's loss scale: cdk_step.hip) - everything downstream is then scaled
     float* dgamma[2];
     float* dbeta[2];
     float* dbias[2];             // gradient of b2

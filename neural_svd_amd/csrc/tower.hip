@@ -96,6 +96,11 @@ __device__ __forceinline__ unsigned bf16_pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((nsvd_f32x2){a, b}, nsvd_bf16x2));
 }
 __device__ __forceinline__ uint2 bf16_pack4(const float4& v) { return make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w)); }
+// the half type by a (wave-uniform) code: 1 = bfloat16, 2 = IEEE float16 (gemm16.h: pack_h)
+__device__ __forceinline__ uint2 half_pack4(const float4& v, int code) {
+    if (code == 2) return make_uint2(nsvd_g16::pack_h<true>(v.x, v.y), nsvd_g16::pack_h<true>(v.z, v.w));
+    return bf16_pack4(v);
+}
 __device__ __forceinline__ unsigned short bf16_one(float a) { return (unsigned short)(bf16_pack2(a, 0.f) & 0xffffu); }
 
 __global__ void __launch_bounds__(256) tower_transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -159,7 +164,7 @@ struct BnFwd {
     float* outT;          // (N, B) transposed copy or null
     int B, N;
     float eps, momentum, slope;
-    int bf16_out;         // out / outT hold bfloat16 values (operands of mixed-precision contractions)
+    int bf16_out;         // out / outT hold 16-bit values (operands of mixed-precision contractions): 1 bfloat16, 2 float16
 };
 
 constexpr int BN_MAXR = 16;  // rows per thread: B / RG with B <= 1024 and RG >= 64
@@ -189,7 +194,7 @@ __device__ __forceinline__ void strip_reduce(float* red, const float4& part, flo
 // thread t then owns column t / (RG / 4) and rows 4 (t % (RG / 4)).. of the batch: one 16-byte store
 template <int STRIP, int NT>
 __device__ __forceinline__ void strip_transpose_out(float* tile, const float4& v, float* outT, int n0, int B, int k,
-                                                    int tid, bool bf16 = false) {
+                                                    int tid, int bf16 = 0) {
     constexpr int CG = StripGeom<STRIP, NT>::CG, RG = StripGeom<STRIP, NT>::RG, LD = STRIP + 1;
     const int c0 = 4 * (tid % CG), rg = tid / CG;
     __syncthreads();  // the previous batch has been read out
@@ -200,7 +205,7 @@ __device__ __forceinline__ void strip_transpose_out(float* tile, const float4& v
     const float4 o = make_float4(tile[r4 * LD + col], tile[(r4 + 1) * LD + col], tile[(r4 + 2) * LD + col],
                                  tile[(r4 + 3) * LD + col]);
     const size_t off = (size_t)(n0 + col) * B + (size_t)RG * k + r4;
-    if (bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(outT) + off) = bf16_pack4(o);
+    if (bf16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(outT) + off) = half_pack4(o, bf16);
     else *reinterpret_cast<float4*>(outT + off) = o;
 }
 
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(NT) tower_bn_forward_kernel(BnFwd a) {
             o.x = o.x > 0.f ? o.x : a.slope * o.x; o.y = o.y > 0.f ? o.y : a.slope * o.y;
             o.z = o.z > 0.f ? o.z : a.slope * o.z; o.w = o.w > 0.f ? o.w : a.slope * o.w;
             const size_t off = (size_t)(rg + RG * k) * a.N + n0 + c0;
-            if (a.bf16_out) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out) + off) = bf16_pack4(o);
+            if (a.bf16_out) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out) + off) = half_pack4(o, a.bf16_out);
             else *reinterpret_cast<float4*>(a.out + off) = o;
             v[k] = o;
         }
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(NT) tower_bn_forward_kernel(BnFwd a) {
 #pragma unroll
             for (int j = 1; j < BN_MAXR; ++j)
                 if (j == k) o = v[j];  // (a run-time index into the register array would put it in scratch)
-            strip_transpose_out<STRIP, NT>(tile, o, a.outT, n0, a.B, k, tid, a.bf16_out != 0);
+            strip_transpose_out<STRIP, NT>(tile, o, a.outT, n0, a.B, k, tid, a.bf16_out);
         }
     }
 }
@@ -310,7 +315,7 @@ struct BnBwd {
     float* dbias;         // (N): column sums of dY (the Linear bias in front of the BatchNorm), or null
     int B, N;
     float slope;
-    int bf16_out;         // dY / dYT hold bfloat16 values (operands of mixed-precision contractions)
+    int bf16_out;         // dY / dYT hold 16-bit values (operands of mixed-precision contractions): 1 bfloat16, 2 float16
 };
 
 template <int STRIP, int NT>
@@ -377,7 +382,7 @@ __global__ void __launch_bounds__(NT) tower_bn_backward_kernel(BnBwd a) {
             sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
             if (a.dY) {
                 const size_t off = (size_t)(rg + RG * k) * a.N + n0 + c0;
-                if (a.bf16_out) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dY) + off) = bf16_pack4(dy);
+                if (a.bf16_out) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dY) + off) = half_pack4(dy, a.bf16_out);
                 else *reinterpret_cast<float4*>(a.dY + off) = dy;
             }
         }
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(NT) tower_bn_backward_kernel(BnBwd a) {
 #pragma unroll
             for (int j = 1; j < BN_MAXR; ++j)
                 if (j == k) o = dh[j];
-            strip_transpose_out<STRIP, NT>(tile, o, a.dYT, n0, a.B, k, tid, a.bf16_out != 0);
+            strip_transpose_out<STRIP, NT>(tile, o, a.dYT, n0, a.B, k, tid, a.bf16_out);
         }
     }
 }
@@ -524,19 +529,24 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 // (opaque: the compiler may not keep the eight floats of a row alive from one phase of a strip kernel to the next - the
 // strip lives in registers PACKED, 4 registers per row, and is unpacked again where it is used)
+template <bool F16 = false>
 __device__ __forceinline__ void unpack8_fresh(uint4 u, float (&v)[8]) {
     asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w));
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    using nsvd_g16::h_hi;
+    using nsvd_g16::h_lo;
+    v[0] = h_lo<F16>(u.x); v[1] = h_hi<F16>(u.x);
+    v[2] = h_lo<F16>(u.y); v[3] = h_hi<F16>(u.y);
+    v[4] = h_lo<F16>(u.z); v[5] = h_hi<F16>(u.z);
+    v[6] = h_lo<F16>(u.w); v[7] = h_hi<F16>(u.w);
 }
 __device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
     v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y);
     v[4] = bf16_lo(u.z); v[5] = bf16_hi(u.z); v[6] = bf16_lo(u.w); v[7] = bf16_hi(u.w);
 }
+template <bool F16 = false>
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
-    return make_uint4(bf16_pack2(v[0], v[1]), bf16_pack2(v[2], v[3]), bf16_pack2(v[4], v[5]), bf16_pack2(v[6], v[7]));
+    using nsvd_g16::pack_h;
+    return make_uint4(pack_h<F16>(v[0], v[1]), pack_h<F16>(v[2], v[3]), pack_h<F16>(v[4], v[5]), pack_h<F16>(v[6], v[7]));
 }
 
 // 16-byte write-through store (sc1): a strip's 32 MB of output leaves for memory while the kernel runs instead of sitting
@@ -554,13 +564,15 @@ struct CastList {
     uint4* out[6];
     size_t n8[6];
 };
+template <bool F16>
 __global__ void __launch_bounds__(256) tower_cast_list_kernel(CastList c) {
+    using nsvd_g16::pack_h;
     const int k = blockIdx.y;
     const float4* in = c.in[k];
     uint4* out = c.out[k];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < c.n8[k]; i += (size_t)gridDim.x * 256) {
         const float4 a = in[2 * i], b = in[2 * i + 1];
-        out[i] = make_uint4(bf16_pack2(a.x, a.y), bf16_pack2(a.z, a.w), bf16_pack2(b.x, b.y), bf16_pack2(b.z, b.w));
+        out[i] = make_uint4(pack_h<F16>(a.x, a.y), pack_h<F16>(a.z, a.w), pack_h<F16>(b.x, b.y), pack_h<F16>(b.z, b.w));
     }
 }
 
@@ -596,6 +608,7 @@ struct Bn16Fwd {
     float eps, momentum, slope;
 };
 
+template <bool F16>
 __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) {
     __shared__ float red[BN16_RG * BN16_STRIP];
     __shared__ float csum[BN16_STRIP], cmean[BN16_STRIP], cinv[BN16_STRIP];
@@ -615,7 +628,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) 
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float v[8];
-            unpack8_fresh(raw[k], v);
+            unpack8_fresh<F16>(raw[k], v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s1[j] += v[j];
         }
@@ -632,7 +645,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) 
     for (int k = 0; k < BN16_MAXR; ++k)  // two-pass variance: mean first, then the squared deviations
         if (k < nr) {
             float v[8];
-            unpack8_fresh(raw[k], v);
+            unpack8_fresh<F16>(raw[k], v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = v[j] - mu[j];
@@ -667,13 +680,13 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_forward_kernel(Bn16Fwd a) 
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float v[8];
-            unpack8_fresh(raw[k], v);
+            unpack8_fresh<F16>(raw[k], v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float o = fmaf((v[j] - mu[j]) * sc[j], sh[j], be[j]);
                 v[j] = o > 0.f ? o : a.slope * o;
             }
-            store16_wt(out + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0, pack8(v));
+            store16_wt(out + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0, pack8<F16>(v));
         }
 }
 
@@ -694,6 +707,7 @@ struct Bn16Bwd {
     float slope;
 };
 
+template <bool F16>
 __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a) {
     __shared__ float red[BN16_RG * BN16_STRIP];
     __shared__ float c1[BN16_STRIP], c2[BN16_STRIP], c3[BN16_STRIP];
@@ -725,8 +739,8 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a)
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float y[8], d[8];
-            unpack8_fresh(yr[k], y);
-            unpack8_fresh(dr[k], d);
+            unpack8_fresh<F16>(yr[k], y);
+            unpack8_fresh<F16>(dr[k], d);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float yh = (y[j] - mu[j]) * inv[j];
@@ -753,8 +767,8 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a)
     for (int k = 0; k < BN16_MAXR; ++k)
         if (k < nr) {
             float y[8], d[8];
-            unpack8_fresh(yr[k], y);
-            unpack8_fresh(dr[k], d);
+            unpack8_fresh<F16>(yr[k], y);
+            unpack8_fresh<F16>(dr[k], d);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float yh = (y[j] - mu[j]) * inv[j];
@@ -763,7 +777,7 @@ __global__ void __launch_bounds__(BN16_NT) tower_bn16_backward_kernel(Bn16Bwd a)
                 sb[j] += dy;
                 d[j] = dy;
             }
-            store16_wt(a.dY[t] + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0, pack8(d));
+            store16_wt(a.dY[t] + (size_t)(rg + BN16_RG * k) * a.N + n0 + c0, pack8<F16>(d));
         }
     bn16_reduce(red, sb, c3, tid);
     if (tid < BN16_STRIP) a.dbias[t][n0 + tid] = c3[tid];
@@ -809,6 +823,7 @@ inline bool tower16_fused(int B, int d0, int d1, int d2, float slope) {
 // gemm_bf16 flag bits: 1 = mixed precision; 2 = the bfloat16 copies of W1 / W2 in the workspace are current (written by
 // the previous step's optimiser kernel, cdk_step.hip): the forward does not cast them again
 constexpr int MIXED_WEIGHTS_READY = 2;
+// bit 4 (NSVD_TOWER16_F16 = 16): the half type is IEEE float16 instead of bfloat16
 
 int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* const* p, int B, int d0, int d1, int d2,
                     float slope, float eps, float momentum, int update_running, int flags, int phase, float* const* z,
@@ -850,7 +865,8 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
         for (int k = 0; k < n; ++k) maxn = c.n8[k] > maxn ? c.n8[k] : maxn;
         size_t blocks = (maxn + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(tower_cast_list_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, c);
+        if (flags & NSVD_TOWER16_F16) hipLaunchKernelGGL(tower_cast_list_kernel<true>, dim3((unsigned)blocks, n), dim3(256), 0, s, c);
+        else hipLaunchKernelGGL(tower_cast_list_kernel<false>, dim3((unsigned)blocks, n), dim3(256), 0, s, c);
         NSVD_CHECK_LAUNCH();
     }
     nsvd_g16::Args g;
@@ -866,6 +882,7 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
             q.mean = w[t].mean1; q.invstd = w[t].inv1; q.out = v[t].A1h;
         }
         c.nt = nt; c.M = B; c.N = d1; c.K = d0; c.eps = eps; c.momentum = momentum; c.slope = slope;
+        c.f16 = (flags & NSVD_TOWER16_F16) ? 1 : 0;
         c.stamps = g_tcol_stamps;
         nsvd_prof_begin(s);  // bench.py --config cfg5 --amp brackets this launch (nsvd_profile_next_forward)
         rc = nsvd_tcol::launch<false>(c, s);
@@ -877,7 +894,7 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
     for (int t = 0; t < nt; ++t) {
         g.p[t].A = v[t].Xh; g.p[t].B = v[t].W1h; g.p[t].C = v[t].Y1h; g.p[t].bias = p[t]->b1;
     }
-    g.nprob = nt; g.K = d0; g.S = 1;
+    g.nprob = nt; g.K = d0; g.S = 1; g.f16 = (flags & NSVD_TOWER16_F16) ? 1 : 0;
     nsvd_g16::set_uniform(g, B, d1, d0, d0, d1);
     nsvd_prof_begin(s);  // bench.py --config cfg5 --amp brackets this contraction (nsvd_profile_next_forward)
     rc = nsvd_g16::launch(g, false, false, true, s);
@@ -893,7 +910,8 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
             f.mean[t] = w[t].mean1; f.invstd[t] = w[t].inv1; f.out[t] = v[t].A1h;
         }
         f.B = B; f.N = d1; f.eps = eps; f.momentum = momentum; f.slope = slope;
-        hipLaunchKernelGGL(tower_bn16_forward_kernel, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, f);
+        if (flags & NSVD_TOWER16_F16) hipLaunchKernelGGL(tower_bn16_forward_kernel<true>, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, f);
+        else hipLaunchKernelGGL(tower_bn16_forward_kernel<false>, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, f);
         NSVD_CHECK_LAUNCH();
     }
     }
@@ -903,7 +921,7 @@ int tower16_forward(int nt, const float* const* x, const nsvd_tower_params* cons
     for (int t = 0; t < nt; ++t) {
         g.p[t].A = v[t].A1h; g.p[t].B = v[t].W2h; g.p[t].C = w[t].Y2p;
     }
-    g.nprob = nt; g.K = d1; g.S = S;
+    g.nprob = nt; g.K = d1; g.S = S; g.f16 = (flags & NSVD_TOWER16_F16) ? 1 : 0;
     nsvd_g16::set_uniform(g, B, d2, d1, d1, d2);
     g.slice_stride = (long)B * d2;
     rc = nsvd_g16::launch(g, false, false, false, s);
@@ -948,7 +966,7 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
         memset(&b, 0, sizeof(b));
         b.dout = dz[t]; b.Y = w[t].Y2; b.mean = w[t].mean2; b.invstd = w[t].inv2; b.gamma = p[t]->g2; b.beta = p[t]->be2;
         b.dY = (float*)v[t].dY2h; b.dYT = nullptr; b.dgamma = grads[t]->g2; b.dbeta = grads[t]->be2;
-        b.dbias = grads[t]->b2; b.B = B; b.N = d2; b.slope = 1.0f; b.bf16_out = 1;
+        b.dbias = grads[t]->b2; b.B = B; b.N = d2; b.slope = 1.0f; b.bf16_out = (flags & NSVD_TOWER16_F16) ? 2 : 1;
         rc = launch_bn_backward(b, s);
         if (rc) return rc;
     }
@@ -964,6 +982,7 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
             q.sumsq = (sumsq && (flags & NSVD_TOWER16_SMALL_SUMSQ)) ? sumsq[t] + sumsq_count16(d0, d1, d2) : nullptr;
         }
         c.nt = nt; c.M = B; c.N = d1; c.K = d2; c.slope = slope;
+        c.f16 = (flags & NSVD_TOWER16_F16) ? 1 : 0;
         c.stamps = g_tcol_stamps;
         rc = nsvd_tcol::launch<true>(c, s);
         if (rc) return rc;
@@ -973,7 +992,7 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
     for (int t = 0; t < nt; ++t) {
         g.p[t].A = v[t].dY2h; g.p[t].B = v[t].W2h; g.p[t].C = v[t].dA1h;
     }
-    g.nprob = nt; g.K = d2; g.S = 1;
+    g.nprob = nt; g.K = d2; g.S = 1; g.f16 = (flags & NSVD_TOWER16_F16) ? 1 : 0;
     nsvd_g16::set_uniform(g, B, d1, d2, d1, d1);
     rc = nsvd_g16::launch(g, false, true, true, s);
     if (rc) return rc;
@@ -987,7 +1006,8 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
             b.sumsq[t] = (sumsq && (flags & NSVD_TOWER16_SMALL_SUMSQ)) ? sumsq[t] + sumsq_count16(d0, d1, d2) : nullptr;
         }
         b.B = B; b.N = d1; b.slope = slope;
-        hipLaunchKernelGGL(tower_bn16_backward_kernel, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, b);
+        if (flags & NSVD_TOWER16_F16) hipLaunchKernelGGL(tower_bn16_backward_kernel<true>, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, b);
+        else hipLaunchKernelGGL(tower_bn16_backward_kernel<false>, dim3(d1 / BN16_STRIP, nt), dim3(BN16_NT), 0, s, b);
         NSVD_CHECK_LAUNCH();
     }
     }
@@ -1003,7 +1023,7 @@ int tower16_backward(int nt, const float* const* x, const nsvd_tower_params* con
         q1.sumsq = sumsq ? sumsq[t] + (d2 / 256) * (d1 / 128) : nullptr;
         q1.M = d1; q1.N = d0; q1.lda = d1; q1.ldb = d0; q1.ldc = d0;
     }
-    g.nprob = 2 * nt; g.K = B; g.S = 1;
+    g.nprob = 2 * nt; g.K = B; g.S = 1; g.f16 = (flags & NSVD_TOWER16_F16) ? 1 : 0;
     return nsvd_g16::launch(g, true, true, false, s);
 }
 
@@ -1188,7 +1208,8 @@ int nsvd_tower_backward_sumsq(const float* x, const nsvd_tower_params* p, const 
         const nsvd_tower_params* gs[1] = {grads};
         void* wss[1] = {ws};
         float* sq[1] = {sumsq};
-        return tower16_backward(1, xs, ps, dzs, B, d0, d1, d2, slope, gs, wss, sumsq ? sq : nullptr, s);
+        return tower16_backward(1, xs, ps, dzs, B, d0, d1, d2, slope, gs, wss, sumsq ? sq : nullptr, s,
+                                gemm_bf16 & NSVD_TOWER16_F16);
     }
     int rc = 0;
     // dY2 = BN2'(dZ), dY2^T, db2 = column sums of dY2

@@ -33,7 +33,10 @@ namespace nsvd_tcol {
 using nsvd_g16::bf16x8;
 using nsvd_g16::dma16;
 using nsvd_g16::f32x4;
-using nsvd_g16::pack_bf16;
+using nsvd_g16::h_hi;
+using nsvd_g16::h_lo;
+using nsvd_g16::mfma16;
+using nsvd_g16::pack_h;
 using nsvd_g16::s16x4;
 typedef unsigned short bf16_t;
 
@@ -66,11 +69,9 @@ struct Args {
     int nt, M, N, K;
     float eps, momentum, slope;
     int nwg;
+    int f16;  // the half type is IEEE float16 instead of bfloat16 (gemm16.h: pack_h)
     unsigned long long* stamps;  // diagnostic, or null: cycles of block 0 / wave 0 - prologue, K loop, epilogue
 };
-
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 // sum over the 16 lanes that share lane >> 4 (the 16 rows of a block), fixed butterfly order; every lane gets the sum
 __device__ __forceinline__ float row16_sum(float v) {
@@ -81,7 +82,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <bool BWD, int NI, int PI, int NBUF>
+template <bool BWD, int NI, int PI, int NBUF, bool F16 = false>
 __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     constexpr int NP = NI / PI;
@@ -216,8 +217,7 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
                 for (int i = 0; i < PI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[p * PI + i][j] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_[j], fa_[i], acc[p * PI + i][j], 0, 0, 0);
+                        acc[p * PI + i][j] = mfma16<F16>(fb_[j], fa_[i], acc[p * PI + i][j]);
             }
         }
     }
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
                     const float t = fmaf((acc[i][j][e] - mu[j][e]) * inv[e], ga[e], be[e]);
                     o[e] = t > 0.f ? t : a.slope * t;
                 }
-                *reinterpret_cast<uint2*>(img + 2048 * i + ia[j]) = make_uint2(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]));
+                *reinterpret_cast<uint2*>(img + 2048 * i + ia[j]) = make_uint2(pack_h<F16>(o[0], o[1]), pack_h<F16>(o[2], o[3]));
             }
         }
         __syncthreads();
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const uint2 u = *reinterpret_cast<const uint2*>(img + 2048 * i + ia[j]);
-                const float av[4] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
+                const float av[4] = {h_lo<F16>(u.x), h_hi<F16>(u.x), h_lo<F16>(u.y), h_hi<F16>(u.y)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool pos = av[e] > 0.f;
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
             for (int i = 0; i < NI; ++i) {
                 char* cell = img + 2048 * i + ia[j];
                 const uint2 u = *reinterpret_cast<const uint2*>(cell);
-                const float av[4] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
+                const float av[4] = {h_lo<F16>(u.x), h_hi<F16>(u.x), h_lo<F16>(u.y), h_hi<F16>(u.y)};
                 float dy[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
                     dy[e] = gi[e] * (acc[i][j][e] - m1[e] - yh * m2[e]);
                     s3[e] += dy[e];
                 }
-                *reinterpret_cast<uint2*>(cell) = make_uint2(pack_bf16(dy[0], dy[1]), pack_bf16(dy[2], dy[3]));
+                *reinterpret_cast<uint2*>(cell) = make_uint2(pack_h<F16>(dy[0], dy[1]), pack_h<F16>(dy[2], dy[3]));
             }
             put_partial(j, 0, s3);
         }
@@ -476,21 +476,26 @@ inline bool shape_ok(int M, int N, int K) {
            128L * K * 2 < (1L << 31) && 64L * (long)N * 2 < (1L << 31) && 128L * (long)N * 2 < (1L << 31);
 }
 
-template <bool BWD, int NI, int PI, int NBUF>
-inline int launch_inst(const Args& a, hipStream_t s) {
+template <bool BWD, int NI, int PI, int NBUF, bool F16>
+inline int launch_inst_t(const Args& a, hipStream_t s) {
     constexpr int ring = NBUF * (8 * 16 * PI * 128 + B_BYTES);
     constexpr int epi = 8 * 16 * NI * 128 + RED_BYTES;
     constexpr int lds_bytes = ring > epi ? ring : epi;
     static_assert(lds_bytes <= 160 * 1024, "tower_col: LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tower_col_kernel<BWD, NI, PI, NBUF>,
+        hipError_t e = hipFuncSetAttribute((const void*)tower_col_kernel<BWD, NI, PI, NBUF, F16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((tower_col_kernel<BWD, NI, PI, NBUF>), dim3((unsigned)a.nwg), dim3(512), lds_bytes, s, a);
+    hipLaunchKernelGGL((tower_col_kernel<BWD, NI, PI, NBUF, F16>), dim3((unsigned)a.nwg), dim3(512), lds_bytes, s, a);
     return 0;
+}
+
+template <bool BWD, int NI, int PI, int NBUF>
+inline int launch_inst(const Args& a, hipStream_t s) {
+    return a.f16 ? launch_inst_t<BWD, NI, PI, NBUF, true>(a, s) : launch_inst_t<BWD, NI, PI, NBUF, false>(a, s);
 }
 
 template <bool BWD>

@@ -909,7 +909,7 @@ def tower_backward(x: torch.Tensor, params: dict, dz: torch.Tensor, slope: float
     grads = {k: torch.empty_like(params[k]) for k in TOWER_KEYS if not k.startswith("r")}
     p, g = _tower_struct(params, False), _tower_struct(grads, False)
     rc = _lib.load().nsvd_tower_backward(_ptr(x, "x"), C.byref(p), _ptr(dz, "dz"), B, d0, d1, d2, float(slope),
-                                         int(bool(gemm_bf16)), C.byref(g), ws.data_ptr(), ws.numel(), _stream())
+                                         int(gemm_bf16), C.byref(g), ws.data_ptr(), ws.numel(), _stream())
     check(rc, "nsvd_tower_backward")
     return grads
 
@@ -948,9 +948,37 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = N
     return (Cm, ss) if want_sumsq else Cm
 
 
+TOWER16_F16 = 16  # gemm_bf16 bit 4: the half type of the mixed-precision towers is IEEE float16 (include/nsvd.h)
+
+
+class GradScaler:
+    """torch.cuda.amp.GradScaler's state on the DEVICE (include/nsvd.h: nsvd_grad_scaler; the reference's AMP branch,
+    examples/cdk/sketchy/main_sketchy.py:161,194-208): nsvd_cdk_step scales the loss gradient, skips the optimiser step
+    on inf / NaN gradients and grows / backs off the scale without any host round trip. ``state()`` copies it back."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        self.buf = torch.zeros(C.sizeof(_lib.GradScalerState) // 4, dtype=torch.int32, device=device)
+        with torch.cuda.device(self.buf.device):
+            check(_lib.load().nsvd_grad_scaler_init(self.buf.data_ptr(), float(init_scale), float(growth_factor),
+                                                    float(backoff_factor), int(growth_interval), _stream()),
+                  "nsvd_grad_scaler_init")
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def state(self) -> dict:
+        """(synchronises) scale, growth_tracker, steps_ok (optimiser = scheduler steps taken), steps_skipped, ..."""
+        raw = self.buf.cpu().numpy().tobytes()
+        st = _lib.GradScalerState.from_buffer_copy(raw)
+        return {n: getattr(st, n) for n, _ in _lib.GradScalerState._fields_}
+
+
 def cdk_step_desc(B: int, d0: int, d1: int, d2: int, slope: float, bn_eps: float, bn_momentum: float, mu: float,
                   normalize_mode: int, set_first_mode_const: bool, lr: float, momentum: float, max_grad_norm: float,
-                  first_step: bool, gemm_bf16: int = 0) -> "_lib.CdkStepDesc":
+                  first_step: bool, gemm_bf16: int = 0, grad_scaler: Optional["GradScaler"] = None,
+                  sched_t_max: int = 0) -> "_lib.CdkStepDesc":
     d = _lib.CdkStepDesc()
     d.B, d.d0, d.d1, d.d2 = int(B), int(d0), int(d1), int(d2)
     d.slope, d.bn_eps, d.bn_momentum, d.mu = float(slope), float(bn_eps), float(bn_momentum), float(mu)
@@ -958,6 +986,8 @@ def cdk_step_desc(B: int, d0: int, d1: int, d2: int, slope: float, bn_eps: float
     d.lr, d.momentum, d.max_grad_norm = float(lr), float(momentum), float(max_grad_norm or 0.0)
     d.first_step = int(bool(first_step))
     d.gemm_bf16 = int(gemm_bf16)
+    d.sched_t_max = int(sched_t_max)
+    d.grad_scaler = grad_scaler.ptr if grad_scaler is not None else None
     return d
 
 

@@ -524,7 +524,13 @@ def _bf16_round(t):
     return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
 
 
-def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
+def _f16_round(t):
+    """round to nearest even to IEEE float16 (overflow -> inf) and back: the half type of the reference's autocast
+    (examples/cdk/sketchy/main_sketchy.py:182)"""
+    return t.to(torch.float32).to(torch.float16).to(t.dtype)
+
+
+def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False, half="bf16"):
     """Linear -> BatchNorm1d (training) -> LeakyReLU(slope) -> Linear -> BatchNorm1d (training) and the hand-derived
     gradient of sum(dz * z): what get_mlp(sizes=[d0, d1, d2], bias=True, nonlinearity='lrelu<slope>', use_bn=True)
     (reference examples/models/mlp.py:129-164) computes with autograd. P: dict W1 (d1, d0), b1, g1, be1 (d1), W2
@@ -538,12 +544,14 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
     gemm_bf16 == "fused": the mixed-precision form with BatchNorm-1 inside the wide contractions (csrc/tower_col.h;
     include/nsvd.h, nsvd_tower_mixed_fused): Y1 and dA1 are NOT rounded (they never leave the accumulators), and the
     backward of BatchNorm-1 recovers the normalised value from the ROUNDED activation it stored,
-    h = A1 > 0 ? A1 : A1 / slope, yhat = (h - beta1) / gamma1, lrelu' from the sign of A1 (slope > 0)."""
+    h = A1 > 0 ? A1 : A1 / slope, yhat = (h - beta1) / gamma1, lrelu' from the sign of A1 (slope > 0).
+    half: "bf16" or "f16" - the 16-bit type those roundings go to (f16: gemm_bf16 flag bit 4 of include/nsvd.h)."""
     B = x.shape[0]
     fused = isinstance(gemm_bf16, str)
     if fused and gemm_bf16 != "fused":
         raise ValueError("gemm_bf16: False, True or 'fused'")
-    r = _bf16_round if gemm_bf16 else (lambda t: t)
+    rh = {"bf16": _bf16_round, "f16": _f16_round}[half]
+    r = rh if gemm_bf16 else (lambda t: t)
     r1 = (lambda t: t) if fused else r  # the rounding of Y1 and dA1
 
     def bn(y, g, be):
@@ -576,7 +584,7 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False):
 
 
 def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm, slope, first_step, eps=1e-5,
-                   bn_momentum=0.1, gemm_bf16=False):
+                   bn_momentum=0.1, gemm_bf16=False, half="bf16", scaler=None, t_max=0):
     """One Sketchy-style CDK training step (reference examples/cdk/sketchy/main_sketchy.py:180-212 with
     scripts/exps/sketchy.sh's switches, AMP off): two towers (get_mlp, examples/models/mlp.py:129-164) behind Identity
     projectors and normalize('l2_ball', sqrt(mu)) (examples/models/siam.py:156-183), NestedLoRAForCDK loss
@@ -584,12 +592,23 @@ def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm
     (torch: coefficient min(1, max_norm / (total_norm + 1e-6))), then torch.optim.SGD with momentum (no dampening, no
     nesterov, no weight decay: buf = g on the first step, else momentum * buf + g; p -= lr * buf). In place on
     `towers` (two dicts W1 b1 g1 be1 W2 b2 g2 be2), `bufs` (same keys) and `running` (two dicts rm1 rv1 rm2 rv2).
-    Returns (loss, operator term, metric term), total gradient norm. Pinned by tests/golden/cdk_step.npz."""
+    Returns (loss, operator term, metric term), total gradient norm. Pinned by tests/golden/cdk_step.npz.
+    scaler: None, or a dict - torch.cuda.amp.GradScaler as the script's AMP branch drives it (main_sketchy.py:161,194-208:
+    scaler.scale(loss).backward(); scaler.unscale_(optimizer); clip_grad_norm_; scaler.step(optimizer); scaler.update();
+    the scheduler steps only with the optimiser) with keys scale, growth_factor, backoff_factor, growth_interval,
+    growth_tracker, steps_ok, steps_skipped (updated in place): the loss gradient is multiplied by scale before the
+    towers' backward; found_inf = the norm of the SCALED gradients is not finite -> nothing is updated, scale *= backoff;
+    else gradients * (1 / scale), clip, SGD, steps_ok += 1, and every growth_interval clean steps scale *= growth.
+    `lr` is then the BASE rate (t_max > 0: cosine over steps_ok) and first_step is steps_ok == 0."""
     r_up = float(mu) ** 0.5
+    if scaler is not None:
+        first_step = scaler["steps_ok"] == 0
+        if t_max > 0:
+            lr = cosine_lr(lr, scaler["steps_ok"], t_max)
     zs, embs = [], []
     for inp, P in ((x, towers[0]), (y, towers[1])):
         z, _, _ = tower_forward_backward(inp, P, torch.zeros(inp.shape[0], P["W2"].shape[0], dtype=inp.dtype), slope, eps,
-                                         gemm_bf16)
+                                         gemm_bf16, half)
         zr = z.detach().clone().requires_grad_(True)
         zs.append(zr)
         embs.append(row_normalize(zr, r_up, "l2_ball"))
@@ -597,13 +616,27 @@ def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm
     grads = []
     for inp, P, zr, e, ge, run in ((x, towers[0], zs[0], embs[0], gf, running[0]),
                                    (y, towers[1], zs[1], embs[1], gg, running[1])):
-        (dz,) = torch.autograd.grad(e, zr, ge)
-        _, g, (st1, st2) = tower_forward_backward(inp, P, dz, slope, eps, gemm_bf16)
+        (dz,) = torch.autograd.grad(e, zr, ge * (scaler["scale"] if scaler is not None else 1.0))
+        _, g, (st1, st2) = tower_forward_backward(inp, P, dz, slope, eps, gemm_bf16, half)
         grads.append(g)
         for tag, st in (("1", st1), ("2", st2)):
             run["rm" + tag].mul_(1 - bn_momentum).add_(bn_momentum * st[0])
             run["rv" + tag].mul_(1 - bn_momentum).add_(bn_momentum * st[2])
     total = torch.sqrt(sum((g[k].double() ** 2).sum() for g in grads for k in g)).to(x.dtype)
+    if scaler is not None:
+        if not bool(torch.isfinite(total)):  # GradScaler.step() skips optimizer.step(); update() backs the scale off
+            scaler["scale"] *= scaler["backoff_factor"]
+            scaler["growth_tracker"] = 0
+            scaler["steps_skipped"] += 1
+            return (loss, lop, lmet), total
+        inv = 1.0 / scaler["scale"]
+        grads = [{k: gk * inv for k, gk in g.items()} for g in grads]  # scaler.unscale_()
+        total = total * inv
+        scaler["steps_ok"] += 1
+        scaler["growth_tracker"] += 1
+        if scaler["growth_tracker"] == scaler["growth_interval"]:
+            scaler["scale"] *= scaler["growth_factor"]
+            scaler["growth_tracker"] = 0
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0) if max_norm and max_norm > 0 else torch.ones_like(total)
     for P, B, g in zip(towers, bufs, grads):
         for k in g:

@@ -51,11 +51,12 @@ def test_struct_layout_matches_header():
     #include <stdio.h>
     #include "nsvd.h"
     #include <stddef.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nsvd_model_desc), sizeof(nsvd_params),
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nsvd_model_desc), sizeof(nsvd_params),
                        sizeof(nsvd_problem), sizeof(nsvd_tower_params), sizeof(nsvd_rmsprop), sizeof(nsvd_cdk_step_desc),
                        offsetof(nsvd_cdk_step_desc, lr), offsetof(nsvd_cdk_step_desc, gemm_bf16),
                        offsetof(nsvd_rmsprop, state), sizeof(nsvd_step_state), offsetof(nsvd_step_state, cur),
-                       offsetof(nsvd_step_state, ema_decay)); return 0; }
+                       offsetof(nsvd_step_state, ema_decay), offsetof(nsvd_cdk_step_desc, grad_scaler),
+                       sizeof(nsvd_grad_scaler), offsetof(nsvd_grad_scaler, steps_ok)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "t.c")
@@ -68,7 +69,8 @@ def test_struct_layout_matches_header():
                                      ctypes.sizeof(_lib.Rmsprop), ctypes.sizeof(_lib.CdkStepDesc),
                                      _lib.CdkStepDesc.lr.offset, _lib.CdkStepDesc.gemm_bf16.offset,
                                      _lib.Rmsprop.state.offset, ctypes.sizeof(_lib.StepState), _lib.StepState.cur.offset,
-                                     _lib.StepState.ema_decay.offset]
+                                     _lib.StepState.ema_decay.offset, _lib.CdkStepDesc.grad_scaler.offset,
+                                     ctypes.sizeof(_lib.GradScalerState), _lib.GradScalerState.steps_ok.offset]
 
 
 def _torch_ext():

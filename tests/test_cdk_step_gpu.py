@@ -192,6 +192,90 @@ def test_cdk_step_mixed_precision_against_the_oracle_with_the_same_rounding(form
     assert l_amp != l_32 and abs(l_amp - l_32) < 2e-2 * max(1.0, abs(l_32)), (l_amp, l_32)
 
 
+@pytest.mark.parametrize("form", ["fused", "strips"])
+def test_cdk_step_float16_with_the_grad_scaler_against_the_oracle(form, monkeypatch):
+    """FusedCdkStep(use_amp=True, amp_dtype="float16"): the reference's own half type and its GradScaler (main_sketchy.py:
+    161,194-208) - eight steps from a loss scale of 2^24 with growth_interval = 2 and CosineAnnealingLR(T_max = 6):
+    the scaled float16 gradients overflow at 2^24 and fit at 2^23 (margins of 25 % and 50 %: found from the oracle, not
+    a knife edge), so the run SKIPS steps 0, 3 and 6 (nothing may change in them but the scale), takes the other five
+    with the scale doubling every second clean step, and the schedule follows the steps TAKEN. Against
+    oracle.cdk_train_step(half="f16", scaler=...) in float64 with the same roundings and the same scaler arithmetic:
+    every step's loss, unscaled gradient norm (or its non-finiteness), the scaler's trajectory, and the final
+    parameters."""
+    from oracle import nsvd_oracle as O
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.cdk import FusedCdkStep
+    sizes, B, mu, lr, mom, max_norm, slope, T = [128, 256, 256], 256, 16.0, 5e-3, 0.9, 1.0, 0.2, 6
+    if form == "strips":
+        monkeypatch.setenv("NSVD_TOWER16_FUSED", "0")
+    assert H.tower_mixed_fused(B, *sizes, slope) == (form == "fused")
+    omode = "fused" if form == "fused" else True
+    nstep = 8
+    g = torch.Generator().manual_seed(77)
+    xs = torch.randn(nstep, B, sizes[0], generator=g)
+    ys = torch.randn(nstep, B, sizes[0], generator=g)
+    model, method = _build(sizes, mu, 11)
+    sd0 = {k: v.detach().double().cpu().clone() for k, v in model.state_dict().items()}
+    fs = FusedCdkStep(method, lr=lr, momentum=mom, max_grad_norm=max_norm, t_max=T, batch_size=B, use_amp=True,
+                      amp_dtype="float16", init_scale=2.0 ** 24, growth_interval=2)
+    assert fs.scaler is not None and fs.scaler_state()["scale"] == 2.0 ** 24
+    towers = [{k: sd0[f"backbones.{s}.{n}"].clone() for k, n in KEYS.items()} for s in "xy"]
+    bufs = [{k: torch.zeros_like(v) for k, v in t.items()} for t in towers]
+    running = [dict(rm1=sd0[f"backbones.{s}.1.running_mean"].clone(), rv1=sd0[f"backbones.{s}.1.running_var"].clone(),
+                    rm2=sd0[f"backbones.{s}.4.running_mean"].clone(), rv2=sd0[f"backbones.{s}.4.running_var"].clone())
+               for s in "xy"]
+    v, M = method.vector_mask.double().cpu(), method.matrix_mask.double().cpu()
+    sc = dict(scale=2.0 ** 24, growth_factor=2.0, backoff_factor=0.5, growth_interval=2, growth_tracker=0, steps_ok=0,
+              steps_skipped=0)
+    skipped = []
+    for t in range(nstep):
+        before = {k: p.detach().clone() for k, p in model.state_dict().items() if "running" not in k and "num_batches" not in k}
+        got = fs.step(xs[t].to(DEV), ys[t].to(DEV)).cpu().double().clone()
+        st = fs.scaler_state()
+        (loss, lop, lmet), total = O.cdk_train_step(xs[t].double(), ys[t].double(), towers, bufs, running, v, M, mu, lr,
+                                                    mom, max_norm, slope, False, gemm_bf16=omode, half="f16", scaler=sc,
+                                                    t_max=T)
+        assert abs(float(got[0]) - float(loss)) < 2e-4 * max(1.0, abs(float(loss))), (t, float(got[0]), float(loss))
+        assert (st["scale"], st["growth_tracker"], st["steps_ok"], st["steps_skipped"]) == \
+            (sc["scale"], sc["growth_tracker"], sc["steps_ok"], sc["steps_skipped"]), (t, st, sc)
+        if not bool(torch.isfinite(total)):
+            skipped.append(t)
+            assert st["last_found_inf"] == 1 and not np.isfinite(float(got[3]))
+            after = model.state_dict()
+            for k, p in before.items():  # scaler.step() skipped optimizer.step(): no parameter moved
+                assert torch.equal(after[k], p), (t, k)
+        else:
+            assert st["last_found_inf"] == 0
+            assert abs(float(got[3]) - float(total)) < 2e-3 * float(total), (t, float(got[3]), float(total))
+    assert skipped == [0, 3, 6], skipped
+    assert sc["steps_ok"] == 5 and sc["scale"] == 2.0 ** 23
+    fs.flush_counters()
+    sd = {k: p.detach().double().cpu() for k, p in model.state_dict().items()}
+    for si, s in enumerate("xy"):
+        for k, n in KEYS.items():
+            got, want = sd[f"backbones.{s}.{n}"], towers[si][k]
+            move = float((want - sd0[f"backbones.{s}.{n}"]).norm())
+            assert float((got - want).norm()) < 5e-3 * move + 1e-6 * float(want.norm()), (s, k)
+        for i, buf in fs.bufs[si].items():
+            if i in ("b1", "b2"):  # a bias in front of a BatchNorm has a zero gradient: rounding noise on both sides
+                assert float(buf.abs().max()) < 1e-5 and float(bufs[si][i].abs().max()) < 1e-5
+                continue
+            assert rel(buf, bufs[si][i]) < 5e-3, (s, i)
+
+
+def test_float16_mode_refuses_what_it_cannot_do():
+    """a GradScaler needs the mixed-precision step; amp_dtype is one of two names"""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.cdk import FusedCdkStep
+    model, method = _build([128, 256, 256], 16.0, 3)
+    with pytest.raises(H.NsvdError):
+        FusedCdkStep(method, lr=1e-3, batch_size=256, use_amp=False, grad_scaler=True)
+    with pytest.raises(H.NsvdError):
+        FusedCdkStep(method, lr=1e-3, batch_size=256, use_amp=True, amp_dtype="float8")
+    fs = FusedCdkStep(method, lr=1e-3, batch_size=256, use_amp=True, amp_dtype="bfloat16")
+    assert fs.scaler is None and fs.scaler_state() is None
+
+
 @pytest.mark.parametrize("amp", [False, True])
 def test_cdk_step_at_headline_size_against_the_oracle(amp):
     """BASELINE.json configs[4] at its own size (B = 1024, towers 512 -> 8192 -> 512, L = 512 + constant mode): ONE fused

@@ -134,12 +134,15 @@ def test_tower_behind_a_trainable_module_passes_the_gradient_upstream():
                                         # bottleneck towers (d1 < d0): the bfloat16 copy of X is the largest cast
                                         # operand there (round 3's scratch was sized by d1 only and overran)
                                         (512, 512, 256, 256), (256, 1024, 256, 512)])
+@pytest.mark.parametrize("half", ["bf16", "f16"])
 @pytest.mark.parametrize("form", ["fused", "strips"])
-def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, d1, d2, form, monkeypatch):
+def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, d1, d2, form, half, monkeypatch):
     """form: "fused" = the wide layer with BatchNorm inside the contraction (csrc/tower_col.h: Y1 and dA1 never stored,
     the backward recovers the normalised value from the stored activation; what slope > 0 runs); "strips" = the
     contraction + strip kernels (NSVD_TOWER16_FUSED=0; what slope == 0 runs). Each against the float64 oracle that
     restates ITS roundings (include/nsvd.h: nsvd_tower_mixed_fused), at the same tolerances.
+    half: the 16-bit type - bfloat16, or IEEE float16 (gemm_bf16 flag bit 4: the reference's autocast dtype,
+    main_sketchy.py:182; 8 x finer roundings: the float32-mode comparison's lower bound is scaled accordingly).
     gemm_bf16 (the counterpart of the reference's autocast branch, main_sketchy.py:161,182): operands and the wide
     activations / gradients stored as bfloat16, float32 accumulation and statistics (include/nsvd.h). Against the
     float64 oracle that rounds the same tensors (its own intermediates differ from the float32 ones by 1e-7, which moves
@@ -158,7 +161,8 @@ def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, 
     fused = H.tower_mixed_fused(B, d0, d1, d2, 0.2)
     assert fused == (form == "fused")
     zo, go, _ = O.tower_forward_backward(x.double(), {k: v.double() for k, v in P.items()}, dz.double(), 0.2,
-                                         gemm_bf16="fused" if fused else True)
+                                         gemm_bf16="fused" if fused else True, half=half)
+    flag = 1 | (H.TOWER16_F16 if half == "f16" else 0)
     Pd = {k: v.to(DEV).contiguous() for k, v in P.items()}
     for k, n in (("rm1", d1), ("rv1", d1), ("rm2", d2), ("rv2", d2)):
         Pd[k] = torch.zeros(n, device=DEV) if k.startswith("rm") else torch.ones(n, device=DEV)
@@ -169,8 +173,8 @@ def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, 
     xd, dzd = x.to(DEV), dz.to(DEV)
     res = {}
     for mixed in (True, False):
-        z = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=mixed)
-        res[mixed] = (z.clone(), H.tower_backward(xd, Pd, dzd, 0.2, ws, gemm_bf16=mixed))
+        z = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=flag if mixed else 0)
+        res[mixed] = (z.clone(), H.tower_backward(xd, Pd, dzd, 0.2, ws, gemm_bf16=flag if mixed else 0))
     torch.cuda.synchronize()
     assert bool((buf[nws:] == 0xA5).all()), "a tower kernel wrote past its workspace"
     z, grads = res[True]
@@ -179,18 +183,22 @@ def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, 
         assert rel(grads[k], go[k]) < 2e-3, (k, rel(grads[k], go[k]))
     # the two modes: different by the operand rounding, and only by that
     z32, g32 = res[False]
-    assert 1e-4 < rel(z, z32) < 2e-2, rel(z, z32)
-    assert 1e-4 < rel(grads["W2"], g32["W2"]) < 5e-2
+    lo = 1e-4 if half == "bf16" else 1e-5
+    assert lo < rel(z, z32) < 2e-2, rel(z, z32)
+    assert lo < rel(grads["W2"], g32["W2"]) < 5e-2
     # bit reproducibility
-    z2 = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=True)
+    z2 = H.tower_forward(xd, Pd, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=flag)
     assert torch.equal(z, z2)
 
 
-def test_tower_module_under_autocast_runs_the_mixed_precision_mode():
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_tower_module_under_autocast_runs_the_mixed_precision_mode(dtype):
     """the reference's Sketchy loop wraps method(x, y) in torch.cuda.amp.autocast (+ GradScaler) unless --disable_amp:
-    inside autocast the tower module takes the mixed-precision mode (same bits as the C call with gemm_bf16 = 1), its
-    output stays float32, and a GradScaler-style scaled backward gives the unscaled gradients back exactly (the scale is
-    a power of two)."""
+    inside autocast the tower module takes the mixed-precision mode with the AUTOCAST dtype as its half type (float16 -
+    the reference's - or bfloat16: same bits as the C call with gemm_bf16 = 1 | 16 / 1), its output stays float32, and
+    a GradScaler-style scaled backward gives the unscaled gradients back exactly (the scale is a power of two; float16:
+    as long as nothing overflows - a scale that does overflow comes back as non-finite gradients, which is what
+    torch's GradScaler looks for)."""
     from neural_svd_amd import hip_ops as H
     from neural_svd_amd.cdk import get_mlp
     torch.manual_seed(3)
@@ -203,15 +211,27 @@ def test_tower_module_under_autocast_runs_the_mixed_precision_mode():
                          ("rv2", m[4], "running_var")):
         P[k] = getattr(mod, attr).detach().clone()
     ws = H.tower_workspace(256, 128, 256, 256, DEV)
-    want = H.tower_forward(x, P, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=True)
-    gwant = H.tower_backward(x, P, dz, 0.2, ws, gemm_bf16=True)
-    with torch.autocast("cuda", dtype=torch.float16):
+    flag = 1 | (H.TOWER16_F16 if dtype == torch.float16 else 0)
+    scale = 65536.0 if dtype == torch.bfloat16 else 8.0  # (dz ~ N(0, 1) here: 65536 dz overflows float16)
+    want = H.tower_forward(x, P, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=flag)
+    gwant = H.tower_backward(x, P, dz, 0.2, ws, gemm_bf16=flag)
+    with torch.autocast("cuda", dtype=dtype):
         out = m(x)
     assert out.dtype == torch.float32 and torch.equal(out, want)
-    (out * dz * 65536.0).sum().backward()
+    (out * dz * scale).sum().backward()
     for k, n in NAMES.items():
-        assert torch.equal(dict(m.named_parameters())[n].grad / 65536.0, gwant[k]), k
+        got = dict(m.named_parameters())[n].grad / scale
+        if dtype == torch.bfloat16:
+            assert torch.equal(got, gwant[k]), k
+        else:  # (float16 has subnormals at 6e-5: the smallest stored gradients round differently under a scale)
+            assert rel(got, gwant[k]) < 1e-3, (k, rel(got, gwant[k]))
     m.zero_grad()
+    if dtype == torch.float16:  # a loss scale the float16 gradients cannot hold: non-finite parameter gradients
+        with torch.autocast("cuda", dtype=dtype):
+            out = m(x)
+        (out * dz * 2.0 ** 20).sum().backward()
+        assert not bool(torch.isfinite(dict(m.named_parameters())[NAMES["W1"]].grad).all())
+        m.zero_grad()
     out32 = m(x)  # outside autocast: float32 contractions
     assert not torch.equal(out32, out) and rel(out32.detach(), out.detach()) < 2e-2
 
