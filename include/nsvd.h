@@ -566,21 +566,23 @@ typedef struct nsvd_cdk_step_desc {
     int32_t gemm_bf16;            /* != 0: the towers in mixed precision (nsvd_tower_forward; bit 1: this workspace's
                                    * bfloat16 weight copies are those the previous nsvd_cdk_step call left; bit 4,
                                    * value 16: the half type is IEEE float16 instead of bfloat16) */
-    int32_t sched_t_max;          /* with grad_scaler only: > 0 = CosineAnnealingLR(T_max) from `lr` over the scaler's
-                                   * count of optimiser steps TAKEN (eta_min 0); 0 = `lr` as given */
+    int32_t reserved0;
     void* grad_scaler;            /* NULL, or a DEVICE nsvd_grad_scaler: the step runs with loss scaling (below) */
 } nsvd_cdk_step_desc;
 /* torch.cuda.amp.GradScaler's state and arithmetic on the device - the reference's AMP branch, on by default in the
  * Sketchy script (examples/cdk/sketchy/main_sketchy.py:161 scaler = GradScaler(enabled=use_amp); :194-208
  * scaler.scale(loss).backward(); scaler.unscale_(optimizer); clip_grad_norm_; scaler.step(optimizer); scaler.update();
- * the scheduler steps only when the optimiser did). With desc.grad_scaler set, nsvd_cdk_step
+ * lr_scheduler.step() on EVERY iteration, skipped or not, :205-206 - this script has no scheduler gate, unlike the PDE
+ * loop's examples/operator/__init__.py:66-72: desc.lr stays the caller's scheduled value of the iteration). With
+ * desc.grad_scaler set, nsvd_cdk_step
  *   - multiplies the loss gradient by `scale` where the backward starts (every stored 16-bit gradient is scaled),
  *   - takes found_inf = the gradient norm (of the scaled gradients, float32) is not finite,
  *   - found_inf: NO parameter, momentum buffer or weight copy is written (scaler.step skips optimizer.step()), scale *=
- *     backoff_factor, growth_tracker = 0, steps_skipped += 1 - and the schedule does not advance;
+ *     backoff_factor, growth_tracker = 0, steps_skipped += 1;
  *   - otherwise: gradients * (1 / scale), then the clip coefficient and the SGD update as without scaling; steps_ok += 1,
  *     growth_tracker += 1 and at growth_interval: scale *= growth_factor, growth_tracker = 0 (GradScaler.update()).
- *   desc.first_step is ignored (the momentum buffers start at steps_ok == 0), desc.lr is the base learning rate.
+ *   desc.first_step is ignored: the momentum buffers start with the first step TAKEN (steps_ok == 0), as torch.optim.SGD
+ *   creates them in its first executed step().
  * The loss values reported are unscaled. Needs the mixed-precision step with the fused narrow end (B % 8 == 0,
  * d2 % 64 == 0, d2 <= 1024), NSVD_EUNSUPPORTED otherwise. Read the state back with a device-to-host copy. */
 typedef struct nsvd_grad_scaler {

@@ -52,7 +52,7 @@ class CdkStepDesc(C.Structure):
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("mu", C.c_float), ("normalize_mode", C.c_int32),
                 ("set_first_mode_const", C.c_int32), ("lr", C.c_double), ("momentum", C.c_double),
                 ("max_grad_norm", C.c_double), ("first_step", C.c_int32), ("gemm_bf16", C.c_int32),
-                ("sched_t_max", C.c_int32), ("grad_scaler", C.c_void_p)]
+                ("reserved0", C.c_int32), ("grad_scaler", C.c_void_p)]
 
 
 class GradScalerState(C.Structure):

@@ -353,11 +353,11 @@ class FusedCdkStep:
     amp_dtype (with use_amp): "bfloat16" (default: the mode above) or "float16" - the reference's own half type. With
     float16 the step runs the reference's GradScaler as well (grad_scaler=None -> on; a hip_ops.GradScaler to share or
     pre-set one; False -> off): the loss gradient is multiplied by the scale where the backward starts, a step whose
-    (scaled) gradient norm is inf / NaN is SKIPPED as a whole - no parameter, momentum buffer or schedule position
-    changes, the scale halves - otherwise the gradients are unscaled before the clip and the scale doubles every
+    (scaled) gradient norm is inf / NaN is SKIPPED as a whole - no parameter or momentum buffer
+    changes (the schedule still advances), the scale halves - otherwise the gradients are unscaled before the clip and the scale doubles every
     growth_interval clean steps (main_sketchy.py:194-208; torch defaults 65536 / 2 / 0.5 / 2000). All of it on the
-    device: ``scaler_state()`` reads it back. The learning-rate schedule then follows the count of steps TAKEN, as the
-    script's scheduler gate does. Same kernels as the bfloat16 mode with the float16 MFMA; pinned to the float64 oracle
+    device: ``scaler_state()`` reads it back. The learning-rate schedule advances on every iteration, skipped or not,
+    as the script's does (main_sketchy.py:205-206: no scheduler gate there, unlike the PDE loop). Same kernels as the bfloat16 mode with the float16 MFMA; pinned to the float64 oracle
     with the same roundings and the same scaler arithmetic (oracle.cdk_train_step(half="f16", scaler=...))."""
 
     def __init__(self, method: "NestedLoRAForCDK", lr: float, momentum: float = 0.9, max_grad_norm: float = 1.0,
@@ -448,16 +448,16 @@ class FusedCdkStep:
         flags = ((3 if weights_ready else 1) | (H.TOWER16_F16 if self.amp_f16 else 0)) if self.use_amp else 0
         return H.cdk_step_desc(self.B, self.d0, self.d1, self.d2, self.slope, self.bn_eps, self.bn_momentum,
                                self.model.mu, self.mode, self.first_const, lr, self.momentum, self.max_grad_norm, first,
-                               gemm_bf16=flags, grad_scaler=self.scaler, sched_t_max=self.t_max if self.scaler else 0)
+                               gemm_bf16=flags, grad_scaler=self.scaler)
 
     def scaler_state(self):
         """the GradScaler's device state (synchronises), or None without one"""
         return self.scaler.state() if self.scaler is not None else None
 
     def current_lr(self) -> float:
-        """CosineAnnealingLR(optimizer, t_max) after self.t scheduler steps (t_max = 0: constant). With a GradScaler the
-        schedule lives on the device and follows the steps TAKEN: this returns the base rate it starts from."""
-        if self.t_max <= 0 or self.scaler is not None:
+        """CosineAnnealingLR(optimizer, t_max) after self.t scheduler steps (t_max = 0: constant). The Sketchy script
+        steps its scheduler on every iteration, skipped by the GradScaler or not (main_sketchy.py:205-206)."""
+        if self.t_max <= 0:
             return self.lr0
         return self.lr0 * (1.0 + math.cos(math.pi * self.t / self.t_max)) / 2.0
 

@@ -53,17 +53,16 @@ __global__ void __launch_bounds__(256) cdk_sumsq_kernel(TensorTable t, float* __
 __global__ void __launch_bounds__(256) cdk_sgd_kernel(TensorTable t, const float* __restrict__ partial, int npartial,
                                                       float max_norm, float* __restrict__ scal,
                                                       float* __restrict__ loss_out, float lr, float momentum, int first,
-                                                      NsvdCdkLossParts lp, const nsvd_grad_scaler* gs, int t_max) {
+                                                      NsvdCdkLossParts lp, const nsvd_grad_scaler* gs) {
     __shared__ double red[256];
     __shared__ float coef_s;
-    // loss scaling (include/nsvd.h: nsvd_grad_scaler): the gradients carry the factor `scale`; the schedule and the
-    // momentum buffers' first step follow the count of steps TAKEN. The state is only READ here (every workgroup the
-    // same values): cdk_scaler_update_kernel advances it behind this kernel.
+    // loss scaling (include/nsvd.h: nsvd_grad_scaler): the gradients carry the factor `scale`; the momentum buffers
+    // start with the first step TAKEN. The state is only READ here (every workgroup the same values):
+    // cdk_scaler_update_kernel advances it behind this kernel.
     float inv_scale = 1.f;
     if (gs) {
         inv_scale = 1.0f / gs->scale;
         first = gs->steps_ok == 0;
-        if (t_max > 0) lr = 0.5f * lr * (1.f + cospif((float)gs->steps_ok / (float)t_max));
     }
     // the step's loss value: the loss kernels left per-block partials (no reduction launch of their own)
     if (blockIdx.x == 0 && loss_out && lp.part_op) nsvd_cdk_loss_sum(lp, reinterpret_cast<float*>(red), loss_out);
@@ -392,7 +391,7 @@ extern "C" int nsvd_cdk_step(const nsvd_cdk_step_desc* d, const float* x, const 
     if (blocks > 2048) blocks = 2048;  // (each workgroup first adds the partials for itself: not too many of them)
     hipLaunchKernelGGL(cdk_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, part0, npart,
                        (float)d->max_grad_norm, w.scal, loss, (float)d->lr, (float)d->momentum, d->first_step, lparts,
-                       (const nsvd_grad_scaler*)d->grad_scaler, d->sched_t_max);
+                       (const nsvd_grad_scaler*)d->grad_scaler);
     NSVD_CHECK_LAUNCH();
     if (d->grad_scaler) {
         hipLaunchKernelGGL(cdk_scaler_update_kernel, dim3(1), dim3(1), 0, s, (nsvd_grad_scaler*)d->grad_scaler, w.scal);

@@ -969,7 +969,7 @@ class GradScaler:
         return self.buf.data_ptr()
 
     def state(self) -> dict:
-        """(synchronises) scale, growth_tracker, steps_ok (optimiser = scheduler steps taken), steps_skipped, ..."""
+        """(synchronises) scale, growth_tracker, steps_ok (optimiser steps taken), steps_skipped, ..."""
         raw = self.buf.cpu().numpy().tobytes()
         st = _lib.GradScalerState.from_buffer_copy(raw)
         return {n: getattr(st, n) for n, _ in _lib.GradScalerState._fields_}
@@ -977,8 +977,7 @@ class GradScaler:
 
 def cdk_step_desc(B: int, d0: int, d1: int, d2: int, slope: float, bn_eps: float, bn_momentum: float, mu: float,
                   normalize_mode: int, set_first_mode_const: bool, lr: float, momentum: float, max_grad_norm: float,
-                  first_step: bool, gemm_bf16: int = 0, grad_scaler: Optional["GradScaler"] = None,
-                  sched_t_max: int = 0) -> "_lib.CdkStepDesc":
+                  first_step: bool, gemm_bf16: int = 0, grad_scaler: Optional["GradScaler"] = None) -> "_lib.CdkStepDesc":
     d = _lib.CdkStepDesc()
     d.B, d.d0, d.d1, d.d2 = int(B), int(d0), int(d1), int(d2)
     d.slope, d.bn_eps, d.bn_momentum, d.mu = float(slope), float(bn_eps), float(bn_momentum), float(mu)
@@ -986,7 +985,6 @@ def cdk_step_desc(B: int, d0: int, d1: int, d2: int, slope: float, bn_eps: float
     d.lr, d.momentum, d.max_grad_norm = float(lr), float(momentum), float(max_grad_norm or 0.0)
     d.first_step = int(bool(first_step))
     d.gemm_bf16 = int(gemm_bf16)
-    d.sched_t_max = int(sched_t_max)
     d.grad_scaler = grad_scaler.ptr if grad_scaler is not None else None
     return d
 

@@ -584,7 +584,7 @@ def tower_forward_backward(x, P, dz, slope, eps=1e-5, gemm_bf16=False, half="bf1
 
 
 def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm, slope, first_step, eps=1e-5,
-                   bn_momentum=0.1, gemm_bf16=False, half="bf16", scaler=None, t_max=0):
+                   bn_momentum=0.1, gemm_bf16=False, half="bf16", scaler=None):
     """One Sketchy-style CDK training step (reference examples/cdk/sketchy/main_sketchy.py:180-212 with
     scripts/exps/sketchy.sh's switches, AMP off): two towers (get_mlp, examples/models/mlp.py:129-164) behind Identity
     projectors and normalize('l2_ball', sqrt(mu)) (examples/models/siam.py:156-183), NestedLoRAForCDK loss
@@ -595,16 +595,14 @@ def cdk_train_step(x, y, towers, bufs, running, v, M, mu, lr, momentum, max_norm
     Returns (loss, operator term, metric term), total gradient norm. Pinned by tests/golden/cdk_step.npz.
     scaler: None, or a dict - torch.cuda.amp.GradScaler as the script's AMP branch drives it (main_sketchy.py:161,194-208:
     scaler.scale(loss).backward(); scaler.unscale_(optimizer); clip_grad_norm_; scaler.step(optimizer); scaler.update();
-    the scheduler steps only with the optimiser) with keys scale, growth_factor, backoff_factor, growth_interval,
+    lr_scheduler.step() on every iteration, :205-206 - `lr` stays the caller's scheduled value) with keys scale, growth_factor, backoff_factor, growth_interval,
     growth_tracker, steps_ok, steps_skipped (updated in place): the loss gradient is multiplied by scale before the
     towers' backward; found_inf = the norm of the SCALED gradients is not finite -> nothing is updated, scale *= backoff;
     else gradients * (1 / scale), clip, SGD, steps_ok += 1, and every growth_interval clean steps scale *= growth.
-    `lr` is then the BASE rate (t_max > 0: cosine over steps_ok) and first_step is steps_ok == 0."""
+    first_step is then steps_ok == 0 (torch.optim.SGD creates its momentum buffers in the first step it executes)."""
     r_up = float(mu) ** 0.5
     if scaler is not None:
         first_step = scaler["steps_ok"] == 0
-        if t_max > 0:
-            lr = cosine_lr(lr, scaler["steps_ok"], t_max)
     zs, embs = [], []
     for inp, P in ((x, towers[0]), (y, towers[1])):
         z, _, _ = tower_forward_backward(inp, P, torch.zeros(inp.shape[0], P["W2"].shape[0], dtype=inp.dtype), slope, eps,

@@ -575,6 +575,93 @@ def golden_cdk_step(out):
                 out[q + f"buf_{k}"] = a
 
 
+def golden_amp(out):
+    """The reference's AMP branch (on by default in the Sketchy script: examples/cdk/sketchy/main_sketchy.py:161,182,
+    194-208) run HERE, on the CPU: torch.cuda.amp.autocast disables itself without a CUDA device, so the same modules run
+    under torch.autocast("cpu", dtype=torch.float16) - Linear / BatchNorm / LeakyReLU outputs are float16 tensors, the
+    masters float32, as under CUDA autocast - with torch.amp.GradScaler("cpu") in GradScaler's place. Not the CUDA kernels'
+    bits (accumulation orders differ), but the reference's own code and torch's own autocast / GradScaler semantics.
+      amp_tower_*: get_mlp([128, 256, 256], lrelu0.2, BatchNorm) forward + backward of sum(dz * z) on 256 rows.
+      amp_step_*:  eight iterations of the loop body of main_sketchy.py:180-212 (sgd momentum 0.9, clip_grad_norm 1,
+                   CosineAnnealingLR(T_max = 6) stepped EVERY iteration as the script does) from torch's default loss scale
+                   of 2^16 with growth_interval = 2 (the scale doubles every second iteration up to 2^20; nothing
+                   overflows - under autocast the reference's LOSS runs in float16 as well, so its overflow threshold,
+                   between 2^20 and 2^21 here, is not that of a build whose loss is float32: skip patterns beyond it are
+                   not comparable): per iteration the loss, the unscaled total norm, the scale after update(); the
+                   parameters after the last one. Initial weights: torch.manual_seed(seed) + the constructor calls."""
+    from examples.models.mlp import get_mlp
+    from examples.models.siam import HeteroNetwork
+    from methods.nestedlora import NestedLoRAForCDK
+    sizes, B, slope = [128, 256, 256], 256, 0.2
+    # ---- tower
+    seed = 51
+    g = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(B, sizes[0], generator=g)
+    dz = torch.randn(B, sizes[2], generator=g)
+    out["amp_tower_cfg"] = np.array([B, sizes[0], sizes[1], sizes[2], seed])
+    out["amp_tower_x"], out["amp_tower_dz"] = x.numpy(), dz.numpy()
+    for tag in ("f16", "f64"):
+        torch.manual_seed(seed)
+        m = get_mlp(sizes=sizes, bias=True, nonlinearity=f"lrelu{slope}", use_bn=True)
+        with torch.no_grad():
+            gg = torch.Generator().manual_seed(2000 + seed)
+            for k in (1, 4):
+                m[k].weight.copy_(1.0 + 0.3 * torch.randn(m[k].weight.shape, generator=gg))
+                m[k].bias.copy_(0.2 * torch.randn(m[k].bias.shape, generator=gg))
+        if tag == "f16":
+            for k, v in m.state_dict().items():
+                if "num_batches" not in k:
+                    out[f"amp_tower_param0_{k}"] = v.detach().numpy().copy()
+            m = m.train()
+            with torch.autocast("cpu", dtype=torch.float16):
+                z = m(x)
+            assert z.dtype == torch.float16
+            (z.float() * dz).sum().backward()
+        else:
+            m = m.double().train()
+            z = m(x.double())
+            (z * dz.double()).sum().backward()
+        q = f"amp_tower_{tag}_"
+        out[q + "z"] = np64(z)
+        for k, v in m.named_parameters():
+            out[q + f"grad_{k}"] = np64(v.grad)
+    # ---- training iterations with the GradScaler
+    seed, mu, lr, T, nstep = 11, 16.0, 5e-3, 6, 8
+    g = torch.Generator().manual_seed(77)
+    xs = torch.randn(nstep, B, sizes[0], generator=g)
+    ys = torch.randn(nstep, B, sizes[0], generator=g)
+    out["amp_step_cfg"] = np.array([B, sizes[0], sizes[1], sizes[2], seed, nstep, T])
+    out["amp_step_hyper"] = np.array([mu, lr, 0.9, 1.0, slope, 2.0 ** 16, 2.0])  # .. init scale, growth interval
+    torch.manual_seed(seed)
+    model = HeteroNetwork(backbones=[get_mlp(sizes=sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True),
+                                     get_mlp(sizes=sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True)],
+                          projectors=[nn.Identity(), nn.Identity()], mu=mu, regularize_mode="l2_ball").train()
+    method = NestedLoRAForCDK(model, neigs=sizes[-1], step=1, sequential=False, set_first_mode_const=True)
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T)
+    scaler = torch.amp.GradScaler("cpu", init_scale=2.0 ** 16, growth_interval=2)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rows = []
+    for t in range(nstep):
+        opt.zero_grad()
+        with torch.autocast("cpu", dtype=torch.float16):
+            _, fx, _, fy = method(xs[t], ys[t])
+            loss, lop, lmet, rj, ri = method.compute_loss(fx, fy)
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        total_norm = nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        scaler.step(opt)
+        scaler.update()
+        sched.step()
+        rows.append([float(loss), float(total_norm), float(scaler.get_scale())])
+    out["amp_step_rows"] = np.array(rows)  # loss | unscaled total norm (inf / nan: skipped) | scale after update()
+    for k, v in model.state_dict().items():
+        if "num_batches" in k:
+            continue
+        out[f"amp_step_param_{k}"] = v.detach().numpy()[..., ::3].copy() if v.dim() == 2 else v.detach().numpy().copy()
+        out[f"amp_step_move_{k}"] = np.array(float((v.detach() - sd0[k]).double().norm()))
+
+
 def golden_ground_truth(out):
     out["gt_hydrogen2d_64"] = Hydrogen2D(charge=1.0).get_eigvals(64)
     out["gt_hydrogen2d_z2_9"] = Hydrogen2D(charge=2.0).get_eigvals(9)
@@ -607,6 +694,12 @@ def main():
         golden_kernel_loss(o)
         np.savez_compressed(os.path.join(HERE, "kernel_loss.npz"), **o)
         print("kernel_loss", os.path.getsize(os.path.join(HERE, "kernel_loss.npz")) // 1024, "KiB")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "amp":
+        o = {}
+        golden_amp(o)
+        np.savez_compressed(os.path.join(HERE, "amp.npz"), **o)
+        print("amp", os.path.getsize(os.path.join(HERE, "amp.npz")) // 1024, "KiB")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "loss_indep":
         o = {}
@@ -646,6 +739,9 @@ def main():
     o = {}
     golden_loss_indep(o)
     np.savez_compressed(os.path.join(HERE, "evd_loss_indep.npz"), **o)
+    o = {}
+    golden_amp(o)
+    np.savez_compressed(os.path.join(HERE, "amp.npz"), **o)
 
     o = {}
     golden_ground_truth(o)
@@ -698,7 +794,7 @@ def main():
                  fourier_scale=1.0, sampling_scale=4.0, batch_size=7, operator_scale=1.0, operator_shift=16.0,
                  apply_exp_mask=1, exp_mask_init_scale=10.0, sequential=0, seed=9)
     np.savez_compressed(os.path.join(HERE, "model_exact.npz"), **o)
-    for fn in ("tower", "kernel_loss", "masks", "evd_loss", "evd_loss_indep", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
+    for fn in ("tower", "kernel_loss", "masks", "evd_loss", "evd_loss_indep", "amp", "cdk_loss", "svd_loss", "normalize", "misc", "model_small", "model_headline", "model_exact"):
         p = os.path.join(HERE, fn + ".npz")
         print(fn, os.path.getsize(p) // 1024, "KiB")
 

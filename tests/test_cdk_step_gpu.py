@@ -198,7 +198,8 @@ def test_cdk_step_float16_with_the_grad_scaler_against_the_oracle(form, monkeypa
     161,194-208) - eight steps from a loss scale of 2^24 with growth_interval = 2 and CosineAnnealingLR(T_max = 6):
     the scaled float16 gradients overflow at 2^24 and fit at 2^23 (margins of 25 % and 50 %: found from the oracle, not
     a knife edge), so the run SKIPS steps 0, 3 and 6 (nothing may change in them but the scale), takes the other five
-    with the scale doubling every second clean step, and the schedule follows the steps TAKEN. Against
+    with the scale doubling every second clean step, and the schedule advances on EVERY iteration as the script's does
+    (main_sketchy.py:205-206). Against
     oracle.cdk_train_step(half="f16", scaler=...) in float64 with the same roundings and the same scaler arithmetic:
     every step's loss, unscaled gradient norm (or its non-finiteness), the scaler's trajectory, and the final
     parameters."""
@@ -232,9 +233,9 @@ def test_cdk_step_float16_with_the_grad_scaler_against_the_oracle(form, monkeypa
         before = {k: p.detach().clone() for k, p in model.state_dict().items() if "running" not in k and "num_batches" not in k}
         got = fs.step(xs[t].to(DEV), ys[t].to(DEV)).cpu().double().clone()
         st = fs.scaler_state()
-        (loss, lop, lmet), total = O.cdk_train_step(xs[t].double(), ys[t].double(), towers, bufs, running, v, M, mu, lr,
-                                                    mom, max_norm, slope, False, gemm_bf16=omode, half="f16", scaler=sc,
-                                                    t_max=T)
+        (loss, lop, lmet), total = O.cdk_train_step(xs[t].double(), ys[t].double(), towers, bufs, running, v, M, mu,
+                                                    O.cosine_lr(lr, t, T), mom, max_norm, slope, False, gemm_bf16=omode,
+                                                    half="f16", scaler=sc)
         assert abs(float(got[0]) - float(loss)) < 2e-4 * max(1.0, abs(float(loss))), (t, float(got[0]), float(loss))
         assert (st["scale"], st["growth_tracker"], st["steps_ok"], st["steps_skipped"]) == \
             (sc["scale"], sc["growth_tracker"], sc["steps_ok"], sc["steps_skipped"]), (t, st, sc)
@@ -261,6 +262,46 @@ def test_cdk_step_float16_with_the_grad_scaler_against_the_oracle(form, monkeypa
                 assert float(buf.abs().max()) < 1e-5 and float(bufs[si][i].abs().max()) < 1e-5
                 continue
             assert rel(buf, bufs[si][i]) < 5e-3, (s, i)
+
+
+@pytest.mark.parametrize("form", ["fused", "strips"])
+def test_cdk_step_float16_against_the_references_amp_loop(form, monkeypatch):
+    """tests/golden/amp.npz: eight iterations of the REFERENCE's Sketchy loop body with its AMP branch on
+    (main_sketchy.py:161,180-212: float16 autocast, GradScaler from 2^16 with growth_interval 2, clip_grad_norm_, SGD
+    momentum, CosineAnnealingLR stepped every iteration) - run on the CPU where the fixture was made. FusedCdkStep(
+    use_amp=True, amp_dtype="float16") from the same weights and batches: the scale's trajectory exactly, the unscaled
+    gradient norms to 2e-4, the losses to 3e-3 (under autocast the reference's loss itself is float16 arithmetic; here
+    it is float32), every parameter's update to 1 % of its length."""
+    from neural_svd_amd import hip_ops as H
+    from neural_svd_amd.cdk import FusedCdkStep
+    if form == "strips":
+        monkeypatch.setenv("NSVD_TOWER16_FUSED", "0")
+    z = G.load("amp")
+    B, d0, d1, d2, seed, nstep, T = [int(v) for v in z["amp_step_cfg"]]
+    mu, lr, mom, max_norm, slope, init_scale, gi = [float(v) for v in z["amp_step_hyper"]]
+    assert H.tower_mixed_fused(B, d0, d1, d2, slope) == (form == "fused")
+    model, method = _build([d0, d1, d2], mu, seed)
+    g = torch.Generator().manual_seed(77)
+    xs, ys = torch.randn(nstep, B, d0, generator=g), torch.randn(nstep, B, d0, generator=g)
+    fs = FusedCdkStep(method, lr=lr, momentum=mom, max_grad_norm=max_norm, t_max=T, batch_size=B, use_amp=True,
+                      amp_dtype="float16", init_scale=init_scale, growth_interval=int(gi))
+    for t in range(nstep):
+        got = fs.step(xs[t].to(DEV), ys[t].to(DEV)).cpu().double().clone()
+        want = z["amp_step_rows"][t]
+        assert abs(float(got[0]) - want[0]) < 3e-3 * abs(want[0]), (t, float(got[0]), want[0])
+        assert abs(float(got[3]) - want[1]) < 2e-4 * want[1], (t, float(got[3]), want[1])
+        assert fs.scaler_state()["scale"] == want[2], (t, fs.scaler_state(), want[2])
+    assert fs.scaler_state()["steps_skipped"] == 0 and fs.scaler_state()["steps_ok"] == nstep
+    sd = {k: p.detach().double().cpu() for k, p in model.state_dict().items()}
+    for s in "xy":
+        for k, n in KEYS.items():
+            if k in ("b1", "b2"):
+                continue  # (a bias in front of a BatchNorm: zero gradient, rounding noise only)
+            ref = torch.tensor(z[f"amp_step_param_backbones.{s}.{n}"]).double()
+            got = sd[f"backbones.{s}.{n}"]
+            got = got[..., ::3] if got.dim() == 2 else got
+            move = float(z[f"amp_step_move_backbones.{s}.{n}"])
+            assert float((got - ref).norm()) < 1e-2 * move, (s, k, float((got - ref).norm()) / move)
 
 
 def test_float16_mode_refuses_what_it_cannot_do():

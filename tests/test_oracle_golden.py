@@ -453,3 +453,71 @@ def test_cdk_train_step_matches_reference(name):
         for rk, n in (("rm1", "1.running_mean"), ("rv1", "1.running_var"), ("rm2", "4.running_mean"), ("rv2", "4.running_var")):
             got, want = R[rk].numpy(), z[q + f"param_backbones.{side}.{n}"]
             assert np.allclose(got.reshape(-1)[::5] if name == "sb" else got, want, rtol=1e-9, atol=1e-12), rk
+
+
+# ------------------------------------------------------------------ the reference's AMP branch (float16 autocast + GradScaler)
+TOWER_KEYS = {"W1": "0.weight", "b1": "0.bias", "g1": "1.weight", "be1": "1.bias", "W2": "3.weight", "b2": "3.bias",
+              "g2": "4.weight", "be2": "4.bias"}
+
+
+@pytest.mark.parametrize("mode", [True, "fused"])
+def test_tower_float16_modes_against_the_references_autocast_run(mode):
+    """tests/golden/amp.npz (make_golden.golden_amp): the reference's tower under torch.autocast(float16) on the CPU - its
+    own modules, torch's own autocast placement of the float16 roundings. The oracle's two float16 modes must be at
+    least as close to that run as that run is to float64 arithmetic (its own rounding error is the yardstick)."""
+    z = G.load("amp")
+    P = {k: torch.tensor(z["amp_tower_param0_" + n]).double() for k, n in TOWER_KEYS.items()}
+    x, dz = torch.tensor(z["amp_tower_x"]).double(), torch.tensor(z["amp_tower_dz"]).double()
+    zo, go, _ = O.tower_forward_backward(x, P, dz, 0.2, gemm_bf16=mode, half="f16")
+    assert G.rel(zo.numpy(), z["amp_tower_f16_z"]) <= G.rel(z["amp_tower_f16_z"], z["amp_tower_f64_z"]) + 2e-4
+    for k, n in TOWER_KEYS.items():
+        if k in ("b1", "b2"):
+            continue  # (a bias in front of a BatchNorm: zero gradient, rounding noise only)
+        ref, exact = z["amp_tower_f16_grad_" + n], z["amp_tower_f64_grad_" + n]
+        assert G.rel(go[k].numpy(), ref) <= G.rel(ref, exact) + 2e-4, (k, G.rel(go[k].numpy(), ref), G.rel(ref, exact))
+
+
+@pytest.mark.parametrize("mode", [True, "fused"])
+def test_cdk_step_float16_grad_scaler_against_the_references_amp_loop(mode):
+    """amp.npz: eight iterations of the Sketchy loop body with its AMP branch on (main_sketchy.py:161,180-212; CPU float16
+    autocast, torch.amp.GradScaler from 2^16 with growth_interval 2). The oracle's float16 + scaler step from the same
+    weights and batches: the scale's trajectory exactly, the unscaled gradient norms to 2e-4, the losses to 3e-3 (under
+    autocast the reference's loss itself is float16 arithmetic), every parameter's update to 1 % of its length."""
+    import torch.nn as nn
+    from neural_svd_amd.cdk import HeteroNetwork, get_mlp
+    z = G.load("amp")
+    B, d0, d1, d2, seed, nstep, T = [int(v) for v in z["amp_step_cfg"]]
+    mu, lr, mom, max_norm, slope, init_scale, gi = [float(v) for v in z["amp_step_hyper"]]
+    torch.manual_seed(seed)  # the reference's constructor calls in the reference's order: same initial weights
+    sizes = [d0, d1, d2]
+    model = HeteroNetwork([get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True),
+                           get_mlp(sizes, bias=True, nonlinearity="lrelu0.2", use_bn=True)],
+                          [nn.Identity(), nn.Identity()], mu=mu, regularize_mode="l2_ball").train()
+    sd0 = {k: v.detach().double().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(77)
+    xs, ys = torch.randn(nstep, B, d0, generator=g), torch.randn(nstep, B, d0, generator=g)
+    v, M = O.cdk_masks(d2, False, 1, True)
+    towers = [{k: sd0[f"backbones.{s}.{n}"].clone() for k, n in TOWER_KEYS.items()} for s in "xy"]
+    bufs = [{k: torch.zeros_like(t_) for k, t_ in t.items()} for t in towers]
+    running = [dict(rm1=sd0[f"backbones.{s}.1.running_mean"].clone(), rv1=sd0[f"backbones.{s}.1.running_var"].clone(),
+                    rm2=sd0[f"backbones.{s}.4.running_mean"].clone(), rv2=sd0[f"backbones.{s}.4.running_var"].clone())
+               for s in "xy"]
+    sc = dict(scale=init_scale, growth_factor=2.0, backoff_factor=0.5, growth_interval=int(gi), growth_tracker=0,
+              steps_ok=0, steps_skipped=0)
+    for t in range(nstep):
+        (loss, _, _), total = O.cdk_train_step(xs[t].double(), ys[t].double(), towers, bufs, running, v.double(),
+                                               M.double(), mu, O.cosine_lr(lr, t, T), mom, max_norm, slope, False,
+                                               gemm_bf16=mode, half="f16", scaler=sc)
+        want = z["amp_step_rows"][t]
+        assert abs(float(loss) - want[0]) < 3e-3 * abs(want[0]), (t, float(loss), want[0])
+        assert abs(float(total) - want[1]) < 2e-4 * want[1], (t, float(total), want[1])
+        assert sc["scale"] == want[2], (t, sc["scale"], want[2])
+    assert sc["steps_skipped"] == 0
+    for si, s in enumerate("xy"):
+        for k, n in TOWER_KEYS.items():
+            if k in ("b1", "b2"):
+                continue
+            ref = torch.tensor(z[f"amp_step_param_backbones.{s}.{n}"]).double()
+            got = towers[si][k][..., ::3] if towers[si][k].dim() == 2 else towers[si][k]
+            move = float(z[f"amp_step_move_backbones.{s}.{n}"])
+            assert float((got - ref).norm()) < 1e-2 * move, (s, k, float((got - ref).norm()) / move)

@@ -191,6 +191,34 @@ def test_tower_mixed_precision_against_the_oracle_with_the_same_rounding(B, d0, 
     assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("form", ["fused", "strips"])
+def test_tower_float16_against_the_references_autocast_run(form, monkeypatch):
+    """tests/golden/amp.npz: the REFERENCE's tower (get_mlp, examples/models/mlp.py:129-164) forward + backward under
+    torch.autocast(float16) - its AMP branch (main_sketchy.py:182), run on the CPU where the fixture was made. The HIP
+    float16 mode, both forms, must be at least as close to that run as that run is to float64 arithmetic."""
+    from neural_svd_amd import hip_ops as H
+    if form == "strips":
+        monkeypatch.setenv("NSVD_TOWER16_FUSED", "0")
+    z = G.load("amp")
+    B, d0, d1, d2, _ = [int(v) for v in z["amp_tower_cfg"]]
+    assert H.tower_mixed_fused(B, d0, d1, d2, 0.2) == (form == "fused")
+    P = {k: torch.tensor(z["amp_tower_param0_" + n]).float().to(DEV).contiguous() for k, n in NAMES.items()}
+    for k, n in (("rm1", "1.running_mean"), ("rv1", "1.running_var"), ("rm2", "4.running_mean"), ("rv2", "4.running_var")):
+        P[k] = torch.tensor(z["amp_tower_param0_" + n]).float().to(DEV).contiguous()
+    x, dz = torch.tensor(z["amp_tower_x"]).to(DEV), torch.tensor(z["amp_tower_dz"]).to(DEV)
+    ws = H.tower_workspace(B, d0, d1, d2, DEV)
+    flag = 1 | H.TOWER16_F16
+    zz = H.tower_forward(x, P, 0.2, 1e-5, 0.1, False, ws, gemm_bf16=flag)
+    gr = H.tower_backward(x, P, dz, 0.2, ws, gemm_bf16=flag)
+    torch.cuda.synchronize()
+    assert rel(zz, z["amp_tower_f16_z"]) <= rel(z["amp_tower_f16_z"], z["amp_tower_f64_z"]) + 2e-4
+    for k, n in NAMES.items():
+        if k in ("b1", "b2"):
+            continue  # (a bias in front of a BatchNorm: zero gradient, rounding noise only)
+        ref, exact = z["amp_tower_f16_grad_" + n], z["amp_tower_f64_grad_" + n]
+        assert rel(gr[k], ref) <= rel(ref, exact) + 2e-4, (k, rel(gr[k], ref), rel(ref, exact))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_tower_module_under_autocast_runs_the_mixed_precision_mode(dtype):
     """the reference's Sketchy loop wraps method(x, y) in torch.cuda.amp.autocast (+ GradScaler) unless --disable_amp:
