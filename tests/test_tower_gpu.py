@@ -251,7 +251,8 @@ def test_tower_module_under_autocast_runs_the_mixed_precision_mode(dtype):
         got = dict(m.named_parameters())[n].grad / scale
         if dtype == torch.bfloat16:
             assert torch.equal(got, gwant[k]), k
-        else:  # (float16 has subnormals at 6e-5: the smallest stored gradients round differently under a scale)
+        elif k not in ("b1", "b2"):  # (float16 has subnormals at 6e-5: the smallest stored gradients round differently
+            # under a scale; the biases in front of a BatchNorm have zero gradients - rounding noise only)
             assert rel(got, gwant[k]) < 1e-3, (k, rel(got, gwant[k]))
     m.zero_grad()
     if dtype == torch.float16:  # a loss scale the float16 gradients cannot hold: non-finite parameter gradients
