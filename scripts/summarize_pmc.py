@@ -21,6 +21,7 @@ SHORT = [("pmlp_fused_fwd_kernel<5, 0, 0", "pmlp_fused_fwd"),  # the headline fo
          ("pmlp_fused_bwd_chain", "pmlp_fused_bwd_chain"), ("fourier_stencil", "fourier_stencil"),
          ("evd_partial", "evd_partial"), ("rmsprop_ema", "rmsprop_ema"), ("distribution_elementwise", "torch_randn"),
          ("pmlp_fused_fwd_kernel<1, 0, 0", "pmlp_fused_fwd_E1"), ("pmlp_fused_fwd_kernel<4, 0, 0, 1>", "pmlp_fused_fwd_plain4"), ("wgrad_reduce", "wgrad_reduce"), ("pmlp_stream_bwd", "pmlp_stream_bwd"), ("pmlp_plain_stream_fwd", "pmlp_plain_stream_fwd"), ("ka_gemm_dma", "ka_gemm_dma"),
+         ("tower_col_kernel<false", "tower_col_fwd"), ("tower_col_kernel<true", "tower_col_bwd"),
          ("tower_gemm_nt", "tower_gemm_nt"), ("gemm16b_kernel<true, true", "gemm16b_wgrad"), ("gemm16b_kernel<false, false, true", "gemm16b_fwd1"), ("gemm16b_kernel<false, true", "gemm16b_dA1"),
          ("gemm16_kernel<true, true", "gemm16_wgrad"), ("gemm16_kernel<false, false, true", "gemm16_fwd1"),
          ("gemm16_kernel<false, true", "gemm16_dA1"), ("gemm16_kernel<false, false, false", "gemm16_fwd2"),
