@@ -169,6 +169,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: libnsvd_hip.so needs libamdhip64.so.7 by name; with torch loaded that name resolves to the HIP runtime
+    # torch itself runs on (its bundled copy) - ONE runtime per process. Loaded the other way round, the library pulls
+    # /opt/rocm's runtime in, torch brings its own, and kernels launched through one cannot see memory allocated
+    # through the other (HIP error 100 at the first launch: found by build() + smoke() in one process)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NsvdError(
             f"{LIB_PATH} not found: the HIP extension has not been built. Run "
