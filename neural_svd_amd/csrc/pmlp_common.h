@@ -112,6 +112,8 @@ struct FusedWs {
     float* base_raw;                  // (L, (1 + 2D) B) head outputs per stencil point (split-stencil forward only)
     float* loss_part;                 // (L, 32 + 1) partial sums of the loss (direct-moment backward, B <= 1024)
     float* kpart;                     // K-split forward only (fwd_kslices() > 1): the slices' partial layer-0 pre-activations
+    unsigned* tickets;                // K-split forward only: one arrival counter per (head, 32-sample block) of the second
+                                      // launch (zeroed by the first): the direction that arrives last forms f, Tf
     size_t bytes;
 };
 
@@ -229,6 +231,7 @@ inline FusedWs carve_fused(const nsvd_model_desc& d, int B, void* base) {
     w.base_raw = take((size_t)d.L * (1 + 2 * (size_t)d.D) * B);
     w.loss_part = take(33 * (size_t)d.L);
     w.kpart = fwd_kpart_floats(d, B) ? take(fwd_kpart_floats(d, B)) : nullptr;
+    w.tickets = w.kpart ? (unsigned*)take((size_t)d.L * (B / BS)) : nullptr;
     w.bytes = off;
     return w;
 }

@@ -66,6 +66,10 @@ struct FwdArgs {
     float* kpart;
     int kplain;  // KS = 2, E = 3 only: the partials were left by PLAIN-form workgroups (five tiles per (head, sample block):
                  // centre, even_0, odd_0, even_1, odd_1) - direction g's workgroup adds tiles 0, 1 + 2 g, 2 + 2 g
+    // K-split, split form: arrival counters per (head, sample block), or null. The KS = 1 launch zeroes them; in the KS = 2
+    // launch the direction group that arrives LAST at a (head, sample block) reads the other groups' raw outputs and forms
+    // f, Tf itself (fd_math.h: the arithmetic of fd_epilogue_kernel, same bits) - no epilogue launch (round 6)
+    unsigned* tickets;
     unsigned long long* stamps;  // diagnostic build only (NSVD_FWD_STAMPS): per-workgroup s_memtime stamps
 };
 
@@ -126,6 +130,9 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
     const int nsb = a.B / (PL ? NC : BS);
     int l, sb, grp = 0, bid = blockIdx.x;
     int kslice = 0;
+    if (KS == 1 && a.tickets && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < a.L * (a.B / BS); i += blockDim.x) a.tickets[i] = 0u;
+    }
     if (KS == 1) {  // K-split, first launch: which slice of layer 0's contraction
         const int per = nsb * a.L * (a.split > 0 ? a.split : 1);
         kslice = __builtin_amdgcn_readfirstlane(bid / per);
@@ -745,6 +752,47 @@ __global__ void __launch_bounds__(256, 1) pmlp_fused_fwd_kernel(FwdArgs a) {
                 a.base_raw[(size_t)l * a.ldr + (size_t)eg * a.B + b0 + sidx] = bve;
             }
         }
+        if constexpr (KS == 2) if (a.tickets) {
+            // the last of the `split` direction groups to arrive at this (head, sample block) forms f, Tf: every wave's
+            // stores are out, ONE agent-scope release, the ticket; the last arriver acquires once and reads with plain
+            // loads (cdna_hip_programming.md, in-launch split-K reduction: this order, always). Correct wherever the
+            // groups run (other XCDs included); which group arrives last changes nothing in the arithmetic.
+            // (the flag lives in the reduction scratch `red`, free behind the barrier: no second LDS object - a new
+            // __shared__ variable would be allocated in EVERY instance of this template, the headline's 155 KB one included)
+            int& last_s = *reinterpret_cast<int*>(red);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned old = __hip_atomic_fetch_add(a.tickets + (size_t)l * nsb + sb, 1u, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+                last_s = old == (unsigned)a.split - 1u;
+                if (last_s) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __syncthreads();
+            if (last_s && tid < BS) {
+                const int b = b0 + tid;
+                float xc[NSVD_FD_MAXD], bE[NSVD_FD_MAXD], bO[NSVD_FD_MAXD];
+                for (int dd = 0; dd < a.D; ++dd) xc[dd] = a.x[(size_t)b * a.D + dd];
+                const float* br = a.base_raw + (size_t)l * a.ldr + b;
+                const float b0v = __builtin_nontemporal_load(br);
+                for (int dd = 0; dd < a.D; ++dd) {
+                    bE[dd] = __builtin_nontemporal_load(br + (size_t)(1 + 2 * dd) * a.B);
+                    bO[dd] = __builtin_nontemporal_load(br + (size_t)(2 + 2 * dd) * a.B);
+                }
+                const float s_l = a.scales ? a.scales[l] : 0.f;
+                const NsvdFdOut o = nsvd_fd_evenodd(b0v, bE, bO, xc, a.D, a.scales != nullptr, s_l, a.prob, a.log_norm);
+                const size_t idx = (size_t)b * a.L + l;
+                a.f[idx] = o.f;
+                a.Tf[idx] = o.Tf;
+                if (a.jac) a.jac[idx] = o.jac;
+                if (a.dsc) a.dsc[idx] = o.dsc;
+            }
+        }
         return;
     }
     // ------------------------------------------------------------------ FD Hamiltonian epilogue
@@ -966,6 +1014,10 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
     if (d.D == 2 && fwd_kslices(d, B) == 4) {  // configs[0]: 4 x 64 workgroups for layer 0, then 64 for the rest
         a.ks = 4;
         a.kpart = w.kpart;
+        {
+            const char* e = getenv("NSVD_KSPLIT_FOLD");  // "0": the separate epilogue launch (A/B measurements, tests)
+            a.tickets = (e && e[0] == '0') ? nullptr : w.tickets;
+        }
         rc = launch_fwd<5, 0, 0, 0, 1>(a, s, 1);  // (the in-run bracket of bench.py spans both launches)
         if (rc) return rc;
         // the rest of the network in SPLIT form - 2 x 64 workgroups of three tiles read the plain-form partials - then
@@ -974,7 +1026,7 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         a.base_raw = w.base_raw;
         a.kplain = 1;
         rc = launch_fwd<3, 0, 0, 0, 2>(a, s, 2);
-        if (rc) return rc;
+        if (rc || a.tickets) return rc;  // (tickets: the last direction group of every tile has formed f, Tf)
         return nsvd_fd_epilogue(w.base_raw, R, x, d.has_exp_mask ? p.scales : nullptr, prob, B, d.D, d.L, f, Tf,
                                 save ? w.jac : nullptr, (save && d.has_exp_mask) ? w.dsc : nullptr, s, 1);
     }
@@ -986,9 +1038,14 @@ int nsvd_fused_forward(const nsvd_model_desc& d, const nsvd_params& p, const nsv
         a.ks = d.D == 2 ? fwd_kslices(d, B) : 1;
         if (a.ks == 2) {  // 2 x 128 workgroups for layer 0, then 128 for the rest of the network
             a.kpart = w.kpart;
+            {
+                const char* e = getenv("NSVD_KSPLIT_FOLD");
+                a.tickets = (e && e[0] == '0') ? nullptr : w.tickets;
+            }
             rc = launch_fwd<3, 0, 0, 0, 1>(a, s, 1);  // (the in-run bracket of bench.py spans both launches)
             if (rc) return rc;
             rc = launch_fwd<3, 0, 0, 0, 2>(a, s, 2);
+            if (rc || a.tickets) return rc;
         } else {
             rc = launch_fwd<3>(a, s);
         }

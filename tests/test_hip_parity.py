@@ -708,6 +708,42 @@ def test_k_split_forward_agrees_with_the_unsplit_kernel():
     assert rel(Tf_ks, Tf_big[:128]) < 2e-5  # (the stencil amplifies the last bits of layer 0 by 1 / eps^2 x eps-sized terms)
 
 
+@pytest.mark.parametrize("L,B,mask,m", [(16, 128, False, 1024), (8, 128, True, 1024), (4, 64, True, 192), (16, 96, False, 256)])
+def test_k_split_epilogue_fold_is_bit_identical(L, B, mask, m, monkeypatch):
+    """K-split forwards (configs[0]: four K slices + the split form; smaller grids: two slices): the direction group that
+    arrives LAST at a (head, sample block) forms f, Tf inside the second launch (arrival tickets, one agent-scope
+    release / acquire pair: pmlp_fwd.hip) - against the same launches followed by the separate finite-difference
+    epilogue kernel (NSVD_KSPLIT_FOLD=0): f, Tf and the saved Jacobian factors bit for bit, repeatedly (whichever
+    group arrives last, the arithmetic is the same), and the backward that consumes them."""
+    D, hidden = 2, (128, 128, 128)  # (m = 192: two K slices in split form; the others: four in plain form)
+    p = O.init_params(L, D, m, hidden, 0.1, exp_mask_init=10.0 if mask else None, seed=L + B)
+    prob = O.Problem(potential=O.POT_HYDROGEN, eps=0.01, op_scale=100.0, op_shift=0.0, sigma=16.0)
+    shape = shape_of(p)
+    ws_t, bs_t, fB, sc = to_dev(p)
+    params = H.pack_params(shape, ws_t, bs_t, fB, sc)
+    hp = hip_problem(prob)
+    x = (16.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(B))).float().to(DEV)
+    df = torch.randn(B, L, generator=torch.Generator().manual_seed(L)).to(DEV) / B
+
+    def run():
+        ws = H.new_workspace(shape, B, DEV)
+        f, Tf = H.operator_forward(shape, params, hp, x, ws, True, H.PATH_FUSED)
+        gw = [torch.zeros_like(w) for w in ws_t]
+        gb = [torch.zeros_like(b) for b in bs_t]
+        gs = torch.zeros_like(sc) if sc is not None else None
+        H.operator_backward(shape, params, hp, x, df, H.pack_params(shape, gw, gb, None, gs), ws, H.PATH_FUSED)
+        torch.cuda.synchronize()
+        return [f.clone(), Tf.clone()] + gw + gb + ([gs] if gs is not None else [])
+    monkeypatch.setenv("NSVD_KSPLIT_FOLD", "0")
+    want = run()
+    monkeypatch.delenv("NSVD_KSPLIT_FOLD")
+    for _ in range(5):
+        got = run()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), i
+    assert bool(torch.isfinite(want[0]).all()) and float(want[1].abs().max()) > 0
+
+
 @pytest.mark.parametrize("D,L,B,mask", [(16, 3, 64, False), (2, 4, 96, True), (40, 1, 32, True), (16, 64, 1024, False),
                                         (5, 32, 2048, True)])
 def test_model_forward_backward_mfma(D, L, B, mask):
