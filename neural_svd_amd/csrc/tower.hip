@@ -1141,11 +1141,13 @@ extern "C" int nsvd_tower_mixed_fused(int B, int d0, int d1, int d2, float slope
 // block 0 / wave 0: prologue, K loop, epilogue, stages), later calls read the last launch's
 extern "C" int nsvd_debug_tcol_stamps(unsigned long long* host) {
     if (!g_tcol_stamps) {
-        hipError_t e = hipMalloc((void**)&g_tcol_stamps, 4 * sizeof(unsigned long long));
+        hipError_t e = hipMalloc((void**)&g_tcol_stamps, (4 + 4 * 1024) * sizeof(unsigned long long));
         if (e != hipSuccess) return -(int)e;
-        return -(int)hipMemset(g_tcol_stamps, 0, 4 * sizeof(unsigned long long));
+        return -(int)hipMemset(g_tcol_stamps, 0, (4 + 4 * 1024) * sizeof(unsigned long long));
     }
-    return -(int)hipMemcpy(host, g_tcol_stamps, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(host, g_tcol_stamps, (4 + 4 * 1024) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(int)e;
+    return -(int)hipMemset(g_tcol_stamps + 4, 0, 4 * 1024 * sizeof(unsigned long long));  // (the end stamps are atomic maxima)
 }
 
 // both towers of a mixed-precision CDK step through every launch together (cdk_step.hip); flags: the gemm_bf16 bits

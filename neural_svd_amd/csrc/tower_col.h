@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
     const int NS = NP * nkt;
 
     const unsigned long long ts0 = a.stamps ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long wc0 = a.stamps ? wall_clock64() : 0ull;
 
     // ---- DMA sources
     const char* sa = reinterpret_cast<const char*>(P.A) + 2L * (long)(w * RW) * K;
@@ -224,6 +225,7 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
 #undef TC_ISSUE
 #undef TC_TR
     const unsigned long long ts2 = a.stamps ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long wc1 = a.stamps ? wall_clock64() : 0ull;
 
     // ---- epilogue. lane = row 16 i + l15 of the wave's rows; registers = columns 16 j + 4 g4 .. + 3 of the tile.
     __syncthreads();  // every wave is done reading the last stage: the ring is free
@@ -466,6 +468,13 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
     if (a.stamps && blockIdx.x == 0 && tid == 0) {
         a.stamps[0] = ts1 - ts0; a.stamps[1] = ts2 - ts1; a.stamps[2] = __builtin_readcyclecounter() - ts2;
         a.stamps[3] = (unsigned long long)NS;
+    }
+    if (a.stamps) {  // every block: start / loop end / end on the 100 MHz clock (waves may end apart: the last one wins)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            if (w == 0) { a.stamps[4 + 4 * blockIdx.x] = wc0; a.stamps[5 + 4 * blockIdx.x] = wc1; }
+            atomicMax(&a.stamps[6 + 4 * blockIdx.x], wall_clock64());
+        }
     }
 #undef TC_WAIT_BARRIER
 }
