@@ -348,7 +348,9 @@ __global__ void __launch_bounds__(512) gemm16_kernel(Args a) {
             // the 15.8 at (1024, 8192, 512) bfloat16 out, 1.5 of 23.5 at (512, 8192, 1024) float32 out
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 vv = {v.x, v.y, v.z, v.w};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
+            // (s_nop 1 inside the string: hipcc pads nothing behind an asm store - its next instruction may overwrite the
+            // data registers before the store has read them: intermittent wrong elements, found in round 6)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dstp), "v"(vv) : "memory");
         }
     }
     if (stamp) {

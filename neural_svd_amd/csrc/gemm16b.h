@@ -198,7 +198,9 @@ __global__ void __launch_bounds__(512, 4) gemm16b_kernel(Args a) {  // (4 waves 
             char* dstp = cbase + (long)(r + ROWS * ps) * P.ldc * (O16 ? 2 : 4) + 16 * cc;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 vv = {v.x, v.y, v.z, v.w};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
+            // (s_nop 1 inside the string: hipcc pads nothing behind an asm store - its next instruction may overwrite the
+            // data registers before the store has read them: intermittent wrong elements, found in round 6)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dstp), "v"(vv) : "memory");
         }
     }
     if (P.sumsq) {

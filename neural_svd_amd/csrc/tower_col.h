@@ -285,7 +285,9 @@ __global__ void __launch_bounds__(512) tower_col_kernel(Args a) {
             char* dst = reinterpret_cast<char*>(out) + ((long)(w * RW + r) * N + n0) * 2 + 16 * chunk;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 vv = {v.x, v.y, v.z, v.w};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+            // (s_nop 1 inside the string: hipcc pads nothing behind an asm store - its next instruction may overwrite the
+            // data registers before the store has read them: intermittent wrong elements, found in round 6)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
         }
     };
 
