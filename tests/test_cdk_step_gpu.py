@@ -379,11 +379,13 @@ def test_cdk_step_at_headline_size_against_the_oracle(amp):
     omode = ("fused" if H.tower_mixed_fused(B, *sizes, slope) else True) if amp else False
     (loss, lop, lmet), total = O.cdk_train_step(x.double(), y.double(), towers, bufs, running, v, M, mu, lr, mom,
                                                 max_norm, slope, True, gemm_bf16=omode)
-    tl = 5e-4 if amp else 2e-5
+    # (mixed precision, measured: loss 8e-7, norm 1.4e-8, updates <= 1.6e-3 of their length - scripts/dev/
+    # cdk_headline_margins.py; the bounds below leave a factor of 3 to 25 and are the float32 mode's where that is looser)
+    tl = 2e-5
     assert abs(float(out[0]) - float(loss)) < tl * max(1.0, abs(float(loss))), (float(out[0]), float(loss))
     assert abs(float(out[1]) - float(lop)) < tl * max(1.0, abs(float(lop)))
     assert abs(float(out[2]) - float(lmet)) < tl * max(1.0, abs(float(lmet)))
-    assert abs(float(out[3]) - float(total)) < (5e-3 if amp else 1e-4) * float(total), (float(out[3]), float(total))
+    assert abs(float(out[3]) - float(total)) < 1e-4 * float(total), (float(out[3]), float(total))
     rows = torch.tensor([0, 1, 127, 128, 255, 256, 300, 511])
     for si, s in enumerate("xy"):
         for k, n in KEYS.items():
@@ -394,7 +396,7 @@ def test_cdk_step_at_headline_size_against_the_oracle(amp):
             move = float((want - start).norm())
             d = float((got - want).norm())
             # the UPDATE (lr x clipped gradient) against the oracle's; float32 storage of the parameter itself: 6e-8 |p|
-            assert d < (2e-2 if amp else 2e-4) * move + 2e-7 * float(want.norm()), (s, k, d, move)
+            assert d < (5e-3 if amp else 2e-4) * move + 2e-7 * float(want.norm()), (s, k, d, move)
         for tag in ("1", "4"):
             for stat in ("running_mean", "running_var"):
                 got = sd[f"backbones.{s}.{tag}.{stat}"]
