@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from neural_svd_amd import hip_ops as H
 dev = "cuda:0"
-for hidden, path in (((128, 128, 128), H.PATH_GENERIC), ((64, 64, 64), H.PATH_AUTO), ((256, 256, 256), H.PATH_AUTO), ((96, 96), H.PATH_AUTO)):
+cases = (((128, 128, 128), H.PATH_GENERIC), ((64, 64, 64), H.PATH_AUTO), ((256, 256, 256), H.PATH_AUTO), ((96, 96), H.PATH_AUTO))
+if len(sys.argv) > 1:  # one width only (for a profile): generic_time.py 64
+    cases = [c for c in cases if c[0][0] == int(sys.argv[1])]
+for hidden, path in cases:
     L, D, m, B = 16, 2, 1024, 512
     shape = H.ModelShape(L=L, D=D, m=m, hidden=hidden)
     g = torch.Generator().manual_seed(0)
