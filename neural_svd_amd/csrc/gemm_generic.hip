@@ -4,6 +4,7 @@
 // k) since round 4 - rounds 1-3 multiplied on the vector ALU (4 x 4 register tiles, 36 TFLOP/s).
 // Used for: ParallelMLP layers (reference mlp.py:204-221), their data gradients and weight
 // gradients (what autograd derives for those einsums).
+#include <stdint.h>
 #include <stdlib.h>
 #include "nsvd_kernels.h"
 
@@ -185,6 +186,244 @@ __global__ void __launch_bounds__(256) gemm_generic2_kernel(NsvdGemm g) {
     }
 }
 
+// Round 6, the vectorised form: the same contraction for launches whose fast axes are 16-byte aligned (every launch of
+// the generic path at batch sizes that are multiples of 4). What changes against the
+// kernel above:
+//  * 16-byte global loads along each operand's contiguous axis (k-contiguous operands are transposed on their way into
+//    the LDS: four 4-byte writes, conflict-free with the 4-float row padding; m / n-contiguous ones go in as ds_write_b128);
+//  * no branch around any load: ragged M / N edges CLAMP the row / column (the values land in accumulator rows / columns
+//    that are never stored), so a K step's loads issue back to back and stay in flight under the previous step's MFMAs;
+//  * larger tiles, chosen per launch: a wave owns MI x NI accumulators of 32 x 32 (2 x 2 waves): 128 x 128 for M > 64
+//    (32 FLOP per staged byte against 21 of the 64 x 128 tile: the staging traffic, L2 -> LDS, is what bounded the kernel
+//    above at 0.49 of the MFMA peak), 64 x 256 or 64 x 128 for M <= 64;
+//  * the stencil-aware softplus prologue (even / odd form, three loads per element) on the same path.
+template <int MI, int NI, bool AK, bool BK, bool EO>
+__global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kernel(NsvdGemm g) {
+    constexpr int TM3 = 64 * MI, TN3 = 64 * NI, LDA = TM3 + PAD, LDB = TN3 + PAD;
+    __shared__ __attribute__((aligned(16))) float As[2][TK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TK][LDB];
+    const int bz = blockIdx.z;
+    const float* A = g.A + (size_t)bz * g.bA;
+    const float* Bm = g.B + (size_t)bz * g.bB;
+    float* C = g.C + (size_t)bz * g.bC;
+    const int m0 = blockIdx.y * TM3, n0 = blockIdx.x * TN3;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;  // this wave: rows 32 MI wm .., columns 32 NI wn ..
+    typedef float f32x16_t __attribute__((ext_vector_type(16)));
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging items of this thread (fixed for the whole loop): MI float4 of A, NI float4 of B (EO: three per item)
+    const float* pa[MI];
+    int wa[MI];  // LDS float offset inside a stage of As
+    int ka[MI], kb[NI];  // first k of the item inside a K step
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int idx = t + 256 * i;
+        if (AK) {  // A[m][k], k contiguous: a float4 = four k of one row
+            const int q = idx & 3, m = idx >> 2;
+            const int gm = min(m0 + m, g.M - 1);
+            pa[i] = A + (size_t)gm * g.sAm + 4 * q;
+            wa[i] = 4 * q * LDA + m;
+            ka[i] = 4 * q;
+        } else {   // A[k][m], m contiguous: a float4 = four rows at one k
+            const int mq = idx % (TM3 / 4), k = idx / (TM3 / 4);
+            const int gm = min(m0 + 4 * mq, g.M - 4);
+            pa[i] = A + (size_t)k * g.sAk + gm;
+            wa[i] = k * LDA + 4 * mq;
+            ka[i] = k;
+        }
+    }
+    const float* pb[NI];
+    int wb[NI];
+    int eoE[NI], eoO[NI];  // EO: float offsets from the element to its pair's even / odd pre-activation (0: centre block)
+    bool eoOdd[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = t + 256 * i;
+        int gn;
+        if (BK) {  // B[n][k], k contiguous
+            const int q = idx & 3, n = idx >> 2;
+            gn = min(n0 + n, g.N - 1);
+            pb[i] = Bm + (size_t)gn * g.sBn + 4 * q;
+            wb[i] = 4 * q * LDB + n;
+            kb[i] = 4 * q;
+        } else {   // B[k][n], n contiguous
+            const int nq = idx % (TN3 / 4), k = idx / (TN3 / 4);
+            gn = min(n0 + 4 * nq, g.N - 4);
+            pb[i] = Bm + (size_t)k * g.sBk + gn;
+            wb[i] = k * LDB + 4 * nq;
+            kb[i] = k;
+        }
+        eoE[i] = eoO[i] = 0; eoOdd[i] = false;
+        if (EO) {  // (n-contiguous only; eo_cols % 4 == 0: the four columns of an item share their stencil block)
+            const int e = gn / g.eo_cols, bcol = gn - e * g.eo_cols;
+            if (e > 0) {
+                const int dd = (e - 1) >> 1;
+                pb[i] = Bm + (size_t)(idx / (TN3 / 4)) * g.sBk + bcol;  // the CENTRE pre-activation
+                eoE[i] = (1 + 2 * dd) * g.eo_cols;
+                eoO[i] = (2 + 2 * dd) * g.eo_cols;
+                eoOdd[i] = (e - 1) & 1;
+            }
+        }
+    }
+    const size_t stepA = AK ? (size_t)TK : (size_t)TK * g.sAk;
+    const size_t stepB = BK ? (size_t)TK : (size_t)TK * g.sBk;
+    float4 ra[MI], rb[NI], rbE[EO ? NI : 1], rbO[EO ? NI : 1];
+    // K tail (K % 16 != 0; k-contiguous operands: K % 4 == 0, so a float4 is inside or outside as a whole): an item past
+    // K loads from the operand's base (valid, aligned) and is staged as ZERO - behind the prologue: softplus(0) = ln 2
+    bool kva[MI], kvb[NI];
+    auto request = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            kva[i] = k0 + ka[i] < g.K;
+            ra[i] = *(const float4*)(kva[i] ? pa[i] : A);
+            pa[i] += stepA;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            kvb[i] = k0 + kb[i] < g.K;
+            const float* p = kvb[i] ? pb[i] : Bm;
+            rb[i] = *(const float4*)p;
+            if (EO) {
+                rbE[i] = *(const float4*)(p + eoE[i]);
+                rbO[i] = *(const float4*)(p + eoO[i]);
+            }
+            pb[i] += stepB;
+        }
+    };
+    auto stage = [&](int buf) {
+        float* as = &As[buf][0][0];
+        float* bs = &Bs[buf][0][0];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (!kva[i]) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (AK) {
+                as[wa[i]] = ra[i].x; as[wa[i] + LDA] = ra[i].y; as[wa[i] + 2 * LDA] = ra[i].z; as[wa[i] + 3 * LDA] = ra[i].w;
+            } else {
+                *(float4*)(as + wa[i]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float4 v = rb[i];
+            if (EO) {
+                if (eoE[i] == 0) {
+                    v.x = nsvd_softplus(v.x); v.y = nsvd_softplus(v.y); v.z = nsvd_softplus(v.z); v.w = nsvd_softplus(v.w);
+                } else {
+                    float ev, od;
+                    nsvd_softplus_evenodd(rb[i].x, rbE[i].x, rbO[i].x, &ev, &od); v.x = eoOdd[i] ? od : ev;
+                    nsvd_softplus_evenodd(rb[i].y, rbE[i].y, rbO[i].y, &ev, &od); v.y = eoOdd[i] ? od : ev;
+                    nsvd_softplus_evenodd(rb[i].z, rbE[i].z, rbO[i].z, &ev, &od); v.z = eoOdd[i] ? od : ev;
+                    nsvd_softplus_evenodd(rb[i].w, rbE[i].w, rbO[i].w, &ev, &od); v.w = eoOdd[i] ? od : ev;
+                }
+            } else if (g.softplus_b) {
+                v.x = nsvd_softplus(v.x); v.y = nsvd_softplus(v.y); v.z = nsvd_softplus(v.z); v.w = nsvd_softplus(v.w);
+            }
+            if (!kvb[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BK) {
+                bs[wb[i]] = v.x; bs[wb[i] + LDB] = v.y; bs[wb[i] + 2 * LDB] = v.z; bs[wb[i] + 3 * LDB] = v.w;
+            } else {
+                *(float4*)(bs + wb[i]) = v;
+            }
+        }
+    };
+    request(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += TK) {
+        const bool more = k0 + TK < g.K;
+        if (more) request(k0 + TK);
+        const float* as = &As[buf][hi][32 * MI * wm + li];
+        const float* bs = &Bs[buf][hi][32 * NI * wn + li];
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            float av[MI], bv[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) av[i] = as[kk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bv[j] = bs[kk * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();  // tile t + 1 is staged, and every wave is done with tile t (the buffer tile t + 2 goes to)
+        buf ^= 1;
+    }
+    // epilogue: every load of an accumulator block (bias, the sigmoid's argument) is issued before the first store, so 16
+    // loads are in flight instead of one per round trip. Addresses = a wave-uniform row base (scalar registers) + ONE
+    // 32-bit lane offset per matrix (generic3_ok: M x row stride < 2^31) - 64-bit addresses per element cost an occupancy step.
+    const float* bias = g.bias ? g.bias + (size_t)bz * g.bBias : nullptr;
+    const float* Z = g.Z ? g.Z + (size_t)bz * g.bZ : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int gn = n0 + 32 * NI * wn + 32 * j + li;
+            const int rb = m0 + 32 * MI * wm + 32 * i + 4 * hi;  // this lane's first row of the block
+            const unsigned zoff = (unsigned)rb * (unsigned)g.sZm + (unsigned)gn;
+            const unsigned coff = (unsigned)rb * (unsigned)g.sCm + (unsigned)gn;
+            const bool centre = !(g.eo_cols > 0 && gn >= g.eo_cols);
+            float zv[16], bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const bool ok = rb + ro < g.M && gn < g.N;
+                bv[r] = (bias && ok) ? (bias + ro)[rb] : 0.f;
+                zv[r] = (g.sigmoid_mul && ok) ? (Z + (size_t)ro * g.sZm)[zoff] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + (centre ? bv[r] : 0.f);
+                if (g.sigmoid_mul) v *= nsvd_sigmoid(zv[r]);
+                if (rb + ro < g.M && gn < g.N) (C + (size_t)ro * g.sCm)[coff] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (the next block's loads stay behind this block's stores: registers)
+        }
+}
+
+template <int MI, int NI>
+int launch_generic3(const NsvdGemm& g, hipStream_t s) {
+    const bool ak = g.sAk == 1, bk = g.sBk == 1;
+    const bool eo = g.softplus_b && g.eo_cols > 0;
+    dim3 grid(nsvd_cdiv(g.N, 64 * NI), nsvd_cdiv(g.M, 64 * MI), g.batch);
+#define NSVD_G3(AKv, BKv, EOv) hipLaunchKernelGGL((gemm_generic3_kernel<MI, NI, AKv, BKv, EOv>), grid, dim3(256), 0, s, g)
+    if (eo) { if (ak) NSVD_G3(true, false, true); else NSVD_G3(false, false, true); }
+    else if (ak && bk) NSVD_G3(true, true, false);
+    else if (ak) NSVD_G3(true, false, false);
+    else if (bk) NSVD_G3(false, true, false);
+    else NSVD_G3(false, false, false);
+#undef NSVD_G3
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+// can the vectorised kernel take this launch? (fast axes contiguous and 16-byte aligned in every batch)
+bool generic3_ok(const NsvdGemm& g) {
+    auto al4 = [](long v) { return (v & 3) == 0; };
+    auto alp = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!alp(g.A) || !alp(g.B) || !al4(g.bA) || !al4(g.bB)) return false;
+    if ((long)g.M * g.sCm >= (1L << 31) || (g.Z && (long)g.M * g.sZm >= (1L << 31))) return false;  // 32-bit lane offsets
+    if (g.sAk == 1) { if (!al4(g.sAm) || !al4(g.K)) return false; }
+    else if (g.sAm == 1) { if (!al4(g.sAk) || !al4(g.M) || g.M < 4) return false; }
+    else return false;
+    if (g.sBk == 1) { if (!al4(g.sBn) || !al4(g.K)) return false; }
+    else if (g.sBn == 1) { if (!al4(g.sBk) || !al4(g.N) || g.N < 4) return false; }
+    else return false;
+    if (g.softplus_b && g.eo_cols > 0 && (g.sBn != 1 || !al4(g.eo_cols) || g.N % g.eo_cols)) return false;
+    return true;
+}
+
 __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
                                                      int n, long ld) {
     // one wave per row
@@ -204,6 +443,22 @@ int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return NSVD_EINVAL;
     // the stencil-aware softplus prologue (three loads per staged element) stays on the 64 x 64 kernel; everything else takes
     // the pipelined 64 x 128 one (NSVD_GEMM_GENERIC2=0: the old kernel everywhere, for A/B measurements)
+    // the vectorised kernel where the launch allows it (NSVD_GEMM_GENERIC3=0: off, for A/B measurements)
+    static const char* e3 = getenv("NSVD_GEMM_GENERIC3");
+    if (!(e3 && e3[0] == '0') && generic3_ok(g)) {
+        // the largest tile that still gives the chip enough workgroups (NSVD_G3_MINWG, default 1024: four per CU, what
+        // the registers and the LDS let reside - measured against 128 / 256 / 512: hidden width 64 0.47 / 0.40 / 0.34 /
+        // 0.34 ms per step, hidden width 128 0.65 / 0.62 / 0.53 / 0.47); a launch too small for any of them takes the
+        // smallest tile
+        static const char* emw = getenv("NSVD_G3_MINWG");
+        const long minwg = emw ? atol(emw) : 1024;
+        auto nwg = [&](int tm, int tn) { return (long)nsvd_cdiv(g.M, tm) * nsvd_cdiv(g.N, tn) * g.batch; };
+        if (g.M > 64 && nwg(128, 128) >= minwg) return launch_generic3<2, 2>(g, s);
+        // (the 64 x 256 instance with the even / odd prologue would spill 40 registers: never chosen)
+        if (!(g.softplus_b && g.eo_cols > 0) && g.N >= 256 && nwg(64, 256) >= minwg) return launch_generic3<1, 4>(g, s);
+        if (nwg(64, 128) >= minwg) return launch_generic3<1, 2>(g, s);
+        return launch_generic3<1, 1>(g, s);
+    }
     static const char* e2 = getenv("NSVD_GEMM_GENERIC2");
     if (!(g.softplus_b && g.eo_cols > 0) && !(e2 && e2[0] == '0')) {
         dim3 grid2(nsvd_cdiv(g.N, T2N), nsvd_cdiv(g.M, T2M), g.batch);

@@ -27,11 +27,13 @@ for hidden, path in cases:
         mom = H.evd_moments(f, Tf, H.MASK_JOINT, None)
         loss, df = H.evd_loss_grad(f, Tf, H.MASK_JOINT, None, None, mom)
         H.operator_backward(shape, params, prob, x, df, grads, ws, path=path)
-    for _ in range(5): step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 50
-    for _ in range(n): step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    for _ in range(20): step()
+    n, blocks = 40, []
+    for _ in range(5):  # median of five blocks (a single block now and then carries a one-off stall of the box)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): step()
+        torch.cuda.synchronize(); blocks.append((time.perf_counter() - t0) / n)
+    dt = sorted(blocks)[2]
     E = 1 + 2 * D
     M = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     flops = 2 * B * L * (E * M + M + (M - dims[0] * dims[1]))
