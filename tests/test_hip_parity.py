@@ -663,6 +663,34 @@ def test_exact_mode_three_dimensional(fpath):
     assert rel(r2["f"], ref["f"]) < 2e-5
 
 
+@pytest.mark.parametrize("hidden,B,D,L,m", [
+    ((64, 64, 64), 512, 2, 3, 256),   # 64 x 64 tiles (M <= 64), every operand form vectorised
+    ((256, 256), 512, 2, 2, 256),     # 128 x 128 tiles where the launch has >= 1024 workgroups, smaller ones elsewhere
+    ((96, 96), 128, 2, 5, 128),       # M = 96: clamped rows of the second 64-row tile
+    ((40, 24), 100, 2, 3, 34),        # K = 68 / 40 / 24 / 100 (K tails by select), N = 500, M = 40 / 24 (ragged everywhere)
+    ((50,), 101, 3, 2, 33),           # nothing 16-byte aligned: the scalar kernel (gemm_generic2) takes every launch
+    ((320, 64), 64, 1, 2, 64),        # M = 320 (three 128-row tiles, the last ragged), D = 1 (three stencil blocks)
+])
+def test_generic_path_at_other_hidden_widths(hidden, B, D, L, m):
+    """Hidden widths the fused MFMA kernels do not take (the reference accepts any --mlp_hidden_dims,
+    examples/models/mlp.py:187-221) run the generic contractions (gemm_generic.hip: round 6's vectorised kernel with its
+    four tile shapes, clamped edges, K tails and the even / odd softplus prologue; the scalar kernel for unaligned
+    launches): f, Tf and every gradient against the float64 oracle at the same tolerances as the fused path."""
+    p = O.init_params(L, D, m, hidden, 0.2, exp_mask_init=4.0, seed=7)
+    prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=3.0)
+    v, M = O.sequential_nesting_masks(L)
+    x = (3.0 * torch.randn(B, D, generator=torch.Generator().manual_seed(11), dtype=torch.float64)).float().double()
+    assert H.path_name(shape_of(p), B, H.PATH_AUTO, hip_problem(prob)) == "generic"
+    ref = O.loss_and_grads(x, p.to(torch.float64), prob, v, M)
+    r = run_hip(p, prob, x, v, M, H.PATH_AUTO, df_override=ref["df"])
+    assert rel(r["f"], ref["f"]) < 2e-5
+    assert rel(r["Tf"], ref["Tf"]) < 1e-4, rel(r["Tf"], ref["Tf"])
+    for i, (a, b) in enumerate(zip(r["grads"], ref["grads"])):
+        assert torch.isfinite(a).all(), i
+        assert rel(a.view(-1), b.reshape(-1)) < 3e-5, (i, rel(a.view(-1), b.reshape(-1)))
+
+
+
 @pytest.mark.parametrize("D,L,B,m", [(3, 3, 96, 64), (2, 16, 128, 64), (2, 16, 128, 256), (2, 4, 64, 128)])
 def test_split_stencil_form(D, L, B, m):
     """The split-stencil form of the fused forward (one direction's two shifted points + the centre per workgroup, raw
