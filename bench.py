@@ -791,6 +791,12 @@ def measure_other_configs(args, dev):
           lambda: scripts_shape(dict(ALT["cfg2"], L=36)))
     guard("reference script shape: oscillator L=55 B=512 sequential (scripts/exps/pde/oscillator.sh)",
           lambda: scripts_shape(dict(ALT["cfg3"], L=55)))
+    # hidden widths the fused MFMA kernels are not instantiated for (the reference takes any --mlp_hidden_dims,
+    # examples/models/mlp.py:187-221): the generic contractions (gemm_generic.hip); the bracket is the layer-0 launch
+    guard("configs[1] with hidden widths (256, 256, 256): generic path",
+          lambda: measure_pde_config(dict(ALT["cfg2"], hidden=(256, 256, 256)), dev, H.PATH_AUTO, 100, 10, 3, 0.3))
+    guard("configs[1] with hidden widths (64, 64, 64): generic path",
+          lambda: measure_pde_config(dict(ALT["cfg2"], hidden=(64, 64, 64)), dev, H.PATH_AUTO, steps, warmup, 3, 0.3))
     for name, config, amp in (("configs[3] dense kernel operator L=64 B=8192 (cfg4)", "cfg4", False),
                               ("configs[4] CDK towers L=512 B=1024 (cfg5), float32", "cfg5", False),
                               ("configs[4] CDK towers L=512 B=1024 (cfg5), mixed precision", "cfg5", True),

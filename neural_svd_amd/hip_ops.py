@@ -807,7 +807,7 @@ def profile_next_forward(ev_start: "torch.cuda.Event", ev_stop: "torch.cuda.Even
 
 
 def dominant_kernel_name(shape: ModelShape, B: int, path: int = PATH_AUTO) -> str:
-    return "pmlp_fused_fwd_kernel" if path_name(shape, B, path).startswith("fused") else "gemm_generic_kernel[layer0]"
+    return "pmlp_fused_fwd_kernel" if path_name(shape, B, path).startswith("fused") else "gemm_generic3_kernel[layer0]"
 
 
 # ------------------------------------------------------------------------------ row normalisation (CDK towers)
