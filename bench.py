@@ -704,8 +704,6 @@ def measure_pde_config(cfg, dev, path, steps, warmup, repeats, prewarm_s):
     d = summarize(blocks, steps, 1, cfg["B"])
     fl_step, fl_fwd = algorithmic_flops(cfg, cfg["B"])
     kname = H.dominant_kernel_name(shape, cfg["B"], path)
-    if kname.startswith("gemm_generic"):
-        fl_fwd = 2.0 * (1 + 2 * cfg["D"]) * cfg["B"] * cfg["L"] * (2 * cfg["m"]) * cfg["hidden"][0]
     kavg = sum(kms) / len(kms)
     out = dict(value=d["value"], unit="steps/s", ms_per_step=d["ms_per_step"], blocks=d["blocks"], steps=steps,
                global_batch=cfg["B"], final_loss=float(tr.loss[0]), params_finite=bool(torch.isfinite(tr.P.flat).all()),
@@ -792,7 +790,7 @@ def measure_other_configs(args, dev):
     guard("reference script shape: oscillator L=55 B=512 sequential (scripts/exps/pde/oscillator.sh)",
           lambda: scripts_shape(dict(ALT["cfg3"], L=55)))
     # hidden widths the fused MFMA kernels are not instantiated for (the reference takes any --mlp_hidden_dims,
-    # examples/models/mlp.py:187-221): the generic contractions (gemm_generic.hip); the bracket is the layer-0 launch
+    # examples/models/mlp.py:187-221): the generic contractions (gemm_generic.hip); the bracket is the whole forward (all its launches)
     guard("configs[1] with hidden widths (256, 256, 256): generic path",
           lambda: measure_pde_config(dict(ALT["cfg2"], hidden=(256, 256, 256)), dev, H.PATH_AUTO, 100, 10, 3, 0.3))
     guard("configs[1] with hidden widths (64, 64, 64): generic path",
@@ -1239,8 +1237,6 @@ def main():
     if use_ev and kms:
         kavg = sum(kms) / len(kms)
         kname = H.dominant_kernel_name(shape, cfg["B"], path)
-        if kname.startswith("gemm_generic"):  # generic path: the bracketed launch is the layer-0 GEMM only
-            flops_fwd = 2.0 * (1 + 2 * cfg["D"]) * cfg["B"] * cfg["L"] * (2 * cfg["m"]) * cfg["hidden"][0]
         ach = flops_fwd / (kavg * 1e-3) / 1e12
         nh = len(cfg["hidden"])
         alg_mb = 4.0 * (n_train + cfg["B"] * 2 * cfg["m"] + nh * trL * cfg["hidden"][0] * trB + 3 * trB * trL) / 1e6

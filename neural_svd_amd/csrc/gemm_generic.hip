@@ -1,100 +1,22 @@
-// Generic strided, batched fp32 GEMM for shapes the fused MFMA kernels do not cover
-// (hidden widths that are not 128, ragged batches). LDS-tiled 64 x 64 x 16; the products on the fp32 MFMA
-// (v_mfma_f32_32x32x2_f32: a wave owns one 32 x 32 quadrant of the tile, one MFMA and two 4-byte LDS reads per pair of
-// k) since round 4 - rounds 1-3 multiplied on the vector ALU (4 x 4 register tiles, 36 TFLOP/s).
-// Used for: ParallelMLP layers (reference mlp.py:204-221), their data gradients and weight
-// gradients (what autograd derives for those einsums).
+// Generic strided, batched fp32 GEMM for shapes the fused MFMA kernels do not cover (hidden widths that are not 128,
+// ragged batches, D > 3), and the in-place activation pass between two layers. Products on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) since round 4 - rounds 1-3 multiplied on the vector ALU (4 x 4 register tiles, 36 TFLOP/s).
+// Used for: ParallelMLP layers (reference mlp.py:204-221), their data gradients and weight gradients (what autograd
+// derives for those einsums). Round 6: the vectorised kernel (gemm_generic3_kernel) takes every aligned launch, the
+// scalar one (gemm_generic2_kernel) the rest; the softplus is no longer a prologue of the NEXT layer's contraction
+// (recomputed by every row tile: the hidden layers ran at 0.34 of peak) but ONE element-wise pass that turns a layer's
+// pre-activations into activations in place (nsvd_softplus_inplace) - the backward reads the stored activations.
 #include <stdint.h>
 #include <stdlib.h>
 #include "nsvd_kernels.h"
 
 namespace {
 
-constexpr int TM = 64, TN = 64, TK = 16, PAD = 4;
+constexpr int TK = 16, PAD = 4;
 
-__global__ void __launch_bounds__(256) gemm_generic_kernel(NsvdGemm g) {
-    __shared__ float As[TK][TM + PAD];
-    __shared__ float Bs[TK][TN + PAD];
-    const int bz = blockIdx.z;
-    const float* A = g.A + (size_t)bz * g.bA;
-    const float* Bm = g.B + (size_t)bz * g.bB;
-    float* C = g.C + (size_t)bz * g.bC;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    const int t = threadIdx.x;
-    const int lane = t & 63, wv = t >> 6;
-    const int li = lane & 31, hi = lane >> 5;
-    const int wm = wv >> 1, wn = wv & 1;  // this wave's quadrant: rows 32 wm .., columns 32 wn ..
-    typedef float f32x16_t __attribute__((ext_vector_type(16)));
-    f32x16_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool a_kfast = (g.sAk == 1);
-    const bool b_nfast = (g.sBn == 1);
-    for (int k0 = 0; k0 < g.K; k0 += TK) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int mm, kk;
-            if (a_kfast) { kk = t & 15; mm = (t >> 4) + 16 * i; }
-            else         { mm = t & 63; kk = (t >> 6) + 4 * i; }
-            const int gm = m0 + mm, gk = k0 + kk;
-            float v = 0.f;
-            if (gm < g.M && gk < g.K) v = A[(size_t)gm * g.sAm + (size_t)gk * g.sAk];
-            As[kk][mm] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int nn, kk;
-            if (b_nfast) { nn = t & 63; kk = (t >> 6) + 4 * i; }
-            else         { kk = t & 15; nn = (t >> 4) + 16 * i; }
-            const int gn = n0 + nn, gk = k0 + kk;
-            float v = 0.f;
-            if (gn < g.N && gk < g.K) {
-                v = Bm[(size_t)gk * g.sBk + (size_t)gn * g.sBn];
-                if (g.softplus_b) {
-                    if (g.eo_cols > 0 && gn >= g.eo_cols) {
-                        const int e = gn / g.eo_cols, bcol = gn - e * g.eo_cols, dd = (e - 1) >> 1;
-                        const float* zr = Bm + (size_t)gk * g.sBk;
-                        const float z0 = zr[(size_t)bcol * g.sBn];
-                        const float zE = zr[(size_t)((1 + 2 * dd) * g.eo_cols + bcol) * g.sBn];
-                        const float zO = zr[(size_t)((2 + 2 * dd) * g.eo_cols + bcol) * g.sBn];
-                        float ev, od;
-                        nsvd_softplus_evenodd(z0, zE, zO, &ev, &od);
-                        v = ((e - 1) & 1) ? od : ev;
-                    } else {
-                        v = nsvd_softplus(v);
-                    }
-                }
-            }
-            Bs[kk][nn] = v;
-        }
-        __syncthreads();
-        // lane (li, hi) feeds row / column li of the quadrant at k = kk + hi: D[i][j] += sum_k A[i][k] B[k][j]
-#pragma unroll
-        for (int kk = 0; kk < TK; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + hi][32 * wm + li], Bs[kk + hi][32 * wn + li], acc, 0, 0, 0);
-        __syncthreads();
-    }
-    const float* bias = g.bias ? g.bias + (size_t)bz * g.bBias : nullptr;
-    const float* Z = g.Z ? g.Z + (size_t)bz * g.bZ : nullptr;
-    // accumulator register r of lane (li, hi): row 8 (r / 4) + 4 hi + r % 4, column li of the quadrant
-    const int gn = n0 + 32 * wn + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (gm >= g.M || gn >= g.N) continue;
-        const float bi = bias ? bias[gm] : 0.f;
-        float v = acc[r] + ((g.eo_cols > 0 && gn >= g.eo_cols) ? 0.f : bi);
-        if (g.sigmoid_mul) v *= nsvd_sigmoid(Z[(size_t)gm * g.sZm + gn]);
-        C[(size_t)gm * g.sCm + gn] = v;
-    }
-}
-
-// The same contraction on 64 x 128 tiles with the NEXT K tile's global loads in flight under the current tile's MFMAs
-// (round 6): a wave owns 32 rows x 64 columns (two 32 x 32 accumulators fed by ONE A value: three 4-byte LDS reads per
-// two MFMAs instead of four), the LDS tiles are double buffered (one workgroup barrier per 16 k instead of two per 16),
-// the staging values of tile t + 1 are requested before tile t is multiplied and written behind it. Takes every launch
-// except the stencil-aware softplus prologue (softplus_b with eo_cols: the forward's hidden layers, a tenth of its
-// work, stay on the kernel above): layer 0 of the forward, every weight- and data-gradient contraction.
+// The scalar kernel (any strides, any alignment): 64 x 128 x 16 LDS tiles, a wave owns 32 rows x 64 columns (two 32 x 32
+// accumulators fed by ONE A value: three 4-byte LDS reads per two MFMAs), the LDS tiles double buffered (one workgroup
+// barrier per 16 k), the staging values of tile t + 1 requested before tile t is multiplied and written behind it.
 constexpr int T2M = 64, T2N = 128;
 
 __global__ void __launch_bounds__(256) gemm_generic2_kernel(NsvdGemm g) {
@@ -140,19 +62,14 @@ __global__ void __launch_bounds__(256) gemm_generic2_kernel(NsvdGemm g) {
             rb[i] = (gn < g.N && gk < g.K) ? Bm[(size_t)gk * g.sBk + (size_t)gn * g.sBn] : 0.f;
         }
     };
-    auto stage = [&](int buf, int k0) {
+    auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) As[buf][akk[i]][amm[i]] = ra[i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v = rb[i];
-            // (softplus of the zero padding would be log 2: padding stays zero)
-            if (g.softplus_b && n0 + bnn[i] < g.N && k0 + bkk[i] < g.K) v = nsvd_softplus(v);
-            Bs[buf][bkk[i]][bnn[i]] = v;
-        }
+        for (int i = 0; i < 8; ++i) Bs[buf][bkk[i]][bnn[i]] = rb[i];
     };
     request(0);
-    stage(0, 0);
+    stage(0);
     __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < g.K; k0 += TK) {
@@ -165,7 +82,7 @@ __global__ void __launch_bounds__(256) gemm_generic2_kernel(NsvdGemm g) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
         }
-        if (more) stage(buf ^ 1, k0 + TK);
+        if (more) stage(buf ^ 1);
         __syncthreads();  // tile t + 1 is staged, and every wave is done with tile t (the buffer tile t + 2 goes to)
         buf ^= 1;
     }
@@ -180,24 +97,24 @@ __global__ void __launch_bounds__(256) gemm_generic2_kernel(NsvdGemm g) {
             if (gm >= g.M || gn >= g.N) continue;
             const float bi = bias ? bias[gm] : 0.f;
             float v = (blk ? acc1[r] : acc0[r]) + ((g.eo_cols > 0 && gn >= g.eo_cols) ? 0.f : bi);
-            if (g.sigmoid_mul) v *= nsvd_sigmoid(Z[(size_t)gm * g.sZm + gn]);
+            if (g.sigmoid_mul) v *= nsvd_sigmoid_from_softplus(Z[(size_t)gm * g.sZm + gn]);
             C[(size_t)gm * g.sCm + gn] = v;
         }
     }
 }
 
 // Round 6, the vectorised form: the same contraction for launches whose fast axes are 16-byte aligned (every launch of
-// the generic path at batch sizes that are multiples of 4). What changes against the
-// kernel above:
+// the generic path at batch sizes that are multiples of 4). What changes against the kernel above:
 //  * 16-byte global loads along each operand's contiguous axis (k-contiguous operands are transposed on their way into
 //    the LDS: four 4-byte writes, conflict-free with the 4-float row padding; m / n-contiguous ones go in as ds_write_b128);
 //  * no branch around any load: ragged M / N edges CLAMP the row / column (the values land in accumulator rows / columns
 //    that are never stored), so a K step's loads issue back to back and stay in flight under the previous step's MFMAs;
-//  * larger tiles, chosen per launch: a wave owns MI x NI accumulators of 32 x 32 (2 x 2 waves): 128 x 128 for M > 64
-//    (32 FLOP per staged byte against 21 of the 64 x 128 tile: the staging traffic, L2 -> LDS, is what bounded the kernel
-//    above at 0.49 of the MFMA peak), 64 x 256 or 64 x 128 for M <= 64;
-//  * the stencil-aware softplus prologue (even / odd form, three loads per element) on the same path.
-template <int MI, int NI, bool AK, bool BK, bool EO>
+//  * larger tiles, chosen per launch: a wave owns MI x NI accumulators of 32 x 32 (2 x 2 waves): 128 x 128 (32 FLOP per
+//    staged byte against 21 of the 64 x 128 tile), 64 x 256, 64 x 128 or 64 x 64 - the largest that still gives the chip
+//    >= 1024 workgroups (four per CU: what the registers and the LDS let reside);
+//  * K tails by select (an item past K loads from the operand's base and is staged as zero);
+//  * the epilogue's loads (bias, the stored activation of the sigmoid factor) batched per accumulator block.
+template <int MI, int NI, bool AK, bool BK>
 __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kernel(NsvdGemm g) {
     constexpr int TM3 = 64 * MI, TN3 = 64 * NI, LDA = TM3 + PAD, LDB = TN3 + PAD;
     __shared__ __attribute__((aligned(16))) float As[2][TK][LDA];
@@ -219,7 +136,7 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // staging items of this thread (fixed for the whole loop): MI float4 of A, NI float4 of B (EO: three per item)
+    // staging items of this thread (fixed for the whole loop): MI float4 of A, NI float4 of B
     const float* pa[MI];
     int wa[MI];  // LDS float offset inside a stage of As
     int ka[MI], kb[NI];  // first k of the item inside a K step
@@ -242,42 +159,28 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
     }
     const float* pb[NI];
     int wb[NI];
-    int eoE[NI], eoO[NI];  // EO: float offsets from the element to its pair's even / odd pre-activation (0: centre block)
-    bool eoOdd[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int idx = t + 256 * i;
-        int gn;
         if (BK) {  // B[n][k], k contiguous
             const int q = idx & 3, n = idx >> 2;
-            gn = min(n0 + n, g.N - 1);
+            const int gn = min(n0 + n, g.N - 1);
             pb[i] = Bm + (size_t)gn * g.sBn + 4 * q;
             wb[i] = 4 * q * LDB + n;
             kb[i] = 4 * q;
         } else {   // B[k][n], n contiguous
             const int nq = idx % (TN3 / 4), k = idx / (TN3 / 4);
-            gn = min(n0 + 4 * nq, g.N - 4);
+            const int gn = min(n0 + 4 * nq, g.N - 4);
             pb[i] = Bm + (size_t)k * g.sBk + gn;
             wb[i] = k * LDB + 4 * nq;
             kb[i] = k;
         }
-        eoE[i] = eoO[i] = 0; eoOdd[i] = false;
-        if (EO) {  // (n-contiguous only; eo_cols % 4 == 0: the four columns of an item share their stencil block)
-            const int e = gn / g.eo_cols, bcol = gn - e * g.eo_cols;
-            if (e > 0) {
-                const int dd = (e - 1) >> 1;
-                pb[i] = Bm + (size_t)(idx / (TN3 / 4)) * g.sBk + bcol;  // the CENTRE pre-activation
-                eoE[i] = (1 + 2 * dd) * g.eo_cols;
-                eoO[i] = (2 + 2 * dd) * g.eo_cols;
-                eoOdd[i] = (e - 1) & 1;
-            }
-        }
     }
     const size_t stepA = AK ? (size_t)TK : (size_t)TK * g.sAk;
     const size_t stepB = BK ? (size_t)TK : (size_t)TK * g.sBk;
-    float4 ra[MI], rb[NI], rbE[EO ? NI : 1], rbO[EO ? NI : 1];
+    float4 ra[MI], rb[NI];
     // K tail (K % 16 != 0; k-contiguous operands: K % 4 == 0, so a float4 is inside or outside as a whole): an item past
-    // K loads from the operand's base (valid, aligned) and is staged as ZERO - behind the prologue: softplus(0) = ln 2
+    // K loads from the operand's base (valid, aligned) and is staged as ZERO
     bool kva[MI], kvb[NI];
     auto request = [&](int k0) {
 #pragma unroll
@@ -289,12 +192,7 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             kvb[i] = k0 + kb[i] < g.K;
-            const float* p = kvb[i] ? pb[i] : Bm;
-            rb[i] = *(const float4*)p;
-            if (EO) {
-                rbE[i] = *(const float4*)(p + eoE[i]);
-                rbO[i] = *(const float4*)(p + eoO[i]);
-            }
+            rb[i] = *(const float4*)(kvb[i] ? pb[i] : Bm);
             pb[i] += stepB;
         }
     };
@@ -303,30 +201,16 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         float* bs = &Bs[buf][0][0];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            if (!kva[i]) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 u = kva[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (AK) {
-                as[wa[i]] = ra[i].x; as[wa[i] + LDA] = ra[i].y; as[wa[i] + 2 * LDA] = ra[i].z; as[wa[i] + 3 * LDA] = ra[i].w;
+                as[wa[i]] = u.x; as[wa[i] + LDA] = u.y; as[wa[i] + 2 * LDA] = u.z; as[wa[i] + 3 * LDA] = u.w;
             } else {
-                *(float4*)(as + wa[i]) = ra[i];
+                *(float4*)(as + wa[i]) = u;
             }
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            float4 v = rb[i];
-            if (EO) {
-                if (eoE[i] == 0) {
-                    v.x = nsvd_softplus(v.x); v.y = nsvd_softplus(v.y); v.z = nsvd_softplus(v.z); v.w = nsvd_softplus(v.w);
-                } else {
-                    float ev, od;
-                    nsvd_softplus_evenodd(rb[i].x, rbE[i].x, rbO[i].x, &ev, &od); v.x = eoOdd[i] ? od : ev;
-                    nsvd_softplus_evenodd(rb[i].y, rbE[i].y, rbO[i].y, &ev, &od); v.y = eoOdd[i] ? od : ev;
-                    nsvd_softplus_evenodd(rb[i].z, rbE[i].z, rbO[i].z, &ev, &od); v.z = eoOdd[i] ? od : ev;
-                    nsvd_softplus_evenodd(rb[i].w, rbE[i].w, rbO[i].w, &ev, &od); v.w = eoOdd[i] ? od : ev;
-                }
-            } else if (g.softplus_b) {
-                v.x = nsvd_softplus(v.x); v.y = nsvd_softplus(v.y); v.z = nsvd_softplus(v.z); v.w = nsvd_softplus(v.w);
-            }
-            if (!kvb[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = kvb[i] ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (BK) {
                 bs[wb[i]] = v.x; bs[wb[i] + LDB] = v.y; bs[wb[i] + 2 * LDB] = v.z; bs[wb[i] + 3 * LDB] = v.w;
             } else {
@@ -359,9 +243,10 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         __syncthreads();  // tile t + 1 is staged, and every wave is done with tile t (the buffer tile t + 2 goes to)
         buf ^= 1;
     }
-    // epilogue: every load of an accumulator block (bias, the sigmoid's argument) is issued before the first store, so 16
-    // loads are in flight instead of one per round trip. Addresses = a wave-uniform row base (scalar registers) + ONE
-    // 32-bit lane offset per matrix (generic3_ok: M x row stride < 2^31) - 64-bit addresses per element cost an occupancy step.
+    // epilogue: every load of an accumulator block (bias, the sigmoid factor's stored activation) is issued before the
+    // first store, so 16 loads are in flight instead of one per round trip. Addresses = a wave-uniform row base (scalar
+    // registers) + ONE 32-bit lane offset per matrix (generic3_ok: M x row stride < 2^31) - 64-bit addresses per element
+    // cost an occupancy step.
     const float* bias = g.bias ? g.bias + (size_t)bz * g.bBias : nullptr;
     const float* Z = g.Z ? g.Z + (size_t)bz * g.bZ : nullptr;
 #pragma unroll
@@ -369,24 +254,24 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int gn = n0 + 32 * NI * wn + 32 * j + li;
-            const int rb = m0 + 32 * MI * wm + 32 * i + 4 * hi;  // this lane's first row of the block
-            const unsigned zoff = (unsigned)rb * (unsigned)g.sZm + (unsigned)gn;
-            const unsigned coff = (unsigned)rb * (unsigned)g.sCm + (unsigned)gn;
+            const int rb0 = m0 + 32 * MI * wm + 32 * i + 4 * hi;  // this lane's first row of the block
+            const unsigned zoff = (unsigned)rb0 * (unsigned)g.sZm + (unsigned)gn;
+            const unsigned coff = (unsigned)rb0 * (unsigned)g.sCm + (unsigned)gn;
             const bool centre = !(g.eo_cols > 0 && gn >= g.eo_cols);
             float zv[16], bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = (r & 3) + 8 * (r >> 2);
-                const bool ok = rb + ro < g.M && gn < g.N;
-                bv[r] = (bias && ok) ? (bias + ro)[rb] : 0.f;
+                const bool ok = rb0 + ro < g.M && gn < g.N;
+                bv[r] = (bias && ok) ? (bias + ro)[rb0] : 0.f;
                 zv[r] = (g.sigmoid_mul && ok) ? (Z + (size_t)ro * g.sZm)[zoff] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] + (centre ? bv[r] : 0.f);
-                if (g.sigmoid_mul) v *= nsvd_sigmoid(zv[r]);
-                if (rb + ro < g.M && gn < g.N) (C + (size_t)ro * g.sCm)[coff] = v;
+                if (g.sigmoid_mul) v *= nsvd_sigmoid_from_softplus(zv[r]);
+                if (rb0 + ro < g.M && gn < g.N) (C + (size_t)ro * g.sCm)[coff] = v;
             }
             __builtin_amdgcn_sched_barrier(0);  // (the next block's loads stay behind this block's stores: registers)
         }
@@ -395,14 +280,12 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
 template <int MI, int NI>
 int launch_generic3(const NsvdGemm& g, hipStream_t s) {
     const bool ak = g.sAk == 1, bk = g.sBk == 1;
-    const bool eo = g.softplus_b && g.eo_cols > 0;
     dim3 grid(nsvd_cdiv(g.N, 64 * NI), nsvd_cdiv(g.M, 64 * MI), g.batch);
-#define NSVD_G3(AKv, BKv, EOv) hipLaunchKernelGGL((gemm_generic3_kernel<MI, NI, AKv, BKv, EOv>), grid, dim3(256), 0, s, g)
-    if (eo) { if (ak) NSVD_G3(true, false, true); else NSVD_G3(false, false, true); }
-    else if (ak && bk) NSVD_G3(true, true, false);
-    else if (ak) NSVD_G3(true, false, false);
-    else if (bk) NSVD_G3(false, true, false);
-    else NSVD_G3(false, false, false);
+#define NSVD_G3(AKv, BKv) hipLaunchKernelGGL((gemm_generic3_kernel<MI, NI, AKv, BKv>), grid, dim3(256), 0, s, g)
+    if (ak && bk) NSVD_G3(true, true);
+    else if (ak) NSVD_G3(true, false);
+    else if (bk) NSVD_G3(false, true);
+    else NSVD_G3(false, false);
 #undef NSVD_G3
     NSVD_CHECK_LAUNCH();
     return 0;
@@ -420,8 +303,54 @@ bool generic3_ok(const NsvdGemm& g) {
     if (g.sBk == 1) { if (!al4(g.sBn) || !al4(g.K)) return false; }
     else if (g.sBn == 1) { if (!al4(g.sBk) || !al4(g.N) || g.N < 4) return false; }
     else return false;
-    if (g.softplus_b && g.eo_cols > 0 && (g.sBn != 1 || !al4(g.eo_cols) || g.N % g.eo_cols)) return false;
     return true;
+}
+
+// In place: a layer's pre-activations -> activations (what the next layer's contraction, the weight gradient and the
+// data gradient's sigmoid factor read). z: rows x R, R = nst * B columns in stencil blocks of B; block 0 = the centre
+// evaluation -> softplus; blocks 1 + 2 d / 2 + 2 d = the even / odd perturbations along d -> the even /
+// odd parts of softplus(z0 + zE +- zO) - softplus(z0) (nsvd_softplus_evenodd). A thread owns one (row, sample) - or
+// four samples - in EVERY block: it reads the centre value before it overwrites it.
+template <bool VEC>
+__global__ void __launch_bounds__(256) softplus_inplace_kernel(float* __restrict__ z, long rows, int B, int nst, long R) {
+    constexpr int W = VEC ? 4 : 1;
+    const long per = B / W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * per) return;
+    const long row = idx / per;
+    const int b = (int)(idx - row * per) * W;
+    float* p = z + row * R + b;
+    float z0[W], a0[W];
+    if constexpr (VEC) {
+        const float4 v = *(const float4*)p;
+        z0[0] = v.x; z0[1] = v.y; z0[2] = v.z; z0[W - 1] = v.w;
+    } else {
+        z0[0] = p[0];
+    }
+#pragma unroll
+    for (int c = 0; c < W; ++c) a0[c] = nsvd_softplus(z0[c]);
+    for (int d = 0; 2 * d + 2 < nst; ++d) {
+        float* pe = p + (long)(1 + 2 * d) * B;
+        float* po = p + (long)(2 + 2 * d) * B;
+        float ze[W], zo[W];
+        if constexpr (VEC) {
+            const float4 e = *(const float4*)pe, o = *(const float4*)po;
+            ze[0] = e.x; ze[1] = e.y; ze[2] = e.z; ze[W - 1] = e.w;
+            zo[0] = o.x; zo[1] = o.y; zo[2] = o.z; zo[W - 1] = o.w;
+        } else {
+            ze[0] = pe[0]; zo[0] = po[0];
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) nsvd_softplus_evenodd(z0[c], ze[c], zo[c], &ze[c], &zo[c]);
+        if constexpr (VEC) {
+            *(float4*)pe = make_float4(ze[0], ze[1], ze[2], ze[W - 1]);
+            *(float4*)po = make_float4(zo[0], zo[1], zo[2], zo[W - 1]);
+        } else {
+            pe[0] = ze[0]; po[0] = zo[0];
+        }
+    }
+    if constexpr (VEC) *(float4*)p = make_float4(a0[0], a0[1], a0[2], a0[W - 1]);
+    else p[0] = a0[0];
 }
 
 __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
@@ -441,8 +370,6 @@ __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ i
 
 int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return NSVD_EINVAL;
-    // the stencil-aware softplus prologue (three loads per staged element) stays on the 64 x 64 kernel; everything else takes
-    // the pipelined 64 x 128 one (NSVD_GEMM_GENERIC2=0: the old kernel everywhere, for A/B measurements)
     // the vectorised kernel where the launch allows it (NSVD_GEMM_GENERIC3=0: off, for A/B measurements)
     static const char* e3 = getenv("NSVD_GEMM_GENERIC3");
     if (!(e3 && e3[0] == '0') && generic3_ok(g)) {
@@ -454,20 +381,24 @@ int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s) {
         const long minwg = emw ? atol(emw) : 1024;
         auto nwg = [&](int tm, int tn) { return (long)nsvd_cdiv(g.M, tm) * nsvd_cdiv(g.N, tn) * g.batch; };
         if (g.M > 64 && nwg(128, 128) >= minwg) return launch_generic3<2, 2>(g, s);
-        // (the 64 x 256 instance with the even / odd prologue would spill 40 registers: never chosen)
-        if (!(g.softplus_b && g.eo_cols > 0) && g.N >= 256 && nwg(64, 256) >= minwg) return launch_generic3<1, 4>(g, s);
+        if (g.N >= 256 && nwg(64, 256) >= minwg) return launch_generic3<1, 4>(g, s);
         if (nwg(64, 128) >= minwg) return launch_generic3<1, 2>(g, s);
         return launch_generic3<1, 1>(g, s);
     }
-    static const char* e2 = getenv("NSVD_GEMM_GENERIC2");
-    if (!(g.softplus_b && g.eo_cols > 0) && !(e2 && e2[0] == '0')) {
-        dim3 grid2(nsvd_cdiv(g.N, T2N), nsvd_cdiv(g.M, T2M), g.batch);
-        hipLaunchKernelGGL(gemm_generic2_kernel, grid2, dim3(256), 0, s, g);
-        NSVD_CHECK_LAUNCH();
-        return 0;
-    }
-    dim3 grid(nsvd_cdiv(g.N, TN), nsvd_cdiv(g.M, TM), g.batch);
-    hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, s, g);
+    dim3 grid2(nsvd_cdiv(g.N, T2N), nsvd_cdiv(g.M, T2M), g.batch);
+    hipLaunchKernelGGL(gemm_generic2_kernel, grid2, dim3(256), 0, s, g);
+    NSVD_CHECK_LAUNCH();
+    return 0;
+}
+
+int nsvd_softplus_inplace(float* z, long rows, int B, int nst, hipStream_t s) {
+    if (!z || rows <= 0 || B <= 0 || nst < 1 || (nst > 1 && (nst & 1) == 0)) return NSVD_EINVAL;
+    const long R = (long)nst * B;
+    const bool vec = (B & 3) == 0 && ((uintptr_t)z & 15) == 0;
+    const long n = rows * (vec ? B / 4 : B);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (vec) hipLaunchKernelGGL(softplus_inplace_kernel<true>, dim3(blocks), dim3(256), 0, s, z, rows, B, nst, R);
+    else hipLaunchKernelGGL(softplus_inplace_kernel<false>, dim3(blocks), dim3(256), 0, s, z, rows, B, nst, R);
     NSVD_CHECK_LAUNCH();
     return 0;
 }

@@ -22,8 +22,8 @@ int nsvd_fourier_plain(const float* x, const float* fourier_B, float* phi, float
 int nsvd_sample_launch(const NsvdSampler& smp, float* x, int B, int D, hipStream_t s);
 
 // ---- generic strided batched GEMM (gemm_generic.hip) -------------------------------------------
-//   C[g][i][j] = epi( sum_k A[g][i*sAm + k*sAk] * pro(B[g][k*sBk + j*sBn]) + bias[g][i] )
-// pro: optional softplus on B elements; epi: optional multiply by sigmoid(Z[g][i*sZm + j]).
+//   C[g][i][j] = epi( sum_k A[g][i*sAm + k*sAk] * B[g][k*sBk + j*sBn] + bias[g][i] )
+// epi: optional multiply by sigmoid(z) GIVEN a = softplus(z) stored at Z[g][i*sZm + j] (nsvd_sigmoid_from_softplus).
 struct NsvdGemm {
     const float* A = nullptr;
     const float* B = nullptr;
@@ -35,15 +35,16 @@ struct NsvdGemm {
     long bBias = 0;
     const float* Z = nullptr;
     long sZm = 0, bZ = 0;
-    int softplus_b = 0;
     int sigmoid_mul = 0;
     // stencil columns in even / odd form (eo_cols = samples per stencil block, 0: off): column j belongs to block
     // e = j / eo_cols (0 the centre, 1 + 2 d / 2 + 2 d the even / odd perturbation along d). The bias joins the centre
-    // block only; with softplus_b the B element of a perturbation column is the even / odd part of the softplus of the
-    // pair (nsvd_softplus_evenodd on the centre, even and odd pre-activations of the same sample: three loads)
+    // block only.
     int eo_cols = 0;
 };
 int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s);
+// in place, z (rows x nst * B, stencil blocks of B columns): pre-activations -> activations; block 0 softplus, blocks
+// 1 + 2 d / 2 + 2 d the even / odd parts of the softplus of the shifted pair (nst = 1: plain softplus)
+int nsvd_softplus_inplace(float* z, long rows, int B, int nst, hipStream_t s);
 
 // out[g][i] = sum_j in[g][i*ld + j], j < n   (bias gradients)
 int nsvd_rowsum(const float* in, float* out, int rows, int n, long ld, hipStream_t s);

@@ -807,7 +807,10 @@ def profile_next_forward(ev_start: "torch.cuda.Event", ev_stop: "torch.cuda.Even
 
 
 def dominant_kernel_name(shape: ModelShape, B: int, path: int = PATH_AUTO) -> str:
-    return "pmlp_fused_fwd_kernel" if path_name(shape, B, path).startswith("fused") else "gemm_generic3_kernel[layer0]"
+    if path_name(shape, B, path).startswith("fused"):
+        return "pmlp_fused_fwd_kernel"
+    # generic path: the bracket spans the whole forward (features, every layer's contraction + activation pass, epilogue)
+    return "generic forward [fourier_evenodd_kernel, gemm_generic3_kernel + softplus_inplace_kernel per layer, fd_epilogue_kernel]"
 
 
 # ------------------------------------------------------------------------------ row normalisation (CDK towers)

@@ -674,8 +674,9 @@ def test_exact_mode_three_dimensional(fpath):
 def test_generic_path_at_other_hidden_widths(hidden, B, D, L, m):
     """Hidden widths the fused MFMA kernels do not take (the reference accepts any --mlp_hidden_dims,
     examples/models/mlp.py:187-221) run the generic contractions (gemm_generic.hip: round 6's vectorised kernel with its
-    four tile shapes, clamped edges, K tails and the even / odd softplus prologue; the scalar kernel for unaligned
-    launches): f, Tf and every gradient against the float64 oracle at the same tolerances as the fused path."""
+    four tile shapes, clamped edges and K tails, the scalar kernel for unaligned launches, the in-place even / odd
+    softplus pass between layers - vectorised and scalar): f, Tf and every gradient against the float64 oracle at the
+    same tolerances as the fused path."""
     p = O.init_params(L, D, m, hidden, 0.2, exp_mask_init=4.0, seed=7)
     prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=3.0)
     v, M = O.sequential_nesting_masks(L)
