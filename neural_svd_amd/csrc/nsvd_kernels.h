@@ -114,6 +114,20 @@ bool nsvd_fused_backward_window_ok(const nsvd_model_desc& d, int B, int l_count)
 int nsvd_rmsprop_launch(float* p, const float* grad, float* sq, float* ema, size_t n, const NsvdHyper& h,
                         hipStream_t s, nsvd_step_state* state = nullptr, int advance = 0);
 
+// the same update over a table of tensors in ONE launch (start[] is filled by the launcher; every pointer 16-byte aligned,
+// else NSVD_EUNSUPPORTED and nothing is launched)
+constexpr int NSVD_OPT_TABLE_MAX = 2 * NSVD_MAX_LAYERS + 1;
+struct NsvdOptTable {
+    float* p[NSVD_OPT_TABLE_MAX];
+    const float* g[NSVD_OPT_TABLE_MAX];
+    float* sq[NSVD_OPT_TABLE_MAX];
+    float* ema[NSVD_OPT_TABLE_MAX];  // all null: no EMA
+    size_t n[NSVD_OPT_TABLE_MAX];
+    size_t start[NSVD_OPT_TABLE_MAX + 1];  // prefix sums in float4 groups
+    int count;
+};
+int nsvd_rmsprop_table_launch(NsvdOptTable& t, const NsvdHyper& h, hipStream_t s);
+
 // ---- CDK towers (tower.hip): the backward with per-workgroup sums of squares of the two weight-gradient contractions
 // (cdk_step.hip clips the global gradient norm without another pass over them)
 int nsvd_tower_sumsq_count(int d0, int d1, int d2, int gemm_bf16 = 0);

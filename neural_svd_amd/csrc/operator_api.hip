@@ -1,6 +1,7 @@
 // extern "C" entry points for the operator forward / backward: argument validation, workspace
 // carving, and the choice between the fused MFMA kernels (pmlp_fwd.hip, pmlp_bwd.hip) and the generic
 // layer-by-layer path implemented here on top of gemm_generic.hip / fd_epilogue.hip.
+#include <stdlib.h>
 #include <string.h>
 #include "nsvd_kernels.h"
 #include "evd_math.h"
@@ -465,8 +466,29 @@ int backward_evd_impl(const nsvd_model_desc* desc, const nsvd_params* params, co
     if (!grads) return NSVD_EINVAL;  // the generic path needs somewhere to put the gradients
     rc = generic_backward(*desc, *params, x, B, w.df, *grads, ws, s);
     if (rc || !opt) return rc;
-    // generic path + fused-step request: one stand-alone optimiser launch per tensor
+    // generic path + fused-step request: ONE stand-alone optimiser launch over the table of tensors (unaligned tensors -
+    // never with torch allocations -: one launch per tensor)
     const int F = 2 * desc->m;
+    {
+        NsvdOptTable tab;
+        memset(&tab, 0, sizeof(tab));
+        int c = 0;
+        auto add = [&](float* pp, const float* gg, float* qq, float* ee, size_t n) {
+            tab.p[c] = pp; tab.g[c] = gg; tab.sq[c] = qq; tab.ema[c] = ee; tab.n[c] = n;
+            ++c;
+        };
+        for (int i = 0; i < desc->nlayers; ++i) {
+            const size_t hin = i == 0 ? (size_t)F : (size_t)desc->dims[i - 1], hout = (size_t)desc->dims[i];
+            add(params->W[i], grads->W[i], st.sq.W[i], st.ema ? st.ema->W[i] : nullptr, (size_t)desc->L * hout * hin);
+            add(params->b[i], grads->b[i], st.sq.b[i], st.ema ? st.ema->b[i] : nullptr, (size_t)desc->L * hout);
+        }
+        if (desc->has_exp_mask)
+            add(params->scales, grads->scales, st.sq.scales, st.ema ? st.ema->scales : nullptr, (size_t)desc->L);
+        tab.count = c;
+        static const char* et = getenv("NSVD_OPT_TABLE");  // 0: one launch per tensor (A/B, bit-identical)
+        rc = (et && et[0] == '0') ? NSVD_EUNSUPPORTED : nsvd_rmsprop_table_launch(tab, st.h, s);
+        if (rc != NSVD_EUNSUPPORTED) return rc;
+    }
     for (int i = 0; i < desc->nlayers; ++i) {
         const size_t hin = i == 0 ? (size_t)F : (size_t)desc->dims[i - 1], hout = (size_t)desc->dims[i];
         rc = nsvd_rmsprop_launch(params->W[i], grads->W[i], st.sq.W[i], st.ema ? st.ema->W[i] : nullptr,
