@@ -196,6 +196,12 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
             pb[i] += stepB;
         }
     };
+    // row sums of A over K (g.rowsum: the bias gradient of a weight-gradient launch, A = dz): a k-contiguous item is
+    // four k of ONE row, the same row at every K step - the first column tile's workgroups add them up as they stage
+    float rs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rs[i] = 0.f;
+    const bool do_rs = AK && g.rowsum != nullptr && blockIdx.x == 0;
     auto stage = [&](int buf) {
         float* as = &As[buf][0][0];
         float* bs = &Bs[buf][0][0];
@@ -203,6 +209,7 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         for (int i = 0; i < MI; ++i) {
             const float4 u = kva[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (AK) {
+                if (do_rs) rs[i] += (u.x + u.y) + (u.z + u.w);
                 as[wa[i]] = u.x; as[wa[i] + LDA] = u.y; as[wa[i] + 2 * LDA] = u.z; as[wa[i] + 3 * LDA] = u.w;
             } else {
                 *(float4*)(as + wa[i]) = u;
@@ -242,6 +249,16 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         if (more) stage(buf ^ 1);
         __syncthreads();  // tile t + 1 is staged, and every wave is done with tile t (the buffer tile t + 2 goes to)
         buf ^= 1;
+    }
+    if (AK && do_rs) {  // the four k-quads of a row sit in four neighbouring lanes
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            const int m = (t + 256 * i) >> 2;
+            if ((t & 3) == 0 && m0 + m < g.M) g.rowsum[(size_t)bz * g.bRowsum + m0 + m] = v;
+        }
     }
     // epilogue: every load of an accumulator block (bias, the sigmoid factor's stored activation) is issued before the
     // first store, so 16 loads are in flight instead of one per round trip. Addresses = a wave-uniform row base (scalar
@@ -368,8 +385,9 @@ __global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ i
 
 }  // namespace
 
-int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s) {
+int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s, bool* rowsum_done) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return NSVD_EINVAL;
+    if (rowsum_done) *rowsum_done = false;
     // the vectorised kernel where the launch allows it (NSVD_GEMM_GENERIC3=0: off, for A/B measurements)
     static const char* e3 = getenv("NSVD_GEMM_GENERIC3");
     if (!(e3 && e3[0] == '0') && generic3_ok(g)) {
@@ -377,6 +395,7 @@ int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s) {
         // the registers and the LDS let reside - measured against 128 / 256 / 512: hidden width 64 0.47 / 0.40 / 0.34 /
         // 0.34 ms per step, hidden width 128 0.65 / 0.62 / 0.53 / 0.47); a launch too small for any of them takes the
         // smallest tile
+        if (rowsum_done) *rowsum_done = g.rowsum != nullptr && g.sAk == 1;  // (the k-contiguous-A instances add the row sums)
         static const char* emw = getenv("NSVD_G3_MINWG");
         const long minwg = emw ? atol(emw) : 1024;
         auto nwg = [&](int tm, int tn) { return (long)nsvd_cdiv(g.M, tm) * nsvd_cdiv(g.N, tn) * g.batch; };

@@ -36,12 +36,16 @@ struct NsvdGemm {
     const float* Z = nullptr;
     long sZm = 0, bZ = 0;
     int sigmoid_mul = 0;
+    // optional: rowsum[g * bRowsum + i] = sum_k A[g][i][k] (the bias gradient beside a weight gradient); computed by the
+    // launch itself where it can (nsvd_gemm_generic's rowsum_done), by nsvd_rowsum otherwise
+    float* rowsum = nullptr;
+    long bRowsum = 0;
     // stencil columns in even / odd form (eo_cols = samples per stencil block, 0: off): column j belongs to block
     // e = j / eo_cols (0 the centre, 1 + 2 d / 2 + 2 d the even / odd perturbation along d). The bias joins the centre
     // block only.
     int eo_cols = 0;
 };
-int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s);
+int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s, bool* rowsum_done = nullptr);
 // in place, z (rows x nst * B, stencil blocks of B columns): pre-activations -> activations; block 0 softplus, blocks
 // 1 + 2 d / 2 + 2 d the even / odd parts of the softplus of the shifted pair (nst = 1: plain softplus)
 int nsvd_softplus_inplace(float* z, long rows, int B, int nst, hipStream_t s);

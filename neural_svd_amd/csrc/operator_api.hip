@@ -162,10 +162,15 @@ int generic_backward(const nsvd_model_desc& d, const nsvd_params& p, const float
         wg.A = w.dz[cur]; wg.sAm = B; wg.sAk = 1; wg.bA = (long)hi * B;
         wg.B = (i == 0) ? w.phiT : w.z[i - 1]; wg.sBk = 1; wg.sBn = R; wg.bB = (i == 0) ? 0 : (long)kin * R;
         wg.C = g.W[i]; wg.sCm = kin; wg.bC = (long)hi * kin;
-        rc = nsvd_gemm_generic(wg, s);
+        // bias gradient = row sums of dz_i: inside the weight-gradient launch where the kernel can, its own launch otherwise
+        wg.rowsum = g.b[i]; wg.bRowsum = hi;
+        bool rowsum_done = false;
+        rc = nsvd_gemm_generic(wg, s, &rowsum_done);
         if (rc) return rc;
-        rc = nsvd_rowsum(w.dz[cur], g.b[i], d.L * hi, B, B, s);
-        if (rc) return rc;
+        if (!rowsum_done) {
+            rc = nsvd_rowsum(w.dz[cur], g.b[i], d.L * hi, B, B, s);
+            if (rc) return rc;
+        }
         if (i > 0) {
             // data gradient: dz_{i-1}[l][k][b] = (sum_n W_i[l][n][k] dz_i[l][n][b]) * sigmoid(z_{i-1}[l][k][b]), the sigmoid
             // from the stored activation (1 - e^-a)
