@@ -17,6 +17,12 @@ for cfg in cfg1 cfg3 cfg4 cfg5; do
   NSVD_PROFILE_PMC=0 timeout 600 bash scripts/collect_profiles.sh ${tag}_$cfg --config $cfg > $out/collect_$cfg.log 2>&1; echo "collect $cfg rc=$?"
 done
 NSVD_PROFILE_PMC=0 timeout 600 bash scripts/collect_profiles.sh ${tag}_cfg5_f16 --config cfg5 --amp --amp-dtype float16 > $out/collect_cfg5_f16.log 2>&1; echo "collect cfg5 f16 rc=$?"
+# the generic path (hidden widths 256 / 64 at configs[1]'s sizes): per-(kernel, grid) launch durations, SQ counters
+TOPN=16 TAILN=2 timeout 300 scripts/gpu/prof_by_grid.sh ${tag}_gen256 /root/repo/scripts/dev/generic_time.py 256 > $out/generic_h256_by_grid.txt 2>&1
+TOPN=16 TAILN=2 timeout 300 scripts/gpu/prof_by_grid.sh ${tag}_gen64 /root/repo/scripts/dev/generic_time.py 64 > $out/generic_h64_by_grid.txt 2>&1
+timeout 300 scripts/gpu/pmc_kernels.sh ${tag}_gen256_pmc "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" /root/repo/scripts/dev/generic_time.py 256 > $out/generic_h256_pmc_sq.txt 2>&1
+timeout 300 scripts/gpu/pmc_kernels.sh ${tag}_gen256_pmc2 "TCC_HIT_sum TCC_MISS_sum" /root/repo/scripts/dev/generic_time.py 256 > $out/generic_h256_pmc_l2.txt 2>&1
+echo "generic evidence done"
 SECONDS=0; timeout 1200 python bench.py --steps 20 --warmup 5 > $out/bench_driver_args.json 2> $out/bench_driver_args.err; echo "bench rc=$? in ${SECONDS}s"
 NSVD_FORCE_DEVICE=0 NSVD_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --accuracy off > $out/bench_n2_gloo.json 2> $out/bench_n2_gloo.err; echo "bench n2 rc=$?"
 timeout 600 python bench.py --gpus 1 --force-exchange --steps 200 --warmup 20 --accuracy off > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err; echo "bench rccl1 rc=$?"
