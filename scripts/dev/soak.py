@@ -14,6 +14,10 @@ cases = [
     ("oscillator bf16x3 L=32 B=4096", dict(L=32, m=256, hidden=(128,) * 3, B=4096, seq=True, pot="o", eps=0.01, path=H.PATH_FUSED_BF16X3)),
     ("generic path: hidden 64x3, L=6, B=256 oscillator", dict(L=6, m=64, hidden=(64,) * 3, B=256, seq=True, pot="o", eps=0.01, lr=1e-3, fs=0.15)),
     ("generic path: ragged B=100, hidden 128x2 hydrogen", dict(L=4, m=128, hidden=(128,) * 2, B=100, seq=False, pot="h", eps=0.01)),
+    ("generic path: hidden 256x3 hydrogen L=16 B=512", dict(L=16, m=1024, hidden=(256,) * 3, B=512, seq=False, pot="h", eps=0.01)),
+    ("generic path: hidden (96, 96) oscillator L=32 B=512", dict(L=32, m=256, hidden=(96, 96), B=512, seq=True, pot="o", eps=0.01)),
+    ("generic path: hidden (40, 24) B=100 (K tails, clamped edges)", dict(L=5, m=34, hidden=(40, 24), B=100, seq=True, pot="o", eps=0.01)),
+    ("generic path: hidden 64x3 B=101 (scalar kernels)", dict(L=3, m=33, hidden=(64,) * 3, B=101, seq=False, pot="h", eps=0.01)),
     ("hydrogen L=16 B=512 jnt step=4", dict(L=16, m=1024, hidden=(128,) * 3, B=512, seq=False, pot="h", eps=0.01, step=4)),
     ("hydrogen L=1 B=512", dict(L=1, m=1024, hidden=(128,) * 3, B=512, seq=True, pot="h", eps=0.01)),
     ("hydrogen L=128 B=64 m=64", dict(L=128, m=64, hidden=(128,) * 3, B=64, seq=True, pot="h", eps=0.01)),
