@@ -396,7 +396,7 @@ int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s, bool* rowsum_done) {
         // 0.34 ms per step, hidden width 128 0.65 / 0.62 / 0.53 / 0.47); a launch too small for any of them takes the
         // smallest tile
         if (rowsum_done) *rowsum_done = g.rowsum != nullptr && g.sAk == 1;  // (the k-contiguous-A instances add the row sums)
-        static const char* emw = getenv("NSVD_G3_MINWG");
+        const char* emw = getenv("NSVD_G3_MINWG");  // (read per launch: the tests switch tile shapes with it)
         const long minwg = emw ? atol(emw) : 1024;
         auto nwg = [&](int tm, int tn) { return (long)nsvd_cdiv(g.M, tm) * nsvd_cdiv(g.N, tn) * g.batch; };
         if (g.M > 64 && nwg(128, 128) >= minwg) return launch_generic3<2, 2>(g, s);

@@ -671,12 +671,19 @@ def test_exact_mode_three_dimensional(fpath):
     ((50,), 101, 3, 2, 33),           # nothing 16-byte aligned: the scalar kernel (gemm_generic2) takes every launch
     ((320, 64), 64, 1, 2, 64),        # M = 320 (three 128-row tiles, the last ragged), D = 1 (three stencil blocks)
 ])
-def test_generic_path_at_other_hidden_widths(hidden, B, D, L, m):
+@pytest.mark.parametrize("minwg", [None, "1", "1000000"])
+def test_generic_path_at_other_hidden_widths(hidden, B, D, L, m, minwg, monkeypatch):
     """Hidden widths the fused MFMA kernels do not take (the reference accepts any --mlp_hidden_dims,
     examples/models/mlp.py:187-221) run the generic contractions (gemm_generic.hip: round 6's vectorised kernel with its
     four tile shapes, clamped edges and K tails, the scalar kernel for unaligned launches, the in-place even / odd
     softplus pass between layers - vectorised and scalar): f, Tf and every gradient against the float64 oracle at the
-    same tolerances as the fused path."""
+    same tolerances as the fused path. minwg: the workgroup count the tile choice asks for (NSVD_G3_MINWG, read per
+    launch) - "1" gives every launch the LARGEST tile its M allows (128 x 128 / 64 x 256: ragged edges inside big tiles),
+    "1000000" the smallest (64 x 64), None the default rule."""
+    if minwg is None:
+        monkeypatch.delenv("NSVD_G3_MINWG", raising=False)
+    else:
+        monkeypatch.setenv("NSVD_G3_MINWG", minwg)
     p = O.init_params(L, D, m, hidden, 0.2, exp_mask_init=4.0, seed=7)
     prob = O.Problem(potential=O.POT_HARMONIC, eps=0.01, op_scale=1.0, op_shift=16.0, sigma=3.0)
     v, M = O.sequential_nesting_masks(L)
