@@ -114,17 +114,28 @@ __global__ void __launch_bounds__(256) gemm_generic2_kernel(NsvdGemm g) {
 //    >= 1024 workgroups (four per CU: what the registers and the LDS let reside);
 //  * K tails by select (an item past K loads from the operand's base and is staged as zero);
 //  * the epilogue's loads (bias, the stored activation of the sigmoid factor) batched per accumulator block.
-template <int MI, int NI, bool AK, bool BK>
-__global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kernel(NsvdGemm g) {
+//  * KG > 1 (64 x 64 tiles only): a launch with too few workgroups for the chip (a hidden layer's weight gradient at
+//    H = 64: 16 tiles, K = 512 - 32 serial K steps of one wave per SIMD, 19 us) gives each workgroup KG groups of four
+//    waves; group kg multiplies the kg-th K range into its own accumulators (its own LDS stages), the partial tiles
+//    meet in the LDS and are added in group order (fixed order: bit-reproducible), group 0 runs the epilogue.
+template <int MI, int NI, bool AK, bool BK, int KG = 1>
+__global__ void __launch_bounds__(256 * KG, KG > 1 ? 1 : (MI * NI >= 4 ? 3 : 4)) gemm_generic3_kernel(NsvdGemm g) {
+    static_assert(KG == 1 || (MI == 1 && NI == 1), "the K groups exist for the 64 x 64 tile only");
     constexpr int TM3 = 64 * MI, TN3 = 64 * NI, LDA = TM3 + PAD, LDB = TN3 + PAD;
-    __shared__ __attribute__((aligned(16))) float As[2][TK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TK][LDB];
+    __shared__ __attribute__((aligned(16))) float AsG[KG][2][TK][LDA];
+    __shared__ __attribute__((aligned(16))) float BsG[KG][2][TK][LDB];
+    const int kg = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
+    float (*As)[TK][LDA] = AsG[kg];
+    float (*Bs)[TK][LDB] = BsG[kg];
+    // this group's K range: whole K steps, the same trip count for every group (the barriers are the workgroup's)
+    const int ksteps = ((g.K + TK - 1) / TK + KG - 1) / KG;
+    const int kbeg = kg * ksteps * TK, kend = min(g.K, kbeg + ksteps * TK);
     const int bz = blockIdx.z;
     const float* A = g.A + (size_t)bz * g.bA;
     const float* Bm = g.B + (size_t)bz * g.bB;
     float* C = g.C + (size_t)bz * g.bC;
     const int m0 = blockIdx.y * TM3, n0 = blockIdx.x * TN3;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     const int lane = t & 63, wv = t >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;  // this wave: rows 32 MI wm .., columns 32 NI wn ..
@@ -146,13 +157,13 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         if (AK) {  // A[m][k], k contiguous: a float4 = four k of one row
             const int q = idx & 3, m = idx >> 2;
             const int gm = min(m0 + m, g.M - 1);
-            pa[i] = A + (size_t)gm * g.sAm + 4 * q;
+            pa[i] = A + (size_t)gm * g.sAm + 4 * q + kbeg;
             wa[i] = 4 * q * LDA + m;
             ka[i] = 4 * q;
         } else {   // A[k][m], m contiguous: a float4 = four rows at one k
             const int mq = idx % (TM3 / 4), k = idx / (TM3 / 4);
             const int gm = min(m0 + 4 * mq, g.M - 4);
-            pa[i] = A + (size_t)k * g.sAk + gm;
+            pa[i] = A + (size_t)(kbeg + k) * g.sAk + gm;
             wa[i] = k * LDA + 4 * mq;
             ka[i] = k;
         }
@@ -165,13 +176,13 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         if (BK) {  // B[n][k], k contiguous
             const int q = idx & 3, n = idx >> 2;
             const int gn = min(n0 + n, g.N - 1);
-            pb[i] = Bm + (size_t)gn * g.sBn + 4 * q;
+            pb[i] = Bm + (size_t)gn * g.sBn + 4 * q + kbeg;
             wb[i] = 4 * q * LDB + n;
             kb[i] = 4 * q;
         } else {   // B[k][n], n contiguous
             const int nq = idx % (TN3 / 4), k = idx / (TN3 / 4);
             const int gn = min(n0 + 4 * nq, g.N - 4);
-            pb[i] = Bm + (size_t)k * g.sBk + gn;
+            pb[i] = Bm + (size_t)(kbeg + k) * g.sBk + gn;
             wb[i] = k * LDB + 4 * nq;
             kb[i] = k;
         }
@@ -185,13 +196,13 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
     auto request = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            kva[i] = k0 + ka[i] < g.K;
+            kva[i] = k0 + ka[i] < kend;
             ra[i] = *(const float4*)(kva[i] ? pa[i] : A);
             pa[i] += stepA;
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            kvb[i] = k0 + kb[i] < g.K;
+            kvb[i] = k0 + kb[i] < kend;
             rb[i] = *(const float4*)(kvb[i] ? pb[i] : Bm);
             pb[i] += stepB;
         }
@@ -225,12 +236,12 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
             }
         }
     };
-    request(0);
+    request(kbeg);
     stage(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < g.K; k0 += TK) {
-        const bool more = k0 + TK < g.K;
+    for (int k0 = kbeg; k0 < kbeg + ksteps * TK; k0 += TK) {
+        const bool more = k0 + TK < kbeg + ksteps * TK;
         if (more) request(k0 + TK);
         const float* as = &As[buf][hi][32 * MI * wm + li];
         const float* bs = &Bs[buf][hi][32 * NI * wn + li];
@@ -249,6 +260,30 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         if (more) stage(buf ^ 1);
         __syncthreads();  // tile t + 1 is staged, and every wave is done with tile t (the buffer tile t + 2 goes to)
         buf ^= 1;
+    }
+    if (KG > 1) {
+        // the groups' partial tiles (and partial row sums) meet in the LDS: group kg > 0 parks its 16 accumulator values
+        // per lane in ITS OWN stage memory (nobody else reads or writes it), group 0 adds them in group order
+        float* park = &AsG[kg][0][0][0];  // 2 * TK * LDA = 2176 floats per As + the group's Bs behind it
+        static_assert(2 * TK * LDA >= 8 * 256 + 128 && 2 * TK * LDB >= 8 * 256 + 128, "a group's stages hold its parked tile");
+        float* parkB = &BsG[kg][0][0][0];
+        if (kg > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* dst = r < 8 ? park + r * 256 : parkB + (r - 8) * 256;
+                dst[t] = acc[0][0][r];
+            }
+            if (AK) (t < 128 ? park : parkB - 128)[8 * 256 + t] = rs[0];  // (2176 floats per array: 8 x 256 values + 128 spare)
+        }
+        __syncthreads();
+        if (kg > 0) return;
+        for (int o = 1; o < KG; ++o) {
+            const float* pa_ = &AsG[o][0][0][0];
+            const float* pb_ = &BsG[o][0][0][0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += (r < 8 ? pa_ + r * 256 : pb_ + (r - 8) * 256)[t];
+            if (AK) rs[0] += (t < 128 ? pa_ : pb_ - 128)[8 * 256 + t];
+        }
     }
     if (AK && do_rs) {  // the four k-quads of a row sit in four neighbouring lanes
 #pragma unroll
@@ -294,11 +329,11 @@ __global__ void __launch_bounds__(256, MI * NI >= 4 ? 3 : 4) gemm_generic3_kerne
         }
 }
 
-template <int MI, int NI>
+template <int MI, int NI, int KG = 1>
 int launch_generic3(const NsvdGemm& g, hipStream_t s) {
     const bool ak = g.sAk == 1, bk = g.sBk == 1;
     dim3 grid(nsvd_cdiv(g.N, 64 * NI), nsvd_cdiv(g.M, 64 * MI), g.batch);
-#define NSVD_G3(AKv, BKv) hipLaunchKernelGGL((gemm_generic3_kernel<MI, NI, AKv, BKv>), grid, dim3(256), 0, s, g)
+#define NSVD_G3(AKv, BKv) hipLaunchKernelGGL((gemm_generic3_kernel<MI, NI, AKv, BKv, KG>), grid, dim3(256 * KG), 0, s, g)
     if (ak && bk) NSVD_G3(true, true);
     else if (ak) NSVD_G3(true, false);
     else if (bk) NSVD_G3(false, true);
@@ -402,6 +437,9 @@ int nsvd_gemm_generic(const NsvdGemm& g, hipStream_t s, bool* rowsum_done) {
         if (g.M > 64 && nwg(128, 128) >= minwg) return launch_generic3<2, 2>(g, s);
         if (g.N >= 256 && nwg(64, 256) >= minwg) return launch_generic3<1, 4>(g, s);
         if (nwg(64, 128) >= minwg) return launch_generic3<1, 2>(g, s);
+        // fewer 64 x 64 tiles than half the CUs and a long contraction: four K groups per workgroup (NSVD_G3_KGROUPS=0: off)
+        const char* ekg = getenv("NSVD_G3_KGROUPS");
+        if (nwg(64, 64) <= 128 && g.K >= 256 && !(ekg && ekg[0] == '0')) return launch_generic3<1, 1, 4>(g, s);
         return launch_generic3<1, 1>(g, s);
     }
     dim3 grid2(nsvd_cdiv(g.N, T2N), nsvd_cdiv(g.M, T2M), g.batch);

@@ -664,7 +664,7 @@ def test_exact_mode_three_dimensional(fpath):
 
 
 @pytest.mark.parametrize("hidden,B,D,L,m", [
-    ((64, 64, 64), 512, 2, 3, 256),   # 64 x 64 tiles (M <= 64), every operand form vectorised
+    ((64, 64, 64), 512, 2, 3, 256),   # 64 x 64 tiles (M <= 64), every operand form vectorised; K groups (K = 512, 3 tiles)
     ((256, 256), 512, 2, 2, 256),     # 128 x 128 tiles where the launch has >= 1024 workgroups, smaller ones elsewhere
     ((96, 96), 128, 2, 5, 128),       # M = 96: clamped rows of the second 64-row tile
     ((40, 24), 100, 2, 3, 34),        # K = 68 / 40 / 24 / 100 (K tails by select), N = 500, M = 40 / 24 (ragged everywhere)
