@@ -670,6 +670,7 @@ def test_exact_mode_three_dimensional(fpath):
     ((40, 24), 100, 2, 3, 34),        # K = 68 / 40 / 24 / 100 (K tails by select), N = 500, M = 40 / 24 (ragged everywhere)
     ((50,), 101, 3, 2, 33),           # nothing 16-byte aligned: the scalar kernel (gemm_generic2) takes every launch
     ((320, 64), 64, 1, 2, 64),        # M = 320 (three 128-row tiles, the last ragged), D = 1 (three stencil blocks)
+    ((64, 48), 272, 2, 2, 40),        # K groups with K = 272: 17 K steps over four groups (5, 5, 5, 2), M = 48 ragged
 ])
 @pytest.mark.parametrize("minwg", [None, "1", "1000000"])
 def test_generic_path_at_other_hidden_widths(hidden, B, D, L, m, minwg, monkeypatch):
